@@ -1,0 +1,118 @@
+/*
+ * mogp_hip.h -- C ABI of libmogp_hip.so: the MI355X (gfx950) exact multi-output GP hot path.
+ *
+ * The reference (GAMES-UChile/mogptk v0.5.1) has no FFI of its own: its hot path is a chain of Python
+ * method calls into torch.  Each entry point below replaces the torch work behind one of those seams;
+ * the reference file:line it stands in for is cited per function (paths relative to the reference root).
+ * INTEGRATION.md shows the ctypes stub a mogptk maintainer would add to bind them.
+ *
+ * Conventions
+ *   - plain C types only; every pointer argument is a HOST pointer owned by the caller for the duration
+ *     of the call only (device-pointer accessors are the explicitly named mogp_dev_* functions);
+ *   - matrices are row-major fp64; X is (N, 1+D) with the channel id in column 0 exactly as the
+ *     reference's kernel format (mogptk/model.py:585-606); arbitrary row order is accepted
+ *     (mogptk/gpr/kernel.py:446-452) -- the library keeps a stable channel sort internally;
+ *   - every function returns 0 on success, a negative MOGP_E* code otherwise; mogp_last_error() gives
+ *     the message of the calling thread's last failure;
+ *   - calls are synchronous (the reference syncs once per iteration at mogptk/model.py:529); a model
+ *     handle is not re-entrant; distinct handles on distinct devices may be used concurrently.
+ */
+#ifndef MOGP_HIP_H
+#define MOGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOGP_OK            0
+#define MOGP_EINVAL       -1   /* bad argument */
+#define MOGP_EHIP         -2   /* HIP runtime error (message has the hipError string) */
+#define MOGP_ENOTPD       -3   /* Cholesky met a non-positive pivot; *info = 1-based index (LAPACK dpotrf convention) */
+#define MOGP_ENONFINITE   -4   /* NaN/Inf met in the Gram matrix (reference prints which: gpr/model.py:249-252) */
+#define MOGP_ENODEVICE    -5   /* no gfx950 device visible */
+
+/* width of one row of the spectral term table for input dimension D:
+ *   [ A, Psi, V_0..V_{D-1}, M_0..M_{D-1}, Delta_0..Delta_{D-1} ]                                     */
+#define MOGP_TERM_WIDTH(D) (2 + 3 * (D))
+/* number of gradient moments per (channel pair, term):
+ *   [ m0 = sum G*E*cos, m4 = sum G*E*sin, m1_d = sum G*u_d^2*E*cos, m2_d = sum G*u_d*E*cos, m3_d = sum G*u_d*E*sin ] */
+#define MOGP_MOMENT_WIDTH(D) (2 + 3 * (D))
+
+typedef struct mogp_ctx mogp_ctx;       /* one per device */
+typedef struct mogp_model mogp_model;   /* one per (X, y) training set: owns all device workspaces */
+
+/* ---- library / device ------------------------------------------------------------------------- */
+const char* mogp_version(void);
+const char* mogp_last_error(void);
+int  mogp_device_count(void);
+/* replaces gpr/config.py:41-52 (use_gpu): bind a context to HIP device `device`. */
+int  mogp_ctx_create(int device, mogp_ctx** out);
+int  mogp_ctx_destroy(mogp_ctx* ctx);
+int  mogp_ctx_device_name(mogp_ctx* ctx, char* buf, int buflen);
+
+/* ---- model: data resident in HBM -------------------------------------------------------------- */
+/* replaces gpr/model.py:89-118 + :418-436 (gpr.Model/Exact.__init__: X, y to the device; the dense eye(N)
+ * of :435 is NOT materialised).  X: N x (1+D), y: N.  C = number of channels (kernel.output_dims). */
+int  mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, const double* y, mogp_model** out);
+int  mogp_model_destroy(mogp_model* m);
+/* replace y (e.g. y - mean(X), gpr/model.py:445-448) */
+int  mogp_model_set_y(mogp_model* m, const double* y);
+
+/* Unified spectral term table: every MOSM / SM / CSM channel-pair block is
+ *   K_ab = sum_t A exp(-1/2 sum_d V_d u_d^2) cos(2 pi (sum_d M_d u_d + Psi)),  u_d = x_a,d - x_b,d + Delta_d.
+ * table: C x C x T x MOGP_TERM_WIDTH(D) doubles, entry [i][j][t] for rows in channel i / columns in channel j.
+ * replaces the parameter algebra at gpr/multioutput.py:182-199 (MOSM), gpr/singleoutput.py:596-600 (SM),
+ * gpr/multioutput.py:432-448 (CSM) as evaluated by the host; the O(n_i n_j) part runs on the device. */
+int  mogp_model_set_terms(mogp_model* m, int T, const double* table);
+
+/* replaces MultiOutputKernel.K (gpr/kernel.py:446-481); stateless, needs only a context and a term table
+ * (C x C x T x MOGP_TERM_WIDTH(D)).  X1 is M1 x (1+D).  X2 == NULL: symmetric Gram K(X1), K_out is M1 x M1
+ * (lower channel pairs + mirror, :458-467).  Otherwise X2 is M2 x (1+D) and K_out is M1 x M2
+ * (all C*C pairs, no symmetry, :468-479).  Rows may be in any order. */
+int  mogp_gram(mogp_ctx* ctx, int C, int D, int T, const double* table,
+               int64_t M1, const double* X1, int64_t M2, const double* X2, double* K_out);
+
+/* flags for mogp_exact_eval */
+#define MOGP_EVAL_GRAD   1   /* also compute the gradient moments */
+
+/* replaces Exact.log_marginal_likelihood (gpr/model.py:438-453) and, with MOGP_EVAL_GRAD, the backward pass
+ * gpr.Model.loss() obtains from autograd (gpr/model.py:279-292):
+ *   Kj = K + diag(noise_var[c(k)]) (+ data_var[k]) + jitter * mean(diag) * I   (gpr/model.py:440-442, :244)
+ *   L = chol(Kj); lml = -N/2 log 2pi - sum log L_kk - 1/2 y^T Kj^-1 y
+ *   G = 1/2 (alpha alpha^T - Kj^-1);  moments[i>=j][t][:] over the FULL symmetric matrix (off-diagonal
+ *   channel blocks counted twice, as autograd sees `res[r1[i],r2[j]] = k; res[r1[j],r2[i]] = k.T`, kernel.py:466-467)
+ *   diagG[c] = sum_{k in c} G_kk;  *trG = trace(G);  *jitter_abs = jitter * mean(diag) actually added.
+ * moments: (C*(C+1)/2) x T x MOGP_MOMENT_WIDTH(D), pair index p = i*(i+1)/2 + j for i >= j.
+ * data_var may be NULL.  moments/diagG/trG may be NULL without MOGP_EVAL_GRAD.
+ * On MOGP_ENOTPD *info is the 1-based failing pivot (in channel-sorted order). */
+int  mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_var, double jitter, int flags,
+                     double* lml, double* moments, double* diagG, double* trG, double* jitter_abs, int64_t* info);
+
+/* replaces Exact.predict_f (gpr/model.py:455-483): mu = Kfs^T Kj^-1 y, var = Kss_diag - colsum((L^-1 Kfs)^2)
+ * (full != 0: var is S x S = Kss - v^T v).  Xs: S x (1+D).  mu: S, var: S or S*S.  No noise added to var.
+ * kss_diag[C]: the kernel's K_diag value per channel as the reference returns it (gpr/kernel.py:483-495; for SM
+ * with D > 1 the reference's K_diag, singleoutput.py:602-605, differs from diag K and is reproduced as is). */
+int  mogp_exact_predict(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
+                        const double* kss_diag, int64_t S, const double* Xs, int full,
+                        double* mu, double* var, int64_t* info);
+
+/* ---- measurement ------------------------------------------------------------------------------- */
+/* stage ids for mogp_stage_ms (HIP-event time of the last mogp_exact_eval on this model's stream) */
+enum { MOGP_ST_GRAM = 0, MOGP_ST_POTRF = 1, MOGP_ST_TRTRI = 2, MOGP_ST_LAUUM = 3, MOGP_ST_SOLVE = 4,
+       MOGP_ST_MOMENTS = 5, MOGP_ST_TOTAL = 6, MOGP_ST_GEMM_KERNEL = 7, MOGP_ST_COUNT = 8 };
+int  mogp_set_profiling(mogp_model* m, int on);
+/* ms[MOGP_ST_COUNT]; MOGP_ST_GEMM_KERNEL = summed duration of every launch of the fp64 MFMA GEMM kernel;
+ * *gemm_launches / *gemm_flops = their count and algorithmic flop total in the last eval. */
+int  mogp_stage_ms(mogp_model* m, double* ms, int64_t* gemm_launches, double* gemm_flops);
+
+/* copy device-resident matrices of the last eval back (tests / CholeskyException payload):
+ * which: 0 = Kj lower factor L (valid after a forward-only eval), 1 = Kj^-1 (after MOGP_EVAL_GRAD),
+ *        2 = alpha (N).  Output in the caller's original row order, full N x N (symmetrised / lower-filled). */
+int  mogp_model_fetch(mogp_model* m, int which, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOGP_HIP_H */

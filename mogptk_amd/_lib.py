@@ -1,0 +1,198 @@
+"""
+ctypes binding of libmogp_hip.so (include/mogp_hip.h).  This is the only place the package touches the
+native library.  There is NO fallback: if the library is missing, or no gfx950 device is visible when a
+compute entry point is called, the call fails loudly.
+"""
+import ctypes
+import os
+import threading
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmogp_hip.so")
+
+MOGP_OK, MOGP_EINVAL, MOGP_EHIP, MOGP_ENOTPD, MOGP_ENONFINITE, MOGP_ENODEVICE = 0, -1, -2, -3, -4, -5
+MOGP_EVAL_GRAD = 1
+ST_GRAM, ST_POTRF, ST_TRTRI, ST_LAUUM, ST_SOLVE, ST_MOMENTS, ST_TOTAL, ST_GEMM_KERNEL, ST_COUNT = range(9)
+
+_lib = None
+_lock = threading.Lock()
+_ctx = {}
+
+c_dp = ctypes.POINTER(ctypes.c_double)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+
+# name -> (restype, argtypes); mirrors include/mogp_hip.h one to one (tests check every symbol is exported)
+SIGNATURES = {
+    "mogp_version": (ctypes.c_char_p, []),
+    "mogp_last_error": (ctypes.c_char_p, []),
+    "mogp_device_count": (ctypes.c_int, []),
+    "mogp_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "mogp_ctx_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "mogp_ctx_device_name": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]),
+    "mogp_model_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, c_dp, c_dp,
+                                         ctypes.POINTER(ctypes.c_void_p)]),
+    "mogp_model_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "mogp_model_set_y": (ctypes.c_int, [ctypes.c_void_p, c_dp]),
+    "mogp_model_set_terms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_dp]),
+    "mogp_gram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp,
+                                 ctypes.c_int64, c_dp, ctypes.c_int64, c_dp, c_dp]),
+    "mogp_exact_eval": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, ctypes.c_int,
+                                       c_dp, c_dp, c_dp, c_dp, c_dp, c_i64p]),
+    "mogp_exact_predict": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.c_int64, c_dp,
+                                          ctypes.c_int, c_dp, c_dp, c_i64p]),
+    "mogp_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "mogp_stage_ms": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i64p, c_dp]),
+    "mogp_model_fetch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_dp]),
+}
+
+
+class MogpError(RuntimeError):
+    def __init__(self, code, message, info=0):
+        super().__init__(message)
+        self.code = code
+        self.info = info
+
+
+def lib():
+    """Load libmogp_hip.so (built in-tree by __graft_entry__.build()).  Raises if it is absent."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    "libmogp_hip.so not found at %s: build it with `python __graft_entry__.py` "
+                    "(hipcc --offload-arch=gfx950).  mogptk_amd has no CPU fallback." % LIB_PATH)
+            l = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(l, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = l
+    return _lib
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(c_dp)
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def check(code, info=0):
+    if code != MOGP_OK:
+        msg = lib().mogp_last_error()
+        raise MogpError(code, (msg.decode() if msg else "mogp error %d" % code), info)
+
+
+def context(device=0):
+    """One C-ABI context per device ordinal, created on first use."""
+    l = lib()
+    with _lock:
+        if device not in _ctx:
+            h = ctypes.c_void_p()
+            check(l.mogp_ctx_create(int(device), ctypes.byref(h)))
+            _ctx[device] = h
+        return _ctx[device]
+
+
+def device_name(device=0):
+    buf = ctypes.create_string_buffer(256)
+    check(lib().mogp_ctx_device_name(context(device), buf, 256))
+    return buf.value.decode()
+
+
+def gram(device, C, D, table, X1, X2=None):
+    """K(X1[,X2]) through mogp_gram."""
+    table = _f64(table)
+    X1 = _f64(X1)
+    X2 = _f64(X2)
+    T = table.shape[2]
+    M1 = X1.shape[0]
+    M2 = M1 if X2 is None else X2.shape[0]
+    out = np.empty((M1, M2), dtype=np.float64)
+    check(lib().mogp_gram(context(device), C, D, T, _dp(table), M1, _dp(X1),
+                          0 if X2 is None else M2, _dp(X2), _dp(out)))
+    return out
+
+
+class ExactHandle:
+    """Owner of one mogp_model (device workspaces for a fixed training set)."""
+
+    def __init__(self, device, X, y, C):
+        X = _f64(X)
+        y = _f64(np.asarray(y).reshape(-1))
+        self.N = X.shape[0]
+        self.D = X.shape[1] - 1
+        self.C = C
+        self.device = device
+        self._h = ctypes.c_void_p()
+        check(lib().mogp_model_create(context(device), self.N, self.D, C, _dp(X), _dp(y), ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value is not None:
+            lib().mogp_model_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_y(self, y):
+        y = _f64(np.asarray(y).reshape(-1))
+        check(lib().mogp_model_set_y(self._h, _dp(y)))
+
+    def set_terms(self, table):
+        table = _f64(table)
+        assert table.shape[0] == self.C and table.shape[1] == self.C and table.shape[3] == 2 + 3 * self.D
+        self.T = table.shape[2]
+        check(lib().mogp_model_set_terms(self._h, self.T, _dp(table)))
+
+    def eval(self, noise_var, jitter, grad=True, data_var=None):
+        """-> dict(lml, moments[P,T,W], diagG[C], trG, jitter_abs)"""
+        noise_var = _f64(noise_var)
+        data_var = _f64(data_var)
+        C, T, W = self.C, self.T, 2 + 3 * self.D
+        lml = ctypes.c_double()
+        trG = ctypes.c_double()
+        jit = ctypes.c_double()
+        info = ctypes.c_int64(0)
+        moments = np.zeros((C * (C + 1) // 2, T, W)) if grad else None
+        diagG = np.zeros(C) if grad else None
+        code = lib().mogp_exact_eval(self._h, _dp(noise_var), _dp(data_var), float(jitter),
+                                     MOGP_EVAL_GRAD if grad else 0, ctypes.byref(lml), _dp(moments), _dp(diagG),
+                                     ctypes.byref(trG), ctypes.byref(jit), ctypes.byref(info))
+        check(code, info.value)
+        return dict(lml=lml.value, moments=moments, diagG=diagG, trG=trG.value, jitter_abs=jit.value)
+
+    def predict(self, noise_var, jitter, kss_diag, Xs, full=False, data_var=None):
+        noise_var = _f64(noise_var)
+        kss_diag = _f64(kss_diag)
+        data_var = _f64(data_var)
+        Xs = _f64(Xs)
+        S = Xs.shape[0]
+        mu = np.empty(S)
+        var = np.empty((S, S) if full else S)
+        info = ctypes.c_int64(0)
+        code = lib().mogp_exact_predict(self._h, _dp(noise_var), _dp(data_var), float(jitter), _dp(kss_diag), S, _dp(Xs),
+                                        1 if full else 0, _dp(mu), _dp(var), ctypes.byref(info))
+        check(code, info.value)
+        return mu.reshape(-1, 1), (var if full else var.reshape(-1, 1))
+
+    def set_profiling(self, on=True):
+        check(lib().mogp_set_profiling(self._h, 1 if on else 0))
+
+    def stage_ms(self):
+        ms = np.zeros(ST_COUNT)
+        n = ctypes.c_int64(0)
+        fl = ctypes.c_double(0)
+        check(lib().mogp_stage_ms(self._h, _dp(ms), ctypes.byref(n), ctypes.byref(fl)))
+        return ms, n.value, fl.value
+
+    def fetch(self, which):
+        out = np.empty(self.N if which == 2 else (self.N, self.N))
+        check(lib().mogp_model_fetch(self._h, which, _dp(out)))
+        return out

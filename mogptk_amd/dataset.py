@@ -1,0 +1,205 @@
+"""
+Minimal Data / DataSet containers.  The reference's data layer (mogptk/data.py, dataset.py, transformer.py:
+pandas loaders, masks, detrending, plotting) is host-side O(N) work outside the hot path (SURVEY.md section 2 rows
+16-18); the HIP path consumes its output `(X, y)` unchanged.  These classes provide only the hooks
+`mogptk.Model` calls on its dataset (mogptk/model.py:200-231, 585-664; models/mosm.py:59-60) so that
+`MOSM(dataset, Q).train(); .predict()` runs end to end without the reference installed.
+"""
+import numpy as np
+
+
+class TransformBase:
+    """identity Y transformer (reference transformer.py: forward/backward(y, x))"""
+
+    def set_data(self, data):
+        pass
+
+    def forward(self, y, x=None):
+        return y
+
+    def backward(self, y, x=None):
+        return y
+
+
+class Data:
+    """One channel: X (n,) or (n, input_dims), Y (n,).  Reference mogptk/data.py:197."""
+
+    def __init__(self, X, Y, Y_err=None, name=None):
+        X = np.asarray(X, dtype=np.float64)
+        if X.ndim == 1:
+            X = X.reshape(-1, 1)
+        Y = np.asarray(Y, dtype=np.float64).reshape(-1)
+        if X.ndim != 2 or X.shape[0] != Y.shape[0]:
+            raise ValueError("X must be (data_points,) or (data_points,input_dims) and match Y")
+        self.X = X
+        self.Y = Y
+        self.Y_err = None if Y_err is None else np.asarray(Y_err, dtype=np.float64).reshape(-1)
+        self.name = name
+        self.mask = np.ones(Y.shape[0], dtype=bool)
+        self.Y_transformer = TransformBase()
+        self.X_pred = X
+
+    def get_name(self):
+        return self.name
+
+    def get_input_dims(self):
+        return self.X.shape[1]
+
+    def has_test_data(self):
+        return bool(np.any(~self.mask))
+
+    def remove_randomly(self, n=None, pct=None, seed=None):
+        """reference data.py:658-690 (uniform removal of training points -> test points)"""
+        if n is None:
+            n = int((0.1 if pct is None else pct) * self.X.shape[0])
+        idx = np.random.default_rng(seed).choice(self.X.shape[0], n, replace=False)
+        self.mask[idx] = False
+
+    def get_data(self, transformed=False):
+        if transformed:
+            return self.X, self.Y_transformer.forward(self.Y, self.X)
+        return self.X, self.Y
+
+    def get_train_data(self, transformed=False):
+        """reference data.py:602-619"""
+        if transformed:
+            return self.X[self.mask, :], self.Y_transformer.forward(self.Y[self.mask], self.X[self.mask, :])
+        return self.X[self.mask, :], self.Y[self.mask]
+
+    def get_test_data(self, transformed=False):
+        X, Y = self.X[~self.mask, :], self.Y[~self.mask]
+        if transformed:
+            return X, self.Y_transformer.forward(Y, X)
+        return X, Y
+
+    def set_prediction_data(self, X):
+        self.X_pred, _ = self._format_X(X)
+
+    def get_prediction_data(self):
+        return self.X_pred
+
+    def _format_X(self, X):
+        X = np.asarray(X, dtype=np.float64)
+        if X.ndim == 1:
+            X = X.reshape(-1, 1)
+        if X.ndim != 2 or X.shape[1] != self.get_input_dims():
+            raise ValueError("X must have %d input dimensions" % self.get_input_dims())
+        return X, None
+
+    def get_nyquist_estimation(self):
+        """0.5 / (minimum distance between points) per input dimension -- reference data.py:924-944"""
+        input_dims = self.get_input_dims()
+        nyquist = np.empty((input_dims,))
+        for i in range(input_dims):
+            x = np.sort(self.X[self.mask, i])
+            dist = np.abs(x[1:] - x[:-1])
+            if len(dist) == 0:
+                nyquist[i] = 0.0
+            else:
+                nyquist[i] = 0.5 / np.min(dist[np.nonzero(dist)])
+        return nyquist
+
+
+class DataSet:
+    """Ordered list of channels.  Reference mogptk/dataset.py:130.
+    DataSet(data0, data1, ...), DataSet([data0, ...]) or DataSet(x, [y0, y1, ...])."""
+
+    def __init__(self, *args, names=None):
+        self.channels = []
+        if len(args) == 2 and not isinstance(args[0], (Data, DataSet)) and isinstance(args[1], (list, tuple)) \
+                and not any(isinstance(a, Data) for a in args[1]):
+            x, ys = args
+            for j, y in enumerate(ys):
+                self.channels.append(Data(x, y, name=None if names is None else names[j]))
+        else:
+            for arg in args:
+                self.append(arg)
+
+    def append(self, arg):
+        if isinstance(arg, Data):
+            self.channels.append(arg)
+        elif isinstance(arg, DataSet):
+            self.channels.extend(arg.channels)
+        elif isinstance(arg, (list, tuple)) and all(isinstance(a, Data) for a in arg):
+            self.channels.extend(arg)
+        elif isinstance(arg, dict) and all(isinstance(a, Data) for a in arg.values()):
+            for k, v in arg.items():
+                v.name = k
+                self.channels.append(v)
+        else:
+            raise ValueError("must append Data, DataSet, or a list/dict of Data")
+
+    def __iter__(self):
+        return iter(self.channels)
+
+    def __len__(self):
+        return len(self.channels)
+
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            return self.channels[self.get_names().index(key)]
+        return self.channels[key]
+
+    def get_names(self):
+        return [c.get_name() for c in self.channels]
+
+    def get_index(self, name):
+        return self.get_names().index(name) if isinstance(name, str) else name
+
+    def get_output_dims(self):
+        return len(self.channels)
+
+    def get_input_dims(self):
+        return [c.get_input_dims() for c in self.channels]
+
+    def has_test_data(self):
+        return [c.has_test_data() for c in self.channels]
+
+    def get_data(self, transformed=False):
+        return [c.get_data(transformed)[0] for c in self.channels], [c.get_data(transformed)[1] for c in self.channels]
+
+    def get_train_data(self, transformed=False):
+        """reference dataset.py:455-485"""
+        return ([c.get_train_data(transformed)[0] for c in self.channels],
+                [c.get_train_data(transformed)[1] for c in self.channels])
+
+    def get_test_data(self, transformed=False):
+        return ([c.get_test_data(transformed)[0] for c in self.channels],
+                [c.get_test_data(transformed)[1] for c in self.channels])
+
+    def get_prediction_data(self):
+        return [c.get_prediction_data() for c in self.channels]
+
+    def set_prediction_data(self, X):
+        X = self._format_X(X)
+        for j, c in enumerate(self.channels):
+            c.X_pred = X[j]
+
+    def get_nyquist_estimation(self):
+        return [c.get_nyquist_estimation() for c in self.channels]
+
+    def _format_X(self, X):
+        """reference dataset.py:199-221"""
+        if isinstance(X, dict):
+            x_dict = X
+            X = self.get_prediction_data()
+            for name, channel_x in x_dict.items():
+                X[self.get_index(name)] = channel_x
+        elif isinstance(X, np.ndarray) or hasattr(X, "detach"):
+            if hasattr(X, "detach"):
+                X = X.detach().cpu().numpy()
+            if X.ndim == 3 and X.shape[0] == self.get_output_dims():
+                X = [X[i, :, :] for i in range(self.get_output_dims())]
+            else:
+                X = [X] * self.get_output_dims()
+        elif not isinstance(X, list):
+            raise ValueError("X must be a list, dict, or numpy.ndarray")
+        elif not any(isinstance(x, (list, np.ndarray)) for x in X):
+            X = [X] * self.get_output_dims()
+        if len(X) != self.get_output_dims():
+            raise ValueError("X must be of shape (data_points,), (data_points,input_dims), or "
+                             "[(data_points,)] * input_dims for each channel")
+        X = list(X)
+        for j, channel in enumerate(self.channels):
+            X[j], _ = channel._format_X(X[j])
+        return X

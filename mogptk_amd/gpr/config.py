@@ -1,0 +1,70 @@
+"""
+Global configuration singleton, mirroring mogptk/gpr/config.py:3-73 for the HIP path.
+
+`config.dtype` is numpy float64 (the only precision the HIP path computes in); `config.device`
+is the HIP device ordinal the C-ABI contexts bind to.
+"""
+import numpy as np
+
+
+class Config:
+    dtype = np.float64
+    device = 0
+    positive_minimum = 1e-8
+
+
+config = Config()
+
+
+def use_double_precision():
+    """mogptk/gpr/config.py:26-30."""
+    config.dtype = np.float64
+
+
+def use_single_precision():
+    """mogptk/gpr/config.py:20-24.  The gfx950 path is fp64 end to end (parity 1e-5 on a gradient that
+    contains the cancellation 1/2(alpha alpha^T - K^-1)); fp32 is refused rather than silently upcast."""
+    raise NotImplementedError("the MI355X exact-GP path computes in float64 only")
+
+
+def use_half_precision():
+    raise NotImplementedError("the MI355X exact-GP path computes in float64 only")
+
+
+def use_gpu(n=None):
+    """mogptk/gpr/config.py:41-52: select the device new models bind to."""
+    from .._lib import lib
+    count = lib().mogp_device_count()
+    if count <= 0:
+        print("HIP device is not available")
+    elif n is not None and (not isinstance(n, int) or n < 0 or count <= n):
+        print("HIP GPU '%s' is not available" % (n,))
+    else:
+        config.device = 0 if n is None else n
+
+
+def use_hip(n=None):
+    """Backend selector in the style of use_gpu(); the HIP path is the only backend."""
+    use_gpu(n)
+
+
+def use_cpu(n=None):
+    """mogptk/gpr/config.py:32-39.  There is no CPU fallback on this path by design."""
+    raise NotImplementedError("mogptk_amd has no CPU path; use the reference mogptk on CPU")
+
+
+def print_gpu_information():
+    """mogptk/gpr/config.py:54-67."""
+    from .._lib import lib, device_name
+    count = lib().mogp_device_count()
+    if count <= 0:
+        print("HIP device is not available")
+        return
+    print("HIP is available:")
+    for n in range(count):
+        print("%2d  %s%s" % (n, device_name(n), " (selected)" if n == config.device else ""))
+
+
+def set_positive_minimum(val):
+    """mogptk/gpr/config.py:69-73."""
+    config.positive_minimum = val

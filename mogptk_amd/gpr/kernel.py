@@ -1,0 +1,226 @@
+"""
+Kernel base classes for the HIP path -- host-side mirror of mogptk/gpr/kernel.py.
+
+A kernel on this path does two things on the host (O(C^2 Q) scalars) and nothing else:
+  * `_spectral_terms(D)`   : constrained parameters -> unified spectral term table
+                              [C, C, T, 2+3D] = [A, Psi, V_d.., M_d.., Delta_d..]   
+  * `_spectral_backward(g)`: d loss / d table  ->  `.grad` on every raw parameter (the chain rule the
+                              reference gets from autograd through gpr/multioutput.py:182-199 etc.)
+All O(N^2) / O(N^3) work (Gram build, Cholesky, solves, gradient moments) runs in the HIP library
+behind the C ABI (include/mogp_hip.h).  There is no CPU fallback.
+"""
+import copy
+import numpy as np
+
+from .config import config
+from .parameter import Parameter, ParameterHolder
+
+
+def term_width(D):
+    return 2 + 3 * D
+
+
+class Kernel(ParameterHolder):
+    """Base kernel (reference gpr/kernel.py:5-191)."""
+
+    def __init__(self, input_dims=None, active_dims=None):
+        if active_dims is not None:
+            raise NotImplementedError("active_dims is not on the HIP path")
+        self.input_dims = input_dims
+        self.active_dims = None
+        self.output_dims = None
+
+    def name(self):
+        return self.__class__.__name__
+
+    def __setattr__(self, name, val):
+        if name == "train":
+            for p in self.parameters():
+                p.train = val
+            return
+        super().__setattr__(name, val)
+
+    def __call__(self, X1, X2=None):
+        """validate + K, reference gpr/kernel.py:23-35"""
+        X1, X2 = self._check_input(X1, X2)
+        return self.K(X1, X2)
+
+    def _check_input(self, X1, X2=None):
+        """reference gpr/kernel.py:60-80"""
+        X1 = np.asarray(X1.detach().cpu().numpy() if hasattr(X1, "detach") else X1, dtype=np.float64)
+        if X1.ndim != 2:
+            raise ValueError("X should have two dimensions (data_points,input_dims)")
+        if X1.shape[0] == 0 or X1.shape[1] == 0:
+            raise ValueError("X must not be empty")
+        if X2 is not None:
+            X2 = np.asarray(X2.detach().cpu().numpy() if hasattr(X2, "detach") else X2, dtype=np.float64)
+            if X2.ndim != 2:
+                raise ValueError("X should have two dimensions (data_points,input_dims)")
+            if X2.shape[0] == 0:
+                raise ValueError("X must not be empty")
+            if X1.shape[1] != X2.shape[1]:
+                raise ValueError("input dimensions for X1 and X2 must match")
+        return X1, X2
+
+    def _check_kernels(self, kernels, length=None):
+        """reference gpr/kernel.py:82-110"""
+        if isinstance(kernels, tuple):
+            if len(kernels) == 1 and isinstance(kernels[0], list):
+                kernels = kernels[0]
+            else:
+                kernels = list(kernels)
+        elif not isinstance(kernels, list):
+            kernels = [kernels]
+        if len(kernels) == 0:
+            raise ValueError("must pass at least one kernel")
+        elif length is not None and len(kernels) != length:
+            if len(kernels) != 1:
+                raise ValueError("must pass %d kernels" % length)
+            for i in range(length - len(kernels)):
+                kernels.append(kernels[0].clone())
+        for kernel in kernels:
+            if not issubclass(type(kernel), Kernel):
+                raise ValueError("must pass kernels")
+        if any(kernel.input_dims != kernels[0].input_dims for kernel in kernels[1:]):
+            raise ValueError("kernels must have same input dimensions")
+        output_dims = [kernel.output_dims for kernel in kernels if kernel.output_dims is not None]
+        if any(output_dim != output_dims[0] for output_dim in output_dims[1:]):
+            raise ValueError("multi-output kernels must have same output dimensions")
+        return kernels
+
+    def clone(self):
+        return copy.deepcopy(self)
+
+    def iterkernels(self):
+        yield self
+
+    # -- the HIP seam ------------------------------------------------------------------------
+    def _channels(self):
+        """number of channels the device sees (single-output kernels run as one implicit channel)"""
+        return 1 if self.output_dims is None else self.output_dims
+
+    def _kernel_format(self, X):
+        """single-output kernels have no channel column: prepend channel 0"""
+        if self.output_dims is None:
+            return np.concatenate([np.zeros((X.shape[0], 1)), X], axis=1)
+        return X
+
+    def _spectral_terms(self, D):
+        raise NotImplementedError("%s is not on the MI355X spectral path (MOSM / SM / CSM are)" % self.name())
+
+    def _spectral_backward(self, gtable):
+        raise NotImplementedError("%s is not on the MI355X spectral path" % self.name())
+
+    def _spectral_diag(self, D):
+        """K_diag value per channel AS THE REFERENCE RETURNS IT (constant per channel for every spectral kernel).
+        Default: the true diagonal sum_t A_cct (Delta = Psi = 0 on i == j blocks); SM overrides (its K_diag
+        differs from diag K when D > 1, reference singleoutput.py:602-605)."""
+        table = self._spectral_terms(D)
+        C = table.shape[0]
+        return np.array([np.sum(table[c, c, :, 0]) for c in range(C)])
+
+    def K(self, X1, X2=None):
+        """Kernel matrix, reference gpr/kernel.py:138-150 (MO: :446-481).  Runs the HIP Gram builder."""
+        from .._lib import gram
+        X1k = self._kernel_format(np.asarray(X1, dtype=np.float64))
+        X2k = None if X2 is None else self._kernel_format(np.asarray(X2, dtype=np.float64))
+        D = X1k.shape[1] - 1
+        return gram(config.device, self._channels(), D, self._spectral_terms(D), X1k, X2k)
+
+    def K_diag(self, X1):
+        """reference gpr/kernel.py:152-163, MO :483-495.  Constant per channel for every spectral kernel."""
+        X1k = self._kernel_format(np.asarray(X1, dtype=np.float64))
+        D = X1k.shape[1] - 1
+        return self._spectral_diag(D)[X1k[:, 0].astype(np.int64)]
+
+    def __add__(self, other):
+        return AddKernel(self, other)
+
+    def __mul__(self, other):
+        return MulKernel(self, other)
+
+
+class Kernels(Kernel):
+    """Base kernel for list of kernels (reference gpr/kernel.py:193-230)."""
+
+    def __init__(self, *kernels):
+        super().__init__()
+        kernels = self._check_kernels(kernels)
+        i = 0
+        while i < len(kernels):
+            if isinstance(kernels[i], self.__class__):
+                subkernels = list(kernels[i].kernels)
+                kernels = kernels[:i] + subkernels + kernels[i + 1:]
+                i += len(subkernels) - 1
+            i += 1
+        self.kernels = list(kernels)
+        self.input_dims = kernels[0].input_dims
+        output_dims = [kernel.output_dims for kernel in kernels if kernel.output_dims is not None]
+        self.output_dims = None if len(output_dims) == 0 else output_dims[0]
+        if any(k.output_dims != self.output_dims for k in kernels):
+            raise NotImplementedError("mixing single- and multi-output kernels is not on the HIP path")
+
+    def name(self):
+        return "[%s]" % (",".join(kernel.name() for kernel in self.kernels),)
+
+    def __getitem__(self, key):
+        return self.kernels[key]
+
+    def iterkernels(self):
+        yield self
+        for kernel in self.kernels:
+            yield kernel
+
+
+class AddKernel(Kernels):
+    """Sum of kernels (reference gpr/kernel.py:232-246).  On the spectral path a sum of kernels is the
+    concatenation of their term tables along T -- one fused pass instead of Q stacked N x N Grams (:243)."""
+
+    def _spectral_diag(self, D):
+        return sum(k._spectral_diag(D) for k in self.kernels)          # :245-246
+
+    def _spectral_terms(self, D):
+        return np.concatenate([k._spectral_terms(D) for k in self.kernels], axis=2)
+
+    def _spectral_backward(self, gtable):
+        t0 = 0
+        D = (gtable.shape[3] - 2) // 3
+        for k in self.kernels:
+            T = k._spectral_terms(D).shape[2]
+            k._spectral_backward(gtable[:, :, t0:t0 + T, :])
+            t0 += T
+
+
+class MulKernel(Kernels):
+    """Product kernel (reference gpr/kernel.py:248-262): not a sum of spectral terms -> out of scope."""
+
+    def _spectral_terms(self, D):
+        raise NotImplementedError("MulKernel is not on the MI355X spectral path")
+
+
+class MixtureKernel(AddKernel):
+    """Sum of Q copies of a kernel (reference gpr/kernel.py:264-276)."""
+
+    def __init__(self, kernel, Q):
+        if not issubclass(type(kernel), Kernel):
+            raise ValueError("must pass kernel")
+        kernels = self._check_kernels(kernel, Q)
+        super().__init__(*kernels)
+
+
+class MultiOutputKernel(Kernel):
+    """Base class of multi-output kernels (reference gpr/kernel.py:381-520): column 0 of X holds the
+    channel id.  The channel split / pair loop / scatter of :446-481 happens inside the HIP library."""
+
+    def __init__(self, output_dims, input_dims=None, active_dims=None):
+        super().__init__(input_dims, active_dims)
+        self.output_dims = output_dims
+
+    def _check_input(self, X1, X2=None):
+        """reference gpr/kernel.py:398-404 (including its slip of re-checking X1 for X2's range)"""
+        X1, X2 = super()._check_input(X1, X2)
+        if not np.all(X1[:, 0] == np.trunc(X1[:, 0])) or not np.all(X1[:, 0] < self.output_dims):
+            raise ValueError("X must have integers for the channel IDs in the first input dimension")
+        if X2 is not None and not np.all(X2[:, 0] == np.trunc(X2[:, 0])) or not np.all(X1[:, 0] < self.output_dims):
+            raise ValueError("X must have integers for the channel IDs in the first input dimension")
+        return X1, X2

@@ -1,0 +1,205 @@
+"""
+Multi-output spectral kernels on the HIP path -- host-side mirror of mogptk/gpr/multioutput.py for the
+three kernels the hot path covers: IndependentMultiOutputKernel (:5-39), MultiOutputSpectralMixtureKernel
+(MOSM, :125-210) and CrossSpectralKernel (CSM, :397-454).
+
+Each class maps its constrained parameters to the unified spectral term table and back-propagates the
+table gradient to its raw parameters; see gpr/kernel.py (this package) for the protocol.
+"""
+import numpy as np
+
+from .config import config
+from .parameter import Parameter
+from .kernel import Kernel, MultiOutputKernel, term_width
+
+PI = np.pi
+
+
+def _accumulate(p, gconstrained):
+    """constrained-space gradient -> raw-space `.grad` (Softplus/Sigmoid link, reference parameter.py:48-49,77-78)"""
+    g = gconstrained * p.dconstrained()
+    p.grad = g if p.grad is None else p.grad + g
+
+
+class IndependentMultiOutputKernel(MultiOutputKernel):
+    """One sub-kernel per channel on the block diagonal, zeros elsewhere (reference gpr/multioutput.py:5-39)."""
+
+    def __init__(self, *kernels, output_dims=None):
+        if output_dims is None:
+            output_dims = len(kernels)
+        super().__init__(output_dims)
+        self.kernels = self._check_kernels(kernels, output_dims)
+        self.input_dims = self.kernels[0].input_dims
+
+    def __getitem__(self, key):
+        return self.kernels[key]
+
+    def name(self):
+        return "%s[%s]" % (self.__class__.__name__, ",".join(k.name() for k in self.kernels))
+
+    def _spectral_terms(self, D):
+        subs = [k._spectral_terms(D)[0, 0] for k in self.kernels]      # each (T_c, W)
+        T = max(s.shape[0] for s in subs)
+        C = self.output_dims
+        table = np.zeros((C, C, T, term_width(D)))                       # A = 0 off the block diagonal (:34)
+        for c, s in enumerate(subs):
+            table[c, c, :s.shape[0]] = s
+        return table
+
+    def _spectral_diag(self, D):
+        return np.array([k._spectral_diag(D)[0] for k in self.kernels])   # reference :36-39
+
+    def _spectral_backward(self, gtable):
+        D = (gtable.shape[3] - 2) // 3
+        for c, k in enumerate(self.kernels):
+            T = k._spectral_terms(D).shape[2]
+            k._spectral_backward(gtable[c:c + 1, c:c + 1, :T])
+
+
+class MultiOutputSpectralMixtureKernel(MultiOutputKernel):
+    """
+    MOSM (reference gpr/multioutput.py:125-210).  Parameters: weight (C,Q), mean/variance/delay (C,Q,D),
+    phase (C,Q); delay/phase are flagged train=False for one channel (:172-174).
+    """
+
+    def __init__(self, Q, output_dims, input_dims=1, active_dims=None):
+        super().__init__(output_dims, input_dims, active_dims)
+        self.input_dims = input_dims
+        self.weight = Parameter(np.ones((output_dims, Q)), lower=config.positive_minimum)
+        self.mean = Parameter(np.zeros((output_dims, Q, input_dims)), lower=config.positive_minimum)
+        self.variance = Parameter(np.ones((output_dims, Q, input_dims)), lower=config.positive_minimum)
+        self.delay = Parameter(np.zeros((output_dims, Q, input_dims)))
+        self.phase = Parameter(np.zeros((output_dims, Q)))
+        if output_dims == 1:
+            self.delay.train = False
+            self.phase.train = False
+        self.twopi = np.power(2.0 * np.pi, float(self.input_dims) / 2.0)
+
+    def _pairs(self):
+        w, mu, v = self.weight(), self.mean(), self.variance()
+        th, ph = self.delay(), self.phase()
+        vi, vj = v[:, None], v[None, :]                 # (C,C,Q,D) broadcast
+        mi, mj = mu[:, None], mu[None, :]
+        s = vi + vj
+        inv = 1.0 / s
+        dmu = mi - mj
+        return w, mu, v, th, ph, vi, vj, mi, mj, s, inv, dmu
+
+    def _spectral_terms(self, D):
+        """reference gpr/multioutput.py:182-199"""
+        if D != self.input_dims:
+            raise ValueError("X must have %d input dimensions" % self.input_dims)
+        C = self.output_dims
+        w, mu, v, th, ph, vi, vj, mi, mj, s, inv, dmu = self._pairs()
+        Q = w.shape[1]
+        table = np.empty((C, C, Q, term_width(D)))
+        mag = w[:, None] * w[None, :] * np.exp(-PI ** 2 * np.sum(dmu * inv * dmu, axis=3))     # :192
+        M = inv * (vi * mj + vj * mi)                                                           # :194
+        V = 2.0 * vi * inv * vj                                                                 # :195
+        table[..., 0] = mag * self.twopi * np.sqrt(np.prod(V, axis=3))                          # :199
+        table[..., 1] = ph[:, None] - ph[None, :]                                               # :197
+        table[..., 2:2 + D] = V
+        table[..., 2 + D:2 + 2 * D] = M
+        table[..., 2 + 2 * D:] = th[:, None] - th[None, :]                                      # :196
+        for c in range(C):                                                                      # i == j branch :183-187
+            table[c, c, :, 0] = w[c] ** 2 * self.twopi * np.sqrt(np.prod(v[c], axis=1))
+            table[c, c, :, 1] = 0.0
+            table[c, c, :, 2:2 + D] = v[c]
+            table[c, c, :, 2 + D:2 + 2 * D] = mu[c]
+            table[c, c, :, 2 + 2 * D:] = 0.0
+        return table
+
+    def _spectral_backward(self, gtable):
+        """Chain rule table -> (weight, mean, variance, delay, phase); gtable is zero for i < j and already
+        carries the symmetric double count of off-diagonal channel blocks."""
+        C = self.output_dims
+        D = self.input_dims
+        w, mu, v, th, ph, vi, vj, mi, mj, s, inv, dmu = self._pairs()
+        table = self._spectral_terms(D)
+        A = table[..., 0]
+        V = table[..., 2:2 + D]
+        M = table[..., 2 + D:2 + 2 * D]
+        gA, gPsi = gtable[..., 0], gtable[..., 1]
+        gV, gM, gDl = gtable[..., 2:2 + D], gtable[..., 2 + D:2 + 2 * D], gtable[..., 2 + 2 * D:]
+
+        off = ~np.eye(C, dtype=bool)
+        o2 = off[:, :, None]
+        o3 = off[:, :, None, None]
+        gAA = np.where(o2, gA * A, 0.0)                                     # (C,C,Q)
+        gw = np.sum(gAA / w[:, None], axis=1) + np.sum(gAA / w[None, :], axis=0)
+        gph = np.sum(np.where(o2, gPsi, 0.0), axis=1) - np.sum(np.where(o2, gPsi, 0.0), axis=0)
+        gDlo = np.where(o3, gDl, 0.0)
+        gth = np.sum(gDlo, axis=1) - np.sum(gDlo, axis=0)
+        gMo = np.where(o3, gM, 0.0)
+        gVo = np.where(o3, gV, 0.0)
+        gAA3 = gAA[..., None]
+        dA_dmu_i = gAA3 * (-2.0 * PI ** 2 * dmu * inv)
+        gmu = np.sum(dA_dmu_i + gMo * vj * inv, axis=1) + np.sum(-dA_dmu_i + gMo * vi * inv, axis=0)
+        dVi = 2.0 * vj * vj * inv * inv
+        dVj = 2.0 * vi * vi * inv * inv
+        common = PI ** 2 * dmu * dmu * inv * inv
+        gv_i = gAA3 * (common + 0.5 * dVi / V) + gVo * dVi + gMo * (mj - M) * inv
+        gv_j = gAA3 * (common + 0.5 * dVj / V) + gVo * dVj + gMo * (mi - M) * inv
+        gv = np.sum(gv_i, axis=1) + np.sum(gv_j, axis=0)
+        for c in range(C):                                                  # i == j blocks
+            gw[c] += gA[c, c] * 2.0 * A[c, c] / w[c]
+            gv[c] += (gA[c, c] * A[c, c])[:, None] / (2.0 * v[c]) + gV[c, c]
+            gmu[c] += gM[c, c]
+        _accumulate(self.weight, gw)
+        _accumulate(self.mean, gmu)
+        _accumulate(self.variance, gv)
+        if C > 1:                                  # with one channel delay/phase never enter the graph (grad None)
+            _accumulate(self.delay, gth)
+            _accumulate(self.phase, gph)
+
+
+class CrossSpectralKernel(MultiOutputKernel):
+    """
+    CSM component (reference gpr/multioutput.py:397-454); use `MixtureKernel(CrossSpectralKernel(...), Q)`.
+    Parameters: amplitude (C,Rq), mean (D,), variance (D,), shift (C,Rq).
+    """
+
+    def __init__(self, output_dims, input_dims=1, Rq=1, active_dims=None):
+        super().__init__(output_dims, input_dims, active_dims)
+        self.input_dims = input_dims
+        self.Rq = Rq
+        self.amplitude = Parameter(np.ones((output_dims, Rq)), lower=config.positive_minimum)
+        self.mean = Parameter(np.zeros(input_dims), lower=config.positive_minimum)
+        self.variance = Parameter(np.ones(input_dims), lower=config.positive_minimum)
+        self.shift = Parameter(np.zeros((output_dims, Rq)))
+
+    def _spectral_terms(self, D):
+        """reference gpr/multioutput.py:432-449"""
+        if D != self.input_dims:
+            raise ValueError("X must have %d input dimensions" % self.input_dims)
+        C, Rq = self.output_dims, self.Rq
+        amp, mu, var, sh = self.amplitude(), self.mean(), self.variance(), self.shift()
+        table = np.empty((C, C, Rq, term_width(D)))
+        table[..., 0] = np.sqrt(amp[:, None] * amp[None, :])        # :444
+        table[..., 1] = sh[:, None] - sh[None, :]                   # :441
+        table[..., 2:2 + D] = var
+        table[..., 2 + D:2 + 2 * D] = mu
+        table[..., 2 + 2 * D:] = 0.0
+        for c in range(C):                                          # i == j branch :433-439
+            table[c, c, :, 0] = amp[c]
+            table[c, c, :, 1] = 0.0
+        return table
+
+    def _spectral_backward(self, gtable):
+        C, D = self.output_dims, self.input_dims
+        amp = self.amplitude()
+        table = self._spectral_terms(D)
+        A = table[..., 0]
+        gA, gPsi = gtable[..., 0], gtable[..., 1]
+        off = ~np.eye(C, dtype=bool)[:, :, None]
+        gAA = np.where(off, gA * A, 0.0)
+        gamp = np.sum(gAA / (2.0 * amp[:, None]), axis=1) + np.sum(gAA / (2.0 * amp[None, :]), axis=0)
+        gPo = np.where(off, gPsi, 0.0)
+        gsh = np.sum(gPo, axis=1) - np.sum(gPo, axis=0)
+        for c in range(C):
+            gamp[c] += gA[c, c]
+        _accumulate(self.amplitude, gamp)
+        _accumulate(self.variance, np.sum(gtable[..., 2:2 + D], axis=(0, 1, 2)))
+        _accumulate(self.mean, np.sum(gtable[..., 2 + D:2 + 2 * D], axis=(0, 1, 2)))
+        if C > 1:
+            _accumulate(self.shift, gsh)

@@ -1,0 +1,315 @@
+"""
+Constrained parameters for the HIP path -- the host-side mirror of mogptk/gpr/parameter.py.
+
+Same surface as the reference's `Parameter` (assign / __call__ / constrained / numpy / peg / lower /
+upper / train / data / grad), with numpy arrays in place of torch tensors: the raw (unconstrained)
+value lives in `.data`, the gradient of the loss with respect to the RAW value in `.grad`
+(that is the coordinate system torch.optim.Adam sees in the reference, mogptk/model.py:557).
+
+Behavioural quirks reproduced on purpose:
+  Q1  Softplus.inverse misplaces `lower` (reference parameter.py:59) -> assign(1.0)() == 1.0000001
+  Q2  assign(lower=/upper=) without a value re-interprets the RAW data as a constrained value
+      (reference parameter.py:253-254)
+  Q3  `train=False` only affects num_parameters(), the optimiser still updates the tensor.
+"""
+import copy
+import sys
+import numpy as np
+
+from .config import config
+
+
+def _asarray(value):
+    if isinstance(value, Parameter):
+        return np.array(value.constrained, dtype=np.float64)
+    if hasattr(value, "detach"):            # torch tensors are accepted at the boundary
+        value = value.detach().cpu().numpy()
+    return np.array(value, dtype=np.float64)
+
+
+class Transform:
+    def forward(self, x):
+        raise NotImplementedError()
+
+    def inverse(self, y):
+        raise NotImplementedError()
+
+    def dforward(self, x):
+        """d constrained / d raw (elementwise)."""
+        raise NotImplementedError()
+
+
+class Softplus(Transform):
+    """y = lower + log(1 + exp(beta x))/beta, linear above beta*x > threshold  (reference parameter.py:30-59)."""
+
+    def __init__(self, lower=0.0, beta=0.1, threshold=20.0):
+        self.beta = beta
+        self.lower = lower
+        self.threshold = threshold
+
+    def forward(self, x):
+        z = self.beta * x
+        big = z > self.threshold
+        with np.errstate(over="ignore"):
+            sp = np.where(big, x, np.log1p(np.exp(np.where(big, 0.0, z))) / self.beta)
+        return self.lower + sp
+
+    def dforward(self, x):
+        z = self.beta * x
+        big = z > self.threshold
+        with np.errstate(over="ignore"):
+            return np.where(big, 1.0, 1.0 / (1.0 + np.exp(-np.where(big, 0.0, z))))
+
+    def inverse(self, y):
+        if abs(self.beta) <= 1e-9 * max(abs(self.beta), 0.0):
+            return 0.0
+        elif self.beta < 0.0:
+            if np.any(self.lower < y):
+                raise ValueError("values must be smaller than %s" % self.lower)
+        elif np.any(y < self.lower):
+            raise ValueError("values must be greater than %s" % self.lower)
+        # quirk Q1: `lower` sits outside the beta product, exactly as reference parameter.py:59
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return (y - self.lower) + np.log(-np.expm1(-self.beta * y - self.lower)) / self.beta
+
+
+class Sigmoid(Transform):
+    """y = lower + (upper-lower) sigmoid(x)  (reference parameter.py:61-96)."""
+
+    def __init__(self, lower=0.0, upper=1.0):
+        self.lower = lower
+        self.upper = upper
+
+    def _sig(self, x):
+        with np.errstate(over="ignore"):
+            return 1.0 / (1.0 + np.exp(-x))
+
+    def forward(self, x):
+        return self.lower + (self.upper - self.lower) * self._sig(x)
+
+    def dforward(self, x):
+        s = self._sig(x)
+        return (self.upper - self.lower) * s * (1.0 - s)
+
+    def inverse(self, y):
+        if np.any(y < self.lower) or np.any(self.upper < y):
+            raise ValueError("values must be between %s and %s" % (self.lower, self.upper))
+        y = (y - self.lower) / (self.upper - self.lower)
+        close = np.isclose(self.lower * np.ones_like(y), self.upper * np.ones_like(y))
+        y = np.where(close, sys.float_info.epsilon, y)
+        with np.errstate(divide="ignore"):
+            return np.log(y) - np.log(1 - y)
+
+
+class Parameter:
+    """
+    Parameter trained in an unconstrained space (reference parameter.py:99-346).
+
+    Args:
+        value: initial value in the CONSTRAINED space.
+        name (str), lower, upper, prior, train: as the reference.
+    """
+
+    def __init__(self, value, name=None, lower=None, upper=None, prior=None, train=True):
+        value = _asarray(value)
+        self.data = value
+        self.grad = None
+        self._name = name
+        self.lower = None
+        self.upper = None
+        self.prior = prior
+        self.train = train
+        self.transform = None
+        self.pegged_parameter = None
+        self.pegged_transform = None
+        self.num_parameters = int(np.prod(value.shape))
+        self.assign(value, lower=lower, upper=upper)
+
+    # -- tensor-like surface -----------------------------------------------------------------
+    @property
+    def shape(self):
+        return self.data.shape
+
+    @property
+    def ndim(self):
+        return self.data.ndim
+
+    def __repr__(self):
+        name = self._name
+        if self.pegged:
+            name = self.pegged_parameter._name
+        if name is None:
+            return "{}".format(self.constrained.tolist())
+        return "{}={}".format(self._name, self.constrained.tolist())
+
+    def __call__(self):
+        return self.constrained
+
+    def clone(self):
+        return copy.deepcopy(self)
+
+    @property
+    def pegged(self):
+        return self.pegged_parameter is not None
+
+    @property
+    def constrained(self):
+        """reference parameter.py:186-201"""
+        if self.pegged:
+            other = self.pegged_parameter.constrained
+            if self.pegged_transform is not None:
+                other = self.pegged_transform(other)
+            return other
+        if self.transform is not None:
+            return self.transform.forward(self.data)
+        return self.data
+
+    def dconstrained(self):
+        """d constrained / d raw, elementwise; the link the reference gets from autograd through
+        Softplus/Sigmoid.forward (parameter.py:48-49,77-78)."""
+        if self.transform is not None:
+            return self.transform.dforward(self.data)
+        return np.ones_like(self.data)
+
+    def numpy(self):
+        return np.array(self.constrained)
+
+    @staticmethod
+    def to_tensor(value):
+        return _asarray(value)
+
+    @staticmethod
+    def to_transform(lower, upper):
+        """reference parameter.py:220-230"""
+        if lower is not None and upper is not None:
+            if np.any(upper < lower):
+                raise ValueError("lower limit %s must be lower than upper limit %s" % (lower, upper))
+            return Sigmoid(lower=lower, upper=upper)
+        elif lower is not None:
+            return Softplus(lower=lower)
+        elif upper is not None:
+            return Softplus(lower=upper, beta=-0.1)
+        return None
+
+    def _fit_shape(self, arr, value, what):
+        if arr.ndim != 0:
+            while arr.ndim < value.ndim and value.shape[arr.ndim] == 1:
+                arr = arr[..., None]
+            while value.ndim < arr.ndim and arr.shape[-1] == 1:
+                arr = arr[..., 0]
+            if arr.shape != value.shape:
+                raise ValueError("%s and value must match shapes: %s != %s" % (what, arr.shape, value.shape))
+        return arr
+
+    def assign(self, value=None, name=None, lower=None, upper=None, prior=None, train=None):
+        """reference parameter.py:232-319 (same order of operations, same quirks)."""
+        if value is not None:
+            value = _asarray(value)
+            origshape = value.shape
+            while value.ndim < self.ndim and self.shape[value.ndim] == 1:
+                value = value[..., None]
+            while self.ndim < value.ndim and value.shape[-1] == 1:
+                value = value[..., 0]
+            if value.shape != self.shape:
+                raise ValueError("parameter shape must match: %s != %s" % (origshape, self.shape))
+        else:
+            value = self.data          # quirk Q2: RAW data re-interpreted as a constrained value
+
+        if lower is not None:
+            lower = self._fit_shape(_asarray(lower), value, "lower")
+        else:
+            lower = self.lower
+        if upper is not None:
+            upper = self._fit_shape(_asarray(upper), value, "upper")
+        else:
+            upper = self.upper
+
+        if name is None:
+            name = self._name
+        elif self._name is not None:
+            idx = self._name.rfind(".")
+            if idx != -1:
+                name = self._name[: idx + 1] + name
+        if prior is None:
+            prior = self.prior
+        if train is None:
+            train = True if self.pegged else self.train
+
+        transform = Parameter.to_transform(lower, upper)
+        if transform is not None:
+            if lower is not None:
+                value = np.where(value < lower, lower * np.ones_like(value), value)
+            if upper is not None:
+                value = np.where(upper < value, upper * np.ones_like(value), value)
+            value = transform.inverse(value)
+
+        self._name = name
+        self.data = np.array(value, dtype=np.float64)
+        self.lower = lower
+        self.upper = upper
+        self.prior = prior
+        self.train = train
+        self.transform = transform
+        self.pegged_parameter = None
+        self.pegged_transform = None
+
+    def peg(self, other, transform=None):
+        """reference parameter.py:321-335"""
+        if not isinstance(other, Parameter):
+            raise ValueError("parameter must be pegged to other parameter object")
+        elif other.pegged:
+            raise ValueError("cannot peg parameter to another pegged parameter")
+        self.pegged_parameter = other
+        self.pegged_transform = transform
+        self.train = False
+
+    def log_prior(self):
+        """reference parameter.py:337-346.  Priors are out of the hot-path scope (all None in the configs)."""
+        if self.prior is None:
+            return 0.0
+        raise NotImplementedError("parameter priors are not on the HIP path")
+
+
+class ParameterHolder:
+    """Minimal stand-in for torch.nn.Module's parameter registry: attributes that are Parameters (or
+    holders, or lists of holders) are enumerated in registration order, like Module.parameters()."""
+
+    def __setattr__(self, name, val):
+        if name != "_order":
+            cur = self.__dict__.get(name)
+            if isinstance(cur, Parameter) and val is not cur:
+                raise AttributeError("parameter is read-only, use Parameter.assign()")
+            if isinstance(val, Parameter) and val._name is None:
+                val._name = "%s.%s" % (self.__class__.__name__, name)
+            elif isinstance(val, (list, tuple)) and len(val) and all(isinstance(v, ParameterHolder) for v in val):
+                for i, item in enumerate(val):
+                    for p in item.parameters():
+                        p._name = "%s[%d].%s" % (self.__class__.__name__, i, p._name)
+            if isinstance(val, (Parameter, ParameterHolder)) or (
+                isinstance(val, (list, tuple)) and len(val) and all(isinstance(v, ParameterHolder) for v in val)
+            ):
+                order = self.__dict__.setdefault("_order", [])
+                if name not in order:
+                    order.append(name)
+        object.__setattr__(self, name, val)
+
+    def parameters(self):
+        """All Parameters in registration order (pegged parameters are not in the graph and get no grad)."""
+        seen = set()
+        for name in self.__dict__.get("_order", []):
+            val = self.__dict__[name]
+            items = val if isinstance(val, (list, tuple)) else [val]
+            for item in items:
+                if isinstance(item, Parameter):
+                    if id(item) not in seen:
+                        seen.add(id(item))
+                        yield item
+                else:
+                    for p in item.parameters():
+                        if id(p) not in seen:
+                            seen.add(id(p))
+                            yield p
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.parameters():
+            p.grad = None if set_to_none else np.zeros_like(p.data)

@@ -1,0 +1,437 @@
+"""
+Training / prediction driver -- host-side mirror of mogptk/model.py (Exact factory :76-100, Model :180-664).
+
+`Model.train()` runs the reference's optimiser loop (mogptk/model.py:541-566) with every loss/gradient
+evaluation being one native call into the HIP library; Adam/SGD/AdaGrad are restated in numpy over the
+P <= a few hundred raw scalars exactly as torch.optim does (defaults, bias correction, per-parameter step
+count, parameters with grad None skipped).
+"""
+import os
+import time
+import math
+import pickle
+import inspect
+import logging
+import numpy as np
+
+from . import gpr
+from .dataset import DataSet
+from .util import (mean_absolute_error, mean_absolute_percentage_error, symmetric_mean_absolute_percentage_error,
+                   mean_squared_error, root_mean_squared_error)
+
+logger = logging.getLogger("mogptk")
+
+
+def LoadModel(filename):
+    """reference mogptk/model.py:62-74"""
+    filename += ".npy"
+    with open(filename, "rb") as r:
+        return pickle.load(r)
+
+
+class Exact:
+    """
+    Exact inference (reference mogptk/model.py:76-100).
+
+    Args:
+        variance (float): Variance of the Gaussian likelihood (default: 1.0 per channel).
+        data_variance: fixed per-point variances added to the diagonal.
+        jitter (float): Relative jitter added before the Cholesky.
+    """
+
+    def __init__(self, variance=None, data_variance=None, jitter=1e-8):
+        self.variance = variance
+        self.data_variance = data_variance
+        self.jitter = jitter
+
+    def _build(self, kernel, x, y, y_err=None, mean=None):
+        variance = self.variance
+        if variance is None:
+            if kernel.output_dims is not None:
+                variance = [1.0] * kernel.output_dims
+            else:
+                variance = 1.0
+        data_variance = self.data_variance
+        if data_variance is None and y_err is not None:
+            data_variance = y_err ** 2
+        return gpr.Exact(kernel, x, y, variance=variance, data_variance=data_variance, jitter=self.jitter, mean=mean)
+
+
+# ---- optimisers over raw parameters (torch.optim semantics) -----------------------------------------
+class _Adam:
+    """torch.optim.Adam(params, lr=1e-3, betas=(0.9,0.999), eps=1e-8, weight_decay=0, amsgrad=False)"""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, **unused):
+        self.params = list(params)
+        self.lr, self.betas, self.eps, self.wd, self.amsgrad = lr, betas, eps, weight_decay, amsgrad
+        self.state = {}
+
+    def step(self):
+        b1, b2 = self.betas
+        for p in self.params:
+            if p.grad is None:
+                continue
+            g = p.grad
+            if self.wd != 0.0:
+                g = g + self.wd * p.data
+            st = self.state.setdefault(id(p), dict(t=0, m=np.zeros_like(p.data), v=np.zeros_like(p.data),
+                                                   vmax=np.zeros_like(p.data)))
+            st["t"] += 1
+            st["m"] = b1 * st["m"] + (1.0 - b1) * g
+            st["v"] = b2 * st["v"] + (1.0 - b2) * g * g
+            bc1 = 1.0 - b1 ** st["t"]
+            bc2 = 1.0 - b2 ** st["t"]
+            v = st["v"]
+            if self.amsgrad:
+                st["vmax"] = np.maximum(st["vmax"], v)
+                v = st["vmax"]
+            denom = np.sqrt(v) / math.sqrt(bc2) + self.eps
+            p.data = p.data - (self.lr / bc1) * st["m"] / denom
+
+
+class _SGD:
+    """torch.optim.SGD(params, lr=1e-3, momentum=0, dampening=0, weight_decay=0, nesterov=False)"""
+
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, **unused):
+        self.params = list(params)
+        self.lr, self.mom, self.damp, self.wd, self.nesterov = lr, momentum, dampening, weight_decay, nesterov
+        self.state = {}
+
+    def step(self):
+        for p in self.params:
+            if p.grad is None:
+                continue
+            g = p.grad
+            if self.wd != 0.0:
+                g = g + self.wd * p.data
+            if self.mom != 0.0:
+                if id(p) not in self.state:
+                    buf = self.state[id(p)] = np.array(g)
+                else:
+                    buf = self.state[id(p)] = self.mom * self.state[id(p)] + (1.0 - self.damp) * g
+                g = g + self.mom * buf if self.nesterov else buf
+            p.data = p.data - self.lr * g
+
+
+class _Adagrad:
+    """torch.optim.Adagrad(params, lr=1e-2, lr_decay=0, weight_decay=0, initial_accumulator_value=0, eps=1e-10)"""
+
+    def __init__(self, params, lr=1e-2, lr_decay=0.0, weight_decay=0.0, initial_accumulator_value=0.0, eps=1e-10, **unused):
+        self.params = list(params)
+        self.lr, self.lr_decay, self.wd, self.eps = lr, lr_decay, weight_decay, eps
+        self.state = {id(p): dict(t=0, s=np.full_like(p.data, initial_accumulator_value)) for p in self.params}
+
+    def step(self):
+        for p in self.params:
+            if p.grad is None:
+                continue
+            st = self.state[id(p)]
+            st["t"] += 1
+            g = p.grad
+            if self.wd != 0.0:
+                g = g + self.wd * p.data
+            clr = self.lr / (1.0 + (st["t"] - 1) * self.lr_decay)
+            st["s"] = st["s"] + g * g
+            p.data = p.data - clr * g / (np.sqrt(st["s"]) + self.eps)
+
+
+def _format_time(t):
+    hours = int(t / 3600)
+    minutes = int((t % 3600) / 60)
+    seconds = int(t % 60)
+    return "%3d:%02d:%02d" % (hours, minutes, seconds)
+
+
+def _format_duration(t):
+    s = ""
+    if 3600 <= t:
+        s += "%d hours " % int(t / 3600)
+    if 60 <= t:
+        s += "%d minutes " % int((t % 3600) / 60)
+    return s + "%.3f seconds" % (t % 60)
+
+
+class Model:
+    def __init__(self, dataset, kernel, inference=Exact(), mean=None, name=None):
+        """
+        Base class of multi-output GP models (reference mogptk/model.py:181-236).
+
+        Args:
+            dataset (DataSet, Data): data of all channels.
+            kernel (mogptk_amd.gpr.Kernel): the kernel.
+            inference: inference model factory, e.g. `mogptk_amd.Exact()`.
+            mean: mean function hook (fixed functions only).
+            name (str): name of the model.
+
+        Attributes:
+            dataset, gpr, times, losses, errors: as the reference.
+        """
+        if not isinstance(dataset, DataSet):
+            dataset = DataSet(dataset)
+        if dataset.get_output_dims() == 0:
+            raise ValueError("dataset must have at least one channel")
+        names = [n for n in dataset.get_names() if n is not None]
+        if len(set(names)) != len(names):
+            raise ValueError("all data channels must have unique names")
+
+        self.name = name
+        self.dataset = dataset
+        self.is_multioutput = kernel.output_dims is not None
+
+        X, Y = self.dataset.get_train_data()
+        x, y = self._to_kernel_format(X, Y)
+
+        y_err = None
+        if all(channel.Y_err is not None for channel in self.dataset):
+            Y_err = [channel.Y_err[channel.mask] for channel in self.dataset]
+            lo = [self.dataset[j].Y_transformer.forward(Y[j] - Y_err[j], X[j]) for j in range(len(self.dataset))]
+            up = [self.dataset[j].Y_transformer.forward(Y[j] + Y_err[j], X[j]) for j in range(len(self.dataset))]
+            y_err = (np.concatenate(up, axis=0) - np.concatenate(lo, axis=0)) / 2.0
+        self.gpr = inference._build(kernel, x, y, y_err, mean)
+
+        self.iters = 0
+        self.times = np.zeros(0)
+        self.losses = np.zeros(0)
+        self.errors = np.zeros(0)
+
+    def __str__(self):
+        s = "Model: %s\n" % self.gpr._get_name()
+        s += "‣ Kernel: %s\n" % self.gpr.kernel.name()
+        s += "‣ Likelihood: %s\n" % self.gpr.likelihood.name()
+        s += "‣ Parameters: %d\n" % self.num_parameters()
+        for p in self.gpr.parameters():
+            s += "  - %s %s\n" % (p._name, p.shape)
+        s += "‣ Channels: %d\n" % len(self.dataset)
+        s += "‣ Training points: %d\n" % self.num_training_points()
+        return s
+
+    def print_parameters(self):
+        self.gpr.print_parameters()
+
+    def parameters(self):
+        """reference mogptk/model.py:266-276"""
+        return list(self.gpr.parameters())
+
+    def num_parameters(self):
+        """reference mogptk/model.py:296-306 (the only place `Parameter.train` matters: quirk Q3)"""
+        return sum(p.num_parameters if p.train else 0 for p in self.gpr.parameters())
+
+    def num_training_points(self):
+        return sum(len(channel.get_train_data()[1]) for channel in self.dataset)
+
+    def save(self, filename):
+        """reference mogptk/model.py:320-336 (pickles the whole model; device handles are dropped and rebuilt lazily)"""
+        filename += ".npy"
+        try:
+            os.remove(filename)
+        except OSError:
+            pass
+        with open(filename, "wb") as w:
+            pickle.dump(self, w)
+
+    def log_marginal_likelihood(self):
+        """reference mogptk/model.py:338-348"""
+        return float(self.gpr.log_marginal_likelihood())
+
+    def BIC(self):
+        return self.num_parameters() * np.log(self.num_training_points()) - 2.0 * self.log_marginal_likelihood()
+
+    def AIC(self):
+        return 2.0 * self.num_parameters() - 2.0 * self.log_marginal_likelihood()
+
+    def loss(self):
+        """reference mogptk/model.py:374-384"""
+        return float(self.gpr.loss())
+
+    def error(self, method="MAE", use_all_data=False):
+        """reference mogptk/model.py:386-439"""
+        if callable(method) and len(inspect.signature(method).parameters) == 1:
+            return method(self)
+        if use_all_data or not any(self.dataset.has_test_data()):
+            X, Y_true = self.dataset.get_data()
+        else:
+            X, Y_true = self.dataset.get_test_data()
+        x = self._to_kernel_format(X)
+        y_pred = self.gpr.predict_y(x)
+        i = 0
+        Y_pred = []
+        for j in range(self.dataset.get_output_dims()):
+            N = X[j].shape[0]
+            Y_pred.append(self.dataset[j].Y_transformer.backward(np.squeeze(y_pred[i:i + N]), X[j]))
+            i += N
+        y_true = np.concatenate(Y_true)
+        y_pred = np.concatenate(Y_pred)
+        if callable(method):
+            return method(y_true, y_pred)
+        fns = {"mae": mean_absolute_error, "mape": mean_absolute_percentage_error,
+               "smape": symmetric_mean_absolute_percentage_error, "mse": mean_squared_error,
+               "rmse": root_mean_squared_error}
+        if method.lower() not in fns:
+            raise ValueError("valid error calculation methods are MAE, MAPE, sMAPE, MSE, and RMSE")
+        return fns[method.lower()](y_true, y_pred)
+
+    def train(self, method="Adam", iters=500, verbose=False, error=None, plot=False, jit=None, **kwargs):
+        """
+        Optimise the hyper-parameters (reference mogptk/model.py:441-579): `iters` optimiser steps and
+        `iters+1` loss evaluations; `times/losses/errors` are continued across calls, the optimiser state is not.
+
+        Args:
+            method (str): Adam, SGD or AdaGrad (LBFGS is not on the HIP path yet).
+            iters (int): number of iterations.
+            verbose (bool): print progress (at most every ~10 s).
+            error (str, function): prediction error evaluated per iteration.
+            plot (bool): accepted; plotting is out of scope.
+            jit (bool): accepted and ignored (one native call per evaluation already).
+            **kwargs: passed to the optimiser (lr=..., betas=..., ...).
+
+        Returns:
+            numpy.ndarray: losses, numpy.ndarray: errors.
+        """
+        error_use_all_data = False
+        if error is not None and all(not channel.has_test_data() for channel in self.dataset):
+            error_use_all_data = True
+        if callable(error):
+            if len(inspect.signature(error).parameters) == 1:
+                e = error(self)
+            else:
+                e = error(np.zeros((1, 1)), np.zeros((1, 1)))
+            if not isinstance(e, float) and (not isinstance(e, np.ndarray) or e.size != 1):
+                raise ValueError("error function must return a float")
+
+        if method.lower() in ("l-bfgs", "lbfgs", "l-bfgs-b", "lbfgsb"):
+            raise NotImplementedError("LBFGS is not on the HIP path yet (SURVEY.md 8f-1); use Adam")
+        elif method.lower() == "adam":
+            method = "Adam"
+        elif method.lower() == "sgd":
+            method = "SGD"
+        elif method.lower() == "adagrad":
+            method = "AdaGrad"
+        else:
+            raise ValueError("optimizer must be LBFGS, Adam, SGD, or AdaGrad")
+
+        if verbose:
+            print("Starting optimization using", method)
+            print("‣ Model: %s" % self.gpr.name())
+            print("  ‣ Kernel: %s" % self.gpr.kernel.name())
+            print("  ‣ Likelihood: %s" % self.gpr.likelihood.name())
+            print("‣ Channels: %d" % len(self.dataset))
+            print("‣ Parameters: %d" % self.num_parameters())
+            print("‣ Training points: %d" % self.num_training_points())
+            print("‣ Iterations: %d" % iters)
+
+        iter_offset = 0
+        times = np.zeros((iters + 1,))
+        losses = np.zeros((iters + 1,))
+        errors = np.zeros((iters + 1,))
+        if self.times.shape[0] != 0:
+            iter_offset = self.times.shape[0] - 1
+            times = np.concatenate((self.times[:-1], times))
+            losses = np.concatenate((self.losses[:-1], losses))
+            errors = np.concatenate((self.errors[:-1] if self.errors.shape[0] == self.times.shape[0]
+                                     else np.zeros(iter_offset), errors))
+        initial_time = time.time()
+        progress_time = 0.0
+
+        iters_len = 1 if iters == 0 else int(math.log10(iter_offset + iters)) + 1
+
+        def progress(i, loss, last=False):
+            nonlocal progress_time
+            elapsed_time = time.time() - initial_time
+            write = verbose and (last or 0.0 <= elapsed_time - progress_time)
+            i += iter_offset
+            times[i] = elapsed_time
+            losses[i] = loss
+            if error is not None:
+                errors[i] = float(self.error(error, error_use_all_data))
+                if write:
+                    print("  %*d/%*d %s  loss=%12g  error=%12g" % (iters_len, i, iters_len, iter_offset + iters,
+                                                                   _format_time(elapsed_time), losses[i], errors[i]))
+            elif write:
+                print("  %*d/%*d %s  loss=%12g" % (iters_len, i, iters_len, iter_offset + iters,
+                                                  _format_time(elapsed_time), losses[i]))
+            if write:
+                progress_time += 10.0 + float(int((elapsed_time - progress_time) / 10.0)) * 10.0
+
+        params = list(self.gpr.parameters())
+        if method == "Adam":
+            optimizer = _Adam(params, **kwargs)
+        elif method == "SGD":
+            optimizer = _SGD(params, **kwargs)
+        else:
+            optimizer = _Adagrad(params, **kwargs)
+
+        for i in range(iters):
+            progress(i, self.loss())
+            optimizer.step()
+        progress(iters, self.loss(), last=True)
+
+        if verbose:
+            print("Optimization finished in %s" % _format_duration(time.time() - initial_time))
+
+        self.iters = iter_offset + iters
+        self.times = times[:iter_offset + iters + 1]
+        self.losses = losses[:iter_offset + iters + 1]
+        if error is not None:
+            self.errors = errors[:iter_offset + iters + 1]
+        return losses, errors
+
+    # ---- predictions ---------------------------------------------------------------------
+    def _to_kernel_format(self, X, Y=None):
+        """reference mogptk/model.py:585-606: concatenate channels in order, prepend the channel id column,
+        apply the per-channel Y transformers."""
+        x = np.concatenate(X, axis=0)
+        if self.is_multioutput:
+            chan = np.concatenate([j * np.ones(len(X[j])) for j in range(len(X))]).reshape(-1, 1)
+            x = np.concatenate([chan, x], axis=1)
+        if Y is None:
+            return x
+        Y = list(Y)
+        for j in range(len(Y)):
+            Y[j] = self.dataset[j].Y_transformer.forward(Y[j], X[j])
+        y = np.concatenate(Y, axis=0).reshape(-1, 1)
+        return x, y
+
+    def predict(self, X=None, ci=None, sigma=2, n=10000, transformed=False):
+        """
+        reference mogptk/model.py:608-664.  Returns (X, mu, lower, upper) as lists per channel, or bare arrays
+        for a single channel.
+        """
+        if X is None:
+            X = self.dataset.get_prediction_data()
+        else:
+            X = self.dataset._format_X(X)
+        x = self._to_kernel_format(X)
+
+        if isinstance(ci, float):
+            ci = (1.0 - ci) / 2.0
+            ci = [ci, 1.0 - ci]
+        if ci is not None:
+            ci = [max(0.0, ci[0]), min(1.0, ci[1])]
+
+        mu, lower, upper = self.gpr.predict_y(x, ci, sigma=sigma, n=n)
+
+        i = 0
+        Mu, Lower, Upper = [], [], []
+        for j in range(self.dataset.get_output_dims()):
+            N = X[j].shape[0]
+            Mu.append(np.squeeze(mu[i:i + N]))
+            Lower.append(np.squeeze(lower[i:i + N]))
+            Upper.append(np.squeeze(upper[i:i + N]))
+            i += N
+
+        if not transformed:
+            for j in range(self.dataset.get_output_dims()):
+                Mu[j] = self.dataset[j].Y_transformer.backward(Mu[j], X[j])
+                Lower[j] = self.dataset[j].Y_transformer.backward(Lower[j], X[j])
+                Upper[j] = self.dataset[j].Y_transformer.backward(Upper[j], X[j])
+
+        if len(self.dataset) == 1:
+            return X[0], Mu[0], Lower[0], Upper[0]
+        return X, Mu, Lower, Upper
+
+    def K(self, X1, X2=None):
+        """reference mogptk/model.py:666-700"""
+        X1 = self._to_kernel_format(self.dataset._format_X(X1))
+        if X2 is not None:
+            X2 = self._to_kernel_format(self.dataset._format_X(X2))
+        return self.gpr.K(X1, X2)

@@ -1,0 +1,315 @@
+"""
+Golden-vector generator.  Runs ONLY in the build container: imports the reference (GAMES-UChile/mogptk,
+mounted read-only at /root/reference) with an IPython stub, evaluates its PyTorch-CPU path on seeded inputs
+and writes small .npz fixtures next to this script.  The fixtures are data (inputs + expected outputs);
+nothing of the reference travels.  Re-run:  python tests/golden/gen_golden.py [--full]
+
+  kernels.npz   K(X), K(X,X2), K_diag for MOSM / SM-in-IMO / CSM-mixture (incl. shuffled row order, D=2)
+  lml_*.npz     LML + d(loss)/d(raw) of every parameter (autograd) at N<=96, one at N=2048
+  predict.npz   predict_f mean/var (+full covariance) and predict_y intervals
+  adam_cfg1.npz airline-passengers SM(Q=3) Adam trajectory (BASELINE.json configs[0])
+  cfg2.npz      [--full] MOSM C=4 Q=3 N=8192 LML + gradient (BASELINE.json configs[1]; ~20 s, 10 GB)
+  cfg4.npz      [--full] CSM C=4 Q=3 N=16384 predict_f at 64 probe rows of S=4096 (configs[3]; ~40 s, 16 GB)
+"""
+import os
+import sys
+import types
+import argparse
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+
+ip, disp = types.ModuleType("IPython"), types.ModuleType("IPython.display")
+disp.display = lambda *a, **k: None
+disp.HTML = lambda s: s
+ip.display = disp
+sys.modules["IPython"] = ip
+sys.modules["IPython.display"] = disp
+sys.path.insert(0, "/root/reference")
+import torch          # noqa: E402
+import mogptk         # noqa: E402
+
+from mogptk_amd import synth   # noqa: E402  (seeded inputs shared with tests and bench)
+
+g = mogptk.gpr
+T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+
+
+def small_data(N, C, D, seed, shuffle=False):
+    rng = np.random.default_rng(seed)
+    n = [N // C + (1 if c < N % C else 0) for c in range(C)]
+    X = np.concatenate([np.concatenate([np.full((n[c], 1), float(c)), rng.uniform(0, 10, (n[c], D))], axis=1)
+                        for c in range(C)])
+    y = np.sin(X[:, 1]) * (1 + 0.3 * X[:, 0]) + 0.1 * rng.standard_normal(N)
+    if shuffle:
+        p = rng.permutation(N)
+        X, y = X[p], y[p]
+    return X, y
+
+
+def build_kernel(kind, C, Q, D, Rq, rng):
+    if kind == "mosm":
+        k = g.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=D)
+        k.weight.assign(rng.uniform(0.5, 1.5, (C, Q)))
+        k.mean.assign(rng.uniform(0.05, 0.5, (C, Q, D)))
+        k.variance.assign(rng.uniform(0.05, 0.5, (C, Q, D)))
+        k.delay.assign(rng.normal(0, 0.3, (C, Q, D)))
+        k.phase.assign(rng.normal(0, 0.3, (C, Q)))
+    elif kind == "sm":
+        k = g.IndependentMultiOutputKernel([g.SpectralMixtureKernel(Q=Q, input_dims=D) for _ in range(C)], output_dims=C)
+        for c in range(C):
+            k[c].magnitude.assign(rng.uniform(0.5, 1.5, Q))
+            k[c].mean.assign(rng.uniform(0.05, 0.5, (Q, D)))
+            k[c].variance.assign(rng.uniform(0.01, 0.1, (Q, D)))
+    elif kind == "csm":
+        k = g.MixtureKernel(g.CrossSpectralKernel(output_dims=C, input_dims=D, Rq=Rq), Q)
+        for q in range(Q):
+            k[q].amplitude.assign(rng.uniform(0.5, 1.5, (C, Rq)))
+            k[q].mean.assign(rng.uniform(0.05, 0.5, D))
+            k[q].variance.assign(rng.uniform(0.05, 0.5, D))
+            k[q].shift.assign(rng.normal(0, 0.3, (C, Rq)))
+    return k
+
+
+def dump_params(prefix, params, out, with_grad=False):
+    for n, p in enumerate(params):
+        out["%sp%d_raw" % (prefix, n)] = p.data.detach().numpy().copy()
+        out["%sp%d_lower" % (prefix, n)] = np.array(np.nan) if p.lower is None else np.asarray(p.lower.detach().numpy() if torch.is_tensor(p.lower) else p.lower)
+        out["%sp%d_upper" % (prefix, n)] = np.array(np.nan) if p.upper is None else np.asarray(p.upper.detach().numpy() if torch.is_tensor(p.upper) else p.upper)
+        out["%sp%d_cons" % (prefix, n)] = p().detach().numpy().copy()
+        if with_grad:
+            out["%sp%d_grad" % (prefix, n)] = np.array(np.nan) if p.grad is None else p.grad.detach().numpy().copy()
+    out[prefix + "names"] = np.array([p._name for p in params])
+
+
+KERNEL_CASES = [  # kind, C, Q, D, Rq, N, N2, shuffle
+    ("mosm", 2, 1, 1, 1, 40, 17, False),
+    ("mosm", 3, 2, 1, 1, 61, 23, True),
+    ("mosm", 3, 3, 2, 1, 48, 19, False),
+    ("mosm", 1, 2, 1, 1, 30, 11, False),
+    ("sm", 1, 3, 1, 1, 33, 12, False),
+    ("sm", 2, 2, 2, 1, 40, 15, True),
+    ("csm", 3, 2, 1, 1, 45, 16, False),
+    ("csm", 2, 2, 1, 2, 38, 14, True),
+    ("csm", 3, 1, 2, 2, 36, 13, False),
+]
+
+
+def gen_kernels():
+    out = {"ncases": np.array(len(KERNEL_CASES))}
+    for n, (kind, C, Q, D, Rq, N, N2, shuffle) in enumerate(KERNEL_CASES):
+        rng = np.random.default_rng(1000 + n)
+        X, _ = small_data(N, C, D, 2000 + n, shuffle)
+        X2, _ = small_data(N2, C, D, 3000 + n, shuffle)
+        k = build_kernel(kind, C, Q, D, Rq, rng)
+        pre = "c%d_" % n
+        out[pre + "meta"] = np.array([C, Q, D, Rq])
+        out[pre + "kind"] = np.array(kind)
+        out[pre + "X"] = X
+        out[pre + "X2"] = X2
+        dump_params(pre, list(k.parameters()), out)
+        with torch.no_grad():
+            out[pre + "K"] = k.K(T(X)).numpy()
+            out[pre + "K12"] = k.K(T(X), T(X2)).numpy()
+            out[pre + "Kdiag"] = k.K_diag(T(X)).numpy()
+    np.savez_compressed(os.path.join(HERE, "kernels.npz"), **out)
+    print("kernels.npz written")
+
+
+LML_CASES = [  # name, kind, C, Q, D, Rq, N, shuffle, scalar_variance
+    ("mosm_c3q2", "mosm", 3, 2, 1, 1, 96, False, False),
+    ("mosm_c2q3_shuf", "mosm", 2, 3, 1, 1, 70, True, False),
+    ("mosm_c3q2_d2", "mosm", 3, 2, 2, 1, 60, False, False),
+    ("mosm_c1q2", "mosm", 1, 2, 1, 1, 50, False, False),
+    ("mosm_scalarvar", "mosm", 2, 2, 1, 1, 64, False, True),
+    ("sm_c1q3", "sm", 1, 3, 1, 1, 80, False, False),
+    ("sm_c2q2_d2", "sm", 2, 2, 2, 1, 72, False, False),
+    ("csm_c3q2", "csm", 3, 2, 1, 1, 90, False, False),
+    ("csm_c2q2r2", "csm", 2, 2, 1, 2, 66, True, False),
+]
+
+
+def lml_case(kind, C, Q, D, Rq, X, y, rng, scalar_variance=False, jitter=1e-8):
+    k = build_kernel(kind, C, Q, D, Rq, rng)
+    scale = rng.uniform(0.1, 0.4) if scalar_variance else rng.uniform(0.1, 0.4, C)
+    m = g.Exact(k, T(X), T(y), variance=(scale ** 2 if scalar_variance else list(scale ** 2)), jitter=jitter)
+    m.likelihood.scale.assign(scale)
+    lml = float(m.log_marginal_likelihood())
+    loss = float(m.loss())
+    return m, lml, loss
+
+
+def gen_lml():
+    for n, (name, kind, C, Q, D, Rq, N, shuffle, sv) in enumerate(LML_CASES):
+        rng = np.random.default_rng(4000 + n)
+        X, y = small_data(N, C, D, 5000 + n, shuffle)
+        m, lml, loss = lml_case(kind, C, Q, D, Rq, X, y, rng, sv)
+        out = {"meta": np.array([C, Q, D, Rq]), "kind": np.array(kind), "X": X, "y": y, "jitter": np.array(m.jitter),
+               "lml": np.array(lml), "loss": np.array(loss), "scalar_variance": np.array(sv)}
+        dump_params("", list(m.parameters()), out, with_grad=True)
+        np.savez_compressed(os.path.join(HERE, "lml_%s.npz" % name), **out)
+        print("lml_%s.npz  lml=%.10f" % (name, lml))
+
+    # one mid-size case on the shared synthetic generator: only outputs are stored
+    C, Q, N = 4, 3, 2048
+    X, y = synth.make_data(N, C)
+    h = synth.mosm_hypers(C, Q)
+    m = ref_mosm(X, y, h, C, Q)
+    lml = float(m.log_marginal_likelihood())
+    loss = float(m.loss())
+    out = {"meta": np.array([C, Q, 1, 1, N]), "lml": np.array(lml), "loss": np.array(loss)}
+    dump_params("", list(m.parameters()), out, with_grad=True)
+    np.savez_compressed(os.path.join(HERE, "lml_synth2048.npz"), **out)
+    print("lml_synth2048.npz lml=%.10f" % lml)
+
+
+def ref_mosm(X, y, h, C, Q, D=1, jitter=1e-8):
+    k = g.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=D)
+    k.weight.assign(h["weight"]); k.mean.assign(h["mean"]); k.variance.assign(h["variance"])
+    k.delay.assign(h["delay"]); k.phase.assign(h["phase"])
+    m = g.Exact(k, T(X), T(y), variance=list(h["scale"] ** 2), jitter=jitter)
+    m.likelihood.scale.assign(h["scale"])
+    return m
+
+
+def ref_csm(X, y, h, C, Q, Rq=1, D=1, jitter=1e-8):
+    k = g.MixtureKernel(g.CrossSpectralKernel(output_dims=C, input_dims=D, Rq=Rq), Q)
+    for q in range(Q):
+        k[q].amplitude.assign(h["amplitude"][q]); k[q].mean.assign(h["mean"][q])
+        k[q].variance.assign(h["variance"][q]); k[q].shift.assign(h["shift"][q])
+    m = g.Exact(k, T(X), T(y), variance=list(h["scale"] ** 2), jitter=jitter)
+    m.likelihood.scale.assign(h["scale"])
+    return m
+
+
+def gen_predict():
+    out = {}
+    cases = [("mosm", 3, 2, 1, 1, 80, 31, False), ("csm", 2, 2, 1, 1, 60, 25, True), ("sm", 1, 3, 1, 1, 70, 29, False)]
+    out["ncases"] = np.array(len(cases))
+    for n, (kind, C, Q, D, Rq, N, S, shuffle) in enumerate(cases):
+        rng = np.random.default_rng(6000 + n)
+        X, y = small_data(N, C, D, 7000 + n, shuffle)
+        Xs, _ = small_data(S, C, D, 8000 + n, shuffle)
+        Xs[:, 1:] = Xs[:, 1:] * 1.2
+        m, lml, loss = lml_case(kind, C, Q, D, Rq, X, y, rng)
+        pre = "c%d_" % n
+        out[pre + "meta"] = np.array([C, Q, D, Rq]); out[pre + "kind"] = np.array(kind)
+        out[pre + "X"] = X; out[pre + "y"] = y; out[pre + "Xs"] = Xs; out[pre + "jitter"] = np.array(m.jitter)
+        dump_params(pre, list(m.parameters()), out)
+        mu, var = m.predict_f(T(Xs))
+        mu2, cov = m.predict_f(T(Xs), full=True)
+        ymu, lo, up = m.predict_y(T(Xs), sigma=2.0)
+        out[pre + "mu"] = mu.numpy(); out[pre + "var"] = var.numpy(); out[pre + "cov"] = cov.numpy()
+        out[pre + "lower"] = lo.numpy(); out[pre + "upper"] = up.numpy()
+    # single-output (no channel column) Exact with a scalar variance: the other CI branch (likelihood.py:370-378)
+    rng = np.random.default_rng(6100)
+    x = np.sort(rng.uniform(0, 10, 50)).reshape(-1, 1)
+    y = np.sin(x[:, 0]) + 0.1 * rng.standard_normal(50)
+    xs = np.linspace(-1, 12, 21).reshape(-1, 1)
+    k = g.SpectralMixtureKernel(Q=2, input_dims=1)
+    k.magnitude.assign([1.0, 0.5]); k.mean.assign([[0.15], [0.3]]); k.variance.assign([[0.02], [0.05]])
+    m = g.Exact(k, T(x), T(y), variance=0.04)
+    out["so_X"] = x; out["so_y"] = y; out["so_Xs"] = xs
+    dump_params("so_", list(m.parameters()), out)
+    mu, var = m.predict_f(T(xs))
+    ymu, lo, up = m.predict_y(T(xs), sigma=2.0)
+    out["so_mu"] = mu.numpy(); out["so_var"] = var.numpy(); out["so_lower"] = lo.numpy(); out["so_upper"] = up.numpy()
+    out["so_lml"] = np.array(float(m.log_marginal_likelihood()))
+    np.savez_compressed(os.path.join(HERE, "predict.npz"), **out)
+    print("predict.npz written")
+
+
+def gen_adam_cfg1():
+    """BASELINE.json configs[0]: SM Q=3 on airline passengers, TransformDetrend(2)+TransformStandard,
+    init_parameters('LS'), train('Adam', iters=100, lr=0.1).  Stores kernel-format inputs (after the
+    reference's transforms), the initial raw parameters, the loss trace and the final raw parameters."""
+    air = np.loadtxt("/root/reference/examples/data/Airline_passenger.csv")
+    data = mogptk.Data(air[:, 0], air[:, 1], name="airline")
+    data.transform(mogptk.TransformDetrend(degree=2))
+    data.transform(mogptk.TransformStandard())
+    torch.manual_seed(1)
+    model = mogptk.SM(data, Q=3)
+    model.init_parameters("LS")
+    out = {"X": model.gpr.X.numpy().copy(), "y": model.gpr.y.numpy().copy(), "jitter": np.array(model.gpr.jitter),
+           "lr": np.array(0.1), "iters": np.array(100)}
+    dump_params("init_", list(model.gpr.parameters()), out)
+    out["lml0"] = np.array(model.log_marginal_likelihood())
+    losses, _ = model.train("Adam", iters=100, lr=0.1, jit=False)
+    out["losses"] = np.array(losses)
+    dump_params("final_", list(model.gpr.parameters()), out)
+    xs = np.linspace(0, 160, 33)
+    _, mu, lo, up = model.predict(xs, transformed=True)
+    out["pred_X"] = xs; out["pred_mu"] = mu; out["pred_lower"] = lo; out["pred_upper"] = up
+    np.savez_compressed(os.path.join(HERE, "adam_cfg1.npz"), **out)
+    print("adam_cfg1.npz lml0=%.10f loss[100]=%.6f" % (out["lml0"], losses[-1]))
+
+
+def gen_quirks():
+    """Q1/Q2 of SURVEY.md 8b as data."""
+    out = {}
+    p = g.Parameter(1.0, lower=1e-8)
+    out["q1_readback"] = p().detach().numpy()
+    out["q1_raw"] = p.data.detach().numpy()
+    t = np.linspace(0, 10, 20)
+    ds = mogptk.DataSet(t, [np.sin(t), np.cos(t)])
+    torch.manual_seed(0)
+    m = mogptk.MOSM(ds, Q=2)
+    out["q2_mean"] = m.gpr.kernel.mean().detach().numpy()
+    out["q2_mean_raw"] = m.gpr.kernel.mean.data.detach().numpy()
+    out["q2_upper"] = m.gpr.kernel.mean.upper.detach().numpy()
+    vals = np.array([0.3, 1e-3, 5.0, 250.0])
+    p = g.Parameter(vals, lower=1e-8)
+    out["sp_vals"] = vals; out["sp_raw"] = p.data.detach().numpy(); out["sp_cons"] = p().detach().numpy()
+    p = g.Parameter(vals, lower=1e-8, upper=300.0)
+    out["sg_raw"] = p.data.detach().numpy(); out["sg_cons"] = p().detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "quirks.npz"), **out)
+    print("quirks.npz written")
+
+
+def gen_cfg2():
+    import time
+    C, Q, N = 4, 3, 8192
+    X, y = synth.make_data(N, C)
+    m = ref_mosm(X, y, synth.mosm_hypers(C, Q), C, Q)
+    t = time.time()
+    loss = float(m.loss())
+    dt = time.time() - t
+    out = {"meta": np.array([C, Q, 1, 1, N]), "loss": np.array(loss), "lml": np.array(-loss), "seconds": np.array(dt),
+           "threads": np.array(torch.get_num_threads())}
+    dump_params("", list(m.parameters()), out, with_grad=True)
+    np.savez_compressed(os.path.join(HERE, "cfg2.npz"), **out)
+    print("cfg2.npz loss=%.10f  (%.1f s/eval on %d threads)" % (loss, dt, torch.get_num_threads()))
+
+
+def gen_cfg4():
+    import time
+    C, Q, N, S = 4, 3, 16384, 4096
+    X, y = synth.make_data(N, C)
+    Xs = synth.test_inputs(S, C)
+    m = ref_csm(X, y, synth.csm_hypers(C, Q), C, Q)
+    t = time.time()
+    mu, var = m.predict_f(T(Xs))
+    dt = time.time() - t
+    probe = np.arange(0, S, S // 64)
+    out = {"meta": np.array([C, Q, 1, 1, N, S]), "probe": probe, "mu": mu.numpy()[probe, 0], "var": var.numpy()[probe, 0],
+           "seconds": np.array(dt)}
+    np.savez_compressed(os.path.join(HERE, "cfg4.npz"), **out)
+    print("cfg4.npz written (%.1f s)" % dt)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "quirks": gen_quirks}
+    full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4}
+    if a.only:
+        {**steps, **full}[a.only]()
+    else:
+        for f in steps.values():
+            f()
+        if a.full:
+            for f in full.values():
+                f()

@@ -1,0 +1,156 @@
+"""
+Host logic on CPU: the term tables, the chain rule table -> raw parameters, the optimiser loop and the driver
+semantics of the product package, with the device replaced by the numpy table model (oracle/table_model.py).
+The native library is NOT exercised here (see tests/test_gpu_parity.py for that); results are compared with the
+reference's own outputs in tests/golden/.
+"""
+import pickle
+import numpy as np
+import pytest
+
+import mogptk_amd
+from mogptk_amd import gpr
+import mogptk_amd._lib as L
+from helpers import load, fixture_params, product_exact, product_kernel, load_raw, relerr
+from oracle.table_model import TableDevice, gram_from_table
+
+
+@pytest.fixture(autouse=True)
+def fake_device(monkeypatch):
+    monkeypatch.setattr(L, "ExactHandle", TableDevice)
+    monkeypatch.setattr(L, "gram", lambda device, C, D, table, X1, X2=None: gram_from_table(np.asarray(table), X1, X2))
+
+
+def test_term_tables_reproduce_reference_kernels():
+    fx = load("kernels.npz")
+    for n in range(int(fx["ncases"])):
+        pre = "c%d_" % n
+        C, Q, D, Rq = [int(v) for v in fx[pre + "meta"]]
+        k = product_kernel(str(fx[pre + "kind"]), C, Q, D, Rq)
+        load_raw(k.parameters(), fixture_params(fx, pre))
+        X, X2 = fx[pre + "X"], fx[pre + "X2"]
+        assert relerr(k.K(X), fx[pre + "K"]) < 1e-13
+        assert relerr(k(X, X2), fx[pre + "K12"]) < 1e-13
+        assert relerr(k.K_diag(X), fx[pre + "Kdiag"]) < 1e-14
+
+
+LML = ["mosm_c3q2", "mosm_c2q3_shuf", "mosm_c3q2_d2", "mosm_c1q2", "mosm_scalarvar", "sm_c1q3", "sm_c2q2_d2",
+       "csm_c3q2", "csm_c2q2r2"]
+
+
+@pytest.mark.parametrize("name", LML)
+def test_loss_and_chain_rule_match_reference_autograd(name):
+    fx = load("lml_%s.npz" % name)
+    m, fp = product_exact(fx)
+    assert abs(float(m.log_marginal_likelihood()) - float(fx["lml"])) < 1e-9 * abs(float(fx["lml"]))
+    loss = m.loss()
+    assert abs(float(loss) - float(fx["loss"])) < 1e-9 * abs(float(fx["loss"]))
+    for p, f in zip(m.parameters(), fp):
+        if f["grad"] is None:
+            assert p.grad is None, p._name      # same graph membership as the reference
+        else:
+            assert p.grad is not None, p._name
+            assert np.max(np.abs(p.grad - f["grad"])) <= 1e-8 * max(1.0, np.max(np.abs(f["grad"]))), (p._name, p.grad, f["grad"])
+
+
+def test_predict_matches_reference():
+    fx = load("predict.npz")
+    for n in range(int(fx["ncases"])):
+        pre = "c%d_" % n
+        m, fp = product_exact(fx, pre)
+        Xs = fx[pre + "Xs"]
+        mu, var = m.predict_f(Xs)
+        assert mu.shape == (Xs.shape[0], 1) and var.shape == (Xs.shape[0], 1)
+        assert relerr(mu, fx[pre + "mu"]) < 1e-9 and np.max(np.abs(var - fx[pre + "var"])) < 1e-9
+        _, cov = m.predict_f(Xs, full=True)
+        assert np.max(np.abs(cov - fx[pre + "cov"])) < 1e-9
+        ymu, lo, up = m.predict_y(Xs, sigma=2.0)
+        assert relerr(lo, fx[pre + "lower"]) < 1e-9 and relerr(up, fx[pre + "upper"]) < 1e-9   # quirk Q4 branch
+
+
+def test_single_output_kernel_without_channel_column():
+    fx = load("predict.npz")
+    k = gpr.SpectralMixtureKernel(Q=2, input_dims=1)
+    m = gpr.Exact(k, fx["so_X"], fx["so_y"], variance=0.04)
+    load_raw(m.parameters(), fixture_params(fx, "so_"))
+    assert abs(float(m.log_marginal_likelihood()) - float(fx["so_lml"])) < 1e-9
+    mu, var = m.predict_f(fx["so_Xs"])
+    assert relerr(mu, fx["so_mu"]) < 1e-9 and np.max(np.abs(var - fx["so_var"])) < 1e-9
+    _, lo, up = m.predict_y(fx["so_Xs"], sigma=2.0)
+    assert relerr(lo, fx["so_lower"]) < 1e-9 and relerr(up, fx["so_upper"]) < 1e-9           # single-output CI branch
+
+
+def _airline_model():
+    fx = load("adam_cfg1.npz")
+    data = mogptk_amd.Data(fx["X"][:, 1], fx["y"][:, 0], name="airline")      # already transformed by the reference
+    model = mogptk_amd.SM(data, Q=3)
+    load_raw(model.gpr.parameters(), fixture_params(fx, "init_"))
+    return fx, model
+
+
+def test_train_adam_trajectory_and_driver_semantics():
+    fx, model = _airline_model()
+    assert abs(model.log_marginal_likelihood() - float(fx["lml0"])) < 1e-9
+    iters = 30
+    losses, errors = model.train("Adam", iters=iters, lr=float(fx["lr"]))
+    assert losses.shape == (iters + 1,) and errors.shape == (iters + 1,)        # iters+1 evaluations (model.py:563-566)
+    assert relerr(losses, fx["losses"][:iters + 1]) < 1e-8
+    assert model.times.shape == (iters + 1,) and model.iters == iters
+    # a second train() call continues the traces but starts a NEW optimiser (model.py:501-509, :557)
+    losses2, _ = model.train("adam", iters=5, lr=float(fx["lr"]))
+    assert losses2.shape == (iters + 5 + 1,) and model.iters == iters + 5
+    assert np.allclose(losses2[:iters], losses[:iters])
+    with pytest.raises(ValueError):
+        model.train("nope")
+
+
+def test_predict_return_shapes_and_pickle_roundtrip(tmp_path):
+    fx, model = _airline_model()
+    xs = fx["pred_X"]
+    X, mu, lo, up = model.predict(xs)
+    assert isinstance(mu, np.ndarray) and mu.shape == (len(xs),)               # bare arrays for one channel (model.py:662-664)
+    model.save(str(tmp_path / "m"))
+    m2 = mogptk_amd.LoadModel(str(tmp_path / "m"))
+    assert m2.gpr._handle is None                                              # device handles are not pickled
+    assert abs(m2.log_marginal_likelihood() - model.log_marginal_likelihood()) < 1e-12
+    t = np.linspace(0, 10, 30)
+    ds = mogptk_amd.DataSet(t, [np.sin(t), np.cos(t)])
+    mm = mogptk_amd.MOSM(ds, Q=2)
+    Xl, Mu, Lo, Up = mm.predict([np.linspace(0, 12, 7), np.linspace(0, 12, 9)])
+    assert isinstance(Mu, list) and Mu[0].shape == (7,) and Mu[1].shape == (9,)
+
+
+def test_quirks_q1_q2_q3():
+    fx = load("quirks.npz")
+    p = gpr.Parameter(1.0, lower=1e-8)
+    assert np.allclose(p(), fx["q1_readback"], rtol=1e-15) and np.allclose(p.data, fx["q1_raw"], rtol=1e-15)
+    p = gpr.Parameter(fx["sp_vals"], lower=1e-8)
+    assert np.allclose(p.data, fx["sp_raw"], rtol=1e-14) and np.allclose(p(), fx["sp_cons"], rtol=1e-14)
+    p = gpr.Parameter(fx["sp_vals"], lower=1e-8, upper=300.0)
+    assert np.allclose(p.data, fx["sg_raw"], rtol=1e-13) and np.allclose(p(), fx["sg_cons"], rtol=1e-14)
+    t = np.linspace(0, 10, 20)
+    ds = mogptk_amd.DataSet(t, [np.sin(t), np.cos(t)])
+    m = mogptk_amd.MOSM(ds, Q=2)
+    assert np.array_equal(m.gpr.kernel.mean(), fx["q2_mean"])                   # Q2: collapsed to the lower bound
+    assert np.all(np.isneginf(m.gpr.kernel.mean.data)) == np.all(np.isneginf(fx["q2_mean_raw"]))
+    assert np.allclose(m.gpr.kernel.mean.upper, fx["q2_upper"])
+    # Q3: train=False only changes num_parameters(); the optimiser still moves the tensor
+    n0 = m.num_parameters()
+    m.gpr.kernel.weight.train = False
+    assert m.num_parameters() == n0 - m.gpr.kernel.weight.num_parameters
+    w0 = m.gpr.kernel.weight.data.copy()
+    m.gpr.kernel.mean.assign(np.full((2, 2, 1), 0.1))
+    m.train("Adam", iters=2, lr=0.1)
+    assert not np.allclose(m.gpr.kernel.weight.data, w0)
+    with pytest.raises(AttributeError):
+        m.gpr.kernel.weight = gpr.Parameter(1.0)
+
+
+def test_unsupported_paths_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        gpr.use_single_precision()
+    with pytest.raises(NotImplementedError):
+        gpr.use_cpu()
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=1, output_dims=2) * gpr.MultiOutputSpectralMixtureKernel(Q=1, output_dims=2)
+    with pytest.raises(NotImplementedError):
+        k._spectral_terms(1)
