@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""
+bench.py -- BASELINE.json's headline metric on MI355X:
+    log-marginal-likelihood + gradient evaluations per second, MOSM C=4 Q=3 N=8192 (configs[1]), exact GP, fp64.
+
+A "step" is one `gpr.Exact.loss()`-equivalent: term table upload, Gram build (+noise +jitter), Cholesky, triangular
+inverse, alpha / log-det, K^-1, gradient-moment pass, moments back to the host, host chain rule to the raw-parameter
+gradient.  X and y are resident in HBM before the timed region (model creation); only the O(C^2 Q) parameter table
+goes host->device per step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL).  Round 1: the evaluation
+does not shard yet, so N ranks run N independent replicas of the workload ("replicas only") and
+`value` is the aggregate evals/s; scaling is therefore "weak".
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the fp64 MFMA GEMM, k_gemm) from HIP events
+recorded around every one of its launches inside the timed region; `cpu_baseline` times the torch-CPU port of the
+reference's op sequence (oracle/torch_port.py) on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X vendor figure for FP64 matrix (v_mfma_f64_16x16x4_f64); see DESIGN.md section 5
+HBM_PEAK_GBS = 8000.0
+
+
+def build_model(N, C, Q, device):
+    from mogptk_amd import gpr, synth
+    gpr.config.device = device
+    X, y = synth.make_data(N, C)
+    h = synth.mosm_hypers(C, Q)
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
+    for name in ("weight", "mean", "variance", "delay", "phase"):
+        getattr(k, name).assign(h[name])
+    m = gpr.Exact(k, X, y, variance=h["scale"] ** 2)
+    m.likelihood.scale.assign(h["scale"])
+    return m, X, y
+
+
+def cpu_baseline(N, C, Q, budget_s=45.0):
+    """torch-CPU port of the reference op sequence, one evaluation of the same workload when it fits the time
+    budget, otherwise the largest power-of-two N that does (stated in `sample`)."""
+    import torch
+    from oracle import torch_port
+    from mogptk_amd import synth, gpr
+    cores = torch.get_num_threads()
+
+    def one(n):
+        X, y = synth.make_data(n, C)
+        h = synth.mosm_hypers(C, Q)
+        raws = {}
+        for name in ("weight", "mean", "variance", "scale"):
+            raws[name] = gpr.Parameter(h[name], lower=1e-8).data
+        raws["delay"], raws["phase"] = h["delay"], h["phase"]
+        t = time.perf_counter()
+        torch_port.mosm_loss_and_grad(X, y, raws, C)
+        return time.perf_counter() - t
+
+    n = 2048
+    t = one(n)
+    while n < N and t * 8.5 < budget_s:       # ~cubic growth per doubling
+        n *= 2
+        t = one(n)
+    if n == N:
+        return dict(value=1.0 / t, unit="evals/s", cores=cores, kind="port",
+                    sample="1 LML+grad eval of the same workload (MOSM C=%d Q=%d N=%d), torch-CPU fp64 port of the "
+                           "reference op sequence, %.1f s" % (C, Q, N, t))
+    scale = (N / n) ** 3
+    return dict(value=1.0 / (t * scale), unit="evals/s", cores=cores, kind="port",
+                sample="1 eval at N=%d took %.1f s; extrapolated to N=%d by N^3 (x%.0f)" % (n, t, N, scale))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--channels", type=int, default=4)
+    ap.add_argument("--q", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import torch
+
+    from mogptk_amd import _lib
+    m, X, y = build_model(a.n, a.channels, a.q, local_rank)
+
+    def sync():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        m.loss()
+    h = m._handle
+    h.set_profiling(True)
+    stage = np.zeros(_lib.ST_COUNT)
+    gemm_flops = 0.0
+    gemm_launches = 0
+    barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        m.loss()
+        ms, nl, fl = h.stage_ms()
+        stage += ms
+        gemm_flops += fl
+        gemm_launches += nl
+    sync(); barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / a.steps
+        value = world * a.steps / dt
+        gemm_s = stage[_lib.ST_GEMM_KERNEL] * 1e-3
+        achieved = gemm_flops / gemm_s / 1e12 if gemm_s > 0 else 0.0
+        N = a.n
+        gram_bytes = 4.0 * N * (N + 1)            # lower triangle written once
+        gram_gbs = gram_bytes * a.steps / (stage[_lib.ST_GRAM] * 1e-3) / 1e9 if stage[_lib.ST_GRAM] > 0 else 0.0
+        mom_gbs = gram_bytes * a.steps / (stage[_lib.ST_MOMENTS] * 1e-3) / 1e9 if stage[_lib.ST_MOMENTS] > 0 else 0.0
+        out = {
+            "metric": "log-marginal-likelihood+grad evals/sec, MOSM C=4 N=8192; 1/2/4/8 GPU",
+            "value": value, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "MOSM C=%d Q=%d N=%d exact GP LML+gradient (BASELINE.json configs[1])" % (a.channels, a.q, N),
+                       "channels": a.channels, "Q": a.q, "N": N, "parallelism": "replicas x%d" % world if world > 1 else "1 gpu",
+                       "device": _lib.device_name(local_rank)},
+            "roofline": {"bound": "mfma", "kernel": "k_gemm (fp64 v_mfma_f64_16x16x4_f64)", "achieved": achieved,
+                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                         "traffic": None,
+                         "launches_per_eval": gemm_launches / a.steps, "avg_launch_us": 1e6 * gemm_s / max(gemm_launches, 1),
+                         "flops_per_eval": gemm_flops / a.steps},
+            "stages_ms_per_eval": {k: float(stage[i] / a.steps) for k, i in
+                                   (("gram", _lib.ST_GRAM), ("potrf", _lib.ST_POTRF), ("trtri", _lib.ST_TRTRI),
+                                    ("solve", _lib.ST_SOLVE), ("lauum", _lib.ST_LAUUM), ("moments", _lib.ST_MOMENTS),
+                                    ("device_total", _lib.ST_TOTAL), ("gemm_kernel", _lib.ST_GEMM_KERNEL))},
+            "gram_hbm": {"achieved": gram_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gram_gbs / HBM_PEAK_GBS,
+                         "bytes_per_launch": gram_bytes},
+            "moments_hbm": {"achieved": mom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mom_gbs / HBM_PEAK_GBS},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(N, a.channels, a.q)
+            except Exception as e:      # the baseline is a report, never a reason to lose the GPU measurement
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

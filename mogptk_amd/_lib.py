@@ -16,7 +16,7 @@ MOGP_EVAL_GRAD = 1
 ST_GRAM, ST_POTRF, ST_TRTRI, ST_LAUUM, ST_SOLVE, ST_MOMENTS, ST_TOTAL, ST_GEMM_KERNEL, ST_COUNT = range(9)
 
 _lib = None
-_lock = threading.Lock()
+_lock = threading.RLock()
 _ctx = {}
 
 c_dp = ctypes.POINTER(ctypes.c_double)

@@ -1,0 +1,715 @@
+// mogp_api.hip -- C ABI of libmogp_hip.so (see include/mogp_hip.h) and the per-evaluation orchestration:
+//   Gram (lower tiles, noise + jitter fused on the diagonal) -> blocked Cholesky -> level-batched triangular inverse
+//   -> alpha / log-det -> LAUUM (K^-1) -> gradient-moment pass -> a few hundred doubles back to the host.
+#include "../../include/mogp_hip.h"
+#include "mogp_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+namespace mogp {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    g_err = std::string("HIP error '") + hipGetErrorString(e) + "' in " + what + " (" + file + ":" + std::to_string(line) + ")";
+    return MOGP_EHIP;
+}
+int launch_potrf_trtri_tile(double* A, int64_t ld, int t, double* invd, double* logdet, unsigned long long* info, hipStream_t s);
+
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count) {
+        if (count <= n) return 0;
+        if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; n = 0; }
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+        n = count;
+        return 0;
+    }
+    void release() { if (p) { hipError_t e = hipFree(p); (void)e; } p = nullptr; n = 0; }
+};
+
+// channel-sorted view of an input matrix X (M x (1+D)): stable sort by channel id
+struct SortedX {
+    int64_t M = 0, Mpad = 0;
+    std::vector<int64_t> perm;        // sorted position -> original row
+    std::vector<int> off;             // [C+1]
+    std::vector<double> xs;           // [D][Mpad]
+    bool identity = true;
+};
+
+static int sort_inputs(const double* X, int64_t M, int D, int C, int64_t pad_to, SortedX& o) {
+    o.M = M;
+    o.Mpad = round_up(std::max<int64_t>(M, 1), pad_to);
+    o.perm.resize(M);
+    o.off.assign(C + 1, 0);
+    std::vector<int> chan(M);
+    for (int64_t r = 0; r < M; ++r) {
+        const double c = X[r * (1 + D)];
+        if (!(c >= 0.0) || c >= (double)C || c != std::floor(c))
+            return fail(MOGP_EINVAL, "X must have integers in [0, output_dims) for the channel IDs in the first input dimension");
+        chan[r] = (int)c;
+        o.off[chan[r] + 1]++;
+    }
+    for (int c = 0; c < C; ++c) o.off[c + 1] += o.off[c];
+    std::vector<int> cur(o.off.begin(), o.off.end() - 1);
+    o.identity = true;
+    for (int64_t r = 0; r < M; ++r) {
+        const int64_t pos = cur[chan[r]]++;
+        o.perm[pos] = r;
+        if (pos != r) o.identity = false;
+    }
+    o.xs.assign((size_t)D * o.Mpad, 0.0);
+    for (int64_t pos = 0; pos < M; ++pos)
+        for (int d = 0; d < D; ++d) o.xs[(size_t)d * o.Mpad + pos] = X[o.perm[pos] * (1 + D) + 1 + d];
+    return 0;
+}
+
+// tiles of the symmetric Gram (lower channel pairs, lower tiles inside diagonal channel blocks), grouped by pair
+static void build_sym_tiles(const std::vector<int>& off, int C, std::vector<GTile>& tiles, std::vector<int>& pair_start) {
+    tiles.clear();
+    pair_start.assign(1, 0);
+    for (int i = 0; i < C; ++i)
+        for (int j = 0; j <= i; ++j) {
+            const int ni = off[i + 1] - off[i], nj = off[j + 1] - off[j];
+            for (int bi = 0; bi * MOGP_GT < ni; ++bi)
+                for (int bj = 0; bj * MOGP_GT < nj; ++bj) {
+                    if (i == j && bj > bi) continue;
+                    GTile t;
+                    t.r0 = off[i] + bi * MOGP_GT; t.c0 = off[j] + bj * MOGP_GT;
+                    t.nr = std::min(MOGP_GT, ni - bi * MOGP_GT); t.nc = std::min(MOGP_GT, nj - bj * MOGP_GT);
+                    t.pair = i * C + j;
+                    t.flags = (i == j && bi == bj) ? GT_DIAG : GT_MIRROR;
+                    tiles.push_back(t);
+                }
+            pair_start.push_back((int)tiles.size());
+        }
+}
+
+static void build_rect_tiles(const std::vector<int>& offr, const std::vector<int>& offc, int C, std::vector<GTile>& tiles) {
+    tiles.clear();
+    for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j) {
+            const int ni = offr[i + 1] - offr[i], nj = offc[j + 1] - offc[j];
+            for (int bi = 0; bi * MOGP_GT < ni; ++bi)
+                for (int bj = 0; bj * MOGP_GT < nj; ++bj) {
+                    GTile t;
+                    t.r0 = offr[i] + bi * MOGP_GT; t.c0 = offc[j] + bj * MOGP_GT;
+                    t.nr = std::min(MOGP_GT, ni - bi * MOGP_GT); t.nc = std::min(MOGP_GT, nj - bj * MOGP_GT);
+                    t.pair = i * C + j;
+                    t.flags = 0;
+                    tiles.push_back(t);
+                }
+        }
+}
+
+}  // namespace mogp
+
+using namespace mogp;
+
+struct mogp_ctx {
+    int device = 0;
+    std::string name;
+};
+
+struct TrtriLevel {
+    std::vector<GemmTask> h1, h2;
+    DevBuf<GemmTask> d1, d2;
+    double flops1 = 0, flops2 = 0;
+};
+
+struct mogp_model {
+    mogp_ctx* ctx = nullptr;
+    int64_t N = 0, Npad = 0;
+    int nb = 0, D = 0, C = 0, T = 0;
+    SortedX sx;
+    std::vector<GTile> tiles;
+    std::vector<int> pair_start;
+    std::vector<double> table;          // host copy [C*C*T*W]
+    hipStream_t st = nullptr;
+
+    DevBuf<double> d_x, d_y, d_A, d_B, d_invd, d_table, d_noise, d_dvar, d_logdet, d_z, d_alpha, d_zz, d_partial, d_moments, d_diagG;
+    DevBuf<GTile> d_tiles;
+    DevBuf<int> d_pair_start, d_chan_off, d_flag;
+    DevBuf<unsigned long long> d_info;
+    std::vector<TrtriLevel> levels;
+
+    // prediction workspaces
+    DevBuf<double> d_xs, d_Ksf, d_Vt, d_mu, d_var, d_kdiag, d_Kss;
+    DevBuf<GTile> d_ptiles;
+
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;          // stage boundaries
+    std::vector<hipEvent_t> gemm_ev;     // pairs around GEMM launches
+    size_t gemm_ev_used = 0;
+    double ms[MOGP_ST_COUNT] = {0};
+    int64_t gemm_launches = 0;
+    double gemm_flops = 0.0;
+    bool have_W = false, have_Kinv = false;
+};
+
+static int use_device(mogp_ctx* c) { HIP_TRY(hipSetDevice(c->device)); return 0; }
+
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* mogp_version(void) { return "mogp_hip 0.1 (gfx950, fp64)"; }
+const char* mogp_last_error(void) { return g_err.c_str(); }
+
+int mogp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mogp_ctx_create(int device, mogp_ctx** out) {
+    if (!out) return fail(MOGP_EINVAL, "mogp_ctx_create: out is null");
+    int n = mogp_device_count();
+    if (n <= 0) return fail(MOGP_ENODEVICE, "no HIP device visible: mogptk_amd has no CPU path");
+    if (device < 0 || device >= n) return fail(MOGP_EINVAL, "mogp_ctx_create: device ordinal out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    mogp_ctx* c = new mogp_ctx();
+    c->device = device;
+    c->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    *out = c;
+    return MOGP_OK;
+}
+
+int mogp_ctx_destroy(mogp_ctx* ctx) { delete ctx; return MOGP_OK; }
+
+int mogp_ctx_device_name(mogp_ctx* ctx, char* buf, int buflen) {
+    if (!ctx || !buf || buflen <= 0) return fail(MOGP_EINVAL, "mogp_ctx_device_name: bad argument");
+    std::snprintf(buf, (size_t)buflen, "%s", ctx->name.c_str());
+    return MOGP_OK;
+}
+
+}  // extern "C"
+
+// ---- TRTRI level tasks ------------------------------------------------------------------------------------------
+// Bottom-up pairing of tile ranges: at level l (block size s = 2^(l-1) tiles) node b owns tiles [2sb, 2sb+2s); its left
+// half [lo, mid) and right half [mid, hi) are already inverted, and  W21 = -W22 * (L21 * W11)  fills the off-diagonal part.
+static void build_trtri_levels(mogp_model* m) {
+    const int nb = m->nb;
+    const int64_t ld = m->Npad;
+    m->levels.clear();
+    for (int s = 1; s < nb; s *= 2) {
+        TrtriLevel lv;
+        for (int lo = 0; lo < nb; lo += 2 * s) {
+            const int mid = lo + s, hi = std::min(lo + 2 * s, nb);
+            if (mid >= hi) continue;
+            for (int ti = mid; ti < hi; ++ti)
+                for (int tj = lo; tj < mid; ++tj) {
+                    GemmTask t1;      // T[ti][tj] = sum_{k = tj..mid} L21[ti][k] * W11[k][tj]      (W11 lower: k >= tj)
+                    t1.a_off = (int64_t)ti * MOGP_TILE * ld + (int64_t)tj * MOGP_TILE;
+                    t1.b_off = (int64_t)tj * MOGP_TILE * ld + (int64_t)tj * MOGP_TILE;
+                    t1.c_off = (int64_t)ti * MOGP_TILE * ld + (int64_t)tj * MOGP_TILE;
+                    t1.kt = (mid - tj) * (MOGP_TILE / 16); t1.pad = 0;
+                    lv.h1.push_back(t1);
+                    GemmTask t2;      // W21[ti][tj] = - sum_{k = mid..ti} W22[ti][k] * T[k][tj]   (W22 lower: k <= ti)
+                    t2.a_off = (int64_t)ti * MOGP_TILE * ld + (int64_t)mid * MOGP_TILE;
+                    t2.b_off = (int64_t)mid * MOGP_TILE * ld + (int64_t)tj * MOGP_TILE;
+                    t2.c_off = t1.c_off;
+                    t2.kt = (ti - mid + 1) * (MOGP_TILE / 16); t2.pad = 0;
+                    lv.h2.push_back(t2);
+                }
+        }
+        auto by_k = [](const GemmTask& a, const GemmTask& b) { return a.kt > b.kt; };
+        std::stable_sort(lv.h1.begin(), lv.h1.end(), by_k);
+        std::stable_sort(lv.h2.begin(), lv.h2.end(), by_k);
+        for (auto& t : lv.h1) lv.flops1 += 2.0 * MOGP_TILE * MOGP_TILE * 16.0 * t.kt;
+        for (auto& t : lv.h2) lv.flops2 += 2.0 * MOGP_TILE * MOGP_TILE * 16.0 * t.kt;
+        m->levels.push_back(std::move(lv));
+    }
+}
+
+static int gemm_call(mogp_model* m, const GemmArgs& g, double flops) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (m->profiling) {
+        if (m->gemm_ev_used + 2 > m->gemm_ev.size()) {
+            for (int i = 0; i < 64; ++i) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); m->gemm_ev.push_back(e); }
+        }
+        e0 = m->gemm_ev[m->gemm_ev_used++];
+        e1 = m->gemm_ev[m->gemm_ev_used++];
+        HIP_TRY(hipEventRecord(e0, m->st));
+    }
+    int rc = launch_gemm(g, m->st);
+    if (rc) return rc;
+    if (m->profiling) HIP_TRY(hipEventRecord(e1, m->st));
+    m->gemm_launches++;
+    m->gemm_flops += flops;
+    return 0;
+}
+
+static int mark(mogp_model* m, int idx) {
+    if (!m->profiling) return 0;
+    while ((int)m->ev.size() <= idx) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); m->ev.push_back(e); }
+    HIP_TRY(hipEventRecord(m->ev[idx], m->st));
+    return 0;
+}
+
+// diagonal value of channel block (c, c) implied by the table (Delta = Psi = 0 there for every kernel on the path)
+static double table_diag(const mogp_model* m, int c) {
+    const int D = m->D, W = 2 + 3 * D;
+    const double* tab = m->table.data() + (size_t)(c * m->C + c) * m->T * W;
+    double s = 0.0;
+    for (int t = 0; t < m->T; ++t) {
+        const double* r = tab + (size_t)t * W;
+        double arg = 0.0, ph = r[1];
+        for (int d = 0; d < D; ++d) { arg += r[2 + d] * r[2 + 2 * D + d] * r[2 + 2 * D + d]; ph += r[2 + D + d] * r[2 + 2 * D + d]; }
+        s += r[0] * std::exp(-0.5 * arg) * std::cos(2.0 * M_PI * ph);
+    }
+    return s;
+}
+
+// Gram + factorisation + inverse factor + alpha.  On return d_A holds W = L^-1, d_alpha = Kj^-1 y.
+static int factorize(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
+                     double* lml, double* jitter_abs, int64_t* info) {
+    const int C = m->C, D = m->D, W = 2 + 3 * D;
+    const int64_t N = m->N, Npad = m->Npad;
+    if (m->T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms must be called before an evaluation");
+    if (!noise_var) return fail(MOGP_EINVAL, "noise_var is null");
+    m->have_W = m->have_Kinv = false;
+    m->gemm_ev_used = 0; m->gemm_launches = 0; m->gemm_flops = 0.0;
+
+    // host scalars: mean of the diagonal for the relative jitter (reference gpr/model.py:244)
+    double dsum = 0.0;
+    for (int c = 0; c < C; ++c) dsum += (double)(m->sx.off[c + 1] - m->sx.off[c]) * (table_diag(m, c) + noise_var[c]);
+    std::vector<double> dv;
+    if (data_var) {
+        dv.resize(Npad, 0.0);
+        for (int64_t pos = 0; pos < N; ++pos) { dv[pos] = data_var[m->sx.perm[pos]]; dsum += dv[pos]; }
+        { int r__ = m->d_dvar.ensure(Npad); if (r__) return r__; }
+        HIP_TRY(hipMemcpyAsync(m->d_dvar.p, dv.data(), Npad * sizeof(double), hipMemcpyHostToDevice, m->st));
+    }
+    const double jabs = jitter * dsum / (double)N;
+    if (jitter_abs) *jitter_abs = jabs;
+
+    HIP_TRY(hipMemcpyAsync(m->d_noise.p, noise_var, C * sizeof(double), hipMemcpyHostToDevice, m->st));
+    const unsigned long long big = std::numeric_limits<unsigned long long>::max();
+    HIP_TRY(hipMemcpyAsync(m->d_info.p, &big, sizeof(big), hipMemcpyHostToDevice, m->st));
+
+    int rc;
+    if ((rc = mark(m, 0))) return rc;
+    GramArgs ga;
+    ga.tiles = m->d_tiles.p; ga.xr = m->d_x.p; ga.xc = m->d_x.p; ga.ldxr = ga.ldxc = Npad;
+    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C;
+    ga.out = m->d_A.p; ga.ldo = Npad; ga.noise = m->d_noise.p; ga.dvar = data_var ? m->d_dvar.p : nullptr;
+    ga.jitter_abs = jabs; ga.mirror = 0;
+    if ((rc = launch_gram(ga, (int)m->tiles.size(), m->st))) return rc;
+    if ((rc = launch_pad_identity(m->d_A.p, Npad, N, Npad, m->st))) return rc;
+    if ((rc = mark(m, 1))) return rc;
+
+    // ---- blocked right-looking Cholesky: leaf (factor + inverse) -> panel = panel * inv(Lkk)^T -> SYRK trailing update
+    const int nb = m->nb;
+    for (int k = 0; k < nb; ++k) {
+        if ((rc = launch_potrf_trtri_tile(m->d_A.p, Npad, k, m->d_invd.p, m->d_logdet.p, m->d_info.p, m->st))) return rc;
+        const int rem = nb - k - 1;
+        if (rem <= 0) break;
+        double* panel = m->d_A.p + (int64_t)(k + 1) * MOGP_TILE * Npad + (int64_t)k * MOGP_TILE;
+        GemmArgs g;
+        g.A = panel; g.lda = Npad; g.a_kmajor = 0;
+        g.B = m->d_invd.p + (int64_t)k * MOGP_TILE * MOGP_TILE; g.ldb = MOGP_TILE; g.b_kmajor = 0;
+        g.C = panel; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
+        g.mode = GM_RECT; g.mt = rem; g.nt = 1; g.K = MOGP_TILE; g.tasks = nullptr; g.ntasks = 0;
+        if ((rc = gemm_call(m, g, gemm_flops(g, nullptr)))) return rc;
+        GemmArgs u;
+        u.A = panel; u.lda = Npad; u.a_kmajor = 0; u.B = panel; u.ldb = Npad; u.b_kmajor = 0;
+        u.C = m->d_A.p + (int64_t)(k + 1) * MOGP_TILE * (Npad + 1); u.ldc = Npad; u.alpha = -1.0; u.beta = 1.0;
+        u.mode = GM_LOWER; u.mt = rem; u.nt = rem; u.K = MOGP_TILE; u.tasks = nullptr; u.ntasks = 0;
+        if ((rc = gemm_call(m, u, gemm_flops(u, nullptr)))) return rc;
+    }
+    if ((rc = mark(m, 2))) return rc;
+
+    // ---- W = L^-1, level by level (all nodes of one level in one launch)
+    if ((rc = launch_put_diag_tiles(m->d_A.p, Npad, nb, m->d_invd.p, m->st))) return rc;
+    for (auto& lv : m->levels) {
+        GemmArgs g;
+        g.A = m->d_A.p; g.lda = Npad; g.a_kmajor = 0; g.B = m->d_A.p; g.ldb = Npad; g.b_kmajor = 1;
+        g.C = m->d_B.p; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
+        g.mode = GM_TASKS; g.mt = g.nt = 0; g.K = 0; g.tasks = lv.d1.p; g.ntasks = (int)lv.h1.size();
+        if ((rc = gemm_call(m, g, lv.flops1))) return rc;
+        g.B = m->d_B.p; g.C = m->d_A.p; g.alpha = -1.0; g.tasks = lv.d2.p; g.ntasks = (int)lv.h2.size();
+        if ((rc = gemm_call(m, g, lv.flops2))) return rc;
+    }
+    if ((rc = mark(m, 3))) return rc;
+
+    // ---- z = W y, alpha = W^T z
+    if ((rc = launch_trmv_lower(m->d_A.p, Npad, Npad, m->d_y.p, m->d_z.p, m->d_zz.p, m->st))) return rc;
+    if ((rc = launch_trmv_lower_t(m->d_A.p, Npad, Npad, m->d_z.p, m->d_alpha.p, m->st))) return rc;
+    if ((rc = mark(m, 4))) return rc;
+
+    // scalars back
+    const int nzz = (int)((Npad + 3) / 4);
+    std::vector<double> hl(nb), hz(nzz);
+    unsigned long long hinfo = 0;
+    HIP_TRY(hipMemcpyAsync(hl.data(), m->d_logdet.p, nb * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipMemcpyAsync(hz.data(), m->d_zz.p, nzz * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipMemcpyAsync(&hinfo, m->d_info.p, sizeof(hinfo), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    if (hinfo != big) {
+        if (info) *info = (int64_t)hinfo;
+        // distinguish NaN / Inf in the Gram from a plain indefinite matrix (reference prints which, gpr/model.py:249-252)
+        int flag = 0;
+        HIP_TRY(hipMemsetAsync(m->d_flag.p, 0, sizeof(int), m->st));
+        if ((rc = launch_gram(ga, (int)m->tiles.size(), m->st))) return rc;
+        if ((rc = launch_nonfinite_scan(m->d_A.p, Npad, N, m->d_flag.p, m->st))) return rc;
+        HIP_TRY(hipMemcpyAsync(&flag, m->d_flag.p, sizeof(int), hipMemcpyDeviceToHost, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));
+        if (flag & 1) return fail(MOGP_ENONFINITE, "linalg.cholesky: kernel matrix has NaNs!");
+        if (flag & 2) return fail(MOGP_ENONFINITE, "linalg.cholesky: kernel matrix has infinities!");
+        return fail(MOGP_ENOTPD, "linalg.cholesky: The factorization could not be completed because the input is not "
+                                 "positive-definite (the leading minor of order " + std::to_string(hinfo) + " is not positive-definite).");
+    }
+    double logdet = 0.0, zz = 0.0;
+    for (double v : hl) logdet += v;
+    for (double v : hz) zz += v;
+    if (lml) *lml = -0.5 * (double)N * std::log(2.0 * M_PI) - logdet - 0.5 * zz;
+    m->have_W = true;
+    return 0;
+}
+
+static void collect_timing(mogp_model* m, int last_mark) {
+    if (!m->profiling) return;
+    auto el = [&](int a, int b) { float t = 0.f; if (hipEventElapsedTime(&t, m->ev[a], m->ev[b]) != hipSuccess) t = 0.f; return (double)t; };
+    std::fill(m->ms, m->ms + MOGP_ST_COUNT, 0.0);
+    m->ms[MOGP_ST_GRAM] = el(0, 1);
+    m->ms[MOGP_ST_POTRF] = el(1, 2);
+    m->ms[MOGP_ST_TRTRI] = el(2, 3);
+    m->ms[MOGP_ST_SOLVE] = el(3, 4);
+    if (last_mark >= 6) { m->ms[MOGP_ST_LAUUM] = el(4, 5); m->ms[MOGP_ST_MOMENTS] = el(5, 6); }
+    m->ms[MOGP_ST_TOTAL] = el(0, last_mark);
+    double gsum = 0.0;
+    for (size_t i = 0; i + 1 < m->gemm_ev_used; i += 2) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, m->gemm_ev[i], m->gemm_ev[i + 1]) == hipSuccess) gsum += t;
+    }
+    m->ms[MOGP_ST_GEMM_KERNEL] = gsum;
+}
+
+extern "C" {
+
+int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, const double* y, mogp_model** out) {
+    if (!ctx || !X || !y || !out) return fail(MOGP_EINVAL, "mogp_model_create: null argument");
+    if (N <= 0 || D <= 0 || D > MOGP_MAXD || C <= 0) return fail(MOGP_EINVAL, "mogp_model_create: need N > 0, 0 < D <= 8, C > 0");
+    int rc;
+    if ((rc = use_device(ctx))) return rc;
+    mogp_model* m = new mogp_model();
+    m->ctx = ctx; m->N = N; m->D = D; m->C = C;
+    if ((rc = sort_inputs(X, N, D, C, MOGP_TILE, m->sx))) { delete m; return rc; }
+    m->Npad = m->sx.Mpad;
+    m->nb = (int)(m->Npad / MOGP_TILE);
+    build_sym_tiles(m->sx.off, C, m->tiles, m->pair_start);
+    build_trtri_levels(m);
+    const int64_t Npad = m->Npad;
+    const int nchunks = (int)((Npad + 511) / 512);
+#define TRY_RC(x) do { int r__ = (x); if (r__) { mogp_model_destroy(m); return r__; } } while (0)
+#define TRY_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { int r__ = hip_fail(e__, #x, __FILE__, __LINE__); mogp_model_destroy(m); return r__; } } while (0)
+    TRY_HIP(hipStreamCreateWithFlags(&m->st, hipStreamNonBlocking));
+    TRY_RC(m->d_x.ensure((size_t)D * Npad));
+    TRY_RC(m->d_y.ensure(Npad));
+    TRY_RC(m->d_A.ensure((size_t)Npad * Npad));
+    TRY_RC(m->d_B.ensure((size_t)Npad * Npad));
+    TRY_RC(m->d_invd.ensure((size_t)m->nb * MOGP_TILE * MOGP_TILE));
+    TRY_RC(m->d_noise.ensure(C));
+    TRY_RC(m->d_logdet.ensure(m->nb));
+    TRY_RC(m->d_z.ensure(Npad));
+    TRY_RC(m->d_alpha.ensure((size_t)(1 + nchunks) * Npad));
+    TRY_RC(m->d_zz.ensure((Npad + 3) / 4));
+    TRY_RC(m->d_diagG.ensure(C));
+    TRY_RC(m->d_info.ensure(1));
+    TRY_RC(m->d_flag.ensure(1));
+    TRY_RC(m->d_tiles.ensure(m->tiles.size()));
+    TRY_RC(m->d_pair_start.ensure(m->pair_start.size()));
+    TRY_RC(m->d_chan_off.ensure(C + 1));
+    TRY_HIP(hipMemcpy(m->d_x.p, m->sx.xs.data(), (size_t)D * Npad * sizeof(double), hipMemcpyHostToDevice));
+    TRY_HIP(hipMemcpy(m->d_tiles.p, m->tiles.data(), m->tiles.size() * sizeof(GTile), hipMemcpyHostToDevice));
+    TRY_HIP(hipMemcpy(m->d_pair_start.p, m->pair_start.data(), m->pair_start.size() * sizeof(int), hipMemcpyHostToDevice));
+    TRY_HIP(hipMemcpy(m->d_chan_off.p, m->sx.off.data(), (C + 1) * sizeof(int), hipMemcpyHostToDevice));
+    for (auto& lv : m->levels) {
+        TRY_RC(lv.d1.ensure(lv.h1.size()));
+        TRY_RC(lv.d2.ensure(lv.h2.size()));
+        TRY_HIP(hipMemcpy(lv.d1.p, lv.h1.data(), lv.h1.size() * sizeof(GemmTask), hipMemcpyHostToDevice));
+        TRY_HIP(hipMemcpy(lv.d2.p, lv.h2.data(), lv.h2.size() * sizeof(GemmTask), hipMemcpyHostToDevice));
+    }
+    // the upper triangle of A is never written by the lower-only Gram; keep it finite
+    TRY_HIP(hipMemset(m->d_A.p, 0, (size_t)Npad * Npad * sizeof(double)));
+    TRY_HIP(hipMemset(m->d_B.p, 0, (size_t)Npad * Npad * sizeof(double)));
+    *out = m;
+    TRY_RC(mogp_model_set_y(m, y));
+#undef TRY_RC
+#undef TRY_HIP
+    return MOGP_OK;
+}
+
+int mogp_model_destroy(mogp_model* m) {
+    if (!m) return MOGP_OK;
+    if (m->ctx) { hipError_t e = hipSetDevice(m->ctx->device); (void)e; }
+    if (m->st) { hipError_t e = hipStreamSynchronize(m->st); (void)e; }
+    for (auto e : m->ev) { hipError_t r = hipEventDestroy(e); (void)r; }
+    for (auto e : m->gemm_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
+    for (auto& lv : m->levels) { lv.d1.release(); lv.d2.release(); }
+    m->d_x.release(); m->d_y.release(); m->d_A.release(); m->d_B.release(); m->d_invd.release(); m->d_table.release();
+    m->d_noise.release(); m->d_dvar.release(); m->d_logdet.release(); m->d_z.release(); m->d_alpha.release(); m->d_zz.release();
+    m->d_partial.release(); m->d_moments.release(); m->d_diagG.release(); m->d_tiles.release(); m->d_pair_start.release();
+    m->d_chan_off.release(); m->d_flag.release(); m->d_info.release();
+    m->d_xs.release(); m->d_Ksf.release(); m->d_Vt.release(); m->d_mu.release(); m->d_var.release(); m->d_kdiag.release();
+    m->d_Kss.release(); m->d_ptiles.release();
+    if (m->st) { hipError_t e = hipStreamDestroy(m->st); (void)e; }
+    delete m;
+    return MOGP_OK;
+}
+
+int mogp_model_set_y(mogp_model* m, const double* y) {
+    if (!m || !y) return fail(MOGP_EINVAL, "mogp_model_set_y: null argument");
+    int rc;
+    if ((rc = use_device(m->ctx))) return rc;
+    std::vector<double> ys(m->Npad, 0.0);
+    for (int64_t pos = 0; pos < m->N; ++pos) ys[pos] = y[m->sx.perm[pos]];
+    HIP_TRY(hipMemcpy(m->d_y.p, ys.data(), m->Npad * sizeof(double), hipMemcpyHostToDevice));
+    return MOGP_OK;
+}
+
+int mogp_model_set_terms(mogp_model* m, int T, const double* table) {
+    if (!m || !table || T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms: bad argument");
+    int rc;
+    if ((rc = use_device(m->ctx))) return rc;
+    const int W = 2 + 3 * m->D;
+    const size_t n = (size_t)m->C * m->C * T * W;
+    for (size_t i = 0; i < n; ++i)
+        if (!std::isfinite(table[i])) return fail(MOGP_ENONFINITE, "spectral term table has non-finite entries (kernel parameters diverged)");
+    m->T = T;
+    m->table.assign(table, table + n);
+    if ((rc = m->d_table.ensure(n))) return rc;
+    if ((rc = m->d_partial.ensure(m->tiles.size() * (size_t)T * W))) return rc;
+    if ((rc = m->d_moments.ensure((size_t)(m->C * (m->C + 1) / 2) * T * W))) return rc;
+    HIP_TRY(hipMemcpyAsync(m->d_table.p, m->table.data(), n * sizeof(double), hipMemcpyHostToDevice, m->st));
+    return MOGP_OK;
+}
+
+int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_var, double jitter, int flags,
+                    double* lml, double* moments, double* diagG, double* trG, double* jitter_abs, int64_t* info) {
+    if (!m) return fail(MOGP_EINVAL, "mogp_exact_eval: model is null");
+    int rc;
+    if ((rc = use_device(m->ctx))) return rc;
+    if (info) *info = 0;
+    if ((rc = factorize(m, noise_var, data_var, jitter, lml, jitter_abs, info))) return rc;
+    if (!(flags & MOGP_EVAL_GRAD)) { collect_timing(m, 4); return MOGP_OK; }
+    if (!moments || !diagG || !trG) return fail(MOGP_EINVAL, "mogp_exact_eval: gradient outputs are null");
+
+    const int C = m->C, D = m->D, W = 2 + 3 * D, T = m->T, P = C * (C + 1) / 2;
+    const int64_t Npad = m->Npad;
+    // K^-1 = W^T W (lower tiles, full diagonal tiles)
+    GemmArgs g;
+    g.A = m->d_A.p; g.lda = Npad; g.a_kmajor = 1; g.B = m->d_A.p; g.ldb = Npad; g.b_kmajor = 1;
+    g.C = m->d_B.p; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
+    g.mode = GM_LAUUM; g.mt = g.nt = m->nb; g.K = (int)Npad; g.tasks = nullptr; g.ntasks = 0;
+    if ((rc = gemm_call(m, g, gemm_flops(g, nullptr)))) return rc;
+    if ((rc = mark(m, 5))) return rc;
+
+    MomentArgs ma;
+    ma.tiles = m->d_tiles.p; ma.ntiles = (int)m->tiles.size(); ma.x = m->d_x.p; ma.ldx = Npad;
+    ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C; ma.kinv = m->d_B.p; ma.ld = Npad; ma.alpha = m->d_alpha.p;
+    ma.partial = m->d_partial.p;
+    if ((rc = launch_moments(ma, m->st))) return rc;
+    if ((rc = launch_moment_reduce(m->d_partial.p, m->d_pair_start.p, P, T, W, m->d_moments.p, m->st))) return rc;
+    if ((rc = launch_diagG(m->d_B.p, Npad, m->d_alpha.p, m->d_chan_off.p, C, m->d_diagG.p, m->st))) return rc;
+    if ((rc = mark(m, 6))) return rc;
+    HIP_TRY(hipMemcpyAsync(moments, m->d_moments.p, (size_t)P * T * W * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipMemcpyAsync(diagG, m->d_diagG.p, C * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    double tr = 0.0;
+    for (int c = 0; c < C; ++c) tr += diagG[c];
+    *trG = tr;
+    m->have_Kinv = true;
+    collect_timing(m, 6);
+    return MOGP_OK;
+}
+
+int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
+                       const double* kss_diag, int64_t S, const double* Xs, int full,
+                       double* mu, double* var, int64_t* info) {
+    if (!m || !Xs || !mu || !var || !kss_diag || S <= 0) return fail(MOGP_EINVAL, "mogp_exact_predict: bad argument");
+    int rc;
+    if ((rc = use_device(m->ctx))) return rc;
+    if (info) *info = 0;
+    double lml = 0.0;
+    if ((rc = factorize(m, noise_var, data_var, jitter, &lml, nullptr, info))) return rc;
+
+    const int C = m->C, D = m->D;
+    const int64_t Npad = m->Npad;
+    SortedX ss;
+    if ((rc = sort_inputs(Xs, S, D, C, MOGP_TILE, ss))) return rc;
+    const int64_t Spad = ss.Mpad;
+    std::vector<GTile> pt;
+    build_rect_tiles(ss.off, m->sx.off, C, pt);
+    if ((rc = m->d_xs.ensure((size_t)D * Spad))) return rc;
+    if ((rc = m->d_Ksf.ensure((size_t)Spad * Npad))) return rc;
+    if ((rc = m->d_Vt.ensure((size_t)Spad * Npad))) return rc;
+    if ((rc = m->d_mu.ensure(Spad))) return rc;
+    if ((rc = m->d_var.ensure(Spad))) return rc;
+    if ((rc = m->d_kdiag.ensure(Spad))) return rc;
+    if ((rc = m->d_ptiles.ensure(pt.size()))) return rc;
+    std::vector<double> kd(Spad, 0.0);
+    for (int c = 0; c < C; ++c)
+        for (int pos = ss.off[c]; pos < ss.off[c + 1]; ++pos) kd[pos] = kss_diag[c];
+    HIP_TRY(hipMemcpyAsync(m->d_xs.p, ss.xs.data(), (size_t)D * Spad * sizeof(double), hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemcpyAsync(m->d_kdiag.p, kd.data(), Spad * sizeof(double), hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemcpyAsync(m->d_ptiles.p, pt.data(), pt.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
+    // padded rows/columns of Ksf must be zero: rows >= S and columns >= N are never written by the Gram kernel
+    HIP_TRY(hipMemsetAsync(m->d_Ksf.p, 0, (size_t)Spad * Npad * sizeof(double), m->st));
+
+    // K_sf = K(Xs, X)   (rows: test points, columns: training points; all C*C pairs, reference kernel.py:468-479 transposed)
+    GramArgs ga;
+    ga.tiles = m->d_ptiles.p; ga.xr = m->d_xs.p; ga.ldxr = Spad; ga.xc = m->d_x.p; ga.ldxc = Npad;
+    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.out = m->d_Ksf.p; ga.ldo = Npad;
+    ga.noise = nullptr; ga.dvar = nullptr; ga.jitter_abs = 0.0; ga.mirror = 0;
+    if ((rc = launch_gram(ga, (int)pt.size(), m->st))) return rc;
+    // mu = K_sf alpha
+    if ((rc = launch_gemv_rows(m->d_Ksf.p, Npad, Spad, Npad, m->d_alpha.p, m->d_mu.p, m->st))) return rc;
+    // V^T = K_sf W^T  (W lower triangular: k <= j)
+    GemmArgs g;
+    g.A = m->d_Ksf.p; g.lda = Npad; g.a_kmajor = 0; g.B = m->d_A.p; g.ldb = Npad; g.b_kmajor = 0;
+    g.C = m->d_Vt.p; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
+    g.mode = GM_KHI_J; g.mt = (int)(Spad / MOGP_TILE); g.nt = m->nb; g.K = (int)Npad; g.tasks = nullptr; g.ntasks = 0;
+    if ((rc = gemm_call(m, g, gemm_flops(g, nullptr)))) return rc;
+
+    std::vector<double> hmu(Spad);
+    HIP_TRY(hipMemcpyAsync(hmu.data(), m->d_mu.p, Spad * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    if (!full) {
+        if ((rc = launch_row_sqnorm_sub(m->d_Vt.p, Npad, Spad, Npad, m->d_kdiag.p, m->d_var.p, m->st))) return rc;
+        std::vector<double> hv(Spad);
+        HIP_TRY(hipMemcpyAsync(hv.data(), m->d_var.p, Spad * sizeof(double), hipMemcpyDeviceToHost, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));
+        for (int64_t pos = 0; pos < S; ++pos) { mu[ss.perm[pos]] = hmu[pos]; var[ss.perm[pos]] = hv[pos]; }
+        return MOGP_OK;
+    }
+    // full covariance: K_ss - V^T V   (reference gpr/model.py:476-478)
+    std::vector<GTile> st_tiles;
+    std::vector<int> ps;
+    build_sym_tiles(ss.off, C, st_tiles, ps);
+    if ((rc = m->d_Kss.ensure((size_t)Spad * Spad))) return rc;
+    if ((rc = m->d_ptiles.ensure(st_tiles.size()))) return rc;
+    HIP_TRY(hipMemsetAsync(m->d_Kss.p, 0, (size_t)Spad * Spad * sizeof(double), m->st));
+    HIP_TRY(hipMemcpyAsync(m->d_ptiles.p, st_tiles.data(), st_tiles.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
+    ga.tiles = m->d_ptiles.p; ga.xc = m->d_xs.p; ga.ldxc = Spad; ga.out = m->d_Kss.p; ga.ldo = Spad; ga.mirror = 1;
+    if ((rc = launch_gram(ga, (int)st_tiles.size(), m->st))) return rc;
+    GemmArgs c;
+    c.A = m->d_Vt.p; c.lda = Npad; c.a_kmajor = 0; c.B = m->d_Vt.p; c.ldb = Npad; c.b_kmajor = 0;
+    c.C = m->d_Kss.p; c.ldc = Spad; c.alpha = -1.0; c.beta = 1.0;
+    c.mode = GM_RECT; c.mt = c.nt = (int)(Spad / MOGP_TILE); c.K = (int)Npad; c.tasks = nullptr; c.ntasks = 0;
+    if ((rc = gemm_call(m, c, gemm_flops(c, nullptr)))) return rc;
+    std::vector<double> hc((size_t)Spad * Spad);
+    HIP_TRY(hipMemcpyAsync(hc.data(), m->d_Kss.p, hc.size() * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    for (int64_t a = 0; a < S; ++a) {
+        mu[ss.perm[a]] = hmu[a];
+        for (int64_t b = 0; b < S; ++b) var[ss.perm[a] * S + ss.perm[b]] = hc[(size_t)a * Spad + b];
+    }
+    return MOGP_OK;
+}
+
+int mogp_gram(mogp_ctx* ctx, int C, int D, int T, const double* table, int64_t M1, const double* X1,
+              int64_t M2, const double* X2, double* K_out) {
+    if (!ctx || !table || !X1 || !K_out || M1 <= 0 || T <= 0 || C <= 0 || D <= 0 || D > MOGP_MAXD)
+        return fail(MOGP_EINVAL, "mogp_gram: bad argument");
+    int rc;
+    if ((rc = use_device(ctx))) return rc;
+    const bool sym = (X2 == nullptr);
+    SortedX s1, s2;
+    if ((rc = sort_inputs(X1, M1, D, C, 1, s1))) return rc;
+    if (!sym && (rc = sort_inputs(X2, M2, D, C, 1, s2))) return rc;
+    const SortedX& sc = sym ? s1 : s2;
+    const int64_t R = s1.M, Cc = sc.M;
+    std::vector<GTile> tiles;
+    std::vector<int> ps;
+    if (sym) build_sym_tiles(s1.off, C, tiles, ps); else build_rect_tiles(s1.off, s2.off, C, tiles);
+    const int W = 2 + 3 * D;
+    DevBuf<double> dx1, dx2, dtab, dout;
+    DevBuf<GTile> dt;
+    auto cleanup = [&]() { dx1.release(); dx2.release(); dtab.release(); dout.release(); dt.release(); };
+#define G_TRY(x) do { int r__ = (x); if (r__) { cleanup(); return r__; } } while (0)
+#define G_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { cleanup(); return hip_fail(e__, #x, __FILE__, __LINE__); } } while (0)
+    G_TRY(dx1.ensure((size_t)D * s1.Mpad));
+    G_TRY(dtab.ensure((size_t)C * C * T * W));
+    G_TRY(dout.ensure((size_t)R * Cc));
+    G_TRY(dt.ensure(std::max<size_t>(tiles.size(), 1)));
+    G_HIP(hipMemcpy(dx1.p, s1.xs.data(), (size_t)D * s1.Mpad * sizeof(double), hipMemcpyHostToDevice));
+    if (!sym) {
+        G_TRY(dx2.ensure((size_t)D * s2.Mpad));
+        G_HIP(hipMemcpy(dx2.p, s2.xs.data(), (size_t)D * s2.Mpad * sizeof(double), hipMemcpyHostToDevice));
+    }
+    G_HIP(hipMemcpy(dtab.p, table, (size_t)C * C * T * W * sizeof(double), hipMemcpyHostToDevice));
+    G_HIP(hipMemcpy(dt.p, tiles.data(), tiles.size() * sizeof(GTile), hipMemcpyHostToDevice));
+    GramArgs ga;
+    ga.tiles = dt.p; ga.xr = dx1.p; ga.ldxr = s1.Mpad; ga.xc = sym ? dx1.p : dx2.p; ga.ldxc = sc.Mpad;
+    ga.table = dtab.p; ga.T = T; ga.D = D; ga.C = C; ga.out = dout.p; ga.ldo = Cc;
+    ga.noise = nullptr; ga.dvar = nullptr; ga.jitter_abs = 0.0; ga.mirror = 1;
+    G_TRY(launch_gram(ga, (int)tiles.size(), nullptr));
+    G_HIP(hipDeviceSynchronize());
+    if (s1.identity && sc.identity) {
+        G_HIP(hipMemcpy(K_out, dout.p, (size_t)R * Cc * sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+        std::vector<double> h((size_t)R * Cc);
+        G_HIP(hipMemcpy(h.data(), dout.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t a = 0; a < R; ++a)
+            for (int64_t b = 0; b < Cc; ++b) K_out[s1.perm[a] * Cc + sc.perm[b]] = h[(size_t)a * Cc + b];
+    }
+    cleanup();
+#undef G_TRY
+#undef G_HIP
+    return MOGP_OK;
+}
+
+int mogp_set_profiling(mogp_model* m, int on) {
+    if (!m) return fail(MOGP_EINVAL, "mogp_set_profiling: model is null");
+    m->profiling = on != 0;
+    return MOGP_OK;
+}
+
+int mogp_stage_ms(mogp_model* m, double* ms, int64_t* gemm_launches, double* gemm_flops) {
+    if (!m || !ms) return fail(MOGP_EINVAL, "mogp_stage_ms: bad argument");
+    for (int i = 0; i < MOGP_ST_COUNT; ++i) ms[i] = m->ms[i];
+    if (gemm_launches) *gemm_launches = m->gemm_launches;
+    if (gemm_flops) *gemm_flops = m->gemm_flops;
+    return MOGP_OK;
+}
+
+int mogp_model_fetch(mogp_model* m, int which, double* out) {
+    if (!m || !out) return fail(MOGP_EINVAL, "mogp_model_fetch: bad argument");
+    int rc;
+    if ((rc = use_device(m->ctx))) return rc;
+    const int64_t N = m->N, Npad = m->Npad;
+    if (which == 2) {
+        if (!m->have_W) return fail(MOGP_EINVAL, "mogp_model_fetch: no evaluation has completed yet");
+        std::vector<double> h(Npad);
+        HIP_TRY(hipMemcpy(h.data(), m->d_alpha.p, Npad * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t pos = 0; pos < N; ++pos) out[m->sx.perm[pos]] = h[pos];
+        return MOGP_OK;
+    }
+    if (which == 0 && !m->have_W) return fail(MOGP_EINVAL, "mogp_model_fetch: no evaluation has completed yet");
+    if (which == 1 && !m->have_Kinv) return fail(MOGP_EINVAL, "mogp_model_fetch: Kj^-1 needs an evaluation with MOGP_EVAL_GRAD");
+    if (which != 0 && which != 1) return fail(MOGP_EINVAL, "mogp_model_fetch: which must be 0, 1 or 2");
+    std::vector<double> h((size_t)Npad * Npad);
+    HIP_TRY(hipMemcpy(h.data(), which == 0 ? m->d_A.p : m->d_B.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t a = 0; a < N; ++a)
+        for (int64_t b = 0; b < N; ++b) {
+            double v;
+            if (which == 0) v = (b <= a) ? h[(size_t)a * Npad + b] : 0.0;                               // W = L^-1 (sorted order)
+            else v = (b <= a) ? h[(size_t)a * Npad + b] : h[(size_t)b * Npad + a];                        // symmetric Kj^-1
+            if (which == 0) out[a * N + b] = v;
+            else out[m->sx.perm[a] * N + m->sx.perm[b]] = v;
+        }
+    return MOGP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+// mogp_internal.h -- shared declarations of libmogp_hip.so (gfx950 only; no other target is supported).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#define MOGP_TILE 128          // linear-algebra tile edge: every dense matrix is padded to a multiple of it
+#define MOGP_GT 64             // Gram / moment tile edge (relative to channel blocks)
+#define MOGP_TC 8              // spectral terms processed per LDS chunk in the Gram / moment kernels
+#define MOGP_MAXD 8            // maximum input dimension
+
+namespace mogp {
+
+// ---- error plumbing --------------------------------------------------------------------------------
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+#define HIP_TRY(x)                                                        \
+    do {                                                                  \
+        hipError_t e__ = (x);                                             \
+        if (e__ != hipSuccess) return mogp::hip_fail(e__, #x, __FILE__, __LINE__); \
+    } while (0)
+
+// ---- Gram / moment tiles ---------------------------------------------------------------------------
+// One descriptor per 64x64 tile of one channel-pair block (never straddles a channel boundary).
+struct GTile {
+    int r0, c0;      // first row / column (global, channel-sorted order)
+    int nr, nc;      // valid rows / columns (<= MOGP_GT)
+    int pair;        // i*C + j : row channel i, column channel j
+    int flags;       // GT_* bits
+};
+enum { GT_MIRROR = 1,     // also write the transpose to (c, r)   (off-diagonal tile of the symmetric Gram)
+       GT_DIAG = 2 };     // tile sits on the matrix diagonal (r0 == c0)
+
+struct GramArgs {
+    const GTile* tiles;
+    const double* xr;      // row inputs   [D][ldxr]
+    const double* xc;      // column inputs [D][ldxc]
+    int64_t ldxr, ldxc;
+    const double* table;   // [C*C][T][W]
+    int T, D, C;
+    double* out;           // row-major, leading dimension ldo
+    int64_t ldo;
+    // diagonal augmentation (symmetric training Gram only; null -> none)
+    const double* noise;   // [C] sigma_c^2
+    const double* dvar;    // [N] per-point variance or null
+    double jitter_abs;
+    int mirror;            // write the transpose of GT_MIRROR tiles too (full symmetric Gram for Kernel.K)
+};
+
+struct MomentArgs {
+    const GTile* tiles;
+    int ntiles;
+    const double* x;       // [D][ldx]
+    int64_t ldx;
+    const double* table;
+    int T, D, C;
+    const double* kinv;    // lower triangle valid, leading dimension ld
+    int64_t ld;
+    const double* alpha;   // [N]
+    double* partial;       // [ntiles][T][W] per-tile partial moments (reduced in fixed order afterwards)
+};
+
+int launch_gram(const GramArgs& a, int ntiles, hipStream_t s);
+int launch_moments(const MomentArgs& a, hipStream_t s);
+// moments[P][T][W] += fixed-order sum of per-tile partials; tile_pair_lower[t] = p index, tiles grouped by pair
+int launch_moment_reduce(const double* partial, const int* pair_start, int npairs, int T, int W, double* out, hipStream_t s);
+// per-channel sum of G_kk = 1/2(alpha_k^2 - kinv_kk): out[c], chan_off device array [C+1]
+int launch_diagG(const double* kinv, int64_t ld, const double* alpha, const int* chan_off, int C, double* out, hipStream_t s);
+
+// ---- dense linear algebra (fp64, MFMA) -------------------------------------------------------------
+enum GemmMode { GM_RECT = 0,      // mt x nt tiles, k in [0, K)
+                GM_LOWER = 1,     // lower tiles of an mt x mt grid (ti >= tj), k in [0, K)
+                GM_LAUUM = 2,     // lower tiles, k in [ti*128, K)            (C = W^T W with W lower triangular)
+                GM_KHI_J = 3,     // RECT, k in [0, (tj+1)*128)               (B lower triangular in [j][k] layout)
+                GM_TASKS = 4 };   // explicit task list
+
+struct GemmTask {              // element offsets relative to the launch's base pointers
+    int64_t a_off, b_off, c_off;
+    int kt;                    // number of 16-wide k blocks
+    int pad;
+};
+
+struct GemmArgs {
+    const double* A; int64_t lda; int a_kmajor;   // a_kmajor 0: A[i*lda + k]   1: A[k*lda + i]
+    const double* B; int64_t ldb; int b_kmajor;   // b_kmajor 0: B[j*ldb + k]   1: B[k*ldb + j]
+    double* C; int64_t ldc;
+    double alpha, beta;                            // C = alpha * A.B^T(+layout) + beta * C
+    int mode, mt, nt, K;
+    const GemmTask* tasks; int ntasks;
+};
+int launch_gemm(const GemmArgs& a, hipStream_t s);
+double gemm_flops(const GemmArgs& a, const std::vector<GemmTask>* host_tasks);
+
+// leaf kernels on 128x128 tiles
+// factor the diagonal tile A[t] = L L^T in place (strict upper part zeroed), write sum log L_kk to logdet[t],
+// record the first non-positive pivot (1-based global index) in *info (atomicMin on a value initialised to INT64_MAX)
+int launch_potrf_tile(double* A, int64_t ld, int t, double* logdet, unsigned long long* info, hipStream_t s);
+// invd[t] = inverse of the lower-triangular diagonal tile t of A (dense 128x128, upper part zero); batch over tiles [t0, t0+nt)
+int launch_trtri_tiles(const double* A, int64_t ld, int t0, int nt, double* invd, hipStream_t s);
+// copy the batch of inverted diagonal tiles into the diagonal tiles of A
+int launch_put_diag_tiles(double* A, int64_t ld, int nt, const double* invd, hipStream_t s);
+// rows >= N of the padded matrix: identity (lower part)
+int launch_pad_identity(double* A, int64_t ld, int64_t N, int64_t Npad, hipStream_t s);
+// z = W y (W lower triangular), and partial[blk] = sum z^2 over the block's rows
+int launch_trmv_lower(const double* W, int64_t ld, int64_t n, const double* y, double* z, double* zz_partial, hipStream_t s);
+// a = W^T z
+int launch_trmv_lower_t(const double* W, int64_t ld, int64_t n, const double* z, double* a, hipStream_t s);
+// out[r] = sum_k M[r][k] * v[k]   (dense row-major rows x n)
+int launch_gemv_rows(const double* M, int64_t ld, int64_t rows, int64_t n, const double* v, double* out, hipStream_t s);
+// out[r] = base[r] - sum_k M[r][k]^2
+int launch_row_sqnorm_sub(const double* M, int64_t ld, int64_t rows, int64_t n, const double* base, double* out, hipStream_t s);
+// non-finite scan of the lower triangle: flag[0] |= 1 if NaN seen, |= 2 if Inf seen
+int launch_nonfinite_scan(const double* A, int64_t ld, int64_t n, int* flag, hipStream_t s);
+
+}  // namespace mogp

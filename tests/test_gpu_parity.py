@@ -1,0 +1,247 @@
+"""
+Parity tests proper: the HIP path, called through the C ABI, against the reference's golden vectors and the numpy
+oracle on the same seeded inputs.  Tolerances: BASELINE.json's north_star asks for <= 1e-5 relative on the log
+marginal likelihood and its gradient; most checks here are much tighter (fp64 end to end) and say so.
+Run on the GPU box:  python -m pytest tests -m gpu
+"""
+import numpy as np
+import pytest
+
+import mogptk_amd
+from mogptk_amd import gpr, synth, _lib
+from helpers import load, fixture_params, product_exact, product_kernel, load_raw, relerr
+from oracle.table_model import TableDevice, gram_from_table
+
+pytestmark = pytest.mark.gpu
+
+
+def grad_close(p, ref, tol):
+    return np.max(np.abs(p - ref)) <= tol * max(np.max(np.abs(ref)), 1e-300)
+
+
+def test_native_library_is_the_path():
+    assert _lib.lib().mogp_device_count() >= 1
+    assert "gfx950" in _lib.device_name(0)
+
+
+def test_gram_matches_reference_fixtures():
+    fx = load("kernels.npz")
+    for n in range(int(fx["ncases"])):
+        pre = "c%d_" % n
+        C, Q, D, Rq = [int(v) for v in fx[pre + "meta"]]
+        k = product_kernel(str(fx[pre + "kind"]), C, Q, D, Rq)
+        load_raw(k.parameters(), fixture_params(fx, pre))
+        X, X2 = fx[pre + "X"], fx[pre + "X2"]
+        K = k.K(X)
+        assert relerr(K, fx[pre + "K"]) < 1e-12, (n, relerr(K, fx[pre + "K"]))
+        assert np.array_equal(K, K.T)                                    # mirrored, not recomputed
+        assert relerr(k(X, X2), fx[pre + "K12"]) < 1e-12
+        assert relerr(k.K_diag(X), fx[pre + "Kdiag"]) < 1e-14
+
+
+LML = ["mosm_c3q2", "mosm_c2q3_shuf", "mosm_c3q2_d2", "mosm_c1q2", "mosm_scalarvar", "sm_c1q3", "sm_c2q2_d2",
+       "csm_c3q2", "csm_c2q2r2"]
+
+
+@pytest.mark.parametrize("name", LML)
+def test_lml_and_gradient_match_reference_autograd(name):
+    fx = load("lml_%s.npz" % name)
+    m, fp = product_exact(fx)
+    assert abs(float(m.log_marginal_likelihood()) - float(fx["lml"])) < 1e-9 * abs(float(fx["lml"]))
+    loss = m.loss()
+    assert abs(float(loss) - float(fx["loss"])) < 1e-9 * abs(float(fx["loss"]))
+    for p, f in zip(m.parameters(), fp):
+        if f["grad"] is None:
+            assert p.grad is None
+        else:
+            assert np.max(np.abs(p.grad - f["grad"])) <= 1e-7 * max(1.0, np.max(np.abs(f["grad"]))), (p._name, p.grad, f["grad"])
+
+
+@pytest.mark.parametrize("N,C,Q,D", [(300, 3, 2, 1), (517, 4, 3, 1), (260, 2, 9, 1), (200, 3, 2, 2), (129, 1, 2, 1)])
+def test_device_raw_outputs_against_numpy_model(N, C, Q, D):
+    """moments / diagG / trG / alpha / L^-1 / K^-1 of the device against the numpy restatement: ragged channel sizes,
+    N not a multiple of the 128 tile, more terms than one LDS chunk (Q=9), D=2."""
+    rng = np.random.default_rng(N)
+    sizes = rng.multinomial(N - C, np.ones(C) / C) + 1
+    X = np.concatenate([np.concatenate([np.full((s, 1), float(c)), rng.uniform(0, 30, (s, D))], axis=1) for c, s in enumerate(sizes)])
+    X = X[rng.permutation(N)]
+    y = rng.standard_normal(N)
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=D)
+    k.weight.assign(rng.uniform(0.5, 1.5, (C, Q))); k.mean.assign(rng.uniform(0.02, 0.4, (C, Q, D)))
+    k.variance.assign(rng.uniform(0.005, 0.05, (C, Q, D))); k.delay.assign(rng.normal(0, 0.3, (C, Q, D)))
+    k.phase.assign(rng.normal(0, 0.3, (C, Q)))
+    table = k._spectral_terms(D)
+    noise = rng.uniform(0.05, 0.2, C)
+    dev = _lib.ExactHandle(0, X, y, C)
+    ref = TableDevice(0, X, y, C)
+    dev.set_terms(table); ref.set_terms(table)
+    a = dev.eval(noise, 1e-8, grad=True)
+    b = ref.eval(noise, 1e-8, grad=True)
+    assert abs(a["lml"] - b["lml"]) < 1e-10 * abs(b["lml"])
+    assert abs(a["jitter_abs"] - b["jitter_abs"]) < 1e-14 * b["jitter_abs"]
+    scale = np.max(np.abs(b["moments"]))
+    assert np.max(np.abs(a["moments"] - b["moments"])) < 1e-9 * scale, np.max(np.abs(a["moments"] - b["moments"])) / scale
+    assert np.max(np.abs(a["diagG"] - b["diagG"])) < 1e-9 * np.max(np.abs(b["diagG"]))
+    assert abs(a["trG"] - b["trG"]) < 1e-9 * abs(b["trG"])
+    # matrices: K^-1 and alpha in the caller's row order
+    Kj, _ = ref._Kj(noise, 1e-8, None)
+    Kinv = np.linalg.inv(Kj)
+    assert relerr(dev.fetch(1), Kinv) < 1e-9
+    assert relerr(dev.fetch(2), Kinv @ y) < 1e-9
+    # a data_variance vector goes through the same path
+    dvar = rng.uniform(0.0, 0.1, N)
+    a2 = dev.eval(noise, 1e-8, grad=False, data_var=dvar)
+    b2 = ref.eval(noise, 1e-8, grad=False, data_var=dvar)
+    assert abs(a2["lml"] - b2["lml"]) < 1e-10 * abs(b2["lml"])
+
+
+def test_predict_matches_reference():
+    fx = load("predict.npz")
+    for n in range(int(fx["ncases"])):
+        pre = "c%d_" % n
+        m, fp = product_exact(fx, pre)
+        Xs = fx[pre + "Xs"]
+        mu, var = m.predict_f(Xs)
+        assert relerr(mu, fx[pre + "mu"]) < 1e-9 and np.max(np.abs(var - fx[pre + "var"])) < 1e-9
+        _, cov = m.predict_f(Xs, full=True)
+        assert np.max(np.abs(cov - fx[pre + "cov"])) < 1e-9
+        _, lo, up = m.predict_y(Xs, sigma=2.0)
+        assert relerr(lo, fx[pre + "lower"]) < 1e-9 and relerr(up, fx[pre + "upper"]) < 1e-9
+    k = gpr.SpectralMixtureKernel(Q=2, input_dims=1)
+    m = gpr.Exact(k, fx["so_X"], fx["so_y"], variance=0.04)
+    load_raw(m.parameters(), fixture_params(fx, "so_"))
+    assert abs(float(m.log_marginal_likelihood()) - float(fx["so_lml"])) < 1e-9
+    mu, var = m.predict_f(fx["so_Xs"])
+    assert relerr(mu, fx["so_mu"]) < 1e-9 and np.max(np.abs(var - fx["so_var"])) < 1e-9
+
+
+def test_adam_trajectory_cfg1_airline():
+    """BASELINE.json configs[0]: all 100 iterations of the reference's Adam run, loss trace and final raw parameters."""
+    fx = load("adam_cfg1.npz")
+    data = mogptk_amd.Data(fx["X"][:, 1], fx["y"][:, 0], name="airline")
+    model = mogptk_amd.SM(data, Q=3)
+    load_raw(model.gpr.parameters(), fixture_params(fx, "init_"))
+    assert abs(model.log_marginal_likelihood() - float(fx["lml0"])) < 1e-9
+    losses, _ = model.train("Adam", iters=int(fx["iters"]), lr=float(fx["lr"]))
+    assert relerr(losses, fx["losses"]) < 1e-7
+    for p, f in zip(model.gpr.parameters(), fixture_params(fx, "final_")):
+        assert np.max(np.abs(p.data - f["raw"])) < 1e-5 * max(1.0, np.max(np.abs(f["raw"]))), p._name
+    X, mu, lo, up = model.predict(fx["pred_X"], transformed=True)
+    assert relerr(mu, fx["pred_mu"]) < 1e-5 and relerr(lo, fx["pred_lower"]) < 1e-5 and relerr(up, fx["pred_upper"]) < 1e-5
+
+
+def _synth_mosm(N, C, Q):
+    X, y = synth.make_data(N, C)
+    h = synth.mosm_hypers(C, Q)
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
+    for name in ("weight", "mean", "variance", "delay", "phase"):
+        getattr(k, name).assign(h[name])
+    m = gpr.Exact(k, X, y, variance=h["scale"] ** 2)
+    m.likelihood.scale.assign(h["scale"])
+    return m
+
+
+@pytest.mark.parametrize("name", ["lml_synth2048.npz", "cfg2.npz"])
+def test_full_size_goldens(name):
+    """seed-generated inputs (mogptk_amd/synth.py), reference outputs stored: N=2048 and BASELINE.json configs[1]
+    (MOSM C=4 Q=3 N=8192).  north_star tolerance: 1e-5 relative on LML and on each gradient tensor."""
+    fx = load(name)
+    C, Q, D, Rq, N = [int(v) for v in fx["meta"]]
+    m = _synth_mosm(N, C, Q)
+    fp = fixture_params(fx)
+    for p, f in zip(m.parameters(), fp):                         # assign() round trip vs the reference's raw values
+        assert np.max(np.abs(p.data - f["raw"])) < 1e-12 * max(1.0, np.max(np.abs(f["raw"])))
+        p.data = np.array(f["raw"])
+    loss = float(m.loss())
+    assert abs(loss - float(fx["loss"])) < 1e-9 * abs(float(fx["loss"])), (loss, float(fx["loss"]))
+    for p, f in zip(m.parameters(), fp):
+        err = np.max(np.abs(p.grad - f["grad"])) / np.max(np.abs(f["grad"]))
+        assert err < 1e-5, (p._name, err)
+
+
+def test_full_size_properties_cfg2():
+    """size-independent properties at N=8192: permutation invariance of LML/gradient, directional derivative by
+    central differences, determinism across repeated evaluations."""
+    C, Q, N = 4, 3, 8192
+    m = _synth_mosm(N, C, Q)
+    l0 = float(m.loss())
+    g0 = [p.grad.copy() for p in m.parameters()]
+    assert float(m.loss()) == l0                                   # bitwise repeatable
+    for g, p in zip(g0, m.parameters()):
+        assert np.array_equal(g, p.grad)
+    # central difference along a random direction in raw space
+    rng = np.random.default_rng(7)
+    dirs = [rng.standard_normal(p.data.shape) for p in m.parameters()]
+    eps = 1e-4
+    base = [p.data.copy() for p in m.parameters()]
+    vals = []
+    for s in (+1, -1):
+        for p, b, d in zip(m.parameters(), base, dirs):
+            p.data = b + s * eps * d
+        vals.append(-float(m.log_marginal_likelihood()))
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    an = sum(float(np.sum(g * d)) for g, d in zip(g0, dirs))
+    assert abs(fd - an) < 1e-5 * abs(an), (fd, an)
+    # row permutation: same model, shuffled rows
+    X, y = synth.make_data(N, C)
+    perm = rng.permutation(N)
+    h = synth.mosm_hypers(C, Q)
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
+    for name in ("weight", "mean", "variance", "delay", "phase"):
+        getattr(k, name).assign(h[name])
+    m2 = gpr.Exact(k, X[perm], y[perm], variance=h["scale"] ** 2)
+    m2.likelihood.scale.assign(h["scale"])
+    l2 = float(m2.loss())
+    assert abs(l2 - l0) < 1e-10 * abs(l0)
+    for g, p in zip(g0, m2.parameters()):
+        assert np.max(np.abs(g - p.grad)) < 1e-8 * np.max(np.abs(g))
+
+
+def test_cfg4_predict_golden():
+    """BASELINE.json configs[3]: CSM C=4 Q=3 N=16384, predictive mean/variance at S=4096 (64 probe rows stored)."""
+    fx = load("cfg4.npz")
+    C, Q, D, Rq, N, S = [int(v) for v in fx["meta"]]
+    X, y = synth.make_data(N, C)
+    h = synth.csm_hypers(C, Q)
+    k = gpr.MixtureKernel(gpr.CrossSpectralKernel(output_dims=C, input_dims=1, Rq=1), Q)
+    for q in range(Q):
+        k[q].amplitude.assign(h["amplitude"][q]); k[q].mean.assign(h["mean"][q])
+        k[q].variance.assign(h["variance"][q]); k[q].shift.assign(h["shift"][q])
+    m = gpr.Exact(k, X, y, variance=h["scale"] ** 2)
+    m.likelihood.scale.assign(h["scale"])
+    mu, var = m.predict_f(synth.test_inputs(S, C))
+    probe = fx["probe"]
+    assert np.max(np.abs(mu[probe, 0] - fx["mu"])) < 1e-6 * np.max(np.abs(fx["mu"]))
+    assert np.max(np.abs(var[probe, 0] - fx["var"])) < 1e-6 * np.max(np.abs(fx["var"]))
+
+
+def test_cholesky_failure_raises_reference_exception():
+    X, y = synth.make_data(256, 2)
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=1, output_dims=2)
+    k.weight.assign(np.full((2, 1), 50.0)); k.mean.assign(np.full((2, 1, 1), 1e-3)); k.variance.assign(np.full((2, 1, 1), 1e-6))
+    m = gpr.Exact(k, X, y, variance=[1e-16, 1e-16], jitter=1e-15)
+    m.likelihood.scale.assign([1e-8, 1e-8])
+    with pytest.raises(mogptk_amd.CholeskyException):
+        m.loss()
+    # and the handle stays usable afterwards
+    k.weight.assign(np.full((2, 1), 1.0)); k.variance.assign(np.full((2, 1, 1), 0.05)); m.likelihood.scale.assign([0.3, 0.3])
+    assert np.isfinite(float(m.loss()))
+
+
+def test_edge_cases():
+    # one training point, one channel empty, N below / at / above a tile edge
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=1, output_dims=2)
+    k.mean.assign(np.full((2, 1, 1), 0.1))
+    for N in (1, 2, 127, 128, 129):
+        X = np.stack([np.zeros(N), np.linspace(0, 5, N)], axis=1)        # channel 1 has no data
+        y = np.sin(X[:, 1])
+        dev = _lib.ExactHandle(0, X, y, 2)
+        ref = TableDevice(0, X, y, 2)
+        t = k._spectral_terms(1)
+        dev.set_terms(t); ref.set_terms(t)
+        a = dev.eval(np.array([0.1, 0.2]), 1e-8, grad=True)
+        b = ref.eval(np.array([0.1, 0.2]), 1e-8, grad=True)
+        assert abs(a["lml"] - b["lml"]) < 1e-10 * max(1.0, abs(b["lml"])), N
+        assert np.max(np.abs(a["moments"] - b["moments"])) < 1e-9 * max(1.0, np.max(np.abs(b["moments"]))), N
+    with pytest.raises(_lib.MogpError):
+        _lib.ExactHandle(0, np.array([[2.0, 0.0]]), np.zeros(1), 2)     # channel id out of range
