@@ -108,7 +108,7 @@ int  mogp_set_profiling(mogp_model* m, int on);
 int  mogp_stage_ms(mogp_model* m, double* ms, int64_t* gemm_launches, double* gemm_flops);
 
 /* copy device-resident matrices of the last eval back (tests / CholeskyException payload):
- * which: 0 = Kj lower factor L (valid after a forward-only eval), 1 = Kj^-1 (after MOGP_EVAL_GRAD),
+ * which: 0 = W = L^-1, inverse of the lower Cholesky factor of Kj, in CHANNEL-SORTED row order (after any eval), 1 = Kj^-1 (after MOGP_EVAL_GRAD),
  *        2 = alpha (N).  Output in the caller's original row order, full N x N (symmetrised / lower-filled). */
 int  mogp_model_fetch(mogp_model* m, int which, double* out);
 
