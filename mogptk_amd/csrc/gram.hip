@@ -271,30 +271,38 @@ int launch_moments(const MomentArgs& a, hipStream_t s) {
     return 0;
 }
 
-// one workgroup per lower channel pair; thread tw sums that pair's tiles in list order (deterministic).
+// one workgroup per (lower channel pair, moment entry): 256 threads stride over that pair's tiles, then a fixed-shape
+// LDS tree -- the summation order depends only on the tile list, so results are bit-reproducible.
 // On a diagonal channel block (i == j) the moments that are odd in tau (m4 = sum g E sin, m2_d = sum g u_d E cos)
 // cancel between (a, b) and (b, a) in the full symmetric sum; the lower-triangle pass cannot see that, so they are
 // set to their exact value, zero, here.
-__global__ void k_moment_reduce(const double* __restrict__ partial, const int* __restrict__ pair_start, int TW, int W,
-                                double* __restrict__ out) {
-    const int p = blockIdx.x;
+__global__ __launch_bounds__(256) void k_moment_reduce(const double* __restrict__ partial, const int* __restrict__ pair_start,
+                                                       int TW, int W, double* __restrict__ out) {
+    const int p = blockIdx.x, tw = blockIdx.y;
     const int b = pair_start[p], e = pair_start[p + 1];
-    int i = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
-    while ((i + 1) * (i + 2) / 2 <= p) ++i;
-    while (i * (i + 1) / 2 > p) --i;
-    const bool diag = (p - i * (i + 1) / 2) == i;
-    const int D = (W - 2) / 3;
-    for (int tw = threadIdx.x; tw < TW; tw += blockDim.x) {
-        const int w = tw % W;
-        double s = 0.0;
-        for (int t = b; t < e; ++t) s += partial[(size_t)t * TW + tw];
-        if (diag && (w == 1 || (w >= 2 + D && w < 2 + 2 * D))) s = 0.0;
-        out[(size_t)p * TW + tw] = s;
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int t = b + threadIdx.x; t < e; t += 256) s += partial[(size_t)t * TW + tw];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int i = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+        while ((i + 1) * (i + 2) / 2 <= p) ++i;
+        while (i * (i + 1) / 2 > p) --i;
+        const bool diag = (p - i * (i + 1) / 2) == i;
+        const int D = (W - 2) / 3, w = tw % W;
+        double v = red[0];
+        if (diag && (w == 1 || (w >= 2 + D && w < 2 + 2 * D))) v = 0.0;
+        out[(size_t)p * TW + tw] = v;
     }
 }
 
 int launch_moment_reduce(const double* partial, const int* pair_start, int npairs, int T, int W, double* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_moment_reduce, dim3(npairs), dim3(64), 0, s, partial, pair_start, T * W, W, out);
+    hipLaunchKernelGGL(k_moment_reduce, dim3(npairs, T * W), dim3(256), 0, s, partial, pair_start, T * W, W, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -115,6 +115,8 @@ static void build_rect_tiles(const std::vector<int>& offr, const std::vector<int
 
 using namespace mogp;
 
+#define MOGP_OUTER 4      // outer Cholesky block = 4 tiles = 512 columns
+
 struct mogp_ctx {
     int device = 0;
     std::string name;
@@ -134,7 +136,9 @@ struct mogp_model {
     std::vector<GTile> tiles;
     std::vector<int> pair_start;
     std::vector<double> table;          // host copy [C*C*T*W]
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr;           // critical-path stream (high priority)
+    hipStream_t st2 = nullptr;          // bulk trailing updates (look-ahead)
+    std::vector<hipEvent_t> sync_ev;    // cross-stream dependencies of the look-ahead schedule
 
     DevBuf<double> d_x, d_y, d_A, d_B, d_invd, d_table, d_noise, d_dvar, d_logdet, d_z, d_alpha, d_zz, d_partial, d_moments, d_diagG;
     DevBuf<GTile> d_tiles;
@@ -232,7 +236,8 @@ static void build_trtri_levels(mogp_model* m) {
     }
 }
 
-static int gemm_call(mogp_model* m, const GemmArgs& g, double flops) {
+static int gemm_call(mogp_model* m, const GemmArgs& g, double flops, hipStream_t st = nullptr) {
+    if (!st) st = m->st;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (m->profiling) {
         if (m->gemm_ev_used + 2 > m->gemm_ev.size()) {
@@ -240,11 +245,11 @@ static int gemm_call(mogp_model* m, const GemmArgs& g, double flops) {
         }
         e0 = m->gemm_ev[m->gemm_ev_used++];
         e1 = m->gemm_ev[m->gemm_ev_used++];
-        HIP_TRY(hipEventRecord(e0, m->st));
+        HIP_TRY(hipEventRecord(e0, st));
     }
-    int rc = launch_gemm(g, m->st);
+    int rc = launch_gemm(g, st);
     if (rc) return rc;
-    if (m->profiling) HIP_TRY(hipEventRecord(e1, m->st));
+    if (m->profiling) HIP_TRY(hipEventRecord(e1, st));
     m->gemm_launches++;
     m->gemm_flops += flops;
     return 0;
@@ -309,31 +314,75 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     if ((rc = launch_pad_identity(m->d_A.p, Npad, N, Npad, m->st))) return rc;
     if ((rc = mark(m, 1))) return rc;
 
-    // ---- blocked right-looking Cholesky: leaf (factor + inverse) -> panel = panel * inv(Lkk)^T -> SYRK trailing update
+    // ---- two-level blocked right-looking Cholesky with look-ahead.
+    // Outer blocks of MOGP_OUTER tiles.  "chain(kb)" = for each 128-column of the block: leaf (factor + inverse) -> panel =
+    // panel * inv(Lkk)^T for ALL rows below -> update of the block's remaining columns (64x64-tile GEMMs: latency-bound).
+    // The trailing matrix gets one K = MOGP_OUTER*128 SYRK per outer block, split in two:
+    //   A(kb): the next block's columns, on the critical stream (chain(kb+1) needs them);
+    //   B(kb): everything to the right, on the bulk stream, overlapping chain(kb+1).
+    // A(kb) and B(kb-1) accumulate into the same tiles, so A(kb) waits for B(kb-1).
     const int nb = m->nb;
-    for (int k = 0; k < nb; ++k) {
-        if ((rc = launch_potrf_trtri_tile(m->d_A.p, Npad, k, m->d_invd.p, m->d_logdet.p, m->d_info.p, m->st))) return rc;
-        const int rem = nb - k - 1;
-        if (rem <= 0) break;
-        double* panel = m->d_A.p + (int64_t)(k + 1) * MOGP_TILE * Npad + (int64_t)k * MOGP_TILE;
-        GemmArgs g;
-        g.A = panel; g.lda = Npad; g.a_kmajor = 0;
-        g.B = m->d_invd.p + (int64_t)k * MOGP_TILE * MOGP_TILE; g.ldb = MOGP_TILE; g.b_kmajor = 0;
-        g.C = panel; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
-        g.mode = GM_RECT; g.mt = rem; g.nt = 1; g.K = MOGP_TILE; g.tasks = nullptr; g.ntasks = 0;
-        if ((rc = gemm_call(m, g, gemm_flops(g, nullptr)))) return rc;
-        GemmArgs u;
-        u.A = panel; u.lda = Npad; u.a_kmajor = 0; u.B = panel; u.ldb = Npad; u.b_kmajor = 0;
-        u.C = m->d_A.p + (int64_t)(k + 1) * MOGP_TILE * (Npad + 1); u.ldc = Npad; u.alpha = -1.0; u.beta = 1.0;
-        u.mode = GM_LOWER; u.mt = rem; u.nt = rem; u.K = MOGP_TILE; u.tasks = nullptr; u.ntasks = 0;
-        if ((rc = gemm_call(m, u, gemm_flops(u, nullptr)))) return rc;
+    const int nouter = (nb + MOGP_OUTER - 1) / MOGP_OUTER;
+    while ((int)m->sync_ev.size() < 2 * nouter + 2) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        m->sync_ev.push_back(e);
     }
+    int last_bulk = -1;
+    for (int kb = 0; kb < nouter; ++kb) {
+        const int k0 = kb * MOGP_OUTER, k1 = std::min(k0 + MOGP_OUTER, nb);
+        for (int k = k0; k < k1; ++k) {
+            if ((rc = launch_potrf_trtri_tile(m->d_A.p, Npad, k, m->d_invd.p, m->d_logdet.p, m->d_info.p, m->st))) return rc;
+            const int rem = nb - k - 1;
+            if (rem <= 0) break;
+            double* panel = m->d_A.p + (int64_t)(k + 1) * MOGP_TILE * Npad + (int64_t)k * MOGP_TILE;
+            GemmArgs g{};
+            g.A = panel; g.lda = Npad; g.a_kmajor = 0;
+            g.B = m->d_invd.p + (int64_t)k * MOGP_TILE * MOGP_TILE; g.ldb = MOGP_TILE; g.b_kmajor = 0;
+            g.C = panel; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
+            g.mode = GM_RECT; g.small = 1; g.mt = 2 * rem; g.nt = 1; g.K = MOGP_TILE;      // 64x128 tiles: in place
+            if ((rc = gemm_call(m, g, gemm_flops(g, nullptr)))) return rc;
+            const int inner = k1 - k - 1;            // columns k+1 .. k1-1 of this outer block
+            if (inner > 0) {
+                GemmArgs u{};
+                u.A = panel; u.lda = Npad; u.a_kmajor = 0; u.B = panel; u.ldb = Npad; u.b_kmajor = 0;
+                u.C = m->d_A.p + (int64_t)(k + 1) * MOGP_TILE * (Npad + 1); u.ldc = Npad; u.alpha = -1.0; u.beta = 1.0;
+                u.mode = GM_RECT_LOWER; u.small = 2; u.mt = 2 * rem; u.nt = 2 * inner; u.K = MOGP_TILE;
+                if ((rc = gemm_call(m, u, gemm_flops(u, nullptr)))) return rc;
+            }
+        }
+        const int rem = nb - k1;
+        if (rem <= 0) break;
+        double* blockp = m->d_A.p + (int64_t)k1 * MOGP_TILE * Npad + (int64_t)k0 * MOGP_TILE;
+        const int K = (k1 - k0) * MOGP_TILE;
+        const int na = std::min(MOGP_OUTER, rem);      // tile columns of the next outer block
+        HIP_TRY(hipEventRecord(m->sync_ev[2 * kb], m->st));                       // chain(kb) done
+        if (rem > na) {                                                           // B(kb) on the bulk stream
+            HIP_TRY(hipStreamWaitEvent(m->st2, m->sync_ev[2 * kb], 0));
+            double* bp = blockp + (int64_t)na * MOGP_TILE * Npad;
+            GemmArgs u{};
+            u.A = bp; u.lda = Npad; u.a_kmajor = 0; u.B = bp; u.ldb = Npad; u.b_kmajor = 0;
+            u.C = m->d_A.p + (int64_t)(k1 + na) * MOGP_TILE * (Npad + 1); u.ldc = Npad; u.alpha = -1.0; u.beta = 1.0;
+            u.mode = GM_LOWER; u.mt = rem - na; u.nt = rem - na; u.K = K;
+            if ((rc = gemm_call(m, u, gemm_flops(u, nullptr), m->st2))) return rc;
+        }
+        if (last_bulk >= 0) HIP_TRY(hipStreamWaitEvent(m->st, m->sync_ev[2 * last_bulk + 1], 0));   // A(kb) after B(kb-1)
+        if (rem > na) { HIP_TRY(hipEventRecord(m->sync_ev[2 * kb + 1], m->st2)); last_bulk = kb; }
+        {
+            GemmArgs u{};                                                         // A(kb): columns k1 .. k1+na-1, rows >= column
+            u.A = blockp; u.lda = Npad; u.a_kmajor = 0; u.B = blockp; u.ldb = Npad; u.b_kmajor = 0;
+            u.C = m->d_A.p + (int64_t)k1 * MOGP_TILE * (Npad + 1); u.ldc = Npad; u.alpha = -1.0; u.beta = 1.0;
+            u.mode = GM_RECT_LOWER; u.mt = rem; u.nt = na; u.K = K;
+            if ((rc = gemm_call(m, u, gemm_flops(u, nullptr)))) return rc;
+        }
+    }
+    if (last_bulk >= 0) HIP_TRY(hipStreamWaitEvent(m->st, m->sync_ev[2 * last_bulk + 1], 0));
     if ((rc = mark(m, 2))) return rc;
 
     // ---- W = L^-1, level by level (all nodes of one level in one launch)
     if ((rc = launch_put_diag_tiles(m->d_A.p, Npad, nb, m->d_invd.p, m->st))) return rc;
     for (auto& lv : m->levels) {
-        GemmArgs g;
+        GemmArgs g{};
         g.A = m->d_A.p; g.lda = Npad; g.a_kmajor = 0; g.B = m->d_A.p; g.ldb = Npad; g.b_kmajor = 1;
         g.C = m->d_B.p; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
         g.mode = GM_TASKS; g.mt = g.nt = 0; g.K = 0; g.tasks = lv.d1.p; g.ntasks = (int)lv.h1.size();
@@ -412,9 +461,15 @@ int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, c
     build_trtri_levels(m);
     const int64_t Npad = m->Npad;
     const int nchunks = (int)((Npad + 511) / 512);
+#define MOGP_OUTER_DEFINED 1
 #define TRY_RC(x) do { int r__ = (x); if (r__) { mogp_model_destroy(m); return r__; } } while (0)
 #define TRY_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { int r__ = hip_fail(e__, #x, __FILE__, __LINE__); mogp_model_destroy(m); return r__; } } while (0)
-    TRY_HIP(hipStreamCreateWithFlags(&m->st, hipStreamNonBlocking));
+    {
+        int lo = 0, hi = 0;
+        TRY_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        TRY_HIP(hipStreamCreateWithPriority(&m->st, hipStreamNonBlocking, hi));
+        TRY_HIP(hipStreamCreateWithPriority(&m->st2, hipStreamNonBlocking, lo));
+    }
     TRY_RC(m->d_x.ensure((size_t)D * Npad));
     TRY_RC(m->d_y.ensure(Npad));
     TRY_RC(m->d_A.ensure((size_t)Npad * Npad));
@@ -457,6 +512,8 @@ int mogp_model_destroy(mogp_model* m) {
     if (m->st) { hipError_t e = hipStreamSynchronize(m->st); (void)e; }
     for (auto e : m->ev) { hipError_t r = hipEventDestroy(e); (void)r; }
     for (auto e : m->gemm_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
+    for (auto e : m->sync_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
+    if (m->st2) { hipError_t e = hipStreamSynchronize(m->st2); (void)e; e = hipStreamDestroy(m->st2); (void)e; }
     for (auto& lv : m->levels) { lv.d1.release(); lv.d2.release(); }
     m->d_x.release(); m->d_y.release(); m->d_A.release(); m->d_B.release(); m->d_invd.release(); m->d_table.release();
     m->d_noise.release(); m->d_dvar.release(); m->d_logdet.release(); m->d_z.release(); m->d_alpha.release(); m->d_zz.release();
@@ -509,7 +566,7 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     const int C = m->C, D = m->D, W = 2 + 3 * D, T = m->T, P = C * (C + 1) / 2;
     const int64_t Npad = m->Npad;
     // K^-1 = W^T W (lower tiles, full diagonal tiles)
-    GemmArgs g;
+    GemmArgs g{};
     g.A = m->d_A.p; g.lda = Npad; g.a_kmajor = 1; g.B = m->d_A.p; g.ldb = Npad; g.b_kmajor = 1;
     g.C = m->d_B.p; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
     g.mode = GM_LAUUM; g.mt = g.nt = m->nb; g.K = (int)Npad; g.tasks = nullptr; g.ntasks = 0;
@@ -577,7 +634,7 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
     // mu = K_sf alpha
     if ((rc = launch_gemv_rows(m->d_Ksf.p, Npad, Spad, Npad, m->d_alpha.p, m->d_mu.p, m->st))) return rc;
     // V^T = K_sf W^T  (W lower triangular: k <= j)
-    GemmArgs g;
+    GemmArgs g{};
     g.A = m->d_Ksf.p; g.lda = Npad; g.a_kmajor = 0; g.B = m->d_A.p; g.ldb = Npad; g.b_kmajor = 0;
     g.C = m->d_Vt.p; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
     g.mode = GM_KHI_J; g.mt = (int)(Spad / MOGP_TILE); g.nt = m->nb; g.K = (int)Npad; g.tasks = nullptr; g.ntasks = 0;
@@ -603,7 +660,7 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
     HIP_TRY(hipMemcpyAsync(m->d_ptiles.p, st_tiles.data(), st_tiles.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
     ga.tiles = m->d_ptiles.p; ga.xc = m->d_xs.p; ga.ldxc = Spad; ga.out = m->d_Kss.p; ga.ldo = Spad; ga.mirror = 1;
     if ((rc = launch_gram(ga, (int)st_tiles.size(), m->st))) return rc;
-    GemmArgs c;
+    GemmArgs c{};
     c.A = m->d_Vt.p; c.lda = Npad; c.a_kmajor = 0; c.B = m->d_Vt.p; c.ldb = Npad; c.b_kmajor = 0;
     c.C = m->d_Kss.p; c.ldc = Spad; c.alpha = -1.0; c.beta = 1.0;
     c.mode = GM_RECT; c.mt = c.nt = (int)(Spad / MOGP_TILE); c.K = (int)Npad; c.tasks = nullptr; c.ntasks = 0;

@@ -73,7 +73,8 @@ enum GemmMode { GM_RECT = 0,      // mt x nt tiles, k in [0, K)
                 GM_LOWER = 1,     // lower tiles of an mt x mt grid (ti >= tj), k in [0, K)
                 GM_LAUUM = 2,     // lower tiles, k in [ti*128, K)            (C = W^T W with W lower triangular)
                 GM_KHI_J = 3,     // RECT, k in [0, (tj+1)*128)               (B lower triangular in [j][k] layout)
-                GM_TASKS = 4 };   // explicit task list
+                GM_TASKS = 4,     // explicit task list
+                GM_RECT_LOWER = 5 }; // mt x nt tiles, only tiles with ti >= tj (others exit), k in [0, K)
 
 struct GemmTask {              // element offsets relative to the launch's base pointers
     int64_t a_off, b_off, c_off;
@@ -88,6 +89,7 @@ struct GemmArgs {
     double alpha, beta;                            // C = alpha * A.B^T(+layout) + beta * C
     int mode, mt, nt, K;
     const GemmTask* tasks; int ntasks;
+    int small;                                     // 0: 128x128 tiles; 1: 64x128; 2: 64x64 (mt / nt count tiles of that shape)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 double gemm_flops(const GemmArgs& a, const std::vector<GemmTask>* host_tasks);
