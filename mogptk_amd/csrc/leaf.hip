@@ -1,25 +1,32 @@
 // leaf.hip -- Cholesky factor + inverse of one 128x128 diagonal tile, the serial critical path of the blocked
-// factorisation (one launch per tile row).  One 256-thread workgroup, the tile lives in LDS ([128][130] fp64, row
-// stride == 2 (mod 32) 8-byte units so 16x4 MFMA fragment reads are conflict-free), work is organised in 16x16
-// sub-blocks:
+// factorisation (one launch per tile row).  One 256-thread workgroup; the LOWER triangle of the tile lives in LDS as 36
+// packed 16x16 blocks (row stride 18 doubles inside a block: == 2 (mod 32) 8-byte units, so 16x4 MFMA fragment reads are
+// conflict-free).  83 KB of LDS, so the workgroup fits on a CU next to a resident 74 KB trailing-update workgroup of
+// the bulk stream (look-ahead schedule in mogp_api.hip) instead of waiting for an empty CU.
 //   POTRF  for sb = 0..7:
-//     P1  waves 0-2, one ROW per lane (the 16 diagonal-block rows + 48 panel rows per wave): right-looking Cholesky of the
-//         16x16 diagonal block where L[j][k] is broadcast with v_readlane (compile-time lane) -- the same instruction
+//     P1  waves 0-2, one ROW per lane (the 16 diagonal-block rows + 48 panel rows per wave): right-looking Cholesky of
+//         the 16x16 diagonal block where L[j][k] is broadcast with v_readlane (compile-time lane) -- the same instruction
 //         stream IS the triangular solve for the panel rows riding along in lanes 16..63
 //     P3  trailing update C_ij -= P_i P_j^T on v_mfma_f64_16x16x4_f64, blocks dealt round-robin to the 4 waves
 //   TRTRI  16x16 diagonal inverses (one column per lane), then block row i = 1..7 in place:
-//          T_j = sum_k L_ik W_kj (MFMA) -> LDS scratch -> W_ij = -W_ii T_j (MFMA)
+//          T_j = sum_k L_ik W_kj (MFMA), W_ij = -W_ii T_j (MFMA; T_j stays in registers: accumulator register r of a lane
+//          is element (4r + lane/16, lane%16), which is exactly the B-operand element of k-group r)
 // Replaces the per-tile share of torch.linalg.cholesky (reference gpr/model.py:246).
 #include "mogp_internal.h"
 
 namespace mogp {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
 
-#define LF_LD 130
-#define LF_MAT (MOGP_TILE * LF_LD)             // doubles
-#define LF_TS (7 * 256)                        // T scratch: 7 blocks of 16x16
-#define LF_LDS_BYTES ((LF_MAT + LF_TS + MOGP_TILE) * 8)
+#define LF_BS 18                               // row stride inside a 16x16 block
+#define LF_BLK (16 * LF_BS)                    // doubles per block
+#define LF_MAT (36 * LF_BLK)                   // packed lower triangle
+#define LF_LDS_BYTES ((LF_MAT + MOGP_TILE + 8) * 8)
+
+__device__ __forceinline__ int lf_blk(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * LF_BLK; }
+// element (r, c), c's block <= r's block
+__device__ __forceinline__ int lf_at(int r, int c) { return lf_blk(r >> 4, c >> 4) + (r & 15) * LF_BS + (c & 15); }
 
 __device__ __forceinline__ double readlane_d(double x, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
@@ -29,36 +36,36 @@ __device__ __forceinline__ double readlane_d(double x, int lane) {
 
 template <int K>
 struct P1Step {
-    static __device__ __forceinline__ void run(double (&a)[16], double* invdiag, int sb, int lane, int& fail) {
+    static __device__ __forceinline__ void run(double (&a)[16], double* invdiag, int sb, bool writer, int& fail) {
         const double d = readlane_d(a[K], K);
         if (!(d > 0.0) && fail < 0) fail = sb * 16 + K;
         const double rs = rsqrt(d);
         a[K] *= rs;
-        if (lane == 0) invdiag[sb * 16 + K] = rs;
+        if (writer) invdiag[sb * 16 + K] = rs;
 #pragma unroll
         for (int j = K + 1; j < 16; ++j) {
             const double ljk = readlane_d(a[K], j);
             a[j] = fma(-a[K], ljk, a[j]);
         }
-        P1Step<K + 1>::run(a, invdiag, sb, lane, fail);
+        P1Step<K + 1>::run(a, invdiag, sb, writer, fail);
     }
 };
 template <>
 struct P1Step<16> {
-    static __device__ __forceinline__ void run(double (&)[16], double*, int, int, int&) {}
+    static __device__ __forceinline__ void run(double (&)[16], double*, int, bool, int&) {}
 };
 
 __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, double* invd, double* logdet,
                                                  unsigned long long* info) {
     extern __shared__ __attribute__((aligned(16))) double lf[];
-    double* M = lf;                       // [128][LF_LD]
-    double* Ts = lf + LF_MAT;             // [7][16][16]
-    double* invdiag = Ts + LF_TS;         // [128]  1 / L_kk
+    double* M = lf;                       // 36 packed lower blocks
+    double* invdiag = lf + LF_MAT;        // [128]  1 / L_kk
+    double* red = invdiag + MOGP_TILE;    // [8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* At = A + (int64_t)t * MOGP_TILE * ld + (int64_t)t * MOGP_TILE;
+    __builtin_amdgcn_s_setprio(3);        // serial critical path: outrank co-resident trailing-update waves
 
-    // ---- load (lower 16-blocks; everything above the block diagonal is zero): 16-byte loads, 8 in flight per thread ----
-    typedef double d2_t __attribute__((ext_vector_type(2)));
+    // ---- load the lower 16-blocks: 16-byte loads, 8 in flight per thread ----
     for (int it = 0; it < 32; it += 8) {
         d2_t v[8];
 #pragma unroll
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, d
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int idx = (it + u) * 256 + tid, r = idx >> 6, c = (idx & 63) * 2;
-            *reinterpret_cast<d2_t*>(M + r * LF_LD + c) = v[u];
+            if ((c >> 4) <= (r >> 4)) *reinterpret_cast<d2_t*>(M + lf_at(r, c)) = v[u];
         }
     }
     __syncthreads();
@@ -81,15 +88,17 @@ __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, d
         // the L[j][k] broadcasts in its own registers), lanes 16-63 hold 48 panel rows: wave w covers c0+16+48w .. +47.
         const bool act = wave < 3 && (wave == 0 || c0 + 16 + 48 * wave < MOGP_TILE);
         const int R = lane < 16 ? c0 + lane : c0 + 16 + 48 * wave + (lane - 16);
+        const bool rowok = act && R < MOGP_TILE;
+        double* rowp = M + (rowok ? lf_blk(R >> 4, sb) + (R & 15) * LF_BS : 0);
         double a[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) a[c] = (act && R < MOGP_TILE) ? M[R * LF_LD + c0 + c] : 0.0;
+        for (int c = 0; c < 16; ++c) a[c] = rowok ? rowp[c] : 0.0;
         __syncthreads();          // every wave has its copy of the diagonal block before wave 0 overwrites it
         if (act) {
-            P1Step<0>::run(a, invdiag, sb, wave == 0 ? lane : 1, fail);
-            if (R < MOGP_TILE && (wave == 0 || lane >= 16)) {
+            P1Step<0>::run(a, invdiag, sb, wave == 0 && lane == 0, fail);
+            if (rowok && (wave == 0 || lane >= 16)) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) M[R * LF_LD + c0 + c] = (lane < 16 && c > lane) ? 0.0 : a[c];
+                for (int c = 0; c < 16; ++c) rowp[c] = (lane < 16 && c > lane) ? 0.0 : a[c];
             }
         }
         __syncthreads();
@@ -102,36 +111,36 @@ __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, d
             while (bi * (bi + 1) / 2 > q) --bi;
             const int bj = q - bi * (bi + 1) / 2;
             const int i = sb + 1 + bi, j = sb + 1 + bj;
-            double* Cb = M + (i * 16 + (lane >> 4)) * LF_LD + j * 16 + (lane & 15);
+            double* Cb = M + lf_blk(i, j) + (lane >> 4) * LF_BS + (lane & 15);
             d4_t acc;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = Cb[4 * r * LF_LD];
-            const double* Pa = M + (i * 16 + (lane & 15)) * LF_LD + c0 + (lane >> 4);
-            const double* Pb = M + (j * 16 + (lane & 15)) * LF_LD + c0 + (lane >> 4);
+            for (int r = 0; r < 4; ++r) acc[r] = Cb[4 * r * LF_BS];
+            const double* Pa = M + lf_blk(i, sb) + (lane & 15) * LF_BS + (lane >> 4);
+            const double* Pb = M + lf_blk(j, sb) + (lane & 15) * LF_BS + (lane >> 4);
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pa[4 * k4], Pb[4 * k4], acc, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Cb[4 * r * LF_LD] = acc[r];
+            for (int r = 0; r < 4; ++r) Cb[4 * r * LF_BS] = acc[r];
         }
         __syncthreads();
     }
 
     // ---- log-determinant share, failure report, L back to global ----
     {
-        double lg = (tid < MOGP_TILE) ? log(M[tid * LF_LD + tid]) : 0.0;
+        double lg = (tid < MOGP_TILE) ? log(M[lf_at(tid, tid)]) : 0.0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off, 64);
-        if (lane == 0) Ts[wave] = lg;
+        if (lane == 0) red[wave] = lg;
         __syncthreads();
         if (tid == 0) {
-            logdet[t] = Ts[0] + Ts[1];
+            logdet[t] = red[0] + red[1];
             if (fail >= 0) atomicMin(info, (unsigned long long)((int64_t)t * MOGP_TILE + fail + 1));
         }
-        __syncthreads();
     }
     for (int it = 0; it < 32; ++it) {
         const int idx = it * 256 + tid, r = idx >> 6, c = (idx & 63) * 2;
-        d2_t v = *reinterpret_cast<const d2_t*>(M + r * LF_LD + c);
+        d2_t v = (d2_t){0.0, 0.0};
+        if ((c >> 4) <= (r >> 4)) v = *reinterpret_cast<const d2_t*>(M + lf_at(r, c));
         if (c > r) v[0] = 0.0;
         if (c + 1 > r) v[1] = 0.0;
         *reinterpret_cast<d2_t*>(At + (int64_t)r * ld + c) = v;
@@ -139,45 +148,53 @@ __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, d
 
     // ---- TRTRI: diagonal 16x16 inverses, one column per lane (8 blocks x 16 columns = waves 0 and 1) ----
     if (tid < MOGP_TILE) {
-        const int b = tid >> 4, c = tid & 15, o = b * 16;
+        const int b = tid >> 4, c = tid & 15;
+        double* Db = M + lf_blk(b, b);
         double w[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             double s = (r == c) ? 1.0 : 0.0;
 #pragma unroll
-            for (int k = 0; k < r; ++k) s = fma(-M[(o + r) * LF_LD + o + k], w[k], s);
-            w[r] = (r < c) ? 0.0 : s * invdiag[o + r];
+            for (int k = 0; k < r; ++k) s = fma(-Db[r * LF_BS + k], w[k], s);
+            w[r] = (r < c) ? 0.0 : s * invdiag[b * 16 + r];
         }
         // all 16 lanes of a block are in one wave and every read above precedes these writes in program order
 #pragma unroll
-        for (int r = 0; r < 16; ++r) M[(o + r) * LF_LD + o + c] = w[r];
+        for (int r = 0; r < 16; ++r) Db[r * LF_BS + c] = w[r];
     }
     __syncthreads();
 
-    // ---- TRTRI: block rows 1..7 in place ----
+    // ---- TRTRI: block rows 1..7 in place.  Row i only reads row i of L and rows < i of W, so a single barrier between
+    // "all T_j of this row computed" and "W_ij written over L_ij" suffices. ----
     for (int i = 1; i < 8; ++i) {
-        for (int j = wave; j < i; j += 4) {
-            d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
-            for (int k = j; k < i; ++k) {
-                const double* La = M + (i * 16 + (lane & 15)) * LF_LD + k * 16 + (lane >> 4);
-                const double* Wb = M + (k * 16 + (lane >> 4)) * LF_LD + j * 16 + (lane & 15);
+        d4_t tacc[2];                          // this wave's T_j (j = wave, wave + 4)
 #pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(La[4 * k4], Wb[4 * k4 * LF_LD], acc, 0, 0, 0);
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = wave + 4 * jj;
+            tacc[jj] = (d4_t){0.0, 0.0, 0.0, 0.0};
+            if (j < i) {
+                for (int k = j; k < i; ++k) {
+                    const double* La = M + lf_blk(i, k) + (lane & 15) * LF_BS + (lane >> 4);
+                    const double* Wb = M + lf_blk(k, j) + (lane >> 4) * LF_BS + (lane & 15);
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4)
+                        tacc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(La[4 * k4], Wb[4 * k4 * LF_BS], tacc[jj], 0, 0, 0);
+                }
             }
-            double* Tj = Ts + j * 256 + (lane >> 4) * 16 + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Tj[4 * r * 16] = acc[r];
         }
         __syncthreads();
-        for (int j = wave; j < i; j += 4) {
-            d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
-            const double* Wa = M + (i * 16 + (lane & 15)) * LF_LD + i * 16 + (lane >> 4);
-            const double* Tb = Ts + j * 256 + (lane >> 4) * 16 + (lane & 15);
 #pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wa[4 * k4], Tb[4 * k4 * 16], acc, 0, 0, 0);
-            double* Wo = M + (i * 16 + (lane >> 4)) * LF_LD + j * 16 + (lane & 15);
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = wave + 4 * jj;
+            if (j < i) {
+                d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+                const double* Wa = M + lf_blk(i, i) + (lane & 15) * LF_BS + (lane >> 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Wo[4 * r * LF_LD] = acc[r];
+                for (int k4 = 0; k4 < 4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wa[4 * k4], tacc[jj][k4], acc, 0, 0, 0);
+                double* Wo = M + lf_blk(i, j) + (lane >> 4) * LF_BS + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Wo[4 * r * LF_BS] = acc[r];
+            }
         }
         __syncthreads();
     }
@@ -185,7 +202,8 @@ __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, d
     double* Wt = invd + (int64_t)t * MOGP_TILE * MOGP_TILE;
     for (int it = 0; it < 32; ++it) {
         const int idx = it * 256 + tid, r = idx >> 6, c = (idx & 63) * 2;
-        d2_t v = *reinterpret_cast<const d2_t*>(M + r * LF_LD + c);
+        d2_t v = (d2_t){0.0, 0.0};
+        if ((c >> 4) <= (r >> 4)) v = *reinterpret_cast<const d2_t*>(M + lf_at(r, c));
         if (c > r) v[0] = 0.0;
         if (c + 1 > r) v[1] = 0.0;
         *reinterpret_cast<d2_t*>(Wt + r * MOGP_TILE + c) = v;

@@ -76,11 +76,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     const int64_t a_step = AKM ? (int64_t)GEMM_BK * g.lda : GEMM_BK;
     const int64_t b_step = BKM ? (int64_t)GEMM_BK * g.ldb : GEMM_BK;
 
+    // beta != 0: start the accumulators at (beta/alpha) * C so the read of C overlaps the first operand loads and the
+    // epilogue is a pure store of alpha * acc.
+    const int crow = wi * (TMR / 2) + (lane >> 4), ccol = wj * (TNC / 2) + (lane & 15);
     d4_t acc[WTM][WTN];
+    if (g.beta != 0.0) {
+        const double sc = g.beta / g.alpha;
 #pragma unroll
-    for (int m = 0; m < WTM; ++m)
+        for (int m = 0; m < WTM; ++m)
 #pragma unroll
-        for (int n = 0; n < WTN; ++n) acc[m][n] = (d4_t){0.0, 0.0, 0.0, 0.0};
+            for (int n = 0; n < WTN; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[m][n][r] = sc * Cp[(int64_t)(crow + m * 16 + 4 * r) * g.ldc + ccol + n * 16];
+    } else {
+#pragma unroll
+        for (int m = 0; m < WTM; ++m)
+#pragma unroll
+            for (int n = 0; n < WTN; ++n) acc[m][n] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    }
+    if (WTM < 4) __builtin_amdgcn_s_setprio(2);      // chain (latency-bound) variants outrank co-resident bulk waves
 
     d2_t ra[NQ_A], rb[NQ_B];
     if (kt > 0) {
@@ -129,18 +143,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     }
 
     // ---- epilogue: C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg ----
-    const int crow = wi * (TMR / 2) + (lane >> 4), ccol = wj * (TNC / 2) + (lane & 15);
 #pragma unroll
     for (int m = 0; m < WTM; ++m)
 #pragma unroll
         for (int n = 0; n < WTN; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double* p = Cp + (int64_t)(crow + m * 16 + 4 * r) * g.ldc + ccol + n * 16;
-                double v = g.alpha * acc[m][n][r];
-                if (g.beta != 0.0) v = fma(g.beta, *p, v);
-                *p = v;
-            }
+            for (int r = 0; r < 4; ++r)
+                Cp[(int64_t)(crow + m * 16 + 4 * r) * g.ldc + ccol + n * 16] = g.alpha * acc[m][n][r];
 }
 
 template <int AKM, int BKM, int WTM, int WTN>

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <limits>
 #include <numeric>
 
@@ -115,7 +116,8 @@ static void build_rect_tiles(const std::vector<int>& offr, const std::vector<int
 
 using namespace mogp;
 
-#define MOGP_OUTER 4      // outer Cholesky block = 4 tiles = 512 columns
+static int g_outer = 4;    // outer Cholesky block in tiles (x128 columns); MOGP_OUTER env var overrides (tuning)
+#define MOGP_OUTER g_outer
 
 struct mogp_ctx {
     int device = 0;
@@ -321,6 +323,7 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     //   A(kb): the next block's columns, on the critical stream (chain(kb+1) needs them);
     //   B(kb): everything to the right, on the bulk stream, overlapping chain(kb+1).
     // A(kb) and B(kb-1) accumulate into the same tiles, so A(kb) waits for B(kb-1).
+    { const char* e = std::getenv("MOGP_OUTER"); if (e && std::atoi(e) > 0) g_outer = std::atoi(e); }
     const int nb = m->nb;
     const int nouter = (nb + MOGP_OUTER - 1) / MOGP_OUTER;
     while ((int)m->sync_ev.size() < 2 * nouter + 2) {
