@@ -98,6 +98,22 @@ int  mogp_exact_predict(mogp_model* m, const double* noise_var, const double* da
                         const double* kss_diag, int64_t S, const double* Xs, int full,
                         double* mu, double* var, int64_t* info);
 
+/* ---- Titsias sparse variational bound (BASELINE.json configs[4]) ------------------------------------------------ */
+/* replaces Titsias.elbo (gpr/model.py:700-724) and, with MOGP_EVAL_GRAD, the autograd backward of gpr.Model.loss():
+ *   Z: M x (1+D) inducing inputs (channel id in column 0), sigma: SCALAR noise scale (gpr/model.py:686-689),
+ *   kff_diag[C]: the kernel's K_diag value per channel (as for mogp_exact_predict).
+ *   *elbo as gpr/model.py:718-723.  Gradient outputs:
+ *   mom_uu: (C(C+1)/2) x T x MOGP_MOMENT_WIDTH(D) moments of dELBO/dKuu (symmetric double count, as mogp_exact_eval),
+ *   mom_uf: (C*C) x T x MOGP_MOMENT_WIDTH(D) moments of dELBO/dKuf, pair index i*C + j (i: inducing channel, j: data channel),
+ *   gZ: M x D  dELBO/dZ[:,1:] in the caller's row order, *trGA = trace(dELBO/dKuu_jittered) (for the relative jitter),
+ *   *dsigma = dELBO/dsigma, *jitter_abs = jitter * mean(diag Kuu). */
+int  mogp_titsias_eval(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kff_diag, int flags,
+                       double* elbo, double* mom_uu, double* mom_uf, double* gZ, double* trGA, double* dsigma,
+                       double* jitter_abs, int64_t* info);
+/* replaces Titsias.predict_f (gpr/model.py:730-765), diagonal variance: mu[S], var[S]. */
+int  mogp_titsias_predict(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kss_diag,
+                          int64_t S, const double* Xs, double* mu, double* var, int64_t* info);
+
 /* ---- measurement ------------------------------------------------------------------------------- */
 /* stage ids for mogp_stage_ms (HIP-event time of the last mogp_exact_eval on this model's stream) */
 enum { MOGP_ST_GRAM = 0, MOGP_ST_POTRF = 1, MOGP_ST_TRTRI = 2, MOGP_ST_LAUUM = 3, MOGP_ST_SOLVE = 4,

@@ -10,6 +10,6 @@ from .gpr.config import *
 from .gpr.model import CholeskyException
 from .util import *
 from .dataset import Data, DataSet, TransformBase
-from .model import Model, Exact, LoadModel
+from .model import Model, Exact, Titsias, LoadModel
 from .wrappers import MOSM, SM, CSM
 from . import gpr

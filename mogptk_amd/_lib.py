@@ -41,6 +41,10 @@ SIGNATURES = {
                                        c_dp, c_dp, c_dp, c_dp, c_dp, c_i64p]),
     "mogp_exact_predict": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.c_int64, c_dp,
                                           ctypes.c_int, c_dp, c_dp, c_i64p]),
+    "mogp_titsias_eval": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, ctypes.c_double, ctypes.c_double, c_dp, ctypes.c_int,
+                                         c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_i64p]),
+    "mogp_titsias_predict": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, ctypes.c_double, ctypes.c_double, c_dp,
+                                            ctypes.c_int64, c_dp, c_dp, c_dp, c_i64p]),
     "mogp_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "mogp_stage_ms": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i64p, c_dp]),
     "mogp_model_fetch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_dp]),
@@ -181,6 +185,34 @@ class ExactHandle:
                                         1 if full else 0, _dp(mu), _dp(var), ctypes.byref(info))
         check(code, info.value)
         return mu.reshape(-1, 1), (var if full else var.reshape(-1, 1))
+
+    def titsias_eval(self, Z, sigma, jitter, kff_diag, grad=True):
+        """Titsias bound (+ gradient outputs) through mogp_titsias_eval"""
+        Z = _f64(Z)
+        kff_diag = _f64(kff_diag)
+        M = Z.shape[0]
+        C, T, W, D = self.C, self.T, 2 + 3 * self.D, self.D
+        elbo, trGA, dsig, jit = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        info = ctypes.c_int64(0)
+        mom_uu = np.zeros((C * (C + 1) // 2, T, W)) if grad else None
+        mom_uf = np.zeros((C * C, T, W)) if grad else None
+        gZ = np.zeros((M, D)) if grad else None
+        code = lib().mogp_titsias_eval(self._h, M, _dp(Z), float(sigma), float(jitter), _dp(kff_diag),
+                                       MOGP_EVAL_GRAD if grad else 0, ctypes.byref(elbo), _dp(mom_uu), _dp(mom_uf), _dp(gZ),
+                                       ctypes.byref(trGA), ctypes.byref(dsig), ctypes.byref(jit), ctypes.byref(info))
+        check(code, info.value)
+        return dict(elbo=elbo.value, mom_uu=mom_uu, mom_uf=mom_uf, gZ=gZ, trGA=trGA.value, dsigma=dsig.value,
+                    jitter_abs=jit.value)
+
+    def titsias_predict(self, Z, sigma, jitter, Xs, kss_diag):
+        Z, Xs, kss_diag = _f64(Z), _f64(Xs), _f64(kss_diag)
+        S = Xs.shape[0]
+        mu, var = np.empty(S), np.empty(S)
+        info = ctypes.c_int64(0)
+        code = lib().mogp_titsias_predict(self._h, Z.shape[0], _dp(Z), float(sigma), float(jitter), _dp(kss_diag), S, _dp(Xs),
+                                          _dp(mu), _dp(var), ctypes.byref(info))
+        check(code, info.value)
+        return mu.reshape(-1, 1), var.reshape(-1, 1)
 
     def set_profiling(self, on=True):
         check(lib().mogp_set_profiling(self._h, 1 if on else 0))

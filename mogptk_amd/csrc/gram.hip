@@ -18,7 +18,8 @@ __device__ __forceinline__ void stage_phases(const double* __restrict__ tab, int
                                              const double (*s_xr)[MOGP_GT], const double (*s_xc)[MOGP_GT],
                                              double (*s_cu)[MOGP_GT], double (*s_su)[MOGP_GT],
                                              double (*s_cw)[MOGP_GT], double (*s_sw)[MOGP_GT],
-                                             double (*s_V)[DM], double (*s_Dl)[DM], int tid) {
+                                             double (*s_V)[DM], double (*s_Dl)[DM], int tid,
+                                             double (*s_M)[DM] = nullptr, double* s_A = nullptr) {
     for (int idx = tid; idx < nt * MOGP_GT * 2; idx += 256) {
         const int which = idx / (nt * MOGP_GT);
         const int rem = idx - which * nt * MOGP_GT;
@@ -45,6 +46,8 @@ __device__ __forceinline__ void stage_phases(const double* __restrict__ tab, int
         const double* row = tab + (size_t)(t0 + t) * W;
         s_V[t][d] = row[2 + d];
         s_Dl[t][d] = row[2 + 2 * D + d];
+        if (s_M) s_M[t][d] = row[2 + D + d];
+        if (s_A && d == 0) s_A[t] = row[0];
     }
 }
 
@@ -148,10 +151,14 @@ int launch_gram(const GramArgs& a, int ntiles, hipStream_t s) {
 
 // ---- gradient moments ---------------------------------------------------------------------------------
 // partial[tile][t][w], w = [ m0 = sum g E cos, m4 = sum g E sin, m1_d = sum g u_d^2 E cos, m2_d = sum g u_d E cos,
-//                           m3_d = sum g u_d E sin ],  g = weight * 1/2 (alpha_a alpha_b - Kinv_ab)
-// weight = 2 (symmetric double count: strictly-lower entries of diagonal channel blocks, every entry of off-diagonal
-// channel blocks -- reference kernel.py:466-467 writes k and k.T), 1 on the matrix diagonal, 0 above it.
-template <int DT>
+//                           m3_d = sum g u_d E sin ].
+// Exact mode (DENSE = false):  g = weight * 1/2 (alpha_a alpha_b - Kinv_ab), weight = 2 (symmetric double count: strictly
+// lower entries of diagonal channel blocks, every entry of off-diagonal channel blocks -- reference kernel.py:466-467
+// writes k and k.T), 1 on the matrix diagonal, 0 above it.
+// Dense mode (DENSE = true, Titsias):  g = weight * (G[a][b] + rcoef ru[a] rw[b]); weight as above when a.sym, else 1.
+// ZG: also accumulate the gradient w.r.t. the row / column INPUTS (inducing points):
+//     dK_ab/dx_a,d = sum_t A_t E [ -V_d u_d cos - 2 pi M_d sin ] = - dK_ab/dx_b,d.
+template <int DT, bool DENSE, bool ZG>
 __global__ __launch_bounds__(256) void k_moments(MomentArgs a) {
     constexpr int DM = DT > 0 ? DT : MOGP_MAXD;
     constexpr int WM = 2 + 3 * DM;
@@ -162,11 +169,14 @@ __global__ __launch_bounds__(256) void k_moments(MomentArgs a) {
     const int tid = threadIdx.x;
     const int cg = tid & 15, rg = tid >> 4;
     const int lane = tid & 63, wave = tid >> 6;
+    const double* xcol = a.xc ? a.xc : a.x;
+    const int64_t ldxc = a.xc ? a.ldxc : a.ldx;
 
     __shared__ double s_xr[DM][MOGP_GT], s_xc[DM][MOGP_GT];
     __shared__ double s_cu[MOGP_TC][MOGP_GT], s_su[MOGP_TC][MOGP_GT], s_cw[MOGP_TC][MOGP_GT], s_sw[MOGP_TC][MOGP_GT];
-    __shared__ double s_V[MOGP_TC][DM], s_Dl[MOGP_TC][DM];
+    __shared__ double s_V[MOGP_TC][DM], s_Dl[MOGP_TC][DM], s_M[MOGP_TC][DM], s_A[MOGP_TC];
     __shared__ double s_red[4][WM];
+    __shared__ double s_gr[ZG ? DM : 1][MOGP_GT], s_gc[ZG ? DM : 1][MOGP_GT];
 
     double* outp = a.partial + (size_t)blockIdx.x * a.T * W;
     bool any = false;
@@ -181,7 +191,10 @@ __global__ __launch_bounds__(256) void k_moments(MomentArgs a) {
         const int rem = idx - which * D * MOGP_GT;
         const int d = rem / MOGP_GT, p = rem - d * MOGP_GT;
         if (which == 0) s_xr[d][p] = p < tl.nr ? a.x[(size_t)d * a.ldx + tl.r0 + p] : 0.0;
-        else            s_xc[d][p] = p < tl.nc ? a.x[(size_t)d * a.ldx + tl.c0 + p] : 0.0;
+        else            s_xc[d][p] = p < tl.nc ? xcol[(size_t)d * ldxc + tl.c0 + p] : 0.0;
+    }
+    if (ZG) {
+        for (int idx = tid; idx < D * MOGP_GT; idx += 256) { s_gr[idx / MOGP_GT][idx % MOGP_GT] = 0.0; s_gc[idx / MOGP_GT][idx % MOGP_GT] = 0.0; }
     }
 
     // g for this thread's 4x4 entries
@@ -190,26 +203,39 @@ __global__ __launch_bounds__(256) void k_moments(MomentArgs a) {
     for (int m = 0; m < 4; ++m) {
         const int lr = rg * 4 + m;
         const int64_t r = tl.r0 + lr;
-        const double ar = lr < tl.nr ? a.alpha[r] : 0.0;
+        double ar = 0.0;
+        if (lr < tl.nr) ar = DENSE ? (a.ru ? a.rcoef * a.ru[r] : 0.0) : a.alpha[r];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int lc = cg * 4 + n;
             const int64_t c = tl.c0 + lc;
             double w = 0.0, v = 0.0;
             if (lr < tl.nr && lc < tl.nc) {
-                w = 2.0;
-                if (tl.flags & GT_DIAG) w = r > c ? 2.0 : (r == c ? 1.0 : 0.0);
-                const int64_t hi = r > c ? r : c, lo = r > c ? c : r;
-                v = 0.5 * (ar * a.alpha[c] - a.kinv[hi * a.ld + lo]);
+                w = (!DENSE || a.sym) ? 2.0 : 1.0;
+                if ((!DENSE || a.sym) && (tl.flags & GT_DIAG)) w = r > c ? 2.0 : (r == c ? 1.0 : 0.0);
+                if (DENSE) {
+                    const int64_t hi = (a.sym && c > r) ? c : r, lo = (a.sym && c > r) ? r : c;
+                    v = a.G[hi * a.ldg + lo] + (a.ru ? ar * a.rw[c] : 0.0);
+                } else {
+                    const int64_t hi = r > c ? r : c, lo = r > c ? c : r;
+                    v = 0.5 * (ar * a.alpha[c] - a.kinv[hi * a.ld + lo]);
+                }
             }
             g[m][n] = w * v;
         }
     }
 
+    double zr[4][DM], zc[4][DM];
+    if (ZG) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            for (int d = 0; d < D; ++d) { zr[m][d] = 0.0; zc[m][d] = 0.0; }
+    }
+
     for (int t0 = 0; t0 < a.T; t0 += MOGP_TC) {
         const int nt = min(MOGP_TC, a.T - t0);
         __syncthreads();
-        stage_phases<DM>(tab, W, D, t0, nt, true, s_xr, s_xc, s_cu, s_su, s_cw, s_sw, s_V, s_Dl, tid);
+        stage_phases<DM>(tab, W, D, t0, nt, true, s_xr, s_xc, s_cu, s_su, s_cw, s_sw, s_V, s_Dl, tid, s_M, s_A);
         __syncthreads();
         double xr[4][DM], xc[4][DM];
 #pragma unroll
@@ -243,6 +269,11 @@ __global__ __launch_bounds__(256) void k_moments(MomentArgs a) {
                         mom[2 + d] = fma(u[d] * u[d], kc, mom[2 + d]);
                         mom[2 + D + d] = fma(u[d], kc, mom[2 + D + d]);
                         mom[2 + 2 * D + d] = fma(u[d], ks, mom[2 + 2 * D + d]);
+                        if (ZG) {
+                            const double j = -s_A[t] * fma(s_V[t][d] * u[d], kc, 6.283185307179586476925286766559 * s_M[t][d] * ks);
+                            zr[m][d] += j;
+                            zc[n][d] -= j;
+                        }
                     }
                 }
             // workgroup reduction (fixed order: butterfly inside the wave, then waves 0..3)
@@ -257,18 +288,45 @@ __global__ __launch_bounds__(256) void k_moments(MomentArgs a) {
             __syncthreads();
         }
     }
+
+    if (ZG) {
+        // rows: the 16 threads of a row group (cg = 0..15) are consecutive lanes -> butterfly, then one LDS add;
+        // columns: LDS atomics; finally one global atomic per point and dimension
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            for (int d = 0; d < D; ++d) {
+                double v = zr[m][d];
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                if (cg == 0) s_gr[d][rg * 4 + m] = v;
+                atomicAdd(&s_gc[d][cg * 4 + m], zc[m][d]);
+            }
+        __syncthreads();
+        for (int idx = tid; idx < D * MOGP_GT; idx += 256) {
+            const int d = idx / MOGP_GT, p = idx - d * MOGP_GT;
+            if (a.gzr && p < tl.nr) atomicAdd(&a.gzr[(size_t)d * a.ldgz + tl.r0 + p], s_gr[d][p]);
+            if (a.gzc && p < tl.nc) atomicAdd(&a.gzc[(size_t)d * a.ldgz + tl.c0 + p], s_gc[d][p]);
+        }
+    }
+}
+
+template <bool DENSE, bool ZG>
+static int launch_moments_t(const MomentArgs& a, hipStream_t s) {
+    switch (a.D) {
+        case 1: hipLaunchKernelGGL((k_moments<1, DENSE, ZG>), dim3(a.ntiles), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_moments<2, DENSE, ZG>), dim3(a.ntiles), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((k_moments<3, DENSE, ZG>), dim3(a.ntiles), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_moments<0, DENSE, ZG>), dim3(a.ntiles), dim3(256), 0, s, a); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int launch_moments(const MomentArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return 0;
-    switch (a.D) {
-        case 1: hipLaunchKernelGGL(k_moments<1>, dim3(a.ntiles), dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(k_moments<2>, dim3(a.ntiles), dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(k_moments<3>, dim3(a.ntiles), dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(k_moments<0>, dim3(a.ntiles), dim3(256), 0, s, a); break;
-    }
-    HIP_TRY(hipGetLastError());
-    return 0;
+    if (a.G == nullptr) return launch_moments_t<false, false>(a, s);
+    if (a.gzr || a.gzc) return launch_moments_t<true, true>(a, s);
+    return launch_moments_t<true, false>(a, s);
 }
 
 // one workgroup per (lower channel pair, moment entry): 256 threads stride over that pair's tiles, then a fixed-shape
@@ -277,7 +335,7 @@ int launch_moments(const MomentArgs& a, hipStream_t s) {
 // cancel between (a, b) and (b, a) in the full symmetric sum; the lower-triangle pass cannot see that, so they are
 // set to their exact value, zero, here.
 __global__ __launch_bounds__(256) void k_moment_reduce(const double* __restrict__ partial, const int* __restrict__ pair_start,
-                                                       int TW, int W, double* __restrict__ out) {
+                                                       int TW, int W, int lower_pairs, double* __restrict__ out) {
     const int p = blockIdx.x, tw = blockIdx.y;
     const int b = pair_start[p], e = pair_start[p + 1];
     __shared__ double red[256];
@@ -293,7 +351,7 @@ __global__ __launch_bounds__(256) void k_moment_reduce(const double* __restrict_
         int i = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
         while ((i + 1) * (i + 2) / 2 <= p) ++i;
         while (i * (i + 1) / 2 > p) --i;
-        const bool diag = (p - i * (i + 1) / 2) == i;
+        const bool diag = lower_pairs && (p - i * (i + 1) / 2) == i;
         const int D = (W - 2) / 3, w = tw % W;
         double v = red[0];
         if (diag && (w == 1 || (w >= 2 + D && w < 2 + 2 * D))) v = 0.0;
@@ -301,8 +359,8 @@ __global__ __launch_bounds__(256) void k_moment_reduce(const double* __restrict_
     }
 }
 
-int launch_moment_reduce(const double* partial, const int* pair_start, int npairs, int T, int W, double* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_moment_reduce, dim3(npairs, T * W), dim3(256), 0, s, partial, pair_start, T * W, W, out);
+int launch_moment_reduce(const double* partial, const int* pair_start, int npairs, int T, int W, double* out, hipStream_t s, int lower_pairs) {
+    hipLaunchKernelGGL(k_moment_reduce, dim3(npairs, T * W), dim3(256), 0, s, partial, pair_start, T * W, W, lower_pairs, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }

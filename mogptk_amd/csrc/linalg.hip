@@ -55,12 +55,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
         Ap = g.A + t.a_off; Bp = g.B + t.b_off; Cp = g.C + t.c_off; kt = t.kt;
     } else {
         int ti, tj;
-        if (g.mode == GM_RECT || g.mode == GM_KHI_J || g.mode == GM_RECT_LOWER) { ti = blockIdx.x / g.nt; tj = blockIdx.x - ti * g.nt; }
-        else { ti = tri_row(blockIdx.x); tj = blockIdx.x - ti * (ti + 1) / 2; }
+        if (g.mode == GM_LOWER || g.mode == GM_LAUUM) { ti = tri_row(blockIdx.x); tj = blockIdx.x - ti * (ti + 1) / 2; }
+        else { ti = blockIdx.x / g.nt; tj = blockIdx.x - ti * g.nt; }
         if (g.mode == GM_RECT_LOWER && (ti + 1) * TMR <= tj * TNC) return;        // tile entirely above the diagonal
         int64_t k0 = 0, k1 = g.K;
-        if (g.mode == GM_LAUUM) k0 = (int64_t)ti * TMR;
+        if (g.mode == GM_LAUUM || g.mode == GM_KLO_I) k0 = (int64_t)ti * TMR;
+        if (g.mode == GM_KLO_J) k0 = (int64_t)tj * TNC;
         if (g.mode == GM_KHI_J) k1 = min((int64_t)g.K, (int64_t)(tj + 1) * TNC);
+        if (g.mode == GM_KHI_I) k1 = min((int64_t)g.K, (int64_t)(ti + 1) * TMR);
         kt = (int)((k1 - k0) / GEMM_BK);
         Ap = g.A + (AKM ? k0 * g.lda + (int64_t)ti * TMR : (int64_t)ti * TMR * g.lda + k0);
         Bp = g.B + (BKM ? k0 * g.ldb + (int64_t)tj * TNC : (int64_t)tj * TNC * g.ldb + k0);
@@ -169,9 +171,9 @@ static int launch_gemm_t(const GemmArgs& a, int grid, hipStream_t s) {
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
     int grid;
     switch (a.mode) {
-        case GM_RECT: case GM_KHI_J: case GM_RECT_LOWER: grid = a.mt * a.nt; break;
         case GM_LOWER: case GM_LAUUM: grid = a.mt * (a.mt + 1) / 2; break;
-        default: grid = a.ntasks; break;
+        case GM_TASKS: grid = a.ntasks; break;
+        default: grid = a.mt * a.nt; break;
     }
     if (grid <= 0) return 0;
     const int v = (a.a_kmajor ? 2 : 0) | (a.b_kmajor ? 1 : 0);
@@ -200,6 +202,9 @@ double gemm_flops(const GemmArgs& a, const std::vector<GemmTask>* host_tasks) {
         case GM_RECT_LOWER: for (int tj = 0; tj < a.nt; ++tj) for (int ti = 0; ti < a.mt; ++ti) if ((ti + 1) * TM > tj * TN) k += a.K; break;
         case GM_LOWER: k = (double)a.mt * (a.mt + 1) / 2 * a.K; break;
         case GM_LAUUM: for (int ti = 0; ti < a.mt; ++ti) k += (double)(ti + 1) * (a.K - ti * TM); break;
+        case GM_KHI_I: for (int ti = 0; ti < a.mt; ++ti) k += (double)a.nt * ((ti + 1) * TM < a.K ? (ti + 1) * TM : a.K); break;
+        case GM_KLO_J: for (int tj = 0; tj < a.nt; ++tj) k += (double)a.mt * (a.K - tj * TN); break;
+        case GM_KLO_I: for (int ti = 0; ti < a.mt; ++ti) k += (double)a.nt * (a.K - ti * TM); break;
         case GM_KHI_J: for (int tj = 0; tj < a.nt; ++tj) k += (double)a.mt * ((tj + 1) * TM < a.K ? (tj + 1) * TM : a.K); break;
         default: if (host_tasks) for (const auto& t : *host_tasks) k += (double)t.kt * GEMM_BK; break;
     }
@@ -322,6 +327,94 @@ __global__ __launch_bounds__(256) void k_row_sqnorm_sub(const double* __restrict
 }
 int launch_row_sqnorm_sub(const double* M, int64_t ld, int64_t rows, int64_t n, const double* base, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_row_sqnorm_sub, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, M, ld, rows, n, base, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+__global__ void k_add_diag(double* A, int64_t ld, int64_t n, double val) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) A[i * ld + i] += val;
+}
+int launch_add_diag(double* A, int64_t ld, int64_t n, double val, hipStream_t s) {
+    hipLaunchKernelGGL(k_add_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A, ld, n, val);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// upper <- lower^T, 64x64 tiles through LDS (one workgroup per strictly-lower or diagonal tile)
+__global__ __launch_bounds__(256) void k_symmetrize(double* A, int64_t ld) {
+    __shared__ double t[64][65];
+    const int ti = tri_row(blockIdx.x), tj = blockIdx.x - ti * (ti + 1) / 2;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) t[r][tx] = A[(int64_t)(ti * 64 + r) * ld + tj * 64 + tx];
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int64_t gr = tj * 64 + r, gc = ti * 64 + tx;
+        if (gc > gr) A[gr * ld + gc] = t[tx][r];
+    }
+}
+int launch_symmetrize(double* A, int64_t ld, int64_t n, hipStream_t s) {
+    const int nt = (int)(n / 64);
+    hipLaunchKernelGGL(k_symmetrize, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, A, ld);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+__global__ void k_combine(double* out, const double* P, const double* Q, int64_t ld, int64_t n, double ca, double cp, double cq) {
+    const int64_t r = blockIdx.x;
+    for (int64_t c = threadIdx.x; c < n; c += blockDim.x) {
+        double v = (r == c ? ca : 0.0) - cp * P[r * ld + c];
+        if (Q) v -= cq * Q[r * ld + c];
+        out[r * ld + c] = v;
+    }
+}
+int launch_combine(double* out, const double* P, const double* Q, int64_t ld, int64_t n, double ca, double cp, double cq, hipStream_t s) {
+    hipLaunchKernelGGL(k_combine, dim3((unsigned)n), dim3(256), 0, s, out, P, Q, ld, n, ca, cp, cq);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// column reductions of a dense rows x n matrix: partial over row chunks of 256, then a fixed-order sum
+__global__ __launch_bounds__(256) void k_gemv_cols_part(const double* __restrict__ M, int64_t ld, int64_t rows, int64_t n,
+                                                        const double* __restrict__ v, double* __restrict__ part) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int64_t r0 = (int64_t)blockIdx.y * 256, r1 = min(rows, r0 + 256);
+    double s = 0.0;
+    if (v) { for (int64_t i = r0; i < r1; ++i) s = fma(M[i * ld + j], v[i], s); }
+    else   { for (int64_t i = r0; i < r1; ++i) { const double x = M[i * ld + j]; s = fma(x, x, s); } }
+    part[(int64_t)blockIdx.y * n + j] = s;
+}
+__global__ void k_sum_parts(const double* __restrict__ part, int64_t n, int nparts, double* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double s = 0.0;
+    for (int c = 0; c < nparts; ++c) s += part[(int64_t)c * n + j];
+    out[j] = s;
+}
+int launch_gemv_cols(const double* M, int64_t ld, int64_t rows, int64_t n, const double* v, double* out, double* scratch, hipStream_t s) {
+    const int nparts = (int)((rows + 255) / 256);       // scratch: nparts * n doubles
+    hipLaunchKernelGGL(k_gemv_cols_part, dim3((unsigned)((n + 255) / 256), (unsigned)nparts), dim3(256), 0, s, M, ld, rows, n, v, scratch);
+    hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scratch, n, nparts, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+__global__ void k_get_diag(const double* A, int64_t ld, int64_t n, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = A[i * ld + i];
+}
+int launch_get_diag(const double* A, int64_t ld, int64_t n, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_get_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A, ld, n, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+__global__ void k_axpby(int64_t n, double a, const double* x, double b, const double* y, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a * x[i] + b * y[i];
+}
+int launch_axpby(int64_t n, double a, const double* x, double b, const double* y, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_axpby, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, a, x, b, y, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -1,8 +1,7 @@
 // mogp_api.hip -- C ABI of libmogp_hip.so (see include/mogp_hip.h) and the per-evaluation orchestration:
 //   Gram (lower tiles, noise + jitter fused on the diagonal) -> blocked Cholesky -> level-batched triangular inverse
 //   -> alpha / log-det -> LAUUM (K^-1) -> gradient-moment pass -> a few hundred doubles back to the host.
-#include "../../include/mogp_hip.h"
-#include "mogp_internal.h"
+#include "mogp_model.h"
 
 #include <algorithm>
 #include <cmath>
@@ -21,33 +20,9 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 }
 int launch_potrf_trtri_tile(double* A, int64_t ld, int t, double* invd, double* logdet, unsigned long long* info, hipStream_t s);
 
-static int fail(int code, const std::string& msg) { g_err = msg; return code; }
-static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
-template <typename T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    int ensure(size_t count) {
-        if (count <= n) return 0;
-        if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; n = 0; }
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
-        n = count;
-        return 0;
-    }
-    void release() { if (p) { hipError_t e = hipFree(p); (void)e; } p = nullptr; n = 0; }
-};
-
-// channel-sorted view of an input matrix X (M x (1+D)): stable sort by channel id
-struct SortedX {
-    int64_t M = 0, Mpad = 0;
-    std::vector<int64_t> perm;        // sorted position -> original row
-    std::vector<int> off;             // [C+1]
-    std::vector<double> xs;           // [D][Mpad]
-    bool identity = true;
-};
-
-static int sort_inputs(const double* X, int64_t M, int D, int C, int64_t pad_to, SortedX& o) {
+int sort_inputs(const double* X, int64_t M, int D, int C, int64_t pad_to, SortedX& o) {
     o.M = M;
     o.Mpad = round_up(std::max<int64_t>(M, 1), pad_to);
     o.perm.resize(M);
@@ -75,7 +50,7 @@ static int sort_inputs(const double* X, int64_t M, int D, int C, int64_t pad_to,
 }
 
 // tiles of the symmetric Gram (lower channel pairs, lower tiles inside diagonal channel blocks), grouped by pair
-static void build_sym_tiles(const std::vector<int>& off, int C, std::vector<GTile>& tiles, std::vector<int>& pair_start) {
+void build_sym_tiles(const std::vector<int>& off, int C, std::vector<GTile>& tiles, std::vector<int>& pair_start) {
     tiles.clear();
     pair_start.assign(1, 0);
     for (int i = 0; i < C; ++i)
@@ -95,8 +70,10 @@ static void build_sym_tiles(const std::vector<int>& off, int C, std::vector<GTil
         }
 }
 
-static void build_rect_tiles(const std::vector<int>& offr, const std::vector<int>& offc, int C, std::vector<GTile>& tiles) {
+void build_rect_tiles(const std::vector<int>& offr, const std::vector<int>& offc, int C, std::vector<GTile>& tiles,
+                      std::vector<int>* pair_start) {
     tiles.clear();
+    if (pair_start) pair_start->assign(1, 0);
     for (int i = 0; i < C; ++i)
         for (int j = 0; j < C; ++j) {
             const int ni = offr[i + 1] - offr[i], nj = offc[j + 1] - offc[j];
@@ -109,6 +86,7 @@ static void build_rect_tiles(const std::vector<int>& offr, const std::vector<int
                     t.flags = 0;
                     tiles.push_back(t);
                 }
+            if (pair_start) pair_start->push_back((int)tiles.size());
         }
 }
 
@@ -119,51 +97,7 @@ using namespace mogp;
 static int g_outer = 4;    // outer Cholesky block in tiles (x128 columns); MOGP_OUTER env var overrides (tuning)
 #define MOGP_OUTER g_outer
 
-struct mogp_ctx {
-    int device = 0;
-    std::string name;
-};
-
-struct TrtriLevel {
-    std::vector<GemmTask> h1, h2;
-    DevBuf<GemmTask> d1, d2;
-    double flops1 = 0, flops2 = 0;
-};
-
-struct mogp_model {
-    mogp_ctx* ctx = nullptr;
-    int64_t N = 0, Npad = 0;
-    int nb = 0, D = 0, C = 0, T = 0;
-    SortedX sx;
-    std::vector<GTile> tiles;
-    std::vector<int> pair_start;
-    std::vector<double> table;          // host copy [C*C*T*W]
-    hipStream_t st = nullptr;           // critical-path stream (high priority)
-    hipStream_t st2 = nullptr;          // bulk trailing updates (look-ahead)
-    std::vector<hipEvent_t> sync_ev;    // cross-stream dependencies of the look-ahead schedule
-
-    DevBuf<double> d_x, d_y, d_A, d_B, d_invd, d_table, d_noise, d_dvar, d_logdet, d_z, d_alpha, d_zz, d_partial, d_moments, d_diagG;
-    DevBuf<GTile> d_tiles;
-    DevBuf<int> d_pair_start, d_chan_off, d_flag;
-    DevBuf<unsigned long long> d_info;
-    std::vector<TrtriLevel> levels;
-
-    // prediction workspaces
-    DevBuf<double> d_xs, d_Ksf, d_Vt, d_mu, d_var, d_kdiag, d_Kss;
-    DevBuf<GTile> d_ptiles;
-
-    // profiling
-    bool profiling = false;
-    std::vector<hipEvent_t> ev;          // stage boundaries
-    std::vector<hipEvent_t> gemm_ev;     // pairs around GEMM launches
-    size_t gemm_ev_used = 0;
-    double ms[MOGP_ST_COUNT] = {0};
-    int64_t gemm_launches = 0;
-    double gemm_flops = 0.0;
-    bool have_W = false, have_Kinv = false;
-};
-
-static int use_device(mogp_ctx* c) { HIP_TRY(hipSetDevice(c->device)); return 0; }
+namespace mogp { int use_device(mogp_ctx* c) { HIP_TRY(hipSetDevice(c->device)); return 0; } }
 
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" {
@@ -204,10 +138,10 @@ int mogp_ctx_device_name(mogp_ctx* ctx, char* buf, int buflen) {
 // ---- TRTRI level tasks ------------------------------------------------------------------------------------------
 // Bottom-up pairing of tile ranges: at level l (block size s = 2^(l-1) tiles) node b owns tiles [2sb, 2sb+2s); its left
 // half [lo, mid) and right half [mid, hi) are already inverted, and  W21 = -W22 * (L21 * W11)  fills the off-diagonal part.
-static void build_trtri_levels(mogp_model* m) {
-    const int nb = m->nb;
-    const int64_t ld = m->Npad;
-    m->levels.clear();
+namespace mogp { void build_trtri_levels(Spd& w) {
+    const int nb = w.nb;
+    const int64_t ld = w.Npad;
+    w.levels.clear();
     for (int s = 1; s < nb; s *= 2) {
         TrtriLevel lv;
         for (int lo = 0; lo < nb; lo += 2 * s) {
@@ -234,11 +168,12 @@ static void build_trtri_levels(mogp_model* m) {
         std::stable_sort(lv.h2.begin(), lv.h2.end(), by_k);
         for (auto& t : lv.h1) lv.flops1 += 2.0 * MOGP_TILE * MOGP_TILE * 16.0 * t.kt;
         for (auto& t : lv.h2) lv.flops2 += 2.0 * MOGP_TILE * MOGP_TILE * 16.0 * t.kt;
-        m->levels.push_back(std::move(lv));
+        w.levels.push_back(std::move(lv));
     }
 }
+}  // namespace mogp
 
-static int gemm_call(mogp_model* m, const GemmArgs& g, double flops, hipStream_t st = nullptr) {
+namespace mogp { int gemm_call(mogp_model* m, const GemmArgs& g, double flops, hipStream_t st) {
     if (!st) st = m->st;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (m->profiling) {
@@ -256,16 +191,142 @@ static int gemm_call(mogp_model* m, const GemmArgs& g, double flops, hipStream_t
     m->gemm_flops += flops;
     return 0;
 }
+}  // namespace mogp
 
-static int mark(mogp_model* m, int idx) {
+namespace mogp { int mark(mogp_model* m, int idx) {
     if (!m->profiling) return 0;
     while ((int)m->ev.size() <= idx) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); m->ev.push_back(e); }
     HIP_TRY(hipEventRecord(m->ev[idx], m->st));
     return 0;
 }
+}  // namespace mogp
+
+// Cholesky of w.A (lower) in place; w.invd gets the inverses of the diagonal 128-tiles, w.logdet the per-tile sums of
+// log L_kk; a non-positive pivot is reported through m->d_info (atomicMin of the 1-based index).
+namespace mogp { int spd_potrf(mogp_model* m, Spd& w) {
+    int rc;
+    // ---- two-level blocked right-looking Cholesky with look-ahead.
+    // Outer blocks of MOGP_OUTER tiles.  "chain(kb)" = for each 128-column of the block: leaf (factor + inverse) -> panel =
+    // panel * inv(Lkk)^T for ALL rows below -> update of the block's remaining columns (64x64-tile GEMMs: latency-bound).
+    // The trailing matrix gets one K = MOGP_OUTER*128 SYRK per outer block, split in two:
+    //   A(kb): the next block's columns, on the critical stream (chain(kb+1) needs them);
+    //   B(kb): everything to the right, on the bulk stream, overlapping chain(kb+1).
+    // A(kb) and B(kb-1) accumulate into the same tiles, so A(kb) waits for B(kb-1).
+    { const char* e = std::getenv("MOGP_OUTER"); if (e && std::atoi(e) > 0) g_outer = std::atoi(e); }
+    const int nb = w.nb;
+    const int nouter = (nb + MOGP_OUTER - 1) / MOGP_OUTER;
+    while ((int)w.sync_ev.size() < 2 * nouter + 2) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        w.sync_ev.push_back(e);
+    }
+    int last_bulk = -1;
+    for (int kb = 0; kb < nouter; ++kb) {
+        const int k0 = kb * MOGP_OUTER, k1 = std::min(k0 + MOGP_OUTER, nb);
+        for (int k = k0; k < k1; ++k) {
+            if ((rc = launch_potrf_trtri_tile(w.A.p, w.Npad, k, w.invd.p, w.logdet.p, m->d_info.p, m->st))) return rc;
+            const int rem = nb - k - 1;
+            if (rem <= 0) break;
+            double* panel = w.A.p + (int64_t)(k + 1) * MOGP_TILE * w.Npad + (int64_t)k * MOGP_TILE;
+            GemmArgs g{};
+            g.A = panel; g.lda = w.Npad; g.a_kmajor = 0;
+            g.B = w.invd.p + (int64_t)k * MOGP_TILE * MOGP_TILE; g.ldb = MOGP_TILE; g.b_kmajor = 0;
+            g.C = panel; g.ldc = w.Npad; g.alpha = 1.0; g.beta = 0.0;
+            g.mode = GM_RECT; g.small = 1; g.mt = 2 * rem; g.nt = 1; g.K = MOGP_TILE;      // 64x128 tiles: in place
+            if ((rc = gemm_call(m, g, gemm_flops(g, nullptr)))) return rc;
+            const int inner = k1 - k - 1;            // columns k+1 .. k1-1 of this outer block
+            if (inner > 0) {
+                GemmArgs u{};
+                u.A = panel; u.lda = w.Npad; u.a_kmajor = 0; u.B = panel; u.ldb = w.Npad; u.b_kmajor = 0;
+                u.C = w.A.p + (int64_t)(k + 1) * MOGP_TILE * (w.Npad + 1); u.ldc = w.Npad; u.alpha = -1.0; u.beta = 1.0;
+                u.mode = GM_RECT_LOWER; u.small = 2; u.mt = 2 * rem; u.nt = 2 * inner; u.K = MOGP_TILE;
+                if ((rc = gemm_call(m, u, gemm_flops(u, nullptr)))) return rc;
+            }
+        }
+        const int rem = nb - k1;
+        if (rem <= 0) break;
+        double* blockp = w.A.p + (int64_t)k1 * MOGP_TILE * w.Npad + (int64_t)k0 * MOGP_TILE;
+        const int K = (k1 - k0) * MOGP_TILE;
+        const int na = std::min(MOGP_OUTER, rem);      // tile columns of the next outer block
+        HIP_TRY(hipEventRecord(w.sync_ev[2 * kb], m->st));                       // chain(kb) done
+        if (rem > na) {                                                           // B(kb) on the bulk stream
+            HIP_TRY(hipStreamWaitEvent(m->st2, w.sync_ev[2 * kb], 0));
+            double* bp = blockp + (int64_t)na * MOGP_TILE * w.Npad;
+            GemmArgs u{};
+            u.A = bp; u.lda = w.Npad; u.a_kmajor = 0; u.B = bp; u.ldb = w.Npad; u.b_kmajor = 0;
+            u.C = w.A.p + (int64_t)(k1 + na) * MOGP_TILE * (w.Npad + 1); u.ldc = w.Npad; u.alpha = -1.0; u.beta = 1.0;
+            u.mode = GM_LOWER; u.mt = rem - na; u.nt = rem - na; u.K = K;
+            if ((rc = gemm_call(m, u, gemm_flops(u, nullptr), m->st2))) return rc;
+        }
+        if (last_bulk >= 0) HIP_TRY(hipStreamWaitEvent(m->st, w.sync_ev[2 * last_bulk + 1], 0));   // A(kb) after B(kb-1)
+        if (rem > na) { HIP_TRY(hipEventRecord(w.sync_ev[2 * kb + 1], m->st2)); last_bulk = kb; }
+        {
+            GemmArgs u{};                                                         // A(kb): columns k1 .. k1+na-1, rows >= column
+            u.A = blockp; u.lda = w.Npad; u.a_kmajor = 0; u.B = blockp; u.ldb = w.Npad; u.b_kmajor = 0;
+            u.C = w.A.p + (int64_t)k1 * MOGP_TILE * (w.Npad + 1); u.ldc = w.Npad; u.alpha = -1.0; u.beta = 1.0;
+            u.mode = GM_RECT_LOWER; u.mt = rem; u.nt = na; u.K = K;
+            if ((rc = gemm_call(m, u, gemm_flops(u, nullptr)))) return rc;
+        }
+    }
+    if (last_bulk >= 0) HIP_TRY(hipStreamWaitEvent(m->st, w.sync_ev[2 * last_bulk + 1], 0));
+    return 0;
+}
+}  // namespace mogp
+
+// w.A: L -> W = L^-1 (lower), level-batched; uses w.B as scratch
+namespace mogp { int spd_trtri(mogp_model* m, Spd& w) {
+    int rc;
+    const int nb = w.nb;
+    // ---- W = L^-1, level by level (all nodes of one level in one launch)
+    if ((rc = launch_put_diag_tiles(w.A.p, w.Npad, nb, w.invd.p, m->st))) return rc;
+    for (auto& lv : w.levels) {
+        GemmArgs g{};
+        g.A = w.A.p; g.lda = w.Npad; g.a_kmajor = 0; g.B = w.A.p; g.ldb = w.Npad; g.b_kmajor = 1;
+        g.C = w.B.p; g.ldc = w.Npad; g.alpha = 1.0; g.beta = 0.0;
+        g.mode = GM_TASKS; g.mt = g.nt = 0; g.K = 0; g.tasks = lv.d1.p; g.ntasks = (int)lv.h1.size();
+        if ((rc = gemm_call(m, g, lv.flops1))) return rc;
+        g.B = w.B.p; g.C = w.A.p; g.alpha = -1.0; g.tasks = lv.d2.p; g.ntasks = (int)lv.h2.size();
+        if ((rc = gemm_call(m, g, lv.flops2))) return rc;
+    }
+    return 0;
+}
+}  // namespace mogp
+
+// w.B (lower tiles, full diagonal tiles) = W^T W with W = w.A lower triangular: ONE LAUUM-mode GEMM launch
+namespace mogp { int spd_lauum(mogp_model* m, Spd& w) {
+    GemmArgs g{};
+    g.A = w.A.p; g.lda = w.Npad; g.a_kmajor = 1; g.B = w.A.p; g.ldb = w.Npad; g.b_kmajor = 1;
+    g.C = w.B.p; g.ldc = w.Npad; g.alpha = 1.0; g.beta = 0.0;
+    g.mode = GM_LAUUM; g.mt = g.nt = w.nb; g.K = (int)w.Npad;
+    return gemm_call(m, g, gemm_flops(g, nullptr));
+}
+}  // namespace mogp
+
+namespace mogp { int spd_alloc(Spd& w, int64_t Npad) {
+    if (w.Npad == Npad) return 0;
+    w.release();
+    w.Npad = Npad; w.nb = (int)(Npad / MOGP_TILE);
+    int rc;
+    if ((rc = w.A.ensure((size_t)Npad * Npad))) return rc;
+    if ((rc = w.B.ensure((size_t)Npad * Npad))) return rc;
+    if ((rc = w.invd.ensure((size_t)w.nb * MOGP_TILE * MOGP_TILE))) return rc;
+    if ((rc = w.logdet.ensure(w.nb))) return rc;
+    build_trtri_levels(w);
+    for (auto& lv : w.levels) {
+        if ((rc = lv.d1.ensure(std::max<size_t>(lv.h1.size(), 1)))) return rc;
+        if ((rc = lv.d2.ensure(std::max<size_t>(lv.h2.size(), 1)))) return rc;
+        HIP_TRY(hipMemcpy(lv.d1.p, lv.h1.data(), lv.h1.size() * sizeof(GemmTask), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(lv.d2.p, lv.h2.data(), lv.h2.size() * sizeof(GemmTask), hipMemcpyHostToDevice));
+    }
+    // nothing ever writes above the block diagonal of A / B; keep it finite
+    HIP_TRY(hipMemset(w.A.p, 0, (size_t)Npad * Npad * sizeof(double)));
+    HIP_TRY(hipMemset(w.B.p, 0, (size_t)Npad * Npad * sizeof(double)));
+    return 0;
+}
+}  // namespace mogp
 
 // diagonal value of channel block (c, c) implied by the table (Delta = Psi = 0 there for every kernel on the path)
-static double table_diag(const mogp_model* m, int c) {
+namespace mogp { double table_diag(const mogp_model* m, int c) {
     const int D = m->D, W = 2 + 3 * D;
     const double* tab = m->table.data() + (size_t)(c * m->C + c) * m->T * W;
     double s = 0.0;
@@ -277,6 +338,7 @@ static double table_diag(const mogp_model* m, int c) {
     }
     return s;
 }
+}  // namespace mogp
 
 // Gram + factorisation + inverse factor + alpha.  On return d_A holds W = L^-1, d_alpha = Kj^-1 y.
 static int factorize(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
@@ -310,101 +372,29 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     GramArgs ga;
     ga.tiles = m->d_tiles.p; ga.xr = m->d_x.p; ga.xc = m->d_x.p; ga.ldxr = ga.ldxc = Npad;
     ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C;
-    ga.out = m->d_A.p; ga.ldo = Npad; ga.noise = m->d_noise.p; ga.dvar = data_var ? m->d_dvar.p : nullptr;
+    ga.out = m->k.A.p; ga.ldo = Npad; ga.noise = m->d_noise.p; ga.dvar = data_var ? m->d_dvar.p : nullptr;
     ga.jitter_abs = jabs; ga.mirror = 0;
     if ((rc = launch_gram(ga, (int)m->tiles.size(), m->st))) return rc;
-    if ((rc = launch_pad_identity(m->d_A.p, Npad, N, Npad, m->st))) return rc;
+    if ((rc = launch_pad_identity(m->k.A.p, Npad, N, Npad, m->st))) return rc;
     if ((rc = mark(m, 1))) return rc;
 
-    // ---- two-level blocked right-looking Cholesky with look-ahead.
-    // Outer blocks of MOGP_OUTER tiles.  "chain(kb)" = for each 128-column of the block: leaf (factor + inverse) -> panel =
-    // panel * inv(Lkk)^T for ALL rows below -> update of the block's remaining columns (64x64-tile GEMMs: latency-bound).
-    // The trailing matrix gets one K = MOGP_OUTER*128 SYRK per outer block, split in two:
-    //   A(kb): the next block's columns, on the critical stream (chain(kb+1) needs them);
-    //   B(kb): everything to the right, on the bulk stream, overlapping chain(kb+1).
-    // A(kb) and B(kb-1) accumulate into the same tiles, so A(kb) waits for B(kb-1).
-    { const char* e = std::getenv("MOGP_OUTER"); if (e && std::atoi(e) > 0) g_outer = std::atoi(e); }
-    const int nb = m->nb;
-    const int nouter = (nb + MOGP_OUTER - 1) / MOGP_OUTER;
-    while ((int)m->sync_ev.size() < 2 * nouter + 2) {
-        hipEvent_t e;
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        m->sync_ev.push_back(e);
-    }
-    int last_bulk = -1;
-    for (int kb = 0; kb < nouter; ++kb) {
-        const int k0 = kb * MOGP_OUTER, k1 = std::min(k0 + MOGP_OUTER, nb);
-        for (int k = k0; k < k1; ++k) {
-            if ((rc = launch_potrf_trtri_tile(m->d_A.p, Npad, k, m->d_invd.p, m->d_logdet.p, m->d_info.p, m->st))) return rc;
-            const int rem = nb - k - 1;
-            if (rem <= 0) break;
-            double* panel = m->d_A.p + (int64_t)(k + 1) * MOGP_TILE * Npad + (int64_t)k * MOGP_TILE;
-            GemmArgs g{};
-            g.A = panel; g.lda = Npad; g.a_kmajor = 0;
-            g.B = m->d_invd.p + (int64_t)k * MOGP_TILE * MOGP_TILE; g.ldb = MOGP_TILE; g.b_kmajor = 0;
-            g.C = panel; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
-            g.mode = GM_RECT; g.small = 1; g.mt = 2 * rem; g.nt = 1; g.K = MOGP_TILE;      // 64x128 tiles: in place
-            if ((rc = gemm_call(m, g, gemm_flops(g, nullptr)))) return rc;
-            const int inner = k1 - k - 1;            // columns k+1 .. k1-1 of this outer block
-            if (inner > 0) {
-                GemmArgs u{};
-                u.A = panel; u.lda = Npad; u.a_kmajor = 0; u.B = panel; u.ldb = Npad; u.b_kmajor = 0;
-                u.C = m->d_A.p + (int64_t)(k + 1) * MOGP_TILE * (Npad + 1); u.ldc = Npad; u.alpha = -1.0; u.beta = 1.0;
-                u.mode = GM_RECT_LOWER; u.small = 2; u.mt = 2 * rem; u.nt = 2 * inner; u.K = MOGP_TILE;
-                if ((rc = gemm_call(m, u, gemm_flops(u, nullptr)))) return rc;
-            }
-        }
-        const int rem = nb - k1;
-        if (rem <= 0) break;
-        double* blockp = m->d_A.p + (int64_t)k1 * MOGP_TILE * Npad + (int64_t)k0 * MOGP_TILE;
-        const int K = (k1 - k0) * MOGP_TILE;
-        const int na = std::min(MOGP_OUTER, rem);      // tile columns of the next outer block
-        HIP_TRY(hipEventRecord(m->sync_ev[2 * kb], m->st));                       // chain(kb) done
-        if (rem > na) {                                                           // B(kb) on the bulk stream
-            HIP_TRY(hipStreamWaitEvent(m->st2, m->sync_ev[2 * kb], 0));
-            double* bp = blockp + (int64_t)na * MOGP_TILE * Npad;
-            GemmArgs u{};
-            u.A = bp; u.lda = Npad; u.a_kmajor = 0; u.B = bp; u.ldb = Npad; u.b_kmajor = 0;
-            u.C = m->d_A.p + (int64_t)(k1 + na) * MOGP_TILE * (Npad + 1); u.ldc = Npad; u.alpha = -1.0; u.beta = 1.0;
-            u.mode = GM_LOWER; u.mt = rem - na; u.nt = rem - na; u.K = K;
-            if ((rc = gemm_call(m, u, gemm_flops(u, nullptr), m->st2))) return rc;
-        }
-        if (last_bulk >= 0) HIP_TRY(hipStreamWaitEvent(m->st, m->sync_ev[2 * last_bulk + 1], 0));   // A(kb) after B(kb-1)
-        if (rem > na) { HIP_TRY(hipEventRecord(m->sync_ev[2 * kb + 1], m->st2)); last_bulk = kb; }
-        {
-            GemmArgs u{};                                                         // A(kb): columns k1 .. k1+na-1, rows >= column
-            u.A = blockp; u.lda = Npad; u.a_kmajor = 0; u.B = blockp; u.ldb = Npad; u.b_kmajor = 0;
-            u.C = m->d_A.p + (int64_t)k1 * MOGP_TILE * (Npad + 1); u.ldc = Npad; u.alpha = -1.0; u.beta = 1.0;
-            u.mode = GM_RECT_LOWER; u.mt = rem; u.nt = na; u.K = K;
-            if ((rc = gemm_call(m, u, gemm_flops(u, nullptr)))) return rc;
-        }
-    }
-    if (last_bulk >= 0) HIP_TRY(hipStreamWaitEvent(m->st, m->sync_ev[2 * last_bulk + 1], 0));
+    if ((rc = spd_potrf(m, m->k))) return rc;
     if ((rc = mark(m, 2))) return rc;
 
-    // ---- W = L^-1, level by level (all nodes of one level in one launch)
-    if ((rc = launch_put_diag_tiles(m->d_A.p, Npad, nb, m->d_invd.p, m->st))) return rc;
-    for (auto& lv : m->levels) {
-        GemmArgs g{};
-        g.A = m->d_A.p; g.lda = Npad; g.a_kmajor = 0; g.B = m->d_A.p; g.ldb = Npad; g.b_kmajor = 1;
-        g.C = m->d_B.p; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
-        g.mode = GM_TASKS; g.mt = g.nt = 0; g.K = 0; g.tasks = lv.d1.p; g.ntasks = (int)lv.h1.size();
-        if ((rc = gemm_call(m, g, lv.flops1))) return rc;
-        g.B = m->d_B.p; g.C = m->d_A.p; g.alpha = -1.0; g.tasks = lv.d2.p; g.ntasks = (int)lv.h2.size();
-        if ((rc = gemm_call(m, g, lv.flops2))) return rc;
-    }
+    if ((rc = spd_trtri(m, m->k))) return rc;
     if ((rc = mark(m, 3))) return rc;
 
     // ---- z = W y, alpha = W^T z
-    if ((rc = launch_trmv_lower(m->d_A.p, Npad, Npad, m->d_y.p, m->d_z.p, m->d_zz.p, m->st))) return rc;
-    if ((rc = launch_trmv_lower_t(m->d_A.p, Npad, Npad, m->d_z.p, m->d_alpha.p, m->st))) return rc;
+    if ((rc = launch_trmv_lower(m->k.A.p, Npad, Npad, m->d_y.p, m->d_z.p, m->d_zz.p, m->st))) return rc;
+    if ((rc = launch_trmv_lower_t(m->k.A.p, Npad, Npad, m->d_z.p, m->d_alpha.p, m->st))) return rc;
     if ((rc = mark(m, 4))) return rc;
 
     // scalars back
     const int nzz = (int)((Npad + 3) / 4);
+    const int nb = m->nb;
     std::vector<double> hl(nb), hz(nzz);
     unsigned long long hinfo = 0;
-    HIP_TRY(hipMemcpyAsync(hl.data(), m->d_logdet.p, nb * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipMemcpyAsync(hl.data(), m->k.logdet.p, nb * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(hz.data(), m->d_zz.p, nzz * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(&hinfo, m->d_info.p, sizeof(hinfo), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
@@ -414,7 +404,7 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
         int flag = 0;
         HIP_TRY(hipMemsetAsync(m->d_flag.p, 0, sizeof(int), m->st));
         if ((rc = launch_gram(ga, (int)m->tiles.size(), m->st))) return rc;
-        if ((rc = launch_nonfinite_scan(m->d_A.p, Npad, N, m->d_flag.p, m->st))) return rc;
+        if ((rc = launch_nonfinite_scan(m->k.A.p, Npad, N, m->d_flag.p, m->st))) return rc;
         HIP_TRY(hipMemcpyAsync(&flag, m->d_flag.p, sizeof(int), hipMemcpyDeviceToHost, m->st));
         HIP_TRY(hipStreamSynchronize(m->st));
         if (flag & 1) return fail(MOGP_ENONFINITE, "linalg.cholesky: kernel matrix has NaNs!");
@@ -461,7 +451,6 @@ int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, c
     m->Npad = m->sx.Mpad;
     m->nb = (int)(m->Npad / MOGP_TILE);
     build_sym_tiles(m->sx.off, C, m->tiles, m->pair_start);
-    build_trtri_levels(m);
     const int64_t Npad = m->Npad;
     const int nchunks = (int)((Npad + 511) / 512);
 #define MOGP_OUTER_DEFINED 1
@@ -473,13 +462,10 @@ int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, c
         TRY_HIP(hipStreamCreateWithPriority(&m->st, hipStreamNonBlocking, hi));
         TRY_HIP(hipStreamCreateWithPriority(&m->st2, hipStreamNonBlocking, lo));
     }
+    TRY_RC(spd_alloc(m->k, Npad));
     TRY_RC(m->d_x.ensure((size_t)D * Npad));
     TRY_RC(m->d_y.ensure(Npad));
-    TRY_RC(m->d_A.ensure((size_t)Npad * Npad));
-    TRY_RC(m->d_B.ensure((size_t)Npad * Npad));
-    TRY_RC(m->d_invd.ensure((size_t)m->nb * MOGP_TILE * MOGP_TILE));
     TRY_RC(m->d_noise.ensure(C));
-    TRY_RC(m->d_logdet.ensure(m->nb));
     TRY_RC(m->d_z.ensure(Npad));
     TRY_RC(m->d_alpha.ensure((size_t)(1 + nchunks) * Npad));
     TRY_RC(m->d_zz.ensure((Npad + 3) / 4));
@@ -493,15 +479,6 @@ int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, c
     TRY_HIP(hipMemcpy(m->d_tiles.p, m->tiles.data(), m->tiles.size() * sizeof(GTile), hipMemcpyHostToDevice));
     TRY_HIP(hipMemcpy(m->d_pair_start.p, m->pair_start.data(), m->pair_start.size() * sizeof(int), hipMemcpyHostToDevice));
     TRY_HIP(hipMemcpy(m->d_chan_off.p, m->sx.off.data(), (C + 1) * sizeof(int), hipMemcpyHostToDevice));
-    for (auto& lv : m->levels) {
-        TRY_RC(lv.d1.ensure(lv.h1.size()));
-        TRY_RC(lv.d2.ensure(lv.h2.size()));
-        TRY_HIP(hipMemcpy(lv.d1.p, lv.h1.data(), lv.h1.size() * sizeof(GemmTask), hipMemcpyHostToDevice));
-        TRY_HIP(hipMemcpy(lv.d2.p, lv.h2.data(), lv.h2.size() * sizeof(GemmTask), hipMemcpyHostToDevice));
-    }
-    // the upper triangle of A is never written by the lower-only Gram; keep it finite
-    TRY_HIP(hipMemset(m->d_A.p, 0, (size_t)Npad * Npad * sizeof(double)));
-    TRY_HIP(hipMemset(m->d_B.p, 0, (size_t)Npad * Npad * sizeof(double)));
     *out = m;
     TRY_RC(mogp_model_set_y(m, y));
 #undef TRY_RC
@@ -515,11 +492,11 @@ int mogp_model_destroy(mogp_model* m) {
     if (m->st) { hipError_t e = hipStreamSynchronize(m->st); (void)e; }
     for (auto e : m->ev) { hipError_t r = hipEventDestroy(e); (void)r; }
     for (auto e : m->gemm_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
-    for (auto e : m->sync_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
     if (m->st2) { hipError_t e = hipStreamSynchronize(m->st2); (void)e; e = hipStreamDestroy(m->st2); (void)e; }
-    for (auto& lv : m->levels) { lv.d1.release(); lv.d2.release(); }
-    m->d_x.release(); m->d_y.release(); m->d_A.release(); m->d_B.release(); m->d_invd.release(); m->d_table.release();
-    m->d_noise.release(); m->d_dvar.release(); m->d_logdet.release(); m->d_z.release(); m->d_alpha.release(); m->d_zz.release();
+    m->k.release();
+    if (m->tw) { m->tw->release(); delete m->tw; m->tw = nullptr; }
+    m->d_x.release(); m->d_y.release(); m->d_table.release();
+    m->d_noise.release(); m->d_dvar.release(); m->d_z.release(); m->d_alpha.release(); m->d_zz.release();
     m->d_partial.release(); m->d_moments.release(); m->d_diagG.release(); m->d_tiles.release(); m->d_pair_start.release();
     m->d_chan_off.release(); m->d_flag.release(); m->d_info.release();
     m->d_xs.release(); m->d_Ksf.release(); m->d_Vt.release(); m->d_mu.release(); m->d_var.release(); m->d_kdiag.release();
@@ -569,20 +546,16 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     const int C = m->C, D = m->D, W = 2 + 3 * D, T = m->T, P = C * (C + 1) / 2;
     const int64_t Npad = m->Npad;
     // K^-1 = W^T W (lower tiles, full diagonal tiles)
-    GemmArgs g{};
-    g.A = m->d_A.p; g.lda = Npad; g.a_kmajor = 1; g.B = m->d_A.p; g.ldb = Npad; g.b_kmajor = 1;
-    g.C = m->d_B.p; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
-    g.mode = GM_LAUUM; g.mt = g.nt = m->nb; g.K = (int)Npad; g.tasks = nullptr; g.ntasks = 0;
-    if ((rc = gemm_call(m, g, gemm_flops(g, nullptr)))) return rc;
+    if ((rc = spd_lauum(m, m->k))) return rc;
     if ((rc = mark(m, 5))) return rc;
 
-    MomentArgs ma;
+    MomentArgs ma{};
     ma.tiles = m->d_tiles.p; ma.ntiles = (int)m->tiles.size(); ma.x = m->d_x.p; ma.ldx = Npad;
-    ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C; ma.kinv = m->d_B.p; ma.ld = Npad; ma.alpha = m->d_alpha.p;
+    ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C; ma.kinv = m->k.B.p; ma.ld = Npad; ma.alpha = m->d_alpha.p;
     ma.partial = m->d_partial.p;
     if ((rc = launch_moments(ma, m->st))) return rc;
     if ((rc = launch_moment_reduce(m->d_partial.p, m->d_pair_start.p, P, T, W, m->d_moments.p, m->st))) return rc;
-    if ((rc = launch_diagG(m->d_B.p, Npad, m->d_alpha.p, m->d_chan_off.p, C, m->d_diagG.p, m->st))) return rc;
+    if ((rc = launch_diagG(m->k.B.p, Npad, m->d_alpha.p, m->d_chan_off.p, C, m->d_diagG.p, m->st))) return rc;
     if ((rc = mark(m, 6))) return rc;
     HIP_TRY(hipMemcpyAsync(moments, m->d_moments.p, (size_t)P * T * W * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(diagG, m->d_diagG.p, C * sizeof(double), hipMemcpyDeviceToHost, m->st));
@@ -638,7 +611,7 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
     if ((rc = launch_gemv_rows(m->d_Ksf.p, Npad, Spad, Npad, m->d_alpha.p, m->d_mu.p, m->st))) return rc;
     // V^T = K_sf W^T  (W lower triangular: k <= j)
     GemmArgs g{};
-    g.A = m->d_Ksf.p; g.lda = Npad; g.a_kmajor = 0; g.B = m->d_A.p; g.ldb = Npad; g.b_kmajor = 0;
+    g.A = m->d_Ksf.p; g.lda = Npad; g.a_kmajor = 0; g.B = m->k.A.p; g.ldb = Npad; g.b_kmajor = 0;
     g.C = m->d_Vt.p; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
     g.mode = GM_KHI_J; g.mt = (int)(Spad / MOGP_TILE); g.nt = m->nb; g.K = (int)Npad; g.tasks = nullptr; g.ntasks = 0;
     if ((rc = gemm_call(m, g, gemm_flops(g, nullptr)))) return rc;
@@ -760,7 +733,7 @@ int mogp_model_fetch(mogp_model* m, int which, double* out) {
     if (which == 1 && !m->have_Kinv) return fail(MOGP_EINVAL, "mogp_model_fetch: Kj^-1 needs an evaluation with MOGP_EVAL_GRAD");
     if (which != 0 && which != 1) return fail(MOGP_EINVAL, "mogp_model_fetch: which must be 0, 1 or 2");
     std::vector<double> h((size_t)Npad * Npad);
-    HIP_TRY(hipMemcpy(h.data(), which == 0 ? m->d_A.p : m->d_B.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h.data(), which == 0 ? m->k.A.p : m->k.B.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int64_t a = 0; a < N; ++a)
         for (int64_t b = 0; b < N; ++b) {
             double v;

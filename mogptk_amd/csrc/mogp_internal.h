@@ -51,20 +51,35 @@ struct GramArgs {
 struct MomentArgs {
     const GTile* tiles;
     int ntiles;
-    const double* x;       // [D][ldx]
+    const double* x;       // row inputs [D][ldx]
     int64_t ldx;
+    const double* xc;      // column inputs [D][ldxc]; null -> the row inputs (symmetric case)
+    int64_t ldxc;
     const double* table;
     int T, D, C;
+    // adjoint source, exact mode (G == null):  g = w * 1/2 (alpha_a alpha_b - kinv_ab), symmetric weights
     const double* kinv;    // lower triangle valid, leading dimension ld
     int64_t ld;
     const double* alpha;   // [N]
+    // adjoint source, dense mode (G != null):  g = w * (G[a][b] + rcoef * ru[a] * rw[b])
+    const double* G;
+    int64_t ldg;
+    const double* ru;      // may be null (no rank-1 term)
+    const double* rw;
+    double rcoef;
+    int sym;               // dense mode: 1 = lower tiles of a symmetric adjoint (weights 2 / 1 on the diagonal / 0 above), 0 = weight 1
+    // per-point input gradients (dense mode only, null = skip): gzr[d][row] += sum_b g dK_ab/dx_a,d ; gzc[d][col] -= ...
+    double* gzr;
+    double* gzc;
+    int64_t ldgz;
     double* partial;       // [ntiles][T][W] per-tile partial moments (reduced in fixed order afterwards)
 };
 
 int launch_gram(const GramArgs& a, int ntiles, hipStream_t s);
 int launch_moments(const MomentArgs& a, hipStream_t s);
 // moments[P][T][W] += fixed-order sum of per-tile partials; tile_pair_lower[t] = p index, tiles grouped by pair
-int launch_moment_reduce(const double* partial, const int* pair_start, int npairs, int T, int W, double* out, hipStream_t s);
+int launch_moment_reduce(const double* partial, const int* pair_start, int npairs, int T, int W, double* out, hipStream_t s,
+                         int lower_pairs = 1);
 // per-channel sum of G_kk = 1/2(alpha_k^2 - kinv_kk): out[c], chan_off device array [C+1]
 int launch_diagG(const double* kinv, int64_t ld, const double* alpha, const int* chan_off, int C, double* out, hipStream_t s);
 
@@ -74,7 +89,10 @@ enum GemmMode { GM_RECT = 0,      // mt x nt tiles, k in [0, K)
                 GM_LAUUM = 2,     // lower tiles, k in [ti*128, K)            (C = W^T W with W lower triangular)
                 GM_KHI_J = 3,     // RECT, k in [0, (tj+1)*128)               (B lower triangular in [j][k] layout)
                 GM_TASKS = 4,     // explicit task list
-                GM_RECT_LOWER = 5 }; // mt x nt tiles, only tiles with ti >= tj (others exit), k in [0, K)
+                GM_RECT_LOWER = 5,  // mt x nt tiles, only tiles with ti >= tj (others exit), k in [0, K)
+                GM_KHI_I = 6,     // RECT, k in [0, (ti+1)*TM)                 (A lower triangular in [i][k] layout)
+                GM_KLO_J = 7,     // RECT, k in [tj*TN, K)                     (B lower triangular in [k][j] layout)
+                GM_KLO_I = 8 };   // RECT, k in [ti*TM, K)                     (A = W^T with W lower triangular, k-major)
 
 struct GemmTask {              // element offsets relative to the launch's base pointers
     int64_t a_off, b_off, c_off;
@@ -112,6 +130,16 @@ int launch_trmv_lower_t(const double* W, int64_t ld, int64_t n, const double* z,
 int launch_gemv_rows(const double* M, int64_t ld, int64_t rows, int64_t n, const double* v, double* out, hipStream_t s);
 // out[r] = base[r] - sum_k M[r][k]^2
 int launch_row_sqnorm_sub(const double* M, int64_t ld, int64_t rows, int64_t n, const double* base, double* out, hipStream_t s);
+// A[i][i] += val for i < n
+int launch_add_diag(double* A, int64_t ld, int64_t n, double val, hipStream_t s);
+// upper triangle <- transpose of the lower triangle (n multiple of 64)
+int launch_symmetrize(double* A, int64_t ld, int64_t n, hipStream_t s);
+// out = ca * I - cp * P - cq * Q (full n x n, all leading dimension ld); Q may be null
+int launch_combine(double* out, const double* P, const double* Q, int64_t ld, int64_t n, double ca, double cp, double cq, hipStream_t s);
+// out[j] = sum_i M[i][j] * v[i]  (v null: sum_i M[i][j]^2),  rows x n dense row-major
+int launch_gemv_cols(const double* M, int64_t ld, int64_t rows, int64_t n, const double* v, double* out, double* scratch, hipStream_t s);
+int launch_get_diag(const double* A, int64_t ld, int64_t n, double* out, hipStream_t s);
+int launch_axpby(int64_t n, double a, const double* x, double b, const double* y, double* out, hipStream_t s);
 // non-finite scan of the lower triangle: flag[0] |= 1 if NaN seen, |= 2 if Inf seen
 int launch_nonfinite_scan(const double* A, int64_t ld, int64_t n, int* flag, hipStream_t s);
 

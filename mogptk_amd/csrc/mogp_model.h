@@ -1,0 +1,135 @@
+// mogp_model.h -- private definitions shared by the translation units of libmogp_hip.so
+#pragma once
+#include "../../include/mogp_hip.h"
+#include "mogp_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+namespace mogp {
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count) {
+        if (count <= n) return 0;
+        if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; n = 0; }
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+        n = count;
+        return 0;
+    }
+    void release() { if (p) { hipError_t e = hipFree(p); (void)e; } p = nullptr; n = 0; }
+};
+
+// channel-sorted view of an input matrix X (M x (1+D)): stable sort by channel id
+struct SortedX {
+    int64_t M = 0, Mpad = 0;
+    std::vector<int64_t> perm;        // sorted position -> original row
+    std::vector<int> off;             // [C+1]
+    std::vector<double> xs;           // [D][Mpad]
+    bool identity = true;
+};
+
+
+int fail(int code, const std::string& msg);
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+int sort_inputs(const double* X, int64_t M, int D, int C, int64_t pad_to, SortedX& o);
+void build_sym_tiles(const std::vector<int>& off, int C, std::vector<GTile>& tiles, std::vector<int>& pair_start);
+void build_rect_tiles(const std::vector<int>& offr, const std::vector<int>& offc, int C, std::vector<GTile>& tiles,
+                      std::vector<int>* pair_start = nullptr);
+
+}  // namespace mogp
+
+using namespace mogp;      // private header: the global handle structs below are built from mogp:: types
+
+struct mogp_ctx {
+    int device = 0;
+    std::string name;
+};
+
+struct TrtriLevel {
+    std::vector<GemmTask> h1, h2;
+    DevBuf<GemmTask> d1, d2;
+    double flops1 = 0, flops2 = 0;
+};
+
+// dense SPD workspace: A (Npad x Npad, lower) -> L -> W = L^-1 in place; B = scratch, then W^T W
+struct Spd {
+    int64_t Npad = 0;
+    int nb = 0;
+    DevBuf<double> A, B, invd, logdet;
+    std::vector<TrtriLevel> levels;
+    std::vector<hipEvent_t> sync_ev;    // cross-stream dependencies of the look-ahead schedule
+    void release() {
+        for (auto& lv : levels) { lv.d1.release(); lv.d2.release(); }
+        for (auto e : sync_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
+        levels.clear(); sync_ev.clear();
+        A.release(); B.release(); invd.release(); logdet.release();
+    }
+};
+
+// workspaces of the Titsias sparse bound (config 5): two M x M SPD systems and three M x N panels
+struct TitsiasWork {
+    int64_t Mpad = 0;
+    Spd a, q;                                           // Kuu (+jitter) and Qs = v v^T / s2 + I
+    DevBuf<double> zx, B, v, GB, Qs, E, R, T1, GA, Hm;  // inputs [D][Mpad]; Kuf, W Kuf, dELBO/dKuf (Mpad x Npad); M x M temporaries
+    DevBuf<double> vec, scratch, gz, partial_uu, partial_uf, mom_uu, mom_uf, zero_noise;
+    DevBuf<GTile> tiles_uu, tiles_uf;
+    DevBuf<int> ps_uu, ps_uf;
+    DevBuf<double> Kus, Aus, Bus;                       // prediction panels (Mpad x Spad)
+    void release() {
+        a.release(); q.release();
+        zx.release(); B.release(); v.release(); GB.release(); Qs.release(); E.release(); R.release(); T1.release(); GA.release(); Hm.release();
+        vec.release(); scratch.release(); gz.release(); partial_uu.release(); partial_uf.release(); mom_uu.release(); mom_uf.release();
+        zero_noise.release(); tiles_uu.release(); tiles_uf.release(); ps_uu.release(); ps_uf.release();
+        Kus.release(); Aus.release(); Bus.release();
+    }
+};
+
+struct mogp_model {
+    mogp_ctx* ctx = nullptr;
+    int64_t N = 0, Npad = 0;
+    int nb = 0, D = 0, C = 0, T = 0;
+    SortedX sx;
+    std::vector<GTile> tiles;
+    std::vector<int> pair_start;
+    std::vector<double> table;          // host copy [C*C*T*W]
+    hipStream_t st = nullptr;           // critical-path stream (high priority)
+    hipStream_t st2 = nullptr;          // bulk trailing updates (look-ahead)
+    Spd k;                              // the N x N system
+
+    DevBuf<double> d_x, d_y, d_table, d_noise, d_dvar, d_z, d_alpha, d_zz, d_partial, d_moments, d_diagG;
+    DevBuf<GTile> d_tiles;
+    DevBuf<int> d_pair_start, d_chan_off, d_flag;
+    DevBuf<unsigned long long> d_info;
+
+    // prediction workspaces
+    DevBuf<double> d_xs, d_Ksf, d_Vt, d_mu, d_var, d_kdiag, d_Kss;
+    DevBuf<GTile> d_ptiles;
+
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;          // stage boundaries
+    std::vector<hipEvent_t> gemm_ev;     // pairs around GEMM launches
+    size_t gemm_ev_used = 0;
+    double ms[MOGP_ST_COUNT] = {0};
+    int64_t gemm_launches = 0;
+    double gemm_flops = 0.0;
+    bool have_W = false, have_Kinv = false;
+    TitsiasWork* tw = nullptr;
+};
+
+
+namespace mogp {
+int use_device(mogp_ctx* c);
+int gemm_call(mogp_model* m, const GemmArgs& g, double flops, hipStream_t st = nullptr);
+int mark(mogp_model* m, int idx);
+double table_diag(const mogp_model* m, int c);
+int spd_alloc(Spd& w, int64_t Npad);
+int spd_potrf(mogp_model* m, Spd& w);
+int spd_trtri(mogp_model* m, Spd& w);
+int spd_lauum(mogp_model* m, Spd& w);
+}  // namespace mogp

@@ -1,0 +1,282 @@
+// titsias.hip -- the Titsias sparse variational bound and its gradient on the device (BASELINE.json configs[4]).
+// Reference: gpr/model.py:700-724 (elbo), :730-765 (predict_f); the gradient replaces autograd through that code.
+//
+// Whitened, cancellation-free forms (A = Kuu + jitter mean(diag Kuu) I = Luu Luu^T, W = Luu^-1, B = Kuf, s2 = sigma^2):
+//   v = W B,  Qs = v v^T / s2 + I = Lq Lq^T,  Pq = Qs^-1,  t1 = Pq (v y),  beta = W^T t1
+//   ELBO      = -N/2 log 2pi - sum log Lq_kk - N log sigma - y^T y /(2 s2) + t1.(v y) /(2 s2^2) - (sum Kff_diag - tr Q)/(2 s2)
+//   dELBO/dB  = W^T (I - Pq) v / s2 + beta (y / s2^2 - B^T beta / s2^3)^T
+//   dELBO/dA  = 1/2 W^T (2 I - Pq - Qs) W - 1/2 beta beta^T / s2^2
+// Every O(M^2 N) product runs on the fp64 MFMA GEMM with the triangular k-ranges skipped; the two adjoints are contracted
+// with the kernel derivatives by the dense-mode moment kernel, which also accumulates the gradient w.r.t. the inducing inputs.
+#include "mogp_model.h"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace mogp {
+int launch_potrf_trtri_tile(double* A, int64_t ld, int t, double* invd, double* logdet, unsigned long long* info, hipStream_t s);
+}
+using namespace mogp;
+
+#define RC(x) do { int r__ = (x); if (r__) return r__; } while (0)
+
+static GemmArgs gemm(const double* A, int64_t lda, int akm, const double* B, int64_t ldb, int bkm, double* C, int64_t ldc,
+                     double alpha, int mode, int mt, int nt, int64_t K) {
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.a_kmajor = akm; g.B = B; g.ldb = ldb; g.b_kmajor = bkm; g.C = C; g.ldc = ldc;
+    g.alpha = alpha; g.beta = 0.0; g.mode = mode; g.mt = mt; g.nt = nt; g.K = (int)K;
+    return g;
+}
+
+static int check_info(mogp_model* m, const char* which, int64_t* info) {
+    unsigned long long hinfo = 0;
+    HIP_TRY(hipMemcpyAsync(&hinfo, m->d_info.p, sizeof(hinfo), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    if (hinfo != std::numeric_limits<unsigned long long>::max()) {
+        if (info) *info = (int64_t)hinfo;
+        return fail(MOGP_ENOTPD, std::string("linalg.cholesky: ") + which + " is not positive-definite (the leading minor of order " +
+                                 std::to_string(hinfo) + " is not positive-definite).");
+    }
+    return 0;
+}
+
+// Common front end: sort Z, build tiles, Kuu -> W (in tw.a.A), Kuf -> tw.B, v -> tw.v, Qs -> tw.Qs, Wq (tw.q.A), Pq (tw.q.B, full),
+// vy, t1 in tw.vec[0 : Mpad], tw.vec[Mpad : 2 Mpad].  Host scalars through `sc`.
+struct TitsiasScalars { double logdet_q, yy, t1vy, t1t1, trPq, trQs, jit; };
+
+static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, SortedX& sz,
+                         std::vector<GTile>& tuu, std::vector<int>& psuu, std::vector<GTile>& tuf, std::vector<int>& psuf,
+                         TitsiasScalars& sc, int64_t* info, bool need_moment_tiles) {
+    const int C = m->C, D = m->D, W = 2 + 3 * D;
+    const int64_t Npad = m->Npad;
+    if (m->T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms must be called before an evaluation");
+    if (!(sigma > 0.0)) return fail(MOGP_EINVAL, "sigma must be positive");
+    RC(sort_inputs(Z, M, D, C, MOGP_TILE, sz));
+    const int64_t Mpad = sz.Mpad;
+    if (!m->tw) m->tw = new TitsiasWork();
+    TitsiasWork& t = *m->tw;
+    const int mt = (int)(Mpad / MOGP_TILE), nt = (int)(Npad / MOGP_TILE);
+    if (t.Mpad != Mpad) {
+        t.Mpad = Mpad;
+        RC(spd_alloc(t.a, Mpad)); RC(spd_alloc(t.q, Mpad));
+        RC(t.zx.ensure((size_t)D * Mpad));
+        RC(t.B.ensure((size_t)Mpad * Npad)); RC(t.v.ensure((size_t)Mpad * Npad));
+        RC(t.Qs.ensure((size_t)Mpad * Mpad));
+        RC(t.vec.ensure((size_t)8 * Mpad + 4 * Npad));
+        RC(t.scratch.ensure((size_t)(Mpad / 256 + 2) * std::max(Npad, Mpad) + (size_t)(Mpad / 512 + 2) * Mpad));
+        RC(t.zero_noise.ensure(C));
+        HIP_TRY(hipMemset(t.zero_noise.p, 0, C * sizeof(double)));
+        HIP_TRY(hipMemset(t.B.p, 0, (size_t)Mpad * Npad * sizeof(double)));      // padding of Kuf stays zero: the Gram kernel never writes it
+    }
+    m->gemm_ev_used = 0; m->gemm_launches = 0; m->gemm_flops = 0.0;
+    build_sym_tiles(sz.off, C, tuu, psuu);
+    build_rect_tiles(sz.off, m->sx.off, C, tuf, &psuf);
+    RC(t.tiles_uu.ensure(tuu.size())); RC(t.tiles_uf.ensure(tuf.size()));
+    HIP_TRY(hipMemcpyAsync(t.zx.p, sz.xs.data(), (size_t)D * Mpad * sizeof(double), hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemcpyAsync(t.tiles_uu.p, tuu.data(), tuu.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemcpyAsync(t.tiles_uf.p, tuf.data(), tuf.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
+    if (need_moment_tiles) {
+        RC(t.ps_uu.ensure(psuu.size())); RC(t.ps_uf.ensure(psuf.size()));
+        HIP_TRY(hipMemcpyAsync(t.ps_uu.p, psuu.data(), psuu.size() * sizeof(int), hipMemcpyHostToDevice, m->st));
+        HIP_TRY(hipMemcpyAsync(t.ps_uf.p, psuf.data(), psuf.size() * sizeof(int), hipMemcpyHostToDevice, m->st));
+        RC(t.partial_uu.ensure(tuu.size() * (size_t)m->T * W)); RC(t.partial_uf.ensure(tuf.size() * (size_t)m->T * W));
+        RC(t.mom_uu.ensure((size_t)(C * (C + 1) / 2) * m->T * W)); RC(t.mom_uf.ensure((size_t)C * C * m->T * W));
+    }
+    const unsigned long long big = std::numeric_limits<unsigned long long>::max();
+    HIP_TRY(hipMemcpyAsync(m->d_info.p, &big, sizeof(big), hipMemcpyHostToDevice, m->st));
+
+    // relative jitter on Kuu (reference gpr/model.py:710 -> :244)
+    double dsum = 0.0;
+    for (int c = 0; c < C; ++c) dsum += (double)(sz.off[c + 1] - sz.off[c]) * table_diag(m, c);
+    sc.jit = jitter * dsum / (double)M;
+
+    GramArgs ga{};
+    ga.tiles = t.tiles_uu.p; ga.xr = t.zx.p; ga.xc = t.zx.p; ga.ldxr = ga.ldxc = Mpad;
+    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.out = t.a.A.p; ga.ldo = Mpad;
+    ga.noise = t.zero_noise.p; ga.dvar = nullptr; ga.jitter_abs = sc.jit; ga.mirror = 0;
+    RC(launch_gram(ga, (int)tuu.size(), m->st));
+    RC(launch_pad_identity(t.a.A.p, Mpad, M, Mpad, m->st));
+    ga.tiles = t.tiles_uf.p; ga.xc = m->d_x.p; ga.ldxc = Npad; ga.out = t.B.p; ga.ldo = Npad; ga.noise = nullptr; ga.jitter_abs = 0.0;
+    RC(launch_gram(ga, (int)tuf.size(), m->st));
+
+    RC(spd_potrf(m, t.a));
+    RC(check_info(m, "Kuu", info));
+    RC(spd_trtri(m, t.a));                                                      // t.a.A = W
+    const double s2 = sigma * sigma;
+    GemmArgs g = gemm(t.a.A.p, Mpad, 0, t.B.p, Npad, 1, t.v.p, Npad, 1.0, GM_KHI_I, mt, nt, Mpad);        // v = W B
+    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
+    g = gemm(t.v.p, Npad, 0, t.v.p, Npad, 0, t.q.A.p, Mpad, 1.0 / s2, GM_LOWER, mt, mt, Npad);            // Qs = v v^T / s2 (+ I)
+    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
+    RC(launch_add_diag(t.q.A.p, Mpad, Mpad, 1.0, m->st));
+    HIP_TRY(hipMemcpyAsync(t.Qs.p, t.q.A.p, (size_t)Mpad * Mpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
+    HIP_TRY(hipMemcpyAsync(m->d_info.p, &big, sizeof(big), hipMemcpyHostToDevice, m->st));
+    RC(spd_potrf(m, t.q));
+    RC(check_info(m, "Q/sigma^2 + I", info));
+    RC(spd_trtri(m, t.q));                                                      // t.q.A = Wq
+    RC(spd_lauum(m, t.q));                                                      // t.q.B = Pq (lower)
+    RC(launch_symmetrize(t.q.B.p, Mpad, Mpad, m->st));
+    double* vy = t.vec.p;
+    double* t1 = t.vec.p + Mpad;
+    double* dg = t.vec.p + 2 * Mpad;                                            // diag Pq, diag Qs
+    RC(launch_gemv_rows(t.v.p, Npad, Mpad, Npad, m->d_y.p, vy, m->st));
+    RC(launch_gemv_rows(t.q.B.p, Mpad, Mpad, Mpad, vy, t1, m->st));
+    RC(launch_get_diag(t.q.B.p, Mpad, Mpad, dg, m->st));
+    RC(launch_get_diag(t.Qs.p, Mpad, Mpad, dg + Mpad, m->st));
+    const int nbq = t.q.nb;
+    std::vector<double> hv((size_t)4 * Mpad), hl(nbq), hy(Npad);
+    HIP_TRY(hipMemcpyAsync(hv.data(), t.vec.p, (size_t)4 * Mpad * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipMemcpyAsync(hl.data(), t.q.logdet.p, nbq * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipMemcpyAsync(hy.data(), m->d_y.p, Npad * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    sc.logdet_q = 0.0; for (double x : hl) sc.logdet_q += x;
+    sc.yy = 0.0; for (double x : hy) sc.yy += x * x;
+    sc.t1vy = sc.t1t1 = sc.trPq = sc.trQs = 0.0;
+    for (int64_t i = 0; i < M; ++i) {
+        sc.t1vy += hv[Mpad + i] * hv[i]; sc.t1t1 += hv[Mpad + i] * hv[Mpad + i];
+        sc.trPq += hv[2 * Mpad + i]; sc.trQs += hv[3 * Mpad + i];
+    }
+    return 0;
+}
+
+extern "C" {
+
+int mogp_titsias_eval(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kff_diag, int flags,
+                      double* elbo, double* mom_uu, double* mom_uf, double* gZ, double* trGA, double* dsigma,
+                      double* jitter_abs, int64_t* info) {
+    if (!m || !Z || !kff_diag || !elbo || M <= 0) return fail(MOGP_EINVAL, "mogp_titsias_eval: bad argument");
+    RC(use_device(m->ctx));
+    if (info) *info = 0;
+    const int C = m->C, D = m->D, W = 2 + 3 * D, T = m->T, P = C * (C + 1) / 2;
+    const int64_t N = m->N, Npad = m->Npad;
+    const bool grad = (flags & MOGP_EVAL_GRAD) != 0;
+    SortedX sz;
+    std::vector<GTile> tuu, tuf;
+    std::vector<int> psuu, psuf;
+    TitsiasScalars sc;
+    RC(titsias_front(m, M, Z, sigma, jitter, sz, tuu, psuu, tuf, psuf, sc, info, grad));
+    TitsiasWork& t = *m->tw;
+    const int64_t Mpad = t.Mpad;
+    const int mt = (int)(Mpad / MOGP_TILE), nt = (int)(Npad / MOGP_TILE);
+    const double s2 = sigma * sigma;
+    double kff = 0.0;
+    for (int c = 0; c < C; ++c) kff += (double)(m->sx.off[c + 1] - m->sx.off[c]) * kff_diag[c];
+    const double trQ = s2 * (sc.trQs - (double)M);
+    *elbo = -0.5 * (double)N * std::log(2.0 * M_PI) - sc.logdet_q - (double)N * std::log(sigma) - 0.5 * sc.yy / s2
+            + 0.5 * sc.t1vy / (s2 * s2) - 0.5 * (kff - trQ) / s2;
+    if (jitter_abs) *jitter_abs = sc.jit;
+    if (!grad) return MOGP_OK;
+    if (!mom_uu || !mom_uf || !gZ || !trGA || !dsigma) return fail(MOGP_EINVAL, "mogp_titsias_eval: gradient outputs are null");
+
+    // d ELBO / d s2, then d sigma  (tr(Pq Q) = s2 (M - tr Pq);  vy^T Pq Q Pq vy = s2 (t1.vy - t1.t1))
+    const double ds2 = -0.5 * (double)N / s2 + 0.5 * ((double)M - sc.trPq) / s2 + 0.5 * sc.yy / (s2 * s2) - sc.t1vy / (s2 * s2 * s2)
+                       + 0.5 * (sc.t1vy - sc.t1t1) / (s2 * s2 * s2) + 0.5 * (kff - trQ) / (s2 * s2);
+    *dsigma = 2.0 * sigma * ds2;
+
+    RC(t.GB.ensure((size_t)Mpad * Npad)); RC(t.E.ensure((size_t)Mpad * Mpad)); RC(t.R.ensure((size_t)Mpad * Mpad));
+    RC(t.T1.ensure((size_t)Mpad * Mpad)); RC(t.GA.ensure((size_t)Mpad * Mpad)); RC(t.Hm.ensure((size_t)Mpad * Mpad));
+    RC(t.gz.ensure((size_t)D * Mpad));
+    double* vy = t.vec.p; (void)vy;
+    double* t1 = t.vec.p + Mpad;
+    double* beta = t.vec.p + 4 * Mpad;            // [Mpad] (+ chunk scratch behind it, see launch_trmv_lower_t)
+    double* dga = t.vec.p + 2 * Mpad;             // reuse: diag of GA
+    double* btb = t.vec.p + 8 * Mpad;             // [Npad]
+    double* r = btb + Npad;                       // [Npad]
+    // beta = W^T t1 : the transposed mat-vec helper wants room for its row-chunk partials right behind the output vector
+    RC(launch_trmv_lower_t(t.a.A.p, Mpad, Mpad, t1, t.scratch.p, m->st));
+    HIP_TRY(hipMemcpyAsync(beta, t.scratch.p, Mpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
+    RC(launch_symmetrize(t.Qs.p, Mpad, Mpad, m->st));
+    RC(launch_combine(t.E.p, t.q.B.p, t.Qs.p, Mpad, Mpad, 2.0, 1.0, 1.0, m->st));            // E = 2I - Pq - Qs
+    RC(launch_combine(t.R.p, t.q.B.p, nullptr, Mpad, Mpad, 1.0, 1.0, 0.0, m->st));           // R = I - Pq
+    GemmArgs g = gemm(t.E.p, Mpad, 0, t.a.A.p, Mpad, 1, t.T1.p, Mpad, 1.0, GM_KLO_J, mt, mt, Mpad);        // T1 = E W
+    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
+    g = gemm(t.a.A.p, Mpad, 1, t.T1.p, Mpad, 1, t.GA.p, Mpad, 0.5, GM_LAUUM, mt, mt, Mpad);                 // GA = 1/2 W^T T1 (lower)
+    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
+    g = gemm(t.a.A.p, Mpad, 1, t.R.p, Mpad, 1, t.Hm.p, Mpad, 1.0, GM_KLO_I, mt, mt, Mpad);                  // Hm = W^T R
+    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
+    g = gemm(t.Hm.p, Mpad, 0, t.v.p, Npad, 1, t.GB.p, Npad, 1.0 / s2, GM_RECT, mt, nt, Mpad);               // GB = Hm v / s2
+    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
+    RC(launch_gemv_cols(t.B.p, Npad, Mpad, Npad, beta, btb, t.scratch.p, m->st));                           // B^T beta
+    RC(launch_axpby(Npad, 1.0 / (s2 * s2), m->d_y.p, -1.0 / (s2 * s2 * s2), btb, r, m->st));
+    RC(launch_get_diag(t.GA.p, Mpad, Mpad, dga, m->st));
+    HIP_TRY(hipMemsetAsync(t.gz.p, 0, (size_t)D * Mpad * sizeof(double), m->st));
+
+    MomentArgs ma{};
+    ma.tiles = t.tiles_uf.p; ma.ntiles = (int)tuf.size(); ma.x = t.zx.p; ma.ldx = Mpad; ma.xc = m->d_x.p; ma.ldxc = Npad;
+    ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C;
+    ma.G = t.GB.p; ma.ldg = Npad; ma.ru = beta; ma.rw = r; ma.rcoef = 1.0; ma.sym = 0;
+    ma.gzr = t.gz.p; ma.gzc = nullptr; ma.ldgz = Mpad; ma.partial = t.partial_uf.p;
+    RC(launch_moments(ma, m->st));
+    RC(launch_moment_reduce(t.partial_uf.p, t.ps_uf.p, C * C, T, W, t.mom_uf.p, m->st, 0));
+    ma.tiles = t.tiles_uu.p; ma.ntiles = (int)tuu.size(); ma.xc = nullptr; ma.ldxc = 0;
+    ma.G = t.GA.p; ma.ldg = Mpad; ma.ru = beta; ma.rw = beta; ma.rcoef = -0.5 / (s2 * s2); ma.sym = 1;
+    ma.gzr = t.gz.p; ma.gzc = t.gz.p; ma.partial = t.partial_uu.p;
+    RC(launch_moments(ma, m->st));
+    RC(launch_moment_reduce(t.partial_uu.p, t.ps_uu.p, P, T, W, t.mom_uu.p, m->st, 1));
+
+    std::vector<double> hgz((size_t)D * Mpad), hb(Mpad), hd(Mpad);
+    HIP_TRY(hipMemcpyAsync(mom_uu, t.mom_uu.p, (size_t)P * T * W * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipMemcpyAsync(mom_uf, t.mom_uf.p, (size_t)C * C * T * W * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipMemcpyAsync(hgz.data(), t.gz.p, hgz.size() * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipMemcpyAsync(hb.data(), beta, Mpad * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipMemcpyAsync(hd.data(), dga, Mpad * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    for (int64_t pos = 0; pos < M; ++pos)
+        for (int d = 0; d < D; ++d) gZ[sz.perm[pos] * D + d] = hgz[(size_t)d * Mpad + pos];
+    double tr = 0.0;
+    for (int64_t i = 0; i < M; ++i) tr += hd[i] - 0.5 * hb[i] * hb[i] / (s2 * s2);
+    *trGA = tr;
+    return MOGP_OK;
+}
+
+int mogp_titsias_predict(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kss_diag,
+                         int64_t S, const double* Xs, double* mu, double* var, int64_t* info) {
+    if (!m || !Z || !kss_diag || !Xs || !mu || !var || M <= 0 || S <= 0) return fail(MOGP_EINVAL, "mogp_titsias_predict: bad argument");
+    RC(use_device(m->ctx));
+    if (info) *info = 0;
+    const int C = m->C, D = m->D;
+    SortedX sz, ss;
+    std::vector<GTile> tuu, tuf, tus;
+    std::vector<int> psuu, psuf;
+    TitsiasScalars sc;
+    RC(titsias_front(m, M, Z, sigma, jitter, sz, tuu, psuu, tuf, psuf, sc, info, false));
+    TitsiasWork& t = *m->tw;
+    const int64_t Mpad = t.Mpad;
+    const double s2 = sigma * sigma;
+    RC(sort_inputs(Xs, S, D, C, MOGP_TILE, ss));
+    const int64_t Spad = ss.Mpad;
+    const int mt = (int)(Mpad / MOGP_TILE), st = (int)(Spad / MOGP_TILE);
+    build_rect_tiles(sz.off, ss.off, C, tus);
+    RC(t.Kus.ensure((size_t)Mpad * Spad)); RC(t.Aus.ensure((size_t)Mpad * Spad)); RC(t.Bus.ensure((size_t)Mpad * Spad));
+    RC(m->d_xs.ensure((size_t)D * Spad)); RC(m->d_ptiles.ensure(tus.size()));
+    RC(m->d_mu.ensure(Spad)); RC(m->d_var.ensure(2 * Spad));
+    HIP_TRY(hipMemcpyAsync(m->d_xs.p, ss.xs.data(), (size_t)D * Spad * sizeof(double), hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemcpyAsync(m->d_ptiles.p, tus.data(), tus.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemsetAsync(t.Kus.p, 0, (size_t)Mpad * Spad * sizeof(double), m->st));
+    GramArgs ga{};
+    ga.tiles = m->d_ptiles.p; ga.xr = t.zx.p; ga.ldxr = Mpad; ga.xc = m->d_xs.p; ga.ldxc = Spad;
+    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.out = t.Kus.p; ga.ldo = Spad; ga.mirror = 0;
+    RC(launch_gram(ga, (int)tus.size(), m->st));
+    GemmArgs g = gemm(t.a.A.p, Mpad, 0, t.Kus.p, Spad, 1, t.Aus.p, Spad, 1.0, GM_KHI_I, mt, st, Mpad);     // a = W Kus
+    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
+    g = gemm(t.q.A.p, Mpad, 0, t.Aus.p, Spad, 1, t.Bus.p, Spad, 1.0, GM_KHI_I, mt, st, Mpad);                // b = Wq a
+    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
+    double* vy = t.vec.p;
+    double* cvec = t.vec.p + 4 * Mpad;
+    RC(launch_trmv_lower(t.q.A.p, Mpad, Mpad, vy, cvec, t.vec.p + 6 * Mpad, m->st));                          // c s2 = Wq vy
+    RC(launch_gemv_cols(t.Bus.p, Spad, Mpad, Spad, cvec, m->d_mu.p, t.scratch.p, m->st));                    // mu s2 = b^T (Wq vy)
+    RC(launch_gemv_cols(t.Aus.p, Spad, Mpad, Spad, nullptr, m->d_var.p, t.scratch.p, m->st));               // colsum a^2
+    RC(launch_gemv_cols(t.Bus.p, Spad, Mpad, Spad, nullptr, m->d_var.p + Spad, t.scratch.p, m->st));        // colsum b^2
+    std::vector<double> hmu(Spad), hv(2 * Spad);
+    HIP_TRY(hipMemcpyAsync(hmu.data(), m->d_mu.p, Spad * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipMemcpyAsync(hv.data(), m->d_var.p, 2 * Spad * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    for (int c = 0; c < C; ++c)
+        for (int pos = ss.off[c]; pos < ss.off[c + 1]; ++pos) {
+            mu[ss.perm[pos]] = hmu[pos] / s2;
+            var[ss.perm[pos]] = kss_diag[c] - hv[pos] + hv[Spad + pos];
+        }
+    return MOGP_OK;
+}
+
+}  // extern "C"

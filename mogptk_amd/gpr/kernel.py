@@ -119,6 +119,15 @@ class Kernel(ParameterHolder):
         C = table.shape[0]
         return np.array([np.sum(table[c, c, :, 0]) for c in range(C)])
 
+    def _spectral_diag_backward(self, gc, D):
+        """accumulate d loss / d K_diag[c] = gc[c] (K_diag as `_spectral_diag` defines it) into the raw gradients.
+        Default: K_diag[c] = sum_t A_cct, so it is a table gradient on the diagonal amplitudes."""
+        table = self._spectral_terms(D)
+        gt = np.zeros_like(table)
+        for c in range(table.shape[0]):
+            gt[c, c, :, 0] = gc[c]
+        self._spectral_backward(gt)
+
     def K(self, X1, X2=None):
         """Kernel matrix, reference gpr/kernel.py:138-150 (MO: :446-481).  Runs the HIP Gram builder."""
         from .._lib import gram
@@ -178,6 +187,10 @@ class AddKernel(Kernels):
 
     def _spectral_diag(self, D):
         return sum(k._spectral_diag(D) for k in self.kernels)          # :245-246
+
+    def _spectral_diag_backward(self, gc, D):
+        for k in self.kernels:
+            k._spectral_diag_backward(gc, D)
 
     def _spectral_terms(self, D):
         return np.concatenate([k._spectral_terms(D) for k in self.kernels], axis=2)

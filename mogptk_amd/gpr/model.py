@@ -31,6 +31,30 @@ def _to_array(X):
     return np.array(X, dtype=np.float64)
 
 
+def _gtable_from_moments(table, mom, D, lower=True):
+    """d(objective)/d(term table) from the device's gradient moments [m0, m4, m1_d, m2_d, m3_d]:
+    dA = m0, dPsi = -2 pi A m4, dV_d = -1/2 A m1_d, dM_d = -2 pi A m3_d, dDelta_d = -V_d A m2_d - 2 pi M_d A m4.
+    lower=True: mom is indexed by lower channel pairs p = i(i+1)/2 + j (symmetric Gram, double count already
+    included); lower=False: mom is indexed by all ordered pairs i*C + j (rectangular Gram)."""
+    C, T = table.shape[0], table.shape[2]
+    gt = np.zeros((C, C, T, 2 + 3 * D))
+    for i in range(C):
+        for j in range((i + 1) if lower else C):
+            m = mom[i * (i + 1) // 2 + j] if lower else mom[i * C + j]
+            tb = table[i, j]
+            A = tb[:, 0]
+            V = tb[:, 2:2 + D]
+            M = tb[:, 2 + D:2 + 2 * D]
+            m0, m4 = m[:, 0], m[:, 1]
+            m1, m2, m3 = m[:, 2:2 + D], m[:, 2 + D:2 + 2 * D], m[:, 2 + 2 * D:]
+            gt[i, j, :, 0] = m0
+            gt[i, j, :, 1] = -2.0 * np.pi * A * m4
+            gt[i, j, :, 2:2 + D] = -0.5 * A[:, None] * m1
+            gt[i, j, :, 2 + D:2 + 2 * D] = -2.0 * np.pi * A[:, None] * m3
+            gt[i, j, :, 2 + 2 * D:] = -V * A[:, None] * m2 - 2.0 * np.pi * M * (A * m4)[:, None]
+    return gt
+
+
 class Model(ParameterHolder):
     """Base model (reference gpr/model.py:80-401)."""
 
@@ -230,21 +254,9 @@ class Exact(Model):
         jit_rel = self.jitter * res["trG"] / N            # d LML / d (mean diag) through the jitter term (:244)
 
         # d LML / d table for the lower channel pairs (i >= j); zero elsewhere
-        gt = np.zeros((C, C, T, W))
+        gt = _gtable_from_moments(table, mom, D, lower=True)
         for i in range(C):
-            for j in range(i + 1):
-                m = mom[i * (i + 1) // 2 + j]                   # (T, W): [m0, m4, m1_d, m2_d, m3_d]
-                tb = table[i, j]
-                A = tb[:, 0]
-                V = tb[:, 2:2 + D]
-                M = tb[:, 2 + D:2 + 2 * D]
-                m0, m4 = m[:, 0], m[:, 1]
-                m1, m2, m3 = m[:, 2:2 + D], m[:, 2 + D:2 + 2 * D], m[:, 2 + 2 * D:]
-                gt[i, j, :, 0] = m0 + (jit_rel * counts[i] if i == j else 0.0)
-                gt[i, j, :, 1] = -2.0 * np.pi * A * m4
-                gt[i, j, :, 2:2 + D] = -0.5 * A[:, None] * m1
-                gt[i, j, :, 2 + D:2 + 2 * D] = -2.0 * np.pi * A[:, None] * m3
-                gt[i, j, :, 2 + 2 * D:] = -V * A[:, None] * m2 - 2.0 * np.pi * M * (A * m4)[:, None]
+            gt[i, i, :, 0] += jit_rel * counts[i]
         self.kernel._spectral_backward(-gt)                    # loss = -LML
 
         # noise: d LML / d sigma_c = 2 sigma_c (sum_{k in c} G_kk + jitter n_c/N tr G)
@@ -273,6 +285,153 @@ class Exact(Model):
                 self.print_parameters()
                 raise CholeskyException(str(e), None, self)
             raise
+        if self.mean is not None:
+            mu = mu + np.asarray(self.mean(X)).reshape(-1, 1)
+        return mu, var
+
+
+# ---- inducing-point initialisation (reference gpr/model.py:11-69) ---------------------------------------------------
+def _linspace_f32(lo, hi, n):
+    """torch.linspace(lo, hi, n) in the reference runs in torch's default dtype float32 (quirk Q6, gpr/model.py:18):
+    step = (end - start)/(n - 1) in float32, first half start + i*step, second half end - (n-1-i)*step."""
+    start, end = np.float32(lo), np.float32(hi)
+    if n == 1:
+        return np.array([start], dtype=np.float64)
+    step = np.float32((end - start) / np.float32(n - 1))
+    out = np.empty(n, dtype=np.float32)
+    half = n // 2
+    for i in range(n):
+        out[i] = start + step * np.float32(i) if i < half else end - step * np.float32(n - i - 1)
+    return out.astype(np.float64)
+
+
+def _init_grid(N, X):
+    n = np.power(N, 1.0 / X.shape[1])
+    if not float(n).is_integer():
+        raise ValueError("number of inducing points must equal N = n^%d" % X.shape[1])
+    n = int(n)
+    axes = [_linspace_f32(np.min(X[:, i]), np.max(X[:, i]), n) for i in range(X.shape[1])]
+    grid = np.meshgrid(*axes, indexing="ij")
+    return np.stack([g.reshape(-1) for g in grid], axis=1)
+
+
+def _init_random(N, X):
+    from scipy.stats import qmc
+    samples = qmc.Halton(d=X.shape[1]).random(n=N)
+    lo, hi = np.min(X, axis=0), np.max(X, axis=0)
+    return lo + (hi - lo) * samples
+
+
+def _init_density(N, X):
+    from scipy.stats import gaussian_kde
+    return gaussian_kde(X.T, bw_method="scott").resample(N).T
+
+
+def init_inducing_points(Z, X, method="grid", output_dims=None):
+    """reference gpr/model.py:36-69.  Z int / list of ints -> locations; an int means PER CHANNEL for multi-output
+    kernels (quirk Q5).  Values pass through float32 like the reference's default-dtype tensor (quirk Q6)."""
+    _init = {"grid": _init_grid, "random": _init_random, "density": _init_density}.get(method, _init_grid)
+    if output_dims is not None:
+        if isinstance(Z, (int, np.integer)) or (all(isinstance(z, (int, np.integer)) for z in Z) and len(Z) == output_dims):
+            M = [int(Z)] * output_dims if isinstance(Z, (int, np.integer)) else [int(z) for z in Z]
+            out = np.zeros((sum(M), X.shape[1]), dtype=np.float32)
+            for j in range(len(M)):
+                m0 = sum(M[:j])
+                out[m0:m0 + M[j], 0] = j
+                out[m0:m0 + M[j], 1:] = _init(M[j], X[X[:, 0] == j, 1:])
+            return out.astype(np.float64)
+    elif isinstance(Z, (int, np.integer)):
+        return _init(int(Z), X)
+    return Z
+
+
+class Titsias(Model):
+    """
+    Sparse GP regression, Titsias 2009 (reference gpr/model.py:668-765): the bound
+        ELBO = log N(y | 0, Kfu Kuu^-1 Kuf + s2 I) - tr(Kff - Kfu Kuu^-1 Kuf) / (2 s2)
+    with trainable inducing inputs `Z` (the channel column of Z carries no gradient) and a SCALAR noise scale.
+    """
+
+    def __init__(self, kernel, X, y, Z, Z_init="grid", variance=1.0, jitter=1e-8, mean=None):
+        variance = Parameter.to_tensor(variance)
+        super().__init__(kernel, X, y, GaussianLikelihood(np.sqrt(variance)), jitter, mean)
+        Z = init_inducing_points(Z, self.X, method=Z_init, output_dims=kernel.output_dims)
+        Z = self._check_input(Z)
+        self.log_marginal_likelihood_constant = 0.5 * self.X.shape[0] * np.log(2.0 * np.pi)
+        self.Z = Parameter(Z, name="induction_points")
+        if kernel.output_dims is not None:
+            self.Z.num_parameters -= self.Z().shape[0]
+
+    def _device_handle(self):
+        if self._handle is None:
+            from .._lib import ExactHandle
+            y = self.y if self.mean is None else self.y - np.asarray(self.mean(self.X)).reshape(-1, 1)
+            self._handle = ExactHandle(config.device, self.kernel._kernel_format(self.X), y, self.kernel._channels())
+        return self._handle
+
+    def _sigma(self):
+        s = np.asarray(self.likelihood.scale())
+        if s.ndim != 0 and s.size != 1:
+            raise ValueError("Titsias takes a scalar noise variance (reference gpr/model.py:686-689)")
+        return float(s.reshape(-1)[0])
+
+    def _run(self, grad):
+        from .._lib import MogpError, MOGP_ENOTPD, MOGP_ENONFINITE
+        h = self._device_handle()
+        D = self.X.shape[1] - (0 if self.kernel.output_dims is None else 1)
+        table = self.kernel._spectral_terms(D)
+        h.set_terms(table)
+        Zk = self.kernel._kernel_format(self.Z())
+        try:
+            res = h.titsias_eval(Zk, self._sigma(), self.jitter, self.kernel._spectral_diag(D), grad=grad)
+        except MogpError as e:
+            if e.code in (MOGP_ENOTPD, MOGP_ENONFINITE):
+                print("ERROR:", str(e), file=sys.__stdout__)
+                self.print_parameters()
+                raise CholeskyException(str(e), None, self)
+            raise
+        return res, table, D, Zk
+
+    def elbo(self):
+        res, _, _, _ = self._run(grad=False)
+        return np.float64(res["elbo"])
+
+    def log_marginal_likelihood(self):
+        """maximise the lower bound (reference gpr/model.py:726-728)"""
+        return self.elbo()
+
+    def loss(self):
+        self.zero_grad(set_to_none=True)
+        res, table, D, Zk = self._run(grad=True)
+        C = table.shape[0]
+        s2 = self._sigma() ** 2
+        M = Zk.shape[0]
+        zc = np.bincount(Zk[:, 0].astype(np.int64), minlength=C).astype(np.float64)
+        xc = np.bincount(self.kernel._kernel_format(self.X)[:, 0].astype(np.int64), minlength=C).astype(np.float64)
+        gt = _gtable_from_moments(table, res["mom_uu"], D, lower=True) + _gtable_from_moments(table, res["mom_uf"], D, lower=False)
+        for i in range(C):
+            gt[i, i, :, 0] += self.jitter * res["trGA"] * zc[i] / M          # jitter * mean(diag Kuu), gpr/model.py:244
+        self.kernel._spectral_backward(-gt)
+        # - 1/(2 s2) sum_k Kff_diag[k]  (gpr/model.py:723): K_diag is constant per channel
+        self.kernel._spectral_diag_backward(0.5 * xc / s2, D)
+        scale = self.likelihood.scale
+        scale.grad = np.reshape(-res["dsigma"], scale.data.shape) * scale.dconstrained()
+        gz = np.zeros(self.Z.data.shape)
+        off = 0 if self.kernel.output_dims is None else 1
+        gz[:, off:] = -res["gZ"]
+        self.Z.grad = gz
+        return np.float64(-res["elbo"] - self.log_prior())
+
+    def predict_f(self, X, full=False):
+        """reference gpr/model.py:730-765"""
+        if full:
+            raise NotImplementedError("full predictive covariance for Titsias is not on the HIP path")
+        X = self._check_input(X)
+        h = self._device_handle()
+        D = self.X.shape[1] - (0 if self.kernel.output_dims is None else 1)
+        h.set_terms(self.kernel._spectral_terms(D))
+        mu, var = h.titsias_predict(self.kernel._kernel_format(self.Z()), self._sigma(), self.jitter,
+                                    self.kernel._kernel_format(X), self.kernel._spectral_diag(D))
         if self.mean is not None:
             mu = mu + np.asarray(self.mean(X)).reshape(-1, 1)
         return mu, var

@@ -49,6 +49,10 @@ class IndependentMultiOutputKernel(MultiOutputKernel):
     def _spectral_diag(self, D):
         return np.array([k._spectral_diag(D)[0] for k in self.kernels])   # reference :36-39
 
+    def _spectral_diag_backward(self, gc, D):
+        for c, k in enumerate(self.kernels):
+            k._spectral_diag_backward(np.array([gc[c]]), D)
+
     def _spectral_backward(self, gtable):
         D = (gtable.shape[3] - 2) // 3
         for c, k in enumerate(self.kernels):

@@ -294,21 +294,25 @@ class ParameterHolder:
         object.__setattr__(self, name, val)
 
     def parameters(self):
-        """All Parameters in registration order (pegged parameters are not in the graph and get no grad)."""
+        """All Parameters in torch.nn.Module.parameters() order: the holder's own Parameters first (registration
+        order), then those of its sub-holders (registration order, recursively)."""
         seen = set()
-        for name in self.__dict__.get("_order", []):
+        order = self.__dict__.get("_order", [])
+        for name in order:
             val = self.__dict__[name]
+            if isinstance(val, Parameter) and id(val) not in seen:
+                seen.add(id(val))
+                yield val
+        for name in order:
+            val = self.__dict__[name]
+            if isinstance(val, Parameter):
+                continue
             items = val if isinstance(val, (list, tuple)) else [val]
             for item in items:
-                if isinstance(item, Parameter):
-                    if id(item) not in seen:
-                        seen.add(id(item))
-                        yield item
-                else:
-                    for p in item.parameters():
-                        if id(p) not in seen:
-                            seen.add(id(p))
-                            yield p
+                for p in item.parameters():
+                    if id(p) not in seen:
+                        seen.add(id(p))
+                        yield p
 
     def zero_grad(self, set_to_none=True):
         for p in self.parameters():

@@ -43,6 +43,9 @@ class SpectralMixtureKernel(Kernel):
     def _spectral_diag(self, D):
         return np.array([np.sum(self.magnitude())])                      # reference :602-605 (not x D)
 
+    def _spectral_diag_backward(self, gc, D):
+        _accumulate(self.magnitude, np.full(self.magnitude.shape, float(gc[0])))
+
     def _spectral_backward(self, gtable):
         D = self.input_dims
         Q = self.magnitude.shape[0]
@@ -75,6 +78,9 @@ class SpectralKernel(Kernel):
 
     def _spectral_diag(self, D):
         return np.array([float(self.magnitude())])                       # reference :558-561
+
+    def _spectral_diag_backward(self, gc, D):
+        _accumulate(self.magnitude, np.reshape(float(gc[0]), self.magnitude.shape))
 
     def _spectral_backward(self, gtable):
         D = self.input_dims

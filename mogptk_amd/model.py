@@ -57,6 +57,28 @@ class Exact:
         return gpr.Exact(kernel, x, y, variance=variance, data_variance=data_variance, jitter=self.jitter, mean=mean)
 
 
+class Titsias:
+    """
+    Sparse inference of Titsias 2009 (reference mogptk/model.py:140-157).
+
+    Args:
+        inducing_points (int, list): number of inducing points (PER CHANNEL for multi-output kernels) or locations.
+        init_inducing_points (str): `grid`, `random`, or `density`.
+        variance (float): variance of the Gaussian likelihood.
+        jitter (float): relative jitter added before the Cholesky.
+    """
+
+    def __init__(self, inducing_points=10, init_inducing_points="grid", variance=1.0, jitter=1e-6):
+        self.inducing_points = inducing_points
+        self.init_inducing_points = init_inducing_points
+        self.variance = variance
+        self.jitter = jitter
+
+    def _build(self, kernel, x, y, y_err=None, mean=None):
+        return gpr.Titsias(kernel, x, y, Z=self.inducing_points, Z_init=self.init_inducing_points,
+                           variance=self.variance, jitter=self.jitter, mean=mean)
+
+
 # ---- optimisers over raw parameters (torch.optim semantics) -----------------------------------------
 class _Adam:
     """torch.optim.Adam(params, lr=1e-3, betas=(0.9,0.999), eps=1e-8, weight_decay=0, amsgrad=False)"""

@@ -113,3 +113,120 @@ class TableDevice:
         cs = Xs[:, 0].astype(np.int64)
         kdiag = np.asarray(kss_diag)[cs]
         return mu, (kdiag - np.sum(v * v, axis=0)).reshape(-1, 1)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Titsias sparse bound from the term table (what mogp_titsias_eval computes) -- reference gpr/model.py:700-724.
+# Whitened forms:  A = Kuu + jitter*mean(diag Kuu) I = Luu Luu^T, W = Luu^-1, v = W Kuf, Q = v v^T, Qs = Q/s2 + I = Lq Lq^T,
+# Pq = Qs^-1, R = I - Pq = Pq Q / s2, beta = W^T Pq v y.
+#   dELBO/dKuf = W^T (R v)/s2 + beta (y/s2^2 - Kuf^T beta/s2^3)^T
+#   dELBO/dA   = 1/2 W^T (R - Q/s2) W - 1/2 beta beta^T / s2^2
+# ----------------------------------------------------------------------------------------------------------------
+def _jr_block(tab, x1, x2):
+    """J_ab,d = d K_ab / d x1_a,d = sum_t A E [ -V_d u_d cos - 2 pi M_d sin ]   (n1, n2, D)"""
+    D = x1.shape[1]
+    A, V, M = tab[:, 0], tab[:, 2:2 + D], tab[:, 2 + D:2 + 2 * D]
+    Ec, Es, u = table_block(tab, x1, x2)
+    return np.einsum("t,tnm,tnmd,td->nmd", A, Ec, u, -V) + np.einsum("t,tnm,td->nmd", A, Es, -TWO_PI * M)
+
+
+def moments_dense(table, G, X1, X2, sym):
+    """moments of a dense adjoint G (rows X1, cols X2).  sym: lower channel pairs with the symmetric double count
+    (G symmetric, X2 is X1) -> (P, T, W); otherwise all ordered pairs -> (C*C, T, W)."""
+    C, T = table.shape[0], table.shape[2]
+    D = X1.shape[1] - 1
+    c1, c2 = X1[:, 0].astype(np.int64), X2[:, 0].astype(np.int64)
+    out = np.zeros(((C * (C + 1) // 2) if sym else C * C, T, 2 + 3 * D))
+    for i in range(C):
+        ri = np.nonzero(c1 == i)[0]
+        for j in range((i + 1) if sym else C):
+            rj = np.nonzero(c2 == j)[0]
+            if len(ri) == 0 or len(rj) == 0:
+                continue
+            Ec, Es, u = table_block(table[i, j], X1[ri, 1:], X2[rj, 1:])
+            g = G[np.ix_(ri, rj)] * (2.0 if (sym and i != j) else 1.0)
+            m = out[i * (i + 1) // 2 + j] if sym else out[i * C + j]
+            m[:, 0] = np.einsum("nm,tnm->t", g, Ec)
+            m[:, 1] = np.einsum("nm,tnm->t", g, Es)
+            m[:, 2:2 + D] = np.einsum("nm,tnm,tnmd->td", g, Ec, u * u)
+            m[:, 2 + D:2 + 2 * D] = np.einsum("nm,tnm,tnmd->td", g, Ec, u)
+            m[:, 2 + 2 * D:] = np.einsum("nm,tnm,tnmd->td", g, Es, u)
+            if sym and i == j:          # odd-in-tau moments cancel over the full symmetric block
+                m[:, 1] = 0.0
+                m[:, 2 + D:2 + 2 * D] = 0.0
+    return out
+
+
+def titsias_eval(self, Z, sigma, jitter, kff_diag, grad=True):
+    from scipy.linalg import solve_triangular
+    X, y, table, C = self.X, self.y, self.table, self.C
+    N, M, D = X.shape[0], Z.shape[0], self.D
+    s2 = sigma * sigma
+    cz = Z[:, 0].astype(np.int64)
+    cx = X[:, 0].astype(np.int64)
+    Kuu = gram_from_table(table, Z)
+    jit = jitter * np.mean(np.diagonal(Kuu))
+    A = Kuu + jit * np.eye(M)
+    B = gram_from_table(table, Z, X)
+    Luu = np.linalg.cholesky(A)
+    W = solve_triangular(Luu, np.eye(M), lower=True)
+    v = W @ B
+    Q = v @ v.T
+    Lq = np.linalg.cholesky(Q / s2 + np.eye(M))
+    vy = v @ y
+    c = solve_triangular(Lq, vy, lower=True) / s2
+    kff = float(np.sum(np.asarray(kff_diag)[cx]))
+    elbo = (-0.5 * N * np.log(TWO_PI) - np.sum(np.log(np.diagonal(Lq))) - N * np.log(sigma) - 0.5 * (y.T @ y).item() / s2
+            + 0.5 * (c.T @ c).item() - 0.5 * (kff - np.trace(Q)) / s2)
+    if not grad:
+        return dict(elbo=elbo, jitter_abs=jit)
+    Lqi = solve_triangular(Lq, np.eye(M), lower=True)
+    Pq = Lqi.T @ Lqi
+    R = Pq @ Q / s2
+    beta = W.T @ (Pq @ vy)
+    r = y / s2 ** 2 - (B.T @ beta) / s2 ** 3
+    GB = W.T @ (R @ v) / s2 + beta @ r.T
+    GA = 0.5 * W.T @ (R - Q / s2) @ W - 0.5 * (beta @ beta.T) / s2 ** 2
+    GA = 0.5 * (GA + GA.T)
+    ds2 = (-0.5 * N / s2 + 0.5 * np.trace(Pq @ Q) / s2 ** 2 + 0.5 * (y.T @ y).item() / s2 ** 2
+           - (vy.T @ Pq @ vy).item() / s2 ** 3 + 0.5 * (vy.T @ Pq @ Q @ Pq @ vy).item() / s2 ** 4
+           + 0.5 * (kff - np.trace(Q)) / s2 ** 2)
+    mom_uu = moments_dense(table, GA, Z, Z, sym=True)
+    mom_uf = moments_dense(table, GB, Z, X, sym=False)
+    gZ = np.zeros((M, D))
+    for i in range(C):
+        ri = np.nonzero(cz == i)[0]
+        if len(ri) == 0:
+            continue
+        for j in range(C):
+            rj = np.nonzero(cx == j)[0]
+            if len(rj):
+                gZ[ri] += np.einsum("nm,nmd->nd", GB[np.ix_(ri, rj)], _jr_block(table[i, j], Z[ri, 1:], X[rj, 1:]))
+            zj = np.nonzero(cz == j)[0]
+            if len(zj):
+                gZ[ri] += 2.0 * np.einsum("nm,nmd->nd", GA[np.ix_(ri, zj)], _jr_block(table[i, j], Z[ri, 1:], Z[zj, 1:]))
+    return dict(elbo=elbo, jitter_abs=jit, mom_uu=mom_uu, mom_uf=mom_uf, gZ=gZ, trGA=float(np.trace(GA)),
+                dsigma=2.0 * sigma * ds2)
+
+
+def titsias_predict(self, Z, sigma, jitter, Xs, kss_diag):
+    """reference gpr/model.py:730-765"""
+    from scipy.linalg import solve_triangular
+    X, y, table = self.X, self.y, self.table
+    s2 = sigma * sigma
+    M = Z.shape[0]
+    Kuu = gram_from_table(table, Z)
+    A = Kuu + jitter * np.mean(np.diagonal(Kuu)) * np.eye(M)
+    Luu = np.linalg.cholesky(A)
+    v = solve_triangular(Luu, gram_from_table(table, Z, X), lower=True)
+    Lq = np.linalg.cholesky(v @ v.T / s2 + np.eye(M))
+    a = solve_triangular(Luu, gram_from_table(table, Z, Xs), lower=True)
+    b = solve_triangular(Lq, a, lower=True)
+    c = solve_triangular(Lq, v @ y, lower=True) / s2
+    mu = b.T @ c
+    var = np.asarray(kss_diag)[Xs[:, 0].astype(np.int64)] - np.sum(a * a, axis=0) + np.sum(b * b, axis=0)
+    return mu, var.reshape(-1, 1)
+
+
+TableDevice.titsias_eval = titsias_eval
+TableDevice.titsias_predict = titsias_predict

@@ -10,6 +10,8 @@ nothing of the reference travels.  Re-run:  python tests/golden/gen_golden.py [-
   adam_cfg1.npz airline-passengers SM(Q=3) Adam trajectory (BASELINE.json configs[0])
   cfg2.npz      [--full] MOSM C=4 Q=3 N=8192 LML + gradient (BASELINE.json configs[1]; ~20 s, 10 GB)
   cfg4.npz      [--full] CSM C=4 Q=3 N=16384 predict_f at 64 probe rows of S=4096 (configs[3]; ~40 s, 16 GB)
+  titsias.npz   small Titsias ELBO + gradients (kernel, scale, inducing points) + predict_f
+  cfg5.npz      [--full] Titsias MOSM C=4 Q=3 N=100000 M=2048 ELBO + gradient (configs[4]; ~60 s, 37 GB)
 """
 import os
 import sys
@@ -298,13 +300,68 @@ def gen_cfg4():
     print("cfg4.npz written (%.1f s)" % dt)
 
 
+
+def ref_titsias_mosm(X, y, h, C, Q, Z, Z_init="grid", jitter=1e-8, scale=None):
+    k = g.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=X.shape[1] - 1)
+    k.weight.assign(h["weight"]); k.mean.assign(h["mean"]); k.variance.assign(h["variance"])
+    k.delay.assign(h["delay"]); k.phase.assign(h["phase"])
+    s = float(np.mean(h["scale"])) if scale is None else scale
+    m = g.Titsias(k, T(X), T(y), Z=Z, Z_init=Z_init, variance=s ** 2, jitter=jitter)
+    m.likelihood.scale.assign(s)
+    return m
+
+
+def gen_titsias():
+    """small Titsias fixtures: ELBO, gradients of every parameter (kernel, scalar scale, inducing points Z incl. its
+    gradient-free channel column), predict_f; quirks Q5 (int = per channel) and Q6 (float32-rounded grid)."""
+    out = {}
+    cases = [(3, 2, 90, [4, 5, 3], False), (2, 3, 120, 6, True), (1, 2, 60, [7], False)]
+    out["ncases"] = np.array(len(cases))
+    for n, (C, Q, N, Zspec, shuffle) in enumerate(cases):
+        rng = np.random.default_rng(9000 + n)
+        X, y = small_data(N, C, 1, 9100 + n, shuffle)
+        h = dict(weight=rng.uniform(0.5, 1.5, (C, Q)), mean=rng.uniform(0.05, 0.5, (C, Q, 1)),
+                 variance=rng.uniform(0.05, 0.5, (C, Q, 1)), delay=rng.normal(0, 0.3, (C, Q, 1)),
+                 phase=rng.normal(0, 0.3, (C, Q)), scale=rng.uniform(0.1, 0.4, C))
+        m = ref_titsias_mosm(X, y, h, C, Q, Zspec)
+        pre = "c%d_" % n
+        out[pre + "meta"] = np.array([C, Q, 1, 1]); out[pre + "X"] = X; out[pre + "y"] = y
+        out[pre + "Zspec"] = np.atleast_1d(np.array(Zspec)); out[pre + "Zspec_is_int"] = np.array(isinstance(Zspec, int))
+        out[pre + "jitter"] = np.array(m.jitter)
+        out[pre + "elbo"] = np.array(float(m.log_marginal_likelihood()))
+        out[pre + "loss"] = np.array(float(m.loss()))
+        dump_params(pre, list(m.parameters()), out, with_grad=True)
+        Xs, _ = small_data(23, C, 1, 9200 + n, shuffle)
+        mu, var = m.predict_f(T(Xs))
+        out[pre + "Xs"] = Xs; out[pre + "mu"] = mu.numpy(); out[pre + "var"] = var.numpy()
+    np.savez_compressed(os.path.join(HERE, "titsias.npz"), **out)
+    print("titsias.npz written")
+
+
+def gen_cfg5():
+    import time
+    C, Q, N, M = 4, 3, 100000, 2048
+    X, y = synth.make_data(N, C)
+    h = synth.mosm_hypers(C, Q)
+    m = ref_titsias_mosm(X, y, h, C, Q, [M // C] * C)
+    t = time.time()
+    loss = float(m.loss())
+    dt = time.time() - t
+    out = {"meta": np.array([C, Q, 1, 1, N, M]), "loss": np.array(loss), "elbo": np.array(-loss), "seconds": np.array(dt),
+           "scale": np.array(float(np.mean(h["scale"])))}
+    dump_params("", list(m.parameters()), out, with_grad=True)
+    np.savez_compressed(os.path.join(HERE, "cfg5.npz"), **out)
+    print("cfg5.npz loss=%.10f (%.1f s)" % (loss, dt))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "quirks": gen_quirks}
-    full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4}
+    steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "quirks": gen_quirks,
+             "titsias": gen_titsias}
+    full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:
         {**steps, **full}[a.only]()
     else:

@@ -245,3 +245,79 @@ def test_edge_cases():
         assert np.max(np.abs(a["moments"] - b["moments"])) < 1e-9 * max(1.0, np.max(np.abs(b["moments"]))), N
     with pytest.raises(_lib.MogpError):
         _lib.ExactHandle(0, np.array([[2.0, 0.0]]), np.zeros(1), 2)     # channel id out of range
+
+
+def _titsias_from_fixture(fx, pre):
+    C, Q, D, Rq = [int(v) for v in fx[pre + "meta"]]
+    fp = fixture_params(fx, pre)
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=D)
+    Zspec = fx[pre + "Zspec"]
+    Zspec = int(Zspec[0]) if bool(fx[pre + "Zspec_is_int"]) else [int(z) for z in Zspec]
+    m = gpr.Titsias(k, fx[pre + "X"], fx[pre + "y"], Z=Zspec, variance=float(fp[-1]["cons"]) ** 2, jitter=float(fx[pre + "jitter"]))
+    load_raw(m.parameters(), fp)
+    return m, fp
+
+
+def test_titsias_matches_reference_fixtures():
+    fx = load("titsias.npz")
+    for n in range(int(fx["ncases"])):
+        pre = "c%d_" % n
+        m, fp = _titsias_from_fixture(fx, pre)
+        assert abs(float(m.log_marginal_likelihood()) - float(fx[pre + "elbo"])) < 1e-9 * abs(float(fx[pre + "elbo"]))
+        assert abs(float(m.loss()) - float(fx[pre + "loss"])) < 1e-9 * abs(float(fx[pre + "loss"]))
+        for p, f in zip(m.parameters(), fp):
+            if f["grad"] is None:
+                assert p.grad is None
+            else:
+                assert np.max(np.abs(p.grad - f["grad"])) <= 1e-7 * max(1.0, np.max(np.abs(f["grad"]))), (n, p._name, p.grad, f["grad"])
+        mu, var = m.predict_f(fx[pre + "Xs"])
+        assert relerr(mu, fx[pre + "mu"]) < 1e-8 and np.max(np.abs(var - fx[pre + "var"])) < 1e-8
+
+
+def test_titsias_device_raw_outputs_against_numpy_model():
+    rng = np.random.default_rng(11)
+    C, Q, N, M = 3, 2, 700, 150
+    X, y = synth.make_data(N - N % C, C)
+    X = X[rng.permutation(X.shape[0])]
+    y = rng.standard_normal(X.shape[0])
+    Z = np.concatenate([np.stack([np.full(M // C, float(c)), np.sort(rng.uniform(0, 100, M // C))], axis=1) for c in range(C)])
+    Z = Z[rng.permutation(Z.shape[0])]
+    h = synth.mosm_hypers(C, Q)
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
+    for name in ("weight", "mean", "variance", "delay", "phase"):
+        getattr(k, name).assign(h[name])
+    table = k._spectral_terms(1)
+    kd = k._spectral_diag(1)
+    dev = _lib.ExactHandle(0, X, y, C)
+    ref = TableDevice(0, X, y, C)
+    dev.set_terms(table); ref.set_terms(table)
+    a = dev.titsias_eval(Z, 0.3, 1e-6, kd, grad=True)
+    b = ref.titsias_eval(Z, 0.3, 1e-6, kd, grad=True)
+    assert abs(a["elbo"] - b["elbo"]) < 1e-9 * abs(b["elbo"])
+    for key in ("mom_uu", "mom_uf", "gZ"):
+        assert np.max(np.abs(a[key] - b[key])) < 1e-7 * np.max(np.abs(b[key])), (key, np.max(np.abs(a[key] - b[key])) / np.max(np.abs(b[key])))
+    assert abs(a["trGA"] - b["trGA"]) < 1e-7 * abs(b["trGA"]) and abs(a["dsigma"] - b["dsigma"]) < 1e-8 * abs(b["dsigma"])
+
+
+def test_cfg5_titsias_golden():
+    """BASELINE.json configs[4]: Titsias, MOSM C=4 Q=3, N=100000, M=2048 (= [512]*4, grid): ELBO and every gradient tensor
+    against the reference (north_star tolerance 1e-5 relative)."""
+    fx = load("cfg5.npz")
+    C, Q, D, Rq, N, M = [int(v) for v in fx["meta"]]
+    X, y = synth.make_data(N, C)
+    h = synth.mosm_hypers(C, Q)
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
+    for name in ("weight", "mean", "variance", "delay", "phase"):
+        getattr(k, name).assign(h[name])
+    s = float(fx["scale"])
+    m = gpr.Titsias(k, X, y, Z=[M // C] * C, variance=s ** 2)
+    m.likelihood.scale.assign(s)
+    fp = fixture_params(fx)
+    for p, f in zip(m.parameters(), fp):
+        assert np.max(np.abs(p.data - f["raw"])) < 1e-12 * max(1.0, np.max(np.abs(f["raw"]))), p._name
+        p.data = np.array(f["raw"])
+    loss = float(m.loss())
+    assert abs(loss - float(fx["loss"])) < 1e-7 * abs(float(fx["loss"])), (loss, float(fx["loss"]))
+    for p, f in zip(m.parameters(), fp):
+        err = np.max(np.abs(p.grad - f["grad"])) / np.max(np.abs(f["grad"]))
+        assert err < 1e-5, (p._name, err)

@@ -154,3 +154,46 @@ def test_unsupported_paths_fail_loudly():
     k = gpr.MultiOutputSpectralMixtureKernel(Q=1, output_dims=2) * gpr.MultiOutputSpectralMixtureKernel(Q=1, output_dims=2)
     with pytest.raises(NotImplementedError):
         k._spectral_terms(1)
+
+
+def _titsias_from_fixture(fx, pre):
+    C, Q, D, Rq = [int(v) for v in fx[pre + "meta"]]
+    fp = fixture_params(fx, pre)
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=D)
+    Zspec = fx[pre + "Zspec"]
+    Zspec = int(Zspec[0]) if bool(fx[pre + "Zspec_is_int"]) else [int(z) for z in Zspec]
+    m = gpr.Titsias(k, fx[pre + "X"], fx[pre + "y"], Z=Zspec, variance=float(fp[-1]["cons"]) ** 2, jitter=float(fx[pre + "jitter"]))
+    return m, fp
+
+
+def test_titsias_bound_gradient_and_quirks_q5_q6():
+    """config 5's model class at fixture size: inducing-point initialisation (int = per channel, float32-rounded grid),
+    parameter order (Z first, like torch.nn.Module.parameters()), ELBO, every gradient incl. dZ and dsigma, predict_f"""
+    fx = load("titsias.npz")
+    for n in range(int(fx["ncases"])):
+        pre = "c%d_" % n
+        m, fp = _titsias_from_fixture(fx, pre)
+        assert [p._name.split(".")[-1] for p in m.parameters()] == [f["name"].split(".")[-1] for f in fp]
+        assert np.array_equal(m.Z.data, fp[0]["raw"])                                  # Q5 + Q6
+        load_raw(m.parameters(), fp)
+        assert abs(float(m.log_marginal_likelihood()) - float(fx[pre + "elbo"])) < 1e-9 * abs(float(fx[pre + "elbo"]))
+        assert abs(float(m.loss()) - float(fx[pre + "loss"])) < 1e-9 * abs(float(fx[pre + "loss"]))
+        for p, f in zip(m.parameters(), fp):
+            if f["grad"] is None:
+                assert p.grad is None, p._name
+            else:
+                assert np.max(np.abs(p.grad - f["grad"])) <= 1e-8 * max(1.0, np.max(np.abs(f["grad"]))), p._name
+        assert np.all(m.Z.grad[:, 0] == 0.0)                                            # gradient-free channel column
+        mu, var = m.predict_f(fx[pre + "Xs"])
+        assert relerr(mu, fx[pre + "mu"]) < 1e-9 and np.max(np.abs(var - fx[pre + "var"])) < 1e-9
+
+
+def test_titsias_through_the_model_wrapper():
+    t = np.linspace(0, 10, 40)
+    ds = mogptk_amd.DataSet(t, [np.sin(t), np.cos(t)])
+    m = mogptk_amd.MOSM(ds, Q=2, inference=mogptk_amd.Titsias(inducing_points=5, variance=0.05))
+    assert m.gpr.Z().shape == (10, 2)                                                  # 5 per channel (quirk Q5)
+    m.gpr.kernel.mean.assign(np.full((2, 2, 1), 0.1))
+    losses, _ = m.train("Adam", iters=3, lr=0.05)
+    assert losses.shape == (4,) and np.all(np.isfinite(losses))
+    assert m.num_parameters() == sum(p.num_parameters for p in m.parameters())        # Z counts without its channel column
