@@ -78,6 +78,34 @@ def cpu_baseline(N, C, Q, budget_s=45.0):
                 sample="1 eval at N=%d took %.1f s; extrapolated to N=%d by N^3 (x%.0f)" % (n, t, N, scale))
 
 
+def timed_region(step, steps, warmup, dist=None, sync=lambda: None, device="cpu"):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on both sides; returns the MAX
+    over ranks of the elapsed wall time (seconds).  `dist` is torch.distributed (initialised) or None."""
+    import torch
+    for _ in range(warmup):
+        step(-1)
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    sync()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt
+
+
+def aggregate_value(world, steps, dt):
+    """whole-job evals/s: every rank ran `steps` evaluations of its own replica in `dt` (max over ranks)"""
+    return world * steps / dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,36 +139,29 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(a.warmup):
-        m.loss()
+    m.loss()                      # creates the device handle (X, y resident in HBM) before anything is timed
     h = m._handle
     stage = np.zeros(_lib.ST_COUNT)
-    gemm_flops = 0.0
-    gemm_launches = 0
+    acc = dict(flops=0.0, launches=0, nprof=0)
     PROFILE_EVERY = 4           # HIP events around every GEMM launch cost ~5 %: sample one step in four, inside the timed region
-    nprof = 0
-    barrier(); sync()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        prof = (i % PROFILE_EVERY) == 0
+
+    def step(i):
+        prof = i >= 0 and (i % PROFILE_EVERY) == 0
         h.set_profiling(prof)
         m.loss()
         if prof:
             ms, nl, fl = h.stage_ms()
-            stage += ms
-            gemm_flops += fl
-            gemm_launches += nl
-            nprof += 1
-    sync(); barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+            stage[:] += ms
+            acc["flops"] += fl
+            acc["launches"] += nl
+            acc["nprof"] += 1
+
+    dt = timed_region(step, a.steps, a.warmup, dist, sync, "cuda" if dist is not None else "cpu")
+    gemm_flops, gemm_launches, nprof = acc["flops"], acc["launches"], max(acc["nprof"], 1)
 
     if rank == 0:
         ms_per_step = 1e3 * dt / a.steps
-        value = world * a.steps / dt
+        value = aggregate_value(world, a.steps, dt)
         gemm_s = stage[_lib.ST_GEMM_KERNEL] * 1e-3
         achieved = gemm_flops / gemm_s / 1e12 if gemm_s > 0 else 0.0
         N = a.n

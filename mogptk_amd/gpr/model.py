@@ -293,16 +293,16 @@ class Exact(Model):
 # ---- inducing-point initialisation (reference gpr/model.py:11-69) ---------------------------------------------------
 def _linspace_f32(lo, hi, n):
     """torch.linspace(lo, hi, n) in the reference runs in torch's default dtype float32 (quirk Q6, gpr/model.py:18):
-    step = (end - start)/(n - 1) in float32, first half start + i*step, second half end - (n-1-i)*step."""
+    step = (end - start)/(n - 1) rounded to float32; first half start + i*step, second half end - (n-1-i)*step, each
+    multiply-add rounded ONCE to float32 (torch's kernel fuses it; verified bit-exact against torch.linspace)."""
     start, end = np.float32(lo), np.float32(hi)
     if n == 1:
         return np.array([start], dtype=np.float64)
-    step = np.float32((end - start) / np.float32(n - 1))
-    out = np.empty(n, dtype=np.float32)
+    step = np.float64(np.float32((end - start) / np.float32(n - 1)))
+    i = np.arange(n)
     half = n // 2
-    for i in range(n):
-        out[i] = start + step * np.float32(i) if i < half else end - step * np.float32(n - i - 1)
-    return out.astype(np.float64)
+    out = np.where(i < half, np.float64(start) + step * i, np.float64(end) - step * (n - i - 1))
+    return out.astype(np.float32).astype(np.float64)
 
 
 def _init_grid(N, X):
