@@ -56,7 +56,7 @@ struct P1Step<16> {
 };
 
 __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, double* invd, double* logdet,
-                                                 unsigned long long* info) {
+                                                 unsigned long long* info, long long info_base) {
     extern __shared__ __attribute__((aligned(16))) double lf[];
     double* M = lf;                       // 36 packed lower blocks
     double* invdiag = lf + LF_MAT;        // [128]  1 / L_kk
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, d
         __syncthreads();
         if (tid == 0) {
             logdet[t] = red[0] + red[1];
-            if (fail >= 0) atomicMin(info, (unsigned long long)((int64_t)t * MOGP_TILE + fail + 1));
+            if (fail >= 0) atomicMin(info, (unsigned long long)(info_base + (int64_t)t * MOGP_TILE + fail + 1));
         }
     }
     for (int it = 0; it < 32; ++it) {
@@ -210,13 +210,14 @@ __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, d
     }
 }
 
-int launch_potrf_trtri_tile(double* A, int64_t ld, int t, double* invd, double* logdet, unsigned long long* info, hipStream_t s) {
+int launch_potrf_trtri_tile(double* A, int64_t ld, int t, double* invd, double* logdet, unsigned long long* info, hipStream_t s,
+                            long long info_base) {
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_leaf128), hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_leaf128, dim3(1), dim3(256), LF_LDS_BYTES, s, A, ld, t, invd, logdet, info);
+    hipLaunchKernelGGL(k_leaf128, dim3(1), dim3(256), LF_LDS_BYTES, s, A, ld, t, invd, logdet, info, info_base);
     HIP_TRY(hipGetLastError());
     return 0;
 }

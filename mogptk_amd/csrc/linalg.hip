@@ -331,6 +331,33 @@ int launch_row_sqnorm_sub(const double* M, int64_t ld, int64_t rows, int64_t n, 
     return 0;
 }
 
+__global__ void k_symv_combine(int64_t n, const double* a, const double* b, const double* A, int64_t ld, const double* y, double sign, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = sign * (a[i] + b[i] - A[i * ld + i] * y[i]);
+}
+int launch_symv_lower(const double* A, int64_t ld, int64_t n, const double* y, double* out, double* scratch, double sign, hipStream_t s) {
+    double* z1 = scratch;                 // tril(A) y            [n] (+ n/4 partials behind it, unused here)
+    double* zz = scratch + n;             // [n/4 + 1]
+    double* z2 = scratch + 2 * n;         // tril(A)^T y          [n] + row-chunk partials
+    int rc;
+    if ((rc = launch_trmv_lower(A, ld, n, y, z1, zz, s))) return rc;
+    if ((rc = launch_trmv_lower_t(A, ld, n, y, z2, s))) return rc;
+    hipLaunchKernelGGL(k_symv_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, z1, z2, A, ld, y, sign, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+__global__ void k_copy2d(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t cols, double scale) {
+    const int64_t r = blockIdx.x;
+    for (int64_t c = threadIdx.x; c < cols; c += blockDim.x) dst[r * ldd + c] = scale * src[r * lds + c];
+}
+int launch_copy2d(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols, double scale, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return 0;
+    hipLaunchKernelGGL(k_copy2d, dim3((unsigned)rows), dim3(256), 0, s, dst, ldd, src, lds, cols, scale);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 __global__ void k_add_diag(double* A, int64_t ld, int64_t n, double val) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) A[i * ld + i] += val;

@@ -18,7 +18,8 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
     g_err = std::string("HIP error '") + hipGetErrorString(e) + "' in " + what + " (" + file + ":" + std::to_string(line) + ")";
     return MOGP_EHIP;
 }
-int launch_potrf_trtri_tile(double* A, int64_t ld, int t, double* invd, double* logdet, unsigned long long* info, hipStream_t s);
+int launch_potrf_trtri_tile(double* A, int64_t ld, int t, double* invd, double* logdet, unsigned long long* info, hipStream_t s,
+                            long long info_base = 0);
 
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
@@ -203,7 +204,7 @@ namespace mogp { int mark(mogp_model* m, int idx) {
 
 // Cholesky of w.A (lower) in place; w.invd gets the inverses of the diagonal 128-tiles, w.logdet the per-tile sums of
 // log L_kk; a non-positive pivot is reported through m->d_info (atomicMin of the 1-based index).
-namespace mogp { int spd_potrf(mogp_model* m, Spd& w) {
+namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base) {
     int rc;
     // ---- two-level blocked right-looking Cholesky with look-ahead.
     // Outer blocks of MOGP_OUTER tiles.  "chain(kb)" = for each 128-column of the block: leaf (factor + inverse) -> panel =
@@ -224,7 +225,7 @@ namespace mogp { int spd_potrf(mogp_model* m, Spd& w) {
     for (int kb = 0; kb < nouter; ++kb) {
         const int k0 = kb * MOGP_OUTER, k1 = std::min(k0 + MOGP_OUTER, nb);
         for (int k = k0; k < k1; ++k) {
-            if ((rc = launch_potrf_trtri_tile(w.A.p, w.Npad, k, w.invd.p, w.logdet.p, m->d_info.p, m->st))) return rc;
+            if ((rc = launch_potrf_trtri_tile(w.A.p, w.Npad, k, w.invd.p, w.logdet.p, m->d_info.p, m->st, info_base))) return rc;
             const int rem = nb - k - 1;
             if (rem <= 0) break;
             double* panel = w.A.p + (int64_t)(k + 1) * MOGP_TILE * w.Npad + (int64_t)k * MOGP_TILE;
@@ -438,6 +439,73 @@ static void collect_timing(mogp_model* m, int last_mark) {
     m->ms[MOGP_ST_GEMM_KERNEL] = gsum;
 }
 
+// Gradient evaluation on the sweep inversion: Gram -> A = -Kj^-1 (one sweep) -> alpha, LML.  On return m->k.A holds -Kj^-1.
+static int eval_sweep(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
+                      double* lml, double* jitter_abs, int64_t* info) {
+    const int C = m->C, D = m->D;
+    const int64_t N = m->N, Npad = m->Npad;
+    if (m->T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms must be called before an evaluation");
+    if (!noise_var) return fail(MOGP_EINVAL, "noise_var is null");
+    m->have_W = m->have_Kinv = false;
+    m->gemm_ev_used = 0; m->gemm_launches = 0; m->gemm_flops = 0.0;
+    double dsum = 0.0;
+    for (int c = 0; c < C; ++c) dsum += (double)(m->sx.off[c + 1] - m->sx.off[c]) * (table_diag(m, c) + noise_var[c]);
+    std::vector<double> dv;
+    if (data_var) {
+        dv.resize(Npad, 0.0);
+        for (int64_t pos = 0; pos < N; ++pos) { dv[pos] = data_var[m->sx.perm[pos]]; dsum += dv[pos]; }
+        { int r__ = m->d_dvar.ensure(Npad); if (r__) return r__; }
+        HIP_TRY(hipMemcpyAsync(m->d_dvar.p, dv.data(), Npad * sizeof(double), hipMemcpyHostToDevice, m->st));
+    }
+    const double jabs = jitter * dsum / (double)N;
+    if (jitter_abs) *jitter_abs = jabs;
+    HIP_TRY(hipMemcpyAsync(m->d_noise.p, noise_var, C * sizeof(double), hipMemcpyHostToDevice, m->st));
+    const unsigned long long big = std::numeric_limits<unsigned long long>::max();
+    HIP_TRY(hipMemcpyAsync(m->d_info.p, &big, sizeof(big), hipMemcpyHostToDevice, m->st));
+    int rc;
+    if ((rc = mark(m, 0))) return rc;
+    GramArgs ga{};
+    ga.tiles = m->d_tiles.p; ga.xr = m->d_x.p; ga.xc = m->d_x.p; ga.ldxr = ga.ldxc = Npad;
+    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C;
+    ga.out = m->k.A.p; ga.ldo = Npad; ga.noise = m->d_noise.p; ga.dvar = data_var ? m->d_dvar.p : nullptr;
+    ga.jitter_abs = jabs; ga.mirror = 0;
+    if ((rc = launch_gram(ga, (int)m->tiles.size(), m->st))) return rc;
+    if ((rc = launch_pad_identity(m->k.A.p, Npad, N, Npad, m->st))) return rc;
+    if ((rc = mark(m, 1))) return rc;
+    if ((rc = spd_sweep(m, m->k))) return rc;
+    if ((rc = mark(m, 2))) return rc;
+    if ((rc = mark(m, 3))) return rc;
+    const int nchunks = (int)((Npad + 511) / 512);
+    if ((rc = m->d_symv.ensure((size_t)(4 + nchunks) * Npad))) return rc;
+    if ((rc = launch_symv_lower(m->k.A.p, Npad, Npad, m->d_y.p, m->d_alpha.p, m->d_symv.p, -1.0, m->st))) return rc;
+    if ((rc = mark(m, 4))) return rc;
+    const int nb = m->nb;
+    std::vector<double> hl(nb), ha(Npad);
+    unsigned long long hinfo = 0;
+    HIP_TRY(hipMemcpyAsync(hl.data(), m->k.logdet.p, nb * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipMemcpyAsync(ha.data(), m->d_alpha.p, Npad * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipMemcpyAsync(&hinfo, m->d_info.p, sizeof(hinfo), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    if (hinfo != big) {
+        if (info) *info = (int64_t)hinfo;
+        int flag = 0;
+        HIP_TRY(hipMemsetAsync(m->d_flag.p, 0, sizeof(int), m->st));
+        if ((rc = launch_gram(ga, (int)m->tiles.size(), m->st))) return rc;
+        if ((rc = launch_nonfinite_scan(m->k.A.p, Npad, N, m->d_flag.p, m->st))) return rc;
+        HIP_TRY(hipMemcpyAsync(&flag, m->d_flag.p, sizeof(int), hipMemcpyDeviceToHost, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));
+        if (flag & 1) return fail(MOGP_ENONFINITE, "linalg.cholesky: kernel matrix has NaNs!");
+        if (flag & 2) return fail(MOGP_ENONFINITE, "linalg.cholesky: kernel matrix has infinities!");
+        return fail(MOGP_ENOTPD, "linalg.cholesky: The factorization could not be completed because the input is not "
+                                 "positive-definite (the leading minor of order " + std::to_string(hinfo) + " is not positive-definite).");
+    }
+    double logdet = 0.0, ya = 0.0;
+    for (double v : hl) logdet += v;
+    for (int64_t i = 0; i < N; ++i) ya += m->hy[i] * ha[i];
+    if (lml) *lml = -0.5 * (double)N * std::log(2.0 * M_PI) - logdet - 0.5 * ya;
+    return 0;
+}
+
 extern "C" {
 
 int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, const double* y, mogp_model** out) {
@@ -493,7 +561,10 @@ int mogp_model_destroy(mogp_model* m) {
     for (auto e : m->ev) { hipError_t r = hipEventDestroy(e); (void)r; }
     for (auto e : m->gemm_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
     if (m->st2) { hipError_t e = hipStreamSynchronize(m->st2); (void)e; e = hipStreamDestroy(m->st2); (void)e; }
-    m->k.release();
+    m->k.release(); m->ws.release(); m->ws_tail.release();
+    for (int b = 0; b < 2; ++b) { m->swU[b].release(); m->swUr[b].release(); }
+    for (auto e : m->sw_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
+    m->d_symv.release();
     if (m->tw) { m->tw->release(); delete m->tw; m->tw = nullptr; }
     m->d_x.release(); m->d_y.release(); m->d_table.release();
     m->d_noise.release(); m->d_dvar.release(); m->d_z.release(); m->d_alpha.release(); m->d_zz.release();
@@ -513,6 +584,7 @@ int mogp_model_set_y(mogp_model* m, const double* y) {
     std::vector<double> ys(m->Npad, 0.0);
     for (int64_t pos = 0; pos < m->N; ++pos) ys[pos] = y[m->sx.perm[pos]];
     HIP_TRY(hipMemcpy(m->d_y.p, ys.data(), m->Npad * sizeof(double), hipMemcpyHostToDevice));
+    m->hy = ys;
     return MOGP_OK;
 }
 
@@ -539,23 +611,31 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     int rc;
     if ((rc = use_device(m->ctx))) return rc;
     if (info) *info = 0;
-    if ((rc = factorize(m, noise_var, data_var, jitter, lml, jitter_abs, info))) return rc;
+    // MOGP_GRAD_PATH=sweep selects the single-sweep blocked inversion (sweep.hip) instead of POTRF -> TRTRI -> LAUUM.  On one
+    // GPU the three-phase path is faster (59 vs 47 evals/s at cfg2: the 512-block inversion chain is not hidden); the sweep needs
+    // one panel exchange per block, which is what a sharded multi-GPU evaluation wants.
+    static const bool use_sweep = []() { const char* e = std::getenv("MOGP_GRAD_PATH"); return e && std::string(e) == "sweep"; }();
+    const bool sweep = use_sweep && (flags & MOGP_EVAL_GRAD);
+    if (sweep) { if ((rc = eval_sweep(m, noise_var, data_var, jitter, lml, jitter_abs, info))) return rc; }
+    else if ((rc = factorize(m, noise_var, data_var, jitter, lml, jitter_abs, info))) return rc;
     if (!(flags & MOGP_EVAL_GRAD)) { collect_timing(m, 4); return MOGP_OK; }
     if (!moments || !diagG || !trG) return fail(MOGP_EINVAL, "mogp_exact_eval: gradient outputs are null");
 
     const int C = m->C, D = m->D, W = 2 + 3 * D, T = m->T, P = C * (C + 1) / 2;
     const int64_t Npad = m->Npad;
-    // K^-1 = W^T W (lower tiles, full diagonal tiles)
-    if ((rc = spd_lauum(m, m->k))) return rc;
+    // K^-1: the sweep left -Kj^-1 in k.A; the POTRF path needs W^T W (lower tiles, full diagonal tiles) in k.B
+    if (!sweep && (rc = spd_lauum(m, m->k))) return rc;
+    const double* kinv = sweep ? m->k.A.p : m->k.B.p;
+    const double ksign = sweep ? -1.0 : 1.0;
     if ((rc = mark(m, 5))) return rc;
 
     MomentArgs ma{};
     ma.tiles = m->d_tiles.p; ma.ntiles = (int)m->tiles.size(); ma.x = m->d_x.p; ma.ldx = Npad;
-    ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C; ma.kinv = m->k.B.p; ma.ld = Npad; ma.alpha = m->d_alpha.p;
+    ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C; ma.kinv = kinv; ma.kinv_sign = ksign; ma.ld = Npad; ma.alpha = m->d_alpha.p;
     ma.partial = m->d_partial.p;
     if ((rc = launch_moments(ma, m->st))) return rc;
     if ((rc = launch_moment_reduce(m->d_partial.p, m->d_pair_start.p, P, T, W, m->d_moments.p, m->st))) return rc;
-    if ((rc = launch_diagG(m->k.B.p, Npad, m->d_alpha.p, m->d_chan_off.p, C, m->d_diagG.p, m->st))) return rc;
+    if ((rc = launch_diagG(kinv, Npad, m->d_alpha.p, m->d_chan_off.p, C, m->d_diagG.p, m->st, ksign))) return rc;
     if ((rc = mark(m, 6))) return rc;
     HIP_TRY(hipMemcpyAsync(moments, m->d_moments.p, (size_t)P * T * W * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(diagG, m->d_diagG.p, C * sizeof(double), hipMemcpyDeviceToHost, m->st));
@@ -564,6 +644,7 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     for (int c = 0; c < C; ++c) tr += diagG[c];
     *trG = tr;
     m->have_Kinv = true;
+    m->kinv_in_A = sweep;
     collect_timing(m, 6);
     return MOGP_OK;
 }
@@ -723,7 +804,7 @@ int mogp_model_fetch(mogp_model* m, int which, double* out) {
     if ((rc = use_device(m->ctx))) return rc;
     const int64_t N = m->N, Npad = m->Npad;
     if (which == 2) {
-        if (!m->have_W) return fail(MOGP_EINVAL, "mogp_model_fetch: no evaluation has completed yet");
+        if (!m->have_W && !m->have_Kinv) return fail(MOGP_EINVAL, "mogp_model_fetch: no evaluation has completed yet");
         std::vector<double> h(Npad);
         HIP_TRY(hipMemcpy(h.data(), m->d_alpha.p, Npad * sizeof(double), hipMemcpyDeviceToHost));
         for (int64_t pos = 0; pos < N; ++pos) out[m->sx.perm[pos]] = h[pos];
@@ -733,7 +814,9 @@ int mogp_model_fetch(mogp_model* m, int which, double* out) {
     if (which == 1 && !m->have_Kinv) return fail(MOGP_EINVAL, "mogp_model_fetch: Kj^-1 needs an evaluation with MOGP_EVAL_GRAD");
     if (which != 0 && which != 1) return fail(MOGP_EINVAL, "mogp_model_fetch: which must be 0, 1 or 2");
     std::vector<double> h((size_t)Npad * Npad);
-    HIP_TRY(hipMemcpy(h.data(), which == 0 ? m->k.A.p : m->k.B.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const bool neg = (which == 1 && m->kinv_in_A);
+    HIP_TRY(hipMemcpy(h.data(), (which == 0 || neg) ? m->k.A.p : m->k.B.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (neg) for (auto& v : h) v = -v;
     for (int64_t a = 0; a < N; ++a)
         for (int64_t b = 0; b < N; ++b) {
             double v;

@@ -61,6 +61,7 @@ struct MomentArgs {
     const double* kinv;    // lower triangle valid, leading dimension ld
     int64_t ld;
     const double* alpha;   // [N]
+    double kinv_sign;      // +1: kinv holds Kj^-1; -1: it holds -Kj^-1 (result of the sweep inversion)
     // adjoint source, dense mode (G != null):  g = w * (G[a][b] + rcoef * ru[a] * rw[b])
     const double* G;
     int64_t ldg;
@@ -81,7 +82,8 @@ int launch_moments(const MomentArgs& a, hipStream_t s);
 int launch_moment_reduce(const double* partial, const int* pair_start, int npairs, int T, int W, double* out, hipStream_t s,
                          int lower_pairs = 1);
 // per-channel sum of G_kk = 1/2(alpha_k^2 - kinv_kk): out[c], chan_off device array [C+1]
-int launch_diagG(const double* kinv, int64_t ld, const double* alpha, const int* chan_off, int C, double* out, hipStream_t s);
+int launch_diagG(const double* kinv, int64_t ld, const double* alpha, const int* chan_off, int C, double* out, hipStream_t s,
+                 double kinv_sign = 1.0);
 
 // ---- dense linear algebra (fp64, MFMA) -------------------------------------------------------------
 enum GemmMode { GM_RECT = 0,      // mt x nt tiles, k in [0, K)
@@ -130,6 +132,10 @@ int launch_trmv_lower_t(const double* W, int64_t ld, int64_t n, const double* z,
 int launch_gemv_rows(const double* M, int64_t ld, int64_t rows, int64_t n, const double* v, double* out, hipStream_t s);
 // out[r] = base[r] - sum_k M[r][k]^2
 int launch_row_sqnorm_sub(const double* M, int64_t ld, int64_t rows, int64_t n, const double* base, double* out, hipStream_t s);
+// out = sign * (tril(A) y + strict_tril(A)^T y): symmetric mat-vec with a lower-stored matrix (scratch: (2 + n/512 + 1) * n doubles)
+int launch_symv_lower(const double* A, int64_t ld, int64_t n, const double* y, double* out, double* scratch, double sign, hipStream_t s);
+// dst[r][c] = scale * src[r][c]
+int launch_copy2d(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols, double scale, hipStream_t s);
 // A[i][i] += val for i < n
 int launch_add_diag(double* A, int64_t ld, int64_t n, double val, hipStream_t s);
 // upper triangle <- transpose of the lower triangle (n multiple of 64)

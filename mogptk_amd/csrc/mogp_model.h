@@ -100,7 +100,12 @@ struct mogp_model {
     hipStream_t st = nullptr;           // critical-path stream (high priority)
     hipStream_t st2 = nullptr;          // bulk trailing updates (look-ahead)
     Spd k;                              // the N x N system
+    Spd ws, ws_tail;                    // Schur-block workspaces of the sweep inversion (outer block / last partial block)
+    DevBuf<double> swU[2], swUr[2];     // old panels of the block being swept (column part, row part), double buffered
+    std::vector<hipEvent_t> sw_ev;
 
+    std::vector<double> hy;             // channel-sorted targets (host copy, Npad)
+    DevBuf<double> d_symv;
     DevBuf<double> d_x, d_y, d_table, d_noise, d_dvar, d_z, d_alpha, d_zz, d_partial, d_moments, d_diagG;
     DevBuf<GTile> d_tiles;
     DevBuf<int> d_pair_start, d_chan_off, d_flag;
@@ -118,7 +123,7 @@ struct mogp_model {
     double ms[MOGP_ST_COUNT] = {0};
     int64_t gemm_launches = 0;
     double gemm_flops = 0.0;
-    bool have_W = false, have_Kinv = false;
+    bool have_W = false, have_Kinv = false, kinv_in_A = false;
     TitsiasWork* tw = nullptr;
 };
 
@@ -129,7 +134,8 @@ int gemm_call(mogp_model* m, const GemmArgs& g, double flops, hipStream_t st = n
 int mark(mogp_model* m, int idx);
 double table_diag(const mogp_model* m, int c);
 int spd_alloc(Spd& w, int64_t Npad);
-int spd_potrf(mogp_model* m, Spd& w);
+int spd_potrf(mogp_model* m, Spd& w, long long info_base = 0);
 int spd_trtri(mogp_model* m, Spd& w);
 int spd_lauum(mogp_model* m, Spd& w);
+int spd_sweep(mogp_model* m, Spd& w);     // w.A (SPD, lower) -> -inverse (lower); w.logdet per tile; failure through m->d_info
 }  // namespace mogp

@@ -15,7 +15,8 @@
 #include <limits>
 
 namespace mogp {
-int launch_potrf_trtri_tile(double* A, int64_t ld, int t, double* invd, double* logdet, unsigned long long* info, hipStream_t s);
+int launch_potrf_trtri_tile(double* A, int64_t ld, int t, double* invd, double* logdet, unsigned long long* info, hipStream_t s,
+                            long long info_base = 0);
 }
 using namespace mogp;
 

@@ -333,3 +333,38 @@ def test_cfg5_titsias_golden():
             assert np.all(p.grad[:, 0] == 0.0)
         else:
             assert err < 1e-5, (p._name, err)          # measured <= 5.2e-7
+
+
+def test_sweep_inversion_path_matches_reference():
+    """the alternative gradient path (single-sweep blocked SPD inversion, MOGP_GRAD_PATH=sweep) against the same golden
+    vectors, in a fresh process because the path is chosen once per process"""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from helpers import load, product_exact, fixture_params
+        from mogptk_amd import gpr, synth
+        for name in ("mosm_c3q2", "mosm_c2q3_shuf", "csm_c3q2", "sm_c2q2_d2"):
+            fx = load("lml_%%s.npz" %% name)
+            m, fp = product_exact(fx)
+            assert abs(float(m.loss()) - float(fx["loss"])) < 1e-9 * abs(float(fx["loss"])), name
+            for p, f in zip(m.parameters(), fp):
+                if f["grad"] is not None:
+                    assert np.max(np.abs(p.grad - f["grad"])) <= 1e-7 * max(1.0, np.max(np.abs(f["grad"]))), (name, p._name)
+        fx = load("cfg2.npz")
+        C, Q, D, Rq, N = [int(v) for v in fx["meta"]]
+        X, y = synth.make_data(N, C); h = synth.mosm_hypers(C, Q)
+        k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
+        for n in ("weight", "mean", "variance", "delay", "phase"): getattr(k, n).assign(h[n])
+        m = gpr.Exact(k, X, y, variance=h["scale"] ** 2); m.likelihood.scale.assign(h["scale"])
+        fp = fixture_params(fx)
+        for p, f in zip(m.parameters(), fp): p.data = np.array(f["raw"])
+        assert abs(float(m.loss()) - float(fx["loss"])) < 1e-9 * abs(float(fx["loss"]))
+        for p, f in zip(m.parameters(), fp):
+            assert np.max(np.abs(p.grad - f["grad"])) / np.max(np.abs(f["grad"])) < 1e-5, p._name
+        print("SWEEP_OK")
+    ''') % (root, os.path.join(root, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, MOGP_GRAD_PATH="sweep"))
+    assert "SWEEP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
