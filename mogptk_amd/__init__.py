@@ -13,3 +13,4 @@ from .dataset import Data, DataSet, TransformBase
 from .model import Model, Exact, Titsias, LoadModel
 from .wrappers import MOSM, SM, CSM
 from . import gpr
+from .dist import use_distributed, use_single_device

@@ -45,6 +45,16 @@ SIGNATURES = {
                                          c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_i64p]),
     "mogp_titsias_predict": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, ctypes.c_double, ctypes.c_double, c_dp,
                                             ctypes.c_int64, c_dp, c_dp, c_dp, c_i64p]),
+    "mogp_shard_config": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "mogp_shard_begin": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.POINTER(ctypes.c_int)]),
+    "mogp_shard_pack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_i64p]),
+    "mogp_shard_unpack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "mogp_shard_row": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), c_i64p,
+                                      ctypes.POINTER(ctypes.c_int)]),
+    "mogp_shard_block": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "mogp_shard_alpha": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), c_i64p]),
+    "mogp_shard_finish": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_i64p]),
+    "mogp_dev_copy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]),
     "mogp_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "mogp_stage_ms": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i64p, c_dp]),
     "mogp_model_fetch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_dp]),
@@ -159,6 +169,10 @@ class ExactHandle:
         """-> dict(lml, moments[P,T,W], diagG[C], trG, jitter_abs)"""
         noise_var = _f64(noise_var)
         data_var = _f64(data_var)
+        from .gpr.config import config as _cfg
+        if grad and getattr(_cfg, "comm", None) is not None and _cfg.comm.world > 1:
+            from . import dist as _dist
+            return _dist.sharded_eval(self, _cfg.comm, noise_var, jitter, data_var)
         C, T, W = self.C, self.T, 2 + 3 * self.D
         lml = ctypes.c_double()
         trG = ctypes.c_double()
@@ -185,6 +199,63 @@ class ExactHandle:
                                         1 if full else 0, _dp(mu), _dp(var), ctypes.byref(info))
         check(code, info.value)
         return mu.reshape(-1, 1), (var if full else var.reshape(-1, 1))
+
+    # -- sharded evaluation stages (mogp_shard_*): buffers are raw device pointers, counts are in doubles ------------------
+    def shard_begin(self, rank, world, noise_var, jitter, data_var=None):
+        check(lib().mogp_shard_config(self._h, int(rank), int(world)))
+        jit, nblocks = ctypes.c_double(), ctypes.c_int()
+        check(lib().mogp_shard_begin(self._h, _dp(_f64(noise_var)), _dp(_f64(data_var)), float(jitter), ctypes.byref(jit), ctypes.byref(nblocks)))
+        return jit.value, nblocks.value
+
+    def shard_pack(self, kb):
+        send, recv, count = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64()
+        check(lib().mogp_shard_pack(self._h, kb, ctypes.byref(send), ctypes.byref(recv), ctypes.byref(count)))
+        return send.value, recv.value, count.value
+
+    def shard_unpack(self, kb):
+        check(lib().mogp_shard_unpack(self._h, kb))
+
+    def shard_pivot_rows(self, kb):
+        nb = -(-self.N // 128)
+        return 0 if kb == 0 else min(4, nb - 4 * kb)
+
+    def shard_row(self, kb, t, phase):
+        buf, count, owner = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int()
+        check(lib().mogp_shard_row(self._h, kb, t, phase, ctypes.byref(buf), ctypes.byref(count), ctypes.byref(owner)))
+        return buf.value, count.value, owner.value
+
+    def shard_block(self, kb):
+        check(lib().mogp_shard_block(self._h, kb))
+
+    def shard_alpha(self):
+        buf, count = ctypes.c_void_p(), ctypes.c_int64()
+        check(lib().mogp_shard_alpha(self._h, ctypes.byref(buf), ctypes.byref(count)))
+        return buf.value, count.value
+
+    def shard_finish(self):
+        C, T, W = self.C, self.T, 2 + 3 * self.D
+        lml, info = ctypes.c_double(), ctypes.c_int64(0)
+        moments, diagG = np.zeros((C * (C + 1) // 2, T, W)), np.zeros(C)
+        check(lib().mogp_shard_finish(self._h, ctypes.byref(lml), _dp(moments), _dp(diagG), ctypes.byref(info)), info.value)
+        return lml.value, moments, diagG
+
+    def mem_tensor(self, ptr, count):
+        import torch
+
+        class _Buf:            # __cuda_array_interface__ view of memory owned by the native library
+            pass
+        b = _Buf()
+        b.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(b, device="cuda")
+
+    def mem_get(self, ptr, count):
+        h = np.empty(int(count), dtype=np.float64)
+        check(lib().mogp_dev_copy(h.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), 8 * int(count), 0))
+        return h
+
+    def mem_put(self, ptr, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        check(lib().mogp_dev_copy(ctypes.c_void_p(ptr), arr.ctypes.data_as(ctypes.c_void_p), 8 * arr.size, 1))
 
     def titsias_eval(self, Z, sigma, jitter, kff_diag, grad=True):
         """Titsias bound (+ gradient outputs) through mogp_titsias_eval"""

@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void k_moments(MomentArgs a) {
                     v = a.G[hi * a.ldg + lo] + (a.ru ? ar * a.rw[c] : 0.0);
                 } else {
                     const int64_t hi = r > c ? r : c, lo = r > c ? c : r;
-                    v = 0.5 * (ar * a.alpha[c] - a.kinv_sign * a.kinv[hi * a.ld + lo]);
+                    if (a.row_mod > 1 && (int)((hi / MOGP_TILE) % a.row_mod) != a.row_rem) w = 0.0;       // row owned by another rank
+                    else v = 0.5 * (ar * a.alpha[c] - a.kinv_sign * a.kinv[hi * a.ld + lo]);
                 }
             }
             g[m][n] = w * v;
@@ -367,11 +368,12 @@ int launch_moment_reduce(const double* partial, const int* pair_start, int npair
 
 // out[c] = sum_{k in channel c} 1/2 (alpha_k^2 - kinv_kk); one workgroup per channel
 __global__ void k_diagG(const double* __restrict__ kinv, int64_t ld, const double* __restrict__ alpha,
-                        const int* __restrict__ chan_off, double* __restrict__ out, double kinv_sign) {
+                        const int* __restrict__ chan_off, double* __restrict__ out, double kinv_sign, int row_mod, int row_rem) {
     const int c = blockIdx.x;
     __shared__ double red[256];
     double s = 0.0;
-    for (int64_t k = chan_off[c] + threadIdx.x; k < chan_off[c + 1]; k += 256) s += 0.5 * (alpha[k] * alpha[k] - kinv_sign * kinv[k * ld + k]);
+    for (int64_t k = chan_off[c] + threadIdx.x; k < chan_off[c + 1]; k += 256)
+        if (row_mod <= 1 || (int)((k / MOGP_TILE) % row_mod) == row_rem) s += 0.5 * (alpha[k] * alpha[k] - kinv_sign * kinv[k * ld + k]);
     red[threadIdx.x] = s;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
@@ -382,8 +384,8 @@ __global__ void k_diagG(const double* __restrict__ kinv, int64_t ld, const doubl
 }
 
 int launch_diagG(const double* kinv, int64_t ld, const double* alpha, const int* chan_off, int C, double* out, hipStream_t s,
-                 double kinv_sign) {
-    hipLaunchKernelGGL(k_diagG, dim3(C), dim3(256), 0, s, kinv, ld, alpha, chan_off, out, kinv_sign);
+                 double kinv_sign, int row_mod, int row_rem) {
+    hipLaunchKernelGGL(k_diagG, dim3(C), dim3(256), 0, s, kinv, ld, alpha, chan_off, out, kinv_sign, row_mod, row_rem);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
         if (g.mode == GM_LOWER || g.mode == GM_LAUUM) { ti = tri_row(blockIdx.x); tj = blockIdx.x - ti * (ti + 1) / 2; }
         else { ti = blockIdx.x / g.nt; tj = blockIdx.x - ti * g.nt; }
         if (g.mode == GM_RECT_LOWER && (ti + 1) * TMR <= tj * TNC) return;        // tile entirely above the diagonal
+        if (g.row_mod > 1 && ((ti + g.row_off) % g.row_mod) != g.row_rem) return;  // tile row owned by another rank
         int64_t k0 = 0, k1 = g.K;
         if (g.mode == GM_LAUUM || g.mode == GM_KLO_I) k0 = (int64_t)ti * TMR;
         if (g.mode == GM_KLO_J) k0 = (int64_t)tj * TNC;
@@ -240,31 +241,34 @@ int launch_pad_identity(double* A, int64_t ld, int64_t N, int64_t Npad, hipStrea
 
 // z_i = sum_{k<=i} W[i][k] y[k]; one wave per row, 4 rows per workgroup; zz_partial[block] = sum of z_i^2 of its rows
 __global__ __launch_bounds__(256) void k_trmv_lower(const double* __restrict__ W, int64_t ld, int64_t n, const double* __restrict__ y,
-                                                    double* __restrict__ z, double* __restrict__ zz_partial) {
+                                                    double* __restrict__ z, double* __restrict__ zz_partial, int row_mod, int row_rem) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + wave;
     __shared__ double zz[4];
     double s = 0.0;
-    if (i < n) {
+    const bool mine = row_mod <= 1 || (int)((i / MOGP_TILE) % row_mod) == row_rem;
+    if (i < n && !mine && lane == 0) z[i] = 0.0;
+    if (i < n && mine) {
         const double* row = W + i * ld;
         for (int64_t k = lane; k <= i; k += 64) s = fma(row[k], y[k], s);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         if (lane == 0) z[i] = s;
     }
-    if (lane == 0) zz[wave] = (i < n) ? s * s : 0.0;
+    if (lane == 0) zz[wave] = (i < n && mine) ? s * s : 0.0;
     __syncthreads();
     if (threadIdx.x == 0) zz_partial[blockIdx.x] = (zz[0] + zz[1]) + (zz[2] + zz[3]);
 }
-int launch_trmv_lower(const double* W, int64_t ld, int64_t n, const double* y, double* z, double* zz_partial, hipStream_t s) {
-    hipLaunchKernelGGL(k_trmv_lower, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, W, ld, n, y, z, zz_partial);
+int launch_trmv_lower(const double* W, int64_t ld, int64_t n, const double* y, double* z, double* zz_partial, hipStream_t s,
+                      int row_mod, int row_rem) {
+    hipLaunchKernelGGL(k_trmv_lower, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, W, ld, n, y, z, zz_partial, row_mod, row_rem);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 // a_j = sum_{i>=j} W[i][j] z_i.  grid (column blocks of 64, row chunks of 512); partial[chunk][j]; fixed-order second pass.
 __global__ __launch_bounds__(256) void k_trmv_lower_t_part(const double* __restrict__ W, int64_t ld, int64_t n,
-                                                           const double* __restrict__ z, double* __restrict__ part) {
+                                                           const double* __restrict__ z, double* __restrict__ part, int row_mod, int row_rem) {
     const int64_t j = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
     const int sub = threadIdx.x >> 6;
     const int64_t r0 = (int64_t)blockIdx.y * 512, r1 = min(n, r0 + 512);
@@ -272,7 +276,8 @@ __global__ __launch_bounds__(256) void k_trmv_lower_t_part(const double* __restr
     double s = 0.0;
     if (j < n) {
         const int64_t start = max(r0, j);
-        for (int64_t i = start + sub; i < r1; i += 4) s = fma(W[i * ld + j], z[i], s);
+        for (int64_t i = start + sub; i < r1; i += 4)
+            if (row_mod <= 1 || (int)((i / MOGP_TILE) % row_mod) == row_rem) s = fma(W[i * ld + j], z[i], s);
     }
     red[sub][threadIdx.x & 63] = s;
     __syncthreads();
@@ -285,11 +290,11 @@ __global__ void k_sum_chunks(const double* __restrict__ part, int64_t n, int nch
     for (int c = (int)(j / 512); c < nchunks; ++c) s += part[(int64_t)c * n + j];
     out[j] = s;
 }
-int launch_trmv_lower_t(const double* W, int64_t ld, int64_t n, const double* z, double* a, hipStream_t s) {
+int launch_trmv_lower_t(const double* W, int64_t ld, int64_t n, const double* z, double* a, hipStream_t s, int row_mod, int row_rem) {
     // partial buffer lives right behind z's vector block: the caller passes `a` with room for (1 + nchunks) * n doubles
     const int nchunks = (int)((n + 511) / 512);
     double* part = a + n;
-    hipLaunchKernelGGL(k_trmv_lower_t_part, dim3((unsigned)((n + 63) / 64), (unsigned)nchunks), dim3(256), 0, s, W, ld, n, z, part);
+    hipLaunchKernelGGL(k_trmv_lower_t_part, dim3((unsigned)((n + 63) / 64), (unsigned)nchunks), dim3(256), 0, s, W, ld, n, z, part, row_mod, row_rem);
     hipLaunchKernelGGL(k_sum_chunks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, n, nchunks, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -331,18 +336,22 @@ int launch_row_sqnorm_sub(const double* M, int64_t ld, int64_t rows, int64_t n, 
     return 0;
 }
 
-__global__ void k_symv_combine(int64_t n, const double* a, const double* b, const double* A, int64_t ld, const double* y, double sign, double* out) {
+__global__ void k_symv_combine(int64_t n, const double* a, const double* b, const double* A, int64_t ld, const double* y, double sign, double* out,
+                               int row_mod, int row_rem) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = sign * (a[i] + b[i] - A[i * ld + i] * y[i]);
+    if (i >= n) return;
+    const bool mine = row_mod <= 1 || (int)((i / MOGP_TILE) % row_mod) == row_rem;      // the diagonal was counted twice only on its owner
+    out[i] = sign * (a[i] + b[i] - (mine ? A[i * ld + i] * y[i] : 0.0));
 }
-int launch_symv_lower(const double* A, int64_t ld, int64_t n, const double* y, double* out, double* scratch, double sign, hipStream_t s) {
+int launch_symv_lower(const double* A, int64_t ld, int64_t n, const double* y, double* out, double* scratch, double sign, hipStream_t s,
+                      int row_mod, int row_rem) {
     double* z1 = scratch;                 // tril(A) y            [n] (+ n/4 partials behind it, unused here)
     double* zz = scratch + n;             // [n/4 + 1]
     double* z2 = scratch + 2 * n;         // tril(A)^T y          [n] + row-chunk partials
     int rc;
-    if ((rc = launch_trmv_lower(A, ld, n, y, z1, zz, s))) return rc;
-    if ((rc = launch_trmv_lower_t(A, ld, n, y, z2, s))) return rc;
-    hipLaunchKernelGGL(k_symv_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, z1, z2, A, ld, y, sign, out);
+    if ((rc = launch_trmv_lower(A, ld, n, y, z1, zz, s, row_mod, row_rem))) return rc;
+    if ((rc = launch_trmv_lower_t(A, ld, n, y, z2, s, row_mod, row_rem))) return rc;
+    hipLaunchKernelGGL(k_symv_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, z1, z2, A, ld, y, sign, out, row_mod, row_rem);
     HIP_TRY(hipGetLastError());
     return 0;
 }

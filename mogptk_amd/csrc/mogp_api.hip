@@ -439,9 +439,9 @@ static void collect_timing(mogp_model* m, int last_mark) {
     m->ms[MOGP_ST_GEMM_KERNEL] = gsum;
 }
 
-// Gradient evaluation on the sweep inversion: Gram -> A = -Kj^-1 (one sweep) -> alpha, LML.  On return m->k.A holds -Kj^-1.
-static int eval_sweep(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
-                      double* lml, double* jitter_abs, int64_t* info) {
+// ---- gradient evaluation on the sweep inversion: Gram -> A = -Kj^-1 (one sweep) -> alpha, LML -------------------------
+// sweep_eval_begin: uploads, Gram (lower, noise + jitter on the diagonal), padding.  m->sh_jabs keeps the absolute jitter.
+static int sweep_eval_begin(mogp_model* m, const double* noise_var, const double* data_var, double jitter) {
     const int C = m->C, D = m->D;
     const int64_t N = m->N, Npad = m->Npad;
     if (m->T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms must be called before an evaluation");
@@ -450,15 +450,14 @@ static int eval_sweep(mogp_model* m, const double* noise_var, const double* data
     m->gemm_ev_used = 0; m->gemm_launches = 0; m->gemm_flops = 0.0;
     double dsum = 0.0;
     for (int c = 0; c < C; ++c) dsum += (double)(m->sx.off[c + 1] - m->sx.off[c]) * (table_diag(m, c) + noise_var[c]);
-    std::vector<double> dv;
+    m->sh_dvar = data_var != nullptr;
     if (data_var) {
-        dv.resize(Npad, 0.0);
+        std::vector<double> dv(Npad, 0.0);
         for (int64_t pos = 0; pos < N; ++pos) { dv[pos] = data_var[m->sx.perm[pos]]; dsum += dv[pos]; }
         { int r__ = m->d_dvar.ensure(Npad); if (r__) return r__; }
-        HIP_TRY(hipMemcpyAsync(m->d_dvar.p, dv.data(), Npad * sizeof(double), hipMemcpyHostToDevice, m->st));
+        HIP_TRY(hipMemcpy(m->d_dvar.p, dv.data(), Npad * sizeof(double), hipMemcpyHostToDevice));
     }
-    const double jabs = jitter * dsum / (double)N;
-    if (jitter_abs) *jitter_abs = jabs;
+    m->sh_jabs = jitter * dsum / (double)N;
     HIP_TRY(hipMemcpyAsync(m->d_noise.p, noise_var, C * sizeof(double), hipMemcpyHostToDevice, m->st));
     const unsigned long long big = std::numeric_limits<unsigned long long>::max();
     HIP_TRY(hipMemcpyAsync(m->d_info.p, &big, sizeof(big), hipMemcpyHostToDevice, m->st));
@@ -468,18 +467,32 @@ static int eval_sweep(mogp_model* m, const double* noise_var, const double* data
     ga.tiles = m->d_tiles.p; ga.xr = m->d_x.p; ga.xc = m->d_x.p; ga.ldxr = ga.ldxc = Npad;
     ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C;
     ga.out = m->k.A.p; ga.ldo = Npad; ga.noise = m->d_noise.p; ga.dvar = data_var ? m->d_dvar.p : nullptr;
-    ga.jitter_abs = jabs; ga.mirror = 0;
+    ga.jitter_abs = m->sh_jabs; ga.mirror = 0;
     if ((rc = launch_gram(ga, (int)m->tiles.size(), m->st))) return rc;
     if ((rc = launch_pad_identity(m->k.A.p, Npad, N, Npad, m->st))) return rc;
     if ((rc = mark(m, 1))) return rc;
-    if ((rc = spd_sweep(m, m->k))) return rc;
+    return 0;
+}
+
+// alpha (or this rank's partial sums of it) = -A y into m->d_alpha
+static int sweep_eval_alpha(mogp_model* m) {
+    const int64_t Npad = m->Npad;
+    int rc;
     if ((rc = mark(m, 2))) return rc;
     if ((rc = mark(m, 3))) return rc;
     const int nchunks = (int)((Npad + 511) / 512);
     if ((rc = m->d_symv.ensure((size_t)(4 + nchunks) * Npad))) return rc;
-    if ((rc = launch_symv_lower(m->k.A.p, Npad, Npad, m->d_y.p, m->d_alpha.p, m->d_symv.p, -1.0, m->st))) return rc;
+    const int rm = m->sh_n > 1 ? m->sh_n : 0;
+    if ((rc = launch_symv_lower(m->k.A.p, Npad, Npad, m->d_y.p, m->d_alpha.p, m->d_symv.p, -1.0, m->st, rm, m->sh_rank))) return rc;
     if ((rc = mark(m, 4))) return rc;
+    return 0;
+}
+
+// scalars back: failure report, log-det (every rank factors every pivot block, so it is complete everywhere), y^T alpha
+static int sweep_eval_scalars(mogp_model* m, double* lml, int64_t* info) {
+    const int64_t N = m->N, Npad = m->Npad;
     const int nb = m->nb;
+    const unsigned long long big = std::numeric_limits<unsigned long long>::max();
     std::vector<double> hl(nb), ha(Npad);
     unsigned long long hinfo = 0;
     HIP_TRY(hipMemcpyAsync(hl.data(), m->k.logdet.p, nb * sizeof(double), hipMemcpyDeviceToHost, m->st));
@@ -488,14 +501,6 @@ static int eval_sweep(mogp_model* m, const double* noise_var, const double* data
     HIP_TRY(hipStreamSynchronize(m->st));
     if (hinfo != big) {
         if (info) *info = (int64_t)hinfo;
-        int flag = 0;
-        HIP_TRY(hipMemsetAsync(m->d_flag.p, 0, sizeof(int), m->st));
-        if ((rc = launch_gram(ga, (int)m->tiles.size(), m->st))) return rc;
-        if ((rc = launch_nonfinite_scan(m->k.A.p, Npad, N, m->d_flag.p, m->st))) return rc;
-        HIP_TRY(hipMemcpyAsync(&flag, m->d_flag.p, sizeof(int), hipMemcpyDeviceToHost, m->st));
-        HIP_TRY(hipStreamSynchronize(m->st));
-        if (flag & 1) return fail(MOGP_ENONFINITE, "linalg.cholesky: kernel matrix has NaNs!");
-        if (flag & 2) return fail(MOGP_ENONFINITE, "linalg.cholesky: kernel matrix has infinities!");
         return fail(MOGP_ENOTPD, "linalg.cholesky: The factorization could not be completed because the input is not "
                                  "positive-definite (the leading minor of order " + std::to_string(hinfo) + " is not positive-definite).");
     }
@@ -504,6 +509,37 @@ static int eval_sweep(mogp_model* m, const double* noise_var, const double* data
     for (int64_t i = 0; i < N; ++i) ya += m->hy[i] * ha[i];
     if (lml) *lml = -0.5 * (double)N * std::log(2.0 * M_PI) - logdet - 0.5 * ya;
     return 0;
+}
+
+// gradient-moment pass over this rank's rows of Kj^-1 (all rows when not sharded); results on the host, stream synced
+static int moment_pass(mogp_model* m, const double* kinv, double ksign, double* moments, double* diagG) {
+    const int C = m->C, D = m->D, W = 2 + 3 * D, T = m->T, P = C * (C + 1) / 2;
+    const int64_t Npad = m->Npad;
+    const int rm = m->sh_n > 1 ? m->sh_n : 0;
+    int rc;
+    MomentArgs ma{};
+    ma.tiles = m->d_tiles.p; ma.ntiles = (int)m->tiles.size(); ma.x = m->d_x.p; ma.ldx = Npad;
+    ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C; ma.kinv = kinv; ma.kinv_sign = ksign; ma.ld = Npad; ma.alpha = m->d_alpha.p;
+    ma.row_mod = rm; ma.row_rem = m->sh_rank;
+    ma.partial = m->d_partial.p;
+    if ((rc = launch_moments(ma, m->st))) return rc;
+    if ((rc = launch_moment_reduce(m->d_partial.p, m->d_pair_start.p, P, T, W, m->d_moments.p, m->st))) return rc;
+    if ((rc = launch_diagG(kinv, Npad, m->d_alpha.p, m->d_chan_off.p, C, m->d_diagG.p, m->st, ksign, rm, m->sh_rank))) return rc;
+    if ((rc = mark(m, 6))) return rc;
+    HIP_TRY(hipMemcpyAsync(moments, m->d_moments.p, (size_t)P * T * W * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipMemcpyAsync(diagG, m->d_diagG.p, C * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    return 0;
+}
+
+static int eval_sweep(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
+                      double* lml, double* jitter_abs, int64_t* info) {
+    int rc;
+    if ((rc = sweep_eval_begin(m, noise_var, data_var, jitter))) return rc;
+    if (jitter_abs) *jitter_abs = m->sh_jabs;
+    if ((rc = spd_sweep(m, m->k))) return rc;
+    if ((rc = sweep_eval_alpha(m))) return rc;
+    return sweep_eval_scalars(m, lml, info);
 }
 
 extern "C" {
@@ -564,7 +600,7 @@ int mogp_model_destroy(mogp_model* m) {
     m->k.release(); m->ws.release(); m->ws_tail.release();
     for (int b = 0; b < 2; ++b) { m->swU[b].release(); m->swUr[b].release(); }
     for (auto e : m->sw_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
-    m->d_symv.release();
+    m->d_symv.release(); m->sh_send.release(); m->sh_recv.release(); m->sh_row.release();
     if (m->tw) { m->tw->release(); delete m->tw; m->tw = nullptr; }
     m->d_x.release(); m->d_y.release(); m->d_table.release();
     m->d_noise.release(); m->d_dvar.release(); m->d_z.release(); m->d_alpha.release(); m->d_zz.release();
@@ -628,18 +664,7 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     const double* kinv = sweep ? m->k.A.p : m->k.B.p;
     const double ksign = sweep ? -1.0 : 1.0;
     if ((rc = mark(m, 5))) return rc;
-
-    MomentArgs ma{};
-    ma.tiles = m->d_tiles.p; ma.ntiles = (int)m->tiles.size(); ma.x = m->d_x.p; ma.ldx = Npad;
-    ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C; ma.kinv = kinv; ma.kinv_sign = ksign; ma.ld = Npad; ma.alpha = m->d_alpha.p;
-    ma.partial = m->d_partial.p;
-    if ((rc = launch_moments(ma, m->st))) return rc;
-    if ((rc = launch_moment_reduce(m->d_partial.p, m->d_pair_start.p, P, T, W, m->d_moments.p, m->st))) return rc;
-    if ((rc = launch_diagG(kinv, Npad, m->d_alpha.p, m->d_chan_off.p, C, m->d_diagG.p, m->st, ksign))) return rc;
-    if ((rc = mark(m, 6))) return rc;
-    HIP_TRY(hipMemcpyAsync(moments, m->d_moments.p, (size_t)P * T * W * sizeof(double), hipMemcpyDeviceToHost, m->st));
-    HIP_TRY(hipMemcpyAsync(diagG, m->d_diagG.p, C * sizeof(double), hipMemcpyDeviceToHost, m->st));
-    HIP_TRY(hipStreamSynchronize(m->st));
+    if ((rc = moment_pass(m, kinv, ksign, moments, diagG))) return rc;
     double tr = 0.0;
     for (int c = 0; c < C; ++c) tr += diagG[c];
     *trG = tr;
@@ -781,6 +806,87 @@ int mogp_gram(mogp_ctx* ctx, int C, int D, int T, const double* table, int64_t M
     cleanup();
 #undef G_TRY
 #undef G_HIP
+    return MOGP_OK;
+}
+
+// ---- sharded evaluation (one process per GPU; collectives are issued by the caller between these calls) --------------------
+int mogp_shard_config(mogp_model* m, int rank, int nranks) {
+    if (!m || nranks < 1 || rank < 0 || rank >= nranks) return fail(MOGP_EINVAL, "mogp_shard_config: bad argument");
+    m->sh_rank = rank; m->sh_n = nranks;
+    return MOGP_OK;
+}
+
+int mogp_shard_begin(mogp_model* m, const double* noise_var, const double* data_var, double jitter, double* jitter_abs, int* nblocks) {
+    if (!m || !nblocks) return fail(MOGP_EINVAL, "mogp_shard_begin: bad argument");
+    int rc;
+    if ((rc = use_device(m->ctx))) return rc;
+    if ((rc = sweep_eval_begin(m, noise_var, data_var, jitter))) return rc;
+    if ((rc = sweep_prepare(m, m->k))) return rc;
+    if (jitter_abs) *jitter_abs = m->sh_jabs;
+    *nblocks = sweep_nblocks(m->k);
+    return MOGP_OK;
+}
+
+int mogp_shard_pack(mogp_model* m, int kb, void** send, void** recv, int64_t* count) {
+    if (!m || !send || !recv || !count) return fail(MOGP_EINVAL, "mogp_shard_pack: bad argument");
+    int rc;
+    if ((rc = use_device(m->ctx))) return rc;
+    double *s = nullptr, *r = nullptr;
+    if ((rc = shard_pack(m, m->k, kb, &s, &r, count))) return rc;
+    *send = s; *recv = r;
+    return MOGP_OK;
+}
+
+int mogp_shard_unpack(mogp_model* m, int kb) {
+    if (!m) return fail(MOGP_EINVAL, "mogp_shard_unpack: bad argument");
+    int rc;
+    if ((rc = use_device(m->ctx))) return rc;
+    return shard_unpack(m, m->k, kb);
+}
+
+int mogp_shard_row(mogp_model* m, int kb, int t, int phase, void** buf, int64_t* count, int* owner) {
+    if (!m || !buf || !count || !owner) return fail(MOGP_EINVAL, "mogp_shard_row: bad argument");
+    int rc;
+    if ((rc = use_device(m->ctx))) return rc;
+    double* b = nullptr;
+    if ((rc = shard_row(m, m->k, kb, t, phase, &b, count, owner))) return rc;
+    *buf = b;
+    return MOGP_OK;
+}
+
+int mogp_shard_block(mogp_model* m, int kb) {
+    if (!m) return fail(MOGP_EINVAL, "mogp_shard_block: bad argument");
+    int rc;
+    if ((rc = use_device(m->ctx))) return rc;
+    return sweep_block(m, m->k, kb);
+}
+
+int mogp_shard_alpha(mogp_model* m, void** vec, int64_t* count) {
+    if (!m || !vec || !count) return fail(MOGP_EINVAL, "mogp_shard_alpha: bad argument");
+    int rc;
+    if ((rc = use_device(m->ctx))) return rc;
+    if ((rc = sweep_finish(m, m->k))) return rc;
+    if ((rc = sweep_eval_alpha(m))) return rc;
+    HIP_TRY(hipStreamSynchronize(m->st));
+    *vec = m->d_alpha.p; *count = m->Npad;
+    return MOGP_OK;
+}
+
+int mogp_shard_finish(mogp_model* m, double* lml, double* moments, double* diagG, int64_t* info) {
+    if (!m || !lml || !moments || !diagG) return fail(MOGP_EINVAL, "mogp_shard_finish: bad argument");
+    int rc;
+    if ((rc = use_device(m->ctx))) return rc;
+    if (info) *info = 0;
+    if ((rc = sweep_eval_scalars(m, lml, info))) return rc;
+    if ((rc = mark(m, 5))) return rc;
+    if ((rc = moment_pass(m, m->k.A.p, -1.0, moments, diagG))) return rc;
+    m->have_Kinv = true; m->kinv_in_A = true;
+    return MOGP_OK;
+}
+
+int mogp_dev_copy(void* dst, const void* src, int64_t bytes, int to_device) {
+    if (!dst || !src || bytes < 0) return fail(MOGP_EINVAL, "mogp_dev_copy: bad argument");
+    HIP_TRY(hipMemcpy(dst, src, (size_t)bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
     return MOGP_OK;
 }
 

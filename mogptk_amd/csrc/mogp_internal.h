@@ -62,6 +62,7 @@ struct MomentArgs {
     int64_t ld;
     const double* alpha;   // [N]
     double kinv_sign;      // +1: kinv holds Kj^-1; -1: it holds -Kj^-1 (result of the sweep inversion)
+    int row_mod, row_rem;  // row_mod > 1 (exact mode): only entries whose matrix row max(a,b) lies in a 128-tile row owned by this rank
     // adjoint source, dense mode (G != null):  g = w * (G[a][b] + rcoef * ru[a] * rw[b])
     const double* G;
     int64_t ldg;
@@ -83,7 +84,7 @@ int launch_moment_reduce(const double* partial, const int* pair_start, int npair
                          int lower_pairs = 1);
 // per-channel sum of G_kk = 1/2(alpha_k^2 - kinv_kk): out[c], chan_off device array [C+1]
 int launch_diagG(const double* kinv, int64_t ld, const double* alpha, const int* chan_off, int C, double* out, hipStream_t s,
-                 double kinv_sign = 1.0);
+                 double kinv_sign = 1.0, int row_mod = 0, int row_rem = 0);
 
 // ---- dense linear algebra (fp64, MFMA) -------------------------------------------------------------
 enum GemmMode { GM_RECT = 0,      // mt x nt tiles, k in [0, K)
@@ -110,6 +111,7 @@ struct GemmArgs {
     int mode, mt, nt, K;
     const GemmTask* tasks; int ntasks;
     int small;                                     // 0: 128x128 tiles; 1: 64x128; 2: 64x64 (mt / nt count tiles of that shape)
+    int row_mod, row_rem, row_off;                 // row_mod > 1: only tile rows with (ti + row_off) % row_mod == row_rem (sharded evaluation)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 double gemm_flops(const GemmArgs& a, const std::vector<GemmTask>* host_tasks);
@@ -125,15 +127,17 @@ int launch_put_diag_tiles(double* A, int64_t ld, int nt, const double* invd, hip
 // rows >= N of the padded matrix: identity (lower part)
 int launch_pad_identity(double* A, int64_t ld, int64_t N, int64_t Npad, hipStream_t s);
 // z = W y (W lower triangular), and partial[blk] = sum z^2 over the block's rows
-int launch_trmv_lower(const double* W, int64_t ld, int64_t n, const double* y, double* z, double* zz_partial, hipStream_t s);
+int launch_trmv_lower(const double* W, int64_t ld, int64_t n, const double* y, double* z, double* zz_partial, hipStream_t s,
+                      int row_mod = 0, int row_rem = 0);
 // a = W^T z
-int launch_trmv_lower_t(const double* W, int64_t ld, int64_t n, const double* z, double* a, hipStream_t s);
+int launch_trmv_lower_t(const double* W, int64_t ld, int64_t n, const double* z, double* a, hipStream_t s, int row_mod = 0, int row_rem = 0);
 // out[r] = sum_k M[r][k] * v[k]   (dense row-major rows x n)
 int launch_gemv_rows(const double* M, int64_t ld, int64_t rows, int64_t n, const double* v, double* out, hipStream_t s);
 // out[r] = base[r] - sum_k M[r][k]^2
 int launch_row_sqnorm_sub(const double* M, int64_t ld, int64_t rows, int64_t n, const double* base, double* out, hipStream_t s);
 // out = sign * (tril(A) y + strict_tril(A)^T y): symmetric mat-vec with a lower-stored matrix (scratch: (2 + n/512 + 1) * n doubles)
-int launch_symv_lower(const double* A, int64_t ld, int64_t n, const double* y, double* out, double* scratch, double sign, hipStream_t s);
+int launch_symv_lower(const double* A, int64_t ld, int64_t n, const double* y, double* out, double* scratch, double sign, hipStream_t s,
+                      int row_mod = 0, int row_rem = 0);
 // dst[r][c] = scale * src[r][c]
 int launch_copy2d(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols, double scale, hipStream_t s);
 // A[i][i] += val for i < n

@@ -103,6 +103,10 @@ struct mogp_model {
     Spd ws, ws_tail;                    // Schur-block workspaces of the sweep inversion (outer block / last partial block)
     DevBuf<double> swU[2], swUr[2];     // old panels of the block being swept (column part, row part), double buffered
     std::vector<hipEvent_t> sw_ev;
+    int sh_rank = 0, sh_n = 1;          // sharded evaluation: this rank owns tile rows i with i % sh_n == sh_rank
+    DevBuf<double> sh_send, sh_recv, sh_row;
+    double sh_jabs = 0.0;
+    bool sh_dvar = false;
 
     std::vector<double> hy;             // channel-sorted targets (host copy, Npad)
     DevBuf<double> d_symv;
@@ -137,5 +141,12 @@ int spd_alloc(Spd& w, int64_t Npad);
 int spd_potrf(mogp_model* m, Spd& w, long long info_base = 0);
 int spd_trtri(mogp_model* m, Spd& w);
 int spd_lauum(mogp_model* m, Spd& w);
-int spd_sweep(mogp_model* m, Spd& w);     // w.A (SPD, lower) -> -inverse (lower); w.logdet per tile; failure through m->d_info
+int spd_sweep(mogp_model* m, Spd& w);
+int sweep_prepare(mogp_model* m, Spd& w);
+int sweep_nblocks(const Spd& w);
+int sweep_block(mogp_model* m, Spd& w, int kb);
+int sweep_finish(mogp_model* m, Spd& w);
+int shard_pack(mogp_model* m, Spd& w, int kb, double** send, double** recv, int64_t* count);
+int shard_unpack(mogp_model* m, Spd& w, int kb);
+int shard_row(mogp_model* m, Spd& w, int kb, int t, int phase, double** buf, int64_t* count, int* owner);     // w.A (SPD, lower) -> -inverse (lower); w.logdet per tile; failure through m->d_info
 }  // namespace mogp

@@ -29,7 +29,7 @@ static GemmArgs upd(const double* A, int64_t lda, int akm, const double* B, int6
 
 namespace mogp {
 
-int spd_sweep(mogp_model* m, Spd& w) {
+int sweep_prepare(mogp_model* m, Spd& w) {
     const int nb = w.nb;
     const int64_t ld = w.Npad;
     const int nouter = (nb + SW_OB - 1) / SW_OB;
@@ -44,71 +44,166 @@ int spd_sweep(mogp_model* m, Spd& w) {
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         m->sw_ev.push_back(e);
     }
+    return 0;
+}
+
+int sweep_nblocks(const Spd& w) { return (w.nb + SW_OB - 1) / SW_OB; }
+
+// one pivot block.  With m->sh_n > 1 (sharded evaluation) the chain (P, panels) is repeated by every rank from the assembled
+// authoritative panel and the rank-Kd update touches only the tile rows this rank owns (row i is owned by rank i % sh_n).
+int sweep_block(mogp_model* m, Spd& w, int kb) {
+    const int nb = w.nb;
+    const int64_t ld = w.Npad;
+    const int rm = m->sh_n > 1 ? m->sh_n : 0, rr = m->sh_rank;
     hipStream_t q1 = m->st, q2 = m->st2;
     double* A = w.A.p;
-    for (int kb = 0; kb < nouter; ++kb) {
-        const int k0 = kb * SW_OB, k1 = std::min(k0 + SW_OB, nb), nk = k1 - k0;
-        const int64_t Kd = (int64_t)nk * MOGP_TILE;
-        const int below = nb - k1;                                   // tile rows under the pivot block
-        Spd& s = (nk == m->ws.nb) ? m->ws : m->ws_tail;
-        double* Akk = A + (int64_t)k0 * MOGP_TILE * (ld + 1);
-        double* Acol = A + (int64_t)k1 * MOGP_TILE * ld + (int64_t)k0 * MOGP_TILE;      // A[O>][K]
-        double* Arow = A + (int64_t)k0 * MOGP_TILE * ld;                                  // A[K][O<]
-        // ---- P = S^-1 on the critical stream
-        RC(launch_copy2d(s.A.p, Kd, Akk, ld, Kd, Kd, 1.0, q1));
-        RC(spd_potrf(m, s, (long long)k0 * MOGP_TILE));
-        HIP_TRY(hipMemcpyAsync(w.logdet.p + k0, s.logdet.p, nk * sizeof(double), hipMemcpyDeviceToDevice, q1));
-        RC(spd_trtri(m, s));
-        RC(spd_lauum(m, s));
-        RC(launch_symmetrize(s.B.p, Kd, Kd, q1));
-        const double* P = s.B.p;
-        // ---- old panels out, new panels X = U P in place, diagonal block = -P
-        double* Uc = m->swU[kb & 1].p;                                                     // [below*128][Kd]
-        double* Ur = m->swUr[kb & 1].p;                                                    // [Kd][ld] (first k0*128 columns used)
-        RC(launch_copy2d(Uc, Kd, Acol, ld, (int64_t)below * MOGP_TILE, Kd, 1.0, q1));
-        RC(launch_copy2d(Ur, ld, Arow, ld, Kd, (int64_t)k0 * MOGP_TILE, 1.0, q1));
-        if (below > 0) {
-            GemmArgs g = upd(Uc, Kd, 0, P, Kd, 0, Acol, ld, GM_RECT, 2 * below, nk, Kd, 1);
-            g.alpha = 1.0; g.beta = 0.0;
-            RC(gemm_call(m, g, gemm_flops(g, nullptr), q1));
-        }
-        if (k0 > 0) {
-            GemmArgs g = upd(P, Kd, 0, Ur, ld, 1, Arow, ld, GM_RECT, nk, k0, Kd);
-            g.alpha = 1.0; g.beta = 0.0;
-            RC(gemm_call(m, g, gemm_flops(g, nullptr), q1));
-        }
-        RC(launch_copy2d(Akk, ld, P, Kd, Kd, Kd, -1.0, q1));
-        HIP_TRY(hipEventRecord(m->sw_ev[2 * kb], q1));                                     // X(kb) ready
-        // ---- rank-Kd update of everything outside the pivot block
-        const int nk2 = std::min(SW_OB, below);                                            // tile columns of the next pivot block
-        if (kb > 0) HIP_TRY(hipStreamWaitEvent(q1, m->sw_ev[2 * (kb - 1) + 1], 0));        // a1/b1 share tiles with bulk(kb-1)
-        if (nk2 > 0) {
-            GemmArgs a1 = upd(Acol, ld, 0, Uc, Kd, 0, A + (int64_t)k1 * MOGP_TILE * (ld + 1), ld, GM_RECT_LOWER, below, nk2, Kd);
-            RC(gemm_call(m, a1, gemm_flops(a1, nullptr), q1));
-            if (k0 > 0) {
-                GemmArgs b1 = upd(Acol, ld, 0, Ur, ld, 1, A + (int64_t)k1 * MOGP_TILE * ld, ld, GM_RECT, nk2, k0, Kd);
-                RC(gemm_call(m, b1, gemm_flops(b1, nullptr), q1));
-            }
-        }
-        HIP_TRY(hipStreamWaitEvent(q2, m->sw_ev[2 * kb], 0));
-        const int rest = below - nk2;
-        if (rest > 0) {
-            const int64_t r0 = (int64_t)(k1 + nk2) * MOGP_TILE;
-            const double* Xr2 = A + r0 * ld + (int64_t)k0 * MOGP_TILE;
-            GemmArgs a2 = upd(Xr2, ld, 0, Uc + (int64_t)nk2 * MOGP_TILE * Kd, Kd, 0, A + r0 * (ld + 1), ld, GM_LOWER, rest, rest, Kd);
-            RC(gemm_call(m, a2, gemm_flops(a2, nullptr), q2));
-            if (k0 > 0) {
-                GemmArgs b2 = upd(Xr2, ld, 0, Ur, ld, 1, A + r0 * ld, ld, GM_RECT, rest, k0, Kd);
-                RC(gemm_call(m, b2, gemm_flops(b2, nullptr), q2));
-            }
-        }
-        if (k0 > 0) {
-            GemmArgs c = upd(Arow, ld, 1, Ur, ld, 1, A, ld, GM_LOWER, k0, k0, Kd);
-            RC(gemm_call(m, c, gemm_flops(c, nullptr), q2));
-        }
-        HIP_TRY(hipEventRecord(m->sw_ev[2 * kb + 1], q2));                                 // bulk(kb) done
+    const int k0 = kb * SW_OB, k1 = std::min(k0 + SW_OB, nb), nk = k1 - k0;
+    const int64_t Kd = (int64_t)nk * MOGP_TILE;
+    const int below = nb - k1;                                   // tile rows under the pivot block
+    Spd& s = (nk == m->ws.nb) ? m->ws : m->ws_tail;
+    double* Akk = A + (int64_t)k0 * MOGP_TILE * (ld + 1);
+    double* Acol = A + (int64_t)k1 * MOGP_TILE * ld + (int64_t)k0 * MOGP_TILE;      // A[O>][K]
+    double* Arow = A + (int64_t)k0 * MOGP_TILE * ld;                                  // A[K][O<]
+    // ---- P = S^-1 on the critical stream
+    RC(launch_copy2d(s.A.p, Kd, Akk, ld, Kd, Kd, 1.0, q1));
+    RC(spd_potrf(m, s, (long long)k0 * MOGP_TILE));
+    HIP_TRY(hipMemcpyAsync(w.logdet.p + k0, s.logdet.p, nk * sizeof(double), hipMemcpyDeviceToDevice, q1));
+    RC(spd_trtri(m, s));
+    RC(spd_lauum(m, s));
+    RC(launch_symmetrize(s.B.p, Kd, Kd, q1));
+    const double* P = s.B.p;
+    // ---- old panels out, new panels X = U P in place, diagonal block = -P
+    double* Uc = m->swU[kb & 1].p;                                                     // [below*128][Kd]
+    double* Ur = m->swUr[kb & 1].p;                                                    // [Kd][ld] (first k0*128 columns used)
+    RC(launch_copy2d(Uc, Kd, Acol, ld, (int64_t)below * MOGP_TILE, Kd, 1.0, q1));
+    RC(launch_copy2d(Ur, ld, Arow, ld, Kd, (int64_t)k0 * MOGP_TILE, 1.0, q1));
+    if (below > 0) {
+        GemmArgs g = upd(Uc, Kd, 0, P, Kd, 0, Acol, ld, GM_RECT, 2 * below, nk, Kd, 1);
+        g.alpha = 1.0; g.beta = 0.0;
+        RC(gemm_call(m, g, gemm_flops(g, nullptr), q1));
     }
-    HIP_TRY(hipStreamWaitEvent(q1, m->sw_ev[2 * (nouter - 1) + 1], 0));
+    if (k0 > 0) {
+        GemmArgs g = upd(P, Kd, 0, Ur, ld, 1, Arow, ld, GM_RECT, nk, k0, Kd);
+        g.alpha = 1.0; g.beta = 0.0;
+        RC(gemm_call(m, g, gemm_flops(g, nullptr), q1));
+    }
+    RC(launch_copy2d(Akk, ld, P, Kd, Kd, Kd, -1.0, q1));
+    HIP_TRY(hipEventRecord(m->sw_ev[2 * kb], q1));                                     // X(kb) ready
+    // ---- rank-Kd update of everything outside the pivot block
+    const int nk2 = std::min(SW_OB, below);                                            // tile columns of the next pivot block
+    if (kb > 0) HIP_TRY(hipStreamWaitEvent(q1, m->sw_ev[2 * (kb - 1) + 1], 0));        // a1/b1 share tiles with bulk(kb-1)
+    if (nk2 > 0) {
+        GemmArgs a1 = upd(Acol, ld, 0, Uc, Kd, 0, A + (int64_t)k1 * MOGP_TILE * (ld + 1), ld, GM_RECT_LOWER, below, nk2, Kd);
+        a1.row_mod = rm; a1.row_rem = rr; a1.row_off = k1;
+        RC(gemm_call(m, a1, gemm_flops(a1, nullptr), q1));
+        if (k0 > 0) {
+            GemmArgs b1 = upd(Acol, ld, 0, Ur, ld, 1, A + (int64_t)k1 * MOGP_TILE * ld, ld, GM_RECT, nk2, k0, Kd);
+            b1.row_mod = rm; b1.row_rem = rr; b1.row_off = k1;
+            RC(gemm_call(m, b1, gemm_flops(b1, nullptr), q1));
+        }
+    }
+    HIP_TRY(hipStreamWaitEvent(q2, m->sw_ev[2 * kb], 0));
+    const int rest = below - nk2;
+    if (rest > 0) {
+        const int64_t r0 = (int64_t)(k1 + nk2) * MOGP_TILE;
+        const double* Xr2 = A + r0 * ld + (int64_t)k0 * MOGP_TILE;
+        GemmArgs a2 = upd(Xr2, ld, 0, Uc + (int64_t)nk2 * MOGP_TILE * Kd, Kd, 0, A + r0 * (ld + 1), ld, GM_LOWER, rest, rest, Kd);
+        a2.row_mod = rm; a2.row_rem = rr; a2.row_off = k1 + nk2;
+        RC(gemm_call(m, a2, gemm_flops(a2, nullptr), q2));
+        if (k0 > 0) {
+            GemmArgs b2 = upd(Xr2, ld, 0, Ur, ld, 1, A + r0 * ld, ld, GM_RECT, rest, k0, Kd);
+            b2.row_mod = rm; b2.row_rem = rr; b2.row_off = k1 + nk2;
+            RC(gemm_call(m, b2, gemm_flops(b2, nullptr), q2));
+        }
+    }
+    if (k0 > 0) {
+        GemmArgs c = upd(Arow, ld, 1, Ur, ld, 1, A, ld, GM_LOWER, k0, k0, Kd);
+        c.row_mod = rm; c.row_rem = rr; c.row_off = 0;
+        RC(gemm_call(m, c, gemm_flops(c, nullptr), q2));
+    }
+    HIP_TRY(hipEventRecord(m->sw_ev[2 * kb + 1], q2));                                 // bulk(kb) done
+    return 0;
+}
+
+int sweep_finish(mogp_model* m, Spd& w) {
+    const int nouter = sweep_nblocks(w);
+    HIP_TRY(hipStreamWaitEvent(m->st, m->sw_ev[2 * (nouter - 1) + 1], 0));
+    return 0;
+}
+
+int spd_sweep(mogp_model* m, Spd& w) {
+    RC(sweep_prepare(m, w));
+    for (int kb = 0; kb < sweep_nblocks(w); ++kb) RC(sweep_block(m, w, kb));
+    return sweep_finish(m, w);
+}
+
+// ---- sharded evaluation: assembling the authoritative panel of pivot block kb -----------------------------------------
+// column part: tile rows i >= k0, 128 x Kd each, owner i % P; rank r's rows are first_r + idx * P
+__global__ void k_shard_pack(const double* __restrict__ A, int64_t ld, int k0, int nb, int P, int rank, int64_t Kd, double* __restrict__ send) {
+    const int first = k0 + ((rank - k0 % P) + P) % P;
+    const int i = first + (int)blockIdx.x * P;
+    if (i >= nb) return;
+    const double* src = A + (int64_t)i * MOGP_TILE * ld + (int64_t)k0 * MOGP_TILE;
+    double* dst = send + (int64_t)blockIdx.x * MOGP_TILE * Kd;
+    for (int64_t e = threadIdx.x; e < MOGP_TILE * Kd; e += blockDim.x) dst[e] = src[(e / Kd) * ld + (e % Kd)];
+}
+__global__ void k_shard_unpack(double* __restrict__ A, int64_t ld, int k0, int nb, int P, int64_t Kd, int64_t chunk, const double* __restrict__ recv) {
+    const int r = blockIdx.y;
+    const int first = k0 + ((r - k0 % P) + P) % P;
+    const int i = first + (int)blockIdx.x * P;
+    if (i >= nb) return;
+    double* dst = A + (int64_t)i * MOGP_TILE * ld + (int64_t)k0 * MOGP_TILE;
+    const double* src = recv + (int64_t)r * chunk + (int64_t)blockIdx.x * MOGP_TILE * Kd;
+    for (int64_t e = threadIdx.x; e < MOGP_TILE * Kd; e += blockDim.x) dst[(e / Kd) * ld + (e % Kd)] = src[e];
+}
+
+static void shard_geometry(const Spd& w, int kb, int P, int& k0, int& nk, int64_t& Kd, int& maxrows) {
+    k0 = kb * SW_OB;
+    const int k1 = std::min(k0 + SW_OB, w.nb);
+    nk = k1 - k0;
+    Kd = (int64_t)nk * MOGP_TILE;
+    maxrows = (w.nb - k0 + P - 1) / P;
+}
+
+int shard_pack(mogp_model* m, Spd& w, int kb, double** send, double** recv, int64_t* count) {
+    const int P = m->sh_n;
+    int k0, nk, maxrows; int64_t Kd;
+    shard_geometry(w, kb, P, k0, nk, Kd, maxrows);
+    const int64_t chunk = (int64_t)maxrows * MOGP_TILE * Kd;
+    RC(m->sh_send.ensure((size_t)chunk)); RC(m->sh_recv.ensure((size_t)chunk * P));
+    hipLaunchKernelGGL(k_shard_pack, dim3(maxrows), dim3(256), 0, m->st, w.A.p, w.Npad, k0, w.nb, P, m->sh_rank, Kd, m->sh_send.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(m->st));           // a1 / b1 of the previous block (critical stream) are in; the bulk stream keeps running
+    *send = m->sh_send.p; *recv = m->sh_recv.p; *count = chunk;
+    return 0;
+}
+
+int shard_unpack(mogp_model* m, Spd& w, int kb) {
+    const int P = m->sh_n;
+    int k0, nk, maxrows; int64_t Kd;
+    shard_geometry(w, kb, P, k0, nk, Kd, maxrows);
+    const int64_t chunk = (int64_t)maxrows * MOGP_TILE * Kd;
+    hipLaunchKernelGGL(k_shard_unpack, dim3(maxrows, P), dim3(256), 0, m->st, w.A.p, w.Npad, k0, w.nb, P, Kd, chunk, m->sh_recv.p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// row part of pivot tile row k0 + t: A[row tile][0 : k0*128], owner (k0 + t) % P.  phase 0: the owner packs it; phase 1: everybody unpacks
+int shard_row(mogp_model* m, Spd& w, int kb, int t, int phase, double** buf, int64_t* count, int* owner) {
+    const int k0 = kb * SW_OB;
+    const int i = k0 + t;
+    const int64_t cols = (int64_t)k0 * MOGP_TILE;
+    *owner = i % m->sh_n;
+    *count = (int64_t)MOGP_TILE * cols;
+    RC(m->sh_row.ensure((size_t)std::max<int64_t>(*count, 1)));
+    *buf = m->sh_row.p;
+    double* Arow = w.A.p + (int64_t)i * MOGP_TILE * w.Npad;
+    if (phase == 0) {
+        if (*owner == m->sh_rank) RC(launch_copy2d(m->sh_row.p, cols, Arow, w.Npad, MOGP_TILE, cols, 1.0, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));
+    } else {
+        RC(launch_copy2d(Arow, w.Npad, m->sh_row.p, cols, MOGP_TILE, cols, 1.0, m->st));
+    }
     return 0;
 }
 

@@ -11,6 +11,7 @@ class Config:
     dtype = np.float64
     device = 0
     positive_minimum = 1e-8
+    comm = None          # mogptk_amd.dist.Comm when exact evaluations are sharded over several GPUs
 
 
 config = Config()

@@ -230,3 +230,163 @@ def titsias_predict(self, Z, sigma, jitter, Xs, kss_diag):
 
 TableDevice.titsias_eval = titsias_eval
 TableDevice.titsias_predict = titsias_predict
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# numpy twin of the SHARDED evaluation stages (mogp_shard_*, mogptk_amd/csrc/sweep.hip): single-sweep blocked
+# inversion with 128-row tiles owned cyclically (tile row i -> rank i % world), 512-wide pivot blocks, the panel of
+# each pivot block assembled by an all-gather (column part) + broadcasts (pivot tile rows), the serial chain repeated
+# by every rank and the rank-512 update restricted to owned rows.  Drives the same mogptk_amd.dist.sharded_eval as the
+# device handle, so tests/test_dist_cpu.py exercises the real orchestration under gloo with two CPU ranks.
+# ----------------------------------------------------------------------------------------------------------------
+TILE, OB = 128, 4
+
+
+def _shard_begin(self, rank, world, noise_var, jitter, data_var=None):
+    self.rank, self.world = rank, world
+    X = self.X
+    order = np.argsort(X[:, 0], kind="stable")            # the device works in channel-sorted order
+    self._order = order
+    Xs = X[order]
+    K = gram_from_table(self.table, Xs)
+    c = Xs[:, 0].astype(np.int64)
+    d = np.diagonal(K) + np.asarray(noise_var)[c] + (0.0 if data_var is None else np.asarray(data_var)[order])
+    jit = jitter * np.mean(d)
+    N = self.N
+    self.Npad = -(-N // TILE) * TILE
+    self.nb = self.Npad // TILE
+    A = np.eye(self.Npad)
+    A[:N, :N] = K
+    A[np.arange(N), np.arange(N)] = d + jit
+    self.A = np.tril(A)                                      # lower storage, like the device
+    self.ys = np.zeros(self.Npad); self.ys[:N] = self.y[order, 0]
+    self.logdet = 0.0
+    self._Xs = Xs
+    return jit, -(-self.nb // OB)
+
+
+def _geom(self, kb):
+    k0 = kb * OB
+    k1 = min(k0 + OB, self.nb)
+    return k0, k1, (k1 - k0) * TILE, -(-(self.nb - k0) // self.world)
+
+
+def _owned_rows(self, k0, r):
+    first = k0 + ((r - k0 % self.world) + self.world) % self.world
+    return list(range(first, self.nb, self.world))
+
+
+def _shard_pack(self, kb):
+    k0, k1, Kd, maxrows = _geom(self, kb)
+    chunk = maxrows * TILE * Kd
+    send = np.zeros(chunk)
+    for idx, i in enumerate(_owned_rows(self, k0, self.rank)):
+        send[idx * TILE * Kd:(idx + 1) * TILE * Kd] = self.A[i * TILE:(i + 1) * TILE, k0 * TILE:k0 * TILE + Kd].reshape(-1)
+    self._recv = np.zeros(chunk * self.world)
+    return send, self._recv, chunk
+
+
+def _shard_unpack(self, kb):
+    k0, k1, Kd, maxrows = _geom(self, kb)
+    chunk = maxrows * TILE * Kd
+    for r in range(self.world):
+        for idx, i in enumerate(_owned_rows(self, k0, r)):
+            self.A[i * TILE:(i + 1) * TILE, k0 * TILE:k0 * TILE + Kd] = self._recv[r * chunk + idx * TILE * Kd:r * chunk + (idx + 1) * TILE * Kd].reshape(TILE, Kd)
+
+
+def _shard_pivot_rows(self, kb):
+    return 0 if kb == 0 else min(OB, self.nb - OB * kb)
+
+
+def _shard_row(self, kb, t, phase):
+    k0 = kb * OB
+    i = k0 + t
+    owner = i % self.world
+    cols = k0 * TILE
+    if phase == 0:
+        self._rowbuf = self.A[i * TILE:(i + 1) * TILE, :cols].reshape(-1).copy() if owner == self.rank else np.zeros(TILE * cols)
+    else:
+        self.A[i * TILE:(i + 1) * TILE, :cols] = self._rowbuf.reshape(TILE, cols)
+    return self._rowbuf, TILE * cols, owner
+
+
+def _shard_block(self, kb):
+    k0, k1, Kd, _ = _geom(self, kb)
+    A, T_ = self.A, TILE
+    a0, a1 = k0 * T_, k1 * T_
+    S = A[a0:a1, a0:a1]
+    S = np.tril(S) + np.tril(S, -1).T
+    L = np.linalg.cholesky(S)
+    self.logdet += np.sum(np.log(np.diagonal(L)))
+    Li = np.linalg.inv(L)
+    P = Li.T @ Li
+    Uc = A[a1:, a0:a1].copy()                      # rows below
+    Ur = A[a0:a1, :a0].copy()                      # row block (transposed part of the panel)
+    A[a1:, a0:a1] = Uc @ P
+    A[a0:a1, :a0] = P @ Ur
+    A[a0:a1, a0:a1] = -P
+    Xc, Xr = A[a1:, a0:a1], A[a0:a1, :a0]
+    mine = lambda i: (i % self.world) == self.rank
+    for i in range(self.nb):                       # rank-Kd update of the owned tile rows outside the pivot block
+        if k0 <= i < k1 or not mine(i):
+            continue
+        rows = slice(i * T_, (i + 1) * T_)
+        if i >= k1:
+            xi = Xc[(i - k1) * T_:(i - k1 + 1) * T_]
+            A[rows, a1:(i + 1) * T_] -= xi @ Uc[:(i - k1 + 1) * T_].T          # (a): columns below the block, j <= i
+            A[rows, :a0] -= xi @ Ur                                             # (b)
+        else:
+            A[rows, :(i + 1) * T_] -= Xr[:, rows].T @ Ur[:, :(i + 1) * T_]      # (c)
+    self.A = A
+
+
+def _shard_alpha(self):
+    A = np.tril(self.A)
+    mask = np.array([(i // TILE) % self.world == self.rank for i in range(self.Npad)])
+    Am = A * mask[:, None]                        # owned rows only
+    z = Am @ self.ys + Am.T @ self.ys - np.where(mask, np.diagonal(A) * self.ys, 0.0)
+    self._alpha = -z
+    return self._alpha, self.Npad
+
+
+def _shard_finish(self):
+    N, C, T, D = self.N, self.C, self.T, self.D
+    alpha = self._alpha[:N]
+    lml = -0.5 * N * np.log(TWO_PI) - self.logdet - 0.5 * float(self.ys[:N] @ alpha)
+    Kinv = -(np.tril(self.A) + np.tril(self.A, -1).T)[:N, :N]
+    mask = np.array([(i // TILE) % self.world == self.rank for i in range(N)])
+    G = 0.5 * (np.outer(alpha, alpha) - Kinv)
+    hi_mine = np.maximum.outer(np.arange(N), np.arange(N))
+    Gm = G * mask[hi_mine]                        # an entry belongs to the owner of row max(a, b)
+    Xs = self._Xs
+    c = Xs[:, 0].astype(np.int64)
+    mom = np.zeros((C * (C + 1) // 2, T, 2 + 3 * D))
+    for i in range(C):
+        ri = np.nonzero(c == i)[0]
+        for j in range(i + 1):
+            rj = np.nonzero(c == j)[0]
+            if len(ri) == 0 or len(rj) == 0:
+                continue
+            Ec, Es, u = table_block(self.table[i, j], Xs[ri, 1:], Xs[rj, 1:])
+            g = Gm[np.ix_(ri, rj)]
+            if i == j:                            # lower triangle counted twice, diagonal once (full symmetric sum)
+                g = np.tril(g, -1) * 2.0 + np.diag(np.diagonal(g))
+            else:
+                g = g * 2.0
+            m = mom[i * (i + 1) // 2 + j]
+            m[:, 0] = np.einsum("nm,tnm->t", g, Ec)
+            m[:, 1] = 0.0 if i == j else np.einsum("nm,tnm->t", g, Es)
+            m[:, 2:2 + D] = np.einsum("nm,tnm,tnmd->td", g, Ec, u * u)
+            m[:, 2 + D:2 + 2 * D] = 0.0 if i == j else np.einsum("nm,tnm,tnmd->td", g, Ec, u)
+            m[:, 2 + 2 * D:] = np.einsum("nm,tnm,tnmd->td", g, Es, u)
+    dG = np.where(mask, np.diagonal(G), 0.0)
+    diagG = np.array([np.sum(dG[c == k]) for k in range(C)])
+    return lml, mom, diagG
+
+
+for _n, _f in (("shard_begin", _shard_begin), ("shard_pack", _shard_pack), ("shard_unpack", _shard_unpack),
+               ("shard_pivot_rows", _shard_pivot_rows), ("shard_row", _shard_row), ("shard_block", _shard_block),
+               ("shard_alpha", _shard_alpha), ("shard_finish", _shard_finish)):
+    setattr(TableDevice, _n, _f)
+TableDevice.mem_get = lambda self, buf, count: np.array(buf[:count], dtype=np.float64)
+TableDevice.mem_put = lambda self, buf, arr: buf.__setitem__(slice(0, len(arr)), arr)

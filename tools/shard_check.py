@@ -1,0 +1,67 @@
+"""
+Run under torch.distributed.run: every rank evaluates the same exact-GP LML+gradient once alone (three-phase path) and once
+sharded over the ranks (mogptk_amd.dist.sharded_eval), and rank 0 prints the differences as one JSON line.
+  backend gloo  -> all ranks may share one GPU (buffers staged through the host): the validation mode of tests/test_gpu_parity.py
+  backend nccl  -> one GPU per rank (RCCL), the production mode
+usage: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/shard_check.py [--n 3000] [--backend gloo] [--reps 3]
+"""
+import argparse, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=3000)
+ap.add_argument("--channels", type=int, default=4)
+ap.add_argument("--q", type=int, default=3)
+ap.add_argument("--backend", default="gloo")
+ap.add_argument("--reps", type=int, default=2)
+a = ap.parse_args()
+
+import torch
+import torch.distributed as dist
+import mogptk_amd
+from mogptk_amd import gpr, synth
+
+rank, local, world = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
+dev = local if a.backend == "nccl" else 0
+if a.backend == "nccl":
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+else:
+    dist.init_process_group("gloo")
+gpr.config.device = dev
+
+X, y = synth.make_data(a.n, a.channels)
+h = synth.mosm_hypers(a.channels, a.q)
+k = gpr.MultiOutputSpectralMixtureKernel(Q=a.q, output_dims=a.channels)
+for name in ("weight", "mean", "variance", "delay", "phase"):
+    getattr(k, name).assign(h[name])
+m = gpr.Exact(k, X, y, variance=h["scale"] ** 2)
+m.likelihood.scale.assign(h["scale"])
+
+l0 = float(m.loss())
+g0 = [p.grad.copy() for p in m.parameters()]
+t = time.perf_counter()
+for _ in range(a.reps):
+    m.loss()
+t_single = (time.perf_counter() - t) / a.reps
+
+mogptk_amd.use_distributed()
+l1 = float(m.loss())
+g1 = [p.grad.copy() for p in m.parameters()]
+dist.barrier()
+t = time.perf_counter()
+for _ in range(a.reps):
+    m.loss()
+dist.barrier()
+t_shard = (time.perf_counter() - t) / a.reps
+
+err = max(float(np.max(np.abs(b - c)) / np.max(np.abs(c))) for b, c in zip(g1, g0))
+errs = torch.tensor([abs(l1 - l0) / abs(l0), err], dtype=torch.float64)
+if a.backend == "nccl":
+    errs = errs.cuda()
+dist.all_reduce(errs, op=dist.ReduceOp.MAX)
+if rank == 0:
+    print(json.dumps(dict(world=world, backend=a.backend, N=a.n, loss=l0, loss_sharded=l1, rel_loss=float(errs[0]), rel_grad=float(errs[1]),
+                          ms_single=1e3 * t_single, ms_sharded=1e3 * t_shard)))
+dist.destroy_process_group()
