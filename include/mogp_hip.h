@@ -119,16 +119,15 @@ int  mogp_titsias_predict(mogp_model* m, int64_t M, const double* Z, double sigm
  * i % nranks == r of the single-sweep inversion (sweep.hip).  The caller issues the collectives (RCCL through
  * torch.distributed in mogptk_amd/dist.py) between these calls; pointers returned through void** are DEVICE pointers owned by
  * the handle, counts are in doubles.  Per evaluation:
- *   begin -> for kb in 0..nblocks-1: { pack; ALL-GATHER(send -> recv, count per rank); unpack;
- *                                      for each pivot tile row t (kb > 0): row(phase 0); BROADCAST(buf, count, owner); row(phase 1);
- *                                      block }
+ *   begin -> for kb in 0..nblocks-1: { pack; ALL-GATHER(send -> recv, count per rank); unpack; block }
+ *            (one collective per 512-wide pivot block: every rank contributes the pivot-block columns of the tile rows it owns plus,
+ *             for the pivot tile rows it owns, the part left of the block; the update of the previous block keeps running underneath)
  *   alpha -> ALL-REDUCE(vec, count, sum) -> finish -> ALL-REDUCE(moments), ALL-REDUCE(diagG) on the host arrays.
  * Results equal mogp_exact_eval's (same moments / diagG definitions); lml is complete on every rank. */
 int  mogp_shard_config(mogp_model* m, int rank, int nranks);
 int  mogp_shard_begin(mogp_model* m, const double* noise_var, const double* data_var, double jitter, double* jitter_abs, int* nblocks);
 int  mogp_shard_pack(mogp_model* m, int kb, void** send, void** recv, int64_t* count);
 int  mogp_shard_unpack(mogp_model* m, int kb);
-int  mogp_shard_row(mogp_model* m, int kb, int t, int phase, void** buf, int64_t* count, int* owner);
 int  mogp_shard_block(mogp_model* m, int kb);
 int  mogp_shard_alpha(mogp_model* m, void** vec, int64_t* count);
 int  mogp_shard_finish(mogp_model* m, double* lml, double* moments, double* diagG, int64_t* info);

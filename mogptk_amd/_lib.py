@@ -49,8 +49,6 @@ SIGNATURES = {
     "mogp_shard_begin": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.POINTER(ctypes.c_int)]),
     "mogp_shard_pack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_i64p]),
     "mogp_shard_unpack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
-    "mogp_shard_row": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), c_i64p,
-                                      ctypes.POINTER(ctypes.c_int)]),
     "mogp_shard_block": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "mogp_shard_alpha": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), c_i64p]),
     "mogp_shard_finish": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_i64p]),
@@ -170,7 +168,7 @@ class ExactHandle:
         noise_var = _f64(noise_var)
         data_var = _f64(data_var)
         from .gpr.config import config as _cfg
-        if grad and getattr(_cfg, "comm", None) is not None and _cfg.comm.world > 1:
+        if grad and getattr(_cfg, "comm", None) is not None and (_cfg.comm.world > 1 or _cfg.comm.force):
             from . import dist as _dist
             return _dist.sharded_eval(self, _cfg.comm, noise_var, jitter, data_var)
         C, T, W = self.C, self.T, 2 + 3 * self.D
@@ -214,15 +212,6 @@ class ExactHandle:
 
     def shard_unpack(self, kb):
         check(lib().mogp_shard_unpack(self._h, kb))
-
-    def shard_pivot_rows(self, kb):
-        nb = -(-self.N // 128)
-        return 0 if kb == 0 else min(4, nb - 4 * kb)
-
-    def shard_row(self, kb, t, phase):
-        buf, count, owner = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int()
-        check(lib().mogp_shard_row(self._h, kb, t, phase, ctypes.byref(buf), ctypes.byref(count), ctypes.byref(owner)))
-        return buf.value, count.value, owner.value
 
     def shard_block(self, kb):
         check(lib().mogp_shard_block(self._h, kb))

@@ -600,7 +600,7 @@ int mogp_model_destroy(mogp_model* m) {
     m->k.release(); m->ws.release(); m->ws_tail.release();
     for (int b = 0; b < 2; ++b) { m->swU[b].release(); m->swUr[b].release(); }
     for (auto e : m->sw_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
-    m->d_symv.release(); m->sh_send.release(); m->sh_recv.release(); m->sh_row.release();
+    m->d_symv.release(); m->sh_send.release(); m->sh_recv.release();
     if (m->tw) { m->tw->release(); delete m->tw; m->tw = nullptr; }
     m->d_x.release(); m->d_y.release(); m->d_table.release();
     m->d_noise.release(); m->d_dvar.release(); m->d_z.release(); m->d_alpha.release(); m->d_zz.release();
@@ -842,16 +842,6 @@ int mogp_shard_unpack(mogp_model* m, int kb) {
     int rc;
     if ((rc = use_device(m->ctx))) return rc;
     return shard_unpack(m, m->k, kb);
-}
-
-int mogp_shard_row(mogp_model* m, int kb, int t, int phase, void** buf, int64_t* count, int* owner) {
-    if (!m || !buf || !count || !owner) return fail(MOGP_EINVAL, "mogp_shard_row: bad argument");
-    int rc;
-    if ((rc = use_device(m->ctx))) return rc;
-    double* b = nullptr;
-    if ((rc = shard_row(m, m->k, kb, t, phase, &b, count, owner))) return rc;
-    *buf = b;
-    return MOGP_OK;
 }
 
 int mogp_shard_block(mogp_model* m, int kb) {

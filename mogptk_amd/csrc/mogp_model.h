@@ -104,7 +104,7 @@ struct mogp_model {
     DevBuf<double> swU[2], swUr[2];     // old panels of the block being swept (column part, row part), double buffered
     std::vector<hipEvent_t> sw_ev;
     int sh_rank = 0, sh_n = 1;          // sharded evaluation: this rank owns tile rows i with i % sh_n == sh_rank
-    DevBuf<double> sh_send, sh_recv, sh_row;
+    DevBuf<double> sh_send, sh_recv;
     double sh_jabs = 0.0;
     bool sh_dvar = false;
 
@@ -148,5 +148,5 @@ int sweep_block(mogp_model* m, Spd& w, int kb);
 int sweep_finish(mogp_model* m, Spd& w);
 int shard_pack(mogp_model* m, Spd& w, int kb, double** send, double** recv, int64_t* count);
 int shard_unpack(mogp_model* m, Spd& w, int kb);
-int shard_row(mogp_model* m, Spd& w, int kb, int t, int phase, double** buf, int64_t* count, int* owner);     // w.A (SPD, lower) -> -inverse (lower); w.logdet per tile; failure through m->d_info
+// w.A (SPD, lower) -> -inverse (lower); w.logdet per tile; failure through m->d_info
 }  // namespace mogp

@@ -137,7 +137,7 @@ int spd_sweep(mogp_model* m, Spd& w) {
     return sweep_finish(m, w);
 }
 
-// ---- sharded evaluation: assembling the authoritative panel of pivot block kb -----------------------------------------
+// ---- sharded evaluation: assembling the authoritative panel of pivot block kb with ONE all-gather ------------------------
 // column part: tile rows i >= k0, 128 x Kd each, owner i % P; rank r's rows are first_r + idx * P
 __global__ void k_shard_pack(const double* __restrict__ A, int64_t ld, int k0, int nb, int P, int rank, int64_t Kd, double* __restrict__ send) {
     const int first = k0 + ((rank - k0 % P) + P) % P;
@@ -157,52 +157,52 @@ __global__ void k_shard_unpack(double* __restrict__ A, int64_t ld, int k0, int n
     for (int64_t e = threadIdx.x; e < MOGP_TILE * Kd; e += blockDim.x) dst[(e / Kd) * ld + (e % Kd)] = src[e];
 }
 
-static void shard_geometry(const Spd& w, int kb, int P, int& k0, int& nk, int64_t& Kd, int& maxrows) {
-    k0 = kb * SW_OB;
-    const int k1 = std::min(k0 + SW_OB, w.nb);
-    nk = k1 - k0;
-    Kd = (int64_t)nk * MOGP_TILE;
-    maxrows = (w.nb - k0 + P - 1) / P;
+// chunk of one rank for pivot block kb: [maxrows column tiles, 128 x Kd each][maxpiv row tiles, 128 x (k0*128) each]
+// (row tiles: the part LEFT of the pivot block of the pivot tile rows this rank owns -- the transposed half of the panel)
+struct ShardGeom { int k0, k1, nk, maxrows, maxpiv; int64_t Kd, cols, rowoff, chunk; };
+static ShardGeom shard_geometry(const Spd& w, int kb, int P) {
+    ShardGeom g;
+    g.k0 = kb * SW_OB;
+    g.k1 = std::min(g.k0 + SW_OB, w.nb);
+    g.nk = g.k1 - g.k0;
+    g.Kd = (int64_t)g.nk * MOGP_TILE;
+    g.cols = (int64_t)g.k0 * MOGP_TILE;
+    g.maxrows = (w.nb - g.k0 + P - 1) / P;
+    g.maxpiv = (g.nk + P - 1) / P;
+    g.rowoff = (int64_t)g.maxrows * MOGP_TILE * g.Kd;
+    g.chunk = g.rowoff + (int64_t)g.maxpiv * MOGP_TILE * g.cols;
+    return g;
 }
+static inline int first_owned(int k0, int P, int r) { return k0 + ((r - k0 % P) + P) % P; }
 
 int shard_pack(mogp_model* m, Spd& w, int kb, double** send, double** recv, int64_t* count) {
     const int P = m->sh_n;
-    int k0, nk, maxrows; int64_t Kd;
-    shard_geometry(w, kb, P, k0, nk, Kd, maxrows);
-    const int64_t chunk = (int64_t)maxrows * MOGP_TILE * Kd;
-    RC(m->sh_send.ensure((size_t)chunk)); RC(m->sh_recv.ensure((size_t)chunk * P));
-    hipLaunchKernelGGL(k_shard_pack, dim3(maxrows), dim3(256), 0, m->st, w.A.p, w.Npad, k0, w.nb, P, m->sh_rank, Kd, m->sh_send.p);
+    const ShardGeom g = shard_geometry(w, kb, P);
+    RC(m->sh_send.ensure((size_t)g.chunk)); RC(m->sh_recv.ensure((size_t)g.chunk * P));
+    hipLaunchKernelGGL(k_shard_pack, dim3(g.maxrows), dim3(256), 0, m->st, w.A.p, w.Npad, g.k0, w.nb, P, m->sh_rank, g.Kd, m->sh_send.p);
     HIP_TRY(hipGetLastError());
+    if (g.cols > 0) {
+        int idx = 0;
+        for (int i = first_owned(g.k0, P, m->sh_rank); i < g.k1; i += P, ++idx)
+            RC(launch_copy2d(m->sh_send.p + g.rowoff + (int64_t)idx * MOGP_TILE * g.cols, g.cols, w.A.p + (int64_t)i * MOGP_TILE * w.Npad, w.Npad,
+                             MOGP_TILE, g.cols, 1.0, m->st));
+    }
     HIP_TRY(hipStreamSynchronize(m->st));           // a1 / b1 of the previous block (critical stream) are in; the bulk stream keeps running
-    *send = m->sh_send.p; *recv = m->sh_recv.p; *count = chunk;
+    *send = m->sh_send.p; *recv = m->sh_recv.p; *count = g.chunk;
     return 0;
 }
 
 int shard_unpack(mogp_model* m, Spd& w, int kb) {
     const int P = m->sh_n;
-    int k0, nk, maxrows; int64_t Kd;
-    shard_geometry(w, kb, P, k0, nk, Kd, maxrows);
-    const int64_t chunk = (int64_t)maxrows * MOGP_TILE * Kd;
-    hipLaunchKernelGGL(k_shard_unpack, dim3(maxrows, P), dim3(256), 0, m->st, w.A.p, w.Npad, k0, w.nb, P, Kd, chunk, m->sh_recv.p);
+    const ShardGeom g = shard_geometry(w, kb, P);
+    hipLaunchKernelGGL(k_shard_unpack, dim3(g.maxrows, P), dim3(256), 0, m->st, w.A.p, w.Npad, g.k0, w.nb, P, g.Kd, g.chunk, m->sh_recv.p);
     HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-// row part of pivot tile row k0 + t: A[row tile][0 : k0*128], owner (k0 + t) % P.  phase 0: the owner packs it; phase 1: everybody unpacks
-int shard_row(mogp_model* m, Spd& w, int kb, int t, int phase, double** buf, int64_t* count, int* owner) {
-    const int k0 = kb * SW_OB;
-    const int i = k0 + t;
-    const int64_t cols = (int64_t)k0 * MOGP_TILE;
-    *owner = i % m->sh_n;
-    *count = (int64_t)MOGP_TILE * cols;
-    RC(m->sh_row.ensure((size_t)std::max<int64_t>(*count, 1)));
-    *buf = m->sh_row.p;
-    double* Arow = w.A.p + (int64_t)i * MOGP_TILE * w.Npad;
-    if (phase == 0) {
-        if (*owner == m->sh_rank) RC(launch_copy2d(m->sh_row.p, cols, Arow, w.Npad, MOGP_TILE, cols, 1.0, m->st));
-        HIP_TRY(hipStreamSynchronize(m->st));
-    } else {
-        RC(launch_copy2d(Arow, w.Npad, m->sh_row.p, cols, MOGP_TILE, cols, 1.0, m->st));
+    if (g.cols > 0) {
+        for (int i = g.k0; i < g.k1; ++i) {
+            const int r = i % P, idx = (i - first_owned(g.k0, P, r)) / P;
+            RC(launch_copy2d(w.A.p + (int64_t)i * MOGP_TILE * w.Npad, w.Npad, m->sh_recv.p + (int64_t)r * g.chunk + g.rowoff + (int64_t)idx * MOGP_TILE * g.cols,
+                             g.cols, MOGP_TILE, g.cols, 1.0, m->st));
+        }
     }
     return 0;
 }

@@ -37,11 +37,17 @@ class Comm:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.device_path = dist.get_backend(group) == "nccl"
+        self.force = False          # route even a 1-rank group through the sharded stages (validation of the RCCL plumbing)
+
+    def _wait(self):
+        # the collective is ordered after torch's current stream; wait for THAT stream only, so the library's bulk stream (still
+        # applying the previous pivot block's update) keeps running underneath the exchange
+        self.torch.cuda.current_stream().synchronize()
 
     def all_gather(self, h, send, recv, count):
         if self.device_path:
             self.dist.all_gather_into_tensor(h.mem_tensor(recv, count * self.world), h.mem_tensor(send, count), group=self.group)
-            self.torch.cuda.synchronize()
+            self._wait()
         else:
             s = self.torch.from_numpy(h.mem_get(send, count))
             r = self.torch.empty(count * self.world, dtype=self.torch.float64)
@@ -53,7 +59,7 @@ class Comm:
             return
         if self.device_path:
             self.dist.broadcast(h.mem_tensor(buf, count), src=src, group=self.group)
-            self.torch.cuda.synchronize()
+            self._wait()
         else:
             t = self.torch.from_numpy(h.mem_get(buf, count) if self.rank == src else np.empty(int(count)))
             self.dist.broadcast(t, src=src, group=self.group)
@@ -63,7 +69,7 @@ class Comm:
     def all_reduce_buf(self, h, buf, count):
         if self.device_path:
             self.dist.all_reduce(h.mem_tensor(buf, count), group=self.group)
-            self.torch.cuda.synchronize()
+            self._wait()
         else:
             t = self.torch.from_numpy(h.mem_get(buf, count))
             self.dist.all_reduce(t, group=self.group)
@@ -100,10 +106,6 @@ def sharded_eval(h, comm, noise_var, jitter, data_var=None):
         send, recv, count = h.shard_pack(kb)
         comm.all_gather(h, send, recv, count)
         h.shard_unpack(kb)
-        for t in range(h.shard_pivot_rows(kb)):
-            buf, count, owner = h.shard_row(kb, t, 0)
-            comm.broadcast(h, buf, count, owner)
-            h.shard_row(kb, t, 1)
         h.shard_block(kb)
     buf, count = h.shard_alpha()
     comm.all_reduce_buf(h, buf, count)

@@ -235,7 +235,7 @@ TableDevice.titsias_predict = titsias_predict
 # ----------------------------------------------------------------------------------------------------------------
 # numpy twin of the SHARDED evaluation stages (mogp_shard_*, mogptk_amd/csrc/sweep.hip): single-sweep blocked
 # inversion with 128-row tiles owned cyclically (tile row i -> rank i % world), 512-wide pivot blocks, the panel of
-# each pivot block assembled by an all-gather (column part) + broadcasts (pivot tile rows), the serial chain repeated
+# each pivot block assembled by ONE all-gather (pivot-block columns of every owned tile row + left part of the owned pivot rows), the serial chain repeated
 # by every rank and the rank-512 update restricted to owned rows.  Drives the same mogptk_amd.dist.sharded_eval as the
 # device handle, so tests/test_dist_cpu.py exercises the real orchestration under gloo with two CPU ranks.
 # ----------------------------------------------------------------------------------------------------------------
@@ -268,7 +268,10 @@ def _shard_begin(self, rank, world, noise_var, jitter, data_var=None):
 def _geom(self, kb):
     k0 = kb * OB
     k1 = min(k0 + OB, self.nb)
-    return k0, k1, (k1 - k0) * TILE, -(-(self.nb - k0) // self.world)
+    Kd = (k1 - k0) * TILE
+    maxrows, maxpiv = -(-(self.nb - k0) // self.world), -(-(k1 - k0) // self.world)
+    rowoff = maxrows * TILE * Kd
+    return k0, k1, Kd, maxrows, rowoff, rowoff + maxpiv * TILE * k0 * TILE
 
 
 def _owned_rows(self, k0, r):
@@ -277,41 +280,29 @@ def _owned_rows(self, k0, r):
 
 
 def _shard_pack(self, kb):
-    k0, k1, Kd, maxrows = _geom(self, kb)
-    chunk = maxrows * TILE * Kd
+    k0, k1, Kd, maxrows, rowoff, chunk = _geom(self, kb)
+    cols = k0 * TILE
     send = np.zeros(chunk)
     for idx, i in enumerate(_owned_rows(self, k0, self.rank)):
         send[idx * TILE * Kd:(idx + 1) * TILE * Kd] = self.A[i * TILE:(i + 1) * TILE, k0 * TILE:k0 * TILE + Kd].reshape(-1)
+        if i < k1 and cols:          # pivot tile row: its part left of the block travels in the same chunk
+            send[rowoff + idx * TILE * cols:rowoff + (idx + 1) * TILE * cols] = self.A[i * TILE:(i + 1) * TILE, :cols].reshape(-1)
     self._recv = np.zeros(chunk * self.world)
     return send, self._recv, chunk
 
 
 def _shard_unpack(self, kb):
-    k0, k1, Kd, maxrows = _geom(self, kb)
-    chunk = maxrows * TILE * Kd
+    k0, k1, Kd, maxrows, rowoff, chunk = _geom(self, kb)
+    cols = k0 * TILE
     for r in range(self.world):
         for idx, i in enumerate(_owned_rows(self, k0, r)):
             self.A[i * TILE:(i + 1) * TILE, k0 * TILE:k0 * TILE + Kd] = self._recv[r * chunk + idx * TILE * Kd:r * chunk + (idx + 1) * TILE * Kd].reshape(TILE, Kd)
-
-
-def _shard_pivot_rows(self, kb):
-    return 0 if kb == 0 else min(OB, self.nb - OB * kb)
-
-
-def _shard_row(self, kb, t, phase):
-    k0 = kb * OB
-    i = k0 + t
-    owner = i % self.world
-    cols = k0 * TILE
-    if phase == 0:
-        self._rowbuf = self.A[i * TILE:(i + 1) * TILE, :cols].reshape(-1).copy() if owner == self.rank else np.zeros(TILE * cols)
-    else:
-        self.A[i * TILE:(i + 1) * TILE, :cols] = self._rowbuf.reshape(TILE, cols)
-    return self._rowbuf, TILE * cols, owner
+            if i < k1 and cols:
+                self.A[i * TILE:(i + 1) * TILE, :cols] = self._recv[r * chunk + rowoff + idx * TILE * cols:r * chunk + rowoff + (idx + 1) * TILE * cols].reshape(TILE, cols)
 
 
 def _shard_block(self, kb):
-    k0, k1, Kd, _ = _geom(self, kb)
+    k0, k1, Kd = _geom(self, kb)[:3]
     A, T_ = self.A, TILE
     a0, a1 = k0 * T_, k1 * T_
     S = A[a0:a1, a0:a1]
@@ -385,7 +376,7 @@ def _shard_finish(self):
 
 
 for _n, _f in (("shard_begin", _shard_begin), ("shard_pack", _shard_pack), ("shard_unpack", _shard_unpack),
-               ("shard_pivot_rows", _shard_pivot_rows), ("shard_row", _shard_row), ("shard_block", _shard_block),
+               ("shard_block", _shard_block),
                ("shard_alpha", _shard_alpha), ("shard_finish", _shard_finish)):
     setattr(TableDevice, _n, _f)
 TableDevice.mem_get = lambda self, buf, count: np.array(buf[:count], dtype=np.float64)

@@ -374,10 +374,10 @@ def test_sharded_eval_two_ranks_one_gpu():
     """the multi-GPU evaluation (mogp_shard_* + mogptk_amd.dist.sharded_eval): two ranks sharing this GPU over gloo (buffers staged
     through the host) must reproduce the single-process loss and raw-parameter gradients; N = 3000 -> 24 tile rows, 6 pivot blocks,
     ragged last tile.  With RCCL the same code exchanges device buffers directly (tools/shard_check.py --backend nccl)."""
-    import json, subprocess, sys
+    import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29631", os.path.join(root, "tools", "shard_check.py"), "--n", "3000", "--backend", "gloo"],
+                          "--master-port", "29631", os.path.join(root, "tools", "shard_check.py"), "--points", "3000", "--backend", "gloo"],
                          capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])

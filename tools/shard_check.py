@@ -3,14 +3,14 @@ Run under torch.distributed.run: every rank evaluates the same exact-GP LML+grad
 sharded over the ranks (mogptk_amd.dist.sharded_eval), and rank 0 prints the differences as one JSON line.
   backend gloo  -> all ranks may share one GPU (buffers staged through the host): the validation mode of tests/test_gpu_parity.py
   backend nccl  -> one GPU per rank (RCCL), the production mode
-usage: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/shard_check.py [--n 3000] [--backend gloo] [--reps 3]
+usage: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/shard_check.py [--points 3000] [--backend gloo] [--reps 3]
 """
 import argparse, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--n", type=int, default=3000)
+ap.add_argument("--points", type=int, default=3000)
 ap.add_argument("--channels", type=int, default=4)
 ap.add_argument("--q", type=int, default=3)
 ap.add_argument("--backend", default="gloo")
@@ -31,7 +31,7 @@ else:
     dist.init_process_group("gloo")
 gpr.config.device = dev
 
-X, y = synth.make_data(a.n, a.channels)
+X, y = synth.make_data(a.points, a.channels)
 h = synth.mosm_hypers(a.channels, a.q)
 k = gpr.MultiOutputSpectralMixtureKernel(Q=a.q, output_dims=a.channels)
 for name in ("weight", "mean", "variance", "delay", "phase"):
@@ -46,7 +46,8 @@ for _ in range(a.reps):
     m.loss()
 t_single = (time.perf_counter() - t) / a.reps
 
-mogptk_amd.use_distributed()
+comm = mogptk_amd.use_distributed()
+comm.force = True
 l1 = float(m.loss())
 g1 = [p.grad.copy() for p in m.parameters()]
 dist.barrier()
@@ -62,6 +63,6 @@ if a.backend == "nccl":
     errs = errs.cuda()
 dist.all_reduce(errs, op=dist.ReduceOp.MAX)
 if rank == 0:
-    print(json.dumps(dict(world=world, backend=a.backend, N=a.n, loss=l0, loss_sharded=l1, rel_loss=float(errs[0]), rel_grad=float(errs[1]),
+    print(json.dumps(dict(world=world, backend=a.backend, N=a.points, loss=l0, loss_sharded=l1, rel_loss=float(errs[0]), rel_grad=float(errs[1]),
                           ms_single=1e3 * t_single, ms_sharded=1e3 * t_shard)))
 dist.destroy_process_group()
