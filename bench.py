@@ -9,9 +9,11 @@ gradient.  X and y are resident in HBM before the timed region (model creation);
 goes host->device per step.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL).  Round 1: the evaluation
-does not shard yet, so N ranks run N independent replicas of the workload ("replicas only") and
-`value` is the aggregate evals/s; scaling is therefore "weak".
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL).  `value` at N > 1 is the aggregate
+evals/s of N independent replicas of the workload (one 16 ms evaluation does not pay for an exchange per pivot block -- DESIGN.md
+section 6), so scaling is "weak".  The sharded evaluation (one evaluation spread over all ranks, RCCL all-gather per pivot
+block) is measured next to it, outside the timed region, and reported in the extra `sharded` object for the bench workload and
+for configs[2] (N=32768), where it is the point.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the fp64 MFMA GEMM, k_gemm) from HIP events
 recorded around every one of its launches inside the timed region; `cpu_baseline` times the torch-CPU port of the
@@ -34,7 +36,8 @@ HBM_PEAK_GBS = 8000.0
 
 def build_model(N, C, Q, device):
     from mogptk_amd import gpr, synth
-    gpr.config.device = device
+    if device is not None:
+        gpr.config.device = device
     X, y = synth.make_data(N, C)
     h = synth.mosm_hypers(C, Q)
     k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
@@ -101,6 +104,38 @@ def timed_region(step, steps, warmup, dist=None, sync=lambda: None, device="cpu"
     return dt
 
 
+def sharded_probe(m, dist, sync, world, cfg3=True):
+    """Extra, outside the timed region: the SAME evaluation sharded over all ranks (mogp_shard_* + one RCCL all-gather per 512-wide
+    pivot block) next to the one-GPU evaluation, at the bench workload and at configs[2] (MOSM C=8 Q=5 N=32768).
+    Reported as `sharded`; never part of `value`."""
+    import mogptk_amd
+
+    def run(model, reps):
+        mogptk_amd.use_single_device()
+        l0 = float(model.loss()); g0 = [p.grad.copy() for p in model.parameters()]
+        sync(); t = time.perf_counter()
+        for _ in range(reps):
+            model.loss()
+        sync(); t_single = (time.perf_counter() - t) / reps
+        comm = mogptk_amd.use_distributed()
+        comm.force = True
+        l1 = float(model.loss()); g1 = [p.grad.copy() for p in model.parameters()]
+        dist.barrier(); sync(); t = time.perf_counter()
+        for _ in range(reps):
+            model.loss()
+        sync(); dist.barrier(); t_shard = (time.perf_counter() - t) / reps
+        mogptk_amd.use_single_device()
+        err = max(float(np.max(np.abs(b - c)) / np.max(np.abs(c))) for b, c in zip(g1, g0))
+        return dict(ms_one_gpu=1e3 * t_single, ms_sharded=1e3 * t_shard, speedup=t_single / t_shard,
+                    rel_loss=abs(l1 - l0) / abs(l0), rel_grad=err)
+
+    out = {"ranks": world, "bench_workload": run(m, 5)}
+    if cfg3:
+        m3, _, _ = build_model(32768, 8, 5, None)      # gpr.config.device is already this rank's GPU
+        out["cfg3_mosm_c8_q5_n32768"] = run(m3, 2)
+    return out
+
+
 def aggregate_value(world, steps, dt):
     """whole-job evals/s: every rank ran `steps` evaluations of its own replica in `dt` (max over ranks)"""
     return world * steps / dt
@@ -115,6 +150,9 @@ def main():
     ap.add_argument("--channels", type=int, default=4)
     ap.add_argument("--q", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-probe", action="store_true", help="also run the sharded-evaluation probe at --gpus 1 (1-rank RCCL group)")
+    ap.add_argument("--no-shard-probe", action="store_true")
+    ap.add_argument("--no-cfg3-probe", action="store_true")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -158,6 +196,23 @@ def main():
 
     dt = timed_region(step, a.steps, a.warmup, dist, sync, "cuda" if dist is not None else "cpu")
     gemm_flops, gemm_launches, nprof = acc["flops"], acc["launches"], max(acc["nprof"], 1)
+    h.set_profiling(False)
+
+    sharded = None
+    if (world > 1 or a.shard_probe) and not a.no_shard_probe:
+        if dist is None:                    # --shard-probe on one GPU: a 1-rank RCCL group exercises the same code path
+            import torch.distributed as dist1
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29655")
+            dist1.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            pd = dist1
+        else:
+            pd = dist
+        try:
+            sharded = sharded_probe(m, pd, sync, world, cfg3=not a.no_cfg3_probe)
+        except Exception as e:              # symmetric across ranks (same code, same inputs); the replica measurement above stands
+            sharded = {"error": repr(e)}
+        if dist is None:
+            pd.destroy_process_group()
 
     if rank == 0:
         ms_per_step = 1e3 * dt / a.steps
@@ -189,14 +244,20 @@ def main():
                          "bytes_per_launch": gram_bytes},
             "moments_hbm": {"achieved": mom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mom_gbs / HBM_PEAK_GBS},
         }
+        if sharded is not None:
+            out["sharded"] = sharded
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, a.channels, a.q)
             except Exception as e:      # the baseline is a report, never a reason to lose the GPU measurement
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
-        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)      # RCCL's start-up banner sits in the C stdio buffer: get it out BEFORE the result line
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -179,8 +179,10 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (grid <= 0) return 0;
     const int v = (a.a_kmajor ? 2 : 0) | (a.b_kmajor ? 1 : 0);
     if (a.small) {
-        if (v != 0 || (a.mode != GM_RECT && a.mode != GM_RECT_LOWER)) {
-            set_error("launch_gemm: small-tile variants are built for k-contiguous operands and RECT grids only");
+        const bool rect = a.mode == GM_RECT || a.mode == GM_RECT_LOWER;
+        if (a.small == 1 && v == 1 && (rect || a.mode == GM_KLO_J || a.mode == GM_KHI_I)) return launch_gemm_t<0, 1, 2, 4>(a, grid, s);
+        if (v != 0 || !rect) {
+            set_error("launch_gemm: small-tile variants are built for A k-contiguous and rectangular grids only");
             return -1;
         }
         return a.small == 1 ? launch_gemm_t<0, 0, 2, 4>(a, grid, s) : launch_gemm_t<0, 0, 2, 2>(a, grid, s);

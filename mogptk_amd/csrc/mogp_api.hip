@@ -204,7 +204,91 @@ namespace mogp { int mark(mogp_model* m, int idx) {
 
 // Cholesky of w.A (lower) in place; w.invd gets the inverses of the diagonal 128-tiles, w.logdet the per-tile sums of
 // log L_kk; a non-positive pivot is reported through m->d_info (atomicMin of the 1-based index).
-namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base) {
+// W[R, c0:r0] = -Wrr * (L[R, c0:r0] * W[c0:r0, c0:r0]) for the tile rows R = [r0, r0 + nr): one step of the row-wise triangular
+// inversion.  The columns' own W block is finished, Wrr = inverse of the diagonal block of R (lower, leading dimension ldr); the
+// product in brackets goes through the same positions of w.B (scratch), the result replaces L in place.
+static int w_rowblock(mogp_model* m, Spd& w, int r0, int nr, int c0, const double* Wrr, int64_t ldr, hipStream_t q) {
+    const int n = r0 - c0;
+    if (n <= 0) return 0;
+    const int64_t ld = w.Npad;
+    const int64_t off = (int64_t)r0 * MOGP_TILE * ld + (int64_t)c0 * MOGP_TILE;
+    const int small = (nr * n < 512) ? 1 : 0;                   // 64 x 128 tiles while the launch is far from filling the chip
+    int rc;
+    GemmArgs g{};
+    g.A = w.A.p + off; g.lda = ld; g.a_kmajor = 0;
+    g.B = w.A.p + (int64_t)c0 * MOGP_TILE * (ld + 1); g.ldb = ld; g.b_kmajor = 1;
+    g.C = w.B.p + off; g.ldc = ld; g.alpha = 1.0; g.beta = 0.0;
+    g.mode = GM_KLO_J; g.small = small; g.mt = small ? 2 * nr : nr; g.nt = n; g.K = n * MOGP_TILE;
+    if ((rc = gemm_call(m, g, gemm_flops(g, nullptr), q))) return rc;
+    GemmArgs h{};
+    h.A = Wrr; h.lda = ldr; h.a_kmajor = 0;
+    h.B = w.B.p + off; h.ldb = ld; h.b_kmajor = 1;
+    h.C = w.A.p + off; h.ldc = ld; h.alpha = -1.0; h.beta = 0.0;
+    h.mode = GM_KHI_I; h.small = small; h.mt = small ? 2 * nr : nr; h.nt = n; h.K = nr * MOGP_TILE;
+    return gemm_call(m, h, gemm_flops(h, nullptr), q);
+}
+
+// The inverse streamed behind the factorisation (fuse_inverse).  W = L^-1 is built by applying the elementary block-column
+// inverses as the chain delivers them: once outer block K (Kd = 512 columns, diagonal block inverse W_KK) is factored,
+//   st4:  W_KK                      (tiny; depends on the chain only, so it is off the serial path of st3)
+//   st3:  W[K, <K]  = W_KK * Wt[K, <K]                 finalise the row block (Wt = the running product, kept in w.Wm)
+//         Wt[>K, K] = -L[>K, K] * W_KK ; Wt[>K, <K] -= L[>K, K] * W[K, <K]        rank-Kd update of all rows below
+//         Kinv[<=K, <=K] += W[K, <=K]^T W[K, <=K]      rank-Kd update of the inverse (w.B)
+// Every large launch is a K = 512 update (the shape the GEMM kernel is fastest on), the same N^3 flops as TRTRI + LAUUM, and it
+// runs in the time the latency-bound chain leaves the chip idle.  L stays in w.A (diagonal blocks replaced by W_KK), W is in
+// w.Wm, (L L^T)^-1 (lower tiles, full diagonal tiles) in w.B.
+static int diag_block_inverse(mogp_model* m, Spd& w, int k0, int k1, hipStream_t q) {
+    const int64_t ld = w.Npad;
+    const int nk = k1 - k0;
+    int rc;
+    if ((rc = launch_put_diag_tiles(w.A.p + (int64_t)k0 * MOGP_TILE * (ld + 1), ld, nk, w.invd.p + (int64_t)k0 * MOGP_TILE * MOGP_TILE, q))) return rc;
+    for (int t = 1; t < nk; ++t)
+        if ((rc = w_rowblock(m, w, k0 + t, 1, k0, w.invd.p + (int64_t)(k0 + t) * MOGP_TILE * MOGP_TILE, MOGP_TILE, q))) return rc;
+    return 0;
+}
+
+static int inverse_behind_chain(mogp_model* m, Spd& w, int k0, int k1, hipStream_t q) {
+    const int64_t ld = w.Npad;
+    const int nk = k1 - k0, rem = w.nb - k1;
+    const int64_t Kd = (int64_t)nk * MOGP_TILE, c0 = (int64_t)k0 * MOGP_TILE;
+    int rc;
+    const double* Wkk = w.A.p + c0 * (ld + 1);
+    double* Wrow = w.Wm.p + c0 * ld;                 // W[K, 0]
+    double* Brow = w.B.p + c0 * ld;                  // scratch now, Kinv[K, 0] afterwards
+    if (k0 > 0) {                                    // finalise the row block through the scratch (not in place)
+        GemmArgs g{};
+        g.A = Wkk; g.lda = ld; g.a_kmajor = 0; g.B = Wrow; g.ldb = ld; g.b_kmajor = 1;
+        g.C = Brow; g.ldc = ld; g.alpha = 1.0; g.beta = 0.0;
+        g.mode = GM_KHI_I; g.small = 1; g.mt = 2 * nk; g.nt = k0; g.K = (int)Kd;
+        if ((rc = gemm_call(m, g, gemm_flops(g, nullptr), q))) return rc;
+        if ((rc = launch_copy2d(Wrow, ld, Brow, ld, Kd, c0, 1.0, q))) return rc;
+    }
+    if ((rc = launch_copy2d(Wrow + c0, ld, Wkk, ld, Kd, Kd, 1.0, q))) return rc;
+    if (rem > 0) {
+        const double* Lp = w.A.p + (int64_t)k1 * MOGP_TILE * ld + c0;          // L[>K, K]
+        double* Wt = w.Wm.p + (int64_t)k1 * MOGP_TILE * ld;                    // Wt[>K, 0]
+        GemmArgs g{};
+        g.A = Lp; g.lda = ld; g.a_kmajor = 0; g.B = Wkk; g.ldb = ld; g.b_kmajor = 1;
+        g.C = Wt + c0; g.ldc = ld; g.alpha = -1.0; g.beta = 0.0;
+        g.mode = GM_KLO_J; g.mt = rem; g.nt = nk; g.K = (int)Kd;
+        if ((rc = gemm_call(m, g, gemm_flops(g, nullptr), q))) return rc;
+        if (k0 > 0) {
+            GemmArgs u{};
+            u.A = Lp; u.lda = ld; u.a_kmajor = 0; u.B = Wrow; u.ldb = ld; u.b_kmajor = 1;
+            u.C = Wt; u.ldc = ld; u.alpha = -1.0; u.beta = 1.0;
+            u.mode = GM_RECT; u.mt = rem; u.nt = k0; u.K = (int)Kd;
+            if ((rc = gemm_call(m, u, gemm_flops(u, nullptr), q))) return rc;
+        }
+    }
+    HIP_TRY(hipMemset2DAsync(Brow, ld * sizeof(double), 0, (size_t)k1 * MOGP_TILE * sizeof(double), (size_t)Kd, q));
+    GemmArgs g{};
+    g.A = Wrow; g.lda = ld; g.a_kmajor = 1; g.B = Wrow; g.ldb = ld; g.b_kmajor = 1;
+    g.C = w.B.p; g.ldc = ld; g.alpha = 1.0; g.beta = 1.0;
+    g.mode = GM_LOWER; g.mt = g.nt = k1; g.K = (int)Kd;
+    return gemm_call(m, g, gemm_flops(g, nullptr), q);
+}
+
+namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base, bool fuse_inverse) {
     int rc;
     // ---- two-level blocked right-looking Cholesky with look-ahead.
     // Outer blocks of MOGP_OUTER tiles.  "chain(kb)" = for each 128-column of the block: leaf (factor + inverse) -> panel =
@@ -221,10 +305,29 @@ namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base) {
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         w.sync_ev.push_back(e);
     }
+    if (fuse_inverse) {
+        if (w.Wm.n < (size_t)w.Npad * w.Npad) {                   // nothing ever writes above the block diagonal: keep it finite
+            if ((rc = w.Wm.ensure((size_t)w.Npad * w.Npad))) return rc;
+            HIP_TRY(hipMemsetAsync(w.Wm.p, 0, (size_t)w.Npad * w.Npad * sizeof(double), m->st));
+            HIP_TRY(hipStreamSynchronize(m->st));
+        }
+        while ((int)w.inv_ev.size() < nouter) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            w.inv_ev.push_back(e);
+        }
+    }
     int last_bulk = -1;
     for (int kb = 0; kb < nouter; ++kb) {
         const int k0 = kb * MOGP_OUTER, k1 = std::min(k0 + MOGP_OUTER, nb);
         for (int k = k0; k < k1; ++k) {
+            if (m->st_leaf) {
+                HIP_TRY(hipEventRecord(m->leaf_ev[0], m->st));
+                HIP_TRY(hipStreamWaitEvent(m->st_leaf, m->leaf_ev[0], 0));
+                if ((rc = launch_potrf_trtri_tile(w.A.p, w.Npad, k, w.invd.p, w.logdet.p, m->d_info.p, m->st_leaf, info_base))) return rc;
+                HIP_TRY(hipEventRecord(m->leaf_ev[1], m->st_leaf));
+                HIP_TRY(hipStreamWaitEvent(m->st, m->leaf_ev[1], 0));
+            } else
             if ((rc = launch_potrf_trtri_tile(w.A.p, w.Npad, k, w.invd.p, w.logdet.p, m->d_info.p, m->st, info_base))) return rc;
             const int rem = nb - k - 1;
             if (rem <= 0) break;
@@ -245,11 +348,18 @@ namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base) {
             }
         }
         const int rem = nb - k1;
+        HIP_TRY(hipEventRecord(w.sync_ev[2 * kb], m->st));                       // chain(kb) done
+        if (fuse_inverse) {
+            HIP_TRY(hipStreamWaitEvent(m->st4, w.sync_ev[2 * kb], 0));
+            if ((rc = diag_block_inverse(m, w, k0, k1, m->st4))) return rc;
+            HIP_TRY(hipEventRecord(w.inv_ev[kb], m->st4));
+            HIP_TRY(hipStreamWaitEvent(m->st3, w.inv_ev[kb], 0));
+            if ((rc = inverse_behind_chain(m, w, k0, k1, m->st3))) return rc;
+        }
         if (rem <= 0) break;
         double* blockp = w.A.p + (int64_t)k1 * MOGP_TILE * w.Npad + (int64_t)k0 * MOGP_TILE;
         const int K = (k1 - k0) * MOGP_TILE;
         const int na = std::min(MOGP_OUTER, rem);      // tile columns of the next outer block
-        HIP_TRY(hipEventRecord(w.sync_ev[2 * kb], m->st));                       // chain(kb) done
         if (rem > na) {                                                           // B(kb) on the bulk stream
             HIP_TRY(hipStreamWaitEvent(m->st2, w.sync_ev[2 * kb], 0));
             double* bp = blockp + (int64_t)na * MOGP_TILE * w.Npad;
@@ -270,6 +380,10 @@ namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base) {
         }
     }
     if (last_bulk >= 0) HIP_TRY(hipStreamWaitEvent(m->st, w.sync_ev[2 * last_bulk + 1], 0));
+    if (fuse_inverse) {
+        HIP_TRY(hipEventRecord(w.sync_ev[2 * nouter], m->st3));
+        HIP_TRY(hipStreamWaitEvent(m->st, w.sync_ev[2 * nouter], 0));
+    }
     return 0;
 }
 }  // namespace mogp
@@ -343,7 +457,7 @@ namespace mogp { double table_diag(const mogp_model* m, int c) {
 
 // Gram + factorisation + inverse factor + alpha.  On return d_A holds W = L^-1, d_alpha = Kj^-1 y.
 static int factorize(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
-                     double* lml, double* jitter_abs, int64_t* info) {
+                     double* lml, double* jitter_abs, int64_t* info, bool fuse_inverse = false) {
     const int C = m->C, D = m->D, W = 2 + 3 * D;
     const int64_t N = m->N, Npad = m->Npad;
     if (m->T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms must be called before an evaluation");
@@ -379,15 +493,17 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     if ((rc = launch_pad_identity(m->k.A.p, Npad, N, Npad, m->st))) return rc;
     if ((rc = mark(m, 1))) return rc;
 
-    if ((rc = spd_potrf(m, m->k))) return rc;
+    if ((rc = spd_potrf(m, m->k, 0, fuse_inverse))) return rc;
     if ((rc = mark(m, 2))) return rc;
 
-    if ((rc = spd_trtri(m, m->k))) return rc;
+    if (!fuse_inverse && (rc = spd_trtri(m, m->k))) return rc;
     if ((rc = mark(m, 3))) return rc;
 
     // ---- z = W y, alpha = W^T z
-    if ((rc = launch_trmv_lower(m->k.A.p, Npad, Npad, m->d_y.p, m->d_z.p, m->d_zz.p, m->st))) return rc;
-    if ((rc = launch_trmv_lower_t(m->k.A.p, Npad, Npad, m->d_z.p, m->d_alpha.p, m->st))) return rc;
+    const double* Wp = fuse_inverse ? m->k.Wm.p : m->k.A.p;
+    m->w_in_Wm = fuse_inverse;
+    if ((rc = launch_trmv_lower(Wp, Npad, Npad, m->d_y.p, m->d_z.p, m->d_zz.p, m->st))) return rc;
+    if ((rc = launch_trmv_lower_t(Wp, Npad, Npad, m->d_z.p, m->d_alpha.p, m->st))) return rc;
     if ((rc = mark(m, 4))) return rc;
 
     // scalars back
@@ -564,7 +680,30 @@ int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, c
         int lo = 0, hi = 0;
         TRY_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         TRY_HIP(hipStreamCreateWithPriority(&m->st, hipStreamNonBlocking, hi));
-        TRY_HIP(hipStreamCreateWithPriority(&m->st2, hipStreamNonBlocking, lo));
+        // The bulk streams leave MOGP_RESERVE_CUS compute units of every XCD to the latency-bound chain: CU-mask bit i is CU
+        // (i / 8) of XCD (i % 8) on gfx950 (tools/micro/cumask.hip), so clearing the first 8 R bits takes R CUs from each XCD.
+        // MOGP_MASK_STREAMS: 0 none, 1 the inverse stream only, 2 both bulk streams.
+        const char* er = std::getenv("MOGP_RESERVE_CUS");
+        const char* em = std::getenv("MOGP_MASK_STREAMS");
+        const int reserve = er ? std::atoi(er) : 0, which = em ? std::atoi(em) : 2;
+        hipDeviceProp_t prop;
+        TRY_HIP(hipGetDeviceProperties(&prop, ctx->device));
+        const int ncu = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        for (int i = 8 * reserve; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
+        const bool masked = reserve > 0 && 8 * reserve < ncu;
+        if (masked && std::getenv("MOGP_LEAF_STREAM")) {          // experiment: the leaf on a stream that owns the reserved CUs
+            std::vector<uint32_t> lm((ncu + 31) / 32, 0u);
+            for (int i = 0; i < 8 * reserve; ++i) lm[i / 32] |= 1u << (i % 32);
+            TRY_HIP(hipExtStreamCreateWithCUMask(&m->st_leaf, (uint32_t)lm.size(), lm.data()));
+            TRY_HIP(hipEventCreateWithFlags(&m->leaf_ev[0], hipEventDisableTiming));
+            TRY_HIP(hipEventCreateWithFlags(&m->leaf_ev[1], hipEventDisableTiming));
+        }
+        if (masked && which >= 2) TRY_HIP(hipExtStreamCreateWithCUMask(&m->st2, (uint32_t)mask.size(), mask.data()));
+        else TRY_HIP(hipStreamCreateWithPriority(&m->st2, hipStreamNonBlocking, (lo + hi) / 2));
+        if (masked && which >= 1) TRY_HIP(hipExtStreamCreateWithCUMask(&m->st3, (uint32_t)mask.size(), mask.data()));
+        else TRY_HIP(hipStreamCreateWithPriority(&m->st3, hipStreamNonBlocking, lo));
+        TRY_HIP(hipStreamCreateWithPriority(&m->st4, hipStreamNonBlocking, (lo + hi) / 2));
     }
     TRY_RC(spd_alloc(m->k, Npad));
     TRY_RC(m->d_x.ensure((size_t)D * Npad));
@@ -597,6 +736,8 @@ int mogp_model_destroy(mogp_model* m) {
     for (auto e : m->ev) { hipError_t r = hipEventDestroy(e); (void)r; }
     for (auto e : m->gemm_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
     if (m->st2) { hipError_t e = hipStreamSynchronize(m->st2); (void)e; e = hipStreamDestroy(m->st2); (void)e; }
+    if (m->st3) { hipError_t e = hipStreamSynchronize(m->st3); (void)e; e = hipStreamDestroy(m->st3); (void)e; }
+    if (m->st4) { hipError_t e = hipStreamSynchronize(m->st4); (void)e; e = hipStreamDestroy(m->st4); (void)e; }
     m->k.release(); m->ws.release(); m->ws_tail.release();
     for (int b = 0; b < 2; ++b) { m->swU[b].release(); m->swUr[b].release(); }
     for (auto e : m->sw_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
@@ -650,17 +791,20 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     // MOGP_GRAD_PATH=sweep selects the single-sweep blocked inversion (sweep.hip) instead of POTRF -> TRTRI -> LAUUM.  On one
     // GPU the three-phase path is faster (59 vs 47 evals/s at cfg2: the 512-block inversion chain is not hidden); the sweep needs
     // one panel exchange per block, which is what a sharded multi-GPU evaluation wants.
-    static const bool use_sweep = []() { const char* e = std::getenv("MOGP_GRAD_PATH"); return e && std::string(e) == "sweep"; }();
-    const bool sweep = use_sweep && (flags & MOGP_EVAL_GRAD);
+    // Default for a gradient evaluation: the inverse streamed behind the factorisation (spd_potrf with fuse_inverse);
+    // MOGP_GRAD_PATH=phases runs POTRF, TRTRI, LAUUM one after the other (the same arithmetic, kept for A/B measurements).
+    static const std::string grad_path = []() { const char* e = std::getenv("MOGP_GRAD_PATH"); return std::string(e ? e : ""); }();
+    const bool sweep = grad_path == "sweep" && (flags & MOGP_EVAL_GRAD);
+    const bool fused = !sweep && grad_path != "phases" && (flags & MOGP_EVAL_GRAD);
     if (sweep) { if ((rc = eval_sweep(m, noise_var, data_var, jitter, lml, jitter_abs, info))) return rc; }
-    else if ((rc = factorize(m, noise_var, data_var, jitter, lml, jitter_abs, info))) return rc;
+    else if ((rc = factorize(m, noise_var, data_var, jitter, lml, jitter_abs, info, fused))) return rc;
     if (!(flags & MOGP_EVAL_GRAD)) { collect_timing(m, 4); return MOGP_OK; }
     if (!moments || !diagG || !trG) return fail(MOGP_EINVAL, "mogp_exact_eval: gradient outputs are null");
 
     const int C = m->C, D = m->D, W = 2 + 3 * D, T = m->T, P = C * (C + 1) / 2;
     const int64_t Npad = m->Npad;
     // K^-1: the sweep left -Kj^-1 in k.A; the POTRF path needs W^T W (lower tiles, full diagonal tiles) in k.B
-    if (!sweep && (rc = spd_lauum(m, m->k))) return rc;
+    if (!sweep && !fused && (rc = spd_lauum(m, m->k))) return rc;
     const double* kinv = sweep ? m->k.A.p : m->k.B.p;
     const double ksign = sweep ? -1.0 : 1.0;
     if ((rc = mark(m, 5))) return rc;
@@ -911,7 +1055,8 @@ int mogp_model_fetch(mogp_model* m, int which, double* out) {
     if (which != 0 && which != 1) return fail(MOGP_EINVAL, "mogp_model_fetch: which must be 0, 1 or 2");
     std::vector<double> h((size_t)Npad * Npad);
     const bool neg = (which == 1 && m->kinv_in_A);
-    HIP_TRY(hipMemcpy(h.data(), (which == 0 || neg) ? m->k.A.p : m->k.B.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const double* src = which == 0 ? (m->w_in_Wm ? m->k.Wm.p : m->k.A.p) : (neg ? m->k.A.p : m->k.B.p);
+    HIP_TRY(hipMemcpy(h.data(), src, h.size() * sizeof(double), hipMemcpyDeviceToHost));
     if (neg) for (auto& v : h) v = -v;
     for (int64_t a = 0; a < N; ++a)
         for (int64_t b = 0; b < N; ++b) {

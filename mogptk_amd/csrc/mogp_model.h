@@ -61,11 +61,15 @@ struct Spd {
     int64_t Npad = 0;
     int nb = 0;
     DevBuf<double> A, B, invd, logdet;
+    DevBuf<double> Wm;                  // W = L^-1 when the inverse is streamed behind the factorisation (spd_potrf fuse_inverse)
     std::vector<TrtriLevel> levels;
     std::vector<hipEvent_t> sync_ev;    // cross-stream dependencies of the look-ahead schedule
+    std::vector<hipEvent_t> inv_ev;
     void release() {
         for (auto& lv : levels) { lv.d1.release(); lv.d2.release(); }
         for (auto e : sync_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
+        for (auto e : inv_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
+        inv_ev.clear(); Wm.release();
         levels.clear(); sync_ev.clear();
         A.release(); B.release(); invd.release(); logdet.release();
     }
@@ -99,6 +103,10 @@ struct mogp_model {
     std::vector<double> table;          // host copy [C*C*T*W]
     hipStream_t st = nullptr;           // critical-path stream (high priority)
     hipStream_t st2 = nullptr;          // bulk trailing updates (look-ahead)
+    hipStream_t st3 = nullptr;          // inverse streamed behind the factorisation (lowest priority)
+    hipStream_t st4 = nullptr;          // diagonal-block inverses W_KK for st3
+    hipStream_t st_leaf = nullptr;      // (experiment) leaf kernels on reserved CUs
+    hipEvent_t leaf_ev[2] = {nullptr, nullptr};
     Spd k;                              // the N x N system
     Spd ws, ws_tail;                    // Schur-block workspaces of the sweep inversion (outer block / last partial block)
     DevBuf<double> swU[2], swUr[2];     // old panels of the block being swept (column part, row part), double buffered
@@ -127,7 +135,7 @@ struct mogp_model {
     double ms[MOGP_ST_COUNT] = {0};
     int64_t gemm_launches = 0;
     double gemm_flops = 0.0;
-    bool have_W = false, have_Kinv = false, kinv_in_A = false;
+    bool have_W = false, have_Kinv = false, kinv_in_A = false, w_in_Wm = false;
     TitsiasWork* tw = nullptr;
 };
 
@@ -138,7 +146,7 @@ int gemm_call(mogp_model* m, const GemmArgs& g, double flops, hipStream_t st = n
 int mark(mogp_model* m, int idx);
 double table_diag(const mogp_model* m, int c);
 int spd_alloc(Spd& w, int64_t Npad);
-int spd_potrf(mogp_model* m, Spd& w, long long info_base = 0);
+int spd_potrf(mogp_model* m, Spd& w, long long info_base = 0, bool fuse_inverse = false);
 int spd_trtri(mogp_model* m, Spd& w);
 int spd_lauum(mogp_model* m, Spd& w);
 int spd_sweep(mogp_model* m, Spd& w);
