@@ -181,6 +181,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.small) {
         const bool rect = a.mode == GM_RECT || a.mode == GM_RECT_LOWER;
         if (a.small == 1 && v == 1 && (rect || a.mode == GM_KLO_J || a.mode == GM_KHI_I)) return launch_gemm_t<0, 1, 2, 4>(a, grid, s);
+        if (a.small == 1 && v == 0 && a.mode == GM_KHI_J) return launch_gemm_t<0, 0, 2, 4>(a, grid, s);
         if (v != 0 || !rect) {
             set_error("launch_gemm: small-tile variants are built for A k-contiguous and rectangular grids only");
             return -1;
@@ -208,7 +209,7 @@ double gemm_flops(const GemmArgs& a, const std::vector<GemmTask>* host_tasks) {
         case GM_KHI_I: for (int ti = 0; ti < a.mt; ++ti) k += (double)a.nt * ((ti + 1) * TM < a.K ? (ti + 1) * TM : a.K); break;
         case GM_KLO_J: for (int tj = 0; tj < a.nt; ++tj) k += (double)a.mt * (a.K - tj * TN); break;
         case GM_KLO_I: for (int ti = 0; ti < a.mt; ++ti) k += (double)a.nt * (a.K - ti * TM); break;
-        case GM_KHI_J: for (int tj = 0; tj < a.nt; ++tj) k += (double)a.mt * ((tj + 1) * TM < a.K ? (tj + 1) * TM : a.K); break;
+        case GM_KHI_J: for (int tj = 0; tj < a.nt; ++tj) k += (double)a.mt * ((tj + 1) * TN < a.K ? (tj + 1) * TN : a.K); break;
         default: if (host_tasks) for (const auto& t : *host_tasks) k += (double)t.kt * GEMM_BK; break;
     }
     return tile * k;

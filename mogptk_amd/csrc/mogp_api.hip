@@ -126,7 +126,12 @@ int mogp_ctx_create(int device, mogp_ctx** out) {
     return MOGP_OK;
 }
 
-int mogp_ctx_destroy(mogp_ctx* ctx) { delete ctx; return MOGP_OK; }
+int mogp_ctx_destroy(mogp_ctx* ctx) {
+    if (!ctx) return MOGP_OK;
+    for (hipStream_t q : {ctx->st, ctx->st2, ctx->st3, ctx->st_priv}) if (q) { hipError_t e = hipStreamSynchronize(q); (void)e; e = hipStreamDestroy(q); (void)e; }
+    delete ctx;
+    return MOGP_OK;
+}
 
 int mogp_ctx_device_name(mogp_ctx* ctx, char* buf, int buflen) {
     if (!ctx || !buf || buflen <= 0) return fail(MOGP_EINVAL, "mogp_ctx_device_name: bad argument");
@@ -204,91 +209,7 @@ namespace mogp { int mark(mogp_model* m, int idx) {
 
 // Cholesky of w.A (lower) in place; w.invd gets the inverses of the diagonal 128-tiles, w.logdet the per-tile sums of
 // log L_kk; a non-positive pivot is reported through m->d_info (atomicMin of the 1-based index).
-// W[R, c0:r0] = -Wrr * (L[R, c0:r0] * W[c0:r0, c0:r0]) for the tile rows R = [r0, r0 + nr): one step of the row-wise triangular
-// inversion.  The columns' own W block is finished, Wrr = inverse of the diagonal block of R (lower, leading dimension ldr); the
-// product in brackets goes through the same positions of w.B (scratch), the result replaces L in place.
-static int w_rowblock(mogp_model* m, Spd& w, int r0, int nr, int c0, const double* Wrr, int64_t ldr, hipStream_t q) {
-    const int n = r0 - c0;
-    if (n <= 0) return 0;
-    const int64_t ld = w.Npad;
-    const int64_t off = (int64_t)r0 * MOGP_TILE * ld + (int64_t)c0 * MOGP_TILE;
-    const int small = (nr * n < 512) ? 1 : 0;                   // 64 x 128 tiles while the launch is far from filling the chip
-    int rc;
-    GemmArgs g{};
-    g.A = w.A.p + off; g.lda = ld; g.a_kmajor = 0;
-    g.B = w.A.p + (int64_t)c0 * MOGP_TILE * (ld + 1); g.ldb = ld; g.b_kmajor = 1;
-    g.C = w.B.p + off; g.ldc = ld; g.alpha = 1.0; g.beta = 0.0;
-    g.mode = GM_KLO_J; g.small = small; g.mt = small ? 2 * nr : nr; g.nt = n; g.K = n * MOGP_TILE;
-    if ((rc = gemm_call(m, g, gemm_flops(g, nullptr), q))) return rc;
-    GemmArgs h{};
-    h.A = Wrr; h.lda = ldr; h.a_kmajor = 0;
-    h.B = w.B.p + off; h.ldb = ld; h.b_kmajor = 1;
-    h.C = w.A.p + off; h.ldc = ld; h.alpha = -1.0; h.beta = 0.0;
-    h.mode = GM_KHI_I; h.small = small; h.mt = small ? 2 * nr : nr; h.nt = n; h.K = nr * MOGP_TILE;
-    return gemm_call(m, h, gemm_flops(h, nullptr), q);
-}
-
-// The inverse streamed behind the factorisation (fuse_inverse).  W = L^-1 is built by applying the elementary block-column
-// inverses as the chain delivers them: once outer block K (Kd = 512 columns, diagonal block inverse W_KK) is factored,
-//   st4:  W_KK                      (tiny; depends on the chain only, so it is off the serial path of st3)
-//   st3:  W[K, <K]  = W_KK * Wt[K, <K]                 finalise the row block (Wt = the running product, kept in w.Wm)
-//         Wt[>K, K] = -L[>K, K] * W_KK ; Wt[>K, <K] -= L[>K, K] * W[K, <K]        rank-Kd update of all rows below
-//         Kinv[<=K, <=K] += W[K, <=K]^T W[K, <=K]      rank-Kd update of the inverse (w.B)
-// Every large launch is a K = 512 update (the shape the GEMM kernel is fastest on), the same N^3 flops as TRTRI + LAUUM, and it
-// runs in the time the latency-bound chain leaves the chip idle.  L stays in w.A (diagonal blocks replaced by W_KK), W is in
-// w.Wm, (L L^T)^-1 (lower tiles, full diagonal tiles) in w.B.
-static int diag_block_inverse(mogp_model* m, Spd& w, int k0, int k1, hipStream_t q) {
-    const int64_t ld = w.Npad;
-    const int nk = k1 - k0;
-    int rc;
-    if ((rc = launch_put_diag_tiles(w.A.p + (int64_t)k0 * MOGP_TILE * (ld + 1), ld, nk, w.invd.p + (int64_t)k0 * MOGP_TILE * MOGP_TILE, q))) return rc;
-    for (int t = 1; t < nk; ++t)
-        if ((rc = w_rowblock(m, w, k0 + t, 1, k0, w.invd.p + (int64_t)(k0 + t) * MOGP_TILE * MOGP_TILE, MOGP_TILE, q))) return rc;
-    return 0;
-}
-
-static int inverse_behind_chain(mogp_model* m, Spd& w, int k0, int k1, hipStream_t q) {
-    const int64_t ld = w.Npad;
-    const int nk = k1 - k0, rem = w.nb - k1;
-    const int64_t Kd = (int64_t)nk * MOGP_TILE, c0 = (int64_t)k0 * MOGP_TILE;
-    int rc;
-    const double* Wkk = w.A.p + c0 * (ld + 1);
-    double* Wrow = w.Wm.p + c0 * ld;                 // W[K, 0]
-    double* Brow = w.B.p + c0 * ld;                  // scratch now, Kinv[K, 0] afterwards
-    if (k0 > 0) {                                    // finalise the row block through the scratch (not in place)
-        GemmArgs g{};
-        g.A = Wkk; g.lda = ld; g.a_kmajor = 0; g.B = Wrow; g.ldb = ld; g.b_kmajor = 1;
-        g.C = Brow; g.ldc = ld; g.alpha = 1.0; g.beta = 0.0;
-        g.mode = GM_KHI_I; g.small = 1; g.mt = 2 * nk; g.nt = k0; g.K = (int)Kd;
-        if ((rc = gemm_call(m, g, gemm_flops(g, nullptr), q))) return rc;
-        if ((rc = launch_copy2d(Wrow, ld, Brow, ld, Kd, c0, 1.0, q))) return rc;
-    }
-    if ((rc = launch_copy2d(Wrow + c0, ld, Wkk, ld, Kd, Kd, 1.0, q))) return rc;
-    if (rem > 0) {
-        const double* Lp = w.A.p + (int64_t)k1 * MOGP_TILE * ld + c0;          // L[>K, K]
-        double* Wt = w.Wm.p + (int64_t)k1 * MOGP_TILE * ld;                    // Wt[>K, 0]
-        GemmArgs g{};
-        g.A = Lp; g.lda = ld; g.a_kmajor = 0; g.B = Wkk; g.ldb = ld; g.b_kmajor = 1;
-        g.C = Wt + c0; g.ldc = ld; g.alpha = -1.0; g.beta = 0.0;
-        g.mode = GM_KLO_J; g.mt = rem; g.nt = nk; g.K = (int)Kd;
-        if ((rc = gemm_call(m, g, gemm_flops(g, nullptr), q))) return rc;
-        if (k0 > 0) {
-            GemmArgs u{};
-            u.A = Lp; u.lda = ld; u.a_kmajor = 0; u.B = Wrow; u.ldb = ld; u.b_kmajor = 1;
-            u.C = Wt; u.ldc = ld; u.alpha = -1.0; u.beta = 1.0;
-            u.mode = GM_RECT; u.mt = rem; u.nt = k0; u.K = (int)Kd;
-            if ((rc = gemm_call(m, u, gemm_flops(u, nullptr), q))) return rc;
-        }
-    }
-    HIP_TRY(hipMemset2DAsync(Brow, ld * sizeof(double), 0, (size_t)k1 * MOGP_TILE * sizeof(double), (size_t)Kd, q));
-    GemmArgs g{};
-    g.A = Wrow; g.lda = ld; g.a_kmajor = 1; g.B = Wrow; g.ldb = ld; g.b_kmajor = 1;
-    g.C = w.B.p; g.ldc = ld; g.alpha = 1.0; g.beta = 1.0;
-    g.mode = GM_LOWER; g.mt = g.nt = k1; g.K = (int)Kd;
-    return gemm_call(m, g, gemm_flops(g, nullptr), q);
-}
-
-namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base, bool fuse_inverse) {
+namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base) {
     int rc;
     // ---- two-level blocked right-looking Cholesky with look-ahead.
     // Outer blocks of MOGP_OUTER tiles.  "chain(kb)" = for each 128-column of the block: leaf (factor + inverse) -> panel =
@@ -305,29 +226,10 @@ namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base, bool 
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         w.sync_ev.push_back(e);
     }
-    if (fuse_inverse) {
-        if (w.Wm.n < (size_t)w.Npad * w.Npad) {                   // nothing ever writes above the block diagonal: keep it finite
-            if ((rc = w.Wm.ensure((size_t)w.Npad * w.Npad))) return rc;
-            HIP_TRY(hipMemsetAsync(w.Wm.p, 0, (size_t)w.Npad * w.Npad * sizeof(double), m->st));
-            HIP_TRY(hipStreamSynchronize(m->st));
-        }
-        while ((int)w.inv_ev.size() < nouter) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            w.inv_ev.push_back(e);
-        }
-    }
     int last_bulk = -1;
     for (int kb = 0; kb < nouter; ++kb) {
         const int k0 = kb * MOGP_OUTER, k1 = std::min(k0 + MOGP_OUTER, nb);
         for (int k = k0; k < k1; ++k) {
-            if (m->st_leaf) {
-                HIP_TRY(hipEventRecord(m->leaf_ev[0], m->st));
-                HIP_TRY(hipStreamWaitEvent(m->st_leaf, m->leaf_ev[0], 0));
-                if ((rc = launch_potrf_trtri_tile(w.A.p, w.Npad, k, w.invd.p, w.logdet.p, m->d_info.p, m->st_leaf, info_base))) return rc;
-                HIP_TRY(hipEventRecord(m->leaf_ev[1], m->st_leaf));
-                HIP_TRY(hipStreamWaitEvent(m->st, m->leaf_ev[1], 0));
-            } else
             if ((rc = launch_potrf_trtri_tile(w.A.p, w.Npad, k, w.invd.p, w.logdet.p, m->d_info.p, m->st, info_base))) return rc;
             const int rem = nb - k - 1;
             if (rem <= 0) break;
@@ -349,13 +251,6 @@ namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base, bool 
         }
         const int rem = nb - k1;
         HIP_TRY(hipEventRecord(w.sync_ev[2 * kb], m->st));                       // chain(kb) done
-        if (fuse_inverse) {
-            HIP_TRY(hipStreamWaitEvent(m->st4, w.sync_ev[2 * kb], 0));
-            if ((rc = diag_block_inverse(m, w, k0, k1, m->st4))) return rc;
-            HIP_TRY(hipEventRecord(w.inv_ev[kb], m->st4));
-            HIP_TRY(hipStreamWaitEvent(m->st3, w.inv_ev[kb], 0));
-            if ((rc = inverse_behind_chain(m, w, k0, k1, m->st3))) return rc;
-        }
         if (rem <= 0) break;
         double* blockp = w.A.p + (int64_t)k1 * MOGP_TILE * w.Npad + (int64_t)k0 * MOGP_TILE;
         const int K = (k1 - k0) * MOGP_TILE;
@@ -380,10 +275,6 @@ namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base, bool 
         }
     }
     if (last_bulk >= 0) HIP_TRY(hipStreamWaitEvent(m->st, w.sync_ev[2 * last_bulk + 1], 0));
-    if (fuse_inverse) {
-        HIP_TRY(hipEventRecord(w.sync_ev[2 * nouter], m->st3));
-        HIP_TRY(hipStreamWaitEvent(m->st, w.sync_ev[2 * nouter], 0));
-    }
     return 0;
 }
 }  // namespace mogp
@@ -493,7 +384,7 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     if ((rc = launch_pad_identity(m->k.A.p, Npad, N, Npad, m->st))) return rc;
     if ((rc = mark(m, 1))) return rc;
 
-    if ((rc = spd_potrf(m, m->k, 0, fuse_inverse))) return rc;
+    if ((rc = fuse_inverse ? spd_potri_fused(m, m->k) : spd_potrf(m, m->k))) return rc;
     if ((rc = mark(m, 2))) return rc;
 
     if (!fuse_inverse && (rc = spd_trtri(m, m->k))) return rc;
@@ -660,6 +551,38 @@ static int eval_sweep(mogp_model* m, const double* noise_var, const double* data
 
 extern "C" {
 
+// the context's streams: critical (high priority, all CUs), private (reserved CUs only), two bulk streams (everything else)
+static int ctx_streams(mogp_ctx* ctx) {
+    if (ctx->streams_ready) return 0;
+    {
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&ctx->st, hipStreamNonBlocking, hi));
+        // MOGP_RESERVE_CUS = R compute units of every XCD are kept for the latency-bound intra-block chain of the fused
+        // factorisation + inversion (potri.hip): CU-mask bit i is CU (i / 8) of XCD (i % 8) on gfx950 (tools/micro/cumask.hip),
+        // so the first 8 R bits are R CUs from each XCD.  st_priv runs ONLY there, the bulk streams everywhere else: a 1-workgroup
+        // leaf that shares its CU with bulk GEMM waves runs 1.6-3x slower (measured), and the dispatcher does not avoid that by itself.
+        const char* er = std::getenv("MOGP_RESERVE_CUS");
+        const int reserve = er ? std::atoi(er) : 2;
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+        const int ncu = prop.multiProcessorCount;
+        const bool masked = reserve > 0 && 16 * reserve < ncu;
+        if (masked) {
+            std::vector<uint32_t> bulk((ncu + 31) / 32, 0u), priv((ncu + 31) / 32, 0u);
+            for (int i = 0; i < ncu; ++i) (i < 8 * reserve ? priv : bulk)[i / 32] |= 1u << (i % 32);
+            HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st_priv, (uint32_t)priv.size(), priv.data()));
+            HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st2, (uint32_t)bulk.size(), bulk.data()));
+            HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st3, (uint32_t)bulk.size(), bulk.data()));
+        } else {
+            HIP_TRY(hipStreamCreateWithPriority(&ctx->st2, hipStreamNonBlocking, (lo + hi) / 2));
+            HIP_TRY(hipStreamCreateWithPriority(&ctx->st3, hipStreamNonBlocking, lo));
+        }
+    }
+    ctx->streams_ready = true;
+    return 0;
+}
+
 int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, const double* y, mogp_model** out) {
     if (!ctx || !X || !y || !out) return fail(MOGP_EINVAL, "mogp_model_create: null argument");
     if (N <= 0 || D <= 0 || D > MOGP_MAXD || C <= 0) return fail(MOGP_EINVAL, "mogp_model_create: need N > 0, 0 < D <= 8, C > 0");
@@ -676,35 +599,8 @@ int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, c
 #define MOGP_OUTER_DEFINED 1
 #define TRY_RC(x) do { int r__ = (x); if (r__) { mogp_model_destroy(m); return r__; } } while (0)
 #define TRY_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { int r__ = hip_fail(e__, #x, __FILE__, __LINE__); mogp_model_destroy(m); return r__; } } while (0)
-    {
-        int lo = 0, hi = 0;
-        TRY_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        TRY_HIP(hipStreamCreateWithPriority(&m->st, hipStreamNonBlocking, hi));
-        // The bulk streams leave MOGP_RESERVE_CUS compute units of every XCD to the latency-bound chain: CU-mask bit i is CU
-        // (i / 8) of XCD (i % 8) on gfx950 (tools/micro/cumask.hip), so clearing the first 8 R bits takes R CUs from each XCD.
-        // MOGP_MASK_STREAMS: 0 none, 1 the inverse stream only, 2 both bulk streams.
-        const char* er = std::getenv("MOGP_RESERVE_CUS");
-        const char* em = std::getenv("MOGP_MASK_STREAMS");
-        const int reserve = er ? std::atoi(er) : 0, which = em ? std::atoi(em) : 2;
-        hipDeviceProp_t prop;
-        TRY_HIP(hipGetDeviceProperties(&prop, ctx->device));
-        const int ncu = prop.multiProcessorCount;
-        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-        for (int i = 8 * reserve; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
-        const bool masked = reserve > 0 && 8 * reserve < ncu;
-        if (masked && std::getenv("MOGP_LEAF_STREAM")) {          // experiment: the leaf on a stream that owns the reserved CUs
-            std::vector<uint32_t> lm((ncu + 31) / 32, 0u);
-            for (int i = 0; i < 8 * reserve; ++i) lm[i / 32] |= 1u << (i % 32);
-            TRY_HIP(hipExtStreamCreateWithCUMask(&m->st_leaf, (uint32_t)lm.size(), lm.data()));
-            TRY_HIP(hipEventCreateWithFlags(&m->leaf_ev[0], hipEventDisableTiming));
-            TRY_HIP(hipEventCreateWithFlags(&m->leaf_ev[1], hipEventDisableTiming));
-        }
-        if (masked && which >= 2) TRY_HIP(hipExtStreamCreateWithCUMask(&m->st2, (uint32_t)mask.size(), mask.data()));
-        else TRY_HIP(hipStreamCreateWithPriority(&m->st2, hipStreamNonBlocking, (lo + hi) / 2));
-        if (masked && which >= 1) TRY_HIP(hipExtStreamCreateWithCUMask(&m->st3, (uint32_t)mask.size(), mask.data()));
-        else TRY_HIP(hipStreamCreateWithPriority(&m->st3, hipStreamNonBlocking, lo));
-        TRY_HIP(hipStreamCreateWithPriority(&m->st4, hipStreamNonBlocking, (lo + hi) / 2));
-    }
+    TRY_RC(ctx_streams(ctx));
+    m->st = ctx->st; m->st2 = ctx->st2; m->st3 = ctx->st3; m->st_priv = ctx->st_priv;
     TRY_RC(spd_alloc(m->k, Npad));
     TRY_RC(m->d_x.ensure((size_t)D * Npad));
     TRY_RC(m->d_y.ensure(Npad));
@@ -735,9 +631,7 @@ int mogp_model_destroy(mogp_model* m) {
     if (m->st) { hipError_t e = hipStreamSynchronize(m->st); (void)e; }
     for (auto e : m->ev) { hipError_t r = hipEventDestroy(e); (void)r; }
     for (auto e : m->gemm_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
-    if (m->st2) { hipError_t e = hipStreamSynchronize(m->st2); (void)e; e = hipStreamDestroy(m->st2); (void)e; }
-    if (m->st3) { hipError_t e = hipStreamSynchronize(m->st3); (void)e; e = hipStreamDestroy(m->st3); (void)e; }
-    if (m->st4) { hipError_t e = hipStreamSynchronize(m->st4); (void)e; e = hipStreamDestroy(m->st4); (void)e; }
+    for (hipStream_t q : {m->st2, m->st3, m->st_priv}) if (q) { hipError_t e = hipStreamSynchronize(q); (void)e; }
     m->k.release(); m->ws.release(); m->ws_tail.release();
     for (int b = 0; b < 2; ++b) { m->swU[b].release(); m->swUr[b].release(); }
     for (auto e : m->sw_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
@@ -749,7 +643,7 @@ int mogp_model_destroy(mogp_model* m) {
     m->d_chan_off.release(); m->d_flag.release(); m->d_info.release();
     m->d_xs.release(); m->d_Ksf.release(); m->d_Vt.release(); m->d_mu.release(); m->d_var.release(); m->d_kdiag.release();
     m->d_Kss.release(); m->d_ptiles.release();
-    if (m->st) { hipError_t e = hipStreamDestroy(m->st); (void)e; }
+
     delete m;
     return MOGP_OK;
 }
@@ -788,14 +682,16 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     int rc;
     if ((rc = use_device(m->ctx))) return rc;
     if (info) *info = 0;
-    // MOGP_GRAD_PATH=sweep selects the single-sweep blocked inversion (sweep.hip) instead of POTRF -> TRTRI -> LAUUM.  On one
-    // GPU the three-phase path is faster (59 vs 47 evals/s at cfg2: the 512-block inversion chain is not hidden); the sweep needs
-    // one panel exchange per block, which is what a sharded multi-GPU evaluation wants.
-    // Default for a gradient evaluation: the inverse streamed behind the factorisation (spd_potrf with fuse_inverse);
-    // MOGP_GRAD_PATH=phases runs POTRF, TRTRI, LAUUM one after the other (the same arithmetic, kept for A/B measurements).
+    // Gradient evaluation, three schedules of the same arithmetic (MOGP_GRAD_PATH = fused | phases | sweep overrides the choice):
+    //   fused   potri.hip: the inverse streamed behind the Cholesky chain.  Wins while the serial chain dominates: 63 vs 59.5 evals/s
+    //           at N = 8192 -- the default up to 96 tile rows (N <= 12288).
+    //   phases  POTRF, TRTRI, LAUUM one after the other: fewer, larger GEMM launches.  Wins once the evaluation is flop-bound
+    //           (80 vs 91 ms at N = 16384, 569 vs 657 ms at N = 32768) -- the default above.
+    //   sweep   sweep.hip: single-sweep blocked inversion; slower on one GPU (47 evals/s at N = 8192) but with one panel
+    //           exchange per pivot block, which is what the sharded multi-GPU evaluation (mogp_shard_*) is built on.
     static const std::string grad_path = []() { const char* e = std::getenv("MOGP_GRAD_PATH"); return std::string(e ? e : ""); }();
     const bool sweep = grad_path == "sweep" && (flags & MOGP_EVAL_GRAD);
-    const bool fused = !sweep && grad_path != "phases" && (flags & MOGP_EVAL_GRAD);
+    const bool fused = !sweep && (flags & MOGP_EVAL_GRAD) && (grad_path == "fused" || (grad_path != "phases" && m->nb <= 96));
     if (sweep) { if ((rc = eval_sweep(m, noise_var, data_var, jitter, lml, jitter_abs, info))) return rc; }
     else if ((rc = factorize(m, noise_var, data_var, jitter, lml, jitter_abs, info, fused))) return rc;
     if (!(flags & MOGP_EVAL_GRAD)) { collect_timing(m, 4); return MOGP_OK; }

@@ -48,6 +48,9 @@ using namespace mogp;      // private header: the global handle structs below ar
 struct mogp_ctx {
     int device = 0;
     std::string name;
+    // streams shared by every model of the context (created once: a CU-masked stream owns a hardware queue, and models come and go)
+    hipStream_t st = nullptr, st2 = nullptr, st3 = nullptr, st_priv = nullptr;
+    bool streams_ready = false;
 };
 
 struct TrtriLevel {
@@ -64,12 +67,13 @@ struct Spd {
     DevBuf<double> Wm;                  // W = L^-1 when the inverse is streamed behind the factorisation (spd_potrf fuse_inverse)
     std::vector<TrtriLevel> levels;
     std::vector<hipEvent_t> sync_ev;    // cross-stream dependencies of the look-ahead schedule
-    std::vector<hipEvent_t> inv_ev;
+    std::vector<hipEvent_t> inv_ev;     // events of the fused schedule (potri.hip)
+    DevBuf<double> Pb[3];               // rotating panel buffers L[>K, K] of the fused schedule (Npad x 512 each)
     void release() {
         for (auto& lv : levels) { lv.d1.release(); lv.d2.release(); }
         for (auto e : sync_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
         for (auto e : inv_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
-        inv_ev.clear(); Wm.release();
+        inv_ev.clear(); Wm.release(); for (auto& b : Pb) b.release();
         levels.clear(); sync_ev.clear();
         A.release(); B.release(); invd.release(); logdet.release();
     }
@@ -104,9 +108,7 @@ struct mogp_model {
     hipStream_t st = nullptr;           // critical-path stream (high priority)
     hipStream_t st2 = nullptr;          // bulk trailing updates (look-ahead)
     hipStream_t st3 = nullptr;          // inverse streamed behind the factorisation (lowest priority)
-    hipStream_t st4 = nullptr;          // diagonal-block inverses W_KK for st3
-    hipStream_t st_leaf = nullptr;      // (experiment) leaf kernels on reserved CUs
-    hipEvent_t leaf_ev[2] = {nullptr, nullptr};
+    hipStream_t st_priv = nullptr;      // intra-block chain of the fused factorisation, on the reserved CUs only
     Spd k;                              // the N x N system
     Spd ws, ws_tail;                    // Schur-block workspaces of the sweep inversion (outer block / last partial block)
     DevBuf<double> swU[2], swUr[2];     // old panels of the block being swept (column part, row part), double buffered
@@ -146,7 +148,8 @@ int gemm_call(mogp_model* m, const GemmArgs& g, double flops, hipStream_t st = n
 int mark(mogp_model* m, int idx);
 double table_diag(const mogp_model* m, int c);
 int spd_alloc(Spd& w, int64_t Npad);
-int spd_potrf(mogp_model* m, Spd& w, long long info_base = 0, bool fuse_inverse = false);
+int spd_potrf(mogp_model* m, Spd& w, long long info_base = 0);
+int spd_potri_fused(mogp_model* m, Spd& w);   // potri.hip: w.A (SPD, lower) -> w.Wm = L^-1, w.B = inverse (lower); w.logdet per tile
 int spd_trtri(mogp_model* m, Spd& w);
 int spd_lauum(mogp_model* m, Spd& w);
 int spd_sweep(mogp_model* m, Spd& w);

@@ -1,0 +1,262 @@
+// potri.hip -- Cholesky factorisation AND inverse of the SPD matrix in ONE schedule (the default gradient path).
+//
+// Why: at N = 8192 the blocked Cholesky is bound by its serial chain (64 leaf factorisations and the small kernels between
+// them), not by flops: it leaves three quarters of the chip idle, and TRTRI + LAUUM (2/3 of all flops) used to run afterwards.
+// Here the inverse is streamed BEHIND the chain as rank-512 updates, and the chain itself is kept off the CUs the bulk work uses.
+//
+// Outer blocks K of 4 tiles (Kd = 512 columns).  Per block, on four streams:
+//   priv  (CU mask = the reserved CUs only)   the whole critical path, in ONE stream:
+//            intra-block chain on the 512 x 512 diagonal block D_KK:
+//              4 x [ leaf (factor + inverse of a 128 tile) -> panel inside the block -> update inside the block ], then W_KK = L_KK^-1
+//            mini-panel            P[K+1 rows] = A[K+1 rows, K] W_KK^T       (the next block's rows only)
+//            next-diagonal update  D_{K+1,K+1} -= P[K+1] P[K+1]^T            -> the chain of block K+1 follows in the same stream
+//            Every launch is <= 64 small workgroups; alone on their CUs they run at their unloaded latency.
+//   crit  (all CUs, high priority)            rest of the panel     P[> K+1]      = A[> K+1, K] W_KK^T
+//                                             next-block columns    A[> K+1, K+1] -= P[> K+1] P[K+1]^T
+//   bulk  (all but the reserved CUs)          A[> K+1, > K+1] -= P[> K+1] P[> K+1]^T   (trailing update, K = 512; block K+2's columns first)
+//   inv   (all but the reserved CUs)          W = L^-1 by elementary block-column inverses, and the inverse itself:
+//            W[K, <K]   = W_KK Wt[K, <K]                            finalise the row block (Wt = running product, in w.Wm)
+//            Wt[>K, K]  = -P W_KK ;  Wt[>K, <K] -= P W[K, <K]       rank-512 update of all rows below
+//            Kinv[<=K, <=K] += W[K, <=K]^T W[K, <=K]                rank-512 update of the inverse (w.B)
+// The panel P = L[>K, K] is consumed only by block K's own updates, so it lives in three rotating Npad x 512 buffers, not in w.A.
+// Critical path per block = intra-block chain + mini-panel + next-diagonal update; everything of N-proportional size is off it.  On return: w.Wm = W = L^-1 (lower), w.B = (L L^T)^-1 (lower tiles, full diagonal tiles),
+// w.logdet / w.invd / the pivot check as in spd_potrf; w.A is consumed.
+#include "mogp_model.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+using namespace mogp;
+
+namespace mogp {
+int launch_potrf_trtri_tile(double* A, int64_t ld, int t, double* invd, double* logdet, unsigned long long* info, hipStream_t s,
+                            long long info_base = 0);
+}
+
+#define RC(x) do { int r__ = (x); if (r__) return r__; } while (0)
+#define FZ_OB 4
+#define FZ_KD (FZ_OB * MOGP_TILE)
+
+namespace {
+
+enum { EV_BLK = 0, EV_DIAG = 1, EV_PANEL = 2, EV_BULK = 3, EV_INV = 4, EV_REST = 5, EV_PER_BLOCK = 6 };
+
+// W[R, c0:r0] = -Wrr * (L[R, c0:r0] * W[c0:r0, c0:r0]) for the tile rows R = [r0, r0 + nr), in place in w.A (the product in
+// brackets goes through the same positions of w.B).  Used inside a diagonal block only, where everything is a handful of tiles.
+int w_rowblock(mogp_model* m, Spd& w, int r0, int nr, int c0, const double* Wrr, int64_t ldr, hipStream_t q) {
+    const int n = r0 - c0;
+    if (n <= 0) return 0;
+    const int64_t ld = w.Npad;
+    const int64_t off = (int64_t)r0 * MOGP_TILE * ld + (int64_t)c0 * MOGP_TILE;
+    GemmArgs g{};
+    g.A = w.A.p + off; g.lda = ld; g.a_kmajor = 0;
+    g.B = w.A.p + (int64_t)c0 * MOGP_TILE * (ld + 1); g.ldb = ld; g.b_kmajor = 1;
+    g.C = w.B.p + off; g.ldc = ld; g.alpha = 1.0; g.beta = 0.0;
+    g.mode = GM_KLO_J; g.small = 1; g.mt = 2 * nr; g.nt = n; g.K = n * MOGP_TILE;
+    RC(gemm_call(m, g, gemm_flops(g, nullptr), q));
+    GemmArgs h{};
+    h.A = Wrr; h.lda = ldr; h.a_kmajor = 0;
+    h.B = w.B.p + off; h.ldb = ld; h.b_kmajor = 1;
+    h.C = w.A.p + off; h.ldc = ld; h.alpha = -1.0; h.beta = 0.0;
+    h.mode = GM_KHI_I; h.small = 1; h.mt = 2 * nr; h.nt = n; h.K = nr * MOGP_TILE;
+    return gemm_call(m, h, gemm_flops(h, nullptr), q);
+}
+
+// factor the diagonal block [k0, k1) of w.A in place and replace it by W_KK = L_KK^-1 (lower; zeros above)
+int intra_block_chain(mogp_model* m, Spd& w, int k0, int k1, hipStream_t q) {
+    const int64_t ld = w.Npad;
+    for (int k = k0; k < k1; ++k) {
+        RC(launch_potrf_trtri_tile(w.A.p, ld, k, w.invd.p, w.logdet.p, m->d_info.p, q, 0));
+        const int ri = k1 - k - 1;                       // tile rows below, inside the block
+        if (ri <= 0) break;
+        double* panel = w.A.p + (int64_t)(k + 1) * MOGP_TILE * ld + (int64_t)k * MOGP_TILE;
+        GemmArgs g{};
+        g.A = panel; g.lda = ld; g.a_kmajor = 0;
+        g.B = w.invd.p + (int64_t)k * MOGP_TILE * MOGP_TILE; g.ldb = MOGP_TILE; g.b_kmajor = 0;
+        g.C = panel; g.ldc = ld; g.alpha = 1.0; g.beta = 0.0;
+        g.mode = GM_RECT; g.small = 1; g.mt = 2 * ri; g.nt = 1; g.K = MOGP_TILE;               // 64 x 128 tiles: in place
+        RC(gemm_call(m, g, gemm_flops(g, nullptr), q));
+        GemmArgs u{};
+        u.A = panel; u.lda = ld; u.a_kmajor = 0; u.B = panel; u.ldb = ld; u.b_kmajor = 0;
+        u.C = w.A.p + (int64_t)(k + 1) * MOGP_TILE * (ld + 1); u.ldc = ld; u.alpha = -1.0; u.beta = 1.0;
+        u.mode = GM_RECT_LOWER; u.small = 2; u.mt = 2 * ri; u.nt = 2 * ri; u.K = MOGP_TILE;
+        RC(gemm_call(m, u, gemm_flops(u, nullptr), q));
+    }
+    const int nk = k1 - k0;
+    RC(launch_put_diag_tiles(w.A.p + (int64_t)k0 * MOGP_TILE * (ld + 1), ld, nk, w.invd.p + (int64_t)k0 * MOGP_TILE * MOGP_TILE, q));
+    for (int t = 1; t < nk; ++t)
+        RC(w_rowblock(m, w, k0 + t, 1, k0, w.invd.p + (int64_t)(k0 + t) * MOGP_TILE * MOGP_TILE, MOGP_TILE, q));
+    return 0;
+}
+
+// P[rows r0 .. r0+nr) = A[rows, K] * W_KK^T  (rows in tiles; P has leading dimension FZ_KD and is indexed by the global row)
+int panel_rows(mogp_model* m, Spd& w, double* P, int k0, int nk, int r0, int nr, bool small, hipStream_t q) {
+    const int64_t ld = w.Npad;
+    GemmArgs g{};
+    g.A = w.A.p + (int64_t)r0 * MOGP_TILE * ld + (int64_t)k0 * MOGP_TILE; g.lda = ld; g.a_kmajor = 0;
+    g.B = w.A.p + (int64_t)k0 * MOGP_TILE * (ld + 1); g.ldb = ld; g.b_kmajor = 0;          // W_KK as [j][k], k <= j
+    g.C = P + (int64_t)r0 * MOGP_TILE * FZ_KD; g.ldc = FZ_KD; g.alpha = 1.0; g.beta = 0.0;
+    g.mode = GM_KHI_J; g.small = small ? 1 : 0; g.mt = small ? 2 * nr : nr; g.nt = nk; g.K = nk * MOGP_TILE;
+    return gemm_call(m, g, gemm_flops(g, nullptr), q);
+}
+
+// the inverse stream's share of block K (see the header); Lp = P[k1 tile row], leading dimension FZ_KD
+int inverse_step(mogp_model* m, Spd& w, int k0, int k1, const double* Lp, hipStream_t q) {
+    const int64_t ld = w.Npad;
+    const int nk = k1 - k0, rem = w.nb - k1;
+    const int64_t Kd = (int64_t)nk * MOGP_TILE, c0 = (int64_t)k0 * MOGP_TILE;
+    const double* Wkk = w.A.p + c0 * (ld + 1);
+    double* Wrow = w.Wm.p + c0 * ld;                 // W[K, 0]
+    double* Brow = w.B.p + c0 * ld;                  // scratch now, Kinv[K, 0] afterwards
+    if (k0 > 0) {                                    // finalise the row block through the scratch (not in place)
+        GemmArgs g{};
+        g.A = Wkk; g.lda = ld; g.a_kmajor = 0; g.B = Wrow; g.ldb = ld; g.b_kmajor = 1;
+        g.C = Brow; g.ldc = ld; g.alpha = 1.0; g.beta = 0.0;
+        g.mode = GM_KHI_I; g.small = 1; g.mt = 2 * nk; g.nt = k0; g.K = (int)Kd;
+        RC(gemm_call(m, g, gemm_flops(g, nullptr), q));
+        RC(launch_copy2d(Wrow, ld, Brow, ld, Kd, c0, 1.0, q));
+    }
+    RC(launch_copy2d(Wrow + c0, ld, Wkk, ld, Kd, Kd, 1.0, q));
+    if (rem > 0) {
+        double* Wt = w.Wm.p + (int64_t)k1 * MOGP_TILE * ld;                    // Wt[>K, 0]
+        GemmArgs g{};
+        g.A = Lp; g.lda = FZ_KD; g.a_kmajor = 0; g.B = Wkk; g.ldb = ld; g.b_kmajor = 1;
+        g.C = Wt + c0; g.ldc = ld; g.alpha = -1.0; g.beta = 0.0;
+        g.mode = GM_KLO_J; g.mt = rem; g.nt = nk; g.K = (int)Kd;
+        RC(gemm_call(m, g, gemm_flops(g, nullptr), q));
+        if (k0 > 0) {
+            GemmArgs u{};
+            u.A = Lp; u.lda = FZ_KD; u.a_kmajor = 0; u.B = Wrow; u.ldb = ld; u.b_kmajor = 1;
+            u.C = Wt; u.ldc = ld; u.alpha = -1.0; u.beta = 1.0;
+            u.mode = GM_RECT; u.mt = rem; u.nt = k0; u.K = (int)Kd;
+            RC(gemm_call(m, u, gemm_flops(u, nullptr), q));
+        }
+    }
+    HIP_TRY(hipMemset2DAsync(Brow, ld * sizeof(double), 0, (size_t)k1 * MOGP_TILE * sizeof(double), (size_t)Kd, q));
+    GemmArgs g{};
+    g.A = Wrow; g.lda = ld; g.a_kmajor = 1; g.B = Wrow; g.ldb = ld; g.b_kmajor = 1;
+    g.C = w.B.p; g.ldc = ld; g.alpha = 1.0; g.beta = 1.0;
+    g.mode = GM_LOWER; g.mt = g.nt = k1; g.K = (int)Kd;
+    return gemm_call(m, g, gemm_flops(g, nullptr), q);
+}
+
+}  // namespace
+
+namespace mogp {
+
+int spd_potri_fused(mogp_model* m, Spd& w) {
+    const int nb = w.nb;
+    const int64_t ld = w.Npad;
+    const int nouter = (nb + FZ_OB - 1) / FZ_OB;
+    const auto t_host0 = std::chrono::steady_clock::now();
+    hipStream_t crit = m->st, priv = m->st_priv ? m->st_priv : m->st, bulk = m->st2, inv = m->st3;
+
+    if (w.Wm.n < (size_t)ld * ld) {                      // nothing ever writes above the block diagonal of W: keep it finite
+        RC(w.Wm.ensure((size_t)ld * ld));
+        HIP_TRY(hipMemsetAsync(w.Wm.p, 0, (size_t)ld * ld * sizeof(double), crit));
+    }
+    for (auto& b : w.Pb) RC(b.ensure((size_t)ld * FZ_KD));
+    while ((int)w.inv_ev.size() < EV_PER_BLOCK * nouter + 1) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        w.inv_ev.push_back(e);
+    }
+    auto ev = [&](int kb, int which) { return w.inv_ev[EV_PER_BLOCK * kb + which]; };
+    hipEvent_t start = w.inv_ev[EV_PER_BLOCK * nouter];
+    HIP_TRY(hipEventRecord(start, crit));                // the Gram matrix is in place
+
+    // Host order matters as much as stream order: a late block takes about as long on the GPU as its ~45 launches take to enqueue,
+    // so the chain of block kb+1 is enqueued before the bulk work of block kb -- but never a wait before the record it refers to.
+    auto geom = [&](int kb, int& k0, int& k1, int& nk, int& rem, int& na, int& k2) {
+        k0 = kb * FZ_OB; k1 = std::min(k0 + FZ_OB, nb); nk = k1 - k0; rem = nb - k1; na = std::min(FZ_OB, rem); k2 = k1 + na;
+    };
+    auto chain = [&](int kb) -> int {                    // priv: factor D_KK, W_KK (its inputs are ordered by the stream itself)
+        int k0, k1, nk, rem, na, k2; geom(kb, k0, k1, nk, rem, na, k2);
+        RC(intra_block_chain(m, w, k0, k1, priv));
+        HIP_TRY(hipEventRecord(ev(kb, EV_BLK), priv));
+        return 0;
+    };
+    auto next_diag = [&](int kb) -> int {                // priv: the next block's panel rows and the next diagonal block
+        int k0, k1, nk, rem, na, k2; geom(kb, k0, k1, nk, rem, na, k2);
+        if (rem <= 0) return 0;
+        double* P = w.Pb[kb % 3].p;
+        if (kb >= 3) HIP_TRY(hipStreamWaitEvent(priv, ev(kb - 3, EV_INV), 0));          // the panel buffer is free again
+        if (kb >= 1) HIP_TRY(hipStreamWaitEvent(priv, ev(kb - 1, EV_BULK), 0));         // bulk1(kb-1): columns K+1;  implies bulk1(kb-2): columns K
+        if (kb >= 1) HIP_TRY(hipStreamWaitEvent(priv, ev(kb - 1, EV_PANEL), 0));        // crit(kb-1): columns K below the diagonal block
+        RC(panel_rows(m, w, P, k0, nk, k1, na, true, priv));
+        const double* Pn = P + (int64_t)k1 * MOGP_TILE * FZ_KD;
+        GemmArgs u{};
+        u.A = Pn; u.lda = FZ_KD; u.a_kmajor = 0; u.B = Pn; u.ldb = FZ_KD; u.b_kmajor = 0;
+        u.C = w.A.p + (int64_t)k1 * MOGP_TILE * (ld + 1); u.ldc = ld; u.alpha = -1.0; u.beta = 1.0;
+        u.mode = GM_RECT_LOWER; u.small = 2; u.mt = 2 * na; u.nt = 2 * na; u.K = nk * MOGP_TILE;
+        RC(gemm_call(m, u, gemm_flops(u, nullptr), priv));
+        HIP_TRY(hipEventRecord(ev(kb, EV_DIAG), priv));
+        return 0;
+    };
+    HIP_TRY(hipStreamWaitEvent(priv, start, 0));
+    RC(chain(0));
+    RC(next_diag(0));
+    for (int kb = 0; kb < nouter; ++kb) {
+        int k0, k1, nk, rem, na, k2; geom(kb, k0, k1, nk, rem, na, k2);
+        const int Kd = nk * MOGP_TILE;
+        double* P = w.Pb[kb % 3].p;
+        const double* Pn = P + (int64_t)k1 * MOGP_TILE * FZ_KD;
+        const double* Pr = P + (int64_t)k2 * MOGP_TILE * FZ_KD;
+        const int nr = rem - na, n1 = std::min(FZ_OB, std::max(nr, 0));
+        // 1. priv: the chain of the next block (needs only the next-diagonal update of this block, which is ahead of it in the stream)
+        if (kb + 1 < nouter) RC(chain(kb + 1));
+        // 2. crit: the rest of the panel, then the next block's columns below its diagonal block
+        if (rem > 0) {
+            HIP_TRY(hipStreamWaitEvent(crit, ev(kb, EV_DIAG), 0));                       // W_KK, a free buffer, the mini-panel
+            if (nr > 0) RC(panel_rows(m, w, P, k0, nk, k2, nr, false, crit));
+            HIP_TRY(hipEventRecord(ev(kb, EV_REST), crit));
+            if (nr > 0) {
+                GemmArgs u{};
+                u.A = Pr; u.lda = FZ_KD; u.a_kmajor = 0; u.B = Pn; u.ldb = FZ_KD; u.b_kmajor = 0;
+                u.C = w.A.p + (int64_t)k2 * MOGP_TILE * ld + (int64_t)k1 * MOGP_TILE; u.ldc = ld; u.alpha = -1.0; u.beta = 1.0;
+                u.mode = GM_RECT; u.mt = nr; u.nt = na; u.K = Kd;
+                RC(gemm_call(m, u, gemm_flops(u, nullptr), crit));
+            }
+            HIP_TRY(hipEventRecord(ev(kb, EV_PANEL), crit));
+        }
+        // 3. bulk: trailing update, the columns of block K+2 first (the chain needs them next)
+        if (nr > 0) {
+            HIP_TRY(hipStreamWaitEvent(bulk, ev(kb, EV_REST), 0));
+            GemmArgs u{};
+            u.A = Pr; u.lda = FZ_KD; u.a_kmajor = 0; u.B = Pr; u.ldb = FZ_KD; u.b_kmajor = 0;
+            u.C = w.A.p + (int64_t)k2 * MOGP_TILE * (ld + 1); u.ldc = ld; u.alpha = -1.0; u.beta = 1.0;
+            u.mode = GM_RECT_LOWER; u.mt = nr; u.nt = n1; u.K = Kd;
+            RC(gemm_call(m, u, gemm_flops(u, nullptr), bulk));
+        }
+        HIP_TRY(hipEventRecord(ev(kb, EV_BULK), bulk));
+        // 4. priv: mini-panel and next-diagonal update of the next block
+        if (kb + 1 < nouter) RC(next_diag(kb + 1));
+        // 5. bulk: the rest of the trailing update
+        if (nr > n1) {
+            const double* Pq = Pr + (int64_t)n1 * MOGP_TILE * FZ_KD;
+            GemmArgs v{};
+            v.A = Pq; v.lda = FZ_KD; v.a_kmajor = 0; v.B = Pq; v.ldb = FZ_KD; v.b_kmajor = 0;
+            v.C = w.A.p + (int64_t)(k2 + n1) * MOGP_TILE * (ld + 1); v.ldc = ld; v.alpha = -1.0; v.beta = 1.0;
+            v.mode = GM_LOWER; v.mt = v.nt = nr - n1; v.K = Kd;
+            RC(gemm_call(m, v, gemm_flops(v, nullptr), bulk));
+        }
+        // 6. inv
+        HIP_TRY(hipStreamWaitEvent(inv, ev(kb, EV_BLK), 0));
+        if (rem > 0) HIP_TRY(hipStreamWaitEvent(inv, ev(kb, EV_REST), 0));
+        RC(inverse_step(m, w, k0, k1, P + (int64_t)k1 * MOGP_TILE * FZ_KD, inv));
+        HIP_TRY(hipEventRecord(ev(kb, EV_INV), inv));
+    }
+    HIP_TRY(hipEventRecord(ev(nouter - 1, EV_DIAG), bulk));                              // reuse: everything on the bulk stream
+    HIP_TRY(hipStreamWaitEvent(crit, ev(nouter - 1, EV_BLK), 0));
+    HIP_TRY(hipStreamWaitEvent(crit, ev(nouter - 1, EV_DIAG), 0));
+    HIP_TRY(hipStreamWaitEvent(crit, ev(nouter - 1, EV_INV), 0));
+    if (std::getenv("MOGP_DEBUG_HOST")) {
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count();
+        fprintf(stderr, "spd_potri_fused: host enqueue %.0f us, %d outer blocks\n", us, nouter);
+    }
+    return 0;
+}
+
+}  // namespace mogp
