@@ -217,12 +217,25 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * dt / a.steps
         value = aggregate_value(world, a.steps, dt)
+        # The GEMM launches of one evaluation run on up to four streams at once (potri.hip), so the sum of their durations
+        # exceeds the wall-clock time they occupy.  `achieved` prices the kernel over the SPAN of the factorisation + inversion
+        # stage (HIP events on the critical stream); `per_launch` is flops / sum of launch durations (what a kernel trace
+        # averages to), `overlap` = sum of durations / span.
         gemm_s = stage[_lib.ST_GEMM_KERNEL] * 1e-3
-        achieved = gemm_flops / gemm_s / 1e12 if gemm_s > 0 else 0.0
+        span_s = (stage[_lib.ST_POTRF] + stage[_lib.ST_TRTRI] + stage[_lib.ST_LAUUM]) * 1e-3
+        achieved = gemm_flops / span_s / 1e12 if span_s > 0 else 0.0
+        per_launch = gemm_flops / gemm_s / 1e12 if gemm_s > 0 else 0.0
         N = a.n
         gram_bytes = 4.0 * N * (N + 1)            # lower triangle written once
         gram_gbs = gram_bytes * nprof / (stage[_lib.ST_GRAM] * 1e-3) / 1e9 if stage[_lib.ST_GRAM] > 0 else 0.0
         mom_gbs = gram_bytes * nprof / (stage[_lib.ST_MOMENTS] * 1e-3) / 1e9 if stage[_lib.ST_MOMENTS] > 0 else 0.0
+        traffic, traffic_src = None, None
+        try:        # L2<->fabric bytes per k_gemm launch from the committed rocprofv3 --pmc passes of this same command (profiles/)
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+                t = json.load(f)
+            traffic, traffic_src = t["bytes_per_launch"], "profiles/r1_pmc_traffic.json: " + t["source"]
+        except Exception:
+            pass
         out = {
             "metric": "log-marginal-likelihood+grad evals/sec, MOSM C=4 N=8192; 1/2/4/8 GPU",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -233,7 +246,9 @@ def main():
                        "device": _lib.device_name(local_rank)},
             "roofline": {"bound": "mfma", "kernel": "k_gemm (fp64 v_mfma_f64_16x16x4_f64)", "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": None,
+                         "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": 8.0 * N * N * (N / 512.0) / max(gemm_launches / nprof, 1.0), "basis": "GEMM flops of the profiled evaluations / wall-clock span of their factorisation+inversion stage",
+                         "per_launch": per_launch, "overlap": gemm_s / span_s if span_s > 0 else None,
                          "launches_per_eval": gemm_launches / nprof, "profiled_steps": nprof, "avg_launch_us": 1e6 * gemm_s / max(gemm_launches, 1),
                          "flops_per_eval": gemm_flops / nprof},
             "stages_ms_per_eval": {k: float(stage[i] / nprof) for k, i in

@@ -54,9 +54,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
         const GemmTask t = g.tasks[blockIdx.x];
         Ap = g.A + t.a_off; Bp = g.B + t.b_off; Cp = g.C + t.c_off; kt = t.kt;
     } else {
+        // XCD-aware tile order: workgroup b is dispatched to XCD b % 8, each with its own L2.  Giving every XCD one contiguous
+        // chunk of the (row-major) tile list keeps a panel row inside one L2 instead of all eight (measured: 2.8x the algorithmic
+        // HBM traffic without it).  Only for the modes whose tiles all cost the same (equal chunks = equal work).
+        int bid = blockIdx.x;
+        if (g.mode == GM_RECT || g.mode == GM_RECT_LOWER || g.mode == GM_LOWER || g.mode == GM_KLO_J || g.mode == GM_KHI_J) {
+            const int grid = gridDim.x, q = grid >> 3, r = grid & 7, x = bid & 7;
+            if (grid >= 64) bid = x * q + min(x, r) + (bid >> 3);
+        }
         int ti, tj;
-        if (g.mode == GM_LOWER || g.mode == GM_LAUUM) { ti = tri_row(blockIdx.x); tj = blockIdx.x - ti * (ti + 1) / 2; }
-        else { ti = blockIdx.x / g.nt; tj = blockIdx.x - ti * g.nt; }
+        if (g.mode == GM_LOWER || g.mode == GM_LAUUM) { ti = tri_row(bid); tj = bid - ti * (ti + 1) / 2; }
+        else { ti = bid / g.nt; tj = bid - ti * g.nt; }
         if (g.mode == GM_RECT_LOWER && (ti + 1) * TMR <= tj * TNC) return;        // tile entirely above the diagonal
         if (g.row_mod > 1 && ((ti + g.row_off) % g.row_mod) != g.row_rem) return;  // tile row owned by another rank
         int64_t k0 = 0, k1 = g.K;
