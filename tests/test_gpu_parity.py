@@ -335,9 +335,11 @@ def test_cfg5_titsias_golden():
             assert err < 1e-5, (p._name, err)          # measured <= 5.2e-7
 
 
-def test_sweep_inversion_path_matches_reference():
-    """the alternative gradient path (single-sweep blocked SPD inversion, MOGP_GRAD_PATH=sweep) against the same golden
-    vectors, in a fresh process because the path is chosen once per process"""
+@pytest.mark.parametrize("path", ["sweep", "phases", "fused"])
+def test_every_gradient_schedule_matches_reference(path):
+    """the three schedules of the gradient evaluation (MOGP_GRAD_PATH: single-sweep inversion; POTRF -> TRTRI -> LAUUM, the default
+    above 96 tile rows; inverse streamed behind the Cholesky chain, the default below) against the same golden vectors, each in a
+    fresh process because the schedule is chosen once per process"""
     import os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent('''
@@ -366,7 +368,7 @@ def test_sweep_inversion_path_matches_reference():
         print("SWEEP_OK")
     ''') % (root, os.path.join(root, "tests"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, MOGP_GRAD_PATH="sweep"))
+                         env=dict(os.environ, MOGP_GRAD_PATH=path))
     assert "SWEEP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
