@@ -111,6 +111,186 @@ class _Adam:
             p.data = p.data - (self.lr / bc1) * st["m"] / denom
 
 
+class _LBFGS:
+    """torch.optim.LBFGS(params, lr=1, max_iter=20, max_eval=None, tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100,
+    line_search_fn=None) over the raw parameters: ONE call of step(closure) runs up to max_iter iterations, as the reference uses it
+    (mogptk/model.py:541-553).  Two-loop recursion with the y.s > 1e-10 curvature guard, first step min(1, 1/|g|_1) lr, optional
+    'strong_wolfe' line search (bracketing by bounded cubic extrapolation, then zoom; c1 = 1e-4, c2 = 0.9)."""
+
+    def __init__(self, params, lr=1.0, max_iter=20, max_eval=None, tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100,
+                 line_search_fn=None):
+        if not 0.0 <= lr:
+            raise ValueError("Invalid learning rate: %s" % lr)
+        self.params = list(params)
+        self.lr, self.max_iter = float(lr), int(max_iter)
+        self.max_eval = int(max_eval) if max_eval is not None else self.max_iter * 5 // 4
+        self.tol_grad, self.tol_change, self.history, self.line_search = tolerance_grad, tolerance_change, int(history_size), line_search_fn
+        self.state = dict(func_evals=0, n_iter=0)
+
+    # flat views over the raw tensors
+    def _grad(self):
+        return np.concatenate([(np.zeros(p.data.size) if p.grad is None else np.asarray(p.grad, dtype=np.float64).reshape(-1)) for p in self.params])
+
+    def _move(self, t, d):
+        o = 0
+        for p in self.params:
+            n = p.data.size
+            p.data = p.data + t * d[o:o + n].reshape(p.data.shape)
+            o += n
+
+    def _snapshot(self):
+        return [p.data.copy() for p in self.params]
+
+    def _restore(self, x):
+        for p, v in zip(self.params, x):
+            p.data = v.copy()
+
+    @staticmethod
+    def _cubic(x1, f1, g1, x2, f2, g2, bounds=None):
+        lo, hi = bounds if bounds is not None else ((x1, x2) if x1 <= x2 else (x2, x1))
+        d1 = g1 + g2 - 3.0 * (f1 - f2) / (x1 - x2)
+        disc = d1 * d1 - g1 * g2
+        if disc >= 0.0:
+            d2 = math.sqrt(disc)
+            if x1 <= x2:
+                pos = x2 - (x2 - x1) * ((g2 + d2 - d1) / (g2 - g1 + 2.0 * d2))
+            else:
+                pos = x1 - (x1 - x2) * ((g1 + d2 - d1) / (g1 - g2 + 2.0 * d2))
+            return min(max(pos, lo), hi)
+        return 0.5 * (lo + hi)
+
+    def _strong_wolfe(self, closure, x0, t, d, f, g, gtd, max_ls, c1=1e-4, c2=0.9, tol=1e-9):
+        def probe(step):
+            self._move(step, d)
+            fv = float(closure())
+            gv = self._grad()
+            self._restore(x0)
+            return fv, gv
+
+        d_norm = float(np.max(np.abs(d)))
+        f_new, g_new = probe(t)
+        evals, it = 1, 0
+        gtd_new = float(g_new @ d)
+        t_prev, f_prev, g_prev, gtd_prev = 0.0, f, g.copy(), gtd
+        done, br = False, None
+        while it < max_ls:
+            if f_new > f + c1 * t * gtd or (it > 1 and f_new >= f_prev):       # sufficient decrease violated: the minimum is bracketed
+                br = dict(t=[t_prev, t], f=[f_prev, f_new], g=[g_prev, g_new.copy()], gtd=[gtd_prev, gtd_new])
+                break
+            if abs(gtd_new) <= -c2 * gtd:                                          # strong Wolfe conditions hold
+                br = dict(t=[t], f=[f_new], g=[g_new], gtd=[gtd_new])
+                done = True
+                break
+            if gtd_new >= 0.0:                                                     # slope changed sign: bracketed
+                br = dict(t=[t_prev, t], f=[f_prev, f_new], g=[g_prev, g_new.copy()], gtd=[gtd_prev, gtd_new])
+                break
+            lo, hi, keep = t + 0.01 * (t - t_prev), t * 10.0, t
+            t = self._cubic(t_prev, f_prev, gtd_prev, t, f_new, gtd_new, bounds=(lo, hi))
+            t_prev, f_prev, g_prev, gtd_prev = keep, f_new, g_new.copy(), gtd_new
+            f_new, g_new = probe(t)
+            evals += 1
+            gtd_new = float(g_new @ d)
+            it += 1
+        if it == max_ls:
+            br = dict(t=[0.0, t], f=[f, f_new], g=[g, g_new], gtd=[gtd, gtd_new])
+        stalled = False
+        low, high = (0, 1) if br["f"][0] <= br["f"][-1] else (1, 0)
+        while not done and it < max_ls:
+            if abs(br["t"][1] - br["t"][0]) * d_norm < tol:
+                break
+            t = self._cubic(br["t"][0], br["f"][0], br["gtd"][0], br["t"][1], br["f"][1], br["gtd"][1])
+            tmax, tmin = max(br["t"]), min(br["t"])
+            eps = 0.1 * (tmax - tmin)
+            if min(tmax - t, t - tmin) < eps:
+                if stalled or t >= tmax or t <= tmin:
+                    t = tmax - eps if abs(t - tmax) < abs(t - tmin) else tmin + eps
+                    stalled = False
+                else:
+                    stalled = True
+            else:
+                stalled = False
+            f_new, g_new = probe(t)
+            evals += 1
+            gtd_new = float(g_new @ d)
+            it += 1
+            if f_new > f + c1 * t * gtd or f_new >= br["f"][low]:
+                br["t"][high], br["f"][high], br["g"][high], br["gtd"][high] = t, f_new, g_new.copy(), gtd_new
+                low, high = (0, 1) if br["f"][0] <= br["f"][1] else (1, 0)
+            else:
+                if abs(gtd_new) <= -c2 * gtd:
+                    done = True
+                elif gtd_new * (br["t"][high] - br["t"][low]) >= 0.0:
+                    br["t"][high], br["f"][high], br["g"][high], br["gtd"][high] = br["t"][low], br["f"][low], br["g"][low], br["gtd"][low]
+                br["t"][low], br["f"][low], br["g"][low], br["gtd"][low] = t, f_new, g_new.copy(), gtd_new
+        return br["f"][low], br["g"][low], br["t"][low], evals
+
+    def step(self, closure):
+        st = self.state
+        first = closure()
+        loss = float(first)
+        evals = 1
+        st["func_evals"] += 1
+        g = self._grad()
+        if np.max(np.abs(g)) <= self.tol_grad:
+            return first
+        d, t = st.get("d"), st.get("t")
+        ys_hist, s_hist, rho = st.get("old_dirs", []), st.get("old_stps", []), st.get("ro", [])
+        h0, g_prev, loss_prev = st.get("H_diag", 1.0), st.get("prev_flat_grad"), st.get("prev_loss")
+        n = 0
+        while n < self.max_iter:
+            n += 1
+            st["n_iter"] += 1
+            if st["n_iter"] == 1:
+                d, ys_hist, s_hist, rho, h0 = -g, [], [], [], 1.0
+            else:
+                y, sv = g - g_prev, d * t
+                ys = float(y @ sv)
+                if ys > 1e-10:
+                    if len(ys_hist) == self.history:
+                        ys_hist.pop(0); s_hist.pop(0); rho.pop(0)
+                    ys_hist.append(y); s_hist.append(sv); rho.append(1.0 / ys)
+                    h0 = ys / float(y @ y)
+                k = len(ys_hist)
+                al = [0.0] * k
+                q = -g
+                for i in range(k - 1, -1, -1):
+                    al[i] = float(s_hist[i] @ q) * rho[i]
+                    q = q - al[i] * ys_hist[i]
+                d = q * h0
+                for i in range(k):
+                    be = float(ys_hist[i] @ d) * rho[i]
+                    d = d + (al[i] - be) * s_hist[i]
+            g_prev, loss_prev = g.copy(), loss
+            t = min(1.0, 1.0 / float(np.sum(np.abs(g)))) * self.lr if st["n_iter"] == 1 else self.lr
+            gtd = float(g @ d)
+            if gtd > -self.tol_change:
+                break
+            ls_evals = 0
+            if self.line_search is not None:
+                if self.line_search != "strong_wolfe":
+                    raise RuntimeError("only 'strong_wolfe' is supported")
+                x0 = self._snapshot()
+                loss, g, t, ls_evals = self._strong_wolfe(closure, x0, t, d, loss, g, gtd, self.max_eval - evals)
+                self._move(t, d)
+                converged = np.max(np.abs(g)) <= self.tol_grad
+            else:
+                self._move(t, d)
+                converged = False
+                if n != self.max_iter:
+                    loss = float(closure())
+                    g = self._grad()
+                    converged = np.max(np.abs(g)) <= self.tol_grad
+                    ls_evals = 1
+            evals += ls_evals
+            st["func_evals"] += ls_evals
+            if n == self.max_iter or evals >= self.max_eval or converged:
+                break
+            if np.max(np.abs(d * t)) <= self.tol_change or abs(loss - loss_prev) < self.tol_change:
+                break
+        st.update(d=d, t=t, old_dirs=ys_hist, old_stps=s_hist, ro=rho, H_diag=h0, prev_flat_grad=g_prev, prev_loss=loss_prev)
+        return first
+
+
 class _SGD:
     """torch.optim.SGD(params, lr=1e-3, momentum=0, dampening=0, weight_decay=0, nesterov=False)"""
 
@@ -298,8 +478,8 @@ class Model:
         `iters+1` loss evaluations; `times/losses/errors` are continued across calls, the optimiser state is not.
 
         Args:
-            method (str): Adam, SGD or AdaGrad (LBFGS is not on the HIP path yet).
-            iters (int): number of iterations.
+            method (str): LBFGS, Adam, SGD or AdaGrad.
+            iters (int): number of iterations (the maximum for LBFGS).
             verbose (bool): print progress (at most every ~10 s).
             error (str, function): prediction error evaluated per iteration.
             plot (bool): accepted; plotting is out of scope.
@@ -321,7 +501,7 @@ class Model:
                 raise ValueError("error function must return a float")
 
         if method.lower() in ("l-bfgs", "lbfgs", "l-bfgs-b", "lbfgsb"):
-            raise NotImplementedError("LBFGS is not on the HIP path yet (SURVEY.md 8f-1); use Adam")
+            method = "LBFGS"
         elif method.lower() == "adam":
             method = "Adam"
         elif method.lower() == "sgd":
@@ -375,16 +555,32 @@ class Model:
                 progress_time += 10.0 + float(int((elapsed_time - progress_time) / 10.0)) * 10.0
 
         params = list(self.gpr.parameters())
-        if method == "Adam":
-            optimizer = _Adam(params, **kwargs)
-        elif method == "SGD":
-            optimizer = _SGD(params, **kwargs)
-        else:
-            optimizer = _Adagrad(params, **kwargs)
+        if method == "LBFGS":
+            # one optimizer.step(closure) runs the whole optimisation; losses are indexed by the function-evaluation count and `iters`
+            # becomes that count afterwards (reference model.py:541-553)
+            if "max_iter" not in kwargs:
+                kwargs["max_iter"] = iters
+            else:
+                iters = kwargs["max_iter"]
+            optimizer = _LBFGS(params, **kwargs)
 
-        for i in range(iters):
-            progress(i, self.loss())
-            optimizer.step()
+            def closure():
+                i = int(optimizer.state["func_evals"])
+                value = self.loss()
+                progress(i, value)
+                return value
+            optimizer.step(closure)
+            iters = int(optimizer.state["func_evals"])
+        else:
+            if method == "Adam":
+                optimizer = _Adam(params, **kwargs)
+            elif method == "SGD":
+                optimizer = _SGD(params, **kwargs)
+            else:
+                optimizer = _Adagrad(params, **kwargs)
+            for i in range(iters):
+                progress(i, self.loss())
+                optimizer.step()
         progress(iters, self.loss(), last=True)
 
         if verbose:

@@ -8,6 +8,7 @@ nothing of the reference travels.  Re-run:  python tests/golden/gen_golden.py [-
   lml_*.npz     LML + d(loss)/d(raw) of every parameter (autograd) at N<=96, one at N=2048
   predict.npz   predict_f mean/var (+full covariance) and predict_y intervals
   adam_cfg1.npz airline-passengers SM(Q=3) Adam trajectory (BASELINE.json configs[0])
+  lbfgs_cfg1.npz the same model under train('LBFGS'): fixed-step and strong-Wolfe loss traces by function evaluation
   cfg2.npz      [--full] MOSM C=4 Q=3 N=8192 LML + gradient (BASELINE.json configs[1]; ~20 s, 10 GB)
   cfg4.npz      [--full] CSM C=4 Q=3 N=16384 predict_f at 64 probe rows of S=4096 (configs[3]; ~40 s, 16 GB)
   titsias.npz   small Titsias ELBO + gradients (kernel, scale, inducing points) + predict_f
@@ -249,6 +250,30 @@ def gen_adam_cfg1():
     print("adam_cfg1.npz lml0=%.10f loss[100]=%.6f" % (out["lml0"], losses[-1]))
 
 
+def gen_lbfgs_cfg1():
+    """the reference's other documented optimiser on the cfg1 model: train('LBFGS') with torch's defaults (fixed step) and with lr / history_size
+    overrides.  Stores the loss traces (indexed by function evaluation, model.py:546-552), model.iters and the
+    final raw parameters; inputs and initial parameters are those of adam_cfg1.npz."""
+    air = np.loadtxt("/root/reference/examples/data/Airline_passenger.csv")
+    out = {}
+    # (line_search_fn='strong_wolfe' cannot be recorded: with the installed torch the reference dies in LBFGS._clone_param, because its
+    #  Parameter.clone() takes no memory_format -- the line search itself is pinned on torch.optim.LBFGS in tests/test_host_logic.py)
+    for tag, kw in (("fixed", dict(iters=40)), ("fixed_lr", dict(iters=25, lr=0.5, history_size=5))):
+        data = mogptk.Data(air[:, 0], air[:, 1], name="airline")
+        data.transform(mogptk.TransformDetrend(degree=2))
+        data.transform(mogptk.TransformStandard())
+        torch.manual_seed(1)
+        model = mogptk.SM(data, Q=3)
+        model.init_parameters("LS")
+        losses, _ = model.train("LBFGS", jit=False, **kw)
+        out[tag + "_losses"] = np.array(model.losses)
+        out[tag + "_iters"] = np.array(model.iters)
+        out[tag + "_max_iter"] = np.array(kw["iters"])
+        dump_params(tag + "_final_", list(model.gpr.parameters()), out)
+        print("lbfgs %s: func evals %d, loss %.8f -> %.8f" % (tag, model.iters, model.losses[0], model.losses[-1]))
+    np.savez_compressed(os.path.join(HERE, "lbfgs_cfg1.npz"), **out)
+
+
 def gen_quirks():
     """Q1/Q2 of SURVEY.md 8b as data."""
     out = {}
@@ -361,7 +386,7 @@ if __name__ == "__main__":
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "quirks": gen_quirks,
+    steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "lbfgs": gen_lbfgs_cfg1, "quirks": gen_quirks,
              "titsias": gen_titsias}
     full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:

@@ -197,6 +197,19 @@ def test_full_size_properties_cfg2():
         assert np.max(np.abs(g - p.grad)) < 1e-8 * np.max(np.abs(g))
 
 
+def test_train_lbfgs_on_device_matches_reference_trace():
+    """Model.train('LBFGS') end to end on the device (reference model.py:541-553) against the trace recorded from the reference"""
+    fx0, fx = load("adam_cfg1.npz"), load("lbfgs_cfg1.npz")
+    data = mogptk_amd.Data(fx0["X"][:, 1], fx0["y"][:, 0], name="airline")
+    model = mogptk_amd.SM(data, Q=3)
+    load_raw(model.gpr.parameters(), fixture_params(fx0, "init_"))
+    model.train("LBFGS", iters=int(fx["fixed_max_iter"]))
+    ref = fx["fixed_losses"]
+    assert model.iters == int(fx["fixed_iters"])
+    assert relerr(model.losses[:15], ref[:15]) < 1e-7
+    assert relerr(model.losses, ref) < 1e-3
+
+
 def test_cfg4_predict_golden():
     """BASELINE.json configs[3]: CSM C=4 Q=3 N=16384, predictive mean/variance at S=4096 (64 probe rows stored)."""
     fx = load("cfg4.npz")

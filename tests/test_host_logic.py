@@ -104,6 +104,68 @@ def test_train_adam_trajectory_and_driver_semantics():
         model.train("nope")
 
 
+def test_train_lbfgs_trajectories_match_reference():
+    """train('LBFGS') (reference model.py:541-553): losses indexed by function evaluation, model.iters = number of evaluations,
+    fixed-step torch defaults and lr / history_size overrides -- against traces recorded from the reference."""
+    fx = load("lbfgs_cfg1.npz")
+    for tag, kw in (("fixed", {}), ("fixed_lr", dict(lr=0.5, history_size=5))):
+        _, model = _airline_model()
+        losses, errors = model.train("LBFGS", iters=int(fx[tag + "_max_iter"]), **kw)
+        ref = fx[tag + "_losses"]
+        assert model.iters == int(fx[tag + "_iters"]) and model.losses.shape == ref.shape
+        assert relerr(model.losses[:15], ref[:15]) < 1e-8                       # measured 1e-12 .. 4e-10: the same algorithm
+        assert relerr(model.losses, ref) < 1e-4                                  # later the curvature pairs amplify rounding (measured 3e-5)
+        for p, f in zip(model.gpr.parameters(), fixture_params(fx, tag + "_final_")):
+            assert np.max(np.abs(p.data - f["raw"])) < 1e-3 * max(1.0, np.max(np.abs(f["raw"]))), p._name   # measured 2e-4
+    for alias in ("l-bfgs", "lbfgsb", "L-BFGS-B"):
+        _, model = _airline_model()
+        model.train(alias, iters=3)
+        assert model.iters == 3
+
+
+def test_lbfgs_matches_torch_on_a_test_function():
+    """the numpy optimiser against torch.optim.LBFGS itself (the semantics the reference relies on), with and without the strong-Wolfe
+    line search, on the 6-dimensional Rosenbrock function: same iterates, same number of function evaluations"""
+    import torch
+    from mogptk_amd.model import _LBFGS
+    from mogptk_amd.gpr import Parameter
+
+    def rosen(x):
+        return ((1.0 - x[:-1]) ** 2).sum() + 100.0 * ((x[1:] - x[:-1] ** 2) ** 2).sum()
+
+    x0 = np.array([-1.2, 1.0, 0.5, -0.3, 0.8, 1.5])
+    for kw in (dict(max_iter=25), dict(max_iter=40, line_search_fn="strong_wolfe"), dict(max_iter=30, lr=0.3, history_size=4),
+               dict(max_iter=60, max_eval=70, line_search_fn="strong_wolfe", tolerance_grad=1e-12, tolerance_change=1e-14)):
+        xt = torch.tensor(x0, dtype=torch.float64, requires_grad=True)
+        opt = torch.optim.LBFGS([xt], **kw)
+        trace_t = []
+
+        def closure_t():
+            opt.zero_grad()
+            f = rosen(xt)
+            f.backward()
+            trace_t.append(float(f))
+            return f
+        opt.step(closure_t)
+
+        p = Parameter(x0.copy())
+        p.data = x0.copy()
+        mine = _LBFGS([p], **kw)
+        trace_m = []
+
+        def closure_m():
+            x = torch.tensor(p.data, dtype=torch.float64, requires_grad=True)
+            f = rosen(x)
+            f.backward()
+            p.grad = x.grad.numpy().copy()
+            trace_m.append(float(f))
+            return float(f)
+        mine.step(closure_m)
+        assert len(trace_m) == len(trace_t) == mine.state["func_evals"], (kw, len(trace_m), len(trace_t))
+        assert relerr(trace_m, trace_t) < 1e-6, (kw, relerr(trace_m, trace_t))      # same evaluation count; values agree to rounding amplification
+        assert np.max(np.abs(p.data - xt.detach().numpy())) < 1e-6, kw
+
+
 def test_predict_return_shapes_and_pickle_roundtrip(tmp_path):
     fx, model = _airline_model()
     xs = fx["pred_X"]
