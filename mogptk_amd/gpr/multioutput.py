@@ -1,7 +1,8 @@
 """
 Multi-output spectral kernels on the HIP path -- host-side mirror of mogptk/gpr/multioutput.py for the
-three kernels the hot path covers: IndependentMultiOutputKernel (:5-39), MultiOutputSpectralMixtureKernel
-(MOSM, :125-210) and CrossSpectralKernel (CSM, :397-454).
+kernels the hot path covers: IndependentMultiOutputKernel (:5-39), MultiOutputSpectralMixtureKernel (MOSM, :125-210),
+CrossSpectralKernel (CSM, :397-454) and -- SURVEY 8f-2, same term table -- MultiOutputSpectralKernel (:41-123) and
+UncoupledMultiOutputSpectralKernel (uMOSM, :212-293).
 
 Each class maps its constrained parameters to the unified spectral term table and back-propagates the
 table gradient to its raw parameters; see gpr/kernel.py (this package) for the protocol.
@@ -79,9 +80,31 @@ class MultiOutputSpectralMixtureKernel(MultiOutputKernel):
             self.phase.train = False
         self.twopi = np.power(2.0 * np.pi, float(self.input_dims) / 2.0)
 
+    # hooks shared with the sibling kernels below (same pair algebra, different parameter layout / magnitude)
+    _phase_scale = 1.0                                   # Psi = _phase_scale * (phase_i - phase_j), in cycles
+
+    def _values(self):
+        """constrained (weight, mean, variance, delay, phase) with a mixture axis: (C,Q), (C,Q,D) x3, (C,Q)"""
+        return self.weight(), self.mean(), self.variance(), self.delay(), self.phase()
+
+    def _magnitude(self, w):
+        """(C,C,Q) magnitude of every channel pair: w_i w_j (reference :184,:192)"""
+        return w[:, None] * w[None, :]
+
+    def _magnitude_backward(self, w, gmag):
+        """gmag: d loss / d magnitude for pairs i >= j (zero above the diagonal) -> gradient of the constrained weight"""
+        return np.sum(gmag * w[None, :], axis=1) + np.sum(gmag * w[:, None], axis=0)
+
+    def _store(self, gw, gmu, gv, gth, gph):
+        _accumulate(self.weight, gw)
+        _accumulate(self.mean, gmu)
+        _accumulate(self.variance, gv)
+        if self.output_dims > 1:                   # with one channel delay/phase never enter the graph (grad None)
+            _accumulate(self.delay, gth)
+            _accumulate(self.phase, gph)
+
     def _pairs(self):
-        w, mu, v = self.weight(), self.mean(), self.variance()
-        th, ph = self.delay(), self.phase()
+        w, mu, v, th, ph = self._values()
         vi, vj = v[:, None], v[None, :]                 # (C,C,Q,D) broadcast
         mi, mj = mu[:, None], mu[None, :]
         s = vi + vj
@@ -95,18 +118,18 @@ class MultiOutputSpectralMixtureKernel(MultiOutputKernel):
             raise ValueError("X must have %d input dimensions" % self.input_dims)
         C = self.output_dims
         w, mu, v, th, ph, vi, vj, mi, mj, s, inv, dmu = self._pairs()
-        Q = w.shape[1]
+        Q = mu.shape[1]
         table = np.empty((C, C, Q, term_width(D)))
-        mag = w[:, None] * w[None, :] * np.exp(-PI ** 2 * np.sum(dmu * inv * dmu, axis=3))     # :192
+        mag = self._magnitude(w) * np.exp(-PI ** 2 * np.sum(dmu * inv * dmu, axis=3))           # :192
         M = inv * (vi * mj + vj * mi)                                                           # :194
         V = 2.0 * vi * inv * vj                                                                 # :195
         table[..., 0] = mag * self.twopi * np.sqrt(np.prod(V, axis=3))                          # :199
-        table[..., 1] = ph[:, None] - ph[None, :]                                               # :197
+        table[..., 1] = self._phase_scale * (ph[:, None] - ph[None, :])                         # :197
         table[..., 2:2 + D] = V
         table[..., 2 + D:2 + 2 * D] = M
         table[..., 2 + 2 * D:] = th[:, None] - th[None, :]                                      # :196
         for c in range(C):                                                                      # i == j branch :183-187
-            table[c, c, :, 0] = w[c] ** 2 * self.twopi * np.sqrt(np.prod(v[c], axis=1))
+            table[c, c, :, 0] = self._magnitude(w)[c, c] * self.twopi * np.sqrt(np.prod(v[c], axis=1))
             table[c, c, :, 1] = 0.0
             table[c, c, :, 2:2 + D] = v[c]
             table[c, c, :, 2 + D:2 + 2 * D] = mu[c]
@@ -130,8 +153,11 @@ class MultiOutputSpectralMixtureKernel(MultiOutputKernel):
         o2 = off[:, :, None]
         o3 = off[:, :, None, None]
         gAA = np.where(o2, gA * A, 0.0)                                     # (C,C,Q)
-        gw = np.sum(gAA / w[:, None], axis=1) + np.sum(gAA / w[None, :], axis=0)
-        gph = np.sum(np.where(o2, gPsi, 0.0), axis=1) - np.sum(np.where(o2, gPsi, 0.0), axis=0)
+        # d A / d magnitude = everything but the magnitude (kept explicit: a magnitude may be zero or negative for the uncoupled kernel)
+        Fm = np.exp(-PI ** 2 * np.sum(dmu * inv * dmu, axis=3)) * self.twopi * np.sqrt(np.prod(V, axis=3))
+        gmag = gA * Fm                                                       # gtable is zero above the diagonal already
+        gw = self._magnitude_backward(w, gmag)
+        gph = self._phase_scale * (np.sum(np.where(o2, gPsi, 0.0), axis=1) - np.sum(np.where(o2, gPsi, 0.0), axis=0))
         gDlo = np.where(o3, gDl, 0.0)
         gth = np.sum(gDlo, axis=1) - np.sum(gDlo, axis=0)
         gMo = np.where(o3, gM, 0.0)
@@ -145,16 +171,67 @@ class MultiOutputSpectralMixtureKernel(MultiOutputKernel):
         gv_i = gAA3 * (common + 0.5 * dVi / V) + gVo * dVi + gMo * (mj - M) * inv
         gv_j = gAA3 * (common + 0.5 * dVj / V) + gVo * dVj + gMo * (mi - M) * inv
         gv = np.sum(gv_i, axis=1) + np.sum(gv_j, axis=0)
-        for c in range(C):                                                  # i == j blocks
-            gw[c] += gA[c, c] * 2.0 * A[c, c] / w[c]
+        for c in range(C):                                                  # i == j blocks (their magnitude part is in gmag already)
             gv[c] += (gA[c, c] * A[c, c])[:, None] / (2.0 * v[c]) + gV[c, c]
             gmu[c] += gM[c, c]
-        _accumulate(self.weight, gw)
-        _accumulate(self.mean, gmu)
-        _accumulate(self.variance, gv)
-        if C > 1:                                  # with one channel delay/phase never enter the graph (grad None)
-            _accumulate(self.delay, gth)
-            _accumulate(self.phase, gph)
+        self._store(gw, gmu, gv, gth, gph)
+
+
+class MultiOutputSpectralKernel(MultiOutputSpectralMixtureKernel):
+    """
+    One MOSM component without the mixture axis (reference gpr/multioutput.py:41-123); use `MixtureKernel(MultiOutputSpectralKernel(...), Q)`.
+    Parameters: weight (C,), mean/variance/delay (C,D), phase (C,).
+    """
+
+    def __init__(self, output_dims, input_dims=1, active_dims=None):
+        MultiOutputKernel.__init__(self, output_dims, input_dims, active_dims)
+        self.input_dims = input_dims
+        self.weight = Parameter(np.ones(output_dims), lower=config.positive_minimum)
+        self.mean = Parameter(np.zeros((output_dims, input_dims)), lower=config.positive_minimum)
+        self.variance = Parameter(np.ones((output_dims, input_dims)), lower=config.positive_minimum)
+        self.delay = Parameter(np.zeros((output_dims, input_dims)))
+        self.phase = Parameter(np.zeros(output_dims))
+        if output_dims == 1:
+            self.delay.train = False
+            self.phase.train = False
+        self.twopi = np.power(2.0 * np.pi, float(self.input_dims) / 2.0)
+
+    def _values(self):
+        return (self.weight()[:, None], self.mean()[:, None], self.variance()[:, None], self.delay()[:, None], self.phase()[:, None])
+
+    def _store(self, gw, gmu, gv, gth, gph):
+        super()._store(gw[:, 0], gmu[:, 0], gv[:, 0], gth[:, 0], gph[:, 0])
+
+
+class UncoupledMultiOutputSpectralKernel(MultiOutputSpectralKernel):
+    """
+    uMOSM (reference gpr/multioutput.py:212-293): like MultiOutputSpectralKernel, but the pair magnitudes are the entries of
+    tril(weight) tril(weight)^T with an unconstrained (C,C) weight, and the phase difference enters the cosine WITHOUT the 2 pi factor
+    (reference :283 -- kept).  Use `MixtureKernel(UncoupledMultiOutputSpectralKernel(...), Q)`.
+    """
+    _phase_scale = 1.0 / (2.0 * np.pi)
+
+    def __init__(self, output_dims, input_dims=1, active_dims=None):
+        super().__init__(output_dims, input_dims, active_dims)
+        del self.__dict__["weight"]
+        self.__dict__["_order"].remove("weight")
+        self.__dict__["_order"].insert(0, "weight")
+        self.weight = Parameter(np.tril(np.ones((output_dims, output_dims))))
+        self.weight.num_parameters = int((output_dims * output_dims + output_dims) / 2)
+
+    def _values(self):
+        return (self.weight(), self.mean()[:, None], self.variance()[:, None], self.delay()[:, None], self.phase()[:, None])
+
+    def _magnitude(self, w):
+        t = np.tril(w)
+        return (t @ t.T)[:, :, None]
+
+    def _magnitude_backward(self, w, gmag):
+        g = gmag[:, :, 0]
+        return np.tril((g + g.T) @ np.tril(w))
+
+    def _store(self, gw, gmu, gv, gth, gph):
+        MultiOutputSpectralMixtureKernel._store(self, gw, gmu[:, 0], gv[:, 0], gth[:, 0], gph[:, 0])
 
 
 class CrossSpectralKernel(MultiOutputKernel):

@@ -8,6 +8,7 @@ nothing of the reference travels.  Re-run:  python tests/golden/gen_golden.py [-
   lml_*.npz     LML + d(loss)/d(raw) of every parameter (autograd) at N<=96, one at N=2048
   predict.npz   predict_f mean/var (+full covariance) and predict_y intervals
   adam_cfg1.npz airline-passengers SM(Q=3) Adam trajectory (BASELINE.json configs[0])
+  kernels_8f2.npz / lml_mosk_* / lml_umosm_*  MultiOutputSpectralKernel and UncoupledMultiOutputSpectralKernel
   lbfgs_cfg1.npz the same model under train('LBFGS'): fixed-step and strong-Wolfe loss traces by function evaluation
   cfg2.npz      [--full] MOSM C=4 Q=3 N=8192 LML + gradient (BASELINE.json configs[1]; ~20 s, 10 GB)
   cfg4.npz      [--full] CSM C=4 Q=3 N=16384 predict_f at 64 probe rows of S=4096 (configs[3]; ~40 s, 16 GB)
@@ -74,6 +75,22 @@ def build_kernel(kind, C, Q, D, Rq, rng):
             k[q].mean.assign(rng.uniform(0.05, 0.5, D))
             k[q].variance.assign(rng.uniform(0.05, 0.5, D))
             k[q].shift.assign(rng.normal(0, 0.3, (C, Rq)))
+    elif kind == "mosk":       # MixtureKernel(MultiOutputSpectralKernel): MOSM components without the mixture axis
+        k = g.MixtureKernel(g.MultiOutputSpectralKernel(output_dims=C, input_dims=D), Q)
+        for q in range(Q):
+            k[q].weight.assign(rng.uniform(0.5, 1.5, C))
+            k[q].mean.assign(rng.uniform(0.05, 0.5, (C, D)))
+            k[q].variance.assign(rng.uniform(0.05, 0.5, (C, D)))
+            k[q].delay.assign(rng.normal(0, 0.3, (C, D)))
+            k[q].phase.assign(rng.normal(0, 0.3, C))
+    elif kind == "umosm":      # MixtureKernel(UncoupledMultiOutputSpectralKernel): lower-triangular (C,C) weight
+        k = g.MixtureKernel(g.UncoupledMultiOutputSpectralKernel(output_dims=C, input_dims=D), Q)
+        for q in range(Q):
+            k[q].weight.assign(np.tril(rng.normal(0.8, 0.4, (C, C))))
+            k[q].mean.assign(rng.uniform(0.05, 0.5, (C, D)))
+            k[q].variance.assign(rng.uniform(0.05, 0.5, (C, D)))
+            k[q].delay.assign(rng.normal(0, 0.3, (C, D)))
+            k[q].phase.assign(rng.normal(0, 0.3, C))
     return k
 
 
@@ -101,10 +118,24 @@ KERNEL_CASES = [  # kind, C, Q, D, Rq, N, N2, shuffle
 ]
 
 
-def gen_kernels():
-    out = {"ncases": np.array(len(KERNEL_CASES))}
-    for n, (kind, C, Q, D, Rq, N, N2, shuffle) in enumerate(KERNEL_CASES):
-        rng = np.random.default_rng(1000 + n)
+KERNEL_CASES_8F2 = [  # the multi-output kernels that share MOSM's term table
+    ("mosk", 3, 2, 1, 1, 45, 16, False),
+    ("mosk", 2, 1, 2, 1, 36, 13, True),
+    ("umosm", 3, 2, 1, 1, 44, 15, False),
+    ("umosm", 2, 2, 2, 1, 38, 12, True),
+    ("umosm", 1, 1, 1, 1, 25, 9, False),
+]
+
+
+def gen_kernels_8f2():
+    gen_kernels(KERNEL_CASES_8F2, "kernels_8f2.npz", 1100)
+
+
+def gen_kernels(cases=None, fname="kernels.npz", seed0=1000):
+    cases = KERNEL_CASES if cases is None else cases
+    out = {"ncases": np.array(len(cases))}
+    for n, (kind, C, Q, D, Rq, N, N2, shuffle) in enumerate(cases):
+        rng = np.random.default_rng(seed0 + n)
         X, _ = small_data(N, C, D, 2000 + n, shuffle)
         X2, _ = small_data(N2, C, D, 3000 + n, shuffle)
         k = build_kernel(kind, C, Q, D, Rq, rng)
@@ -118,8 +149,8 @@ def gen_kernels():
             out[pre + "K"] = k.K(T(X)).numpy()
             out[pre + "K12"] = k.K(T(X), T(X2)).numpy()
             out[pre + "Kdiag"] = k.K_diag(T(X)).numpy()
-    np.savez_compressed(os.path.join(HERE, "kernels.npz"), **out)
-    print("kernels.npz written")
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, "written")
 
 
 LML_CASES = [  # name, kind, C, Q, D, Rq, N, shuffle, scalar_variance
@@ -145,10 +176,23 @@ def lml_case(kind, C, Q, D, Rq, X, y, rng, scalar_variance=False, jitter=1e-8):
     return m, lml, loss
 
 
-def gen_lml():
-    for n, (name, kind, C, Q, D, Rq, N, shuffle, sv) in enumerate(LML_CASES):
-        rng = np.random.default_rng(4000 + n)
-        X, y = small_data(N, C, D, 5000 + n, shuffle)
+LML_CASES_8F2 = [
+    ("mosk_c3q2", "mosk", 3, 2, 1, 1, 84, False, False),
+    ("mosk_c2q1_d2", "mosk", 2, 1, 2, 1, 60, True, False),
+    ("umosm_c3q2", "umosm", 3, 2, 1, 1, 90, False, False),
+    ("umosm_c2q2_d2", "umosm", 2, 2, 2, 1, 64, True, False),
+]
+
+
+def gen_lml_8f2():
+    gen_lml(LML_CASES_8F2, 4100, synth_case=False)
+
+
+def gen_lml(cases=None, seed0=4000, synth_case=True):
+    cases = LML_CASES if cases is None else cases
+    for n, (name, kind, C, Q, D, Rq, N, shuffle, sv) in enumerate(cases):
+        rng = np.random.default_rng(seed0 + n)
+        X, y = small_data(N, C, D, seed0 + 1000 + n, shuffle)
         m, lml, loss = lml_case(kind, C, Q, D, Rq, X, y, rng, sv)
         out = {"meta": np.array([C, Q, D, Rq]), "kind": np.array(kind), "X": X, "y": y, "jitter": np.array(m.jitter),
                "lml": np.array(lml), "loss": np.array(loss), "scalar_variance": np.array(sv)}
@@ -156,6 +200,8 @@ def gen_lml():
         np.savez_compressed(os.path.join(HERE, "lml_%s.npz" % name), **out)
         print("lml_%s.npz  lml=%.10f" % (name, lml))
 
+    if not synth_case:
+        return
     # one mid-size case on the shared synthetic generator: only outputs are stored
     C, Q, N = 4, 3, 2048
     X, y = synth.make_data(N, C)
@@ -387,6 +433,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "lbfgs": gen_lbfgs_cfg1, "quirks": gen_quirks,
+             "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2,
              "titsias": gen_titsias}
     full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:

@@ -88,6 +88,10 @@ def product_kernel(kind, C, Q, D, Rq):
         return g.IndependentMultiOutputKernel([g.SpectralMixtureKernel(Q=Q, input_dims=D) for _ in range(C)], output_dims=C)
     if kind == "csm":
         return g.MixtureKernel(g.CrossSpectralKernel(output_dims=C, input_dims=D, Rq=Rq), Q)
+    if kind == "mosk":
+        return g.MixtureKernel(g.MultiOutputSpectralKernel(output_dims=C, input_dims=D), Q)
+    if kind == "umosm":
+        return g.MixtureKernel(g.UncoupledMultiOutputSpectralKernel(output_dims=C, input_dims=D), Q)
     raise ValueError(kind)
 
 

@@ -24,8 +24,9 @@ def test_native_library_is_the_path():
     assert "gfx950" in _lib.device_name(0)
 
 
-def test_gram_matches_reference_fixtures():
-    fx = load("kernels.npz")
+@pytest.mark.parametrize("fixture", ["kernels.npz", "kernels_8f2.npz"])
+def test_gram_matches_reference_fixtures(fixture):
+    fx = load(fixture)
     for n in range(int(fx["ncases"])):
         pre = "c%d_" % n
         C, Q, D, Rq = [int(v) for v in fx[pre + "meta"]]
@@ -40,7 +41,8 @@ def test_gram_matches_reference_fixtures():
 
 
 LML = ["mosm_c3q2", "mosm_c2q3_shuf", "mosm_c3q2_d2", "mosm_c1q2", "mosm_scalarvar", "sm_c1q3", "sm_c2q2_d2",
-       "csm_c3q2", "csm_c2q2r2"]
+       "csm_c3q2", "csm_c2q2r2",
+       "mosk_c3q2", "mosk_c2q1_d2", "umosm_c3q2", "umosm_c2q2_d2"]          # same term table, other parameter algebra
 
 
 @pytest.mark.parametrize("name", LML)

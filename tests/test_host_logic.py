@@ -21,8 +21,9 @@ def fake_device(monkeypatch):
     monkeypatch.setattr(L, "gram", lambda device, C, D, table, X1, X2=None: gram_from_table(np.asarray(table), X1, X2))
 
 
-def test_term_tables_reproduce_reference_kernels():
-    fx = load("kernels.npz")
+@pytest.mark.parametrize("fixture", ["kernels.npz", "kernels_8f2.npz"])
+def test_term_tables_reproduce_reference_kernels(fixture):
+    fx = load(fixture)
     for n in range(int(fx["ncases"])):
         pre = "c%d_" % n
         C, Q, D, Rq = [int(v) for v in fx[pre + "meta"]]
@@ -35,7 +36,8 @@ def test_term_tables_reproduce_reference_kernels():
 
 
 LML = ["mosm_c3q2", "mosm_c2q3_shuf", "mosm_c3q2_d2", "mosm_c1q2", "mosm_scalarvar", "sm_c1q3", "sm_c2q2_d2",
-       "csm_c3q2", "csm_c2q2r2"]
+       "csm_c3q2", "csm_c2q2r2",
+       "mosk_c3q2", "mosk_c2q1_d2", "umosm_c3q2", "umosm_c2q2_d2"]          # same term table, other parameter algebra
 
 
 @pytest.mark.parametrize("name", LML)
