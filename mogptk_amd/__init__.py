@@ -11,6 +11,6 @@ from .gpr.model import CholeskyException
 from .util import *
 from .dataset import Data, DataSet, TransformBase
 from .model import Model, Exact, Titsias, LoadModel
-from .wrappers import MOSM, SM, CSM
+from .wrappers import MOSM, SM, CSM, SM_LMC
 from . import gpr
 from .dist import use_distributed, use_single_device

@@ -284,3 +284,87 @@ class CrossSpectralKernel(MultiOutputKernel):
         _accumulate(self.mean, np.sum(gtable[..., 2 + D:2 + 2 * D], axis=(0, 1, 2)))
         if C > 1:
             _accumulate(self.shift, gsh)
+
+
+class LinearModelOfCoregionalizationKernel(MultiOutputKernel):
+    """
+    LMC (reference gpr/multioutput.py:456-502): K_ij = sum_q (sum_r w_iqr w_jqr) k_q(x, x') over Q single-output base kernels.
+    On the spectral path every base kernel must provide a term table (SpectralKernel / SpectralMixtureKernel): the LMC table is
+    their concatenation along T with the amplitudes scaled by B_q[i, j] = sum_r w_iqr w_jqr -- still ONE fused Gram pass.
+    Parameters: weight (C, Q, Rq) > 0, then the base kernels' own.
+    """
+
+    def __init__(self, *kernels, output_dims, input_dims=1, Q=None, Rq=1):
+        super().__init__(output_dims, input_dims)
+        if Q is None:
+            Q = len(kernels)
+        kernels = self._check_kernels(kernels, Q)
+        if any(k.output_dims is not None for k in kernels):
+            raise NotImplementedError("LMC over multi-output base kernels is not on the HIP path")
+        self.input_dims = input_dims
+        self.kernels = list(kernels)
+        self.weight = Parameter(np.ones((output_dims, Q, Rq)), lower=config.positive_minimum)
+
+    def __getitem__(self, key):
+        return self.kernels[key]
+
+    def name(self):
+        return "%s[%s]" % (self.__class__.__name__, ",".join(k.name() for k in self.kernels))
+
+    def iterkernels(self):
+        yield self
+        for kernel in self.kernels:
+            yield kernel
+
+    def _coreg(self):
+        w = self.weight()                                                   # (C,Q,Rq)
+        return np.einsum("iqr,jqr->ijq", w, w)                               # B_q[i,j]  (:493)
+
+    def _spectral_terms(self, D):
+        B = self._coreg()
+        C = self.output_dims
+        parts = []
+        for q, k in enumerate(self.kernels):
+            sub = k._spectral_terms(D)[0, 0]                                 # (T_q, W): Psi = Delta = 0 for single-output kernels
+            part = np.broadcast_to(sub, (C, C) + sub.shape).copy()
+            part[..., 0] = B[:, :, q, None] * sub[None, None, :, 0]
+            parts.append(part)
+        return np.concatenate(parts, axis=2)
+
+    def _spectral_diag(self, D):
+        """reference :497-502: sum_q (sum_r w_cqr^2) K_diag_q -- with the base kernel's own K_diag convention"""
+        B = self._coreg()
+        kd = np.array([k._spectral_diag(D)[0] for k in self.kernels])        # (Q,)
+        return np.einsum("ccq,q->c", B, kd)
+
+    def _weight_backward(self, gB):
+        """gB[i,j,q]: d loss / d B_q[i,j] over the pairs the loss actually uses (any pattern) -> weight"""
+        w = self.weight()
+        _accumulate(self.weight, np.einsum("ijq,jqr->iqr", gB, w) + np.einsum("ijq,iqr->jqr", gB, w))
+
+    def _spectral_diag_backward(self, gc, D):
+        B = self._coreg()
+        C = self.output_dims
+        gB = np.zeros_like(B)
+        for q, k in enumerate(self.kernels):
+            kd = k._spectral_diag(D)[0]
+            for c in range(C):
+                gB[c, c, q] = gc[c] * kd
+            k._spectral_diag_backward(np.array([np.sum(gc * B[np.arange(C), np.arange(C), q])]), D)
+        self._weight_backward(gB)
+
+    def _spectral_backward(self, gtable):
+        D = (gtable.shape[3] - 2) // 3
+        B = self._coreg()
+        gB = np.zeros_like(B)
+        t0 = 0
+        for q, k in enumerate(self.kernels):
+            sub = k._spectral_terms(D)[0, 0]
+            T = sub.shape[0]
+            g = gtable[:, :, t0:t0 + T, :]                                   # zero above the diagonal, double count included
+            gB[:, :, q] = np.sum(g[..., 0] * sub[None, None, :, 0], axis=2)
+            gsub = np.sum(g, axis=(0, 1))                                    # V, M columns: the same base value in every pair
+            gsub[:, 0] = np.einsum("ijt,ij->t", g[..., 0], B[:, :, q])
+            k._spectral_backward(gsub[None, None])
+            t0 += T
+        self._weight_backward(gB)

@@ -1,5 +1,5 @@
 """
-Model wrappers MOSM / SM / CSM -- host-side mirror of mogptk/models/{mosm,sm,csm}.py constructors.
+Model wrappers MOSM / SM / CSM / SM_LMC -- host-side mirror of mogptk/models/{mosm,sm,csm,sm_lmc}.py constructors.
 
 Constructor semantics are part of the drop-in boundary and are reproduced including quirk Q2
 (SURVEY.md 8b): the Nyquist re-bounding `mean.assign(upper=...)` at mosm.py:60 / sm.py:60 / csm.py:64
@@ -11,7 +11,7 @@ import numpy as np
 from .dataset import DataSet
 from .model import Model, Exact, logger
 from .gpr import (MultiOutputSpectralMixtureKernel, IndependentMultiOutputKernel, SpectralMixtureKernel,
-                  CrossSpectralKernel, MixtureKernel)
+                  CrossSpectralKernel, MixtureKernel, LinearModelOfCoregionalizationKernel, SpectralKernel)
 
 
 def _rand(*shape):
@@ -98,6 +98,40 @@ class CSM(Model):
         self.Rq = Rq
         nyquist = np.amin(self.dataset.get_nyquist_estimation(), axis=0)
         for q in range(Q):
+            self.gpr.kernel[q].mean.assign(upper=np.maximum(self.gpr.kernel[q].mean.lower, nyquist))
+
+    def init_parameters(self, method="BNSE", iters=500):
+        raise NotImplementedError("init_parameters is not built yet (SURVEY.md 8f-3)")
+
+
+class SM_LMC(Model):
+    """Spectral-mixture linear model of coregionalization with Q components of Rq latent functions (reference
+    models/sm_lmc.py:8-67): LMC over Q SpectralKernel base kernels whose magnitudes are pegged to 1 (train=False; the LMC weight
+    carries the amplitude), Nyquist upper bound on the means (with quirk Q2, as in the other wrappers)."""
+
+    def __init__(self, dataset, Q=1, Rq=1, inference=Exact(), mean=None, name="SM-LMC"):
+        if not isinstance(dataset, DataSet):
+            dataset = DataSet(dataset)
+        output_dims = dataset.get_output_dims()
+        input_dims = dataset.get_input_dims()[0]
+        for input_dim in dataset.get_input_dims()[1:]:
+            if input_dim != input_dims:
+                raise ValueError("input dimensions for all channels must match")
+
+        spectral = [SpectralKernel(input_dims) for q in range(Q)]
+        kernel = LinearModelOfCoregionalizationKernel(spectral, output_dims=output_dims, input_dims=input_dims, Q=Q, Rq=Rq)
+        kernel.weight.assign(_rand(output_dims, Q, Rq))
+        for q in range(Q):
+            kernel[q].magnitude.assign(_rand(1))
+            kernel[q].mean.assign(_rand(input_dims))
+            kernel[q].variance.assign(_rand(input_dims))
+
+        super().__init__(dataset, kernel, inference, mean, name)
+        self.Q = Q
+        self.Rq = Rq
+        nyquist = np.amin(self.dataset.get_nyquist_estimation(), axis=0)
+        for q in range(Q):
+            self.gpr.kernel[q].magnitude.assign(1.0, train=False)      # handled by the LMC weight (sm_lmc.py:65)
             self.gpr.kernel[q].mean.assign(upper=np.maximum(self.gpr.kernel[q].mean.lower, nyquist))
 
     def init_parameters(self, method="BNSE", iters=500):

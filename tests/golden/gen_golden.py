@@ -9,6 +9,7 @@ nothing of the reference travels.  Re-run:  python tests/golden/gen_golden.py [-
   predict.npz   predict_f mean/var (+full covariance) and predict_y intervals
   adam_cfg1.npz airline-passengers SM(Q=3) Adam trajectory (BASELINE.json configs[0])
   kernels_8f2.npz / lml_mosk_* / lml_umosm_*  MultiOutputSpectralKernel and UncoupledMultiOutputSpectralKernel
+  sm_lmc.npz     the SM_LMC wrapper: constructor state, loss + gradient, a short Adam trace
   lbfgs_cfg1.npz the same model under train('LBFGS'): fixed-step and strong-Wolfe loss traces by function evaluation
   cfg2.npz      [--full] MOSM C=4 Q=3 N=8192 LML + gradient (BASELINE.json configs[1]; ~20 s, 10 GB)
   cfg4.npz      [--full] CSM C=4 Q=3 N=16384 predict_f at 64 probe rows of S=4096 (configs[3]; ~40 s, 16 GB)
@@ -91,6 +92,20 @@ def build_kernel(kind, C, Q, D, Rq, rng):
             k[q].variance.assign(rng.uniform(0.05, 0.5, (C, D)))
             k[q].delay.assign(rng.normal(0, 0.3, (C, D)))
             k[q].phase.assign(rng.normal(0, 0.3, C))
+    elif kind == "lmc":        # LMC over Q SpectralKernel base kernels, weight (C,Q,Rq)
+        k = g.LinearModelOfCoregionalizationKernel(g.SpectralKernel(input_dims=D), output_dims=C, input_dims=D, Q=Q, Rq=Rq)
+        k.weight.assign(rng.uniform(0.5, 1.5, (C, Q, Rq)))
+        for q in range(Q):
+            k[q].magnitude.assign(rng.uniform(0.5, 1.5))
+            k[q].mean.assign(rng.uniform(0.05, 0.5, D))
+            k[q].variance.assign(rng.uniform(0.01, 0.1, D))
+    elif kind == "lmc_sm":     # LMC over spectral-mixture base kernels (3 components each)
+        k = g.LinearModelOfCoregionalizationKernel(g.SpectralMixtureKernel(Q=3, input_dims=D), output_dims=C, input_dims=D, Q=Q, Rq=Rq)
+        k.weight.assign(rng.uniform(0.5, 1.5, (C, Q, Rq)))
+        for q in range(Q):
+            k[q].magnitude.assign(rng.uniform(0.5, 1.5, 3))
+            k[q].mean.assign(rng.uniform(0.05, 0.5, (3, D)))
+            k[q].variance.assign(rng.uniform(0.01, 0.1, (3, D)))
     return k
 
 
@@ -124,6 +139,9 @@ KERNEL_CASES_8F2 = [  # the multi-output kernels that share MOSM's 
     ("umosm", 3, 2, 1, 1, 44, 15, False),
     ("umosm", 2, 2, 2, 1, 38, 12, True),
     ("umosm", 1, 1, 1, 1, 25, 9, False),
+    ("lmc", 3, 2, 1, 2, 42, 14, False),
+    ("lmc", 2, 3, 2, 1, 36, 12, True),
+    ("lmc_sm", 2, 2, 1, 1, 30, 11, False),
 ]
 
 
@@ -181,6 +199,9 @@ LML_CASES_8F2 = [
     ("mosk_c2q1_d2", "mosk", 2, 1, 2, 1, 60, True, False),
     ("umosm_c3q2", "umosm", 3, 2, 1, 1, 90, False, False),
     ("umosm_c2q2_d2", "umosm", 2, 2, 2, 1, 64, True, False),
+    ("lmc_c3q2r2", "lmc", 3, 2, 1, 2, 84, False, False),
+    ("lmc_c2q3_d2", "lmc", 2, 3, 2, 1, 60, True, False),
+    ("lmcsm_c2q2", "lmc_sm", 2, 2, 1, 1, 66, False, False),
 ]
 
 
@@ -342,6 +363,33 @@ def gen_quirks():
     print("quirks.npz written")
 
 
+def gen_smlmc():
+    """the SM_LMC wrapper (models/sm_lmc.py): constructor state (bounds, train flags, Nyquist re-bounding incl. quirk Q2), then explicit
+    values for everything it draws at random, the loss and its gradient, and a short Adam run"""
+    t = np.linspace(0, 10, 50)
+    ds = mogptk.DataSet(t, [np.sin(0.5 * t), 2.0 * np.sin(0.2 * t) + 0.1 * np.cos(3 * t), np.cos(0.7 * t)])
+    torch.manual_seed(3)
+    m = mogptk.SM_LMC(ds, Q=2, Rq=2)
+    out = {"t": t, "Y": np.stack([ds[j].Y for j in range(3)]), "Q": np.array(2), "Rq": np.array(2)}
+    dump_params("ctor_", list(m.gpr.parameters()), out)
+    out["ctor_train"] = np.array([bool(p.train) for p in m.gpr.parameters()])
+    out["num_parameters"] = np.array(m.num_parameters())
+    rng = np.random.default_rng(77)
+    m.gpr.kernel.weight.assign(rng.uniform(0.3, 1.2, (3, 2, 2)))
+    for q in range(2):
+        m.gpr.kernel[q].mean.assign(rng.uniform(0.05, 0.4, 1))
+        m.gpr.kernel[q].variance.assign(rng.uniform(0.01, 0.1, 1))
+    m.gpr.likelihood.scale.assign(rng.uniform(0.1, 0.3, 3))
+    out["lml"] = np.array(m.log_marginal_likelihood())
+    m.gpr.zero_grad(); loss = m.gpr.loss()
+    out["loss"] = np.array(float(loss))
+    dump_params("", list(m.gpr.parameters()), out, with_grad=True)
+    losses, _ = m.train("Adam", iters=10, lr=0.05, jit=False)
+    out["adam_losses"] = np.array(losses)
+    np.savez_compressed(os.path.join(HERE, "sm_lmc.npz"), **out)
+    print("sm_lmc.npz lml=%.10f params=%d" % (out["lml"], out["num_parameters"]))
+
+
 def gen_cfg2():
     import time
     C, Q, N = 4, 3, 8192
@@ -433,7 +481,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "lbfgs": gen_lbfgs_cfg1, "quirks": gen_quirks,
-             "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2,
+             "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2, "smlmc": gen_smlmc,
              "titsias": gen_titsias}
     full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:

@@ -90,6 +90,10 @@ def product_kernel(kind, C, Q, D, Rq):
         return g.MixtureKernel(g.CrossSpectralKernel(output_dims=C, input_dims=D, Rq=Rq), Q)
     if kind == "mosk":
         return g.MixtureKernel(g.MultiOutputSpectralKernel(output_dims=C, input_dims=D), Q)
+    if kind == "lmc":
+        return g.LinearModelOfCoregionalizationKernel(g.SpectralKernel(input_dims=D), output_dims=C, input_dims=D, Q=Q, Rq=Rq)
+    if kind == "lmc_sm":
+        return g.LinearModelOfCoregionalizationKernel(g.SpectralMixtureKernel(Q=3, input_dims=D), output_dims=C, input_dims=D, Q=Q, Rq=Rq)
     if kind == "umosm":
         return g.MixtureKernel(g.UncoupledMultiOutputSpectralKernel(output_dims=C, input_dims=D), Q)
     raise ValueError(kind)

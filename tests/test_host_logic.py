@@ -37,7 +37,7 @@ def test_term_tables_reproduce_reference_kernels(fixture):
 
 LML = ["mosm_c3q2", "mosm_c2q3_shuf", "mosm_c3q2_d2", "mosm_c1q2", "mosm_scalarvar", "sm_c1q3", "sm_c2q2_d2",
        "csm_c3q2", "csm_c2q2r2",
-       "mosk_c3q2", "mosk_c2q1_d2", "umosm_c3q2", "umosm_c2q2_d2"]          # same term table, other parameter algebra
+       "mosk_c3q2", "mosk_c2q1_d2", "umosm_c3q2", "umosm_c2q2_d2", "lmc_c3q2r2", "lmc_c2q3_d2", "lmcsm_c2q2"]          # same term table, other parameter algebra
 
 
 @pytest.mark.parametrize("name", LML)
@@ -208,6 +208,37 @@ def test_quirks_q1_q2_q3():
     assert not np.allclose(m.gpr.kernel.weight.data, w0)
     with pytest.raises(AttributeError):
         m.gpr.kernel.weight = gpr.Parameter(1.0)
+
+
+def test_sm_lmc_wrapper_matches_reference():
+    """SM_LMC (reference models/sm_lmc.py): constructor state -- bounds, train flags, pegged magnitudes, Nyquist re-bounding with quirk
+    Q2 --, then loss, gradient and an Adam trace at explicit parameter values"""
+    fx = load("sm_lmc.npz")
+    ds = mogptk_amd.DataSet(fx["t"], [fx["Y"][j] for j in range(3)])
+    m = mogptk_amd.SM_LMC(ds, Q=int(fx["Q"]), Rq=int(fx["Rq"]))
+    params = list(m.gpr.parameters())
+    ctor = fixture_params(fx, "ctor_")
+    assert [p._name for p in params] == [str(n) for n in fx["ctor_names"]]
+    assert [bool(p.train) for p in params] == [bool(b) for b in fx["ctor_train"]]
+    assert m.num_parameters() == int(fx["num_parameters"])
+    for p, f in zip(params, ctor):
+        for mine, ref in ((p.lower, f["lower"]), (p.upper, f["upper"])):
+            assert (mine is None) == (ref is None), p._name
+            if ref is not None:
+                assert np.allclose(np.broadcast_to(mine, np.shape(ref)), ref, rtol=1e-12), p._name
+        if p._name.endswith("magnitude") or p._name.endswith("mean"):          # not random: pegged to 1 / collapsed by quirk Q2
+            assert np.allclose(p(), f["cons"], rtol=1e-12), p._name
+    fp = fixture_params(fx)
+    load_raw(params, fp)
+    assert abs(m.log_marginal_likelihood() - float(fx["lml"])) < 1e-9 * abs(float(fx["lml"]))
+    assert abs(float(m.gpr.loss()) - float(fx["loss"])) < 1e-9 * abs(float(fx["loss"]))
+    for p, f in zip(params, fp):
+        if f["grad"] is None:
+            assert p.grad is None, p._name
+        else:
+            assert np.max(np.abs(p.grad - f["grad"])) <= 1e-8 * max(1.0, np.max(np.abs(f["grad"]))), p._name
+    losses, _ = m.train("Adam", iters=10, lr=0.05)
+    assert relerr(losses, fx["adam_losses"]) < 1e-8
 
 
 def test_unsupported_paths_fail_loudly():
