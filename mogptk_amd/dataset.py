@@ -86,6 +86,57 @@ class Data:
             raise ValueError("X must have %d input dimensions" % self.get_input_dims())
         return X, None
 
+    def _get_psd_peaks(self, w, psd):
+        """peaks of a spectrum as (amplitude, position, variance), biggest first -- reference data.py:946-961: scipy's find_peaks,
+        half-maximum widths turned into Gaussian variances (FWHM^2 / 8 ln 2), amplitude = sqrt(peak height)"""
+        from scipy import signal
+        peaks, _ = signal.find_peaks(psd)
+        if len(peaks) == 0:
+            return np.array([]), np.array([]), np.array([])
+        peaks = peaks[np.argsort(psd[peaks])[::-1]]
+        peaks = peaks[0.0 < psd[peaks]]
+        widths, _, _, _ = signal.peak_widths(psd, peaks, rel_height=0.5)
+        widths = widths * (w[1] - w[0])
+        return np.sqrt(psd[peaks]), w[peaks], widths ** 2 / (8.0 * np.log(2.0))
+
+    def get_ls_estimation(self, Q=1, n=10000):
+        """Q biggest peaks of the Lomb-Scargle periodogram per input dimension: (amplitudes, means, variances), each (Q, input_dims)
+        -- reference data.py:963-1002, including its re-use of `n` for the number of peaks found (which shortens the frequency grid
+        of the following input dimensions)"""
+        from scipy import signal
+        input_dims = self.get_input_dims()
+        A, B, C = np.zeros((Q, input_dims)), np.zeros((Q, input_dims)), np.zeros((Q, input_dims))
+        nyquist = self.get_nyquist_estimation()
+        x, y = self.get_train_data(transformed=True)
+        for i in range(input_dims):
+            w = np.linspace(0.0, nyquist[i], n)[1:]
+            psd = signal.lombscargle(x[:, i] * 2.0 * np.pi, y, w)
+            psd /= x.shape[0] / 4.0
+            amplitudes, positions, variances = self._get_psd_peaks(w, psd)
+            if len(positions) == 0:
+                continue
+            if Q < len(amplitudes):
+                amplitudes, positions, variances = amplitudes[:Q], positions[:Q], variances[:Q]
+            n = len(amplitudes)
+            A[:n, i] = amplitudes
+            B[:n, i] = positions
+            C[:n, i] = variances
+        return A, B, C
+
+    def get_sm_estimation(self, Q=1, method="LS", optimizer="Adam", iters=200, params={}):
+        """fit a single-output spectral mixture to this channel on the device and return its (magnitude, mean, variance) --
+        reference data.py:1053-1087"""
+        from .wrappers import SM
+        input_dims = self.get_input_dims()
+        sm = SM(self, Q)
+        sm.init_parameters(method)
+        sm.train(method=optimizer, iters=iters, **params)
+        A = sm.gpr.kernel[0].magnitude.numpy().reshape(-1, 1).repeat(input_dims, axis=1)
+        return A, sm.gpr.kernel[0].mean.numpy(), sm.gpr.kernel[0].variance.numpy()
+
+    def get_bnse_estimation(self, Q=1, n=1000, iters=200):
+        raise NotImplementedError("BNSE (reference init.py) is not built yet (SURVEY.md 8f-3); use method='LS' or 'SM'")
+
     def get_nyquist_estimation(self):
         """0.5 / (minimum distance between points) per input dimension -- reference data.py:924-944"""
         input_dims = self.get_input_dims()
@@ -174,6 +225,19 @@ class DataSet:
         X = self._format_X(X)
         for j, c in enumerate(self.channels):
             c.X_pred = X[j]
+
+    def get_ls_estimation(self, Q=1, n=10000):
+        """per channel -- reference dataset.py:579-603"""
+        out = [channel.get_ls_estimation(Q, n) for channel in self.channels]
+        return [o[0] for o in out], [o[1] for o in out], [o[2] for o in out]
+
+    def get_sm_estimation(self, Q=1, method="LS", optimizer="Adam", iters=200, params={}):
+        """per channel -- reference dataset.py:634-660"""
+        out = [channel.get_sm_estimation(Q, method, optimizer, iters, params) for channel in self.channels]
+        return [o[0] for o in out], [o[1] for o in out], [o[2] for o in out]
+
+    def get_bnse_estimation(self, Q=1, n=1000, iters=200):
+        raise NotImplementedError("BNSE (reference init.py) is not built yet (SURVEY.md 8f-3); use method='LS' or 'SM'")
 
     def get_nyquist_estimation(self):
         return [c.get_nyquist_estimation() for c in self.channels]

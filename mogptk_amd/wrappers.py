@@ -4,7 +4,7 @@ Model wrappers MOSM / SM / CSM / SM_LMC -- host-side mirror of mogptk/models/{mo
 Constructor semantics are part of the drop-in boundary and are reproduced including quirk Q2
 (SURVEY.md 8b): the Nyquist re-bounding `mean.assign(upper=...)` at mosm.py:60 / sm.py:60 / csm.py:64
 re-interprets the raw values as constrained ones and collapses every `mean` to its lower bound until the
-user assigns values (or calls init_parameters, which is outside the hot path: SURVEY.md 8f-3).
+user assigns values or calls init_parameters ('LS', 'SM' and 'IPS' are built, BNSE is not).
 """
 import numpy as np
 
@@ -17,6 +17,34 @@ from .gpr import (MultiOutputSpectralMixtureKernel, IndependentMultiOutputKernel
 def _rand(*shape):
     # the reference draws torch.rand (mosm.py:53-55); numpy's global stream plays that role here
     return np.random.rand(*shape)
+
+
+def _estimate(model, method, iters, what):
+    """shared front of init_parameters (reference mosm.py:80-91, csm.py:80-91, sm_lmc.py:94-105)"""
+    if method.lower() not in ("bnse", "ls", "sm"):
+        raise ValueError("valid methods of estimation are BNSE, LS, and SM")
+    if method.lower() == "bnse":
+        amplitudes, means, variances = model.dataset.get_bnse_estimation(model.Q, iters=iters)
+    elif method.lower() == "ls":
+        amplitudes, means, variances = model.dataset.get_ls_estimation(model.Q)
+    else:
+        amplitudes, means, variances = model.dataset.get_sm_estimation(model.Q, iters=iters)
+    if len(amplitudes) == 0:
+        logger.warning("{} could not find peaks for {}".format(method, what))
+        return None
+    return amplitudes, means, variances
+
+
+def _init_noise(model):
+    """the noise scale from the spread of every channel (reference mosm.py:106-113 and its siblings)"""
+    from .gpr import GaussianLikelihood
+    if isinstance(model.gpr.likelihood, GaussianLikelihood):
+        _, Y = model.dataset.get_train_data(transformed=True)
+        Y_std = [Y[j].std() for j in range(model.dataset.get_output_dims())]
+        if np.ndim(model.gpr.likelihood.scale()) == 0:
+            model.gpr.likelihood.scale.assign(np.mean(Y_std))
+        else:
+            model.gpr.likelihood.scale.assign(Y_std)
 
 
 class MOSM(Model):
@@ -42,9 +70,27 @@ class MOSM(Model):
         self.gpr.kernel.mean.assign(upper=np.maximum(self.gpr.kernel.mean.lower, nyquist))
 
     def init_parameters(self, method="BNSE", iters=500):
-        raise NotImplementedError("init_parameters (BNSE / Lomb-Scargle / SM estimation, reference mosm.py:62-113) "
-                                  "is a caller of the hot path and not built yet (SURVEY.md 8f-3); "
-                                  "assign hyper-parameters with model.gpr.kernel.<param>.assign(...)")
+        """Estimate kernel parameters from the data (reference models/mosm.py:62-113): spectrum peaks per channel by BNSE (not built
+        yet), Lomb-Scargle ('LS') or a fitted single-output spectral mixture ('SM', trained on the device); the noise scale from
+        the spread of every channel."""
+        input_dims = self.dataset.get_input_dims()
+        output_dims = self.dataset.get_output_dims()
+        est = _estimate(self, method, iters, "MOSM")
+        if est is None:
+            return
+        amplitudes, means, variances = est
+        weight = np.zeros((output_dims, self.Q))
+        mean = np.zeros((output_dims, self.Q, input_dims[0]))
+        variance = np.zeros((output_dims, self.Q, input_dims[0]))
+        for q in range(self.Q):
+            for j in range(output_dims):
+                weight[j, q] = 10.0 * amplitudes[j][q, :].mean()
+                mean[j, q, :] = means[j][q, :]
+                variance[j, q, :] = variances[j][q, :]
+        self.gpr.kernel.weight.assign(weight)
+        self.gpr.kernel.mean.assign(mean)
+        self.gpr.kernel.variance.assign(variance)
+        _init_noise(self)
 
 
 class SM(Model):
@@ -71,7 +117,36 @@ class SM(Model):
             self.gpr.kernel[j].mean.assign(upper=np.maximum(self.gpr.kernel[j].mean.lower, nyquist[j, :, :]))
 
     def init_parameters(self, method="LS", iters=500):
-        raise NotImplementedError("init_parameters is not built yet (SURVEY.md 8f-3)")
+        """reference models/sm.py:62-121: 'IPS' (independent parameter sampling), 'LS' (Lomb-Scargle peaks) or 'BNSE' (not built yet)"""
+        input_dims = self.dataset.get_input_dims()
+        output_dims = self.dataset.get_output_dims()
+        if method.lower() not in ("ips", "ls", "bnse"):
+            raise ValueError("valid methods of estimation are IPS, LS, and BNSE")
+        if method.lower() == "ips":
+            for j in range(output_dims):
+                nyquist = self.dataset[j].get_nyquist_estimation()
+                x = self.dataset[j].X[self.dataset[j].mask, :]
+                y = self.dataset[j].Y_transformer.forward(self.dataset[j].Y[self.dataset[j].mask], x)
+                x_range = np.max(x, axis=0) - np.min(x, axis=0)
+                self.gpr.kernel[j].magnitude.assign([2.0 * y.std() / self.Q] * self.Q)
+                self.gpr.kernel[j].mean.assign(nyquist * _rand(self.Q, input_dims[j]))
+                self.gpr.kernel[j].variance.assign(1.0 / (np.abs(np.random.randn(self.Q, input_dims[j])) * x_range))
+            return
+        elif method.lower() == "ls":
+            amplitudes, means, variances = self.dataset.get_ls_estimation(self.Q)
+            if len(amplitudes) == 0:
+                logger.warning("LS could not find peaks for SM")
+                return
+        else:
+            amplitudes, means, variances = self.dataset.get_bnse_estimation(self.Q, iters=iters)
+            if np.sum(amplitudes) == 0.0:
+                logger.warning("BNSE could not find peaks for SM")
+                return
+        for j in range(output_dims):
+            self.gpr.kernel[j].magnitude.assign(amplitudes[j].mean(axis=1) ** 2)
+            self.gpr.kernel[j].mean.assign(means[j])
+            self.gpr.kernel[j].variance.assign(variances[j])
+        _init_noise(self)
 
 
 class CSM(Model):
@@ -101,7 +176,22 @@ class CSM(Model):
             self.gpr.kernel[q].mean.assign(upper=np.maximum(self.gpr.kernel[q].mean.lower, nyquist))
 
     def init_parameters(self, method="BNSE", iters=500):
-        raise NotImplementedError("init_parameters is not built yet (SURVEY.md 8f-3)")
+        """reference models/csm.py:66-111"""
+        est = _estimate(self, method, iters, "MOSM")           # (sic: the reference's message says MOSM here too, csm.py:90)
+        if est is None:
+            return
+        amplitudes, means, variances = est
+        output_dims = self.dataset.get_output_dims()
+        means = np.concatenate(means, axis=0)
+        variances = np.concatenate(variances, axis=0)
+        constant = np.empty((output_dims, self.Q, self.Rq), dtype=np.float32)   # the reference fills a float32 torch.rand tensor (csm.py:96)
+        for q in range(self.Q):
+            for j in range(len(self.dataset)):
+                constant[j, q, :] = amplitudes[j][q, :].mean() ** 2 / self.Rq
+            self.gpr.kernel[q].amplitude.assign(constant[:, q, :])
+            self.gpr.kernel[q].mean.assign(means[q, :])
+            self.gpr.kernel[q].variance.assign(variances[q, :])
+        _init_noise(self)
 
 
 class SM_LMC(Model):
@@ -135,4 +225,19 @@ class SM_LMC(Model):
             self.gpr.kernel[q].mean.assign(upper=np.maximum(self.gpr.kernel[q].mean.lower, nyquist))
 
     def init_parameters(self, method="BNSE", iters=500):
-        raise NotImplementedError("init_parameters is not built yet (SURVEY.md 8f-3)")
+        """reference models/sm_lmc.py:69-121"""
+        est = _estimate(self, method, iters, "SM-LMC")
+        if est is None:
+            return
+        amplitudes, means, variances = est
+        output_dims = self.dataset.get_output_dims()
+        means = np.concatenate(means, axis=0)
+        variances = np.concatenate(variances, axis=0)
+        constant = np.empty((output_dims, self.Q, self.Rq), dtype=np.float32)   # float32 in the reference too (sm_lmc.py:110)
+        for q in range(self.Q):
+            for j in range(len(self.dataset)):
+                constant[j, q, :] = amplitudes[j][q, :].mean() / self.Rq
+            self.gpr.kernel[q].mean.assign(means[q, :])
+            self.gpr.kernel[q].variance.assign(variances[q, :])
+        self.gpr.kernel.weight.assign(constant)
+        _init_noise(self)

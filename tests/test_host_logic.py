@@ -241,6 +241,37 @@ def test_sm_lmc_wrapper_matches_reference():
     assert relerr(losses, fx["adam_losses"]) < 1e-8
 
 
+def test_init_parameters_ls_matches_reference():
+    """Lomb-Scargle peak estimates (data.py:946-1002) and init_parameters('LS') of the four wrappers against the reference"""
+    fx = load("init_ls.npz")
+    chans = [(fx["x%d" % j], fx["y%d" % j]) for j in range(int(fx["nchan"]))]
+    ds = mogptk_amd.DataSet(*[mogptk_amd.Data(x, y) for x, y in chans])
+    assert np.allclose(np.stack(ds.get_nyquist_estimation()), fx["nyquist"], rtol=1e-13)
+    A, B, C = ds.get_ls_estimation(Q=3)
+    assert relerr(np.stack(A), fx["ls_A"]) < 1e-10 and relerr(np.stack(B), fx["ls_B"]) < 1e-12 and relerr(np.stack(C), fx["ls_C"]) < 1e-9
+    for tag, make in (("mosm", lambda: mogptk_amd.MOSM(ds, Q=2)), ("sm", lambda: mogptk_amd.SM(ds, Q=3)),
+                      ("csm", lambda: mogptk_amd.CSM(ds, Q=2, Rq=2)), ("smlmc", lambda: mogptk_amd.SM_LMC(ds, Q=2, Rq=2))):
+        m = make()
+        m.init_parameters("LS")
+        fp = fixture_params(fx, tag + "_")
+        for p, f in zip(m.gpr.parameters(), fp):
+            random_in_reference = tag in ("mosm",) and (p._name.endswith("delay") or p._name.endswith("phase"))
+            random_in_reference |= tag == "csm" and p._name.endswith("shift")
+            if random_in_reference:
+                continue                                    # drawn from torch.rand by the constructor, untouched by init_parameters
+            assert np.allclose(p(), f["cons"], rtol=1e-8, atol=1e-12), (tag, p._name, p(), f["cons"])
+        if tag in ("sm", "smlmc"):                          # nothing random left: the whole model state is reproduced
+            assert abs(m.log_marginal_likelihood() - float(fx[tag + "_lml"])) < 1e-7 * abs(float(fx[tag + "_lml"]))
+    with pytest.raises(ValueError):
+        mogptk_amd.MOSM(ds, Q=2).init_parameters("nope")
+    with pytest.raises(NotImplementedError):
+        mogptk_amd.MOSM(ds, Q=2).init_parameters("BNSE")
+    # the 'SM' method: a spectral mixture fitted per channel on the device (here: its numpy twin), then handed to MOSM
+    m = mogptk_amd.MOSM(mogptk_amd.DataSet(*[mogptk_amd.Data(x[:40], y[:40]) for x, y in chans[:2]]), Q=2)
+    m.init_parameters("SM", iters=5)
+    assert np.all(np.isfinite(m.gpr.kernel.mean())) and np.isfinite(m.log_marginal_likelihood())
+
+
 def test_unsupported_paths_fail_loudly():
     with pytest.raises(NotImplementedError):
         gpr.use_single_precision()
