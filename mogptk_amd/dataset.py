@@ -135,7 +135,31 @@ class Data:
         return A, sm.gpr.kernel[0].mean.numpy(), sm.gpr.kernel[0].variance.numpy()
 
     def get_bnse_estimation(self, Q=1, n=1000, iters=200):
-        raise NotImplementedError("BNSE (reference init.py) is not built yet (SURVEY.md 8f-3); use method='LS' or 'SM'")
+        """Q biggest peaks of the BNSE spectrum per input dimension -- reference data.py:1004-1051 (the GP fit runs on the device)"""
+        from .init import BNSE
+        input_dims = self.get_input_dims()
+        A, B, C = np.zeros((Q, input_dims)), np.zeros((Q, input_dims)), np.zeros((Q, input_dims))
+        nyquist = self.get_nyquist_estimation()
+        x, y = self.get_train_data(transformed=True)
+        y_err = None
+        if self.Y_err is not None:
+            y_err_lower = self.Y_transformer.forward(y - self.Y_err[self.mask], x)
+            y_err_upper = self.Y_transformer.forward(y + self.Y_err[self.mask], x)
+            y_err = (y_err_upper - y_err_lower) / 2.0
+        for i in range(input_dims):
+            w, psd, _ = BNSE(x[:, i], y, y_err=y_err, max_freq=nyquist[i], n=n, iters=iters)
+            psd /= (np.max(x[:, i]) - np.min(x[:, i])) ** 2
+            psd *= np.pi
+            amplitudes, positions, variances = self._get_psd_peaks(w, psd)
+            if len(positions) == 0:
+                continue
+            if Q < len(amplitudes):
+                amplitudes, positions, variances = amplitudes[:Q], positions[:Q], variances[:Q]
+            num = len(amplitudes)
+            A[:num, i] = amplitudes
+            B[:num, i] = positions
+            C[:num, i] = variances
+        return A, B, C
 
     def get_nyquist_estimation(self):
         """0.5 / (minimum distance between points) per input dimension -- reference data.py:924-944"""
@@ -231,13 +255,15 @@ class DataSet:
         out = [channel.get_ls_estimation(Q, n) for channel in self.channels]
         return [o[0] for o in out], [o[1] for o in out], [o[2] for o in out]
 
-    def get_sm_estimation(self, Q=1, method="LS", optimizer="Adam", iters=200, params={}):
-        """per channel -- reference dataset.py:634-660"""
+    def get_sm_estimation(self, Q=1, method="BNSE", optimizer="Adam", iters=200, params={}):
+        """per channel -- reference dataset.py:632-660 (its default initialisation of the fitted mixtures is BNSE)"""
         out = [channel.get_sm_estimation(Q, method, optimizer, iters, params) for channel in self.channels]
         return [o[0] for o in out], [o[1] for o in out], [o[2] for o in out]
 
     def get_bnse_estimation(self, Q=1, n=1000, iters=200):
-        raise NotImplementedError("BNSE (reference init.py) is not built yet (SURVEY.md 8f-3); use method='LS' or 'SM'")
+        """per channel -- reference dataset.py:605-632"""
+        out = [channel.get_bnse_estimation(Q, n, iters) for channel in self.channels]
+        return [o[0] for o in out], [o[1] for o in out], [o[2] for o in out]
 
     def get_nyquist_estimation(self):
         return [c.get_nyquist_estimation() for c in self.channels]

@@ -4,7 +4,7 @@ Model wrappers MOSM / SM / CSM / SM_LMC -- host-side mirror of mogptk/models/{mo
 Constructor semantics are part of the drop-in boundary and are reproduced including quirk Q2
 (SURVEY.md 8b): the Nyquist re-bounding `mean.assign(upper=...)` at mosm.py:60 / sm.py:60 / csm.py:64
 re-interprets the raw values as constrained ones and collapses every `mean` to its lower bound until the
-user assigns values or calls init_parameters ('LS', 'SM' and 'IPS' are built, BNSE is not).
+user assigns values or calls init_parameters ('BNSE', 'LS', 'SM' and 'IPS').
 """
 import numpy as np
 
@@ -70,8 +70,8 @@ class MOSM(Model):
         self.gpr.kernel.mean.assign(upper=np.maximum(self.gpr.kernel.mean.lower, nyquist))
 
     def init_parameters(self, method="BNSE", iters=500):
-        """Estimate kernel parameters from the data (reference models/mosm.py:62-113): spectrum peaks per channel by BNSE (not built
-        yet), Lomb-Scargle ('LS') or a fitted single-output spectral mixture ('SM', trained on the device); the noise scale from
+        """Estimate kernel parameters from the data (reference models/mosm.py:62-113): spectrum peaks per channel by BNSE,
+        Lomb-Scargle ('LS') or a fitted single-output spectral mixture ('SM', trained on the device); the noise scale from
         the spread of every channel."""
         input_dims = self.dataset.get_input_dims()
         output_dims = self.dataset.get_output_dims()
@@ -117,7 +117,7 @@ class SM(Model):
             self.gpr.kernel[j].mean.assign(upper=np.maximum(self.gpr.kernel[j].mean.lower, nyquist[j, :, :]))
 
     def init_parameters(self, method="LS", iters=500):
-        """reference models/sm.py:62-121: 'IPS' (independent parameter sampling), 'LS' (Lomb-Scargle peaks) or 'BNSE' (not built yet)"""
+        """reference models/sm.py:62-121: 'IPS' (independent parameter sampling), 'LS' (Lomb-Scargle peaks) or 'BNSE'"""
         input_dims = self.dataset.get_input_dims()
         output_dims = self.dataset.get_output_dims()
         if method.lower() not in ("ips", "ls", "bnse"):

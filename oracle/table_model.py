@@ -75,6 +75,7 @@ class TableDevice:
         z = solve_triangular(L, self.y, lower=True)
         alpha = solve_triangular(L.T, z, lower=False)
         lml = -0.5 * self.N * np.log(TWO_PI) - np.sum(np.log(np.diagonal(L))) - 0.5 * (self.y.T @ alpha).item()
+        self._last = (K, alpha)
         if not grad:
             return dict(lml=lml, moments=None, diagG=None, trG=0.0, jitter_abs=jit)
         Li = solve_triangular(L, np.eye(self.N), lower=True)
@@ -99,6 +100,18 @@ class TableDevice:
         dG = np.diagonal(G)
         diagG = np.array([np.sum(dG[c == k]) for k in range(C)])
         return dict(lml=lml, moments=mom, diagG=diagG, trG=float(np.sum(dG)), jitter_abs=jit)
+
+    def fetch(self, which):
+        """what mogp_model_fetch returns after the last evaluation: 0 = W = L^-1 in channel-sorted row order, 1 = Kj^-1, 2 = alpha"""
+        from scipy.linalg import solve_triangular
+        K, alpha = self._last
+        if which == 2:
+            return alpha.reshape(-1).copy()
+        if which == 1:
+            return np.linalg.inv(K)
+        order = np.argsort(self.X[:, 0], kind="stable")
+        L = np.linalg.cholesky(K[np.ix_(order, order)])
+        return solve_triangular(L, np.eye(self.N), lower=True)
 
     def predict(self, noise_var, jitter, kss_diag, Xs, full=False, data_var=None):
         from scipy.linalg import solve_triangular

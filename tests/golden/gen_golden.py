@@ -11,6 +11,7 @@ nothing of the reference travels.  Re-run:  python tests/golden/gen_golden.py [-
   kernels_8f2.npz / lml_mosk_* / lml_umosm_*  MultiOutputSpectralKernel and UncoupledMultiOutputSpectralKernel
   sm_lmc.npz     the SM_LMC wrapper: constructor state, loss + gradient, a short Adam trace
   init_ls.npz    Lomb-Scargle peak estimates and init_parameters('LS') of MOSM / SM / CSM / SM_LMC
+  bnse.npz       BNSE spectra (init.py), BNSE peak estimates and MOSM.init_parameters('BNSE')
   lbfgs_cfg1.npz the same model under train('LBFGS'): fixed-step and strong-Wolfe loss traces by function evaluation
   cfg2.npz      [--full] MOSM C=4 Q=3 N=8192 LML + gradient (BASELINE.json configs[1]; ~20 s, 10 GB)
   cfg4.npz      [--full] CSM C=4 Q=3 N=16384 predict_f at 64 probe rows of S=4096 (configs[3]; ~40 s, 16 GB)
@@ -420,6 +421,31 @@ def gen_init_ls():
     print("init_ls.npz written; mosm lml %.8f" % out["mosm_lml"])
 
 
+def gen_bnse():
+    """BNSE (init.py): the spectrum of a two-tone signal after a 60-step GP fit, with and without observation errors; the peak
+    estimates of a 2-channel data set and MOSM.init_parameters('BNSE') on it"""
+    rng = np.random.default_rng(21)
+    x = np.sort(rng.uniform(0.0, 40.0, 110))
+    y = np.sin(2 * np.pi * 0.15 * x) + 0.6 * np.cos(2 * np.pi * 0.37 * x) + 0.05 * rng.standard_normal(x.size)
+    out = {"x": x.copy(), "y": y.copy()}
+    w, mu, var = mogptk.BNSE(x.copy(), y, n=150, iters=60, jit=False)
+    out["w"] = w; out["mu"] = mu; out["var"] = var
+    yerr = rng.uniform(0.02, 0.1, x.size)
+    w2, mu2, var2 = mogptk.BNSE(x.copy(), y, y_err=yerr, max_freq=0.9, n=120, iters=40, jit=False)
+    out["yerr"] = yerr; out["w2"] = w2; out["mu2"] = mu2; out["var2"] = var2
+    x1 = np.sort(rng.uniform(0.0, 50.0, 90))
+    y1 = 1.5 * np.sin(2 * np.pi * 0.09 * x1 + 0.4) + 0.05 * rng.standard_normal(x1.size)
+    ds = mogptk.DataSet(mogptk.Data(x, y), mogptk.Data(x1, y1))
+    A, B, C = ds.get_bnse_estimation(Q=2, n=400, iters=50)
+    out["x1"] = x1; out["y1"] = y1; out["est_A"] = np.stack(A); out["est_B"] = np.stack(B); out["est_C"] = np.stack(C)
+    torch.manual_seed(2)
+    m = mogptk.MOSM(ds, Q=2)
+    m.init_parameters("BNSE", iters=50)
+    dump_params("mosm_", list(m.gpr.parameters()), out)
+    np.savez_compressed(os.path.join(HERE, "bnse.npz"), **out)
+    print("bnse.npz written; PSD peak at %.4f" % w[np.argmax(mu)])
+
+
 def gen_cfg2():
     import time
     C, Q, N = 4, 3, 8192
@@ -511,7 +537,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "lbfgs": gen_lbfgs_cfg1, "quirks": gen_quirks,
-             "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2, "smlmc": gen_smlmc, "init_ls": gen_init_ls,
+             "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2, "smlmc": gen_smlmc, "init_ls": gen_init_ls, "bnse": gen_bnse,
              "titsias": gen_titsias}
     full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:

@@ -212,6 +212,16 @@ def test_train_lbfgs_on_device_matches_reference_trace():
     assert relerr(model.losses, ref) < 1e-3
 
 
+def test_bnse_on_device_matches_reference():
+    """BNSE end to end on the device: 60 Adam steps of an Exact + SpectralKernel fit, then W = L^-1 and alpha fetched
+    from the library for the spectrum posterior; against the reference's spectra"""
+    fx = load("bnse.npz")
+    w, mu, var = mogptk_amd.BNSE(fx["x"].copy(), fx["y"], n=150, iters=60)
+    assert relerr(mu, fx["mu"]) < 1e-5 and relerr(var, fx["var"]) < 1e-5
+    w2, mu2, var2 = mogptk_amd.BNSE(fx["x"].copy(), fx["y"], y_err=fx["yerr"], max_freq=0.9, n=120, iters=40)
+    assert relerr(mu2, fx["mu2"]) < 1e-5 and relerr(var2, fx["var2"]) < 1e-5
+
+
 def test_cfg4_predict_golden():
     """BASELINE.json configs[3]: CSM C=4 Q=3 N=16384, predictive mean/variance at S=4096 (64 probe rows stored)."""
     fx = load("cfg4.npz")
