@@ -124,6 +124,7 @@ int launch_potrf_tile(double* A, int64_t ld, int t, double* logdet, unsigned lon
 int launch_trtri_tiles(const double* A, int64_t ld, int t0, int nt, double* invd, hipStream_t s);
 // copy the batch of inverted diagonal tiles into the diagonal tiles of A
 int launch_put_diag_tiles(double* A, int64_t ld, int nt, const double* invd, hipStream_t s);
+int launch_wkk(const double* Ablk, int64_t ld, const double* invd, int nk, double* Wk, int64_t ldw, hipStream_t s);
 // rows >= N of the padded matrix: identity (lower part)
 int launch_pad_identity(double* A, int64_t ld, int64_t N, int64_t Npad, hipStream_t s);
 // z = W y (W lower triangular), and partial[blk] = sum z^2 over the block's rows

@@ -60,6 +60,7 @@ struct TrtriLevel {
 };
 
 // dense SPD workspace: A (Npad x Npad, lower) -> L -> W = L^-1 in place; B = scratch, then W^T W
+#define MOGP_NPANEL 4       // the factorisation may run this many outer blocks ahead of the inverse stream
 struct Spd {
     int64_t Npad = 0;
     int nb = 0;
@@ -68,12 +69,13 @@ struct Spd {
     std::vector<TrtriLevel> levels;
     std::vector<hipEvent_t> sync_ev;    // cross-stream dependencies of the look-ahead schedule
     std::vector<hipEvent_t> inv_ev;     // events of the fused schedule (potri.hip)
-    DevBuf<double> Pb[3];               // rotating panel buffers L[>K, K] of the fused schedule (Npad x 512 each)
+    DevBuf<double> Wd;                  // W_KK = L_KK^-1 of every outer block of the fused schedule (512 x 512 each, wkk.hip)
+    DevBuf<double> Pb[MOGP_NPANEL];     // rotating panel buffers L[>K, K] of the fused schedule (Npad x 512 each)
     void release() {
         for (auto& lv : levels) { lv.d1.release(); lv.d2.release(); }
         for (auto e : sync_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
         for (auto e : inv_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
-        inv_ev.clear(); Wm.release(); for (auto& b : Pb) b.release();
+        inv_ev.clear(); Wm.release(); Wd.release(); for (auto& b : Pb) b.release();
         levels.clear(); sync_ev.clear();
         A.release(); B.release(); invd.release(); logdet.release();
     }

@@ -8,6 +8,7 @@
 //   priv  (CU mask = the reserved CUs only)   the whole critical path, in ONE stream:
 //            intra-block chain on the 512 x 512 diagonal block D_KK:
 //              4 x [ leaf (factor + inverse of a 128 tile) -> panel inside the block -> update inside the block ], then W_KK = L_KK^-1
+//              in one launch (wkk.hip: 32 workgroups, each a 16-column strip of one column block; out of place)
 //            mini-panel            P[K+1 rows] = A[K+1 rows, K] W_KK^T       (the next block's rows only)
 //            next-diagonal update  D_{K+1,K+1} -= P[K+1] P[K+1]^T            -> the chain of block K+1 follows in the same stream
 //            Every launch is <= 64 small workgroups; alone on their CUs they run at their unloaded latency.
@@ -18,9 +19,9 @@
 //            W[K, <K]   = W_KK Wt[K, <K]                            finalise the row block (Wt = running product, in w.Wm)
 //            Wt[>K, K]  = -P W_KK ;  Wt[>K, <K] -= P W[K, <K]       rank-512 update of all rows below
 //            Kinv[<=K, <=K] += W[K, <=K]^T W[K, <=K]                rank-512 update of the inverse (w.B)
-// The panel P = L[>K, K] is consumed only by block K's own updates, so it lives in three rotating Npad x 512 buffers, not in w.A.
+// The panel P = L[>K, K] is consumed only by block K's own updates, so it lives in MOGP_NPANEL rotating Npad x 512 buffers, not in w.A.
 // Critical path per block = intra-block chain + mini-panel + next-diagonal update; everything of N-proportional size is off it.  On return: w.Wm = W = L^-1 (lower), w.B = (L L^T)^-1 (lower tiles, full diagonal tiles),
-// w.logdet / w.invd / the pivot check as in spd_potrf; w.A is consumed.
+// w.logdet / w.invd / the pivot check as in spd_potrf; w.A is consumed (Schur data; its diagonal blocks keep L_KK).
 #include "mogp_model.h"
 
 #include <algorithm>
@@ -43,29 +44,8 @@ namespace {
 
 enum { EV_BLK = 0, EV_DIAG = 1, EV_PANEL = 2, EV_BULK = 3, EV_INV = 4, EV_REST = 5, EV_PER_BLOCK = 6 };
 
-// W[R, c0:r0] = -Wrr * (L[R, c0:r0] * W[c0:r0, c0:r0]) for the tile rows R = [r0, r0 + nr), in place in w.A (the product in
-// brackets goes through the same positions of w.B).  Used inside a diagonal block only, where everything is a handful of tiles.
-int w_rowblock(mogp_model* m, Spd& w, int r0, int nr, int c0, const double* Wrr, int64_t ldr, hipStream_t q) {
-    const int n = r0 - c0;
-    if (n <= 0) return 0;
-    const int64_t ld = w.Npad;
-    const int64_t off = (int64_t)r0 * MOGP_TILE * ld + (int64_t)c0 * MOGP_TILE;
-    GemmArgs g{};
-    g.A = w.A.p + off; g.lda = ld; g.a_kmajor = 0;
-    g.B = w.A.p + (int64_t)c0 * MOGP_TILE * (ld + 1); g.ldb = ld; g.b_kmajor = 1;
-    g.C = w.B.p + off; g.ldc = ld; g.alpha = 1.0; g.beta = 0.0;
-    g.mode = GM_KLO_J; g.small = 1; g.mt = 2 * nr; g.nt = n; g.K = n * MOGP_TILE;
-    RC(gemm_call(m, g, gemm_flops(g, nullptr), q));
-    GemmArgs h{};
-    h.A = Wrr; h.lda = ldr; h.a_kmajor = 0;
-    h.B = w.B.p + off; h.ldb = ld; h.b_kmajor = 1;
-    h.C = w.A.p + off; h.ldc = ld; h.alpha = -1.0; h.beta = 0.0;
-    h.mode = GM_KHI_I; h.small = 1; h.mt = 2 * nr; h.nt = n; h.K = nr * MOGP_TILE;
-    return gemm_call(m, h, gemm_flops(h, nullptr), q);
-}
-
-// factor the diagonal block [k0, k1) of w.A in place and replace it by W_KK = L_KK^-1 (lower; zeros above)
-int intra_block_chain(mogp_model* m, Spd& w, int k0, int k1, hipStream_t q) {
+// factor the diagonal block [k0, k1) of w.A in place (L_KK) and put W_KK = L_KK^-1 (lower; zeros above) into Wk (leading dimension FZ_KD)
+int intra_block_chain(mogp_model* m, Spd& w, double* Wk, int k0, int k1, hipStream_t q) {
     const int64_t ld = w.Npad;
     for (int k = k0; k < k1; ++k) {
         RC(launch_potrf_trtri_tile(w.A.p, ld, k, w.invd.p, w.logdet.p, m->d_info.p, q, 0));
@@ -84,45 +64,41 @@ int intra_block_chain(mogp_model* m, Spd& w, int k0, int k1, hipStream_t q) {
         u.mode = GM_RECT_LOWER; u.small = 2; u.mt = 2 * ri; u.nt = 2 * ri; u.K = MOGP_TILE;
         RC(gemm_call(m, u, gemm_flops(u, nullptr), q));
     }
-    const int nk = k1 - k0;
-    RC(launch_put_diag_tiles(w.A.p + (int64_t)k0 * MOGP_TILE * (ld + 1), ld, nk, w.invd.p + (int64_t)k0 * MOGP_TILE * MOGP_TILE, q));
-    for (int t = 1; t < nk; ++t)
-        RC(w_rowblock(m, w, k0 + t, 1, k0, w.invd.p + (int64_t)(k0 + t) * MOGP_TILE * MOGP_TILE, MOGP_TILE, q));
-    return 0;
+    // W_KK = L_KK^-1 in one launch, out of place (wkk.hip)
+    return launch_wkk(w.A.p + (int64_t)k0 * MOGP_TILE * (ld + 1), ld, w.invd.p + (int64_t)k0 * MOGP_TILE * MOGP_TILE, k1 - k0, Wk, FZ_KD, q);
 }
 
 // P[rows r0 .. r0+nr) = A[rows, K] * W_KK^T  (rows in tiles; P has leading dimension FZ_KD and is indexed by the global row)
-int panel_rows(mogp_model* m, Spd& w, double* P, int k0, int nk, int r0, int nr, bool small, hipStream_t q) {
+int panel_rows(mogp_model* m, Spd& w, double* P, const double* Wk, int k0, int nk, int r0, int nr, bool small, hipStream_t q) {
     const int64_t ld = w.Npad;
     GemmArgs g{};
     g.A = w.A.p + (int64_t)r0 * MOGP_TILE * ld + (int64_t)k0 * MOGP_TILE; g.lda = ld; g.a_kmajor = 0;
-    g.B = w.A.p + (int64_t)k0 * MOGP_TILE * (ld + 1); g.ldb = ld; g.b_kmajor = 0;          // W_KK as [j][k], k <= j
+    g.B = Wk; g.ldb = FZ_KD; g.b_kmajor = 0;                                              // W_KK as [j][k], k <= j
     g.C = P + (int64_t)r0 * MOGP_TILE * FZ_KD; g.ldc = FZ_KD; g.alpha = 1.0; g.beta = 0.0;
     g.mode = GM_KHI_J; g.small = small ? 1 : 0; g.mt = small ? 2 * nr : nr; g.nt = nk; g.K = nk * MOGP_TILE;
     return gemm_call(m, g, gemm_flops(g, nullptr), q);
 }
 
 // the inverse stream's share of block K (see the header); Lp = P[k1 tile row], leading dimension FZ_KD
-int inverse_step(mogp_model* m, Spd& w, int k0, int k1, const double* Lp, hipStream_t q) {
+int inverse_step(mogp_model* m, Spd& w, const double* Wkk, int k0, int k1, const double* Lp, hipStream_t q) {
     const int64_t ld = w.Npad;
     const int nk = k1 - k0, rem = w.nb - k1;
     const int64_t Kd = (int64_t)nk * MOGP_TILE, c0 = (int64_t)k0 * MOGP_TILE;
-    const double* Wkk = w.A.p + c0 * (ld + 1);
     double* Wrow = w.Wm.p + c0 * ld;                 // W[K, 0]
     double* Brow = w.B.p + c0 * ld;                  // scratch now, Kinv[K, 0] afterwards
     if (k0 > 0) {                                    // finalise the row block through the scratch (not in place)
         GemmArgs g{};
-        g.A = Wkk; g.lda = ld; g.a_kmajor = 0; g.B = Wrow; g.ldb = ld; g.b_kmajor = 1;
+        g.A = Wkk; g.lda = FZ_KD; g.a_kmajor = 0; g.B = Wrow; g.ldb = ld; g.b_kmajor = 1;
         g.C = Brow; g.ldc = ld; g.alpha = 1.0; g.beta = 0.0;
         g.mode = GM_KHI_I; g.small = 1; g.mt = 2 * nk; g.nt = k0; g.K = (int)Kd;
         RC(gemm_call(m, g, gemm_flops(g, nullptr), q));
         RC(launch_copy2d(Wrow, ld, Brow, ld, Kd, c0, 1.0, q));
     }
-    RC(launch_copy2d(Wrow + c0, ld, Wkk, ld, Kd, Kd, 1.0, q));
+    RC(launch_copy2d(Wrow + c0, ld, Wkk, FZ_KD, Kd, Kd, 1.0, q));
     if (rem > 0) {
         double* Wt = w.Wm.p + (int64_t)k1 * MOGP_TILE * ld;                    // Wt[>K, 0]
         GemmArgs g{};
-        g.A = Lp; g.lda = FZ_KD; g.a_kmajor = 0; g.B = Wkk; g.ldb = ld; g.b_kmajor = 1;
+        g.A = Lp; g.lda = FZ_KD; g.a_kmajor = 0; g.B = Wkk; g.ldb = FZ_KD; g.b_kmajor = 1;
         g.C = Wt + c0; g.ldc = ld; g.alpha = -1.0; g.beta = 0.0;
         g.mode = GM_KLO_J; g.mt = rem; g.nt = nk; g.K = (int)Kd;
         RC(gemm_call(m, g, gemm_flops(g, nullptr), q));
@@ -158,6 +134,11 @@ int spd_potri_fused(mogp_model* m, Spd& w) {
         HIP_TRY(hipMemsetAsync(w.Wm.p, 0, (size_t)ld * ld * sizeof(double), crit));
     }
     for (auto& b : w.Pb) RC(b.ensure((size_t)ld * FZ_KD));
+    if (w.Wd.n < (size_t)nouter * FZ_KD * FZ_KD) {       // W_KK store: tiles above the diagonal are never written and must be zero
+        RC(w.Wd.ensure((size_t)nouter * FZ_KD * FZ_KD));
+        HIP_TRY(hipMemsetAsync(w.Wd.p, 0, (size_t)nouter * FZ_KD * FZ_KD * sizeof(double), crit));
+    }
+    auto Wk = [&](int kb) { return w.Wd.p + (int64_t)kb * FZ_KD * FZ_KD; };
     while ((int)w.inv_ev.size() < EV_PER_BLOCK * nouter + 1) {
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -174,18 +155,18 @@ int spd_potri_fused(mogp_model* m, Spd& w) {
     };
     auto chain = [&](int kb) -> int {                    // priv: factor D_KK, W_KK (its inputs are ordered by the stream itself)
         int k0, k1, nk, rem, na, k2; geom(kb, k0, k1, nk, rem, na, k2);
-        RC(intra_block_chain(m, w, k0, k1, priv));
+        RC(intra_block_chain(m, w, Wk(kb), k0, k1, priv));
         HIP_TRY(hipEventRecord(ev(kb, EV_BLK), priv));
         return 0;
     };
     auto next_diag = [&](int kb) -> int {                // priv: the next block's panel rows and the next diagonal block
         int k0, k1, nk, rem, na, k2; geom(kb, k0, k1, nk, rem, na, k2);
         if (rem <= 0) return 0;
-        double* P = w.Pb[kb % 3].p;
-        if (kb >= 3) HIP_TRY(hipStreamWaitEvent(priv, ev(kb - 3, EV_INV), 0));          // the panel buffer is free again
+        double* P = w.Pb[kb % MOGP_NPANEL].p;
+        if (kb >= MOGP_NPANEL) HIP_TRY(hipStreamWaitEvent(priv, ev(kb - MOGP_NPANEL, EV_INV), 0));   // the panel buffer is free again
         if (kb >= 1) HIP_TRY(hipStreamWaitEvent(priv, ev(kb - 1, EV_BULK), 0));         // bulk1(kb-1): columns K+1;  implies bulk1(kb-2): columns K
         if (kb >= 1) HIP_TRY(hipStreamWaitEvent(priv, ev(kb - 1, EV_PANEL), 0));        // crit(kb-1): columns K below the diagonal block
-        RC(panel_rows(m, w, P, k0, nk, k1, na, true, priv));
+        RC(panel_rows(m, w, P, Wk(kb), k0, nk, k1, na, true, priv));
         const double* Pn = P + (int64_t)k1 * MOGP_TILE * FZ_KD;
         GemmArgs u{};
         u.A = Pn; u.lda = FZ_KD; u.a_kmajor = 0; u.B = Pn; u.ldb = FZ_KD; u.b_kmajor = 0;
@@ -201,7 +182,7 @@ int spd_potri_fused(mogp_model* m, Spd& w) {
     for (int kb = 0; kb < nouter; ++kb) {
         int k0, k1, nk, rem, na, k2; geom(kb, k0, k1, nk, rem, na, k2);
         const int Kd = nk * MOGP_TILE;
-        double* P = w.Pb[kb % 3].p;
+        double* P = w.Pb[kb % MOGP_NPANEL].p;
         const double* Pn = P + (int64_t)k1 * MOGP_TILE * FZ_KD;
         const double* Pr = P + (int64_t)k2 * MOGP_TILE * FZ_KD;
         const int nr = rem - na, n1 = std::min(FZ_OB, std::max(nr, 0));
@@ -210,7 +191,7 @@ int spd_potri_fused(mogp_model* m, Spd& w) {
         // 2. crit: the rest of the panel, then the next block's columns below its diagonal block
         if (rem > 0) {
             HIP_TRY(hipStreamWaitEvent(crit, ev(kb, EV_DIAG), 0));                       // W_KK, a free buffer, the mini-panel
-            if (nr > 0) RC(panel_rows(m, w, P, k0, nk, k2, nr, false, crit));
+            if (nr > 0) RC(panel_rows(m, w, P, Wk(kb), k0, nk, k2, nr, false, crit));
             HIP_TRY(hipEventRecord(ev(kb, EV_REST), crit));
             if (nr > 0) {
                 GemmArgs u{};
@@ -245,7 +226,7 @@ int spd_potri_fused(mogp_model* m, Spd& w) {
         // 6. inv
         HIP_TRY(hipStreamWaitEvent(inv, ev(kb, EV_BLK), 0));
         if (rem > 0) HIP_TRY(hipStreamWaitEvent(inv, ev(kb, EV_REST), 0));
-        RC(inverse_step(m, w, k0, k1, P + (int64_t)k1 * MOGP_TILE * FZ_KD, inv));
+        RC(inverse_step(m, w, Wk(kb), k0, k1, P + (int64_t)k1 * MOGP_TILE * FZ_KD, inv));
         HIP_TRY(hipEventRecord(ev(kb, EV_INV), inv));
     }
     HIP_TRY(hipEventRecord(ev(nouter - 1, EV_DIAG), bulk));                              // reuse: everything on the bulk stream
