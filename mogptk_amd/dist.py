@@ -101,15 +101,29 @@ def use_single_device():
 def sharded_eval(h, comm, noise_var, jitter, data_var=None):
     """mogp_exact_eval(..., MOGP_EVAL_GRAD) sharded over comm.world ranks; same return dict on every rank.
     `h` is a device handle (mogptk_amd._lib.ExactHandle, or its numpy twin in the tests) exposing the shard_* stages."""
+    import os, time
+    prof = os.environ.get("MOGP_SHARD_PROFILE")
+    tm = dict(begin=0.0, pack=0.0, gather=0.0, unpack_block=0.0, alpha=0.0, finish=0.0)
+    t0 = time.perf_counter()
     jit, nblocks = h.shard_begin(comm.rank, comm.world, noise_var, jitter, data_var)
+    t1 = time.perf_counter(); tm["begin"] += t1 - t0
     for kb in range(nblocks):
+        t0 = time.perf_counter()
         send, recv, count = h.shard_pack(kb)
+        t1 = time.perf_counter(); tm["pack"] += t1 - t0
         comm.all_gather(h, send, recv, count)
+        t2 = time.perf_counter(); tm["gather"] += t2 - t1
         h.shard_unpack(kb)
         h.shard_block(kb)
+        tm["unpack_block"] += time.perf_counter() - t2
+    t0 = time.perf_counter()
     buf, count = h.shard_alpha()
     comm.all_reduce_buf(h, buf, count)
+    t1 = time.perf_counter(); tm["alpha"] += t1 - t0
     lml, moments, diagG = h.shard_finish()
+    tm["finish"] += time.perf_counter() - t1
+    if prof and comm.rank == 0:
+        print("sharded_eval ms:", {k: round(1e3 * v, 2) for k, v in tm.items()}, flush=True)
     comm.all_reduce_host(moments)
     comm.all_reduce_host(diagG)
     return dict(lml=lml, moments=moments, diagG=diagG, trG=float(np.sum(diagG)), jitter_abs=jit)
