@@ -181,7 +181,7 @@ def main():
     h = m._handle
     stage = np.zeros(_lib.ST_COUNT)
     acc = dict(flops=0.0, launches=0, nprof=0)
-    PROFILE_EVERY = 4           # HIP events around every GEMM launch cost ~5 %: sample one step in four, inside the timed region
+    PROFILE_EVERY = 10          # HIP events around every GEMM launch cost ~5 % of a step: sample one step in ten, inside the timed region
 
     def step(i):
         prof = i >= 0 and (i % PROFILE_EVERY) == 0
