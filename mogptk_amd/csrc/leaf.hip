@@ -11,6 +11,7 @@
 //   TRTRI  16x16 diagonal inverses (one column per lane), then block row i = 1..7 in place:
 //          T_j = sum_k L_ik W_kj (MFMA), W_ij = -W_ii T_j (MFMA; T_j stays in registers: accumulator register r of a lane
 //          is element (4r + lane/16, lane%16), which is exactly the B-operand element of k-group r)
+// Outputs: invd (the tile inverse, zeros above the diagonal), logdet[t], the pivot check -- not L_kk (see below).
 // Replaces the per-tile share of torch.linalg.cholesky (reference gpr/model.py:246).
 #include "mogp_internal.h"
 
@@ -34,18 +35,30 @@ __device__ __forceinline__ double readlane_d(double x, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// 1/sqrt(d) for the pivots: hardware seed (v_rsq_f64) + one third-order correction  y (1 + e/2 + 3 e^2/8),  e = 1 - d y^2.
+// The pivots are Schur complements of a jittered Gram matrix (no denormal / overflow scaling needed); full double precision for any
+// seed good to 2^-18.  Four dependent operations instead of the library routine's ~20 on the serial chain of the factorisation.
+__device__ __forceinline__ double fast_rsqrt(double d) {
+    const double y = __builtin_amdgcn_rsq(d);
+    const double e = fma(-d * y, y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);
+}
+
 template <int K>
 struct P1Step {
     static __device__ __forceinline__ void run(double (&a)[16], double* invdiag, int sb, bool writer, int& fail) {
         const double d = readlane_d(a[K], K);
         if (!(d > 0.0) && fail < 0) fail = sb * 16 + K;
-        const double rs = rsqrt(d);
+        const double rs = fast_rsqrt(d);
         a[K] *= rs;
         if (writer) invdiag[sb * 16 + K] = rs;
 #pragma unroll
         for (int j = K + 1; j < 16; ++j) {
             const double ljk = readlane_d(a[K], j);
             a[j] = fma(-a[K], ljk, a[j]);
+            // pin the update here: left to itself the optimiser sinks it to the column that first needs a[j], keeps every broadcast
+            // (30 SGPRs per column) alive until then, overflows the scalar file and pays a v_writelane / v_readlane pair per value
+            asm volatile("" : "+v"(a[j]));
         }
         P1Step<K + 1>::run(a, invdiag, sb, writer, fail);
     }
@@ -65,17 +78,17 @@ __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, d
     double* At = A + (int64_t)t * MOGP_TILE * ld + (int64_t)t * MOGP_TILE;
     __builtin_amdgcn_s_setprio(3);        // serial critical path: outrank co-resident trailing-update waves
 
-    // ---- load the lower 16-blocks: 16-byte loads, 8 in flight per thread ----
-    for (int it = 0; it < 32; it += 8) {
-        d2_t v[8];
+    // ---- load the lower 16-blocks: 16-byte loads, all 32 of a thread in flight at once (one memory round trip) ----
+    {
+        d2_t v[32];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = (it + u) * 256 + tid, r = idx >> 6, c = (idx & 63) * 2;
+        for (int u = 0; u < 32; ++u) {
+            const int idx = u * 256 + tid, r = idx >> 6, c = (idx & 63) * 2;
             v[u] = ((c >> 4) <= (r >> 4)) ? *reinterpret_cast<const d2_t*>(At + (int64_t)r * ld + c) : (d2_t){0.0, 0.0};
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = (it + u) * 256 + tid, r = idx >> 6, c = (idx & 63) * 2;
+        for (int u = 0; u < 32; ++u) {
+            const int idx = u * 256 + tid, r = idx >> 6, c = (idx & 63) * 2;
             if ((c >> 4) <= (r >> 4)) *reinterpret_cast<d2_t*>(M + lf_at(r, c)) = v[u];
         }
     }
@@ -125,7 +138,7 @@ __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, d
         __syncthreads();
     }
 
-    // ---- log-determinant share, failure report, L back to global ----
+    // ---- log-determinant share, failure report ----
     {
         double lg = (tid < MOGP_TILE) ? log(M[lf_at(tid, tid)]) : 0.0;
 #pragma unroll
@@ -137,14 +150,8 @@ __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, d
             if (fail >= 0) atomicMin(info, (unsigned long long)(info_base + (int64_t)t * MOGP_TILE + fail + 1));
         }
     }
-    for (int it = 0; it < 32; ++it) {
-        const int idx = it * 256 + tid, r = idx >> 6, c = (idx & 63) * 2;
-        d2_t v = (d2_t){0.0, 0.0};
-        if ((c >> 4) <= (r >> 4)) v = *reinterpret_cast<const d2_t*>(M + lf_at(r, c));
-        if (c > r) v[0] = 0.0;
-        if (c + 1 > r) v[1] = 0.0;
-        *reinterpret_cast<d2_t*>(At + (int64_t)r * ld + c) = v;
-    }
+    // The factor L_kk itself is NOT written back: every consumer works with the tile inverse (panel = panel * invd^T, W_KK rows,
+    // put_diag_tiles before TRTRI) and the log-determinant is taken here, so the diagonal tile of A keeps its (consumed) input.
 
     // ---- TRTRI: diagonal 16x16 inverses, one column per lane (8 blocks x 16 columns = waves 0 and 1) ----
     if (tid < MOGP_TILE) {
