@@ -62,15 +62,19 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def test_sharded_evaluation_two_gloo_ranks(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_sharded_evaluation_gloo_ranks(tmp_path, ranks):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % dict(root=ROOT, tests=os.path.join(ROOT, "tests")))
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % ranks,
+                          "--master-addr", "127.0.0.1", "--master-port", str(29615 + ranks), str(script)],
                          capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert r["world"] == 2
+    assert r["world"] == ranks
     assert abs(r["loss"] - r["ref_loss"]) < 1e-10 * abs(r["ref_loss"]) and r["err"] < 1e-9      # sharded == single process
     assert r["gold"] < 1e-8                                                                      # == reference autograd
     assert abs(r["l_shard"] - r["l_single"]) < 1e-10 * abs(r["l_single"]) and r["err2"] < 1e-8

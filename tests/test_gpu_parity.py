@@ -397,17 +397,18 @@ def test_every_gradient_schedule_matches_reference(path):
     assert "SWEEP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-def test_sharded_eval_two_ranks_one_gpu():
-    """the multi-GPU evaluation (mogp_shard_* + mogptk_amd.dist.sharded_eval): two ranks sharing this GPU over gloo (buffers staged
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_sharded_eval_ranks_sharing_one_gpu(ranks):
+    """the multi-GPU evaluation (mogp_shard_* + mogptk_amd.dist.sharded_eval): 2 / 4 ranks sharing this GPU over gloo (buffers staged
     through the host) must reproduce the single-process loss and raw-parameter gradients; N = 3000 -> 24 tile rows, 6 pivot blocks,
     ragged last tile.  With RCCL the same code exchanges device buffers directly (tools/shard_check.py --backend nccl)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29631", os.path.join(root, "tools", "shard_check.py"), "--points", "3000", "--backend", "gloo"],
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % ranks, "--master-addr", "127.0.0.1",
+                          "--master-port", str(29630 + ranks), os.path.join(root, "tools", "shard_check.py"), "--points", "3000", "--backend", "gloo"],
                          capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert r["world"] == 2
+    assert r["world"] == ranks
     assert r["rel_loss"] < 1e-10, r
     assert r["rel_grad"] < 1e-7, r          # tolerance: 1e-5 (north_star); measured ~1e-10
