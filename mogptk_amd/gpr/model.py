@@ -38,20 +38,23 @@ def _gtable_from_moments(table, mom, D, lower=True):
     included); lower=False: mom is indexed by all ordered pairs i*C + j (rectangular Gram)."""
     C, T = table.shape[0], table.shape[2]
     gt = np.zeros((C, C, T, 2 + 3 * D))
-    for i in range(C):
-        for j in range((i + 1) if lower else C):
-            m = mom[i * (i + 1) // 2 + j] if lower else mom[i * C + j]
-            tb = table[i, j]
-            A = tb[:, 0]
-            V = tb[:, 2:2 + D]
-            M = tb[:, 2 + D:2 + 2 * D]
-            m0, m4 = m[:, 0], m[:, 1]
-            m1, m2, m3 = m[:, 2:2 + D], m[:, 2 + D:2 + 2 * D], m[:, 2 + 2 * D:]
-            gt[i, j, :, 0] = m0
-            gt[i, j, :, 1] = -2.0 * np.pi * A * m4
-            gt[i, j, :, 2:2 + D] = -0.5 * A[:, None] * m1
-            gt[i, j, :, 2 + D:2 + 2 * D] = -2.0 * np.pi * A[:, None] * m3
-            gt[i, j, :, 2 + 2 * D:] = -V * A[:, None] * m2 - 2.0 * np.pi * M * (A * m4)[:, None]
+    if lower:
+        ii, jj = np.tril_indices(C)                     # row-major lower pairs: exactly p = i(i+1)/2 + j
+    else:
+        ii, jj = np.divmod(np.arange(C * C), C)
+    tb = table[ii, jj]                                  # (P, T, W)
+    A = tb[..., 0]
+    V = tb[..., 2:2 + D]
+    M = tb[..., 2 + D:2 + 2 * D]
+    m0, m4 = mom[..., 0], mom[..., 1]
+    m1, m2, m3 = mom[..., 2:2 + D], mom[..., 2 + D:2 + 2 * D], mom[..., 2 + 2 * D:]
+    g = np.empty_like(tb)
+    g[..., 0] = m0
+    g[..., 1] = -2.0 * np.pi * A * m4
+    g[..., 2:2 + D] = -0.5 * A[..., None] * m1
+    g[..., 2 + D:2 + 2 * D] = -2.0 * np.pi * A[..., None] * m3
+    g[..., 2 + 2 * D:] = -V * A[..., None] * m2 - 2.0 * np.pi * M * (A * m4)[..., None]
+    gt[ii, jj] = g
     return gt
 
 
@@ -250,7 +253,9 @@ class Exact(Model):
         N = self.X.shape[0]
         W = 2 + 3 * D
         mom = res["moments"]
-        counts = np.bincount(self.kernel._kernel_format(self.X)[:, 0].astype(np.int64), minlength=C).astype(np.float64)
+        if getattr(self, "_counts", None) is None or len(self._counts) != C:     # X is fixed per model (reference gpr/model.py:113-118)
+            self._counts = np.bincount(self.kernel._kernel_format(self.X)[:, 0].astype(np.int64), minlength=C).astype(np.float64)
+        counts = self._counts
         jit_rel = self.jitter * res["trG"] / N            # d LML / d (mean diag) through the jitter term (:244)
 
         # d LML / d table for the lower channel pairs (i >= j); zero elsewhere

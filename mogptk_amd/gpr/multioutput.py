@@ -103,7 +103,28 @@ class MultiOutputSpectralMixtureKernel(MultiOutputKernel):
             _accumulate(self.delay, gth)
             _accumulate(self.phase, gph)
 
+    def _memo_key(self):
+        parts = []
+        for p in (self.weight, self.mean, self.variance, self.delay, self.phase):
+            parts.append(p.data.tobytes())
+            for b in (p.lower, p.upper):
+                parts.append(b"-" if b is None else np.asarray(b, dtype=np.float64).tobytes())
+            if p.pegged:
+                parts.append(p.pegged_parameter.data.tobytes())
+        return b"|".join(parts)
+
     def _pairs(self):
+        # one evaluation asks for the pair algebra three times (terms for the device, terms and pairs again in the chain rule) at the
+        # SAME raw values: keep the last result, keyed on the raw parameter bytes (~60 doubles)
+        key = self._memo_key()
+        memo = self.__dict__.get("_pairs_memo")
+        if memo is not None and memo[0] == key:
+            return memo[1]
+        out = self._pairs_compute()
+        self.__dict__["_pairs_memo"] = (key, out)
+        return out
+
+    def _pairs_compute(self):
         w, mu, v, th, ph = self._values()
         vi, vj = v[:, None], v[None, :]                 # (C,C,Q,D) broadcast
         mi, mj = mu[:, None], mu[None, :]
@@ -113,9 +134,18 @@ class MultiOutputSpectralMixtureKernel(MultiOutputKernel):
         return w, mu, v, th, ph, vi, vj, mi, mj, s, inv, dmu
 
     def _spectral_terms(self, D):
-        """reference gpr/multioutput.py:182-199"""
+        """reference gpr/multioutput.py:182-199 (memoised like _pairs; the returned table is shared -- treat it as read-only)"""
         if D != self.input_dims:
             raise ValueError("X must have %d input dimensions" % self.input_dims)
+        key = self._memo_key()
+        memo = self.__dict__.get("_terms_memo")
+        if memo is not None and memo[0] == key:
+            return memo[1]
+        table = self._spectral_terms_compute(D)
+        self.__dict__["_terms_memo"] = (key, table)
+        return table
+
+    def _spectral_terms_compute(self, D):
         C = self.output_dims
         w, mu, v, th, ph, vi, vj, mi, mj, s, inv, dmu = self._pairs()
         Q = mu.shape[1]
