@@ -349,7 +349,7 @@ namespace mogp { double table_diag(const mogp_model* m, int c) {
 // Gram + factorisation + inverse factor + alpha.  On return d_A holds W = L^-1, d_alpha = Kj^-1 y.
 static int factorize(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
                      double* lml, double* jitter_abs, int64_t* info, bool fuse_inverse = false) {
-    const int C = m->C, D = m->D, W = 2 + 3 * D;
+    const int C = m->C, D = m->D;
     const int64_t N = m->N, Npad = m->Npad;
     if (m->T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms must be called before an evaluation");
     if (!noise_var) return fail(MOGP_EINVAL, "noise_var is null");
@@ -697,8 +697,8 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     if (!(flags & MOGP_EVAL_GRAD)) { collect_timing(m, 4); return MOGP_OK; }
     if (!moments || !diagG || !trG) return fail(MOGP_EINVAL, "mogp_exact_eval: gradient outputs are null");
 
-    const int C = m->C, D = m->D, W = 2 + 3 * D, T = m->T, P = C * (C + 1) / 2;
-    const int64_t Npad = m->Npad;
+    const int C = m->C;
+
     // K^-1: the sweep left -Kj^-1 in k.A; the POTRF path needs W^T W (lower tiles, full diagonal tiles) in k.B
     if (!sweep && !fused && (rc = spd_lauum(m, m->k))) return rc;
     const double* kinv = sweep ? m->k.A.p : m->k.B.p;
