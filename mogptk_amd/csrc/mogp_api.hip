@@ -395,6 +395,7 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     m->w_in_Wm = fuse_inverse;
     if ((rc = launch_trmv_lower(Wp, Npad, Npad, m->d_y.p, m->d_z.p, m->d_zz.p, m->st))) return rc;
     if ((rc = launch_trmv_lower_t(Wp, Npad, Npad, m->d_z.p, m->d_alpha.p, m->st))) return rc;
+    if (fuse_inverse && (rc = spd_potri_fused_finish(m, m->k))) return rc;
     if ((rc = mark(m, 4))) return rc;
 
     // scalars back

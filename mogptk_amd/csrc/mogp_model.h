@@ -69,6 +69,7 @@ struct Spd {
     std::vector<TrtriLevel> levels;
     std::vector<hipEvent_t> sync_ev;    // cross-stream dependencies of the look-ahead schedule
     std::vector<hipEvent_t> inv_ev;     // events of the fused schedule (potri.hip)
+    hipEvent_t fused_last_inv = nullptr;
     DevBuf<double> Wd;                  // W_KK = L_KK^-1 of every outer block of the fused schedule (512 x 512 each, wkk.hip)
     DevBuf<double> Pb[MOGP_NPANEL];     // rotating panel buffers L[>K, K] of the fused schedule (Npad x 512 each)
     void release() {
@@ -151,7 +152,8 @@ int mark(mogp_model* m, int idx);
 double table_diag(const mogp_model* m, int c);
 int spd_alloc(Spd& w, int64_t Npad);
 int spd_potrf(mogp_model* m, Spd& w, long long info_base = 0);
-int spd_potri_fused(mogp_model* m, Spd& w);   // potri.hip: w.A (SPD, lower) -> w.Wm = L^-1, w.B = inverse (lower); w.logdet per tile
+int spd_potri_fused(mogp_model* m, Spd& w);
+int spd_potri_fused_finish(mogp_model* m, Spd& w);   // joins the inverse stream: call before reading w.B   // potri.hip: w.A (SPD, lower) -> w.Wm = L^-1, w.B = inverse (lower); w.logdet per tile
 int spd_trtri(mogp_model* m, Spd& w);
 int spd_lauum(mogp_model* m, Spd& w);
 int spd_sweep(mogp_model* m, Spd& w);

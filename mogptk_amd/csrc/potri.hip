@@ -80,7 +80,7 @@ int panel_rows(mogp_model* m, Spd& w, double* P, const double* Wk, int k0, int n
 }
 
 // the inverse stream's share of block K (see the header); Lp = P[k1 tile row], leading dimension FZ_KD
-int inverse_step(mogp_model* m, Spd& w, const double* Wkk, int k0, int k1, const double* Lp, hipStream_t q) {
+int inverse_step(mogp_model* m, Spd& w, const double* Wkk, int k0, int k1, const double* Lp, hipStream_t q, hipEvent_t w_final) {
     const int64_t ld = w.Npad;
     const int nk = k1 - k0, rem = w.nb - k1;
     const int64_t Kd = (int64_t)nk * MOGP_TILE, c0 = (int64_t)k0 * MOGP_TILE;
@@ -95,6 +95,7 @@ int inverse_step(mogp_model* m, Spd& w, const double* Wkk, int k0, int k1, const
         RC(launch_copy2d(Wrow, ld, Brow, ld, Kd, c0, 1.0, q));
     }
     RC(launch_copy2d(Wrow + c0, ld, Wkk, FZ_KD, Kd, Kd, 1.0, q));
+    if (w_final) HIP_TRY(hipEventRecord(w_final, q));           // the last row block: W = L^-1 is complete
     if (rem > 0) {
         double* Wt = w.Wm.p + (int64_t)k1 * MOGP_TILE * ld;                    // Wt[>K, 0]
         GemmArgs g{};
@@ -139,13 +140,13 @@ int spd_potri_fused(mogp_model* m, Spd& w) {
         HIP_TRY(hipMemsetAsync(w.Wd.p, 0, (size_t)nouter * FZ_KD * FZ_KD * sizeof(double), crit));
     }
     auto Wk = [&](int kb) { return w.Wd.p + (int64_t)kb * FZ_KD * FZ_KD; };
-    while ((int)w.inv_ev.size() < EV_PER_BLOCK * nouter + 1) {
+    while ((int)w.inv_ev.size() < EV_PER_BLOCK * nouter + 2) {
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         w.inv_ev.push_back(e);
     }
     auto ev = [&](int kb, int which) { return w.inv_ev[EV_PER_BLOCK * kb + which]; };
-    hipEvent_t start = w.inv_ev[EV_PER_BLOCK * nouter];
+    hipEvent_t start = w.inv_ev[EV_PER_BLOCK * nouter], w_ready = w.inv_ev[EV_PER_BLOCK * nouter + 1];
     HIP_TRY(hipEventRecord(start, crit));                // the Gram matrix is in place
 
     // Host order matters as much as stream order: a late block takes about as long on the GPU as its ~45 launches take to enqueue,
@@ -226,17 +227,27 @@ int spd_potri_fused(mogp_model* m, Spd& w) {
         // 6. inv
         HIP_TRY(hipStreamWaitEvent(inv, ev(kb, EV_BLK), 0));
         if (rem > 0) HIP_TRY(hipStreamWaitEvent(inv, ev(kb, EV_REST), 0));
-        RC(inverse_step(m, w, Wk(kb), k0, k1, P + (int64_t)k1 * MOGP_TILE * FZ_KD, inv));
+        RC(inverse_step(m, w, Wk(kb), k0, k1, P + (int64_t)k1 * MOGP_TILE * FZ_KD, inv, kb == nouter - 1 ? w_ready : nullptr));
         HIP_TRY(hipEventRecord(ev(kb, EV_INV), inv));
     }
     HIP_TRY(hipEventRecord(ev(nouter - 1, EV_DIAG), bulk));                              // reuse: everything on the bulk stream
     HIP_TRY(hipStreamWaitEvent(crit, ev(nouter - 1, EV_BLK), 0));
     HIP_TRY(hipStreamWaitEvent(crit, ev(nouter - 1, EV_DIAG), 0));
-    HIP_TRY(hipStreamWaitEvent(crit, ev(nouter - 1, EV_INV), 0));
+    // W is complete one step before the inverse: the caller's W y / W^T z run next to the last accumulate of the inverse and
+    // spd_potri_fused_finish() joins the inverse stream afterwards
+    HIP_TRY(hipStreamWaitEvent(crit, w_ready, 0));
+    w.fused_last_inv = ev(nouter - 1, EV_INV);
     if (std::getenv("MOGP_DEBUG_HOST")) {
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count();
         fprintf(stderr, "spd_potri_fused: host enqueue %.0f us, %d outer blocks\n", us, nouter);
     }
+    return 0;
+}
+
+
+// the inverse (w.B) is complete on the critical stream after this
+int spd_potri_fused_finish(mogp_model* m, Spd& w) {
+    if (w.fused_last_inv) HIP_TRY(hipStreamWaitEvent(m->st, w.fused_last_inv, 0));
     return 0;
 }
 
