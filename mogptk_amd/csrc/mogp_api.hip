@@ -128,7 +128,7 @@ int mogp_ctx_create(int device, mogp_ctx** out) {
 
 int mogp_ctx_destroy(mogp_ctx* ctx) {
     if (!ctx) return MOGP_OK;
-    for (hipStream_t q : {ctx->st, ctx->st2, ctx->st3, ctx->st_priv}) if (q) { hipError_t e = hipStreamSynchronize(q); (void)e; e = hipStreamDestroy(q); (void)e; }
+    for (hipStream_t q : {ctx->st, ctx->st2, ctx->st2u, ctx->st3, ctx->st_priv}) if (q) { hipError_t e = hipStreamSynchronize(q); (void)e; e = hipStreamDestroy(q); (void)e; }
     delete ctx;
     return MOGP_OK;
 }
@@ -211,6 +211,10 @@ namespace mogp { int mark(mogp_model* m, int idx) {
 // log L_kk; a non-positive pivot is reported through m->d_info (atomicMin of the 1-based index).
 namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base) {
     int rc;
+    // Bulk stream: the one masked to everything but the reserved CUs while the serial chain matters -- the chain's small kernels (this
+    // stream, all CUs) then find idle CUs instead of sharing one with GEMM waves: 15.9 vs 21.1 ms per evaluation at N = 8192, 74 vs 82 ms
+    // for the N = 16384 prediction.  Once the work is flop-bound the 6 % of CUs matter more (sweep at N = 32768: 597 vs 638 ms): all CUs.
+    hipStream_t bulk_q = (w.nb > MOGP_CHAIN_BOUND_TILES && m->st2u) ? m->st2u : m->st2;
     // ---- two-level blocked right-looking Cholesky with look-ahead.
     // Outer blocks of MOGP_OUTER tiles.  "chain(kb)" = for each 128-column of the block: leaf (factor + inverse) -> panel =
     // panel * inv(Lkk)^T for ALL rows below -> update of the block's remaining columns (64x64-tile GEMMs: latency-bound).
@@ -256,16 +260,16 @@ namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base) {
         const int K = (k1 - k0) * MOGP_TILE;
         const int na = std::min(MOGP_OUTER, rem);      // tile columns of the next outer block
         if (rem > na) {                                                           // B(kb) on the bulk stream
-            HIP_TRY(hipStreamWaitEvent(m->st2, w.sync_ev[2 * kb], 0));
+            HIP_TRY(hipStreamWaitEvent(bulk_q, w.sync_ev[2 * kb], 0));
             double* bp = blockp + (int64_t)na * MOGP_TILE * w.Npad;
             GemmArgs u{};
             u.A = bp; u.lda = w.Npad; u.a_kmajor = 0; u.B = bp; u.ldb = w.Npad; u.b_kmajor = 0;
             u.C = w.A.p + (int64_t)(k1 + na) * MOGP_TILE * (w.Npad + 1); u.ldc = w.Npad; u.alpha = -1.0; u.beta = 1.0;
             u.mode = GM_LOWER; u.mt = rem - na; u.nt = rem - na; u.K = K;
-            if ((rc = gemm_call(m, u, gemm_flops(u, nullptr), m->st2))) return rc;
+            if ((rc = gemm_call(m, u, gemm_flops(u, nullptr), bulk_q))) return rc;
         }
         if (last_bulk >= 0) HIP_TRY(hipStreamWaitEvent(m->st, w.sync_ev[2 * last_bulk + 1], 0));   // A(kb) after B(kb-1)
-        if (rem > na) { HIP_TRY(hipEventRecord(w.sync_ev[2 * kb + 1], m->st2)); last_bulk = kb; }
+        if (rem > na) { HIP_TRY(hipEventRecord(w.sync_ev[2 * kb + 1], bulk_q)); last_bulk = kb; }
         {
             GemmArgs u{};                                                         // A(kb): columns k1 .. k1+na-1, rows >= column
             u.A = blockp; u.lda = w.Npad; u.a_kmajor = 0; u.B = blockp; u.ldb = w.Npad; u.b_kmajor = 0;
@@ -555,9 +559,11 @@ extern "C" {
 // the context's streams: critical (high priority, all CUs), private (reserved CUs only), two bulk streams (everything else)
 static int ctx_streams(mogp_ctx* ctx) {
     if (ctx->streams_ready) return 0;
+    int lo_prio = 0;
     {
         int lo = 0, hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        lo_prio = lo;
         HIP_TRY(hipStreamCreateWithPriority(&ctx->st, hipStreamNonBlocking, hi));
         // MOGP_RESERVE_CUS = R compute units of every XCD are kept for the latency-bound intra-block chain of the fused
         // factorisation + inversion (potri.hip): CU-mask bit i is CU (i / 8) of XCD (i % 8) on gfx950 (tools/micro/cumask.hip),
@@ -580,6 +586,14 @@ static int ctx_streams(mogp_ctx* ctx) {
             HIP_TRY(hipStreamCreateWithPriority(&ctx->st3, hipStreamNonBlocking, lo));
         }
     }
+    {   // bulk stream over ALL CUs (full mask), used once an evaluation is flop-bound
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+        std::vector<uint32_t> all((prop.multiProcessorCount + 31) / 32, 0u);
+        for (int i = 0; i < prop.multiProcessorCount; ++i) all[i / 32] |= 1u << (i % 32);
+        if (ctx->st_priv) HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st2u, (uint32_t)all.size(), all.data()));
+        else HIP_TRY(hipStreamCreateWithPriority(&ctx->st2u, hipStreamNonBlocking, lo_prio));
+    }
     ctx->streams_ready = true;
     return 0;
 }
@@ -601,7 +615,7 @@ int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, c
 #define TRY_RC(x) do { int r__ = (x); if (r__) { mogp_model_destroy(m); return r__; } } while (0)
 #define TRY_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { int r__ = hip_fail(e__, #x, __FILE__, __LINE__); mogp_model_destroy(m); return r__; } } while (0)
     TRY_RC(ctx_streams(ctx));
-    m->st = ctx->st; m->st2 = ctx->st2; m->st3 = ctx->st3; m->st_priv = ctx->st_priv;
+    m->st = ctx->st; m->st2 = ctx->st2; m->st2u = ctx->st2u; m->st3 = ctx->st3; m->st_priv = ctx->st_priv;
     TRY_RC(spd_alloc(m->k, Npad));
     TRY_RC(m->d_x.ensure((size_t)D * Npad));
     TRY_RC(m->d_y.ensure(Npad));
@@ -632,7 +646,7 @@ int mogp_model_destroy(mogp_model* m) {
     if (m->st) { hipError_t e = hipStreamSynchronize(m->st); (void)e; }
     for (auto e : m->ev) { hipError_t r = hipEventDestroy(e); (void)r; }
     for (auto e : m->gemm_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
-    for (hipStream_t q : {m->st2, m->st3, m->st_priv}) if (q) { hipError_t e = hipStreamSynchronize(q); (void)e; }
+    for (hipStream_t q : {m->st2, m->st2u, m->st3, m->st_priv}) if (q) { hipError_t e = hipStreamSynchronize(q); (void)e; }
     m->k.release(); m->ws.release(); m->ws_tail.release();
     for (int b = 0; b < 2; ++b) { m->swU[b].release(); m->swUr[b].release(); }
     for (auto e : m->sw_ev) { hipError_t r = hipEventDestroy(e); (void)r; }

@@ -49,7 +49,7 @@ struct mogp_ctx {
     int device = 0;
     std::string name;
     // streams shared by every model of the context (created once: a CU-masked stream owns a hardware queue, and models come and go)
-    hipStream_t st = nullptr, st2 = nullptr, st3 = nullptr, st_priv = nullptr;
+    hipStream_t st = nullptr, st2 = nullptr, st3 = nullptr, st_priv = nullptr, st2u = nullptr;
     bool streams_ready = false;
 };
 
@@ -60,6 +60,7 @@ struct TrtriLevel {
 };
 
 // dense SPD workspace: A (Npad x Npad, lower) -> L -> W = L^-1 in place; B = scratch, then W^T W
+#define MOGP_CHAIN_BOUND_TILES 160   // up to this many 128-row tiles (N <= 20480) the bulk work stays off the reserved CUs
 #define MOGP_NPANEL 4       // the factorisation may run this many outer blocks ahead of the inverse stream
 struct Spd {
     int64_t Npad = 0;
@@ -109,7 +110,8 @@ struct mogp_model {
     std::vector<int> pair_start;
     std::vector<double> table;          // host copy [C*C*T*W]
     hipStream_t st = nullptr;           // critical-path stream (high priority)
-    hipStream_t st2 = nullptr;          // bulk trailing updates (look-ahead)
+    hipStream_t st2 = nullptr;          // bulk trailing updates of the fused schedule (CU-masked: everything but the reserved CUs)
+    hipStream_t st2u = nullptr;         // bulk trailing updates over ALL CUs, for flop-bound sizes (MOGP_CHAIN_BOUND_TILES)
     hipStream_t st3 = nullptr;          // inverse streamed behind the factorisation (lowest priority)
     hipStream_t st_priv = nullptr;      // intra-block chain of the fused factorisation, on the reserved CUs only
     Spd k;                              // the N x N system

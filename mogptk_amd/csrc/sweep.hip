@@ -55,7 +55,7 @@ int sweep_block(mogp_model* m, Spd& w, int kb) {
     const int nb = w.nb;
     const int64_t ld = w.Npad;
     const int rm = m->sh_n > 1 ? m->sh_n : 0, rr = m->sh_rank;
-    hipStream_t q1 = m->st, q2 = m->st2;
+    hipStream_t q1 = m->st, q2 = (w.nb > MOGP_CHAIN_BOUND_TILES && m->st2u) ? m->st2u : m->st2;      // see spd_potrf
     double* A = w.A.p;
     const int k0 = kb * SW_OB, k1 = std::min(k0 + SW_OB, nb), nk = k1 - k0;
     const int64_t Kd = (int64_t)nk * MOGP_TILE;
