@@ -698,15 +698,15 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     if ((rc = use_device(m->ctx))) return rc;
     if (info) *info = 0;
     // Gradient evaluation, three schedules of the same arithmetic (MOGP_GRAD_PATH = fused | phases | sweep overrides the choice):
-    //   fused   potri.hip: the inverse streamed behind the Cholesky chain.  Wins while the serial chain dominates: 63 vs 59.5 evals/s
-    //           at N = 8192 -- the default up to 96 tile rows (N <= 12288).
+    //   fused   potri.hip: the inverse streamed behind the Cholesky chain.  Wins while the serial chain dominates: 15.1 vs 15.9 ms at
+    //           N = 8192, 20.1 vs 21.1 ms at N = 9216, even at N = 10240 -- the default up to 80 tile rows.
     //   phases  POTRF, TRTRI, LAUUM one after the other: fewer, larger GEMM launches.  Wins once the evaluation is flop-bound
-    //           (80 vs 91 ms at N = 16384, 569 vs 657 ms at N = 32768) -- the default above.
+    //           (38.8 vs 41.8 ms at N = 12288, 80.6 vs 90.1 ms at N = 16384, 569 vs 657 ms at N = 32768) -- the default above.
     //   sweep   sweep.hip: single-sweep blocked inversion; slower on one GPU (47 evals/s at N = 8192) but with one panel
     //           exchange per pivot block, which is what the sharded multi-GPU evaluation (mogp_shard_*) is built on.
     static const std::string grad_path = []() { const char* e = std::getenv("MOGP_GRAD_PATH"); return std::string(e ? e : ""); }();
     const bool sweep = grad_path == "sweep" && (flags & MOGP_EVAL_GRAD);
-    const bool fused = !sweep && (flags & MOGP_EVAL_GRAD) && (grad_path == "fused" || (grad_path != "phases" && m->nb <= 96));
+    const bool fused = !sweep && (flags & MOGP_EVAL_GRAD) && (grad_path == "fused" || (grad_path != "phases" && m->nb <= 80));
     if (sweep) { if ((rc = eval_sweep(m, noise_var, data_var, jitter, lml, jitter_abs, info))) return rc; }
     else if ((rc = factorize(m, noise_var, data_var, jitter, lml, jitter_abs, info, fused))) return rc;
     if (!(flags & MOGP_EVAL_GRAD)) { collect_timing(m, 4); return MOGP_OK; }

@@ -363,7 +363,7 @@ def test_cfg5_titsias_golden():
 @pytest.mark.parametrize("path", ["sweep", "phases", "fused"])
 def test_every_gradient_schedule_matches_reference(path):
     """the three schedules of the gradient evaluation (MOGP_GRAD_PATH: single-sweep inversion; POTRF -> TRTRI -> LAUUM, the default
-    above 96 tile rows; inverse streamed behind the Cholesky chain, the default below) against the same golden vectors, each in a
+    above 80 tile rows; inverse streamed behind the Cholesky chain, the default below) against the same golden vectors, each in a
     fresh process because the schedule is chosen once per process"""
     import os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
