@@ -20,6 +20,39 @@ def term_width(D):
     return 2 + 3 * D
 
 
+# One evaluation asks every kernel of a composition for its term table several times (push to the device, then again at each level
+# of the chain rule -- AddKernel even asks only to learn T) while no parameter can change.  A model evaluation opens this cache.
+_TERMS_CACHE = None
+
+
+class terms_cache:
+    """context: memoise `_spectral_terms` per kernel object for the duration of ONE model evaluation (tables are shared: read-only)"""
+
+    def __enter__(self):
+        global _TERMS_CACHE
+        self._prev = _TERMS_CACHE
+        _TERMS_CACHE = {}
+        return self
+
+    def __exit__(self, *exc):
+        global _TERMS_CACHE
+        _TERMS_CACHE = self._prev
+        return False
+
+
+def cached_terms(fn):
+    def wrapper(self, D):
+        cache = _TERMS_CACHE
+        if cache is None:
+            return fn(self, D)
+        key = (id(self), D)
+        if key not in cache:
+            cache[key] = fn(self, D)
+        return cache[key]
+    wrapper.__doc__ = fn.__doc__
+    return wrapper
+
+
 class Kernel(ParameterHolder):
     """Base kernel (reference gpr/kernel.py:5-191)."""
 
@@ -192,6 +225,7 @@ class AddKernel(Kernels):
         for k in self.kernels:
             k._spectral_diag_backward(gc, D)
 
+    @cached_terms
     def _spectral_terms(self, D):
         return np.concatenate([k._spectral_terms(D) for k in self.kernels], axis=2)
 

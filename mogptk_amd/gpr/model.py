@@ -9,7 +9,7 @@ from math import erf, sqrt
 
 from .config import config
 from .parameter import Parameter, ParameterHolder
-from .kernel import Kernel
+from .kernel import Kernel, terms_cache
 from .likelihood import Likelihood, GaussianLikelihood
 
 
@@ -154,6 +154,10 @@ class Model(ParameterHolder):
         pass
 
     def loss(self):
+        with terms_cache():                 # parameters are frozen between the table push and the chain rule
+            return self._loss_impl()
+
+    def _loss_impl(self):
         raise NotImplementedError()
 
     def K(self, X1, X2=None):
@@ -243,7 +247,7 @@ class Exact(Model):
         res, _, _ = self._eval(grad=False)
         return np.float64(res["lml"])
 
-    def loss(self):
+    def _loss_impl(self):
         """reference gpr/model.py:279-292: zero grads, loss = -LML - log prior, fresh `.grad` on every
         parameter in the graph.  Gradients come from the device's moment pass + the host chain rule."""
         self.zero_grad(set_to_none=True)
@@ -405,7 +409,7 @@ class Titsias(Model):
         """maximise the lower bound (reference gpr/model.py:726-728)"""
         return self.elbo()
 
-    def loss(self):
+    def _loss_impl(self):
         self.zero_grad(set_to_none=True)
         res, table, D, Zk = self._run(grad=True)
         C = table.shape[0]

@@ -11,7 +11,7 @@ import numpy as np
 
 from .config import config
 from .parameter import Parameter
-from .kernel import Kernel, MultiOutputKernel, term_width
+from .kernel import Kernel, MultiOutputKernel, term_width, cached_terms
 
 PI = np.pi
 
@@ -38,6 +38,7 @@ class IndependentMultiOutputKernel(MultiOutputKernel):
     def name(self):
         return "%s[%s]" % (self.__class__.__name__, ",".join(k.name() for k in self.kernels))
 
+    @cached_terms
     def _spectral_terms(self, D):
         subs = [k._spectral_terms(D)[0, 0] for k in self.kernels]      # each (T_c, W)
         T = max(s.shape[0] for s in subs)
@@ -133,6 +134,7 @@ class MultiOutputSpectralMixtureKernel(MultiOutputKernel):
         dmu = mi - mj
         return w, mu, v, th, ph, vi, vj, mi, mj, s, inv, dmu
 
+    @cached_terms
     def _spectral_terms(self, D):
         """reference gpr/multioutput.py:182-199 (memoised like _pairs; the returned table is shared -- treat it as read-only)"""
         if D != self.input_dims:
@@ -279,6 +281,7 @@ class CrossSpectralKernel(MultiOutputKernel):
         self.variance = Parameter(np.ones(input_dims), lower=config.positive_minimum)
         self.shift = Parameter(np.zeros((output_dims, Rq)))
 
+    @cached_terms
     def _spectral_terms(self, D):
         """reference gpr/multioutput.py:432-449"""
         if D != self.input_dims:
@@ -350,6 +353,7 @@ class LinearModelOfCoregionalizationKernel(MultiOutputKernel):
         w = self.weight()                                                   # (C,Q,Rq)
         return np.einsum("iqr,jqr->ijq", w, w)                               # B_q[i,j]  (:493)
 
+    @cached_terms
     def _spectral_terms(self, D):
         B = self._coreg()
         C = self.output_dims

@@ -7,7 +7,7 @@ import numpy as np
 
 from .config import config
 from .parameter import Parameter
-from .kernel import Kernel, term_width
+from .kernel import Kernel, term_width, cached_terms
 from .multioutput import _accumulate
 
 FOUR_PI2 = 4.0 * np.pi ** 2
@@ -26,6 +26,7 @@ class SpectralMixtureKernel(Kernel):
         self.mean = Parameter(np.zeros((Q, input_dims)), lower=config.positive_minimum)
         self.variance = Parameter(np.ones((Q, input_dims)), lower=config.positive_minimum)
 
+    @cached_terms
     def _spectral_terms(self, D):
         if D != self.input_dims:
             raise ValueError("X must have %d input dimensions" % self.input_dims)
@@ -65,6 +66,7 @@ class SpectralKernel(Kernel):
         self.mean = Parameter(np.zeros(input_dims), lower=config.positive_minimum)
         self.variance = Parameter(np.ones(input_dims), lower=config.positive_minimum)
 
+    @cached_terms
     def _spectral_terms(self, D):
         if D != self.input_dims:
             raise ValueError("X must have %d input dimensions" % self.input_dims)
