@@ -7,7 +7,8 @@
 //     P1  waves 0-2, one ROW per lane (the 16 diagonal-block rows + 48 panel rows per wave): right-looking Cholesky of
 //         the 16x16 diagonal block where L[j][k] is broadcast with v_readlane (compile-time lane) -- the same instruction
 //         stream IS the triangular solve for the panel rows riding along in lanes 16..63
-//     P3  trailing update C_ij -= P_i P_j^T on v_mfma_f64_16x16x4_f64, blocks dealt round-robin to the 4 waves
+//     P3  trailing update C_ij -= P_i P_j^T on v_mfma_f64_16x16x4_f64: the block column the next P1 reads right away (all waves),
+//         the rest one step later on the waves that sit out P1 (look-ahead, hidden behind the serial micro-panel)
 //   TRTRI  16x16 diagonal inverses (one column per lane), then block row i = 1..7 in place:
 //          T_j = sum_k L_ik W_kj (MFMA), W_ij = -W_ii T_j (MFMA; T_j stays in registers: accumulator register r of a lane
 //          is element (4r + lane/16, lane%16), which is exactly the B-operand element of k-group r)
@@ -68,6 +69,23 @@ struct P1Step<16> {
     static __device__ __forceinline__ void run(double (&)[16], double*, int, bool, int&) {}
 };
 
+// number of block columns of step s's trailing update that are applied right away (the rest is deferred to the look-ahead)
+__device__ __forceinline__ int lf_now(int s) { return s == 0 ? 3 : (s == 1 ? 2 : 1); }
+
+// C(i, j) -= P(i, kc) P(j, kc)^T on 16 x 16 blocks of the packed tile (one wave)
+__device__ __forceinline__ void lf_update(double* M, int i, int j, int kc, int lane) {
+    double* Cb = M + lf_blk(i, j) + (lane >> 4) * LF_BS + (lane & 15);
+    d4_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = Cb[4 * r * LF_BS];
+    const double* Pa = M + lf_blk(i, kc) + (lane & 15) * LF_BS + (lane >> 4);
+    const double* Pb = M + lf_blk(j, kc) + (lane & 15) * LF_BS + (lane >> 4);
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pa[4 * k4], Pb[4 * k4], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Cb[4 * r * LF_BS] = acc[r];
+}
+
 __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, double* invd, double* logdet,
                                                  unsigned long long* info, long long info_base) {
     extern __shared__ __attribute__((aligned(16))) double lf[];
@@ -113,27 +131,31 @@ __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, d
 #pragma unroll
                 for (int c = 0; c < 16; ++c) rowp[c] = (lane < 16 && c > lane) ? 0.0 : a[c];
             }
+        } else if (sb > 0) {
+            // look-ahead: the part of the PREVIOUS step's trailing update that the micro-panel above does not read (block columns
+            // >= sb + nc(sb - 1), from panel column sb - 1) runs here, on the waves that have no rows in P1 (wave 3; waves 2 and 1 once
+            // their panel rows are gone), hidden behind the serial factorisation
+            const int first_idle = sb >= 4 ? 1 : 2, nidle = 4 - first_idle;
+            const int j0 = sb + lf_now(sb - 1);                 // first deferred block column
+            const int nr = 8 - j0, nb2 = nr > 0 ? nr * (nr + 1) / 2 : 0;
+            for (int q = wave - first_idle; q < nb2; q += nidle) {
+                int bi = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
+                while ((bi + 1) * (bi + 2) / 2 <= q) ++bi;
+                while (bi * (bi + 1) / 2 > q) --bi;
+                const int bj = q - bi * (bi + 1) / 2;
+                lf_update(M, j0 + bi, j0 + bj, sb - 1, lane);
+            }
         }
         __syncthreads();
-        // ---- P3: C_ij -= P_i P_j^T for sb < j <= i <= 7 ----
-        const int nrem = 7 - sb;
-        const int nblk = nrem * (nrem + 1) / 2;
-        for (int q = wave; q < nblk; q += 4) {
-            int bi = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
-            while ((bi + 1) * (bi + 2) / 2 <= q) ++bi;
-            while (bi * (bi + 1) / 2 > q) --bi;
-            const int bj = q - bi * (bi + 1) / 2;
-            const int i = sb + 1 + bi, j = sb + 1 + bj;
-            double* Cb = M + lf_blk(i, j) + (lane >> 4) * LF_BS + (lane & 15);
-            d4_t acc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = Cb[4 * r * LF_BS];
-            const double* Pa = M + lf_blk(i, sb) + (lane & 15) * LF_BS + (lane >> 4);
-            const double* Pb = M + lf_blk(j, sb) + (lane & 15) * LF_BS + (lane >> 4);
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pa[4 * k4], Pb[4 * k4], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Cb[4 * r * LF_BS] = acc[r];
+        // ---- P3, the part done right away: block columns sb + 1 .. sb + nc(sb) from panel column sb (the next micro-panel reads the
+        // first of them; taking three / two columns in the first two steps keeps the deferred rest within what two idle waves finish
+        // behind one P1) ----
+        {
+            const int jn = min(sb + lf_now(sb), 7);
+            int cnt = 0;
+            for (int j = sb + 1; j <= jn; ++j)
+                for (int i = j; i < 8; ++i, ++cnt)
+                    if ((cnt & 3) == wave) lf_update(M, i, j, sb, lane);
         }
         __syncthreads();
     }

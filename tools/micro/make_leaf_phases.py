@@ -10,9 +10,9 @@ edits = [
      'namespace mogp {\n__device__ unsigned long long g_leaf_t[64];\n#define MARK(i) do { __syncthreads(); if (threadIdx.x == 0) g_leaf_t[i] = __builtin_readcyclecounter(); } while (0)\n\ntypedef double d4_t'),
     ('    __builtin_amdgcn_s_setprio(3);        // serial critical path: outrank co-resident trailing-update waves\n', '    __builtin_amdgcn_s_setprio(3);\n    MARK(0);\n'),
     ('    int fail = -1;\n    for (int sb = 0; sb < 8; ++sb) {', '    MARK(1);\n    int fail = -1;\n    for (int sb = 0; sb < 8; ++sb) {'),
-    ('        // ---- P3: C_ij -= P_i P_j^T for sb < j <= i <= 7 ----', '        MARK(2 + 2 * sb);\n        // ---- P3: C_ij -= P_i P_j^T for sb < j <= i <= 7 ----'),
-    ('            for (int r = 0; r < 4; ++r) Cb[4 * r * LF_BS] = acc[r];\n        }\n        __syncthreads();\n    }\n',
-     '            for (int r = 0; r < 4; ++r) Cb[4 * r * LF_BS] = acc[r];\n        }\n        __syncthreads();\n        MARK(3 + 2 * sb);\n    }\n'),
+    ('        // ---- P3, the part done right away:', '        MARK(2 + 2 * sb);\n        // ---- P3, the part done right away:'),
+    ('                    if ((cnt & 3) == wave) lf_update(M, i, j, sb, lane);\n        }\n        __syncthreads();\n    }\n',
+     '                    if ((cnt & 3) == wave) lf_update(M, i, j, sb, lane);\n        }\n        __syncthreads();\n        MARK(3 + 2 * sb);\n    }\n'),
     ('    // ---- TRTRI: diagonal 16x16 inverses, one column per lane', '    MARK(20);\n    // ---- TRTRI: diagonal 16x16 inverses, one column per lane'),
     ('    // ---- TRTRI: block rows 1..7 in place.', '    MARK(21);\n    // ---- TRTRI: block rows 1..7 in place.'),
     ('    double* Wt = invd + (int64_t)t * MOGP_TILE * MOGP_TILE;\n    for (int it = 0; it < 32; ++it) {', '    MARK(22);\n    double* Wt = invd + (int64_t)t * MOGP_TILE * MOGP_TILE;\n    for (int it = 0; it < 32; ++it) {'),
