@@ -9,9 +9,9 @@
 //         stream IS the triangular solve for the panel rows riding along in lanes 16..63
 //     P3  trailing update C_ij -= P_i P_j^T on v_mfma_f64_16x16x4_f64: the block column the next P1 reads right away (all waves),
 //         the rest one step later on the waves that sit out P1 (look-ahead, hidden behind the serial micro-panel)
-//   TRTRI  16x16 diagonal inverses (one column per lane), then block row i = 1..7 in place:
-//          T_j = sum_k L_ik W_kj (MFMA), W_ij = -W_ii T_j (MFMA; T_j stays in registers: accumulator register r of a lane
-//          is element (4r + lane/16, lane%16), which is exactly the B-operand element of k-group r)
+//   TRTRI  16x16 diagonal inverses (one column per lane), then the off-diagonal blocks by block COLUMN, two columns per wave, no
+//          barriers: T = sum_k L_ik W_kj (MFMA), W_ij = -W_ii T (MFMA); finished blocks stay in registers -- accumulator register r
+//          of a lane is element (4r + lane/16, lane%16), which is exactly the B-operand element of k-group r
 // Outputs: invd (the tile inverse, zeros above the diagonal), logdet[t], the pivot check -- not L_kk (see below).
 // Replaces the per-tile share of torch.linalg.cholesky (reference gpr/model.py:246).
 #include "mogp_internal.h"
@@ -193,46 +193,57 @@ __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, d
     }
     __syncthreads();
 
-    // ---- TRTRI: block rows 1..7 in place.  Row i only reads row i of L and rows < i of W, so a single barrier between
-    // "all T_j of this row computed" and "W_ij written over L_ij" suffices. ----
-    for (int i = 1; i < 8; ++i) {
-        d4_t tacc[2];                          // this wave's T_j (j = wave, wave + 4)
+    // ---- TRTRI, off-diagonal blocks: W_ij = -W_ii sum_{k = j}^{i-1} L_ik W_kj.  Block COLUMNS of W are independent, so every wave takes
+    // two of them (j and 7 - j: 8 + 1, 7 + 2, ... blocks -- balanced) and walks down the rows with NO barrier: L and the diagonal
+    // inverses are only read, and the wave keeps its finished blocks W_kj in registers -- a block in MFMA accumulator layout (register
+    // r of a lane = row 4 r + lane / 16, column lane % 16) is exactly the B operand of k-group r.  Results go straight to the global
+    // tile inverse; the loop at the end writes only the diagonal blocks and the zeros above them.
+    double* Wt = invd + (int64_t)t * MOGP_TILE * MOGP_TILE;
+    const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int j = wave + 4 * jj;
-            tacc[jj] = (d4_t){0.0, 0.0, 0.0, 0.0};
-            if (j < i) {
-                for (int k = j; k < i; ++k) {
-                    const double* La = M + lf_blk(i, k) + (lane & 15) * LF_BS + (lane >> 4);
-                    const double* Wb = M + lf_blk(k, j) + (lane >> 4) * LF_BS + (lane & 15);
+    for (int half = 0; half < 2; ++half) {
+        const int j = __builtin_amdgcn_readfirstlane(half == 0 ? wave : 7 - wave);
+        d4_t wcol[8];
 #pragma unroll
-                    for (int k4 = 0; k4 < 4; ++k4)
-                        tacc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(La[4 * k4], Wb[4 * k4 * LF_BS], tacc[jj], 0, 0, 0);
+        for (int k = 0; k < 8; ++k) wcol[k] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        {
+            const double* Dj = M + lf_blk(j, j) + lk * LF_BS + lr;            // W_jj in accumulator layout
+            d4_t v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = Dj[4 * r * LF_BS];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (k == j) wcol[k] = v;
+        }
+#pragma unroll
+        for (int i = 1; i < 8; ++i) {
+            if (i > j) {
+                d4_t tacc = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    if (k >= j && k < i) {
+                        const double* La = M + lf_blk(i, k) + lr * LF_BS + lk;
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; ++k4) tacc = __builtin_amdgcn_mfma_f64_16x16x4f64(La[4 * k4], wcol[k][k4], tacc, 0, 0, 0);
+                    }
                 }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int j = wave + 4 * jj;
-            if (j < i) {
                 d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
-                const double* Wa = M + lf_blk(i, i) + (lane & 15) * LF_BS + (lane >> 4);
+                const double* Wa = M + lf_blk(i, i) + lr * LF_BS + lk;
 #pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wa[4 * k4], tacc[jj][k4], acc, 0, 0, 0);
-                double* Wo = M + lf_blk(i, j) + (lane >> 4) * LF_BS + (lane & 15);
+                for (int k4 = 0; k4 < 4; ++k4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wa[4 * k4], tacc[k4], acc, 0, 0, 0);
+                wcol[i] = acc;
+                double* Wo = Wt + (int64_t)(16 * i + lk) * MOGP_TILE + 16 * j + lr;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Wo[4 * r * LF_BS] = acc[r];
+                for (int r = 0; r < 4; ++r) Wo[4 * r * MOGP_TILE] = acc[r];
             }
         }
-        __syncthreads();
     }
 
-    double* Wt = invd + (int64_t)t * MOGP_TILE * MOGP_TILE;
+    // diagonal 16 x 16 blocks of the tile inverse (from LDS) and zeros above them; the blocks below were written by the column waves
     for (int it = 0; it < 32; ++it) {
         const int idx = it * 256 + tid, r = idx >> 6, c = (idx & 63) * 2;
+        if ((c >> 4) < (r >> 4)) continue;
         d2_t v = (d2_t){0.0, 0.0};
-        if ((c >> 4) <= (r >> 4)) v = *reinterpret_cast<const d2_t*>(M + lf_at(r, c));
+        if ((c >> 4) == (r >> 4)) v = *reinterpret_cast<const d2_t*>(M + lf_at(r, c));
         if (c > r) v[0] = 0.0;
         if (c + 1 > r) v[1] = 0.0;
         *reinterpret_cast<d2_t*>(Wt + r * MOGP_TILE + c) = v;

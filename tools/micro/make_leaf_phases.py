@@ -14,8 +14,8 @@ edits = [
     ('                    if ((cnt & 3) == wave) lf_update(M, i, j, sb, lane);\n        }\n        __syncthreads();\n    }\n',
      '                    if ((cnt & 3) == wave) lf_update(M, i, j, sb, lane);\n        }\n        __syncthreads();\n        MARK(3 + 2 * sb);\n    }\n'),
     ('    // ---- TRTRI: diagonal 16x16 inverses, one column per lane', '    MARK(20);\n    // ---- TRTRI: diagonal 16x16 inverses, one column per lane'),
-    ('    // ---- TRTRI: block rows 1..7 in place.', '    MARK(21);\n    // ---- TRTRI: block rows 1..7 in place.'),
-    ('    double* Wt = invd + (int64_t)t * MOGP_TILE * MOGP_TILE;\n    for (int it = 0; it < 32; ++it) {', '    MARK(22);\n    double* Wt = invd + (int64_t)t * MOGP_TILE * MOGP_TILE;\n    for (int it = 0; it < 32; ++it) {'),
+    ('    // ---- TRTRI, off-diagonal blocks:', '    MARK(21);\n    // ---- TRTRI, off-diagonal blocks:'),
+    ('    // diagonal 16 x 16 blocks of the tile inverse (from LDS)', '    MARK(22);\n    // diagonal 16 x 16 blocks of the tile inverse (from LDS)'),
     ('        *reinterpret_cast<d2_t*>(Wt + r * MOGP_TILE + c) = v;\n    }\n}\n', '        *reinterpret_cast<d2_t*>(Wt + r * MOGP_TILE + c) = v;\n    }\n    MARK(23);\n}\n'),
 ]
 for old, new in edits:
