@@ -222,6 +222,40 @@ def test_bnse_on_device_matches_reference():
     assert relerr(mu2, fx["mu2"]) < 1e-5 and relerr(var2, fx["var2"]) < 1e-5
 
 
+def test_cfg3_size_gradient_is_the_derivative_of_the_lml():
+    """BASELINE.json configs[2] (MOSM C=8 Q=5 N=32768) cannot be run by the reference in the build container (its autograd working set
+    exceeds the memory), so there is no golden vector at this size.  Size-independent property instead: the gradient the device returns
+    is the derivative of the LML it returns -- central difference along a random direction in raw-parameter space."""
+    C, Q, N = 8, 5, 32768
+    X, y = synth.make_data(N, C)
+    h = synth.mosm_hypers(C, Q)
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
+    for name in ("weight", "mean", "variance", "delay", "phase"):
+        getattr(k, name).assign(h[name])
+    m = gpr.Exact(k, X, y, variance=h["scale"] ** 2)
+    m.likelihood.scale.assign(h["scale"])
+    loss0 = float(m.loss())
+    params = list(m.parameters())
+    g = [p.grad.copy() for p in params]
+    raw0 = [p.data.copy() for p in params]
+    rng = np.random.default_rng(3)
+    d = [rng.standard_normal(p.data.shape) for p in params]
+    nrm = np.sqrt(sum(float(np.sum(v * v)) for v in d))
+    d = [v / nrm for v in d]
+    gd = sum(float(np.sum(a * b)) for a, b in zip(g, d))
+    eps = 1e-4
+    vals = []
+    for sgn in (+1.0, -1.0):
+        for p, r, v in zip(params, raw0, d):
+            p.data = r + sgn * eps * v
+        vals.append(-float(m.log_marginal_likelihood()))
+    for p, r in zip(params, raw0):
+        p.data = r
+    fd = (vals[0] - vals[1]) / (2.0 * eps)
+    assert np.isfinite(loss0) and abs(gd) > 1e-3 * np.sqrt(sum(float(np.sum(a * a)) for a in g)) * 1e-3
+    assert abs(fd - gd) < 1e-5 * abs(gd) + 1e-7 * abs(loss0), (fd, gd, loss0)
+
+
 def test_cfg4_predict_golden():
     """BASELINE.json configs[3]: CSM C=4 Q=3 N=16384, predictive mean/variance at S=4096 (64 probe rows stored)."""
     fx = load("cfg4.npz")
