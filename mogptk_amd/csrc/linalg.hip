@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
         if (g.mode == GM_LOWER || g.mode == GM_LAUUM) { ti = tri_row(bid); tj = bid - ti * (ti + 1) / 2; }
         else { ti = bid / g.nt; tj = bid - ti * g.nt; }
         if (g.mode == GM_RECT_LOWER && (ti + 1) * TMR <= tj * TNC) return;        // tile entirely above the diagonal
-        if (g.row_mod > 1 && ((ti + g.row_off) % g.row_mod) != g.row_rem) return;  // tile row owned by another rank
+        if (g.row_mod > 1 && (((ti >> g.row_shift) + g.row_off) % g.row_mod) != g.row_rem) return;  // tile row owned by another rank
         int64_t k0 = 0, k1 = g.K;
         if (g.mode == GM_LAUUM || g.mode == GM_KLO_I) k0 = (int64_t)ti * TMR;
         if (g.mode == GM_KLO_J) k0 = (int64_t)tj * TNC;

@@ -80,6 +80,7 @@ int sweep_block(mogp_model* m, Spd& w, int kb) {
     if (below > 0) {
         GemmArgs g = upd(Uc, Kd, 0, P, Kd, 0, Acol, ld, GM_RECT, 2 * below, nk, Kd, 1);
         g.alpha = 1.0; g.beta = 0.0;
+        g.row_mod = rm; g.row_rem = rr; g.row_off = k1; g.row_shift = 1;    // sharded: X = U P only for the tile rows this rank updates
         RC(gemm_call(m, g, gemm_flops(g, nullptr), q1));
     }
     if (k0 > 0) {
