@@ -53,13 +53,19 @@ struct P1Step {
         const double rs = fast_rsqrt(d);
         a[K] *= rs;
         if (writer) invdiag[sb * 16 + K] = rs;
+        // four broadcasts, then four updates: distinct scalar pairs, so the v_readlane -> VALU hazard slots are shared instead of paid
+        // per update.  The updates are pinned here: left to itself the optimiser sinks them to the column that first needs a[j], keeps
+        // every broadcast (30 SGPRs per column) alive until then, overflows the scalar file and pays a v_writelane / v_readlane pair
+        // per value.
 #pragma unroll
-        for (int j = K + 1; j < 16; ++j) {
-            const double ljk = readlane_d(a[K], j);
-            a[j] = fma(-a[K], ljk, a[j]);
-            // pin the update here: left to itself the optimiser sinks it to the column that first needs a[j], keeps every broadcast
-            // (30 SGPRs per column) alive until then, overflows the scalar file and pays a v_writelane / v_readlane pair per value
-            asm volatile("" : "+v"(a[j]));
+        for (int j0 = K + 1; j0 < 16; j0 += 4) {
+            double l[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) l[u] = (j0 + u < 16) ? readlane_d(a[K], (j0 + u < 16) ? j0 + u : 15) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (j0 + u < 16) a[j0 + u] = fma(-a[K], l[u], a[j0 + u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (j0 + u < 16) asm volatile("" : "+v"(a[j0 + u]));
         }
         P1Step<K + 1>::run(a, invdiag, sb, writer, fail);
     }
