@@ -11,7 +11,7 @@ from .gpr.model import CholeskyException
 from .util import *
 from .dataset import Data, DataSet, TransformBase
 from .model import Model, Exact, Titsias, LoadModel
-from .wrappers import MOSM, SM, CSM, SM_LMC
+from .wrappers import MOSM, SM, CSM, SM_LMC, CONV
 from .init import BNSE
 from . import gpr
 from .dist import use_distributed, use_single_device

@@ -402,3 +402,47 @@ class LinearModelOfCoregionalizationKernel(MultiOutputKernel):
             k._spectral_backward(gsub[None, None])
             t0 += T
         self._weight_backward(gB)
+
+
+class GaussianConvolutionProcessKernel(MultiOutputKernel):
+    """
+    CONV (reference gpr/multioutput.py:504-553): K_ij = w_i w_j sqrt(prod b / prod s_ij) exp(-1/2 sum_d tau_d^2 / s_ij,d) with
+    s_ij = v_i + v_j + b.  One Gaussian term per channel pair in the term table (V = 1 / s_ij, no cosine: M = Delta = Psi = 0); the
+    reference's `X2 is None` branch (:536-540) is the i == j case of the same expression.  Use `MixtureKernel(..., Q)`.
+    Parameters: weight (C,) > 0, variance (C, D) >= 0, base_variance (D,) > 0.
+    """
+
+    def __init__(self, output_dims, input_dims=1, active_dims=None):
+        super().__init__(output_dims, input_dims, active_dims)
+        self.input_dims = input_dims
+        self.weight = Parameter(np.ones(output_dims), lower=config.positive_minimum)
+        self.variance = Parameter(np.ones((output_dims, input_dims)), lower=0.0)
+        self.base_variance = Parameter(np.ones(input_dims), lower=config.positive_minimum)
+
+    def _parts(self):
+        w, v, b = self.weight(), self.variance(), self.base_variance()
+        s = v[:, None, :] + v[None, :, :] + b                               # (C,C,D)
+        A = w[:, None] * w[None, :] * np.sqrt(np.prod(b) / np.prod(s, axis=2))
+        return w, v, b, s, A
+
+    @cached_terms
+    def _spectral_terms(self, D):
+        if D != self.input_dims:
+            raise ValueError("X must have %d input dimensions" % self.input_dims)
+        w, v, b, s, A = self._parts()
+        C = self.output_dims
+        table = np.zeros((C, C, 1, term_width(D)))
+        table[:, :, 0, 0] = A
+        table[:, :, 0, 2:2 + D] = 1.0 / s
+        return table
+
+    def _spectral_backward(self, gtable):
+        D = self.input_dims
+        w, v, b, s, A = self._parts()
+        gA = gtable[:, :, 0, 0]                                               # pairs i >= j, double count included
+        gV = gtable[:, :, 0, 2:2 + D]
+        gAA = gA * A
+        gs = -0.5 * gAA[:, :, None] / s - gV / (s * s)                       # d loss / d s_ij,d
+        _accumulate(self.weight, (np.sum(gAA, axis=1) + np.sum(gAA, axis=0)) / w)
+        _accumulate(self.variance, np.sum(gs, axis=1) + np.sum(gs, axis=0))   # s_ij depends on v_i and on v_j (twice on v_i when i == j)
+        _accumulate(self.base_variance, np.sum(gs, axis=(0, 1)) + 0.5 * np.sum(gAA) / b)

@@ -1,5 +1,5 @@
 """
-Model wrappers MOSM / SM / CSM / SM_LMC -- host-side mirror of mogptk/models/{mosm,sm,csm,sm_lmc}.py constructors.
+Model wrappers MOSM / SM / CSM / SM_LMC / CONV -- host-side mirror of mogptk/models/{mosm,sm,csm,sm_lmc,conv}.py constructors.
 
 Constructor semantics are part of the drop-in boundary and are reproduced including quirk Q2
 (SURVEY.md 8b): the Nyquist re-bounding `mean.assign(upper=...)` at mosm.py:60 / sm.py:60 / csm.py:64
@@ -11,7 +11,8 @@ import numpy as np
 from .dataset import DataSet
 from .model import Model, Exact, logger
 from .gpr import (MultiOutputSpectralMixtureKernel, IndependentMultiOutputKernel, SpectralMixtureKernel,
-                  CrossSpectralKernel, MixtureKernel, LinearModelOfCoregionalizationKernel, SpectralKernel)
+                  CrossSpectralKernel, MixtureKernel, LinearModelOfCoregionalizationKernel, SpectralKernel,
+                  GaussianConvolutionProcessKernel)
 
 
 def _rand(*shape):
@@ -240,4 +241,36 @@ class SM_LMC(Model):
             self.gpr.kernel[q].mean.assign(means[q, :])
             self.gpr.kernel[q].variance.assign(variances[q, :])
         self.gpr.kernel.weight.assign(constant)
+        _init_noise(self)
+
+
+class CONV(Model):
+    """Convolutional Gaussian model with Q components (reference models/conv.py:8-52)."""
+
+    def __init__(self, dataset, Q=1, inference=Exact(), mean=None, name="CONV"):
+        if not isinstance(dataset, DataSet):
+            dataset = DataSet(dataset)
+        output_dims = dataset.get_output_dims()
+        input_dims = dataset.get_input_dims()[0]
+        for input_dim in dataset.get_input_dims()[1:]:
+            if input_dim != input_dims:
+                raise ValueError("input dimensions for all channels must match")
+        conv = GaussianConvolutionProcessKernel(output_dims=output_dims, input_dims=input_dims)
+        kernel = MixtureKernel(conv, Q)
+        for q in range(Q):
+            kernel[q].weight.assign(_rand(output_dims))
+            kernel[q].variance.assign(_rand(output_dims, input_dims))
+            kernel[q].base_variance.assign(_rand(input_dims))
+        super().__init__(dataset, kernel, inference, mean, name)
+        self.Q = Q
+
+    def init_parameters(self, method="SM", iters=500):
+        """reference models/conv.py:54-97"""
+        est = _estimate(self, method, iters, "MOSM")           # (sic, conv.py:82)
+        if est is None:
+            return
+        amplitudes, means, variances = est
+        for q in range(self.Q):
+            self.gpr.kernel[q].weight.assign([5.0 * amplitude[q, :].mean() for amplitude in amplitudes])
+            self.gpr.kernel[q].variance.assign([10.0 * variance[q, :] for variance in variances])
         _init_noise(self)

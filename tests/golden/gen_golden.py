@@ -108,6 +108,12 @@ def build_kernel(kind, C, Q, D, Rq, rng):
             k[q].magnitude.assign(rng.uniform(0.5, 1.5, 3))
             k[q].mean.assign(rng.uniform(0.05, 0.5, (3, D)))
             k[q].variance.assign(rng.uniform(0.01, 0.1, (3, D)))
+    elif kind == "conv":       # MixtureKernel(GaussianConvolutionProcessKernel)
+        k = g.MixtureKernel(g.GaussianConvolutionProcessKernel(output_dims=C, input_dims=D), Q)
+        for q in range(Q):
+            k[q].weight.assign(rng.uniform(0.5, 1.5, C))
+            k[q].variance.assign(rng.uniform(0.05, 1.0, (C, D)))
+            k[q].base_variance.assign(rng.uniform(0.1, 1.0, D))
     return k
 
 
@@ -144,6 +150,8 @@ KERNEL_CASES_8F2 = [  # the multi-output kernels that share MOSM's 
     ("lmc", 3, 2, 1, 2, 42, 14, False),
     ("lmc", 2, 3, 2, 1, 36, 12, True),
     ("lmc_sm", 2, 2, 1, 1, 30, 11, False),
+    ("conv", 3, 2, 1, 1, 40, 13, False),
+    ("conv", 2, 1, 2, 1, 34, 12, True),
 ]
 
 
@@ -204,6 +212,8 @@ LML_CASES_8F2 = [
     ("lmc_c3q2r2", "lmc", 3, 2, 1, 2, 84, False, False),
     ("lmc_c2q3_d2", "lmc", 2, 3, 2, 1, 60, True, False),
     ("lmcsm_c2q2", "lmc_sm", 2, 2, 1, 1, 66, False, False),
+    ("conv_c3q2", "conv", 3, 2, 1, 1, 78, False, False),
+    ("conv_c2q1_d2", "conv", 2, 1, 2, 1, 60, True, False),
 ]
 
 

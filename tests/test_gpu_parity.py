@@ -42,7 +42,7 @@ def test_gram_matches_reference_fixtures(fixture):
 
 LML = ["mosm_c3q2", "mosm_c2q3_shuf", "mosm_c3q2_d2", "mosm_c1q2", "mosm_scalarvar", "sm_c1q3", "sm_c2q2_d2",
        "csm_c3q2", "csm_c2q2r2",
-       "mosk_c3q2", "mosk_c2q1_d2", "umosm_c3q2", "umosm_c2q2_d2", "lmc_c3q2r2", "lmc_c2q3_d2", "lmcsm_c2q2"]          # same term table, other parameter algebra
+       "mosk_c3q2", "mosk_c2q1_d2", "umosm_c3q2", "umosm_c2q2_d2", "lmc_c3q2r2", "lmc_c2q3_d2", "lmcsm_c2q2", "conv_c3q2", "conv_c2q1_d2"]          # same term table, other parameter algebra
 
 
 @pytest.mark.parametrize("name", LML)
