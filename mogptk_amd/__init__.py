@@ -9,7 +9,9 @@ Every O(N^2)/O(N^3) stage runs in hand-written HIP (gfx950) behind the C ABI of 
 from .gpr.config import *
 from .gpr.model import CholeskyException
 from .util import *
-from .dataset import Data, DataSet, TransformBase
+from .dataset import Data, DataSet
+from .transformer import (Transformer, TransformBase, TransformDetrend, TransformLinear, TransformNormalize, TransformLog,
+                          TransformStandard)
 from .model import Model, Exact, Titsias, LoadModel
 from .wrappers import MOSM, SM, CSM, SM_LMC, CONV
 from .init import BNSE

@@ -8,17 +8,7 @@ pandas loaders, masks, detrending, plotting) is host-side O(N) work outside the 
 import numpy as np
 
 
-class TransformBase:
-    """identity Y transformer (reference transformer.py: forward/backward(y, x))"""
-
-    def set_data(self, data):
-        pass
-
-    def forward(self, y, x=None):
-        return y
-
-    def backward(self, y, x=None):
-        return y
+from .transformer import Transformer, TransformBase
 
 
 class Data:
@@ -36,8 +26,12 @@ class Data:
         self.Y_err = None if Y_err is None else np.asarray(Y_err, dtype=np.float64).reshape(-1)
         self.name = name
         self.mask = np.ones(Y.shape[0], dtype=bool)
-        self.Y_transformer = TransformBase()
+        self.Y_transformer = Transformer()
         self.X_pred = X
+
+    def transform(self, transformer):
+        """fit a Y transformer (class or instance) on the data as transformed so far and append it -- reference data.py:457-471"""
+        self.Y_transformer.append(transformer, self.Y, self.X)
 
     def get_name(self):
         return self.name
@@ -249,6 +243,11 @@ class DataSet:
         X = self._format_X(X)
         for j, c in enumerate(self.channels):
             c.X_pred = X[j]
+
+    def transform(self, transformer):
+        """the same Y transformer (fitted per channel) on every channel -- reference dataset.py:transform"""
+        for channel in self.channels:
+            channel.transform(transformer)
 
     def get_ls_estimation(self, Q=1, n=10000):
         """per channel -- reference dataset.py:579-603"""

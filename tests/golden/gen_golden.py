@@ -12,6 +12,7 @@ nothing of the reference travels.  Re-run:  python tests/golden/gen_golden.py [-
   sm_lmc.npz     the SM_LMC wrapper: constructor state, loss + gradient, a short Adam trace
   init_ls.npz    Lomb-Scargle peak estimates and init_parameters('LS') of MOSM / SM / CSM / SM_LMC
   bnse.npz       BNSE spectra (init.py), BNSE peak estimates and MOSM.init_parameters('BNSE')
+  transformers.npz Y transformers alone and chained; the raw airline series of configs[0]
   lbfgs_cfg1.npz the same model under train('LBFGS'): fixed-step and strong-Wolfe loss traces by function evaluation
   cfg2.npz      [--full] MOSM C=4 Q=3 N=8192 LML + gradient (BASELINE.json configs[1]; ~20 s, 10 GB)
   cfg4.npz      [--full] CSM C=4 Q=3 N=16384 predict_f at 64 probe rows of S=4096 (configs[3]; ~40 s, 16 GB)
@@ -456,6 +457,32 @@ def gen_bnse():
     print("bnse.npz written; PSD peak at %.4f" % w[np.argmax(mu)])
 
 
+def gen_transformers():
+    """Y transformers (transformer.py) one by one and chained, on seeded data and on the airline-passenger series of configs[0]
+    (raw series stored: 144 points; its transformed version is what adam_cfg1.npz holds)"""
+    rng = np.random.default_rng(9)
+    x = np.sort(rng.uniform(0, 20, 60)).reshape(-1, 1)
+    y = 5.0 + 0.8 * x[:, 0] + 0.05 * x[:, 0] ** 2 + np.sin(x[:, 0]) + 0.1 * rng.standard_normal(60)
+    out = {"x": x, "y": y}
+    cases = {"detrend2": [mogptk.TransformDetrend(degree=2)], "linear": [mogptk.TransformLinear(bias=1.5, slope=0.7)],
+             "normalize": [mogptk.TransformNormalize], "log": [mogptk.TransformLog], "standard": [mogptk.TransformStandard],
+             "chain": [mogptk.TransformDetrend(degree=1), mogptk.TransformLog, mogptk.TransformStandard()]}
+    for name, ts in cases.items():
+        d = mogptk.Data(x[:, 0].copy(), y.copy())
+        for t in ts:
+            d.transform(t)
+        _, yt = d.get_data(transformed=True)
+        out[name + "_fwd"] = yt
+        out[name + "_bwd"] = d.Y_transformer.backward(yt + 0.25, d.X)
+    air = np.loadtxt("/root/reference/examples/data/Airline_passenger.csv")
+    out["air_x"] = air[:, 0]; out["air_y"] = air[:, 1]
+    d = mogptk.Data(air[:, 0], air[:, 1], name="airline")
+    d.transform(mogptk.TransformDetrend(degree=2)); d.transform(mogptk.TransformStandard())
+    out["air_yt"] = d.get_data(transformed=True)[1]
+    np.savez_compressed(os.path.join(HERE, "transformers.npz"), **out)
+    print("transformers.npz written")
+
+
 def gen_cfg2():
     import time
     C, Q, N = 4, 3, 8192
@@ -547,7 +574,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "lbfgs": gen_lbfgs_cfg1, "quirks": gen_quirks,
-             "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2, "smlmc": gen_smlmc, "init_ls": gen_init_ls, "bnse": gen_bnse,
+             "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2, "smlmc": gen_smlmc, "init_ls": gen_init_ls, "bnse": gen_bnse, "transformers": gen_transformers,
              "titsias": gen_titsias}
     full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:

@@ -290,6 +290,38 @@ def test_bnse_matches_reference():
         assert np.allclose(p(), f["cons"], rtol=1e-4, atol=1e-10), (p._name, p(), f["cons"])
 
 
+def test_transformers_match_reference_and_cfg1_end_to_end():
+    """Y transformers (reference transformer.py) alone and chained; and BASELINE.json configs[0] from the raw series: transforms ->
+    SM(Q=3) -> init_parameters('LS') reproduces the kernel-format data and the initial parameters of adam_cfg1.npz"""
+    fx = load("transformers.npz")
+    cases = {"detrend2": [mogptk_amd.TransformDetrend(degree=2)], "linear": [mogptk_amd.TransformLinear(bias=1.5, slope=0.7)],
+             "normalize": [mogptk_amd.TransformNormalize], "log": [mogptk_amd.TransformLog], "standard": [mogptk_amd.TransformStandard],
+             "chain": [mogptk_amd.TransformDetrend(degree=1), mogptk_amd.TransformLog, mogptk_amd.TransformStandard()]}
+    for name, ts in cases.items():
+        d = mogptk_amd.Data(fx["x"][:, 0].copy(), fx["y"].copy())
+        for t in ts:
+            d.transform(t)
+        _, yt = d.get_data(transformed=True)
+        assert relerr(yt, fx[name + "_fwd"]) < 1e-13, name
+        assert relerr(d.Y_transformer.backward(yt + 0.25, d.X), fx[name + "_bwd"]) < 1e-13, name
+    with pytest.raises(ValueError):
+        mogptk_amd.Transformer([object()])
+    d = mogptk_amd.Data(fx["air_x"], fx["air_y"], name="airline")
+    d.transform(mogptk_amd.TransformDetrend(degree=2)); d.transform(mogptk_amd.TransformStandard())
+    assert relerr(d.get_data(transformed=True)[1], fx["air_yt"]) < 1e-12
+    gold = load("adam_cfg1.npz")
+    model = mogptk_amd.SM(d, Q=3)
+    model.init_parameters("LS")
+    assert relerr(model.gpr.y[:, 0], gold["y"][:, 0]) < 1e-12
+    for p, f in zip(model.gpr.parameters(), fixture_params(gold, "init_")):
+        assert np.allclose(p(), f["cons"], rtol=1e-8, atol=1e-12), p._name
+    assert abs(model.log_marginal_likelihood() - float(gold["lml0"])) < 1e-7 * abs(float(gold["lml0"]))
+    losses, _ = model.train("Adam", iters=20, lr=float(gold["lr"]))
+    assert relerr(losses, gold["losses"][:21]) < 1e-6
+    X, mu, lo, up = model.predict(gold["pred_X"])             # back-transformed by default
+    assert np.all(np.isfinite(mu)) and mu.shape == (len(gold["pred_X"]),)
+
+
 def test_unsupported_paths_fail_loudly():
     with pytest.raises(NotImplementedError):
         gpr.use_single_precision()
