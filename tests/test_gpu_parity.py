@@ -59,7 +59,7 @@ def test_lml_and_gradient_match_reference_autograd(name):
             assert np.max(np.abs(p.grad - f["grad"])) <= 1e-7 * max(1.0, np.max(np.abs(f["grad"]))), (p._name, p.grad, f["grad"])
 
 
-@pytest.mark.parametrize("N,C,Q,D", [(300, 3, 2, 1), (517, 4, 3, 1), (260, 2, 9, 1), (200, 3, 2, 2), (129, 1, 2, 1)])
+@pytest.mark.parametrize("N,C,Q,D", [(300, 3, 2, 1), (517, 4, 3, 1), (260, 2, 9, 1), (200, 3, 2, 2), (129, 1, 2, 1), (1350, 3, 2, 1), (2900, 4, 1, 1)])
 def test_device_raw_outputs_against_numpy_model(N, C, Q, D):
     """moments / diagG / trG / alpha / L^-1 / K^-1 of the device against the numpy restatement: ragged channel sizes,
     N not a multiple of the 128 tile, more terms than one LDS chunk (Q=9), D=2."""
