@@ -139,8 +139,10 @@ class ExactHandle:
         self.D = X.shape[1] - 1
         self.C = C
         self.device = device
-        self._h = ctypes.c_void_p()
-        check(lib().mogp_model_create(context(device), self.N, self.D, C, _dp(X), _dp(y), ctypes.byref(self._h)))
+        h = ctypes.c_void_p()
+        self._h = ctypes.c_void_p()             # stays null if creation fails: close() / __del__ then have nothing to destroy
+        check(lib().mogp_model_create(context(device), self.N, self.D, C, _dp(X), _dp(y), ctypes.byref(h)))
+        self._h = h
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value is not None:

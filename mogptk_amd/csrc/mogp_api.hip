@@ -600,6 +600,7 @@ static int ctx_streams(mogp_ctx* ctx) {
 
 int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, const double* y, mogp_model** out) {
     if (!ctx || !X || !y || !out) return fail(MOGP_EINVAL, "mogp_model_create: null argument");
+    *out = nullptr;
     if (N <= 0 || D <= 0 || D > MOGP_MAXD || C <= 0) return fail(MOGP_EINVAL, "mogp_model_create: need N > 0, 0 < D <= 8, C > 0");
     int rc;
     if ((rc = use_device(ctx))) return rc;
@@ -633,10 +634,10 @@ int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, c
     TRY_HIP(hipMemcpy(m->d_tiles.p, m->tiles.data(), m->tiles.size() * sizeof(GTile), hipMemcpyHostToDevice));
     TRY_HIP(hipMemcpy(m->d_pair_start.p, m->pair_start.data(), m->pair_start.size() * sizeof(int), hipMemcpyHostToDevice));
     TRY_HIP(hipMemcpy(m->d_chan_off.p, m->sx.off.data(), (C + 1) * sizeof(int), hipMemcpyHostToDevice));
-    *out = m;
     TRY_RC(mogp_model_set_y(m, y));
 #undef TRY_RC
 #undef TRY_HIP
+    *out = m;                                   // only a fully built model is handed out (a failure above has destroyed it)
     return MOGP_OK;
 }
 

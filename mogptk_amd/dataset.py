@@ -43,11 +43,25 @@ class Data:
         return bool(np.any(~self.mask))
 
     def remove_randomly(self, n=None, pct=None, seed=None):
-        """reference data.py:658-690 (uniform removal of training points -> test points)"""
+        """reference data.py:683-705 (uniform removal of training points -> test points): `n` points, or a fraction `pct`; nothing when
+        neither is given.  `seed` (not in the reference, which draws from torch's global generator) makes the draw reproducible."""
         if n is None:
-            n = int((0.1 if pct is None else pct) * self.X.shape[0])
-        idx = np.random.default_rng(seed).choice(self.X.shape[0], n, replace=False)
+            n = 0 if pct is None else int(pct * len(self.Y))
+        elif isinstance(n, bool) or not isinstance(n, (int, np.integer)):
+            raise ValueError("n must be an integer")
+        idx = np.random.default_rng(seed).permutation(len(self.Y))[:n]
         self.mask[idx] = False
+
+    def remove_range(self, start=None, end=None, dim=None):
+        """reference data.py:731-775: the observations with start <= x <= end (all input dimensions, or `dim` only) become test points"""
+        D = self.get_input_dims()
+        dims = range(D) if dim is None else [dim]
+        lo = np.full(D, -np.inf) if start is None else np.broadcast_to(np.asarray(start, dtype=np.float64), (D,))
+        hi = np.full(D, np.inf) if end is None else np.broadcast_to(np.asarray(end, dtype=np.float64), (D,))
+        m = np.ones(len(self.Y), dtype=bool)
+        for i in dims:
+            m &= (self.X[:, i] >= lo[i]) & (self.X[:, i] <= hi[i])
+        self.mask[m] = False
 
     def get_data(self, transformed=False):
         if transformed:

@@ -276,7 +276,7 @@ class Exact(Model):
             gsc = 2.0 * sc * gnoise
         else:
             gsc = np.reshape(2.0 * sc * np.sum(gnoise), sc.shape)
-        scale.grad = -gsc * scale.dconstrained()
+        scale.accumulate_grad(-gsc)
         return np.float64(-res["lml"] - self.log_prior())
 
     def predict_f(self, X, full=False):
@@ -424,11 +424,11 @@ class Titsias(Model):
         # - 1/(2 s2) sum_k Kff_diag[k]  (gpr/model.py:723): K_diag is constant per channel
         self.kernel._spectral_diag_backward(0.5 * xc / s2, D)
         scale = self.likelihood.scale
-        scale.grad = np.reshape(-res["dsigma"], scale.data.shape) * scale.dconstrained()
+        scale.accumulate_grad(np.reshape(-res["dsigma"], scale.data.shape))
         gz = np.zeros(self.Z.data.shape)
         off = 0 if self.kernel.output_dims is None else 1
         gz[:, off:] = -res["gZ"]
-        self.Z.grad = gz
+        self.Z.accumulate_grad(gz)
         return np.float64(-res["elbo"] - self.log_prior())
 
     def predict_f(self, X, full=False):

@@ -17,9 +17,9 @@ PI = np.pi
 
 
 def _accumulate(p, gconstrained):
-    """constrained-space gradient -> raw-space `.grad` (Softplus/Sigmoid link, reference parameter.py:48-49,77-78)"""
-    g = gconstrained * p.dconstrained()
-    p.grad = g if p.grad is None else p.grad + g
+    """constrained-space gradient -> raw-space `.grad` (Softplus/Sigmoid link, reference parameter.py:48-49,77-78); a pegged
+    parameter hands it on to the parameter it follows"""
+    p.accumulate_grad(gconstrained)
 
 
 class IndependentMultiOutputKernel(MultiOutputKernel):

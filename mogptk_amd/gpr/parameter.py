@@ -101,6 +101,30 @@ class Sigmoid(Transform):
             return np.log(y) - np.log(1 - y)
 
 
+def _vjp(fn, x, g):
+    """g^T d fn(x)/dx for a small numpy-analytic `fn` (a peg transform): complex-step Jacobian, column by column; central
+    differences when `fn` does not accept complex input.  x has at most a few hundred entries."""
+    x = np.asarray(x, dtype=np.float64)
+    g = np.asarray(g, dtype=np.float64).reshape(-1)
+    out = np.zeros(x.size)
+    flat = x.reshape(-1)
+    for k in range(x.size):
+        try:
+            z = flat.astype(np.complex128)
+            z[k] += 1e-30j
+            col = np.imag(np.asarray(fn(z.reshape(x.shape)))).reshape(-1) / 1e-30
+            if not np.all(np.isfinite(col)):
+                raise ValueError
+        except Exception:
+            h = 1e-6 * max(1.0, abs(flat[k]))
+            a, b = flat.copy(), flat.copy()
+            a[k] += h
+            b[k] -= h
+            col = (np.asarray(fn(a.reshape(x.shape)), dtype=np.float64) - np.asarray(fn(b.reshape(x.shape)), dtype=np.float64)).reshape(-1) / (2 * h)
+        out[k] = np.dot(g, col)
+    return out.reshape(x.shape)
+
+
 class Parameter:
     """
     Parameter trained in an unconstrained space (reference parameter.py:99-346).
@@ -170,6 +194,20 @@ class Parameter:
         if self.transform is not None:
             return self.transform.dforward(self.data)
         return np.ones_like(self.data)
+
+    def accumulate_grad(self, gconstrained):
+        """add d loss / d constrained-value to the raw-space `.grad` of the parameter that OWNS the value.  A pegged parameter owns
+        nothing: the reference's autograd routes its gradient through `pegged_transform` to the parameter it follows
+        (parameter.py:186-201), and the pegged tensor itself keeps grad None (quirk Q3)."""
+        g = np.asarray(gconstrained, dtype=np.float64)
+        if self.pegged:
+            other = self.pegged_parameter
+            if self.pegged_transform is not None:
+                g = _vjp(self.pegged_transform, other.constrained, g)
+            other.accumulate_grad(np.reshape(g, other.data.shape))
+            return
+        g = g * self.dconstrained()
+        self.grad = g if self.grad is None else self.grad + g
 
     def numpy(self):
         return np.array(self.constrained)

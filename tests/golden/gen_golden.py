@@ -13,6 +13,8 @@ nothing of the reference travels.  Re-run:  python tests/golden/gen_golden.py [-
   init_ls.npz    Lomb-Scargle peak estimates and init_parameters('LS') of MOSM / SM / CSM / SM_LMC
   bnse.npz       BNSE spectra (init.py), BNSE peak estimates and MOSM.init_parameters('BNSE')
   transformers.npz Y transformers alone and chained; the raw airline series of configs[0]
+  opt_traces.npz train('SGD' | 'AdaGrad') traces, the per-iteration error= path and a continued train() call on the cfg1 model
+  peg.npz        loss + gradients of a model with pegged parameters (identity and 2x transforms)
   lbfgs_cfg1.npz the same model under train('LBFGS'): fixed-step and strong-Wolfe loss traces by function evaluation
   cfg2.npz      [--full] MOSM C=4 Q=3 N=8192 LML + gradient (BASELINE.json configs[1]; ~20 s, 10 GB)
   cfg4.npz      [--full] CSM C=4 Q=3 N=16384 predict_f at 64 probe rows of S=4096 (configs[3]; ~40 s, 16 GB)
@@ -354,6 +356,72 @@ def gen_lbfgs_cfg1():
     np.savez_compressed(os.path.join(HERE, "lbfgs_cfg1.npz"), **out)
 
 
+
+def _cfg1_model(remove=0):
+    air = np.loadtxt("/root/reference/examples/data/Airline_passenger.csv")
+    data = mogptk.Data(air[:, 0], air[:, 1], name="airline")
+    if remove:
+        data.remove_range(start=air[-remove, 0] - 1e-9)        # the last `remove` points become test points
+    data.transform(mogptk.TransformDetrend(degree=2))
+    data.transform(mogptk.TransformStandard())
+    torch.manual_seed(1)
+    model = mogptk.SM(data, Q=3)
+    model.init_parameters("LS")
+    return model
+
+
+def gen_opt_traces():
+    """SURVEY 8f-1 remainder: train('SGD') (plain and with momentum / nesterov / weight decay), train('AdaGrad') and the per-iteration
+    `error=` path (model.py:531-532: a full predict per iteration), on the cfg1 model; a continued second train() call
+    (iter_offset, model.py:501-509).  Inputs / initial parameters are those of adam_cfg1.npz."""
+    out = {}
+    runs = (("sgd", "SGD", dict(iters=12, lr=2e-4)),
+            ("sgd_mom", "sgd", dict(iters=12, lr=1e-4, momentum=0.9, nesterov=True, weight_decay=1e-3)),
+            ("adagrad", "AdaGrad", dict(iters=12, lr=0.05)),
+            ("adagrad_decay", "adagrad", dict(iters=12, lr=0.05, lr_decay=0.1, initial_accumulator_value=0.5)))
+    for tag, method, kw in runs:
+        model = _cfg1_model()
+        losses, _ = model.train(method, jit=False, **kw)
+        out[tag + "_losses"] = np.array(model.losses)
+        dump_params(tag + "_final_", list(model.gpr.parameters()), out)
+        print("%s: loss %.8f -> %.8f" % (tag, model.losses[0], model.losses[-1]))
+    # error= with held-out test points, then a continued call
+    model = _cfg1_model(remove=24)
+    out["err_X"] = model.gpr.X.numpy().copy(); out["err_y"] = model.gpr.y.numpy().copy()
+    dump_params("err_init_", list(model.gpr.parameters()), out)
+    losses, errors = model.train("Adam", iters=8, lr=0.05, error="MAE", jit=False)
+    out["err_losses"] = np.array(model.losses); out["err_errors"] = np.array(model.errors)
+    losses, errors = model.train("Adam", iters=5, lr=0.05, error="sMAPE", jit=False)
+    out["err_losses2"] = np.array(model.losses); out["err_errors2"] = np.array(model.errors); out["err_iters2"] = np.array(model.iters)
+    out["err_rmse_all"] = np.array(model.error("RMSE", use_all_data=True))
+    # error= without test data (falls back to all data), custom callable
+    model = _cfg1_model()
+    losses, errors = model.train("Adam", iters=4, lr=0.05, error=lambda yt, yp: float(np.max(np.abs(yt - yp))), jit=False)
+    out["errall_errors"] = np.array(model.errors)
+    np.savez_compressed(os.path.join(HERE, "opt_traces.npz"), **out)
+    print("opt_traces.npz written")
+
+
+def gen_peg():
+    """Parameter.peg (parameter.py:321-335): autograd sends a pegged parameter's gradient to the parameter it follows, through the
+    peg transform; the pegged tensor itself keeps grad None.  MOSM with channel 1's noise pegged to channel 0's... is not expressible
+    (one tensor); so: SM-in-IMO, kernel[1].mean pegged to 2 x kernel[0].mean, kernel[1].magnitude pegged to kernel[0].magnitude."""
+    rng = np.random.default_rng(909)
+    C, Q, D, N = 2, 2, 1, 64
+    X, y = small_data(N, C, D, 910)
+    k = build_kernel("sm", C, Q, D, 1, rng)
+    k[1].mean.peg(k[0].mean, lambda x: 2.0 * x)
+    k[1].magnitude.peg(k[0].magnitude)
+    scale = rng.uniform(0.1, 0.4, C)
+    m = g.Exact(k, T(X), T(y), variance=list(scale ** 2))
+    m.likelihood.scale.assign(scale)
+    out = {"meta": np.array([C, Q, D, 1]), "X": X, "y": y, "jitter": np.array(m.jitter)}
+    out["lml"] = np.array(float(m.log_marginal_likelihood()))
+    out["loss"] = np.array(float(m.loss()))
+    dump_params("", list(m.parameters()), out, with_grad=True)
+    np.savez_compressed(os.path.join(HERE, "peg.npz"), **out)
+    print("peg.npz lml=%.10f" % out["lml"], [None if p.grad is None else p.grad.shape for p in m.parameters()])
+
 def gen_quirks():
     """Q1/Q2 of SURVEY.md 8b as data."""
     out = {}
@@ -575,7 +643,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "lbfgs": gen_lbfgs_cfg1, "quirks": gen_quirks,
              "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2, "smlmc": gen_smlmc, "init_ls": gen_init_ls, "bnse": gen_bnse, "transformers": gen_transformers,
-             "titsias": gen_titsias}
+             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg}
     full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:
         {**steps, **full}[a.only]()

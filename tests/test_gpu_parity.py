@@ -446,3 +446,12 @@ def test_sharded_eval_ranks_sharing_one_gpu(ranks):
     assert r["world"] == ranks
     assert r["rel_loss"] < 1e-10, r
     assert r["rel_grad"] < 1e-7, r          # tolerance: 1e-5 (north_star); measured ~1e-10
+
+
+def test_sgd_adagrad_error_path_and_pegging_on_device():
+    """SURVEY 8f-1 remainder on the device: SGD / AdaGrad traces, the per-iteration error= path (a device prediction per iteration)
+    and pegged parameters, against the same reference recordings as the CPU suite"""
+    from test_host_logic import check_opt_traces, check_error_path, check_pegged_parameters
+    check_opt_traces(tol_loss=1e-8, tol_raw=1e-7)
+    check_error_path(tol=1e-6)
+    check_pegged_parameters()
