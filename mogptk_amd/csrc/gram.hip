@@ -2,119 +2,337 @@
 //
 // Every MOSM / SM / CSM channel-pair block is   K_ab = sum_t A_t exp(-1/2 sum_d V_td u_d^2) cos(2 pi (sum_d M_td u_d + Psi_t)),
 // u_d = x_a,d - x_b,d + Delta_td   (reference: gpr/multioutput.py:182-204, :432-449; gpr/singleoutput.py:594-600).
-// The cosine splits per point:  cos(2 pi (p_a - q_b)) = cos(2 pi p_a) cos(2 pi q_b) + sin(2 pi p_a) sin(2 pi q_b)  with
-// p_a = sum_d M_d (x_a,d + Delta_d) + Psi,  q_b = sum_d M_d x_b,d, so a 64x64 tile needs 2*64*T sincos (staged in LDS)
-// and one exp + a handful of FMAs per entry and term.  One workgroup = one 64x64 tile of one channel-pair block,
-// 256 threads, 4x4 entries per thread; rows of the output are written in 32-byte runs (coalesced across 16 lanes).
+//
+// Cosine: splits per point,  cos(2 pi (p_a - q_b)) = cos(2 pi p_a) cos(2 pi q_b) + sin(2 pi p_a) sin(2 pi q_b)  with
+// p_a = sum_d M_d (x_a,d + Delta_d) + Psi,  q_b = sum_d M_d x_b,d.  The per-point factors are computed ONCE per launch into a phase
+// table (k_phase_table: C T N sincospi instead of one per point and tile) and read back by the tiles.
+//
+// Gaussian: one 64x64 tile of sorted time series spans a small input range, so with the tile centres c_r, c_c
+// (p = x_a - c_r, q = x_b - c_c, s = c_r - c_c + Delta, u = p - q + s)
+//     exp(-1/2 V u^2) = exp(-1/2 V s^2) * exp(-1/2 V (p^2 + 2 p s)) * exp(-1/2 V (q^2 - 2 q s)) * exp(V p q)
+//                       per tile            per row                     per column                   per entry, |V p q| small.
+// The per-row / per-column factors are folded into the staged cosine factors (128 exp per tile and term instead of 4096) and the
+// cross term is a Taylor polynomial whose degree (4 .. 14) is chosen per tile and term from max |V p q| (truncation < 2e-17): an entry
+// costs one multiply, N FMAs and three more FMAs instead of a library exp.  Tiles whose inputs are spread too far for that (unsorted
+// rows, huge gaps) take the general path (exp per entry); a term whose Gaussian is below e^-50 everywhere in the tile is skipped
+// (absolute error < 2e-22 A).  One workgroup = one 64x64 tile of one channel-pair block, 256 threads, 4x4 entries per thread; full
+// interior tiles store 32-byte runs.
 #include "mogp_internal.h"
+
+#include <algorithm>
+#include <cstdlib>
 
 namespace mogp {
 
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ double frac_turn(double p) { return p - rint(p); }
 
-// stage per-point phase factors of one chunk of terms into LDS
-template <int DM>
-__device__ __forceinline__ void stage_phases(const double* __restrict__ tab, int W, int D, int t0, int nt, bool unit_amp,
-                                             const double (*s_xr)[MOGP_GT], const double (*s_xc)[MOGP_GT],
-                                             double (*s_cu)[MOGP_GT], double (*s_su)[MOGP_GT],
-                                             double (*s_cw)[MOGP_GT], double (*s_sw)[MOGP_GT],
-                                             double (*s_V)[DM], double (*s_Dl)[DM], int tid,
-                                             double (*s_M)[DM] = nullptr, double* s_A = nullptr) {
-    for (int idx = tid; idx < nt * MOGP_GT * 2; idx += 256) {
-        const int which = idx / (nt * MOGP_GT);
-        const int rem = idx - which * nt * MOGP_GT;
-        const int t = rem / MOGP_GT, p = rem - t * MOGP_GT;
-        const double* row = tab + (size_t)(t0 + t) * W;
-        double ph = which == 0 ? row[1] : 0.0;
-        for (int d = 0; d < D; ++d) {
-            const double m = row[2 + D + d];
-            ph = which == 0 ? fma(m, s_xr[d][p] + row[2 + 2 * D + d], ph) : fma(m, s_xc[d][p], ph);
-        }
-        double sn, cs;
-        sincospi(2.0 * frac_turn(ph), &sn, &cs);
-        if (which == 0) {
-            const double amp = unit_amp ? 1.0 : row[0];
-            s_cu[t][p] = amp * cs;
-            s_su[t][p] = amp * sn;
-        } else {
-            s_cw[t][p] = cs;
-            s_sw[t][p] = sn;
-        }
+#define GT_SKIP (-1)     // term negligible in this tile
+#define GT_GENERAL 0     // exp per entry
+#define GT_SKIP_EXPONENT 50.0
+
+// e^x for |x| < 700: Cody-Waite reduction, degree-13 Taylor on |r| <= ln2 / 2 (truncation 4e-18), ldexp
+__device__ __forceinline__ double fast_exp(double x) {
+    const double n = rint(x * 1.44269504088896338700e+00);
+    double r = fma(-n, 6.93147180369123816490e-01, x);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                  // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);                // 1/12!
+    p = fma(p, r, 2.505210838544172e-08);               // 1/11!
+    p = fma(p, r, 2.755731922398589e-07);               // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);              // 1/9!
+    p = fma(p, r, 2.48015873015873e-05);                // 1/8!
+    p = fma(p, r, 1.984126984126984e-04);               // 1/7!
+    p = fma(p, r, 1.388888888888889e-03);               // 1/6!
+    p = fma(p, r, 8.333333333333333e-03);               // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);              // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);              // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+// sum_{k <= N} z^k / k!   (Horner)
+template <int N>
+__device__ __forceinline__ double exp_taylor(double z) {
+    constexpr double c[15] = {1.0, 1.0, 0.5, 1.6666666666666666e-01, 4.1666666666666664e-02, 8.333333333333333e-03,
+                              1.388888888888889e-03, 1.984126984126984e-04, 2.48015873015873e-05, 2.7557319223985893e-06,
+                              2.755731922398589e-07, 2.505210838544172e-08, 2.08767569878681e-09, 1.6059043836821613e-10,
+                              1.1470745597729725e-11};
+    double p = c[N];
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) p = fma(p, z, c[k]);
+    return p;
+}
+
+// ---- phase table: cos / sin of the per-point phases, once per launch --------------------------------------------------------
+// role 0 (rows):    cs[(o T + t) ld + a] = cos 2 pi (sum_d M_d (x_a,d + Delta_d) + Psi)   of pair (chan(a), o), term t
+// role 1 (columns): cs[(o T + t) ld + b] = cos 2 pi (sum_d M_d x_b,d)                     of pair (o, chan(b)), term t
+struct PhaseArgs {
+    const double* x; int64_t ld; const int* off; const double* table; int T, D, C, role; double* cs; double* sn;
+};
+__global__ __launch_bounds__(256) void k_phase_table(PhaseArgs a) {
+    const int64_t pt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pt >= a.off[a.C]) return;
+    const int o = blockIdx.y, t = blockIdx.z, D = a.D, W = 2 + 3 * D;
+    int c = 0;
+    while (pt >= a.off[c + 1]) ++c;
+    const int pair = a.role == 0 ? c * a.C + o : o * a.C + c;
+    const double* row = a.table + ((size_t)pair * a.T + t) * W;
+    double ph = a.role == 0 ? row[1] : 0.0;
+    for (int d = 0; d < D; ++d) {
+        const double m = row[2 + D + d], xv = a.x[(size_t)d * a.ld + pt];
+        ph = a.role == 0 ? fma(m, xv + row[2 + 2 * D + d], ph) : fma(m, xv, ph);
     }
-    for (int idx = tid; idx < nt * D; idx += 256) {
-        const int t = idx / D, d = idx - t * D;
-        const double* row = tab + (size_t)(t0 + t) * W;
-        s_V[t][d] = row[2 + d];
-        s_Dl[t][d] = row[2 + 2 * D + d];
-        if (s_M) s_M[t][d] = row[2 + D + d];
-        if (s_A && d == 0) s_A[t] = row[0];
+    double sn, cs;
+    sincospi(2.0 * frac_turn(ph), &sn, &cs);
+    const size_t idx = ((size_t)o * a.T + t) * a.ld + pt;
+    a.cs[idx] = cs;
+    a.sn[idx] = sn;
+}
+
+// centre and half span of every 64-point block of every channel (the row / column ranges of the tiles), stored at the index of the
+// block's first point:  cen[d * ld + start], half[d * ld + start].  One wave per block.
+struct CentreArgs { const double* x; int64_t ld; const int* off; int C, D; double* cen; double* half; };
+__global__ __launch_bounds__(64) void k_block_centres(CentreArgs a) {
+    int b = blockIdx.x, c = 0;
+    for (; c < a.C; ++c) {
+        const int nb = (a.off[c + 1] - a.off[c] + MOGP_GT - 1) / MOGP_GT;
+        if (b < nb) break;
+        b -= nb;
+    }
+    if (c >= a.C) return;
+    const int start = a.off[c] + b * MOGP_GT, n = min(MOGP_GT, a.off[c + 1] - start), lane = threadIdx.x;
+    for (int d = 0; d < a.D; ++d) {
+        const double v = a.x[(size_t)d * a.ld + start + (lane < n ? lane : 0)];
+        double lo = v, hi = v;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lo = fmin(lo, __shfl_xor(lo, off, 64)); hi = fmax(hi, __shfl_xor(hi, off, 64)); }
+        if (lane == 0) { a.cen[(size_t)d * a.ld + start] = 0.5 * (lo + hi); a.half[(size_t)d * a.ld + start] = 0.5 * (hi - lo); }
     }
 }
 
-template <int DT>
-__global__ __launch_bounds__(256) void k_gram(GramArgs a) {
-    constexpr int DM = DT > 0 ? DT : MOGP_MAXD;
-    const int D = DT > 0 ? DT : a.D;
-    const int W = 2 + 3 * D;
-    const GTile tl = a.tiles[blockIdx.x];
-    const double* tab = a.table + (size_t)tl.pair * a.T * W;
-    const int tid = threadIdx.x;
-    const int cg = tid & 15, rg = tid >> 4;
+// workspace layout: [row cos | row sin] (C T ldr each) [col cos | col sin] (C T ldc each) [row centres | row half spans] (D ldr each)
+// [col centres | col half spans] (D ldc each)
+size_t phase_ws_doubles(int C, int T, int64_t ldr, int64_t ldc) { return (size_t)2 * (C * T + MOGP_MAXD) * (size_t)(ldr + ldc); }   // sized for any D
 
-    __shared__ double s_xr[DM][MOGP_GT], s_xc[DM][MOGP_GT];
-    __shared__ double s_cu[MOGP_TC][MOGP_GT], s_su[MOGP_TC][MOGP_GT], s_cw[MOGP_TC][MOGP_GT], s_sw[MOGP_TC][MOGP_GT];
-    __shared__ double s_V[MOGP_TC][DM], s_Dl[MOGP_TC][DM];
+struct PhaseView {                       // device pointers into the workspace of one launch
+    const double *rcs, *rsn, *ccs, *csn, *rcen, *rhalf, *ccen, *chalf;
+};
+__host__ __device__ static inline PhaseView phase_view(double* ws, int C, int T, int D, int64_t ldr, int64_t ldc) {
+    PhaseView v;
+    double* p = ws;
+    v.rcs = p; p += (size_t)C * T * ldr; v.rsn = p; p += (size_t)C * T * ldr;
+    v.ccs = p; p += (size_t)C * T * ldc; v.csn = p; p += (size_t)C * T * ldc;
+    v.rcen = p; p += (size_t)D * ldr; v.rhalf = p; p += (size_t)D * ldr;
+    v.ccen = p; p += (size_t)D * ldc; v.chalf = p;
+    return v;
+}
 
-    for (int idx = tid; idx < D * MOGP_GT * 2; idx += 256) {
-        const int which = idx / (D * MOGP_GT);
-        const int rem = idx - which * D * MOGP_GT;
-        const int d = rem / MOGP_GT, p = rem - d * MOGP_GT;
-        if (which == 0) s_xr[d][p] = p < tl.nr ? a.xr[(size_t)d * a.ldxr + tl.r0 + p] : 0.0;
-        else            s_xc[d][p] = p < tl.nc ? a.xc[(size_t)d * a.ldxc + tl.c0 + p] : 0.0;
+static int launch_phase_tables(const PhaseRef& ph, const double* xr, int64_t ldxr, int64_t nr, const double* xc, int64_t ldxc, int64_t nc,
+                               const double* table, int T, int D, int C, hipStream_t s) {
+    if (!ph.ws || !ph.offr || !ph.offc) { set_error("Gram / moment launch without a phase workspace"); return -1; }
+    const PhaseView v = phase_view(ph.ws, C, T, D, ldxr, ldxc);
+    PhaseArgs a;
+    a.table = table; a.T = T; a.D = D; a.C = C;
+    a.x = xr; a.ld = ldxr; a.off = ph.offr; a.role = 0; a.cs = const_cast<double*>(v.rcs); a.sn = const_cast<double*>(v.rsn);
+    if (nr > 0) hipLaunchKernelGGL(k_phase_table, dim3((unsigned)((nr + 255) / 256), C, T), dim3(256), 0, s, a);
+    a.x = xc; a.ld = ldxc; a.off = ph.offc; a.role = 1; a.cs = const_cast<double*>(v.ccs); a.sn = const_cast<double*>(v.csn);
+    if (nc > 0) hipLaunchKernelGGL(k_phase_table, dim3((unsigned)((nc + 255) / 256), C, T), dim3(256), 0, s, a);
+    CentreArgs c;
+    c.C = C; c.D = D;
+    c.x = xr; c.ld = ldxr; c.off = ph.offr; c.cen = const_cast<double*>(v.rcen); c.half = const_cast<double*>(v.rhalf);
+    if (nr > 0) hipLaunchKernelGGL(k_block_centres, dim3((unsigned)((nr + MOGP_GT - 1) / MOGP_GT + C)), dim3(64), 0, s, c);
+    c.x = xc; c.ld = ldxc; c.off = ph.offc; c.cen = const_cast<double*>(v.ccen); c.half = const_cast<double*>(v.chalf);
+    if (nc > 0) hipLaunchKernelGGL(k_block_centres, dim3((unsigned)((nc + MOGP_GT - 1) / MOGP_GT + C)), dim3(64), 0, s, c);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- per-tile staging shared by the Gram and the moment kernel -----------------------------------------------------------------
+// Everything a tile needs from global memory depends on its descriptor only and is requested in ONE batch (the thread's own centred
+// inputs, and for each of its staging items the term-table row, the point's input and its phase factors); every thread derives the
+// term's mode and tile scalars itself (a handful of flops, identical in all threads), so a chunk of terms costs one barrier.
+template <int DM>
+struct TileLds {
+    double cu[MOGP_TC][MOGP_GT], su[MOGP_TC][MOGP_GT], cw[MOGP_TC][MOGP_GT], sw[MOGP_TC][MOGP_GT];
+    double V[MOGP_TC][DM], s[MOGP_TC][DM], M[MOGP_TC][DM], A[MOGP_TC];
+    int deg[MOGP_TC];
+};
+template <int DM>
+struct TileCtx { double cr[DM], cc[DM], hr[DM], hc[DM]; };      // tile centres and half spans (rows, columns)
+
+template <int DM>
+__device__ __forceinline__ void tile_centres(TileCtx<DM>& X, const GTile& tl, int D, const PhaseView& v, int64_t ldxr, int64_t ldxc) {
+    for (int d = 0; d < D; ++d) {
+        X.cr[d] = v.rcen[(size_t)d * ldxr + tl.r0]; X.hr[d] = v.rhalf[(size_t)d * ldxr + tl.r0];
+        X.cc[d] = v.ccen[(size_t)d * ldxc + tl.c0]; X.hc[d] = v.chalf[(size_t)d * ldxc + tl.c0];
     }
-    bool any = false;
-    for (int t = 0; t < a.T; ++t) any |= (tab[(size_t)t * W] != 0.0);
+}
 
-    double acc[4][4];
+template <int DM>
+__device__ __forceinline__ void tile_context(TileCtx<DM>& X, double (&p)[4][DM], double (&q)[4][DM], const GTile& tl, int D,
+                                             const PhaseView& v, const double* __restrict__ xr, int64_t ldxr,
+                                             const double* __restrict__ xc, int64_t ldxc, int rg, int cg) {
+    tile_centres<DM>(X, tl, D, v, ldxr, ldxc);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = 0.0;
+        for (int d = 0; d < D; ++d) {
+            p[m][d] = xr[(size_t)d * ldxr + tl.r0 + min(rg * 4 + m, tl.nr - 1)] - X.cr[d];
+            q[m][d] = xc[(size_t)d * ldxc + tl.c0 + min(cg * 4 + m, tl.nc - 1)] - X.cc[d];
+        }
+}
 
-    if (any) {
-        for (int t0 = 0; t0 < a.T; t0 += MOGP_TC) {
-            const int nt = min(MOGP_TC, a.T - t0);
-            __syncthreads();
-            stage_phases<DM>(tab, W, D, t0, nt, false, s_xr, s_xc, s_cu, s_su, s_cw, s_sw, s_V, s_Dl, tid);
-            __syncthreads();
-            double xr[4][DM], xc[4][DM];
+constexpr int STAGE_ITEMS = MOGP_TC * MOGP_GT * 2 / 256;      // staging items per thread and chunk (4)
+template <int DM>
+struct StageItem { double x[DM], cs, sn; };                   // what is prefetched per item: the point's input and its phase factors
+
+template <int DM>
+__device__ __forceinline__ void stage_item_load(StageItem<DM>& I, int which, int t, int pnt, const GTile& tl, int D, int C, int T, int t0,
+                                                const PhaseView& v, const double* __restrict__ xr, int64_t ldxr,
+                                                const double* __restrict__ xc, int64_t ldxc) {
+    const int i = tl.pair / C, j = tl.pair - i * C;
+    if (which == 0) {
+        const int64_t g = tl.r0 + min(pnt, tl.nr - 1);
+        const size_t k = ((size_t)j * T + t0 + t) * ldxr + g;             // rows: table (j, t, point)
+        I.cs = v.rcs[k]; I.sn = v.rsn[k];
+        for (int d = 0; d < D; ++d) I.x[d] = xr[(size_t)d * ldxr + g];
+    } else {
+        const int64_t g = tl.c0 + min(pnt, tl.nc - 1);
+        const size_t k = ((size_t)i * T + t0 + t) * ldxc + g;             // columns: table (i, t, point)
+        I.cs = v.ccs[k]; I.sn = v.csn[k];
+        for (int d = 0; d < D; ++d) I.x[d] = xc[(size_t)d * ldxc + g];
+    }
+}
+
+// AMP: fold the amplitude A_t into the row factors (Gram); otherwise unit amplitude (moments).  `tab`: the pair's term rows (LDS copy or
+// global memory -- a generic pointer), W doubles each.
+template <int DM, bool AMP>
+__device__ __forceinline__ void stage_item_compute(TileLds<DM>& L, const StageItem<DM>& I, const TileCtx<DM>& X, const double* tab, int W,
+                                                   int which, int t, int pnt, int D, int t0) {
+    const double* row = tab + (size_t)(t0 + t) * W;
+    const double A = row[0];
+    double zmax = 0.0, es = 0.0, emin = 0.0, efac = 0.0, s[DM], V[DM];
+    for (int d = 0; d < D; ++d) {
+        V[d] = row[2 + d];
+        const double hr = X.hr[d], hc = X.hc[d];
+        s[d] = (X.cr[d] - X.cc[d]) + row[2 + 2 * D + d];
+        zmax += fabs(V[d]) * hr * hc;
+        es += V[d] * s[d] * s[d];
+        const double mu = fmax(0.0, fabs(s[d]) - hr - hc);                      // smallest |u_d| in the tile
+        emin += V[d] * mu * mu;
+        efac += fabs(V[d]) * (hr * hr + hc * hc + 2.0 * (hr + hc) * fabs(s[d]));    // bound on the row / column exponents
+    }
+    int deg;
+    if ((AMP && A == 0.0) || 0.5 * emin > GT_SKIP_EXPONENT) deg = GT_SKIP;
+    else if (!(zmax <= 0.45) || !(0.5 * es < 600.0) || !(0.5 * efac < 600.0)) deg = GT_GENERAL;
+    else deg = zmax <= 1.19e-3 ? 4 : (zmax <= 0.0139 ? 6 : (zmax <= 0.0578 ? 8 : (zmax <= 0.2147 ? 11 : 14)));
+    if (pnt == 0 && which == 0) {
+        L.deg[t] = deg; L.A[t] = A;
+        for (int d = 0; d < D; ++d) { L.V[t][d] = V[d]; L.s[t][d] = s[d]; L.M[t][d] = row[2 + D + d]; }
+    }
+    if (deg == GT_SKIP) return;
+    double f = 1.0;
+    if (deg != GT_GENERAL) {
+        double e = 0.0;
+        if (which == 0) {                                  // rows: exp(-1/2 V (p + s)^2), the tile scalar exp(-1/2 V s^2) included
+            for (int d = 0; d < D; ++d) { const double pp = I.x[d] - X.cr[d]; e = fma(V[d], fma(pp, pp, s[d] * s[d]) + 2.0 * pp * s[d], e); }
+        } else {                                           // columns: exp(-1/2 V (q^2 - 2 q s))
+            for (int d = 0; d < D; ++d) { const double qq = I.x[d] - X.cc[d]; e = fma(V[d], qq * qq - 2.0 * qq * s[d], e); }
+        }
+        f = fast_exp(-0.5 * e);
+    }
+    if (which == 0) {
+        if (AMP) f *= A;
+        L.cu[t][pnt] = f * I.cs; L.su[t][pnt] = f * I.sn;
+    } else {
+        L.cw[t][pnt] = f * I.cs; L.sw[t][pnt] = f * I.sn;
+    }
+}
+
+// Staging items of a chunk: (rows | columns) x term x point.  Wave w of the workgroup handles rows (w even) or columns (w odd) of the terms
+// w / 2, w / 2 + 2, w / 2 + 4, w / 2 + 6, lane = point: no index arithmetic, and which / t are wave-uniform.
+#define STAGE_MAP(tid) const int st_wave = __builtin_amdgcn_readfirstlane((tid) >> 6), st_which = st_wave & 1, st_tb = st_wave >> 1, st_pnt = (tid) & 63
+
+// one chunk of terms into LDS; BATCH: all items' loads first (one memory round trip), else item by item (large D: registers)
+template <int DM, bool AMP, bool BATCH>
+__device__ __forceinline__ void stage_chunk(TileLds<DM>& L, const TileCtx<DM>& X, const GTile& tl, const double* tab, int W, int D,
+                                            int C, int T, int t0, int nt, const PhaseView& v, const double* __restrict__ xr, int64_t ldxr,
+                                            const double* __restrict__ xc, int64_t ldxc, int tid) {
+    STAGE_MAP(tid);
+    if (BATCH) {
+        StageItem<DM> I[STAGE_ITEMS];
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-                for (int d = 0; d < D; ++d) { xr[m][d] = s_xr[d][rg * 4 + m]; xc[m][d] = s_xc[d][cg * 4 + m]; }
-            for (int t = 0; t < nt; ++t) {
-                double cu[4], su[4], cw[4], sw[4];
+        for (int k = 0; k < STAGE_ITEMS; ++k)
+            if (st_tb + 2 * k < nt) stage_item_load<DM>(I[k], st_which, st_tb + 2 * k, st_pnt, tl, D, C, T, t0, v, xr, ldxr, xc, ldxc);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    cu[m] = s_cu[t][rg * 4 + m]; su[m] = s_su[t][rg * 4 + m];
-                    cw[m] = s_cw[t][cg * 4 + m]; sw[m] = s_sw[t][cg * 4 + m];
-                }
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) {
-                        double arg = 0.0;
-                        for (int d = 0; d < D; ++d) {
-                            const double u = (xr[m][d] - xc[n][d]) + s_Dl[t][d];
-                            arg = fma(s_V[t][d] * u, u, arg);
-                        }
-                        const double e = exp(-0.5 * arg);
-                        acc[m][n] = fma(e, fma(cu[m], cw[n], su[m] * sw[n]), acc[m][n]);
-                    }
-            }
+        for (int k = 0; k < STAGE_ITEMS; ++k)
+            if (st_tb + 2 * k < nt) stage_item_compute<DM, AMP>(L, I[k], X, tab, W, st_which, st_tb + 2 * k, st_pnt, D, t0);
+    } else {
+        for (int t = st_tb; t < nt; t += 2) {
+            StageItem<DM> I;
+            stage_item_load<DM>(I, st_which, t, st_pnt, tl, D, C, T, t0, v, xr, ldxr, xc, ldxc);
+            stage_item_compute<DM, AMP>(L, I, X, tab, W, st_which, t, st_pnt, D, t0);
         }
     }
+}
 
-    // epilogue: diagonal augmentation + stores
+// Gaussian factor of one entry on the general path
+template <int DM>
+__device__ __forceinline__ double gauss_general(const double (&p)[DM], const double (&q)[DM], const double* V, const double* s, int D) {
+    double arg = 0.0;
+    for (int d = 0; d < D; ++d) { const double u = (p[d] - q[d]) + s[d]; arg = fma(V[d] * u, u, arg); }
+    return exp(-0.5 * arg);
+}
+
+template <int DM, int N>
+__device__ __forceinline__ void gram_term(double (&acc)[4][4], const double (&p)[4][DM], const double (&q)[4][DM], const double* V, const double* s,
+                                          int D, const double (&cu)[4], const double (&su)[4], const double (&cw)[4], const double (&sw)[4]) {
+    double vp[4][DM];
+    if (N > 0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            for (int d = 0; d < D; ++d) vp[m][d] = V[d] * p[m][d];
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        if (m == 2) __builtin_amdgcn_sched_barrier(0);      // two groups of eight independent Horner chains: enough to cover the FMA
+                                                            // latency, half the live registers of sixteen
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            double e;
+            if (N > 0) {
+                double z = vp[m][0] * q[n][0];
+                for (int d = 1; d < D; ++d) z = fma(vp[m][d], q[n][d], z);
+                e = exp_taylor<N>(z);
+            } else {
+                e = gauss_general<DM>(p[m], q[n], V, s, D);
+            }
+            acc[m][n] = fma(e, fma(cu[m], cw[n], su[m] * sw[n]), acc[m][n]);
+        }
+    }
+}
+
+// tile epilogue: full interior tiles store 32-byte runs; diagonal / ragged tiles take the per-element path (augmentation, lower part only)
+__device__ __forceinline__ void gram_store(const GramArgs& a, const GTile& tl, const double (&acc)[4][4], int rg, int cg) {
+    const bool full = tl.nr == MOGP_GT && tl.nc == MOGP_GT && !(tl.flags & GT_DIAG) && ((tl.c0 & 1) == 0) && ((a.ldo & 1) == 0);
+    if (full) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            double* o = a.out + (int64_t)(tl.r0 + rg * 4 + m) * a.ldo + tl.c0 + cg * 4;
+            *reinterpret_cast<d2_t*>(o) = (d2_t){acc[m][0], acc[m][1]};
+            *reinterpret_cast<d2_t*>(o + 2) = (d2_t){acc[m][2], acc[m][3]};
+        }
+        if (a.mirror && (tl.flags & GT_MIRROR)) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) a.out[(int64_t)(tl.c0 + cg * 4 + n) * a.ldo + tl.r0 + rg * 4 + m] = acc[m][n];
+        }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int lr = rg * 4 + m;
@@ -137,13 +355,132 @@ __global__ __launch_bounds__(256) void k_gram(GramArgs a) {
     }
 }
 
-int launch_gram(const GramArgs& a, int ntiles, hipStream_t s) {
+// Persistent workgroups (two per CU), software pipelined over tiles blockIdx.x, + gridDim.x, ...: a tile's global reads (its centred
+// inputs and staging items, all functions of the descriptor alone) are issued one tile ahead, before the previous tile's main loop, and
+// the descriptor itself two tiles ahead -- a tile-per-workgroup launch spends more time in these two dependent memory round trips than
+// in its arithmetic (measured: 66 of 126 us).  The staged factors are double buffered in LDS: one barrier per tile.
+template <int DT>
+__global__ __launch_bounds__(256, 2) void k_gram(GramArgs a, int ntiles) {
+    constexpr int DM = DT > 0 ? DT : MOGP_MAXD;
+    constexpr bool BATCH = DT == 1;
+    const int D = DT > 0 ? DT : a.D;
+    const int W = 2 + 3 * D;
+    const int tid = threadIdx.x;
+    const int cg = tid & 15, rg = tid >> 4;
+    __shared__ TileLds<DM> Lb[2];
+    extern __shared__ __attribute__((aligned(16))) double s_tab[];     // the whole term table when it fits (a.tab_lds)
+    const PhaseView v = phase_view(a.ph.ws, a.C, a.T, D, a.ldxr, a.ldxc);
+    const int stride = gridDim.x, nt0 = min(MOGP_TC, a.T);
+    STAGE_MAP(tid);
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    if (a.tab_lds) {
+        for (int e = tid; e < a.C * a.C * a.T * W; e += 256) s_tab[e] = a.table[e];
+        __syncthreads();
+    }
+    const double* tabbase = a.tab_lds ? s_tab : a.table;
+    GTile tl = a.tiles[tile];
+    GTile tl1 = a.tiles[min(tile + stride, ntiles - 1)];
+    TileCtx<DM> X;
+    double p[4][DM], q[4][DM];
+    StageItem<DM> I[BATCH ? STAGE_ITEMS : 1];
+    tile_context<DM>(X, p, q, tl, D, v, a.xr, a.ldxr, a.xc, a.ldxc, rg, cg);
+    if (BATCH) {
+#pragma unroll
+        for (int k = 0; k < STAGE_ITEMS; ++k)
+            if (st_tb + 2 * k < nt0) stage_item_load<DM>(I[k], st_which, st_tb + 2 * k, st_pnt, tl, D, a.C, a.T, 0, v, a.xr, a.ldxr, a.xc, a.ldxc);
+    }
+    int buf = 0;
+    while (true) {
+        TileLds<DM>& L = Lb[buf];
+        const GTile cur = tl;
+        const double* tab = tabbase + (size_t)cur.pair * a.T * W;
+        // stage this tile's first chunk of terms (from the prefetched registers when batched)
+        if (BATCH) {
+#pragma unroll
+            for (int k = 0; k < STAGE_ITEMS; ++k)
+                if (st_tb + 2 * k < nt0) stage_item_compute<DM, true>(L, I[k], X, tab, W, st_which, st_tb + 2 * k, st_pnt, D, 0);
+        } else {
+            stage_chunk<DM, true, false>(L, X, cur, tab, W, D, a.C, a.T, 0, nt0, v, a.xr, a.ldxr, a.xc, a.ldxc, tid);
+        }
+        double pc[4][DM], qc[4][DM];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            for (int d = 0; d < D; ++d) { pc[m][d] = p[m][d]; qc[m][d] = q[m][d]; }
+        // prefetch the next tile (its descriptor arrived during the previous iteration), and the descriptor after it
+        const int nxt = tile + stride;
+        const bool more = nxt < ntiles;
+        if (more) {
+            tl = tl1;
+            tl1 = a.tiles[min(nxt + stride, ntiles - 1)];
+            tile_context<DM>(X, p, q, tl, D, v, a.xr, a.ldxr, a.xc, a.ldxc, rg, cg);
+            if (BATCH) {
+#pragma unroll
+                for (int k = 0; k < STAGE_ITEMS; ++k)
+                    if (st_tb + 2 * k < nt0) stage_item_load<DM>(I[k], st_which, st_tb + 2 * k, st_pnt, tl, D, a.C, a.T, 0, v, a.xr, a.ldxr, a.xc, a.ldxc);
+            }
+        }
+        __syncthreads();
+
+        double acc[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = 0.0;
+        for (int t0 = 0; t0 < a.T; t0 += MOGP_TC) {
+            const int nt = min(MOGP_TC, a.T - t0);
+            if (t0 > 0) {                                   // more than MOGP_TC terms: the later chunks are staged in place
+                __syncthreads();
+                TileCtx<DM> Xc;
+                tile_centres<DM>(Xc, cur, D, v, a.ldxr, a.ldxc);
+                stage_chunk<DM, true, false>(L, Xc, cur, tab, W, D, a.C, a.T, t0, nt, v, a.xr, a.ldxr, a.xc, a.ldxc, tid);
+                __syncthreads();
+            }
+            for (int t = 0; t < nt; ++t) {
+                const int deg = L.deg[t];
+                if (deg == GT_SKIP || (a.dbg & 2)) continue;
+                double cu[4], su[4], cw[4], sw[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    cu[m] = L.cu[t][rg * 4 + m]; su[m] = L.su[t][rg * 4 + m];
+                    cw[m] = L.cw[t][cg * 4 + m]; sw[m] = L.sw[t][cg * 4 + m];
+                }
+                switch (deg) {
+                    case 4: gram_term<DM, 4>(acc, pc, qc, L.V[t], L.s[t], D, cu, su, cw, sw); break;
+                    case 6: gram_term<DM, 6>(acc, pc, qc, L.V[t], L.s[t], D, cu, su, cw, sw); break;
+                    case 8: gram_term<DM, 8>(acc, pc, qc, L.V[t], L.s[t], D, cu, su, cw, sw); break;
+                    case 11: gram_term<DM, 11>(acc, pc, qc, L.V[t], L.s[t], D, cu, su, cw, sw); break;
+                    case 14: gram_term<DM, 14>(acc, pc, qc, L.V[t], L.s[t], D, cu, su, cw, sw); break;
+                    default: gram_term<DM, 0>(acc, pc, qc, L.V[t], L.s[t], D, cu, su, cw, sw); break;
+                }
+            }
+        }
+        if (a.T > MOGP_TC) __syncthreads();                // the in-place chunks above must be consumed before this buffer is restaged
+        if (!((a.dbg & 1) && acc[0][0] != 12345.678)) gram_store(a, cur, acc, rg, cg);
+        if (!more) break;
+        tile = nxt;
+        buf ^= 1;
+    }
+}
+
+int launch_gram(const GramArgs& a0, int ntiles, hipStream_t s) {
     if (ntiles <= 0) return 0;
+    GramArgs a = a0;
+    static const int dbg = []() { const char* e = std::getenv("MOGP_GRAM_DBG"); return e ? std::atoi(e) : 0; }();
+    a.dbg = dbg;
+    int rc = launch_phase_tables(a.ph, a.xr, a.ldxr, a.nrows, a.xc, a.ldxc, a.ncols, a.table, a.T, a.D, a.C, s);
+    if (rc) return rc;
+    static const int ncu = []() { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256; return pr.multiProcessorCount; }();
+    const int grid = std::min(ntiles, 2 * ncu);              // persistent: two workgroups per CU (__launch_bounds__(256, 2))
+    const size_t tab_bytes = (size_t)a.C * a.C * a.T * (2 + 3 * a.D) * sizeof(double);
+    a.tab_lds = tab_bytes <= 24 * 1024;                      // the term table rides in LDS when small (it is read by every staging item)
+    const size_t dyn = a.tab_lds ? tab_bytes : 0;
     switch (a.D) {
-        case 1: hipLaunchKernelGGL(k_gram<1>, dim3(ntiles), dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(k_gram<2>, dim3(ntiles), dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(k_gram<3>, dim3(ntiles), dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(k_gram<0>, dim3(ntiles), dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL(k_gram<1>, dim3(grid), dim3(256), dyn, s, a, ntiles); break;
+        case 2: hipLaunchKernelGGL(k_gram<2>, dim3(grid), dim3(256), dyn, s, a, ntiles); break;
+        case 3: hipLaunchKernelGGL(k_gram<3>, dim3(grid), dim3(256), dyn, s, a, ntiles); break;
+        default: hipLaunchKernelGGL(k_gram<0>, dim3(grid), dim3(256), dyn, s, a, ntiles); break;
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -158,24 +495,69 @@ int launch_gram(const GramArgs& a, int ntiles, hipStream_t s) {
 // Dense mode (DENSE = true, Titsias):  g = weight * (G[a][b] + rcoef ru[a] rw[b]); weight as above when a.sym, else 1.
 // ZG: also accumulate the gradient w.r.t. the row / column INPUTS (inducing points):
 //     dK_ab/dx_a,d = sum_t A_t E [ -V_d u_d cos - 2 pi M_d sin ] = - dK_ab/dx_b,d.
+// A thread accumulates the W moments of its 16 entries of one term in registers; the workgroup reduction goes through LDS (16 slice sums
+// of 16 threads each, then a 4-step butterfly: fixed order, bit-reproducible) with ONE barrier per term.
+template <int DM, int N, bool ZG>
+__device__ __forceinline__ void moment_term(double* mom, const double (&g)[4][4], const double (&p)[4][DM], const double (&q)[4][DM],
+                                            const double* V, const double* s, const double* Mv, double A, int D,
+                                            const double (&cu)[4], const double (&su)[4], const double (&cw)[4], const double (&sw)[4],
+                                            double (&zr)[4][DM], double (&zc)[4][DM]) {
+    double vp[4][DM];
+    if (N > 0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            for (int d = 0; d < D; ++d) vp[m][d] = V[d] * p[m][d];
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            double u[DM];
+            for (int d = 0; d < D; ++d) u[d] = (p[m][d] - q[n][d]) + s[d];
+            double e;
+            if (N > 0) {
+                double z = vp[m][0] * q[n][0];
+                for (int d = 1; d < D; ++d) z = fma(vp[m][d], q[n][d], z);
+                e = exp_taylor<N>(z);
+            } else {
+                e = gauss_general<DM>(p[m], q[n], V, s, D);
+            }
+            const double ge = g[m][n] * e;
+            const double kc = ge * fma(cu[m], cw[n], su[m] * sw[n]);
+            const double ks = ge * fma(su[m], cw[n], -cu[m] * sw[n]);
+            mom[0] += kc;
+            mom[1] += ks;
+            for (int d = 0; d < D; ++d) {
+                const double uk = u[d] * kc;
+                mom[2 + d] = fma(u[d], uk, mom[2 + d]);
+                mom[2 + D + d] += uk;
+                mom[2 + 2 * D + d] = fma(u[d], ks, mom[2 + 2 * D + d]);
+                if (ZG) {
+                    const double j = -A * fma(V[d], uk, 6.283185307179586476925286766559 * Mv[d] * ks);
+                    zr[m][d] += j;
+                    zc[n][d] -= j;
+                }
+            }
+        }
+}
+
 template <int DT, bool DENSE, bool ZG>
 __global__ __launch_bounds__(256) void k_moments(MomentArgs a) {
     constexpr int DM = DT > 0 ? DT : MOGP_MAXD;
     constexpr int WM = 2 + 3 * DM;
+    constexpr int RSTRIDE = 256 + 16;                        // one moment of all threads, +1 per 16 (the slice reads hit distinct banks)
+    constexpr int NBUF = WM <= 11 ? 2 : 1;                   // double-buffered reduction staging: one barrier per term instead of two
     const int D = DT > 0 ? DT : a.D;
     const int W = 2 + 3 * D;
     const GTile tl = a.tiles[blockIdx.x];
     const double* tab = a.table + (size_t)tl.pair * a.T * W;
     const int tid = threadIdx.x;
     const int cg = tid & 15, rg = tid >> 4;
-    const int lane = tid & 63, wave = tid >> 6;
     const double* xcol = a.xc ? a.xc : a.x;
     const int64_t ldxc = a.xc ? a.ldxc : a.ldx;
 
-    __shared__ double s_xr[DM][MOGP_GT], s_xc[DM][MOGP_GT];
-    __shared__ double s_cu[MOGP_TC][MOGP_GT], s_su[MOGP_TC][MOGP_GT], s_cw[MOGP_TC][MOGP_GT], s_sw[MOGP_TC][MOGP_GT];
-    __shared__ double s_V[MOGP_TC][DM], s_Dl[MOGP_TC][DM], s_M[MOGP_TC][DM], s_A[MOGP_TC];
-    __shared__ double s_red[4][WM];
+    __shared__ TileLds<DM> L;
+    __shared__ double s_red[NBUF][WM * RSTRIDE];
     __shared__ double s_gr[ZG ? DM : 1][MOGP_GT], s_gc[ZG ? DM : 1][MOGP_GT];
 
     double* outp = a.partial + (size_t)blockIdx.x * a.T * W;
@@ -186,13 +568,10 @@ __global__ __launch_bounds__(256) void k_moments(MomentArgs a) {
         return;
     }
 
-    for (int idx = tid; idx < D * MOGP_GT * 2; idx += 256) {
-        const int which = idx / (D * MOGP_GT);
-        const int rem = idx - which * D * MOGP_GT;
-        const int d = rem / MOGP_GT, p = rem - d * MOGP_GT;
-        if (which == 0) s_xr[d][p] = p < tl.nr ? a.x[(size_t)d * a.ldx + tl.r0 + p] : 0.0;
-        else            s_xc[d][p] = p < tl.nc ? xcol[(size_t)d * ldxc + tl.c0 + p] : 0.0;
-    }
+    const PhaseView v = phase_view(a.ph.ws, a.C, a.T, D, a.ldx, ldxc);
+    TileCtx<DM> X;
+    double p[4][DM], q[4][DM];
+    tile_context<DM>(X, p, q, tl, D, v, a.x, a.ldx, xcol, ldxc, rg, cg);
     if (ZG) {
         for (int idx = tid; idx < D * MOGP_GT; idx += 256) { s_gr[idx / MOGP_GT][idx % MOGP_GT] = 0.0; s_gc[idx / MOGP_GT][idx % MOGP_GT] = 0.0; }
     }
@@ -233,66 +612,60 @@ __global__ __launch_bounds__(256) void k_moments(MomentArgs a) {
             for (int d = 0; d < D; ++d) { zr[m][d] = 0.0; zc[m][d] = 0.0; }
     }
 
+    int nred = 0;                                            // reductions done so far (selects the staging buffer)
     for (int t0 = 0; t0 < a.T; t0 += MOGP_TC) {
         const int nt = min(MOGP_TC, a.T - t0);
         __syncthreads();
-        stage_phases<DM>(tab, W, D, t0, nt, true, s_xr, s_xc, s_cu, s_su, s_cw, s_sw, s_V, s_Dl, tid, s_M, s_A);
+        stage_chunk<DM, false, (DT == 1)>(L, X, tl, tab, W, D, a.C, a.T, t0, nt, v, a.x, a.ldx, xcol, ldxc, tid);
         __syncthreads();
-        double xr[4][DM], xc[4][DM];
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-            for (int d = 0; d < D; ++d) { xr[m][d] = s_xr[d][rg * 4 + m]; xc[m][d] = s_xc[d][cg * 4 + m]; }
         for (int t = 0; t < nt; ++t) {
+            const int deg = L.deg[t];
+            if (deg == GT_SKIP) {                            // uniform across the workgroup
+                if (tid < W) outp[(size_t)(t0 + t) * W + tid] = 0.0;
+                continue;
+            }
             double mom[WM];
-            for (int w = 0; w < W; ++w) mom[w] = 0.0;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) mom[w] = 0.0;
             double cu[4], su[4], cw[4], sw[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                cu[m] = s_cu[t][rg * 4 + m]; su[m] = s_su[t][rg * 4 + m];
-                cw[m] = s_cw[t][cg * 4 + m]; sw[m] = s_sw[t][cg * 4 + m];
+                cu[m] = L.cu[t][rg * 4 + m]; su[m] = L.su[t][rg * 4 + m];
+                cw[m] = L.cw[t][cg * 4 + m]; sw[m] = L.sw[t][cg * 4 + m];
             }
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    double u[DM];
-                    double arg = 0.0;
-                    for (int d = 0; d < D; ++d) {
-                        u[d] = (xr[m][d] - xc[n][d]) + s_Dl[t][d];
-                        arg = fma(s_V[t][d] * u[d], u[d], arg);
-                    }
-                    const double ge = g[m][n] * exp(-0.5 * arg);
-                    const double kc = ge * fma(cu[m], cw[n], su[m] * sw[n]);
-                    const double ks = ge * fma(su[m], cw[n], -cu[m] * sw[n]);
-                    mom[0] += kc;
-                    mom[1] += ks;
-                    for (int d = 0; d < D; ++d) {
-                        mom[2 + d] = fma(u[d] * u[d], kc, mom[2 + d]);
-                        mom[2 + D + d] = fma(u[d], kc, mom[2 + D + d]);
-                        mom[2 + 2 * D + d] = fma(u[d], ks, mom[2 + 2 * D + d]);
-                        if (ZG) {
-                            const double j = -s_A[t] * fma(s_V[t][d] * u[d], kc, 6.283185307179586476925286766559 * s_M[t][d] * ks);
-                            zr[m][d] += j;
-                            zc[n][d] -= j;
-                        }
-                    }
-                }
-            // workgroup reduction (fixed order: butterfly inside the wave, then waves 0..3)
-            for (int w = 0; w < W; ++w) {
-                double v = mom[w];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-                if (lane == 0) s_red[wave][w] = v;
+            switch (deg) {
+                case 4: moment_term<DM, 4, ZG>(mom, g, p, q, L.V[t], L.s[t], L.M[t], L.A[t], D, cu, su, cw, sw, zr, zc); break;
+                case 6: moment_term<DM, 6, ZG>(mom, g, p, q, L.V[t], L.s[t], L.M[t], L.A[t], D, cu, su, cw, sw, zr, zc); break;
+                case 8: moment_term<DM, 8, ZG>(mom, g, p, q, L.V[t], L.s[t], L.M[t], L.A[t], D, cu, su, cw, sw, zr, zc); break;
+                case 11: moment_term<DM, 11, ZG>(mom, g, p, q, L.V[t], L.s[t], L.M[t], L.A[t], D, cu, su, cw, sw, zr, zc); break;
+                case 14: moment_term<DM, 14, ZG>(mom, g, p, q, L.V[t], L.s[t], L.M[t], L.A[t], D, cu, su, cw, sw, zr, zc); break;
+                default: moment_term<DM, 0, ZG>(mom, g, p, q, L.V[t], L.s[t], L.M[t], L.A[t], D, cu, su, cw, sw, zr, zc); break;
             }
+            // workgroup reduction of the W moments of this term through LDS, fixed order: thread (w, i) adds the values of threads
+            // 16 i .. 16 i + 15, a 4-step butterfly over i finishes.  With two staging buffers the next term's writes need no second
+            // barrier (a buffer is reused two terms later, behind the barrier of the term in between).
+            double* rb = s_red[nred % NBUF];
+            ++nred;
+            for (int w = 0; w < W; ++w) rb[w * RSTRIDE + tid + (tid >> 4)] = mom[w];
             __syncthreads();
-            if (tid < W) outp[(size_t)(t0 + t) * W + tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
-            __syncthreads();
+            if (tid < 16 * W) {
+                const int w = tid >> 4, i = tid & 15;
+                const double* src = rb + w * RSTRIDE + i * 17;
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v += src[k];
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                if (i == 0) outp[(size_t)(t0 + t) * W + w] = v;
+            }
+            if (NBUF == 1) __syncthreads();
         }
     }
 
     if (ZG) {
         // rows: the 16 threads of a row group (cg = 0..15) are consecutive lanes -> butterfly, then one LDS add;
         // columns: LDS atomics; finally one global atomic per point and dimension
+        __syncthreads();
 #pragma unroll
         for (int m = 0; m < 4; ++m)
             for (int d = 0; d < D; ++d) {
@@ -304,9 +677,9 @@ __global__ __launch_bounds__(256) void k_moments(MomentArgs a) {
             }
         __syncthreads();
         for (int idx = tid; idx < D * MOGP_GT; idx += 256) {
-            const int d = idx / MOGP_GT, p = idx - d * MOGP_GT;
-            if (a.gzr && p < tl.nr) atomicAdd(&a.gzr[(size_t)d * a.ldgz + tl.r0 + p], s_gr[d][p]);
-            if (a.gzc && p < tl.nc) atomicAdd(&a.gzc[(size_t)d * a.ldgz + tl.c0 + p], s_gc[d][p]);
+            const int d = idx / MOGP_GT, pnt = idx - d * MOGP_GT;
+            if (a.gzr && pnt < tl.nr) atomicAdd(&a.gzr[(size_t)d * a.ldgz + tl.r0 + pnt], s_gr[d][pnt]);
+            if (a.gzc && pnt < tl.nc) atomicAdd(&a.gzc[(size_t)d * a.ldgz + tl.c0 + pnt], s_gc[d][pnt]);
         }
     }
 }
@@ -325,6 +698,10 @@ static int launch_moments_t(const MomentArgs& a, hipStream_t s) {
 
 int launch_moments(const MomentArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return 0;
+    const double* xc = a.xc ? a.xc : a.x;
+    const int64_t ldxc = a.xc ? a.ldxc : a.ldx;
+    int rc = launch_phase_tables(a.ph, a.x, a.ldx, a.nrows, xc, ldxc, a.xc ? a.ncols : a.nrows, a.table, a.T, a.D, a.C, s);
+    if (rc) return rc;
     if (a.G == nullptr) return launch_moments_t<false, false>(a, s);
     if (a.gzr || a.gzc) return launch_moments_t<true, true>(a, s);
     return launch_moments_t<true, false>(a, s);

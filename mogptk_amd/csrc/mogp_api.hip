@@ -380,7 +380,8 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     int rc;
     if ((rc = mark(m, 0))) return rc;
     GramArgs ga;
-    ga.tiles = m->d_tiles.p; ga.xr = m->d_x.p; ga.xc = m->d_x.p; ga.ldxr = ga.ldxc = Npad;
+    ga.tiles = m->d_tiles.p; ga.xr = m->d_x.p; ga.xc = m->d_x.p; ga.ldxr = ga.ldxc = Npad; ga.nrows = ga.ncols = N;
+    if ((rc = m->ph_xx.prepare(m->sx.off, m->sx.off, C, m->T, Npad, Npad, m->st, ga.ph))) return rc;
     ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C;
     ga.out = m->k.A.p; ga.ldo = Npad; ga.noise = m->d_noise.p; ga.dvar = data_var ? m->d_dvar.p : nullptr;
     ga.jitter_abs = jabs; ga.mirror = 0;
@@ -476,7 +477,8 @@ static int sweep_eval_begin(mogp_model* m, const double* noise_var, const double
     int rc;
     if ((rc = mark(m, 0))) return rc;
     GramArgs ga{};
-    ga.tiles = m->d_tiles.p; ga.xr = m->d_x.p; ga.xc = m->d_x.p; ga.ldxr = ga.ldxc = Npad;
+    ga.tiles = m->d_tiles.p; ga.xr = m->d_x.p; ga.xc = m->d_x.p; ga.ldxr = ga.ldxc = Npad; ga.nrows = ga.ncols = N;
+    if ((rc = m->ph_xx.prepare(m->sx.off, m->sx.off, C, m->T, Npad, Npad, m->st, ga.ph))) return rc;
     ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C;
     ga.out = m->k.A.p; ga.ldo = Npad; ga.noise = m->d_noise.p; ga.dvar = data_var ? m->d_dvar.p : nullptr;
     ga.jitter_abs = m->sh_jabs; ga.mirror = 0;
@@ -530,7 +532,8 @@ static int moment_pass(mogp_model* m, const double* kinv, double ksign, double* 
     const int rm = m->sh_n > 1 ? m->sh_n : 0;
     int rc;
     MomentArgs ma{};
-    ma.tiles = m->d_tiles.p; ma.ntiles = (int)m->tiles.size(); ma.x = m->d_x.p; ma.ldx = Npad;
+    ma.tiles = m->d_tiles.p; ma.ntiles = (int)m->tiles.size(); ma.x = m->d_x.p; ma.ldx = Npad; ma.nrows = ma.ncols = m->N;
+    if ((rc = m->ph_xx.prepare(m->sx.off, m->sx.off, C, T, Npad, Npad, m->st, ma.ph))) return rc;
     ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C; ma.kinv = kinv; ma.kinv_sign = ksign; ma.ld = Npad; ma.alpha = m->d_alpha.p;
     ma.row_mod = rm; ma.row_rem = m->sh_rank;
     ma.partial = m->d_partial.p;
@@ -659,6 +662,7 @@ int mogp_model_destroy(mogp_model* m) {
     m->d_chan_off.release(); m->d_flag.release(); m->d_info.release();
     m->d_xs.release(); m->d_Ksf.release(); m->d_Vt.release(); m->d_mu.release(); m->d_var.release(); m->d_kdiag.release();
     m->d_Kss.release(); m->d_ptiles.release();
+    m->ph_xx.release(); m->ph_sx.release(); m->ph_ss.release();
 
     delete m;
     return MOGP_OK;
@@ -765,7 +769,8 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
 
     // K_sf = K(Xs, X)   (rows: test points, columns: training points; all C*C pairs, reference kernel.py:468-479 transposed)
     GramArgs ga;
-    ga.tiles = m->d_ptiles.p; ga.xr = m->d_xs.p; ga.ldxr = Spad; ga.xc = m->d_x.p; ga.ldxc = Npad;
+    ga.tiles = m->d_ptiles.p; ga.xr = m->d_xs.p; ga.ldxr = Spad; ga.xc = m->d_x.p; ga.ldxc = Npad; ga.nrows = S; ga.ncols = m->N;
+    if ((rc = m->ph_sx.prepare(ss.off, m->sx.off, C, m->T, Spad, Npad, m->st, ga.ph))) return rc;
     ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.out = m->d_Ksf.p; ga.ldo = Npad;
     ga.noise = nullptr; ga.dvar = nullptr; ga.jitter_abs = 0.0; ga.mirror = 0;
     if ((rc = launch_gram(ga, (int)pt.size(), m->st))) return rc;
@@ -796,7 +801,8 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
     if ((rc = m->d_ptiles.ensure(st_tiles.size()))) return rc;
     HIP_TRY(hipMemsetAsync(m->d_Kss.p, 0, (size_t)Spad * Spad * sizeof(double), m->st));
     HIP_TRY(hipMemcpyAsync(m->d_ptiles.p, st_tiles.data(), st_tiles.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
-    ga.tiles = m->d_ptiles.p; ga.xc = m->d_xs.p; ga.ldxc = Spad; ga.out = m->d_Kss.p; ga.ldo = Spad; ga.mirror = 1;
+    ga.tiles = m->d_ptiles.p; ga.xc = m->d_xs.p; ga.ldxc = Spad; ga.ncols = S; ga.out = m->d_Kss.p; ga.ldo = Spad; ga.mirror = 1;
+    if ((rc = m->ph_ss.prepare(ss.off, ss.off, C, m->T, Spad, Spad, m->st, ga.ph))) return rc;
     if ((rc = launch_gram(ga, (int)st_tiles.size(), m->st))) return rc;
     GemmArgs c{};
     c.A = m->d_Vt.p; c.lda = Npad; c.a_kmajor = 0; c.B = m->d_Vt.p; c.ldb = Npad; c.b_kmajor = 0;
@@ -831,7 +837,8 @@ int mogp_gram(mogp_ctx* ctx, int C, int D, int T, const double* table, int64_t M
     const int W = 2 + 3 * D;
     DevBuf<double> dx1, dx2, dtab, dout;
     DevBuf<GTile> dt;
-    auto cleanup = [&]() { dx1.release(); dx2.release(); dtab.release(); dout.release(); dt.release(); };
+    PhaseWs ph;
+    auto cleanup = [&]() { dx1.release(); dx2.release(); dtab.release(); dout.release(); dt.release(); ph.release(); };
 #define G_TRY(x) do { int r__ = (x); if (r__) { cleanup(); return r__; } } while (0)
 #define G_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { cleanup(); return hip_fail(e__, #x, __FILE__, __LINE__); } } while (0)
     G_TRY(dx1.ensure((size_t)D * s1.Mpad));
@@ -846,7 +853,8 @@ int mogp_gram(mogp_ctx* ctx, int C, int D, int T, const double* table, int64_t M
     G_HIP(hipMemcpy(dtab.p, table, (size_t)C * C * T * W * sizeof(double), hipMemcpyHostToDevice));
     G_HIP(hipMemcpy(dt.p, tiles.data(), tiles.size() * sizeof(GTile), hipMemcpyHostToDevice));
     GramArgs ga;
-    ga.tiles = dt.p; ga.xr = dx1.p; ga.ldxr = s1.Mpad; ga.xc = sym ? dx1.p : dx2.p; ga.ldxc = sc.Mpad;
+    ga.tiles = dt.p; ga.xr = dx1.p; ga.ldxr = s1.Mpad; ga.xc = sym ? dx1.p : dx2.p; ga.ldxc = sc.Mpad; ga.nrows = R; ga.ncols = Cc;
+    G_TRY(ph.prepare(s1.off, sc.off, C, T, s1.Mpad, sc.Mpad, nullptr, ga.ph));
     ga.table = dtab.p; ga.T = T; ga.D = D; ga.C = C; ga.out = dout.p; ga.ldo = Cc;
     ga.noise = nullptr; ga.dvar = nullptr; ga.jitter_abs = 0.0; ga.mirror = 1;
     G_TRY(launch_gram(ga, (int)tiles.size(), nullptr));

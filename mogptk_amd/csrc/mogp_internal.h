@@ -32,11 +32,22 @@ struct GTile {
 enum { GT_MIRROR = 1,     // also write the transpose to (c, r)   (off-diagonal tile of the symmetric Gram)
        GT_DIAG = 2 };     // tile sits on the matrix diagonal (r0 == c0)
 
+// phase-table workspace of one Gram / moment launch (gram.hip): device channel offsets [C+1] of the row / column inputs and
+// phase_ws_doubles(C, T, ldxr, ldxc) doubles of scratch
+struct PhaseRef {
+    const int* offr = nullptr;
+    const int* offc = nullptr;
+    double* ws = nullptr;
+};
+size_t phase_ws_doubles(int C, int T, int64_t ldr, int64_t ldc);
+
 struct GramArgs {
     const GTile* tiles;
     const double* xr;      // row inputs   [D][ldxr]
     const double* xc;      // column inputs [D][ldxc]
     int64_t ldxr, ldxc;
+    int64_t nrows, ncols;  // number of row / column points (all channels)
+    PhaseRef ph;
     const double* table;   // [C*C][T][W]
     int T, D, C;
     double* out;           // row-major, leading dimension ldo
@@ -46,6 +57,8 @@ struct GramArgs {
     const double* dvar;    // [N] per-point variance or null
     double jitter_abs;
     int mirror;            // write the transpose of GT_MIRROR tiles too (full symmetric Gram for Kernel.K)
+    int dbg;               // measurement only (MOGP_GRAM_DBG): 1 = no stores, 2 = no terms (stores only)
+    int tab_lds;           // set by the launcher: the term table is copied to LDS
 };
 
 struct MomentArgs {
@@ -55,6 +68,8 @@ struct MomentArgs {
     int64_t ldx;
     const double* xc;      // column inputs [D][ldxc]; null -> the row inputs (symmetric case)
     int64_t ldxc;
+    int64_t nrows, ncols;  // number of row / column points (ncols unused when xc is null)
+    PhaseRef ph;
     const double* table;
     int T, D, C;
     // adjoint source, exact mode (G == null):  g = w * 1/2 (alpha_a alpha_b - kinv_ab), symmetric weights
@@ -75,6 +90,7 @@ struct MomentArgs {
     double* gzc;
     int64_t ldgz;
     double* partial;       // [ntiles][T][W] per-tile partial moments (reduced in fixed order afterwards)
+    int tab_lds;           // set by the launcher: the term table is copied to LDS
 };
 
 int launch_gram(const GramArgs& a, int ntiles, hipStream_t s);

@@ -24,6 +24,31 @@ struct DevBuf {
     void release() { if (p) { hipError_t e = hipFree(p); (void)e; } p = nullptr; n = 0; }
 };
 
+// phase-table workspace for Gram / moment launches over one (row inputs, column inputs) combination: scratch + the device copies
+// of the two channel-offset arrays (uploaded only when they change)
+struct PhaseWs {
+    DevBuf<double> ws;
+    DevBuf<int> offr, offc;
+    std::vector<int> hr, hc;
+    int prepare(const std::vector<int>& r, const std::vector<int>& c, int C, int T, int64_t ldr, int64_t ldc, hipStream_t s, PhaseRef& out) {
+        int rc;
+        if ((rc = ws.ensure(phase_ws_doubles(C, T, ldr, ldc)))) return rc;
+        if (hr != r) {
+            if ((rc = offr.ensure(r.size()))) return rc;
+            hr = r;
+            HIP_TRY(hipMemcpyAsync(offr.p, hr.data(), hr.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        }
+        if (hc != c) {
+            if ((rc = offc.ensure(c.size()))) return rc;
+            hc = c;
+            HIP_TRY(hipMemcpyAsync(offc.p, hc.data(), hc.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        }
+        out.offr = offr.p; out.offc = offc.p; out.ws = ws.p;
+        return 0;
+    }
+    void release() { ws.release(); offr.release(); offc.release(); hr.clear(); hc.clear(); }
+};
+
 // channel-sorted view of an input matrix X (M x (1+D)): stable sort by channel id
 struct SortedX {
     int64_t M = 0, Mpad = 0;
@@ -92,7 +117,9 @@ struct TitsiasWork {
     DevBuf<GTile> tiles_uu, tiles_uf;
     DevBuf<int> ps_uu, ps_uf;
     DevBuf<double> Kus, Aus, Bus;                       // prediction panels (Mpad x Spad)
+    PhaseWs ph_zz, ph_zx, ph_zs;                        // phase tables: (Z, Z), (Z, X), (Z, Xs)
     void release() {
+        ph_zz.release(); ph_zx.release(); ph_zs.release();
         a.release(); q.release();
         zx.release(); B.release(); v.release(); GB.release(); Qs.release(); E.release(); R.release(); T1.release(); GA.release(); Hm.release();
         vec.release(); scratch.release(); gz.release(); partial_uu.release(); partial_uf.release(); mom_uu.release(); mom_uf.release();
@@ -133,6 +160,7 @@ struct mogp_model {
     // prediction workspaces
     DevBuf<double> d_xs, d_Ksf, d_Vt, d_mu, d_var, d_kdiag, d_Kss;
     DevBuf<GTile> d_ptiles;
+    PhaseWs ph_xx, ph_sx, ph_ss;                        // phase tables: (X, X), (Xs, X), (Xs, Xs)
 
     // profiling
     bool profiling = false;

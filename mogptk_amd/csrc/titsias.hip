@@ -93,12 +93,14 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     sc.jit = jitter * dsum / (double)M;
 
     GramArgs ga{};
-    ga.tiles = t.tiles_uu.p; ga.xr = t.zx.p; ga.xc = t.zx.p; ga.ldxr = ga.ldxc = Mpad;
+    ga.tiles = t.tiles_uu.p; ga.xr = t.zx.p; ga.xc = t.zx.p; ga.ldxr = ga.ldxc = Mpad; ga.nrows = ga.ncols = M;
+    RC(t.ph_zz.prepare(sz.off, sz.off, C, m->T, Mpad, Mpad, m->st, ga.ph));
     ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.out = t.a.A.p; ga.ldo = Mpad;
     ga.noise = t.zero_noise.p; ga.dvar = nullptr; ga.jitter_abs = sc.jit; ga.mirror = 0;
     RC(launch_gram(ga, (int)tuu.size(), m->st));
     RC(launch_pad_identity(t.a.A.p, Mpad, M, Mpad, m->st));
-    ga.tiles = t.tiles_uf.p; ga.xc = m->d_x.p; ga.ldxc = Npad; ga.out = t.B.p; ga.ldo = Npad; ga.noise = nullptr; ga.jitter_abs = 0.0;
+    ga.tiles = t.tiles_uf.p; ga.xc = m->d_x.p; ga.ldxc = Npad; ga.ncols = m->N; ga.out = t.B.p; ga.ldo = Npad; ga.noise = nullptr; ga.jitter_abs = 0.0;
+    RC(t.ph_zx.prepare(sz.off, m->sx.off, C, m->T, Mpad, Npad, m->st, ga.ph));
     RC(launch_gram(ga, (int)tuf.size(), m->st));
 
     RC(spd_potrf(m, t.a));
@@ -204,12 +206,15 @@ int mogp_titsias_eval(mogp_model* m, int64_t M, const double* Z, double sigma, d
 
     MomentArgs ma{};
     ma.tiles = t.tiles_uf.p; ma.ntiles = (int)tuf.size(); ma.x = t.zx.p; ma.ldx = Mpad; ma.xc = m->d_x.p; ma.ldxc = Npad;
+    ma.nrows = M; ma.ncols = N;
+    RC(t.ph_zx.prepare(sz.off, m->sx.off, C, T, Mpad, Npad, m->st, ma.ph));
     ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C;
     ma.G = t.GB.p; ma.ldg = Npad; ma.ru = beta; ma.rw = r; ma.rcoef = 1.0; ma.sym = 0;
     ma.gzr = t.gz.p; ma.gzc = nullptr; ma.ldgz = Mpad; ma.partial = t.partial_uf.p;
     RC(launch_moments(ma, m->st));
     RC(launch_moment_reduce(t.partial_uf.p, t.ps_uf.p, C * C, T, W, t.mom_uf.p, m->st, 0));
-    ma.tiles = t.tiles_uu.p; ma.ntiles = (int)tuu.size(); ma.xc = nullptr; ma.ldxc = 0;
+    ma.tiles = t.tiles_uu.p; ma.ntiles = (int)tuu.size(); ma.xc = nullptr; ma.ldxc = 0; ma.ncols = M;
+    RC(t.ph_zz.prepare(sz.off, sz.off, C, T, Mpad, Mpad, m->st, ma.ph));
     ma.G = t.GA.p; ma.ldg = Mpad; ma.ru = beta; ma.rw = beta; ma.rcoef = -0.5 / (s2 * s2); ma.sym = 1;
     ma.gzr = t.gz.p; ma.gzc = t.gz.p; ma.partial = t.partial_uu.p;
     RC(launch_moments(ma, m->st));
@@ -255,7 +260,8 @@ int mogp_titsias_predict(mogp_model* m, int64_t M, const double* Z, double sigma
     HIP_TRY(hipMemcpyAsync(m->d_ptiles.p, tus.data(), tus.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemsetAsync(t.Kus.p, 0, (size_t)Mpad * Spad * sizeof(double), m->st));
     GramArgs ga{};
-    ga.tiles = m->d_ptiles.p; ga.xr = t.zx.p; ga.ldxr = Mpad; ga.xc = m->d_xs.p; ga.ldxc = Spad;
+    ga.tiles = m->d_ptiles.p; ga.xr = t.zx.p; ga.ldxr = Mpad; ga.xc = m->d_xs.p; ga.ldxc = Spad; ga.nrows = M; ga.ncols = S;
+    RC(t.ph_zs.prepare(sz.off, ss.off, C, m->T, Mpad, Spad, m->st, ga.ph));
     ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.out = t.Kus.p; ga.ldo = Spad; ga.mirror = 0;
     RC(launch_gram(ga, (int)tus.size(), m->st));
     GemmArgs g = gemm(t.a.A.p, Mpad, 0, t.Kus.p, Spad, 1, t.Aus.p, Spad, 1.0, GM_KHI_I, mt, st, Mpad);     // a = W Kus
