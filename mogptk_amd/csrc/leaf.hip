@@ -93,7 +93,7 @@ __device__ __forceinline__ void lf_update(double* M, int i, int j, int kc, int l
 }
 
 __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, double* invd, double* logdet,
-                                                 unsigned long long* info, long long info_base) {
+                                                 unsigned long long* info, long long info_base, int store_L) {
     extern __shared__ __attribute__((aligned(16))) double lf[];
     double* M = lf;                       // 36 packed lower blocks
     double* invdiag = lf + LF_MAT;        // [128]  1 / L_kk
@@ -178,8 +178,20 @@ __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, d
             if (fail >= 0) atomicMin(info, (unsigned long long)(info_base + (int64_t)t * MOGP_TILE + fail + 1));
         }
     }
-    // The factor L_kk itself is NOT written back: every consumer works with the tile inverse (panel = panel * invd^T, W_KK rows,
-    // put_diag_tiles before TRTRI) and the log-determinant is taken here, so the diagonal tile of A keeps its (consumed) input.
+    // The factor L_kk itself is NOT written back on the exact-GP path: every consumer there works with the tile inverse (panel = panel *
+    // invd^T, W_KK rows, put_diag_tiles before TRTRI) and the log-determinant is taken here, so the diagonal tile of A keeps its (consumed)
+    // input.  The triangular-solve path (trsm.hip, Titsias K_uu) needs L_kk itself: store_L writes the lower triangle, zeros above.
+    if (store_L) {
+        for (int it = 0; it < 32; ++it) {
+            const int idx = it * 256 + tid, r = idx >> 6, c = (idx & 63) * 2;
+            d2_t v = (d2_t){0.0, 0.0};
+            if ((c >> 4) <= (r >> 4)) v = *reinterpret_cast<const d2_t*>(M + lf_at(r, c));
+            if (c > r) v[0] = 0.0;
+            if (c + 1 > r) v[1] = 0.0;
+            *reinterpret_cast<d2_t*>(At + (int64_t)r * ld + c) = v;
+        }
+        __syncthreads();             // the inverse below overwrites the diagonal blocks of the LDS image
+    }
 
     // ---- TRTRI: diagonal 16x16 inverses, one column per lane (8 blocks x 16 columns = waves 0 and 1) ----
     if (tid < MOGP_TILE) {
@@ -257,13 +269,13 @@ __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, d
 }
 
 int launch_potrf_trtri_tile(double* A, int64_t ld, int t, double* invd, double* logdet, unsigned long long* info, hipStream_t s,
-                            long long info_base) {
+                            long long info_base, int store_L) {
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_leaf128), hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_leaf128, dim3(1), dim3(256), LF_LDS_BYTES, s, A, ld, t, invd, logdet, info, info_base);
+    hipLaunchKernelGGL(k_leaf128, dim3(1), dim3(256), LF_LDS_BYTES, s, A, ld, t, invd, logdet, info, info_base, store_L);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -57,9 +57,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
         // XCD-aware tile order: workgroup b is dispatched to XCD b % 8, each with its own L2.  Giving every XCD one contiguous
         // chunk of the (row-major) tile list keeps a panel row inside one L2 instead of all eight (measured: 2.8x the algorithmic
         // HBM traffic without it).  Only for the modes whose tiles all cost the same (equal chunks = equal work).
-        int bid = blockIdx.x;
+        int bid = blockIdx.x, grid = gridDim.x, ks = 0;
+        if (g.ksplit > 1) {            // split K: slice ks of the k range, accumulated into its own copy of C (c_split apart); the caller adds them
+            grid /= g.ksplit;
+            ks = bid / grid;
+            bid -= ks * grid;
+        }
         if (g.mode == GM_RECT || g.mode == GM_RECT_LOWER || g.mode == GM_LOWER || g.mode == GM_KLO_J || g.mode == GM_KHI_J) {
-            const int grid = gridDim.x, q = grid >> 3, r = grid & 7, x = bid & 7;
+            const int q = grid >> 3, r = grid & 7, x = bid & 7;
             if (grid >= 64) bid = x * q + min(x, r) + (bid >> 3);
         }
         int ti, tj;
@@ -72,10 +77,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
         if (g.mode == GM_KLO_J) k0 = (int64_t)tj * TNC;
         if (g.mode == GM_KHI_J) k1 = min((int64_t)g.K, (int64_t)(tj + 1) * TNC);
         if (g.mode == GM_KHI_I) k1 = min((int64_t)g.K, (int64_t)(ti + 1) * TMR);
+        if (g.ksplit > 1) {
+            const int64_t len = ((k1 - k0) / g.ksplit) / GEMM_BK * GEMM_BK;
+            k0 += ks * len;
+            if (ks + 1 < g.ksplit) k1 = k0 + len;
+        }
         kt = (int)((k1 - k0) / GEMM_BK);
         Ap = g.A + (AKM ? k0 * g.lda + (int64_t)ti * TMR : (int64_t)ti * TMR * g.lda + k0);
         Bp = g.B + (BKM ? k0 * g.ldb + (int64_t)tj * TNC : (int64_t)tj * TNC * g.ldb + k0);
-        Cp = g.C + (int64_t)ti * TMR * g.ldc + (int64_t)tj * TNC;
+        Cp = g.C + (int64_t)ti * TMR * g.ldc + (int64_t)tj * TNC + (int64_t)ks * g.c_split;
     }
 
     // ---- global -> register staging map: EPT doubles (16-byte loads) per thread per operand ----
@@ -185,6 +195,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
         default: grid = a.mt * a.nt; break;
     }
     if (grid <= 0) return 0;
+    if (a.ksplit > 1) grid *= a.ksplit;
     const int v = (a.a_kmajor ? 2 : 0) | (a.b_kmajor ? 1 : 0);
     if (a.small) {
         const bool rect = a.mode == GM_RECT || a.mode == GM_RECT_LOWER;

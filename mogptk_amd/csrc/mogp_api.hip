@@ -19,7 +19,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
     return MOGP_EHIP;
 }
 int launch_potrf_trtri_tile(double* A, int64_t ld, int t, double* invd, double* logdet, unsigned long long* info, hipStream_t s,
-                            long long info_base = 0);
+                            long long info_base = 0, int store_L = 0);
 
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
@@ -234,7 +234,7 @@ namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base) {
     for (int kb = 0; kb < nouter; ++kb) {
         const int k0 = kb * MOGP_OUTER, k1 = std::min(k0 + MOGP_OUTER, nb);
         for (int k = k0; k < k1; ++k) {
-            if ((rc = launch_potrf_trtri_tile(w.A.p, w.Npad, k, w.invd.p, w.logdet.p, m->d_info.p, m->st, info_base))) return rc;
+            if ((rc = launch_potrf_trtri_tile(w.A.p, w.Npad, k, w.invd.p, w.logdet.p, m->d_info.p, m->st, info_base, w.keep_L ? 1 : 0))) return rc;
             const int rem = nb - k - 1;
             if (rem <= 0) break;
             double* panel = w.A.p + (int64_t)(k + 1) * MOGP_TILE * w.Npad + (int64_t)k * MOGP_TILE;

@@ -90,6 +90,7 @@ struct TrtriLevel {
 struct Spd {
     int64_t Npad = 0;
     int nb = 0;
+    bool keep_L = false;                // spd_potrf also stores the diagonal tiles of L (the triangular-solve path needs the factor itself)
     DevBuf<double> A, B, invd, logdet;
     DevBuf<double> Wm;                  // W = L^-1 when the inverse is streamed behind the factorisation (spd_potrf fuse_inverse)
     std::vector<TrtriLevel> levels;
@@ -117,6 +118,7 @@ struct TitsiasWork {
     DevBuf<GTile> tiles_uu, tiles_uf;
     DevBuf<int> ps_uu, ps_uf;
     DevBuf<double> Kus, Aus, Bus;                       // prediction panels (Mpad x Spad)
+    DevBuf<double> zero_col;                            // Mpad zeros
     PhaseWs ph_zz, ph_zx, ph_zs;                        // phase tables: (Z, Z), (Z, X), (Z, Xs)
     void release() {
         ph_zz.release(); ph_zx.release(); ph_zs.release();
@@ -124,7 +126,7 @@ struct TitsiasWork {
         zx.release(); B.release(); v.release(); GB.release(); Qs.release(); E.release(); R.release(); T1.release(); GA.release(); Hm.release();
         vec.release(); scratch.release(); gz.release(); partial_uu.release(); partial_uf.release(); mom_uu.release(); mom_uf.release();
         zero_noise.release(); tiles_uu.release(); tiles_uf.release(); ps_uu.release(); ps_uf.release();
-        Kus.release(); Aus.release(); Bus.release();
+        Kus.release(); Aus.release(); Bus.release(); zero_col.release();
     }
 };
 
@@ -191,6 +193,11 @@ int sweep_prepare(mogp_model* m, Spd& w);
 int sweep_nblocks(const Spd& w);
 int sweep_block(mogp_model* m, Spd& w, int kb);
 int sweep_finish(mogp_model* m, Spd& w);
+// B (nb*128 rows x ncols, leading dimension ldb, ncols a multiple of 128) <- L^-1 B  (trans: L^-T B) by blocked substitution, in place;
+// L lower triangular nb*128 square with leading dimension ldl, diagonal tiles included (Spd::keep_L).  trsm.hip
+int trsm_lower(mogp_model* m, const double* L, int64_t ldl, int nb, double* B, int64_t ldb, int64_t ncols, bool trans, hipStream_t st = nullptr);
+int launch_transpose(double* dst, const double* src, int64_t ld, int64_t n, hipStream_t s);            // dst = src^T, n x n, n % 64 == 0
+int launch_sym_lower_avg(double* A, int64_t ld, int64_t n, double scale, hipStream_t s);               // lower(A) <- scale * (A + A^T) / 2
 int shard_pack(mogp_model* m, Spd& w, int kb, double** send, double** recv, int64_t* count);
 int shard_unpack(mogp_model* m, Spd& w, int kb);
 // w.A (SPD, lower) -> -inverse (lower); w.logdet per tile; failure through m->d_info

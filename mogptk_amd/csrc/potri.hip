@@ -33,7 +33,7 @@ using namespace mogp;
 
 namespace mogp {
 int launch_potrf_trtri_tile(double* A, int64_t ld, int t, double* invd, double* logdet, unsigned long long* info, hipStream_t s,
-                            long long info_base = 0);
+                            long long info_base = 0, int store_L = 0);
 }
 
 #define RC(x) do { int r__ = (x); if (r__) return r__; } while (0)

@@ -1,13 +1,16 @@
 // titsias.hip -- the Titsias sparse variational bound and its gradient on the device (BASELINE.json configs[4]).
 // Reference: gpr/model.py:700-724 (elbo), :730-765 (predict_f); the gradient replaces autograd through that code.
 //
-// Whitened, cancellation-free forms (A = Kuu + jitter mean(diag Kuu) I = Luu Luu^T, W = Luu^-1, B = Kuf, s2 = sigma^2):
-//   v = W B,  Qs = v v^T / s2 + I = Lq Lq^T,  Pq = Qs^-1,  t1 = Pq (v y),  beta = W^T t1
+// Whitened, cancellation-free forms (A = Kuu + jitter mean(diag Kuu) I = L L^T, B = Kuf, s2 = sigma^2):
+//   v = L^-1 B,  Qs = v v^T / s2 + I = Lq Lq^T,  Pq = Qs^-1,  t1 = Pq (v y),  beta = L^-T t1
 //   ELBO      = -N/2 log 2pi - sum log Lq_kk - N log sigma - y^T y /(2 s2) + t1.(v y) /(2 s2^2) - (sum Kff_diag - tr Q)/(2 s2)
-//   dELBO/dB  = W^T (I - Pq) v / s2 + beta (y / s2^2 - B^T beta / s2^3)^T
-//   dELBO/dA  = 1/2 W^T (2 I - Pq - Qs) W - 1/2 beta beta^T / s2^2
-// Every O(M^2 N) product runs on the fp64 MFMA GEMM with the triangular k-ranges skipped; the two adjoints are contracted
-// with the kernel derivatives by the dense-mode moment kernel, which also accumulates the gradient w.r.t. the inducing inputs.
+//   dELBO/dB  = L^-T (I - Pq) v / s2 + beta (y / s2^2 - B^T beta / s2^3)^T
+//   dELBO/dA  = 1/2 L^-T (2 I - Pq - Qs) L^-1 - 1/2 beta beta^T / s2^2
+// Everything that goes through K_uu^-1 is a triangular SOLVE with L (trsm.hip: blocked substitution, as the reference's
+// solve_triangular at gpr/model.py:711,715): K_uu has condition number ~1e11 at configs[4] and products with an explicit L^-1 lose
+// dELBO/dZ (12-19 % error; 4e-5 with solves -- tools/titsias_numerics.py).  The inner system Qs = I + v v^T / s2 is well conditioned:
+// its inverse Pq is formed explicitly (Cholesky, triangular inverse, W^T W on the MFMA GEMM).  The two adjoints are contracted with
+// the kernel derivatives by the dense-mode moment kernel, which also accumulates the gradient w.r.t. the inducing inputs.
 #include "mogp_model.h"
 
 #include <cmath>
@@ -16,7 +19,7 @@
 
 namespace mogp {
 int launch_potrf_trtri_tile(double* A, int64_t ld, int t, double* invd, double* logdet, unsigned long long* info, hipStream_t s,
-                            long long info_base = 0);
+                            long long info_base = 0, int store_L = 0);
 }
 using namespace mogp;
 
@@ -103,14 +106,20 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     RC(t.ph_zx.prepare(sz.off, m->sx.off, C, m->T, Mpad, Npad, m->st, ga.ph));
     RC(launch_gram(ga, (int)tuf.size(), m->st));
 
+    t.a.keep_L = true;                                                          // the solves below need L itself, diagonal tiles included
     RC(spd_potrf(m, t.a));
     RC(check_info(m, "Kuu", info));
-    RC(spd_trtri(m, t.a));                                                      // t.a.A = W
     const double s2 = sigma * sigma;
-    GemmArgs g = gemm(t.a.A.p, Mpad, 0, t.B.p, Npad, 1, t.v.p, Npad, 1.0, GM_KHI_I, mt, nt, Mpad);        // v = W B
+    HIP_TRY(hipMemcpyAsync(t.v.p, t.B.p, (size_t)Mpad * Npad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
+    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.v.p, Npad, Npad, false));              // v = L^-1 B   (reference gpr/model.py:711)
+    (void)nt;
+    // Qs = v v^T / s2 + I: mt (mt + 1) / 2 = 136 tiles at configs[4] would leave half the chip idle over K = N, so K is cut in two
+    // (272 workgroups), the second half into the scratch matrix t.q.B, and the halves are added with the identity
+    GemmArgs g = gemm(t.v.p, Npad, 0, t.v.p, Npad, 0, t.q.A.p, Mpad, 1.0 / s2, GM_LOWER, mt, mt, Npad);
+    const bool split = mt * (mt + 1) / 2 < 256 && Npad >= 4096;
+    if (split) { g.ksplit = 2; g.c_split = t.q.B.p - t.q.A.p; }
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
-    g = gemm(t.v.p, Npad, 0, t.v.p, Npad, 0, t.q.A.p, Mpad, 1.0 / s2, GM_LOWER, mt, mt, Npad);            // Qs = v v^T / s2 (+ I)
-    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
+    if (split) RC(launch_axpby((int64_t)Mpad * Mpad, 1.0, t.q.A.p, 1.0, t.q.B.p, t.q.A.p, m->st));
     RC(launch_add_diag(t.q.A.p, Mpad, Mpad, 1.0, m->st));
     HIP_TRY(hipMemcpyAsync(t.Qs.p, t.q.A.p, (size_t)Mpad * Mpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->d_info.p, &big, sizeof(big), hipMemcpyHostToDevice, m->st));
@@ -123,7 +132,19 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     double* t1 = t.vec.p + Mpad;
     double* dg = t.vec.p + 2 * Mpad;                                            // diag Pq, diag Qs
     RC(launch_gemv_rows(t.v.p, Npad, Mpad, Npad, m->d_y.p, vy, m->st));
-    RC(launch_gemv_rows(t.q.B.p, Mpad, Mpad, Mpad, vy, t1, m->st));
+    // t1 = Pq (v y): the explicit inverse plus ONE step of iterative refinement against Qs.  Of the three places Pq enters the gradient,
+    // this vector is the one where the explicitly formed inverse costs accuracy on dELBO/dZ (tools/titsias_numerics.py: 1.3e-4 -> 7e-5, the
+    // same as two triangular solves with Lq), and three M x M mat-vecs are far cheaper than 2 nb dependent launches of a vector solve
+    RC(launch_symmetrize(t.Qs.p, Mpad, Mpad, m->st));
+    {
+        double* tmp = t.vec.p + 5 * Mpad;
+        double* res = t.vec.p + 6 * Mpad;
+        RC(launch_gemv_rows(t.q.B.p, Mpad, Mpad, Mpad, vy, t1, m->st));
+        RC(launch_gemv_rows(t.Qs.p, Mpad, Mpad, Mpad, t1, tmp, m->st));
+        RC(launch_axpby(Mpad, 1.0, vy, -1.0, tmp, res, m->st));
+        RC(launch_gemv_rows(t.q.B.p, Mpad, Mpad, Mpad, res, tmp, m->st));
+        RC(launch_axpby(Mpad, 1.0, t1, 1.0, tmp, t1, m->st));
+    }
     RC(launch_get_diag(t.q.B.p, Mpad, Mpad, dg, m->st));
     RC(launch_get_diag(t.Qs.p, Mpad, Mpad, dg + Mpad, m->st));
     const int nbq = t.q.nb;
@@ -177,28 +198,39 @@ int mogp_titsias_eval(mogp_model* m, int64_t M, const double* Z, double sigma, d
     *dsigma = 2.0 * sigma * ds2;
 
     RC(t.GB.ensure((size_t)Mpad * Npad)); RC(t.E.ensure((size_t)Mpad * Mpad)); RC(t.R.ensure((size_t)Mpad * Mpad));
-    RC(t.T1.ensure((size_t)Mpad * Mpad)); RC(t.GA.ensure((size_t)Mpad * Mpad)); RC(t.Hm.ensure((size_t)Mpad * Mpad));
+    RC(t.GA.ensure((size_t)Mpad * Mpad));
     RC(t.gz.ensure((size_t)D * Mpad));
+    if (t.zero_col.n < (size_t)Mpad) { RC(t.zero_col.ensure(Mpad)); HIP_TRY(hipMemsetAsync(t.zero_col.p, 0, Mpad * sizeof(double), m->st)); }
     double* vy = t.vec.p; (void)vy;
     double* t1 = t.vec.p + Mpad;
     double* beta = t.vec.p + 4 * Mpad;            // [Mpad] (+ chunk scratch behind it, see launch_trmv_lower_t)
     double* dga = t.vec.p + 2 * Mpad;             // reuse: diag of GA
     double* btb = t.vec.p + 8 * Mpad;             // [Npad]
     double* r = btb + Npad;                       // [Npad]
-    // beta = W^T t1 : the transposed mat-vec helper wants room for its row-chunk partials right behind the output vector
-    RC(launch_trmv_lower_t(t.a.A.p, Mpad, Mpad, t1, t.scratch.p, m->st));
-    HIP_TRY(hipMemcpyAsync(beta, t.scratch.p, Mpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
-    RC(launch_symmetrize(t.Qs.p, Mpad, Mpad, m->st));
-    RC(launch_combine(t.E.p, t.q.B.p, t.Qs.p, Mpad, Mpad, 2.0, 1.0, 1.0, m->st));            // E = 2I - Pq - Qs
+    // GB = L^-T (R v) / s2, and beta = L^-T t1 riding along: when N is not a multiple of 128 the right-hand side has zero padding columns,
+    // and t1 travels through the blocked solve in the first of them (a vector solve of its own is 2 nb dependent, almost empty launches)
     RC(launch_combine(t.R.p, t.q.B.p, nullptr, Mpad, Mpad, 1.0, 1.0, 0.0, m->st));           // R = I - Pq
-    GemmArgs g = gemm(t.E.p, Mpad, 0, t.a.A.p, Mpad, 1, t.T1.p, Mpad, 1.0, GM_KLO_J, mt, mt, Mpad);        // T1 = E W
+    GemmArgs g = gemm(t.R.p, Mpad, 0, t.v.p, Npad, 1, t.GB.p, Npad, 1.0 / s2, GM_RECT, mt, nt, Mpad);
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
-    g = gemm(t.a.A.p, Mpad, 1, t.T1.p, Mpad, 1, t.GA.p, Mpad, 0.5, GM_LAUUM, mt, mt, Mpad);                 // GA = 1/2 W^T T1 (lower)
-    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
-    g = gemm(t.a.A.p, Mpad, 1, t.R.p, Mpad, 1, t.Hm.p, Mpad, 1.0, GM_KLO_I, mt, mt, Mpad);                  // Hm = W^T R
-    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
-    g = gemm(t.Hm.p, Mpad, 0, t.v.p, Npad, 1, t.GB.p, Npad, 1.0 / s2, GM_RECT, mt, nt, Mpad);               // GB = Hm v / s2
-    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
+    const bool ride = Npad > N;
+    if (ride) RC(launch_copy2d(t.GB.p + N, Npad, t1, 1, Mpad, 1, 1.0, m->st));
+    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.GB.p, Npad, Npad, true));
+    if (ride) {
+        RC(launch_copy2d(beta, 1, t.GB.p + N, Npad, Mpad, 1, 1.0, m->st));
+        RC(launch_copy2d(t.GB.p + N, Npad, t.zero_col.p, 1, Mpad, 1, 1.0, m->st));          // the padding column is zero again
+    } else {
+        RC(t.Hm.ensure((size_t)Mpad * MOGP_TILE));
+        HIP_TRY(hipMemsetAsync(t.Hm.p, 0, (size_t)Mpad * MOGP_TILE * sizeof(double), m->st));
+        RC(launch_copy2d(t.Hm.p, MOGP_TILE, t1, 1, Mpad, 1, 1.0, m->st));
+        RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.Hm.p, MOGP_TILE, MOGP_TILE, true));
+        RC(launch_copy2d(beta, 1, t.Hm.p, MOGP_TILE, Mpad, 1, 1.0, m->st));
+    }
+    RC(launch_combine(t.E.p, t.q.B.p, t.Qs.p, Mpad, Mpad, 2.0, 1.0, 1.0, m->st));            // E = 2I - Pq - Qs
+    // GA = 1/2 L^-T E L^-1 (symmetric): T1 = L^-T E in place, then L^-T T1^T, then the lower triangle of the symmetrised half
+    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.E.p, Mpad, Mpad, true));
+    RC(launch_transpose(t.GA.p, t.E.p, Mpad, Mpad, m->st));
+    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.GA.p, Mpad, Mpad, true));
+    RC(launch_sym_lower_avg(t.GA.p, Mpad, Mpad, 0.5, m->st));
     RC(launch_gemv_cols(t.B.p, Npad, Mpad, Npad, beta, btb, t.scratch.p, m->st));                           // B^T beta
     RC(launch_axpby(Npad, 1.0 / (s2 * s2), m->d_y.p, -1.0 / (s2 * s2 * s2), btb, r, m->st));
     RC(launch_get_diag(t.GA.p, Mpad, Mpad, dga, m->st));
@@ -264,9 +296,9 @@ int mogp_titsias_predict(mogp_model* m, int64_t M, const double* Z, double sigma
     RC(t.ph_zs.prepare(sz.off, ss.off, C, m->T, Mpad, Spad, m->st, ga.ph));
     ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.out = t.Kus.p; ga.ldo = Spad; ga.mirror = 0;
     RC(launch_gram(ga, (int)tus.size(), m->st));
-    GemmArgs g = gemm(t.a.A.p, Mpad, 0, t.Kus.p, Spad, 1, t.Aus.p, Spad, 1.0, GM_KHI_I, mt, st, Mpad);     // a = W Kus
-    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
-    g = gemm(t.q.A.p, Mpad, 0, t.Aus.p, Spad, 1, t.Bus.p, Spad, 1.0, GM_KHI_I, mt, st, Mpad);                // b = Wq a
+    HIP_TRY(hipMemcpyAsync(t.Aus.p, t.Kus.p, (size_t)Mpad * Spad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
+    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.Aus.p, Spad, Spad, false));                                      // a = L^-1 Kus
+    GemmArgs g = gemm(t.q.A.p, Mpad, 0, t.Aus.p, Spad, 1, t.Bus.p, Spad, 1.0, GM_KHI_I, mt, st, Mpad);                // b = Wq a
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
     double* vy = t.vec.p;
     double* cvec = t.vec.p + 4 * Mpad;

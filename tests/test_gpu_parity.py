@@ -381,17 +381,20 @@ def test_cfg5_titsias_golden():
     for p, f in zip(m.parameters(), fp):
         err = np.max(np.abs(p.grad - f["grad"])) / np.max(np.abs(f["grad"]))
         if p._name.endswith("induction_points"):
-            # dELBO/dZ is O(1e-2) here, the residue of O(1e4) terms cancelling through a K_uu with condition number ~1e11
-            # (512 grid points per channel, 0.2 apart).  The reference's own value moves by 2.4e-3 relative when only its
-            # thread count changes (measured: tests/golden/gen_golden.py docstring), and the explicit-inverse GEMM
-            # formulation used on the device is ~100x noisier than triangular solves on this one tensor.
-            # Pin it on the scale that matters to the optimiser step (the overall gradient scale) and on direction.
-            assert np.max(np.abs(p.grad - f["grad"])) < 1e-6 * gscale, (p._name, err)
+            # dELBO/dZ is O(1e-2) here, the residue of O(1e4) terms cancelling through a K_uu with condition number ~1e11 (512 grid points
+            # per channel, 0.2 apart): the reference's OWN value moves by 2.35e-3 of this tensor when only its thread count changes
+            # (8 vs 3 torch threads, tests/golden/gen_golden.py docstring), so 1e-5 against one of its runs is below its noise floor.
+            # With every K_uu^-1 a triangular solve (trsm.hip) the device sits at 3.6e-3 .. 4.8e-3 of the tensor (run to run: fp64
+            # atomics in the per-point accumulation), 1.5 - 2 x the reference's own spread; an 80-bit evaluation at the same
+            # conditioning puts the solve formulation at 5e-5 of the truth and the explicit-inverse one of round 1 at 12-19 %
+            # (tools/titsias_numerics.py).  Asserted: within 4 x the reference's own spread, and the direction to five nines.
+            assert err < 1e-2, (p._name, err)
+            assert np.max(np.abs(p.grad - f["grad"])) < 1e-7 * gscale, (p._name, err)
             g, r = p.grad[:, 1], f["grad"][:, 1]
-            assert np.dot(g, r) / (np.linalg.norm(g) * np.linalg.norm(r)) > 0.8
+            assert np.dot(g, r) / (np.linalg.norm(g) * np.linalg.norm(r)) > 0.9999
             assert np.all(p.grad[:, 0] == 0.0)
         else:
-            assert err < 1e-5, (p._name, err)          # measured <= 5.2e-7
+            assert err < 1e-6, (p._name, err)          # measured <= 6.4e-8
 
 
 @pytest.mark.parametrize("path", ["sweep", "phases", "fused"])
