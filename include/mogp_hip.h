@@ -114,16 +114,44 @@ int  mogp_titsias_eval(mogp_model* m, int64_t M, const double* Z, double sigma, 
 int  mogp_titsias_predict(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kss_diag,
                           int64_t S, const double* Xs, double* mu, double* var, int64_t* info);
 
-/* ---- sharded exact evaluation across the GPUs of one node --------------------------------------------------
- * One process per GPU, each with its own model handle on the FULL training set.  Rank r owns the 128-row tile rows i with
- * i % nranks == r of the single-sweep inversion (sweep.hip).  The caller issues the collectives (RCCL through
- * torch.distributed in mogptk_amd/dist.py) between these calls; pointers returned through void** are DEVICE pointers owned by
- * the handle, counts are in doubles.  Per evaluation:
- *   begin -> for kb in 0..nblocks-1: { pack; ALL-GATHER(send -> recv, count per rank); unpack; block }
- *            (one collective per 512-wide pivot block: every rank contributes the pivot-block columns of the tile rows it owns plus,
- *             for the pivot tile rows it owns, the part left of the block; the update of the previous block keeps running underneath)
+/* ---- sharded exact evaluation / prediction across the GPUs of one node -------------------------------------------
+ * The reference has no distributed code at all (no torch.distributed / NCCL call site: SURVEY.md section 5); this is new design behind the
+ * same seams as mogp_exact_eval / mogp_exact_predict (gpr/model.py:438-453, :279-292, :455-483).
+ * One process per GPU, each with its own context and a model handle on the FULL training set (X, y are O(N)).  Rank r owns the 128-row
+ * tile rows i with i % nranks == r: it BUILDS only the Gram / moment tiles of those rows, holds only those rows of the work matrix current,
+ * and applies the rank-512 updates of the single-sweep inversion (sweep.hip) to them alone -- the O(N^3) work is divided by nranks.
+ * Per 512-wide pivot block ONE all-gather (the block's column panel from the owners of its tile rows + the left part of the pivot rows);
+ * once per evaluation an all-reduce of alpha (Npad doubles) and of the gradient moments / diagonal sums (a few kB).  The collectives are
+ * issued by the library itself on its critical HIP stream: with RCCL nothing returns to the host between pack, exchange, unpack and the
+ * block's arithmetic, and the previous block's trailing update keeps running on the bulk stream underneath the exchange.
+ *
+ * Communicator (per context).  RCCL: rank 0 calls mogp_comm_unique_id, the caller distributes the 128 bytes (any transport), every rank
+ * calls mogp_comm_init_rccl.  External: two callbacks on DEVICE pointers (counts in doubles; the library drains its stream before each
+ * call and the callback returns when the result is in place): for transports without a device path and for tests with several ranks on
+ * one GPU, which RCCL refuses. */
+#define MOGP_COMM_ID_BYTES 128
+typedef int (*mogp_allgather_cb)(void* user, const void* send_dev, void* recv_dev, int64_t count);   /* recv holds nranks * count */
+typedef int (*mogp_allreduce_cb)(void* user, void* buf_dev, int64_t count);                          /* sum over ranks, in place */
+int  mogp_comm_unique_id(void* id128);
+int  mogp_comm_init_rccl(mogp_ctx* ctx, const void* id128, int rank, int nranks);
+int  mogp_comm_init_external(mogp_ctx* ctx, int rank, int nranks, mogp_allgather_cb allgather, mogp_allreduce_cb allreduce, void* user);
+int  mogp_comm_destroy(mogp_ctx* ctx);
+/* kind: 0 none, 1 RCCL, 2 external */
+int  mogp_comm_info(mogp_ctx* ctx, int* kind, int* rank, int* nranks);
+/* mogp_exact_eval(..., MOGP_EVAL_GRAD) sharded over the context's communicator: same outputs, identical on every rank. */
+int  mogp_exact_eval_sharded(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
+                             double* lml, double* moments, double* diagG, double* trG, double* jitter_abs, int64_t* info);
+/* mogp_exact_predict (diagonal variance) sharded: the inversion as above, one all-gather of Kj^-1 (N^2 doubles), then every rank takes a
+ * block of the test points ("column blocks of K_fs are independent") and the results are summed into full mu / var on
+ * every rank. */
+int  mogp_exact_predict_sharded(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
+                                const double* kss_diag, int64_t S, const double* Xs, double* mu, double* var, int64_t* info);
+
+/* The stages of the sharded evaluation one by one, for a caller that issues the collectives itself (the numpy twin of this protocol in
+ * oracle/table_model.py runs under gloo on CPU through exactly this sequence -- mogptk_amd/dist.py:sharded_eval):
+ *   config -> begin -> for kb in 0..nblocks-1: { pack; ALL-GATHER(send -> recv, count per rank); unpack; block }
  *   alpha -> ALL-REDUCE(vec, count, sum) -> finish -> ALL-REDUCE(moments), ALL-REDUCE(diagG) on the host arrays.
- * Results equal mogp_exact_eval's (same moments / diagG definitions); lml is complete on every rank. */
+ * Pointers returned through void** are DEVICE pointers owned by the handle, counts are in doubles. */
 int  mogp_shard_config(mogp_model* m, int rank, int nranks);
 int  mogp_shard_begin(mogp_model* m, const double* noise_var, const double* data_var, double jitter, double* jitter_abs, int* nblocks);
 int  mogp_shard_pack(mogp_model* m, int kb, void** send, void** recv, int64_t* count);

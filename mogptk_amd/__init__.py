@@ -16,4 +16,4 @@ from .model import Model, Exact, Titsias, LoadModel
 from .wrappers import MOSM, SM, CSM, SM_LMC, CONV
 from .init import BNSE
 from . import gpr
-from .dist import use_distributed, use_single_device
+from .dist import use_distributed, use_single_device, use_protocol, shutdown_distributed

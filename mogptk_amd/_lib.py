@@ -13,6 +13,9 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmogp_hip.so")
 
 MOGP_OK, MOGP_EINVAL, MOGP_EHIP, MOGP_ENOTPD, MOGP_ENONFINITE, MOGP_ENODEVICE = 0, -1, -2, -3, -4, -5
 MOGP_EVAL_GRAD = 1
+COMM_ID_BYTES = 128
+ALLGATHER_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
+ALLREDUCE_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
 ST_GRAM, ST_POTRF, ST_TRTRI, ST_LAUUM, ST_SOLVE, ST_MOMENTS, ST_TOTAL, ST_GEMM_KERNEL, ST_COUNT = range(9)
 
 _lib = None
@@ -45,6 +48,13 @@ SIGNATURES = {
                                          c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_i64p]),
     "mogp_titsias_predict": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, ctypes.c_double, ctypes.c_double, c_dp,
                                             ctypes.c_int64, c_dp, c_dp, c_dp, c_i64p]),
+    "mogp_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "mogp_comm_init_rccl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "mogp_comm_init_external": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "mogp_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "mogp_comm_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "mogp_exact_eval_sharded": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, c_dp, c_dp, c_dp, c_dp, c_dp, c_i64p]),
+    "mogp_exact_predict_sharded": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.c_int64, c_dp, c_dp, c_dp, c_i64p]),
     "mogp_shard_config": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "mogp_shard_begin": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.POINTER(ctypes.c_int)]),
     "mogp_shard_pack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_i64p]),
@@ -170,9 +180,12 @@ class ExactHandle:
         noise_var = _f64(noise_var)
         data_var = _f64(data_var)
         from .gpr.config import config as _cfg
-        if grad and getattr(_cfg, "comm", None) is not None and (_cfg.comm.world > 1 or _cfg.comm.force):
+        comm = getattr(_cfg, "comm", None)
+        if grad and comm is not None and (comm.world > 1 or comm.force):
+            if getattr(comm, "native", False):
+                return self.eval_sharded(noise_var, jitter, data_var)
             from . import dist as _dist
-            return _dist.sharded_eval(self, _cfg.comm, noise_var, jitter, data_var)
+            return _dist.sharded_eval(self, comm, noise_var, jitter, data_var)
         C, T, W = self.C, self.T, 2 + 3 * self.D
         lml = ctypes.c_double()
         trG = ctypes.c_double()
@@ -186,12 +199,30 @@ class ExactHandle:
         check(code, info.value)
         return dict(lml=lml.value, moments=moments, diagG=diagG, trG=trG.value, jitter_abs=jit.value)
 
+    def eval_sharded(self, noise_var, jitter, data_var=None):
+        """mogp_exact_eval_sharded: the evaluation spread over the ranks of the context's communicator (collectives inside the library)"""
+        C, T, W = self.C, self.T, 2 + 3 * self.D
+        lml, trG, jit, info = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64(0)
+        moments, diagG = np.zeros((C * (C + 1) // 2, T, W)), np.zeros(C)
+        code = lib().mogp_exact_eval_sharded(self._h, _dp(_f64(noise_var)), _dp(_f64(data_var)), float(jitter), ctypes.byref(lml), _dp(moments),
+                                             _dp(diagG), ctypes.byref(trG), ctypes.byref(jit), ctypes.byref(info))
+        check(code, info.value)
+        return dict(lml=lml.value, moments=moments, diagG=diagG, trG=trG.value, jitter_abs=jit.value)
+
     def predict(self, noise_var, jitter, kss_diag, Xs, full=False, data_var=None):
         noise_var = _f64(noise_var)
         kss_diag = _f64(kss_diag)
         data_var = _f64(data_var)
         Xs = _f64(Xs)
         S = Xs.shape[0]
+        from .gpr.config import config as _cfg
+        comm = getattr(_cfg, "comm", None)
+        if not full and comm is not None and getattr(comm, "native", False) and (comm.world > 1 or comm.force):
+            mu, var, info = np.empty(S), np.empty(S), ctypes.c_int64(0)
+            code = lib().mogp_exact_predict_sharded(self._h, _dp(noise_var), _dp(data_var), float(jitter), _dp(kss_diag), S, _dp(Xs),
+                                                    _dp(mu), _dp(var), ctypes.byref(info))
+            check(code, info.value)
+            return mu.reshape(-1, 1), var.reshape(-1, 1)
         mu = np.empty(S)
         var = np.empty((S, S) if full else S)
         info = ctypes.c_int64(0)
@@ -229,15 +260,6 @@ class ExactHandle:
         moments, diagG = np.zeros((C * (C + 1) // 2, T, W)), np.zeros(C)
         check(lib().mogp_shard_finish(self._h, ctypes.byref(lml), _dp(moments), _dp(diagG), ctypes.byref(info)), info.value)
         return lml.value, moments, diagG
-
-    def mem_tensor(self, ptr, count):
-        import torch
-
-        class _Buf:            # __cuda_array_interface__ view of memory owned by the native library
-            pass
-        b = _Buf()
-        b.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
-        return torch.as_tensor(b, device="cuda")
 
     def mem_get(self, ptr, count):
         h = np.empty(int(count), dtype=np.float64)

@@ -482,7 +482,9 @@ static int sweep_eval_begin(mogp_model* m, const double* noise_var, const double
     ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C;
     ga.out = m->k.A.p; ga.ldo = Npad; ga.noise = m->d_noise.p; ga.dvar = data_var ? m->d_dvar.p : nullptr;
     ga.jitter_abs = m->sh_jabs; ga.mirror = 0;
-    if ((rc = launch_gram(ga, (int)m->tiles.size(), m->st))) return rc;
+    const bool own = m->sh_n > 1 && m->own_n == m->sh_n && m->own_rank == m->sh_rank;
+    if (own) ga.tiles = m->d_tiles_own.p;
+    if ((rc = launch_gram(ga, (int)(own ? m->tiles_own.size() : m->tiles.size()), m->st))) return rc;
     if ((rc = launch_pad_identity(m->k.A.p, Npad, N, Npad, m->st))) return rc;
     if ((rc = mark(m, 1))) return rc;
     return 0;
@@ -525,22 +527,30 @@ static int sweep_eval_scalars(mogp_model* m, double* lml, int64_t* info) {
     return 0;
 }
 
-// gradient-moment pass over this rank's rows of Kj^-1 (all rows when not sharded); results on the host, stream synced
-static int moment_pass(mogp_model* m, const double* kinv, double ksign, double* moments, double* diagG) {
+// gradient-moment pass over this rank's rows of Kj^-1 (all rows when not sharded): results in m->d_moments / m->d_diagG
+static int moment_pass_device(mogp_model* m, const double* kinv, double ksign) {
     const int C = m->C, D = m->D, W = 2 + 3 * D, T = m->T, P = C * (C + 1) / 2;
     const int64_t Npad = m->Npad;
     const int rm = m->sh_n > 1 ? m->sh_n : 0;
+    const bool own = m->sh_n > 1 && m->own_n == m->sh_n && m->own_rank == m->sh_rank;
     int rc;
     MomentArgs ma{};
-    ma.tiles = m->d_tiles.p; ma.ntiles = (int)m->tiles.size(); ma.x = m->d_x.p; ma.ldx = Npad; ma.nrows = ma.ncols = m->N;
+    ma.tiles = own ? m->d_tiles_own.p : m->d_tiles.p; ma.ntiles = (int)(own ? m->tiles_own.size() : m->tiles.size());
+    ma.x = m->d_x.p; ma.ldx = Npad; ma.nrows = ma.ncols = m->N;
     if ((rc = m->ph_xx.prepare(m->sx.off, m->sx.off, C, T, Npad, Npad, m->st, ma.ph))) return rc;
     ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C; ma.kinv = kinv; ma.kinv_sign = ksign; ma.ld = Npad; ma.alpha = m->d_alpha.p;
     ma.row_mod = rm; ma.row_rem = m->sh_rank;
     ma.partial = m->d_partial.p;
     if ((rc = launch_moments(ma, m->st))) return rc;
-    if ((rc = launch_moment_reduce(m->d_partial.p, m->d_pair_start.p, P, T, W, m->d_moments.p, m->st))) return rc;
+    if ((rc = launch_moment_reduce(m->d_partial.p, own ? m->d_pair_start_own.p : m->d_pair_start.p, P, T, W, m->d_moments.p, m->st))) return rc;
     if ((rc = launch_diagG(kinv, Npad, m->d_alpha.p, m->d_chan_off.p, C, m->d_diagG.p, m->st, ksign, rm, m->sh_rank))) return rc;
-    if ((rc = mark(m, 6))) return rc;
+    return mark(m, 6);
+}
+
+static int moment_pass(mogp_model* m, const double* kinv, double ksign, double* moments, double* diagG) {
+    const int C = m->C, W = 2 + 3 * m->D, T = m->T, P = C * (C + 1) / 2;
+    int rc;
+    if ((rc = moment_pass_device(m, kinv, ksign))) return rc;
     HIP_TRY(hipMemcpyAsync(moments, m->d_moments.p, (size_t)P * T * W * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(diagG, m->d_diagG.p, C * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
@@ -877,6 +887,27 @@ int mogp_gram(mogp_ctx* ctx, int C, int D, int T, const double* table, int64_t M
 int mogp_shard_config(mogp_model* m, int rank, int nranks) {
     if (!m || nranks < 1 || rank < 0 || rank >= nranks) return fail(MOGP_EINVAL, "mogp_shard_config: bad argument");
     m->sh_rank = rank; m->sh_n = nranks;
+    if (nranks > 1 && (m->own_rank != rank || m->own_n != nranks)) {
+        // each rank generates exactly the Gram / moment tiles it owns: a 64-row tile is kept if one of the (at most two)
+        // 128-row tile rows it touches belongs to this rank; nothing else of the work matrix is ever read on this rank (sweep.hip)
+        int rc;
+        if ((rc = use_device(m->ctx))) return rc;
+        m->tiles_own.clear();
+        m->pair_start_own.assign(1, 0);
+        for (size_t p = 0; p + 1 < m->pair_start.size(); ++p) {
+            for (int t = m->pair_start[p]; t < m->pair_start[p + 1]; ++t) {
+                const GTile& g = m->tiles[t];
+                const int a = g.r0 / MOGP_TILE, b = (g.r0 + g.nr - 1) / MOGP_TILE;
+                if (a % nranks == rank || b % nranks == rank) m->tiles_own.push_back(g);
+            }
+            m->pair_start_own.push_back((int)m->tiles_own.size());
+        }
+        if ((rc = m->d_tiles_own.ensure(std::max<size_t>(m->tiles_own.size(), 1)))) return rc;
+        if ((rc = m->d_pair_start_own.ensure(m->pair_start_own.size()))) return rc;
+        HIP_TRY(hipMemcpy(m->d_tiles_own.p, m->tiles_own.data(), m->tiles_own.size() * sizeof(GTile), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(m->d_pair_start_own.p, m->pair_start_own.data(), m->pair_start_own.size() * sizeof(int), hipMemcpyHostToDevice));
+        m->own_rank = rank; m->own_n = nranks;
+    }
     return MOGP_OK;
 }
 
@@ -897,6 +928,7 @@ int mogp_shard_pack(mogp_model* m, int kb, void** send, void** recv, int64_t* co
     if ((rc = use_device(m->ctx))) return rc;
     double *s = nullptr, *r = nullptr;
     if ((rc = shard_pack(m, m->k, kb, &s, &r, count))) return rc;
+    HIP_TRY(hipStreamSynchronize(m->st));           // the caller's collective runs outside this stream; the bulk stream keeps running
     *send = s; *recv = r;
     return MOGP_OK;
 }
@@ -935,6 +967,160 @@ int mogp_shard_finish(mogp_model* m, double* lml, double* moments, double* diagG
     if ((rc = mark(m, 5))) return rc;
     if ((rc = moment_pass(m, m->k.A.p, -1.0, moments, diagG))) return rc;
     m->have_Kinv = true; m->kinv_in_A = true;
+    return MOGP_OK;
+}
+
+// ---- the sharded evaluation as ONE call: the collectives are issued here, on the model's critical stream (comm.hip) ---------------------
+static int sharded_inverse(mogp_model* m, const double* noise_var, const double* data_var, double jitter, double* jitter_abs) {
+    mogp_comm& c = m->ctx->comm;
+    int rc;
+    if ((rc = mogp_shard_config(m, c.rank, c.n))) return rc;
+    if ((rc = sweep_eval_begin(m, noise_var, data_var, jitter))) return rc;
+    if ((rc = sweep_prepare(m, m->k))) return rc;
+    if (jitter_abs) *jitter_abs = m->sh_jabs;
+    const int nblocks = sweep_nblocks(m->k);
+    for (int kb = 0; kb < nblocks; ++kb) {
+        double *send = nullptr, *recv = nullptr;
+        int64_t count = 0;
+        if ((rc = shard_pack(m, m->k, kb, &send, &recv, &count))) return rc;
+        if ((rc = comm_allgather(m->ctx, send, recv, count, m->st))) return rc;       // stream ordered: no host round trip with RCCL
+        if ((rc = shard_unpack(m, m->k, kb))) return rc;
+        if ((rc = sweep_block(m, m->k, kb))) return rc;
+    }
+    if ((rc = sweep_finish(m, m->k))) return rc;
+    if ((rc = sweep_eval_alpha(m))) return rc;                                         // owned-row partial sums of alpha
+    return comm_allreduce(m->ctx, m->d_alpha.p, m->Npad, m->st);
+}
+
+int mogp_exact_eval_sharded(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
+                            double* lml, double* moments, double* diagG, double* trG, double* jitter_abs, int64_t* info) {
+    if (!m || !lml || !moments || !diagG || !trG) return fail(MOGP_EINVAL, "mogp_exact_eval_sharded: bad argument");
+    int rc;
+    if ((rc = use_device(m->ctx))) return rc;
+    if (info) *info = 0;
+    const int C = m->C, W = 2 + 3 * m->D, T = m->T, P = C * (C + 1) / 2;
+    if ((rc = sharded_inverse(m, noise_var, data_var, jitter, jitter_abs))) return rc;
+    if ((rc = mark(m, 5))) return rc;
+    if ((rc = moment_pass_device(m, m->k.A.p, -1.0))) return rc;                       // owned rows only
+    if ((rc = comm_allreduce(m->ctx, m->d_moments.p, (int64_t)P * T * W, m->st))) return rc;
+    if ((rc = comm_allreduce(m->ctx, m->d_diagG.p, C, m->st))) return rc;
+    HIP_TRY(hipMemcpyAsync(moments, m->d_moments.p, (size_t)P * T * W * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipMemcpyAsync(diagG, m->d_diagG.p, C * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    if ((rc = sweep_eval_scalars(m, lml, info))) return rc;                            // syncs the stream
+    double tr = 0.0;
+    for (int c = 0; c < C; ++c) tr += diagG[c];
+    *trG = tr;
+    m->have_Kinv = true; m->kinv_in_A = true;
+    collect_timing(m, 6);
+    return MOGP_OK;
+}
+
+// tile row i (128 rows, full width) of A: packed [idx][128][Npad] in the send buffer of its owner, idx = i / P
+__global__ void k_rows_pack(const double* __restrict__ A, int64_t ld, int nb, int P, int rank, double* __restrict__ send) {
+    const int i = rank + (int)blockIdx.x * P;
+    if (i >= nb) return;
+    const double* src = A + (int64_t)i * MOGP_TILE * ld;
+    double* dst = send + (int64_t)blockIdx.x * MOGP_TILE * ld;
+    for (int64_t e = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; e < (int64_t)MOGP_TILE * ld; e += (int64_t)gridDim.y * blockDim.x) dst[e] = src[e];
+}
+__global__ void k_rows_unpack(double* __restrict__ Kfull, int64_t ld, int nb, int P, int64_t chunk, const double* __restrict__ recv, double scale) {
+    const int r = blockIdx.z;
+    const int i = r + (int)blockIdx.x * P;
+    if (i >= nb) return;
+    const double* src = recv + (int64_t)r * chunk + (int64_t)blockIdx.x * MOGP_TILE * ld;
+    double* dst = Kfull + (int64_t)i * MOGP_TILE * ld;
+    for (int64_t e = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; e < (int64_t)MOGP_TILE * ld; e += (int64_t)gridDim.y * blockDim.x) dst[e] = scale * src[e];
+}
+// out[r] = base[r] - sum_k A[r][k] B[r][k]
+__global__ __launch_bounds__(256) void k_row_dot_sub(const double* __restrict__ A, const double* __restrict__ B, int64_t ld, int64_t rows, int64_t n,
+                                                     const double* __restrict__ base, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= rows) return;
+    double s = 0.0;
+    for (int64_t k = lane; k < n; k += 64) s = fma(A[i * ld + k], B[i * ld + k], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) out[i] = base[i] - s;
+}
+
+int mogp_exact_predict_sharded(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
+                               const double* kss_diag, int64_t S, const double* Xs, double* mu, double* var, int64_t* info) {
+    if (!m || !Xs || !mu || !var || !kss_diag || S <= 0) return fail(MOGP_EINVAL, "mogp_exact_predict_sharded: bad argument");
+    int rc;
+    if ((rc = use_device(m->ctx))) return rc;
+    if (info) *info = 0;
+    mogp_comm& cm = m->ctx->comm;
+    const int P = cm.n, rank = cm.rank, C = m->C, D = m->D, nb = m->nb;
+    const int64_t Npad = m->Npad;
+    // 1. the inversion, sharded exactly like the gradient evaluation: owned rows of -Kj^-1 in k.A, alpha complete on every rank
+    if ((rc = sharded_inverse(m, noise_var, data_var, jitter, nullptr))) return rc;
+    double lml = 0.0;
+    if ((rc = sweep_eval_scalars(m, &lml, info))) return rc;                           // failure report (not positive definite)
+    // 2. ONE all-gather of the owned tile rows -> the full Kj^-1 (lower) in k.B on every rank, then mirrored
+    const int maxrows = (nb + P - 1) / P;
+    const int64_t chunk = (int64_t)maxrows * MOGP_TILE * Npad;
+    if ((rc = m->sh_send.ensure((size_t)chunk))) return rc;
+    if ((rc = m->sh_recv.ensure((size_t)chunk * P))) return rc;
+    hipLaunchKernelGGL(k_rows_pack, dim3(maxrows, 64), dim3(256), 0, m->st, m->k.A.p, Npad, nb, P, rank, m->sh_send.p);
+    HIP_TRY(hipGetLastError());
+    if ((rc = comm_allgather(m->ctx, m->sh_send.p, m->sh_recv.p, chunk, m->st))) return rc;
+    hipLaunchKernelGGL(k_rows_unpack, dim3(maxrows, 64, P), dim3(256), 0, m->st, m->k.B.p, Npad, nb, P, chunk, m->sh_recv.p, -1.0);
+    HIP_TRY(hipGetLastError());
+    if ((rc = launch_symmetrize(m->k.B.p, Npad, Npad, m->st))) return rc;
+    // 3. this rank's block of the (channel-sorted) test points: 128-row tiles t0 .. t1
+    SortedX ss;
+    if ((rc = sort_inputs(Xs, S, D, C, MOGP_TILE, ss))) return rc;
+    const int64_t Spad = ss.Mpad;
+    const int st = (int)(Spad / MOGP_TILE), per = (st + P - 1) / P;
+    const int t0 = std::min(st, rank * per), t1 = std::min(st, t0 + per);
+    const int64_t row0 = (int64_t)t0 * MOGP_TILE, rows = (int64_t)(t1 - t0) * MOGP_TILE;
+    std::vector<GTile> all, pt;
+    build_rect_tiles(ss.off, m->sx.off, C, all);
+    for (const GTile& g : all) if (g.r0 + g.nr > row0 && g.r0 < row0 + rows) pt.push_back(g);
+    if ((rc = m->d_xs.ensure((size_t)D * Spad))) return rc;
+    if ((rc = m->d_Ksf.ensure((size_t)Spad * Npad))) return rc;
+    if ((rc = m->d_Vt.ensure((size_t)Spad * Npad))) return rc;
+    if ((rc = m->d_mu.ensure(Spad))) return rc;
+    if ((rc = m->d_var.ensure(Spad))) return rc;
+    if ((rc = m->d_kdiag.ensure(Spad))) return rc;
+    if ((rc = m->d_ptiles.ensure(std::max<size_t>(pt.size(), 1)))) return rc;
+    std::vector<double> kd(Spad, 0.0);
+    for (int c = 0; c < C; ++c)
+        for (int pos = ss.off[c]; pos < ss.off[c + 1]; ++pos) kd[pos] = kss_diag[c];
+    HIP_TRY(hipMemcpyAsync(m->d_xs.p, ss.xs.data(), (size_t)D * Spad * sizeof(double), hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemcpyAsync(m->d_kdiag.p, kd.data(), Spad * sizeof(double), hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemcpyAsync(m->d_ptiles.p, pt.data(), pt.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemsetAsync(m->d_mu.p, 0, Spad * sizeof(double), m->st));
+    HIP_TRY(hipMemsetAsync(m->d_var.p, 0, Spad * sizeof(double), m->st));
+    if (rows > 0) {
+        HIP_TRY(hipMemsetAsync(m->d_Ksf.p + row0 * Npad, 0, (size_t)rows * Npad * sizeof(double), m->st));   // padded rows / columns stay zero
+        GramArgs ga;
+        ga.tiles = m->d_ptiles.p; ga.xr = m->d_xs.p; ga.ldxr = Spad; ga.xc = m->d_x.p; ga.ldxc = Npad; ga.nrows = S; ga.ncols = m->N;
+        if ((rc = m->ph_sx.prepare(ss.off, m->sx.off, C, m->T, Spad, Npad, m->st, ga.ph))) return rc;
+        ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.out = m->d_Ksf.p; ga.ldo = Npad;
+        ga.noise = nullptr; ga.dvar = nullptr; ga.jitter_abs = 0.0; ga.mirror = 0;
+        if ((rc = launch_gram(ga, (int)pt.size(), m->st))) return rc;
+        const double* Kloc = m->d_Ksf.p + row0 * Npad;
+        if ((rc = launch_gemv_rows(Kloc, Npad, rows, Npad, m->d_alpha.p, m->d_mu.p + row0, m->st))) return rc;            // mu = K_sf alpha
+        GemmArgs g{};                                                                                                  // V = K_sf Kj^-1
+        g.A = Kloc; g.lda = Npad; g.a_kmajor = 0; g.B = m->k.B.p; g.ldb = Npad; g.b_kmajor = 0;
+        g.C = m->d_Vt.p + row0 * Npad; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
+        g.mode = GM_RECT; g.mt = t1 - t0; g.nt = nb; g.K = (int)Npad;
+        if ((rc = gemm_call(m, g, gemm_flops(g, nullptr)))) return rc;
+        hipLaunchKernelGGL(k_row_dot_sub, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, m->st, Kloc, m->d_Vt.p + row0 * Npad, Npad, rows, Npad,
+                           m->d_kdiag.p + row0, m->d_var.p + row0);                                                    // var = K_ss - rowsum(K_sf o V)
+        HIP_TRY(hipGetLastError());
+    }
+    // 4. every rank gets every block: the vectors are zero outside the own block, so a sum is a gather
+    if ((rc = comm_allreduce(m->ctx, m->d_mu.p, Spad, m->st))) return rc;
+    if ((rc = comm_allreduce(m->ctx, m->d_var.p, Spad, m->st))) return rc;
+    std::vector<double> hmu(Spad), hv(Spad);
+    HIP_TRY(hipMemcpyAsync(hmu.data(), m->d_mu.p, Spad * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipMemcpyAsync(hv.data(), m->d_var.p, Spad * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    for (int64_t pos = 0; pos < S; ++pos) { mu[ss.perm[pos]] = hmu[pos]; var[ss.perm[pos]] = hv[pos]; }
+    m->have_Kinv = false; m->have_W = false;
     return MOGP_OK;
 }
 

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -70,8 +71,18 @@ void build_rect_tiles(const std::vector<int>& offr, const std::vector<int>& offc
 
 using namespace mogp;      // private header: the global handle structs below are built from mogp:: types
 
+enum { MOGP_COMM_NONE = 0, MOGP_COMM_RCCL = 1, MOGP_COMM_EXTERNAL = 2 };
+struct mogp_comm {                       // communicator of the sharded evaluation (comm.hip)
+    int kind = MOGP_COMM_NONE, rank = 0, n = 1;
+    void* nccl = nullptr;                // ncclComm_t
+    mogp_allgather_cb allgather = nullptr;
+    mogp_allreduce_cb allreduce = nullptr;
+    void* user = nullptr;
+};
+
 struct mogp_ctx {
     int device = 0;
+    mogp_comm comm;
     std::string name;
     // streams shared by every model of the context (created once: a CU-masked stream owns a hardware queue, and models come and go)
     hipStream_t st = nullptr, st2 = nullptr, st3 = nullptr, st_priv = nullptr, st2u = nullptr;
@@ -148,6 +159,11 @@ struct mogp_model {
     DevBuf<double> swU[2], swUr[2];     // old panels of the block being swept (column part, row part), double buffered
     std::vector<hipEvent_t> sw_ev;
     int sh_rank = 0, sh_n = 1;          // sharded evaluation: this rank owns tile rows i with i % sh_n == sh_rank
+    std::vector<GTile> tiles_own;       // the Gram / moment tiles that touch an owned tile row (grouped by pair like `tiles`)
+    std::vector<int> pair_start_own;
+    DevBuf<GTile> d_tiles_own;
+    DevBuf<int> d_pair_start_own;
+    int own_rank = -1, own_n = 0;       // (rank, nranks) the owned lists were built for
     DevBuf<double> sh_send, sh_recv;
     double sh_jabs = 0.0;
     bool sh_dvar = false;
@@ -198,6 +214,8 @@ int sweep_finish(mogp_model* m, Spd& w);
 int trsm_lower(mogp_model* m, const double* L, int64_t ldl, int nb, double* B, int64_t ldb, int64_t ncols, bool trans, hipStream_t st = nullptr);
 int launch_transpose(double* dst, const double* src, int64_t ld, int64_t n, hipStream_t s);            // dst = src^T, n x n, n % 64 == 0
 int launch_sym_lower_avg(double* A, int64_t ld, int64_t n, double scale, hipStream_t s);               // lower(A) <- scale * (A + A^T) / 2
+int comm_allgather(mogp_ctx* ctx, const double* send, double* recv, int64_t count, hipStream_t st);   // count doubles per rank, device memory
+int comm_allreduce(mogp_ctx* ctx, double* buf, int64_t count, hipStream_t st);                        // sum, in place
 int shard_pack(mogp_model* m, Spd& w, int kb, double** send, double** recv, int64_t* count);
 int shard_unpack(mogp_model* m, Spd& w, int kb);
 // w.A (SPD, lower) -> -inverse (lower); w.logdet per tile; failure through m->d_info

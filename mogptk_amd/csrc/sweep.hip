@@ -188,7 +188,6 @@ int shard_pack(mogp_model* m, Spd& w, int kb, double** send, double** recv, int6
             RC(launch_copy2d(m->sh_send.p + g.rowoff + (int64_t)idx * MOGP_TILE * g.cols, g.cols, w.A.p + (int64_t)i * MOGP_TILE * w.Npad, w.Npad,
                              MOGP_TILE, g.cols, 1.0, m->st));
     }
-    HIP_TRY(hipStreamSynchronize(m->st));           // a1 / b1 of the previous block (critical stream) are in; the bulk stream keeps running
     *send = m->sh_send.p; *recv = m->sh_recv.p; *count = g.chunk;
     return 0;
 }

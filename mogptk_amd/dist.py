@@ -1,22 +1,26 @@
 """
-Sharded exact-GP evaluation across the GPUs of one node: one process per GPU, `torch.distributed`
-collectives (backend "nccl" = RCCL over xGMI in production) issued between the stage calls of the C ABI
-(`mogp_shard_*`, include/mogp_hip.h).
+Sharded exact-GP evaluation and prediction across the GPUs of one node: one process per GPU.
 
     import torch.distributed as dist, mogptk_amd
-    dist.init_process_group("nccl")
-    mogptk_amd.use_distributed()          # every gpr.Exact.loss() of this process is now sharded over the group
+    dist.init_process_group("nccl")       # or "gloo": only used here to hand 128 bytes around and, with gloo, as the transport
+    mogptk_amd.use_distributed()          # every gpr.Exact.loss() / predict_f() of this process is now sharded over the group
     model.train(...)
 
-What is exchanged per LML+gradient evaluation of an N-point model (Npad = N rounded up to 128, 512-wide pivot blocks):
-  per pivot block: ONE all-gather of the block's column panel ((Npad - k0) x 512 doubles in total) and up to four broadcasts
-  of the pivot tile rows (128 x k0 doubles each)  -- N^2 doubles per evaluation in total;
-  once: all-reduce of alpha (Npad doubles), of the gradient moments (C(C+1)/2 x T x (2+3D)) and of diag sums (C).
-Every rank holds the full training set and a full-size work matrix (8.6 GB at N = 32768: nothing against 288 GB), owns the
-128-row tile rows i with i % world == rank, repeats the cheap serial chain (512 x 512 block inversions, panels) and applies
-the rank-512 updates to its own rows only -- the O(N^3) work is divided by `world`.
+The collectives of the hot path are issued by the native library itself (mogptk_amd/csrc/comm.hip), not by torch:
+  * group backend "nccl"  -> the library opens its own RCCL communicator (unique id from rank 0, broadcast once through the group) and
+    enqueues ncclAllGather / ncclAllReduce on its own HIP streams: no host round trip inside an evaluation;
+  * any other backend     -> two callbacks that stage the device buffers through the host and call the group's collectives (tests with
+    several ranks sharing one GPU, which RCCL refuses; machines without a device transport).
+What is exchanged per LML+gradient evaluation of an N-point model (Npad = N rounded up to 128, 512-wide pivot blocks): per pivot block
+ONE all-gather -- the block's column panel, each tile row from its owner, plus the part left of the block of the pivot tile rows (N^2
+doubles per evaluation in total); once: all-reduce of alpha (Npad doubles), of the gradient moments (C(C+1)/2 x T x (2+3D)) and of the
+diagonal sums (C).  Every rank holds the full training set and a full-size work matrix (8.6 GB at N = 32768: nothing against 288 GB) but
+BUILDS only the Gram / moment tiles of the 128-row tile rows it owns (i % world == rank), repeats the cheap serial chain (512 x 512 block
+inversions, panels) and applies the rank-512 updates to its own rows only: the O(N^3) work is divided by `world`.  A sharded prediction
+adds one all-gather of Kj^-1 and splits the test points over the ranks.
 
-With backend "gloo" (CPU tests, or several ranks sharing one GPU for validation) buffers are staged through the host.
+`sharded_eval` below is the same protocol spelt out stage by stage over the `mogp_shard_*` entry points; the numpy twin of the device
+stages (oracle/table_model.py) runs it under gloo on CPU ranks in tests/test_dist_cpu.py.
 """
 import ctypes
 import numpy as np
@@ -25,10 +29,10 @@ from . import _lib
 
 
 class Comm:
-    """thin adapter over torch.distributed.  Buffers are opaque references handed out by the device handle; the handle's
-    `mem_tensor / mem_get / mem_put` turn them into a device tensor (RCCL path) or move them through the host (gloo)."""
+    """The process group as the rest of the package sees it: rank / world, and whether the native library owns the collectives
+    (`native`), in which case ExactHandle calls mogp_exact_eval_sharded / mogp_exact_predict_sharded directly."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, native=False):
         import torch
         import torch.distributed as dist
         if not dist.is_initialized():
@@ -36,94 +40,145 @@ class Comm:
         self.torch, self.dist, self.group = torch, dist, group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self.device_path = dist.get_backend(group) == "nccl"
-        self.force = False          # route even a 1-rank group through the sharded stages (validation of the RCCL plumbing)
+        self.native = native
+        self.force = False          # route even a 1-rank group through the sharded path (validation of the plumbing)
+        self._keep = []             # ctypes callbacks must outlive the communicator
 
-    def _wait(self):
-        # the collective is ordered after torch's current stream; wait for THAT stream only, so the library's bulk stream (still
-        # applying the previous pivot block's update) keeps running underneath the exchange
-        self.torch.cuda.current_stream().synchronize()
+    # ---- host-staged collectives on raw device pointers (external back end of comm.hip, and the stage-by-stage protocol below) ----
+    def _get(self, ptr, count):
+        h = np.empty(int(count), dtype=np.float64)
+        _lib.check(_lib.lib().mogp_dev_copy(h.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), 8 * int(count), 0))
+        return h
 
-    def all_gather(self, h, send, recv, count):
-        if self.device_path:
-            self.dist.all_gather_into_tensor(h.mem_tensor(recv, count * self.world), h.mem_tensor(send, count), group=self.group)
-            self._wait()
-        else:
-            s = self.torch.from_numpy(h.mem_get(send, count))
-            r = self.torch.empty(count * self.world, dtype=self.torch.float64)
+    def _put(self, ptr, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        _lib.check(_lib.lib().mogp_dev_copy(ctypes.c_void_p(ptr), arr.ctypes.data_as(ctypes.c_void_p), 8 * arr.size, 1))
+
+    def _cb_allgather(self, user, send, recv, count):
+        try:
+            s = self.torch.from_numpy(self._get(send, count))
+            r = self.torch.empty(int(count) * self.world, dtype=self.torch.float64)
             self.dist.all_gather_into_tensor(r, s, group=self.group)
-            h.mem_put(recv, r.numpy())
+            self._put(recv, r.numpy())
+            return 0
+        except Exception:           # a Python exception must not unwind through the C frame
+            import traceback
+            traceback.print_exc()
+            return 1
 
-    def broadcast(self, h, buf, count, src):
-        if count == 0:
-            return
-        if self.device_path:
-            self.dist.broadcast(h.mem_tensor(buf, count), src=src, group=self.group)
-            self._wait()
-        else:
-            t = self.torch.from_numpy(h.mem_get(buf, count) if self.rank == src else np.empty(int(count)))
-            self.dist.broadcast(t, src=src, group=self.group)
-            if self.rank != src:
-                h.mem_put(buf, t.numpy())
+    def _cb_allreduce(self, user, buf, count):
+        try:
+            t = self.torch.from_numpy(self._get(buf, count))
+            self.dist.all_reduce(t, group=self.group)
+            self._put(buf, t.numpy())
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    # ---- collectives of the stage-by-stage protocol (device handle or numpy twin) ----
+    def all_gather(self, h, send, recv, count):
+        s = self.torch.from_numpy(h.mem_get(send, count))
+        r = self.torch.empty(count * self.world, dtype=self.torch.float64)
+        self.dist.all_gather_into_tensor(r, s, group=self.group)
+        h.mem_put(recv, r.numpy())
 
     def all_reduce_buf(self, h, buf, count):
-        if self.device_path:
-            self.dist.all_reduce(h.mem_tensor(buf, count), group=self.group)
-            self._wait()
-        else:
-            t = self.torch.from_numpy(h.mem_get(buf, count))
-            self.dist.all_reduce(t, group=self.group)
-            h.mem_put(buf, t.numpy())
+        t = self.torch.from_numpy(h.mem_get(buf, count))
+        self.dist.all_reduce(t, group=self.group)
+        h.mem_put(buf, t.numpy())
 
     def all_reduce_host(self, arr):
         t = self.torch.from_numpy(arr)
-        if self.device_path:
-            t = t.cuda()
-            self.dist.all_reduce(t, group=self.group)
-            arr[...] = t.cpu().numpy()
-        else:
-            self.dist.all_reduce(t, group=self.group)
+        self.dist.all_reduce(t, group=self.group)
         return arr
 
 
-def use_distributed(group=None):
-    """shard every exact LML+gradient evaluation of this process over the ranks of `group` (default: the world)"""
+def _broadcast_bytes(comm, payload):
+    """rank 0's bytes to every rank of the group, through whatever backend the group has"""
+    torch, dist = comm.torch, comm.dist
+    on_gpu = dist.get_backend(comm.group) == "nccl"
+    t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
+    if on_gpu:
+        t = t.cuda()
+    src = dist.get_global_rank(comm.group, 0) if comm.group is not None else 0
+    dist.broadcast(t, src=src, group=comm.group)
+    return bytes(t.cpu().numpy().tobytes())
+
+
+_native = {}        # (group id, transport, device) -> Comm whose communicator lives in the native context
+
+
+def use_distributed(group=None, transport="auto"):
+    """Shard every exact LML+gradient evaluation and prediction of this process over the ranks of `group` (default: the world).
+    transport: "rccl" (the library's own RCCL communicator), "host" (callbacks staging through the host over the group's backend), or
+    "auto" (rccl when the group's backend is nccl, else host).  The communicator is created once per (group, transport) and reused."""
     from .gpr.config import config
-    config.comm = Comm(group)
+    comm = Comm(group, native=True)
+    if transport == "auto":
+        transport = "rccl" if comm.dist.get_backend(group) == "nccl" else "host"
+    key = (id(group), transport, config.device)
+    if key in _native:
+        config.comm = _native[key]
+        return config.comm
+    l = _lib.lib()
+    ctx = _lib.context(config.device)
+    if transport == "rccl":
+        ident = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+        if comm.rank == 0:
+            _lib.check(l.mogp_comm_unique_id(ident))
+        payload = _broadcast_bytes(comm, ident.raw)
+        buf = ctypes.create_string_buffer(payload, _lib.COMM_ID_BYTES)
+        _lib.check(l.mogp_comm_init_rccl(ctx, buf, comm.rank, comm.world))
+    elif transport == "host":
+        ag, ar = _lib.ALLGATHER_CB(comm._cb_allgather), _lib.ALLREDUCE_CB(comm._cb_allreduce)
+        comm._keep = [ag, ar]
+        _lib.check(l.mogp_comm_init_external(ctx, comm.rank, comm.world, ctypes.cast(ag, ctypes.c_void_p), ctypes.cast(ar, ctypes.c_void_p), None))
+    else:
+        raise ValueError("transport must be 'auto', 'rccl' or 'host'")
+    comm.transport = transport
+    _native.clear()             # a context holds one communicator: a new one replaces whatever was there
+    _native[key] = comm
+    config.comm = comm
+    return comm
+
+
+def use_protocol(group=None):
+    """Route evaluations through the stage-by-stage protocol `sharded_eval` below (collectives issued here, buffers staged through the
+    host).  This is what the CPU tests drive with the numpy twin of the device stages; on a device it is the slow, explicit form."""
+    from .gpr.config import config
+    config.comm = Comm(group, native=False)
     return config.comm
 
 
 def use_single_device():
+    """evaluations run on this process's GPU alone again (the native communicator, if any, stays alive for the next use_distributed)"""
     from .gpr.config import config
     config.comm = None
 
 
+def shutdown_distributed():
+    """destroy the native communicator (call before dist.destroy_process_group)"""
+    from .gpr.config import config
+    config.comm = None
+    if _native:
+        _native.clear()
+        _lib.check(_lib.lib().mogp_comm_destroy(_lib.context(config.device)))
+
+
 def sharded_eval(h, comm, noise_var, jitter, data_var=None):
-    """mogp_exact_eval(..., MOGP_EVAL_GRAD) sharded over comm.world ranks; same return dict on every rank.
-    `h` is a device handle (mogptk_amd._lib.ExactHandle, or its numpy twin in the tests) exposing the shard_* stages."""
-    import os, time
-    prof = os.environ.get("MOGP_SHARD_PROFILE")
-    tm = dict(begin=0.0, pack=0.0, gather=0.0, unpack_block=0.0, alpha=0.0, finish=0.0)
-    t0 = time.perf_counter()
+    """mogp_exact_eval(..., MOGP_EVAL_GRAD) sharded over comm.world ranks, one stage at a time; same return dict on every rank.
+    `h` is a device handle (mogptk_amd._lib.ExactHandle) or its numpy twin exposing the shard_* stages."""
     jit, nblocks = h.shard_begin(comm.rank, comm.world, noise_var, jitter, data_var)
-    t1 = time.perf_counter(); tm["begin"] += t1 - t0
     for kb in range(nblocks):
-        t0 = time.perf_counter()
         send, recv, count = h.shard_pack(kb)
-        t1 = time.perf_counter(); tm["pack"] += t1 - t0
         comm.all_gather(h, send, recv, count)
-        t2 = time.perf_counter(); tm["gather"] += t2 - t1
         h.shard_unpack(kb)
         h.shard_block(kb)
-        tm["unpack_block"] += time.perf_counter() - t2
-    t0 = time.perf_counter()
     buf, count = h.shard_alpha()
     comm.all_reduce_buf(h, buf, count)
-    t1 = time.perf_counter(); tm["alpha"] += t1 - t0
     lml, moments, diagG = h.shard_finish()
-    tm["finish"] += time.perf_counter() - t1
-    if prof and comm.rank == 0:
-        print("sharded_eval ms:", {k: round(1e3 * v, 2) for k, v in tm.items()}, flush=True)
     comm.all_reduce_host(moments)
     comm.all_reduce_host(diagG)
     return dict(lml=lml, moments=moments, diagG=diagG, trG=float(np.sum(diagG)), jitter_abs=jit)

@@ -31,7 +31,7 @@ WORKER = textwrap.dedent('''
     m, fp = product_exact(fx)
     ref_loss = float(m.loss()); ref_grads = [None if p.grad is None else p.grad.copy() for p in m.parameters()]
     # route grad evaluations through dist.sharded_eval: TableDevice has no comm hook of its own, so patch its eval
-    comm = mogptk_amd.use_distributed()
+    comm = mogptk_amd.use_protocol()
     from mogptk_amd import dist as D
     single = TableDevice.eval
     TableDevice.eval = lambda self, noise, jitter, grad=True, data_var=None: (

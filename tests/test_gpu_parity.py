@@ -434,11 +434,12 @@ def test_every_gradient_schedule_matches_reference(path):
     assert "SWEEP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-@pytest.mark.parametrize("ranks", [2, 4])
+@pytest.mark.parametrize("ranks", [2, 4, 8])
 def test_sharded_eval_ranks_sharing_one_gpu(ranks):
-    """the multi-GPU evaluation (mogp_shard_* + mogptk_amd.dist.sharded_eval): 2 / 4 ranks sharing this GPU over gloo (buffers staged
-    through the host) must reproduce the single-process loss and raw-parameter gradients; N = 3000 -> 24 tile rows, 6 pivot blocks,
-    ragged last tile.  With RCCL the same code exchanges device buffers directly (tools/shard_check.py --backend nccl)."""
+    """the multi-GPU evaluation and prediction (mogp_exact_eval_sharded / mogp_exact_predict_sharded: owned Gram + moment tiles, the
+    collectives issued inside the library): 2 / 4 / 8 ranks sharing this GPU -- RCCL refuses duplicate devices, so the library's
+    communicator is the external one, its callbacks staging through the host over gloo -- must reproduce the single-process loss,
+    raw-parameter gradients and predictive mean / variance; N = 3000 -> 24 tile rows, 6 pivot blocks, ragged last tile."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % ranks, "--master-addr", "127.0.0.1",
@@ -449,6 +450,21 @@ def test_sharded_eval_ranks_sharing_one_gpu(ranks):
     assert r["world"] == ranks
     assert r["rel_loss"] < 1e-10, r
     assert r["rel_grad"] < 1e-7, r          # tolerance: 1e-5 (north_star); measured ~1e-10
+    assert r["rel_predict"] < 1e-7, r       # sharded prediction (Kj^-1 all-gathered, test points split) against the one-GPU solve
+
+
+def test_rccl_communicator_single_rank():
+    """the library's own RCCL communicator (dlopen'ed librccl, unique id, ncclAllGather / ncclAllReduce on the library's streams) on a
+    1-rank group: the sharded evaluation and prediction through it equal the one-GPU ones.  More ranks need more GPUs."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29641", os.path.join(root, "tools", "shard_check.py"), "--points", "2000", "--backend", "nccl"],
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["transport"] == "rccl" and r["world"] == 1
+    assert r["rel_loss"] < 1e-10 and r["rel_grad"] < 1e-7 and r["rel_predict"] < 1e-7, r
 
 
 def test_sgd_adagrad_error_path_and_pegging_on_device():

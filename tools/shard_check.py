@@ -1,8 +1,10 @@
 """
-Run under torch.distributed.run: every rank evaluates the same exact-GP LML+gradient once alone (three-phase path) and once
-sharded over the ranks (mogptk_amd.dist.sharded_eval), and rank 0 prints the differences as one JSON line.
-  backend gloo  -> all ranks may share one GPU (buffers staged through the host): the validation mode of tests/test_gpu_parity.py
-  backend nccl  -> one GPU per rank (RCCL), the production mode
+Run under torch.distributed.run: every rank evaluates the same exact-GP LML+gradient and prediction once alone and once sharded over
+the ranks (mogp_exact_eval_sharded / mogp_exact_predict_sharded: owned Gram / moment tiles, collectives issued inside the library), and
+rank 0 prints the differences as one JSON line.
+  backend gloo  -> all ranks may share one GPU; the library's collectives go through host-staging callbacks (external communicator):
+                   the validation mode of tests/test_gpu_parity.py
+  backend nccl  -> one GPU per rank, the library's own RCCL communicator on its own streams: the production mode
 usage: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/shard_check.py [--points 3000] [--backend gloo] [--reps 3]
 """
 import argparse, json, os, sys, time
@@ -57,12 +59,20 @@ for _ in range(a.reps):
 dist.barrier()
 t_shard = (time.perf_counter() - t) / a.reps
 
+# prediction: the inversion sharded the same way, Kj^-1 all-gathered once, the test points split over the ranks
+Xs = synth.test_inputs(max(40, a.points // 10), a.channels)
+mu1, var1 = m.predict_f(Xs)
+mogptk_amd.use_single_device()
+mu0, var0 = m.predict_f(Xs)
+perr = max(float(np.max(np.abs(mu1 - mu0)) / np.max(np.abs(mu0))), float(np.max(np.abs(var1 - var0)) / np.max(np.abs(var0))))
+
 err = max(float(np.max(np.abs(b - c)) / np.max(np.abs(c))) for b, c in zip(g1, g0))
-errs = torch.tensor([abs(l1 - l0) / abs(l0), err], dtype=torch.float64)
+errs = torch.tensor([abs(l1 - l0) / abs(l0), err, perr], dtype=torch.float64)
 if a.backend == "nccl":
     errs = errs.cuda()
 dist.all_reduce(errs, op=dist.ReduceOp.MAX)
 if rank == 0:
-    print(json.dumps(dict(world=world, backend=a.backend, N=a.points, loss=l0, loss_sharded=l1, rel_loss=float(errs[0]), rel_grad=float(errs[1]),
-                          ms_single=1e3 * t_single, ms_sharded=1e3 * t_shard)))
+    print(json.dumps(dict(world=world, backend=a.backend, N=a.points, loss=l0, loss_sharded=l1, rel_loss=float(errs[0]), rel_grad=float(errs[1]), rel_predict=float(errs[2]),
+                          transport=comm.transport, ms_single=1e3 * t_single, ms_sharded=1e3 * t_shard)))
+mogptk_amd.shutdown_distributed()
 dist.destroy_process_group()
