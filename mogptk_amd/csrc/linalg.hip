@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     const double* Bp;
     double* Cp;
     int kt;
+    bool fresh = false;                  // this tile row starts from zero although the launch accumulates (beta0_from)
     if (g.mode == GM_TASKS) {
         const GemmTask t = g.tasks[blockIdx.x];
         Ap = g.A + t.a_off; Bp = g.B + t.b_off; Cp = g.C + t.c_off; kt = t.kt;
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
         if (g.mode == GM_LOWER || g.mode == GM_LAUUM) { ti = tri_row(bid); tj = bid - ti * (ti + 1) / 2; }
         else { ti = bid / g.nt; tj = bid - ti * g.nt; }
         if (g.mode == GM_RECT_LOWER && (ti + 1) * TMR <= tj * TNC) return;        // tile entirely above the diagonal
+        fresh = g.beta0_from > 0 && ti >= g.beta0_from - 1;
         if (g.row_mod > 1 && (((ti >> g.row_shift) + g.row_off) % g.row_mod) != g.row_rem) return;  // tile row owned by another rank
         int64_t k0 = 0, k1 = g.K;
         if (g.mode == GM_LAUUM || g.mode == GM_KLO_I) k0 = (int64_t)ti * TMR;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     // epilogue is a pure store of alpha * acc.
     const int crow = wi * (TMR / 2) + (lane >> 4), ccol = wj * (TNC / 2) + (lane & 15);
     d4_t acc[WTM][WTN];
-    if (g.beta != 0.0) {
+    if (g.beta != 0.0 && !fresh) {
         const double sc = g.beta / g.alpha;
 #pragma unroll
         for (int m = 0; m < WTM; ++m)

@@ -351,8 +351,20 @@ namespace mogp { double table_diag(const mogp_model* m, int c) {
 }  // namespace mogp
 
 // Gram + factorisation + inverse factor + alpha.  On return d_A holds W = L^-1, d_alpha = Kj^-1 y.
+static int pin_ensure(mogp_model* m, size_t n) {
+    if (n <= m->h_pin_n) return 0;
+    if (m->h_pin) { hipError_t e = hipHostFree(m->h_pin); (void)e; m->h_pin = nullptr; m->h_pin_n = 0; }
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_pin), n * sizeof(double), hipHostMallocDefault));
+    m->h_pin_n = n;
+    return 0;
+}
+
+static int factorize_finish(mogp_model* m, const GramArgs& ga, double* lml, int64_t* info);
+
+// defer: enqueue only -- the scalars travel to the pinned block asynchronously and factorize_finish() (after the caller's ONE stream sync)
+// turns them into the LML / the failure report
 static int factorize(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
-                     double* lml, double* jitter_abs, int64_t* info, bool fuse_inverse = false) {
+                     double* lml, double* jitter_abs, int64_t* info, bool fuse_inverse = false, bool defer = false, GramArgs* ga_out = nullptr) {
     const int C = m->C, D = m->D;
     const int64_t N = m->N, Npad = m->Npad;
     if (m->T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms must be called before an evaluation");
@@ -403,15 +415,26 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     if (fuse_inverse && (rc = spd_potri_fused_finish(m, m->k))) return rc;
     if ((rc = mark(m, 4))) return rc;
 
-    // scalars back
+    // scalars back: [nb log-det parts][nzz z^T z parts][pivot report] through the pinned block
     const int nzz = (int)((Npad + 3) / 4);
     const int nb = m->nb;
-    std::vector<double> hl(nb), hz(nzz);
-    unsigned long long hinfo = 0;
-    HIP_TRY(hipMemcpyAsync(hl.data(), m->k.logdet.p, nb * sizeof(double), hipMemcpyDeviceToHost, m->st));
-    HIP_TRY(hipMemcpyAsync(hz.data(), m->d_zz.p, nzz * sizeof(double), hipMemcpyDeviceToHost, m->st));
-    HIP_TRY(hipMemcpyAsync(&hinfo, m->d_info.p, sizeof(hinfo), hipMemcpyDeviceToHost, m->st));
+    if ((rc = pin_ensure(m, (size_t)nb + nzz + 1 + (size_t)(C * (C + 1) / 2) * m->T * (2 + 3 * D) + C))) return rc;
+    HIP_TRY(hipMemcpyAsync(m->h_pin, m->k.logdet.p, nb * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipMemcpyAsync(m->h_pin + nb, m->d_zz.p, nzz * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipMemcpyAsync(m->h_pin + nb + nzz, m->d_info.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, m->st));
+    if (ga_out) *ga_out = ga;
+    if (defer) return 0;
     HIP_TRY(hipStreamSynchronize(m->st));
+    return factorize_finish(m, ga, lml, info);
+}
+
+static int factorize_finish(mogp_model* m, const GramArgs& ga, double* lml, int64_t* info) {
+    const int64_t N = m->N, Npad = m->Npad;
+    const int nzz = (int)((Npad + 3) / 4), nb = m->nb;
+    const unsigned long long big = std::numeric_limits<unsigned long long>::max();
+    unsigned long long hinfo = 0;
+    std::memcpy(&hinfo, m->h_pin + nb + nzz, sizeof(hinfo));
+    int rc;
     if (hinfo != big) {
         if (info) *info = (int64_t)hinfo;
         // distinguish NaN / Inf in the Gram from a plain indefinite matrix (reference prints which, gpr/model.py:249-252)
@@ -427,8 +450,8 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
                                  "positive-definite (the leading minor of order " + std::to_string(hinfo) + " is not positive-definite).");
     }
     double logdet = 0.0, zz = 0.0;
-    for (double v : hl) logdet += v;
-    for (double v : hz) zz += v;
+    for (int i = 0; i < nb; ++i) logdet += m->h_pin[i];
+    for (int i = 0; i < nzz; ++i) zz += m->h_pin[nb + i];
     if (lml) *lml = -0.5 * (double)N * std::log(2.0 * M_PI) - logdet - 0.5 * zz;
     m->have_W = true;
     return 0;
@@ -673,6 +696,7 @@ int mogp_model_destroy(mogp_model* m) {
     m->d_xs.release(); m->d_Ksf.release(); m->d_Vt.release(); m->d_mu.release(); m->d_var.release(); m->d_kdiag.release();
     m->d_Kss.release(); m->d_ptiles.release();
     m->ph_xx.release(); m->ph_sx.release(); m->ph_ss.release();
+    if (m->h_pin) { hipError_t e = hipHostFree(m->h_pin); (void)e; m->h_pin = nullptr; }
 
     delete m;
     return MOGP_OK;
@@ -722,19 +746,33 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     static const std::string grad_path = []() { const char* e = std::getenv("MOGP_GRAD_PATH"); return std::string(e ? e : ""); }();
     const bool sweep = grad_path == "sweep" && (flags & MOGP_EVAL_GRAD);
     const bool fused = !sweep && (flags & MOGP_EVAL_GRAD) && (grad_path == "fused" || (grad_path != "phases" && m->nb <= 80));
+    const bool grad = (flags & MOGP_EVAL_GRAD) != 0;
+    GramArgs ga{};
     if (sweep) { if ((rc = eval_sweep(m, noise_var, data_var, jitter, lml, jitter_abs, info))) return rc; }
-    else if ((rc = factorize(m, noise_var, data_var, jitter, lml, jitter_abs, info, fused))) return rc;
-    if (!(flags & MOGP_EVAL_GRAD)) { collect_timing(m, 4); return MOGP_OK; }
+    else if ((rc = factorize(m, noise_var, data_var, jitter, lml, jitter_abs, info, fused, grad, &ga))) return rc;
+    if (!grad) { collect_timing(m, 4); return MOGP_OK; }
     if (!moments || !diagG || !trG) return fail(MOGP_EINVAL, "mogp_exact_eval: gradient outputs are null");
 
-    const int C = m->C;
+    const int C = m->C, W = 2 + 3 * m->D, T = m->T, P = C * (C + 1) / 2;
 
     // K^-1: the sweep left -Kj^-1 in k.A; the POTRF path needs W^T W (lower tiles, full diagonal tiles) in k.B
     if (!sweep && !fused && (rc = spd_lauum(m, m->k))) return rc;
     const double* kinv = sweep ? m->k.A.p : m->k.B.p;
     const double ksign = sweep ? -1.0 : 1.0;
     if ((rc = mark(m, 5))) return rc;
-    if ((rc = moment_pass(m, kinv, ksign, moments, diagG))) return rc;
+    if (sweep) {
+        if ((rc = moment_pass(m, kinv, ksign, moments, diagG))) return rc;
+    } else {
+        // everything of this evaluation is enqueued before the host waits ONCE: scalars and moments come back through the pinned block
+        if ((rc = moment_pass_device(m, kinv, ksign))) return rc;
+        const size_t off = (size_t)m->nb + (size_t)((m->Npad + 3) / 4) + 1;
+        HIP_TRY(hipMemcpyAsync(m->h_pin + off, m->d_moments.p, (size_t)P * T * W * sizeof(double), hipMemcpyDeviceToHost, m->st));
+        HIP_TRY(hipMemcpyAsync(m->h_pin + off + (size_t)P * T * W, m->d_diagG.p, C * sizeof(double), hipMemcpyDeviceToHost, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));
+        if ((rc = factorize_finish(m, ga, lml, info))) return rc;
+        std::memcpy(moments, m->h_pin + off, (size_t)P * T * W * sizeof(double));
+        std::memcpy(diagG, m->h_pin + off + (size_t)P * T * W, C * sizeof(double));
+    }
     double tr = 0.0;
     for (int c = 0; c < C; ++c) tr += diagG[c];
     *trG = tr;

@@ -127,6 +127,7 @@ struct GemmArgs {
     int mode, mt, nt, K;
     const GemmTask* tasks; int ntasks;
     int small;                                     // 0: 128x128 tiles; 1: 64x128; 2: 64x64 (mt / nt count tiles of that shape)
+    int beta0_from;                                // > 0: tile rows ti >= beta0_from - 1 are written with beta = 0 (fresh rows of an accumulator: no memset)
     int ksplit; int64_t c_split;                   // ksplit > 1: the k range is cut into ksplit slices, slice s accumulates into C + s * c_split (not with GM_TASKS)
     int row_mod, row_rem, row_off, row_shift;      // row_mod > 1: only tile rows with ((ti >> row_shift) + row_off) % row_mod == row_rem
                                                    // (sharded evaluation; row_shift = 1 when the launch uses 64-row tiles: ownership is per 128 rows)

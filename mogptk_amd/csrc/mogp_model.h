@@ -180,6 +180,9 @@ struct mogp_model {
     DevBuf<GTile> d_ptiles;
     PhaseWs ph_xx, ph_sx, ph_ss;                        // phase tables: (X, X), (Xs, X), (Xs, Xs)
 
+    double* h_pin = nullptr;            // pinned host block for the per-evaluation scalars (log-det parts, z^T z parts, pivot report, moments):
+    size_t h_pin_n = 0;                 // asynchronous device-to-host copies need page-locked memory, and with them an evaluation has ONE stream sync
+
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> ev;          // stage boundaries

@@ -111,11 +111,11 @@ int inverse_step(mogp_model* m, Spd& w, const double* Wkk, int k0, int k1, const
             RC(gemm_call(m, u, gemm_flops(u, nullptr), q));
         }
     }
-    HIP_TRY(hipMemset2DAsync(Brow, ld * sizeof(double), 0, (size_t)k1 * MOGP_TILE * sizeof(double), (size_t)Kd, q));
     GemmArgs g{};
     g.A = Wrow; g.lda = ld; g.a_kmajor = 1; g.B = Wrow; g.ldb = ld; g.b_kmajor = 1;
     g.C = w.B.p; g.ldc = ld; g.alpha = 1.0; g.beta = 1.0;
     g.mode = GM_LOWER; g.mt = g.nt = k1; g.K = (int)Kd;
+    g.beta0_from = k0 + 1;                         // the row block K of the inverse is new (it held scratch): written, not accumulated -- no memset
     return gemm_call(m, g, gemm_flops(g, nullptr), q);
 }
 
