@@ -66,6 +66,17 @@ int  mogp_model_set_y(mogp_model* m, const double* y);
  * replaces the parameter algebra at gpr/multioutput.py:182-199 (MOSM), gpr/singleoutput.py:596-600 (SM),
  * gpr/multioutput.py:432-448 (CSM) as evaluated by the host; the O(n_i n_j) part runs on the device. */
 int  mogp_model_set_terms(mogp_model* m, int T, const double* table);
+/* Terms with a Gaussian envelope on the input MIDPOINT (MultiOutputHarmonizableSpectralKernel, gpr/multioutput.py:295-395):
+ *   K_ab = sum_t A exp(-1/2 sum_d V_d u_d^2) cos(2 pi (sum_d M_d u_d + Psi)) exp(-1/2 sum_d L_d ((x_a,d + x_b,d)/2 - c_d)^2)
+ * rows of width 2 + 5 D = [ A, Psi, V_d, M_d, Delta_d, L_d, c_d ]; width 2 + 3 D is mogp_model_set_terms.  With the wide rows the gradient
+ * has two more moments per dimension, [ .., m5_d = sum G a_d^2 E cos, m6_d = sum G a_d E cos ], a_d = (x_a,d + x_b,d)/2 - c_d (every moment
+ * array of mogp_exact_eval then has rows of that width), the kernel's diagonal is no longer constant per channel -- supply it with
+ * mogp_model_set_point_diag, and pass kss_diag to mogp_exact_predict per TEST POINT (S values, caller order) instead of per channel.
+ * The Titsias entry points do not take enveloped terms. */
+int  mogp_model_set_terms_ex(mogp_model* m, int T, int width, const double* table);
+/* K_diag(X) of the N training points in the caller's row order (reference gpr/kernel.py:483-495): enters the relative jitter
+ * jitter * mean(diag) (gpr/model.py:244).  NULL: back to the per-channel constant implied by the table. */
+int  mogp_model_set_point_diag(mogp_model* m, const double* kdiag);
 
 /* replaces MultiOutputKernel.K (gpr/kernel.py:446-481); stateless, needs only a context and a term table
  * (C x C x T x MOGP_TERM_WIDTH(D)).  X1 is M1 x (1+D).  X2 == NULL: symmetric Gram K(X1), K_out is M1 x M1
@@ -73,6 +84,9 @@ int  mogp_model_set_terms(mogp_model* m, int T, const double* table);
  * (all C*C pairs, no symmetry, :468-479).  Rows may be in any order. */
 int  mogp_gram(mogp_ctx* ctx, int C, int D, int T, const double* table,
                int64_t M1, const double* X1, int64_t M2, const double* X2, double* K_out);
+/* the same with rows of `width` = 2 + 3 D or 2 + 5 D (envelope, see mogp_model_set_terms_ex) */
+int  mogp_gram_ex(mogp_ctx* ctx, int C, int D, int T, int width, const double* table,
+                  int64_t M1, const double* X1, int64_t M2, const double* X2, double* K_out);
 
 /* flags for mogp_exact_eval */
 #define MOGP_EVAL_GRAD   1   /* also compute the gradient moments */

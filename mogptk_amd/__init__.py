@@ -13,7 +13,7 @@ from .dataset import Data, DataSet
 from .transformer import (Transformer, TransformBase, TransformDetrend, TransformLinear, TransformNormalize, TransformLog,
                           TransformStandard)
 from .model import Model, Exact, Titsias, LoadModel
-from .wrappers import MOSM, SM, CSM, SM_LMC, CONV
+from .wrappers import MOSM, SM, CSM, SM_LMC, CONV, MOHSM
 from .init import BNSE
 from . import gpr
 from .dist import use_distributed, use_single_device, use_protocol, shutdown_distributed

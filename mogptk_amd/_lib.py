@@ -38,6 +38,10 @@ SIGNATURES = {
     "mogp_model_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "mogp_model_set_y": (ctypes.c_int, [ctypes.c_void_p, c_dp]),
     "mogp_model_set_terms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_dp]),
+    "mogp_model_set_terms_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_dp]),
+    "mogp_model_set_point_diag": (ctypes.c_int, [ctypes.c_void_p, c_dp]),
+    "mogp_gram_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp,
+                                    ctypes.c_int64, c_dp, ctypes.c_int64, c_dp, c_dp]),
     "mogp_gram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp,
                                  ctypes.c_int64, c_dp, ctypes.c_int64, c_dp, c_dp]),
     "mogp_exact_eval": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, ctypes.c_int,
@@ -134,8 +138,8 @@ def gram(device, C, D, table, X1, X2=None):
     M1 = X1.shape[0]
     M2 = M1 if X2 is None else X2.shape[0]
     out = np.empty((M1, M2), dtype=np.float64)
-    check(lib().mogp_gram(context(device), C, D, T, _dp(table), M1, _dp(X1),
-                          0 if X2 is None else M2, _dp(X2), _dp(out)))
+    check(lib().mogp_gram_ex(context(device), C, D, T, int(table.shape[3]), _dp(table), M1, _dp(X1),
+                             0 if X2 is None else M2, _dp(X2), _dp(out)))
     return out
 
 
@@ -171,9 +175,14 @@ class ExactHandle:
 
     def set_terms(self, table):
         table = _f64(table)
-        assert table.shape[0] == self.C and table.shape[1] == self.C and table.shape[3] == 2 + 3 * self.D
+        assert table.shape[0] == self.C and table.shape[1] == self.C and table.shape[3] in (2 + 3 * self.D, 2 + 5 * self.D)
         self.T = table.shape[2]
-        check(lib().mogp_model_set_terms(self._h, self.T, _dp(table)))
+        self.W = int(table.shape[3])                 # 2 + 3 D, or 2 + 5 D for terms with an envelope (MOHSM)
+        check(lib().mogp_model_set_terms_ex(self._h, self.T, self.W, _dp(table)))
+
+    def set_point_diag(self, kdiag):
+        """K_diag per training point for kernels whose diagonal is not constant per channel (None: back to the table's constant)"""
+        check(lib().mogp_model_set_point_diag(self._h, _dp(_f64(kdiag))))
 
     def eval(self, noise_var, jitter, grad=True, data_var=None):
         """-> dict(lml, moments[P,T,W], diagG[C], trG, jitter_abs)"""
@@ -186,7 +195,7 @@ class ExactHandle:
                 return self.eval_sharded(noise_var, jitter, data_var)
             from . import dist as _dist
             return _dist.sharded_eval(self, comm, noise_var, jitter, data_var)
-        C, T, W = self.C, self.T, 2 + 3 * self.D
+        C, T, W = self.C, self.T, self.W
         lml = ctypes.c_double()
         trG = ctypes.c_double()
         jit = ctypes.c_double()
@@ -201,7 +210,7 @@ class ExactHandle:
 
     def eval_sharded(self, noise_var, jitter, data_var=None):
         """mogp_exact_eval_sharded: the evaluation spread over the ranks of the context's communicator (collectives inside the library)"""
-        C, T, W = self.C, self.T, 2 + 3 * self.D
+        C, T, W = self.C, self.T, self.W
         lml, trG, jit, info = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64(0)
         moments, diagG = np.zeros((C * (C + 1) // 2, T, W)), np.zeros(C)
         code = lib().mogp_exact_eval_sharded(self._h, _dp(_f64(noise_var)), _dp(_f64(data_var)), float(jitter), ctypes.byref(lml), _dp(moments),
@@ -255,7 +264,7 @@ class ExactHandle:
         return buf.value, count.value
 
     def shard_finish(self):
-        C, T, W = self.C, self.T, 2 + 3 * self.D
+        C, T, W = self.C, self.T, self.W
         lml, info = ctypes.c_double(), ctypes.c_int64(0)
         moments, diagG = np.zeros((C * (C + 1) // 2, T, W)), np.zeros(C)
         check(lib().mogp_shard_finish(self._h, ctypes.byref(lml), _dp(moments), _dp(diagG), ctypes.byref(info)), info.value)

@@ -71,12 +71,12 @@ __device__ __forceinline__ double exp_taylor(double z) {
 // role 0 (rows):    cs[(o T + t) ld + a] = cos 2 pi (sum_d M_d (x_a,d + Delta_d) + Psi)   of pair (chan(a), o), term t
 // role 1 (columns): cs[(o T + t) ld + b] = cos 2 pi (sum_d M_d x_b,d)                     of pair (o, chan(b)), term t
 struct PhaseArgs {
-    const double* x; int64_t ld; const int* off; const double* table; int T, D, C, role; double* cs; double* sn;
+    const double* x; int64_t ld; const int* off; const double* table; int T, D, C, W, role; double* cs; double* sn;
 };
 __global__ __launch_bounds__(256) void k_phase_table(PhaseArgs a) {
     const int64_t pt = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (pt >= a.off[a.C]) return;
-    const int o = blockIdx.y, t = blockIdx.z, D = a.D, W = 2 + 3 * D;
+    const int o = blockIdx.y, t = blockIdx.z, D = a.D, W = a.W;
     int c = 0;
     while (pt >= a.off[c + 1]) ++c;
     const int pair = a.role == 0 ? c * a.C + o : o * a.C + c;
@@ -132,11 +132,11 @@ __host__ __device__ static inline PhaseView phase_view(double* ws, int C, int T,
 }
 
 static int launch_phase_tables(const PhaseRef& ph, const double* xr, int64_t ldxr, int64_t nr, const double* xc, int64_t ldxc, int64_t nc,
-                               const double* table, int T, int D, int C, hipStream_t s) {
+                               const double* table, int T, int D, int C, int W, hipStream_t s) {
     if (!ph.ws || !ph.offr || !ph.offc) { set_error("Gram / moment launch without a phase workspace"); return -1; }
     const PhaseView v = phase_view(ph.ws, C, T, D, ldxr, ldxc);
     PhaseArgs a;
-    a.table = table; a.T = T; a.D = D; a.C = C;
+    a.table = table; a.T = T; a.D = D; a.C = C; a.W = W;
     a.x = xr; a.ld = ldxr; a.off = ph.offr; a.role = 0; a.cs = const_cast<double*>(v.rcs); a.sn = const_cast<double*>(v.rsn);
     if (nr > 0) hipLaunchKernelGGL(k_phase_table, dim3((unsigned)((nr + 255) / 256), C, T), dim3(256), 0, s, a);
     a.x = xc; a.ld = ldxc; a.off = ph.offc; a.role = 1; a.cs = const_cast<double*>(v.ccs); a.sn = const_cast<double*>(v.csn);
@@ -159,6 +159,8 @@ template <int DM>
 struct TileLds {
     double cu[MOGP_TC][MOGP_GT], su[MOGP_TC][MOGP_GT], cw[MOGP_TC][MOGP_GT], sw[MOGP_TC][MOGP_GT];
     double V[MOGP_TC][DM], s[MOGP_TC][DM], M[MOGP_TC][DM], A[MOGP_TC];
+    double Kp[MOGP_TC][DM];                                // coefficient of the cross term p q: V - L / 4 (= V without an envelope)
+    double L[MOGP_TC][DM], e[MOGP_TC][DM];                 // envelope precision and offset: (x_a + x_b)/2 - c = (p + q)/2 + e
     int deg[MOGP_TC];
 };
 template <int DM>
@@ -214,16 +216,21 @@ __device__ __forceinline__ void stage_item_compute(TileLds<DM>& L, const StageIt
                                                    int which, int t, int pnt, int D, int t0) {
     const double* row = tab + (size_t)(t0 + t) * W;
     const double A = row[0];
-    double zmax = 0.0, es = 0.0, emin = 0.0, efac = 0.0, s[DM], V[DM];
+    const bool env = W > 2 + 3 * D;
+    double zmax = 0.0, es = 0.0, emin = 0.0, efac = 0.0, s[DM], V[DM], Lv[DM], er[DM], ec[DM];
     for (int d = 0; d < D; ++d) {
         V[d] = row[2 + d];
+        Lv[d] = env ? row[2 + 3 * D + d] : 0.0;
+        const double cn = env ? row[2 + 4 * D + d] : 0.0;
+        er[d] = X.cr[d] - cn; ec[d] = X.cc[d] - cn;
         const double hr = X.hr[d], hc = X.hc[d];
         s[d] = (X.cr[d] - X.cc[d]) + row[2 + 2 * D + d];
-        zmax += fabs(V[d]) * hr * hc;
+        zmax += fabs(V[d] - 0.25 * Lv[d]) * hr * hc;
         es += V[d] * s[d] * s[d];
         const double mu = fmax(0.0, fabs(s[d]) - hr - hc);                      // smallest |u_d| in the tile
         emin += V[d] * mu * mu;
-        efac += fabs(V[d]) * (hr * hr + hc * hc + 2.0 * (hr + hc) * fabs(s[d]));    // bound on the row / column exponents
+        const double amax = 0.5 * (fabs(er[d]) + hr + fabs(ec[d]) + hc);          // largest |midpoint - c| in the tile
+        efac += fabs(V[d]) * (hr * hr + hc * hc + 2.0 * (hr + hc) * fabs(s[d])) + Lv[d] * amax * amax;    // bound on the row / column exponents
     }
     int deg;
     if ((AMP && A == 0.0) || 0.5 * emin > GT_SKIP_EXPONENT) deg = GT_SKIP;
@@ -231,16 +238,30 @@ __device__ __forceinline__ void stage_item_compute(TileLds<DM>& L, const StageIt
     else deg = zmax <= 1.19e-3 ? 4 : (zmax <= 0.0139 ? 6 : (zmax <= 0.0578 ? 8 : (zmax <= 0.2147 ? 11 : 14)));
     if (pnt == 0 && which == 0) {
         L.deg[t] = deg; L.A[t] = A;
-        for (int d = 0; d < D; ++d) { L.V[t][d] = V[d]; L.s[t][d] = s[d]; L.M[t][d] = row[2 + D + d]; }
+        for (int d = 0; d < D; ++d) {
+            L.V[t][d] = V[d]; L.s[t][d] = s[d]; L.M[t][d] = row[2 + D + d];
+            L.Kp[t][d] = V[d] - 0.25 * Lv[d]; L.L[t][d] = Lv[d]; L.e[t][d] = 0.5 * (er[d] + ec[d]);
+        }
     }
     if (deg == GT_SKIP) return;
     double f = 1.0;
     if (deg != GT_GENERAL) {
+        // exponent = -1/2 V (p - q + s)^2 - L/8 ((p + er) + (q + ec))^2, split into a row part, a column part and the cross term (V - L/4) p q
         double e = 0.0;
-        if (which == 0) {                                  // rows: exp(-1/2 V (p + s)^2), the tile scalar exp(-1/2 V s^2) included
-            for (int d = 0; d < D; ++d) { const double pp = I.x[d] - X.cr[d]; e = fma(V[d], fma(pp, pp, s[d] * s[d]) + 2.0 * pp * s[d], e); }
-        } else {                                           // columns: exp(-1/2 V (q^2 - 2 q s))
-            for (int d = 0; d < D; ++d) { const double qq = I.x[d] - X.cc[d]; e = fma(V[d], qq * qq - 2.0 * qq * s[d], e); }
+        if (which == 0) {                                  // rows: the tile scalars exp(-1/2 V s^2 - L/4 er ec) included
+            for (int d = 0; d < D; ++d) {
+                const double pp = I.x[d] - X.cr[d];
+                e = fma(V[d], fma(pp, pp, s[d] * s[d]) + 2.0 * pp * s[d], e);
+                const double pe = pp + er[d];
+                e = fma(0.25 * Lv[d], pe * pe + 2.0 * ec[d] * pe, e);
+            }
+        } else {                                           // columns
+            for (int d = 0; d < D; ++d) {
+                const double qq = I.x[d] - X.cc[d];
+                e = fma(V[d], qq * qq - 2.0 * qq * s[d], e);
+                const double qe = qq + ec[d];
+                e = fma(0.25 * Lv[d], qe * qe + 2.0 * qq * er[d], e);
+            }
         }
         f = fast_exp(-0.5 * e);
     }
@@ -281,20 +302,26 @@ __device__ __forceinline__ void stage_chunk(TileLds<DM>& L, const TileCtx<DM>& X
 
 // Gaussian factor of one entry on the general path
 template <int DM>
-__device__ __forceinline__ double gauss_general(const double (&p)[DM], const double (&q)[DM], const double* V, const double* s, int D) {
+__device__ __forceinline__ double gauss_general(const double (&p)[DM], const double (&q)[DM], const double* V, const double* s,
+                                                const double* Lv, const double* ev, int D) {
     double arg = 0.0;
-    for (int d = 0; d < D; ++d) { const double u = (p[d] - q[d]) + s[d]; arg = fma(V[d] * u, u, arg); }
+    for (int d = 0; d < D; ++d) {
+        const double u = (p[d] - q[d]) + s[d];
+        arg = fma(V[d] * u, u, arg);
+        const double a = 0.5 * (p[d] + q[d]) + ev[d];          // envelope on the midpoint (L = 0 without one)
+        arg = fma(Lv[d] * a, a, arg);
+    }
     return exp(-0.5 * arg);
 }
 
 template <int DM, int N>
-__device__ __forceinline__ void gram_term(double (&acc)[4][4], const double (&p)[4][DM], const double (&q)[4][DM], const double* V, const double* s,
+__device__ __forceinline__ void gram_term(double (&acc)[4][4], const double (&p)[4][DM], const double (&q)[4][DM], const TileLds<DM>& L, int t,
                                           int D, const double (&cu)[4], const double (&su)[4], const double (&cw)[4], const double (&sw)[4]) {
     double vp[4][DM];
     if (N > 0) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-            for (int d = 0; d < D; ++d) vp[m][d] = V[d] * p[m][d];
+            for (int d = 0; d < D; ++d) vp[m][d] = L.Kp[t][d] * p[m][d];
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -308,7 +335,7 @@ __device__ __forceinline__ void gram_term(double (&acc)[4][4], const double (&p)
                 for (int d = 1; d < D; ++d) z = fma(vp[m][d], q[n][d], z);
                 e = exp_taylor<N>(z);
             } else {
-                e = gauss_general<DM>(p[m], q[n], V, s, D);
+                e = gauss_general<DM>(p[m], q[n], L.V[t], L.s[t], L.L[t], L.e[t], D);
             }
             acc[m][n] = fma(e, fma(cu[m], cw[n], su[m] * sw[n]), acc[m][n]);
         }
@@ -364,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a, int ntiles) {
     constexpr int DM = DT > 0 ? DT : MOGP_MAXD;
     constexpr bool BATCH = DT == 1;
     const int D = DT > 0 ? DT : a.D;
-    const int W = 2 + 3 * D;
+    const int W = a.W;
     const int tid = threadIdx.x;
     const int cg = tid & 15, rg = tid >> 4;
     __shared__ TileLds<DM> Lb[2];
@@ -447,12 +474,12 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a, int ntiles) {
                     cw[m] = L.cw[t][cg * 4 + m]; sw[m] = L.sw[t][cg * 4 + m];
                 }
                 switch (deg) {
-                    case 4: gram_term<DM, 4>(acc, pc, qc, L.V[t], L.s[t], D, cu, su, cw, sw); break;
-                    case 6: gram_term<DM, 6>(acc, pc, qc, L.V[t], L.s[t], D, cu, su, cw, sw); break;
-                    case 8: gram_term<DM, 8>(acc, pc, qc, L.V[t], L.s[t], D, cu, su, cw, sw); break;
-                    case 11: gram_term<DM, 11>(acc, pc, qc, L.V[t], L.s[t], D, cu, su, cw, sw); break;
-                    case 14: gram_term<DM, 14>(acc, pc, qc, L.V[t], L.s[t], D, cu, su, cw, sw); break;
-                    default: gram_term<DM, 0>(acc, pc, qc, L.V[t], L.s[t], D, cu, su, cw, sw); break;
+                    case 4: gram_term<DM, 4>(acc, pc, qc, L, t, D, cu, su, cw, sw); break;
+                    case 6: gram_term<DM, 6>(acc, pc, qc, L, t, D, cu, su, cw, sw); break;
+                    case 8: gram_term<DM, 8>(acc, pc, qc, L, t, D, cu, su, cw, sw); break;
+                    case 11: gram_term<DM, 11>(acc, pc, qc, L, t, D, cu, su, cw, sw); break;
+                    case 14: gram_term<DM, 14>(acc, pc, qc, L, t, D, cu, su, cw, sw); break;
+                    default: gram_term<DM, 0>(acc, pc, qc, L, t, D, cu, su, cw, sw); break;
                 }
             }
         }
@@ -467,13 +494,14 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a, int ntiles) {
 int launch_gram(const GramArgs& a0, int ntiles, hipStream_t s) {
     if (ntiles <= 0) return 0;
     GramArgs a = a0;
+    if (a.W <= 0) a.W = 2 + 3 * a.D;
     static const int dbg = []() { const char* e = std::getenv("MOGP_GRAM_DBG"); return e ? std::atoi(e) : 0; }();
     a.dbg = dbg;
-    int rc = launch_phase_tables(a.ph, a.xr, a.ldxr, a.nrows, a.xc, a.ldxc, a.ncols, a.table, a.T, a.D, a.C, s);
+    int rc = launch_phase_tables(a.ph, a.xr, a.ldxr, a.nrows, a.xc, a.ldxc, a.ncols, a.table, a.T, a.D, a.C, a.W, s);
     if (rc) return rc;
     static const int ncu = []() { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256; return pr.multiProcessorCount; }();
     const int grid = std::min(ntiles, 2 * ncu);              // persistent: two workgroups per CU (__launch_bounds__(256, 2))
-    const size_t tab_bytes = (size_t)a.C * a.C * a.T * (2 + 3 * a.D) * sizeof(double);
+    const size_t tab_bytes = (size_t)a.C * a.C * a.T * a.W * sizeof(double);
     a.tab_lds = tab_bytes <= 24 * 1024;                      // the term table rides in LDS when small (it is read by every staging item)
     const size_t dyn = a.tab_lds ? tab_bytes : 0;
     switch (a.D) {
@@ -497,16 +525,20 @@ int launch_gram(const GramArgs& a0, int ntiles, hipStream_t s) {
 //     dK_ab/dx_a,d = sum_t A_t E [ -V_d u_d cos - 2 pi M_d sin ] = - dK_ab/dx_b,d.
 // A thread accumulates the W moments of its 16 entries of one term in registers; the workgroup reduction goes through LDS (16 slice sums
 // of 16 threads each, then a 4-step butterfly: fixed order, bit-reproducible) with ONE barrier per term.
-template <int DM, int N, bool ZG>
+template <int DM, int N, bool ZG, bool ENV>
 __device__ __forceinline__ void moment_term(double* mom, const double (&g)[4][4], const double (&p)[4][DM], const double (&q)[4][DM],
-                                            const double* V, const double* s, const double* Mv, double A, int D,
+                                            const TileLds<DM>& L, int t, int D,
                                             const double (&cu)[4], const double (&su)[4], const double (&cw)[4], const double (&sw)[4],
                                             double (&zr)[4][DM], double (&zc)[4][DM]) {
+    const double* V = L.V[t];
+    const double* s = L.s[t];
+    const double* Mv = L.M[t];
+    const double A = L.A[t];
     double vp[4][DM];
     if (N > 0) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-            for (int d = 0; d < D; ++d) vp[m][d] = V[d] * p[m][d];
+            for (int d = 0; d < D; ++d) vp[m][d] = L.Kp[t][d] * p[m][d];
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -520,7 +552,7 @@ __device__ __forceinline__ void moment_term(double* mom, const double (&g)[4][4]
                 for (int d = 1; d < D; ++d) z = fma(vp[m][d], q[n][d], z);
                 e = exp_taylor<N>(z);
             } else {
-                e = gauss_general<DM>(p[m], q[n], V, s, D);
+                e = gauss_general<DM>(p[m], q[n], V, s, L.L[t], L.e[t], D);
             }
             const double ge = g[m][n] * e;
             const double kc = ge * fma(cu[m], cw[n], su[m] * sw[n]);
@@ -532,6 +564,12 @@ __device__ __forceinline__ void moment_term(double* mom, const double (&g)[4][4]
                 mom[2 + d] = fma(u[d], uk, mom[2 + d]);
                 mom[2 + D + d] += uk;
                 mom[2 + 2 * D + d] = fma(u[d], ks, mom[2 + 2 * D + d]);
+                if (ENV) {                                 // envelope moments: a = midpoint - centre
+                    const double a = 0.5 * (p[m][d] + q[n][d]) + L.e[t][d];
+                    const double ak = a * kc;
+                    mom[2 + 3 * D + d] = fma(a, ak, mom[2 + 3 * D + d]);
+                    mom[2 + 4 * D + d] += ak;
+                }
                 if (ZG) {
                     const double j = -A * fma(V[d], uk, 6.283185307179586476925286766559 * Mv[d] * ks);
                     zr[m][d] += j;
@@ -541,14 +579,14 @@ __device__ __forceinline__ void moment_term(double* mom, const double (&g)[4][4]
         }
 }
 
-template <int DT, bool DENSE, bool ZG>
+template <int DT, bool DENSE, bool ZG, bool ENV>
 __global__ __launch_bounds__(256) void k_moments(MomentArgs a) {
     constexpr int DM = DT > 0 ? DT : MOGP_MAXD;
-    constexpr int WM = 2 + 3 * DM;
+    constexpr int WM = 2 + (ENV ? 5 : 3) * DM;
     constexpr int RSTRIDE = 256 + 16;                        // one moment of all threads, +1 per 16 (the slice reads hit distinct banks)
     constexpr int NBUF = WM <= 11 ? 2 : 1;                   // double-buffered reduction staging: one barrier per term instead of two
     const int D = DT > 0 ? DT : a.D;
-    const int W = 2 + 3 * D;
+    const int W = a.W;
     const GTile tl = a.tiles[blockIdx.x];
     const double* tab = a.table + (size_t)tl.pair * a.T * W;
     const int tid = threadIdx.x;
@@ -634,12 +672,12 @@ __global__ __launch_bounds__(256) void k_moments(MomentArgs a) {
                 cw[m] = L.cw[t][cg * 4 + m]; sw[m] = L.sw[t][cg * 4 + m];
             }
             switch (deg) {
-                case 4: moment_term<DM, 4, ZG>(mom, g, p, q, L.V[t], L.s[t], L.M[t], L.A[t], D, cu, su, cw, sw, zr, zc); break;
-                case 6: moment_term<DM, 6, ZG>(mom, g, p, q, L.V[t], L.s[t], L.M[t], L.A[t], D, cu, su, cw, sw, zr, zc); break;
-                case 8: moment_term<DM, 8, ZG>(mom, g, p, q, L.V[t], L.s[t], L.M[t], L.A[t], D, cu, su, cw, sw, zr, zc); break;
-                case 11: moment_term<DM, 11, ZG>(mom, g, p, q, L.V[t], L.s[t], L.M[t], L.A[t], D, cu, su, cw, sw, zr, zc); break;
-                case 14: moment_term<DM, 14, ZG>(mom, g, p, q, L.V[t], L.s[t], L.M[t], L.A[t], D, cu, su, cw, sw, zr, zc); break;
-                default: moment_term<DM, 0, ZG>(mom, g, p, q, L.V[t], L.s[t], L.M[t], L.A[t], D, cu, su, cw, sw, zr, zc); break;
+                case 4: moment_term<DM, 4, ZG, ENV>(mom, g, p, q, L, t, D, cu, su, cw, sw, zr, zc); break;
+                case 6: moment_term<DM, 6, ZG, ENV>(mom, g, p, q, L, t, D, cu, su, cw, sw, zr, zc); break;
+                case 8: moment_term<DM, 8, ZG, ENV>(mom, g, p, q, L, t, D, cu, su, cw, sw, zr, zc); break;
+                case 11: moment_term<DM, 11, ZG, ENV>(mom, g, p, q, L, t, D, cu, su, cw, sw, zr, zc); break;
+                case 14: moment_term<DM, 14, ZG, ENV>(mom, g, p, q, L, t, D, cu, su, cw, sw, zr, zc); break;
+                default: moment_term<DM, 0, ZG, ENV>(mom, g, p, q, L, t, D, cu, su, cw, sw, zr, zc); break;
             }
             // workgroup reduction of the W moments of this term through LDS, fixed order: thread (w, i) adds the values of threads
             // 16 i .. 16 i + 15, a 4-step butterfly over i finishes.  With two staging buffers the next term's writes need no second
@@ -684,27 +722,31 @@ __global__ __launch_bounds__(256) void k_moments(MomentArgs a) {
     }
 }
 
-template <bool DENSE, bool ZG>
+template <bool DENSE, bool ZG, bool ENV>
 static int launch_moments_t(const MomentArgs& a, hipStream_t s) {
     switch (a.D) {
-        case 1: hipLaunchKernelGGL((k_moments<1, DENSE, ZG>), dim3(a.ntiles), dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((k_moments<2, DENSE, ZG>), dim3(a.ntiles), dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL((k_moments<3, DENSE, ZG>), dim3(a.ntiles), dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((k_moments<0, DENSE, ZG>), dim3(a.ntiles), dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((k_moments<1, DENSE, ZG, ENV>), dim3(a.ntiles), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_moments<2, DENSE, ZG, ENV>), dim3(a.ntiles), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((k_moments<3, DENSE, ZG, ENV>), dim3(a.ntiles), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_moments<0, DENSE, ZG, ENV>), dim3(a.ntiles), dim3(256), 0, s, a); break;
     }
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-int launch_moments(const MomentArgs& a, hipStream_t s) {
-    if (a.ntiles <= 0) return 0;
+int launch_moments(const MomentArgs& a0, hipStream_t s) {
+    if (a0.ntiles <= 0) return 0;
+    MomentArgs a = a0;
+    if (a.W <= 0) a.W = 2 + 3 * a.D;
+    const bool env = a.W > 2 + 3 * a.D;
     const double* xc = a.xc ? a.xc : a.x;
     const int64_t ldxc = a.xc ? a.ldxc : a.ldx;
-    int rc = launch_phase_tables(a.ph, a.x, a.ldx, a.nrows, xc, ldxc, a.xc ? a.ncols : a.nrows, a.table, a.T, a.D, a.C, s);
+    int rc = launch_phase_tables(a.ph, a.x, a.ldx, a.nrows, xc, ldxc, a.xc ? a.ncols : a.nrows, a.table, a.T, a.D, a.C, a.W, s);
     if (rc) return rc;
-    if (a.G == nullptr) return launch_moments_t<false, false>(a, s);
-    if (a.gzr || a.gzc) return launch_moments_t<true, true>(a, s);
-    return launch_moments_t<true, false>(a, s);
+    if (a.G == nullptr) return env ? launch_moments_t<false, false, true>(a, s) : launch_moments_t<false, false, false>(a, s);
+    if (env) { set_error("the dense-adjoint moment pass (Titsias) does not take terms with an envelope"); return -1; }
+    if (a.gzr || a.gzc) return launch_moments_t<true, true, false>(a, s);
+    return launch_moments_t<true, false, false>(a, s);
 }
 
 // one workgroup per (lower channel pair, moment entry): 256 threads stride over that pair's tiles, then a fixed-shape
@@ -713,7 +755,7 @@ int launch_moments(const MomentArgs& a, hipStream_t s) {
 // cancel between (a, b) and (b, a) in the full symmetric sum; the lower-triangle pass cannot see that, so they are
 // set to their exact value, zero, here.
 __global__ __launch_bounds__(256) void k_moment_reduce(const double* __restrict__ partial, const int* __restrict__ pair_start,
-                                                       int TW, int W, int lower_pairs, double* __restrict__ out) {
+                                                       int TW, int W, int D, int lower_pairs, double* __restrict__ out) {
     const int p = blockIdx.x, tw = blockIdx.y;
     const int b = pair_start[p], e = pair_start[p + 1];
     __shared__ double red[256];
@@ -730,15 +772,15 @@ __global__ __launch_bounds__(256) void k_moment_reduce(const double* __restrict_
         while ((i + 1) * (i + 2) / 2 <= p) ++i;
         while (i * (i + 1) / 2 > p) --i;
         const bool diag = lower_pairs && (p - i * (i + 1) / 2) == i;
-        const int D = (W - 2) / 3, w = tw % W;
+        const int w = tw % W;
         double v = red[0];
         if (diag && (w == 1 || (w >= 2 + D && w < 2 + 2 * D))) v = 0.0;
         out[(size_t)p * TW + tw] = v;
     }
 }
 
-int launch_moment_reduce(const double* partial, const int* pair_start, int npairs, int T, int W, double* out, hipStream_t s, int lower_pairs) {
-    hipLaunchKernelGGL(k_moment_reduce, dim3(npairs, T * W), dim3(256), 0, s, partial, pair_start, T * W, W, lower_pairs, out);
+int launch_moment_reduce(const double* partial, const int* pair_start, int npairs, int T, int W, int D, double* out, hipStream_t s, int lower_pairs) {
+    hipLaunchKernelGGL(k_moment_reduce, dim3(npairs, T * W), dim3(256), 0, s, partial, pair_start, T * W, W, D, lower_pairs, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }

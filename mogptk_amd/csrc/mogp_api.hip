@@ -337,7 +337,7 @@ namespace mogp { int spd_alloc(Spd& w, int64_t Npad) {
 
 // diagonal value of channel block (c, c) implied by the table (Delta = Psi = 0 there for every kernel on the path)
 namespace mogp { double table_diag(const mogp_model* m, int c) {
-    const int D = m->D, W = 2 + 3 * D;
+    const int D = m->D, W = m->Wt;
     const double* tab = m->table.data() + (size_t)(c * m->C + c) * m->T * W;
     double s = 0.0;
     for (int t = 0; t < m->T; ++t) {
@@ -374,6 +374,10 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
 
     // host scalars: mean of the diagonal for the relative jitter (reference gpr/model.py:244)
     double dsum = 0.0;
+    if (!m->point_diag.empty()) {       // non-stationary kernels: the caller supplied K_diag per point (mogp_model_set_point_diag)
+        for (int c = 0; c < C; ++c)
+            for (int k = m->sx.off[c]; k < m->sx.off[c + 1]; ++k) dsum += m->point_diag[k] + noise_var[c];
+    } else
     for (int c = 0; c < C; ++c) dsum += (double)(m->sx.off[c + 1] - m->sx.off[c]) * (table_diag(m, c) + noise_var[c]);
     std::vector<double> dv;
     if (data_var) {
@@ -394,7 +398,7 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     GramArgs ga;
     ga.tiles = m->d_tiles.p; ga.xr = m->d_x.p; ga.xc = m->d_x.p; ga.ldxr = ga.ldxc = Npad; ga.nrows = ga.ncols = N;
     if ((rc = m->ph_xx.prepare(m->sx.off, m->sx.off, C, m->T, Npad, Npad, m->st, ga.ph))) return rc;
-    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C;
+    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = m->Wt;
     ga.out = m->k.A.p; ga.ldo = Npad; ga.noise = m->d_noise.p; ga.dvar = data_var ? m->d_dvar.p : nullptr;
     ga.jitter_abs = jabs; ga.mirror = 0;
     if ((rc = launch_gram(ga, (int)m->tiles.size(), m->st))) return rc;
@@ -418,7 +422,7 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     // scalars back: [nb log-det parts][nzz z^T z parts][pivot report] through the pinned block
     const int nzz = (int)((Npad + 3) / 4);
     const int nb = m->nb;
-    if ((rc = pin_ensure(m, (size_t)nb + nzz + 1 + (size_t)(C * (C + 1) / 2) * m->T * (2 + 3 * D) + C))) return rc;
+    if ((rc = pin_ensure(m, (size_t)nb + nzz + 1 + (size_t)(C * (C + 1) / 2) * m->T * m->Wt + C))) return rc;
     HIP_TRY(hipMemcpyAsync(m->h_pin, m->k.logdet.p, nb * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(m->h_pin + nb, m->d_zz.p, nzz * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(m->h_pin + nb + nzz, m->d_info.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, m->st));
@@ -485,6 +489,10 @@ static int sweep_eval_begin(mogp_model* m, const double* noise_var, const double
     m->have_W = m->have_Kinv = false;
     m->gemm_ev_used = 0; m->gemm_launches = 0; m->gemm_flops = 0.0;
     double dsum = 0.0;
+    if (!m->point_diag.empty()) {
+        for (int c = 0; c < C; ++c)
+            for (int k = m->sx.off[c]; k < m->sx.off[c + 1]; ++k) dsum += m->point_diag[k] + noise_var[c];
+    } else
     for (int c = 0; c < C; ++c) dsum += (double)(m->sx.off[c + 1] - m->sx.off[c]) * (table_diag(m, c) + noise_var[c]);
     m->sh_dvar = data_var != nullptr;
     if (data_var) {
@@ -502,7 +510,7 @@ static int sweep_eval_begin(mogp_model* m, const double* noise_var, const double
     GramArgs ga{};
     ga.tiles = m->d_tiles.p; ga.xr = m->d_x.p; ga.xc = m->d_x.p; ga.ldxr = ga.ldxc = Npad; ga.nrows = ga.ncols = N;
     if ((rc = m->ph_xx.prepare(m->sx.off, m->sx.off, C, m->T, Npad, Npad, m->st, ga.ph))) return rc;
-    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C;
+    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = m->Wt;
     ga.out = m->k.A.p; ga.ldo = Npad; ga.noise = m->d_noise.p; ga.dvar = data_var ? m->d_dvar.p : nullptr;
     ga.jitter_abs = m->sh_jabs; ga.mirror = 0;
     const bool own = m->sh_n > 1 && m->own_n == m->sh_n && m->own_rank == m->sh_rank;
@@ -552,7 +560,7 @@ static int sweep_eval_scalars(mogp_model* m, double* lml, int64_t* info) {
 
 // gradient-moment pass over this rank's rows of Kj^-1 (all rows when not sharded): results in m->d_moments / m->d_diagG
 static int moment_pass_device(mogp_model* m, const double* kinv, double ksign) {
-    const int C = m->C, D = m->D, W = 2 + 3 * D, T = m->T, P = C * (C + 1) / 2;
+    const int C = m->C, D = m->D, W = m->Wt, T = m->T, P = C * (C + 1) / 2;
     const int64_t Npad = m->Npad;
     const int rm = m->sh_n > 1 ? m->sh_n : 0;
     const bool own = m->sh_n > 1 && m->own_n == m->sh_n && m->own_rank == m->sh_rank;
@@ -561,17 +569,17 @@ static int moment_pass_device(mogp_model* m, const double* kinv, double ksign) {
     ma.tiles = own ? m->d_tiles_own.p : m->d_tiles.p; ma.ntiles = (int)(own ? m->tiles_own.size() : m->tiles.size());
     ma.x = m->d_x.p; ma.ldx = Npad; ma.nrows = ma.ncols = m->N;
     if ((rc = m->ph_xx.prepare(m->sx.off, m->sx.off, C, T, Npad, Npad, m->st, ma.ph))) return rc;
-    ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C; ma.kinv = kinv; ma.kinv_sign = ksign; ma.ld = Npad; ma.alpha = m->d_alpha.p;
+    ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C; ma.W = W; ma.kinv = kinv; ma.kinv_sign = ksign; ma.ld = Npad; ma.alpha = m->d_alpha.p;
     ma.row_mod = rm; ma.row_rem = m->sh_rank;
     ma.partial = m->d_partial.p;
     if ((rc = launch_moments(ma, m->st))) return rc;
-    if ((rc = launch_moment_reduce(m->d_partial.p, own ? m->d_pair_start_own.p : m->d_pair_start.p, P, T, W, m->d_moments.p, m->st))) return rc;
+    if ((rc = launch_moment_reduce(m->d_partial.p, own ? m->d_pair_start_own.p : m->d_pair_start.p, P, T, W, D, m->d_moments.p, m->st))) return rc;
     if ((rc = launch_diagG(kinv, Npad, m->d_alpha.p, m->d_chan_off.p, C, m->d_diagG.p, m->st, ksign, rm, m->sh_rank))) return rc;
     return mark(m, 6);
 }
 
 static int moment_pass(mogp_model* m, const double* kinv, double ksign, double* moments, double* diagG) {
-    const int C = m->C, W = 2 + 3 * m->D, T = m->T, P = C * (C + 1) / 2;
+    const int C = m->C, W = m->Wt, T = m->T, P = C * (C + 1) / 2;
     int rc;
     if ((rc = moment_pass_device(m, kinv, ksign))) return rc;
     HIP_TRY(hipMemcpyAsync(moments, m->d_moments.p, (size_t)P * T * W * sizeof(double), hipMemcpyDeviceToHost, m->st));
@@ -713,20 +721,37 @@ int mogp_model_set_y(mogp_model* m, const double* y) {
     return MOGP_OK;
 }
 
-int mogp_model_set_terms(mogp_model* m, int T, const double* table) {
+int mogp_model_set_terms_ex(mogp_model* m, int T, int width, const double* table) {
     if (!m || !table || T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms: bad argument");
+    if (width != 2 + 3 * m->D && width != 2 + 5 * m->D) return fail(MOGP_EINVAL, "mogp_model_set_terms: the row width must be 2 + 3 D or 2 + 5 D");
     int rc;
     if ((rc = use_device(m->ctx))) return rc;
-    const int W = 2 + 3 * m->D;
+    const int W = width;
     const size_t n = (size_t)m->C * m->C * T * W;
     for (size_t i = 0; i < n; ++i)
         if (!std::isfinite(table[i])) return fail(MOGP_ENONFINITE, "spectral term table has non-finite entries (kernel parameters diverged)");
     m->T = T;
+    m->Wt = W;
     m->table.assign(table, table + n);
     if ((rc = m->d_table.ensure(n))) return rc;
     if ((rc = m->d_partial.ensure(m->tiles.size() * (size_t)T * W))) return rc;
     if ((rc = m->d_moments.ensure((size_t)(m->C * (m->C + 1) / 2) * T * W))) return rc;
     HIP_TRY(hipMemcpyAsync(m->d_table.p, m->table.data(), n * sizeof(double), hipMemcpyHostToDevice, m->st));
+    return MOGP_OK;
+}
+
+int mogp_model_set_terms(mogp_model* m, int T, const double* table) {
+    if (!m) return fail(MOGP_EINVAL, "mogp_model_set_terms: bad argument");
+    return mogp_model_set_terms_ex(m, T, 2 + 3 * m->D, table);
+}
+
+int mogp_model_set_point_diag(mogp_model* m, const double* kdiag) {
+    if (!m) return fail(MOGP_EINVAL, "mogp_model_set_point_diag: model is null");
+    m->point_diag.clear();
+    if (kdiag) {
+        m->point_diag.resize(m->N);
+        for (int64_t pos = 0; pos < m->N; ++pos) m->point_diag[pos] = kdiag[m->sx.perm[pos]];
+    }
     return MOGP_OK;
 }
 
@@ -753,7 +778,7 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     if (!grad) { collect_timing(m, 4); return MOGP_OK; }
     if (!moments || !diagG || !trG) return fail(MOGP_EINVAL, "mogp_exact_eval: gradient outputs are null");
 
-    const int C = m->C, W = 2 + 3 * m->D, T = m->T, P = C * (C + 1) / 2;
+    const int C = m->C, W = m->Wt, T = m->T, P = C * (C + 1) / 2;
 
     // K^-1: the sweep left -Kj^-1 in k.A; the POTRF path needs W^T W (lower tiles, full diagonal tiles) in k.B
     if (!sweep && !fused && (rc = spd_lauum(m, m->k))) return rc;
@@ -807,8 +832,9 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
     if ((rc = m->d_kdiag.ensure(Spad))) return rc;
     if ((rc = m->d_ptiles.ensure(pt.size()))) return rc;
     std::vector<double> kd(Spad, 0.0);
+    const bool per_point = m->Wt > 2 + 3 * D;          // terms with an envelope: kss_diag holds one value per test point (caller order)
     for (int c = 0; c < C; ++c)
-        for (int pos = ss.off[c]; pos < ss.off[c + 1]; ++pos) kd[pos] = kss_diag[c];
+        for (int pos = ss.off[c]; pos < ss.off[c + 1]; ++pos) kd[pos] = per_point ? kss_diag[ss.perm[pos]] : kss_diag[c];
     HIP_TRY(hipMemcpyAsync(m->d_xs.p, ss.xs.data(), (size_t)D * Spad * sizeof(double), hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->d_kdiag.p, kd.data(), Spad * sizeof(double), hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->d_ptiles.p, pt.data(), pt.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
@@ -819,7 +845,7 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
     GramArgs ga;
     ga.tiles = m->d_ptiles.p; ga.xr = m->d_xs.p; ga.ldxr = Spad; ga.xc = m->d_x.p; ga.ldxc = Npad; ga.nrows = S; ga.ncols = m->N;
     if ((rc = m->ph_sx.prepare(ss.off, m->sx.off, C, m->T, Spad, Npad, m->st, ga.ph))) return rc;
-    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.out = m->d_Ksf.p; ga.ldo = Npad;
+    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = m->Wt; ga.out = m->d_Ksf.p; ga.ldo = Npad;
     ga.noise = nullptr; ga.dvar = nullptr; ga.jitter_abs = 0.0; ga.mirror = 0;
     if ((rc = launch_gram(ga, (int)pt.size(), m->st))) return rc;
     // mu = K_sf alpha
@@ -869,7 +895,12 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
 
 int mogp_gram(mogp_ctx* ctx, int C, int D, int T, const double* table, int64_t M1, const double* X1,
               int64_t M2, const double* X2, double* K_out) {
-    if (!ctx || !table || !X1 || !K_out || M1 <= 0 || T <= 0 || C <= 0 || D <= 0 || D > MOGP_MAXD)
+    return mogp_gram_ex(ctx, C, D, T, 2 + 3 * D, table, M1, X1, M2, X2, K_out);
+}
+
+int mogp_gram_ex(mogp_ctx* ctx, int C, int D, int T, int width, const double* table, int64_t M1, const double* X1,
+                 int64_t M2, const double* X2, double* K_out) {
+    if (!ctx || !table || !X1 || !K_out || M1 <= 0 || T <= 0 || C <= 0 || D <= 0 || D > MOGP_MAXD || (width != 2 + 3 * D && width != 2 + 5 * D))
         return fail(MOGP_EINVAL, "mogp_gram: bad argument");
     int rc;
     if ((rc = use_device(ctx))) return rc;
@@ -882,7 +913,7 @@ int mogp_gram(mogp_ctx* ctx, int C, int D, int T, const double* table, int64_t M
     std::vector<GTile> tiles;
     std::vector<int> ps;
     if (sym) build_sym_tiles(s1.off, C, tiles, ps); else build_rect_tiles(s1.off, s2.off, C, tiles);
-    const int W = 2 + 3 * D;
+    const int W = width;
     DevBuf<double> dx1, dx2, dtab, dout;
     DevBuf<GTile> dt;
     PhaseWs ph;
@@ -903,7 +934,7 @@ int mogp_gram(mogp_ctx* ctx, int C, int D, int T, const double* table, int64_t M
     GramArgs ga;
     ga.tiles = dt.p; ga.xr = dx1.p; ga.ldxr = s1.Mpad; ga.xc = sym ? dx1.p : dx2.p; ga.ldxc = sc.Mpad; ga.nrows = R; ga.ncols = Cc;
     G_TRY(ph.prepare(s1.off, sc.off, C, T, s1.Mpad, sc.Mpad, nullptr, ga.ph));
-    ga.table = dtab.p; ga.T = T; ga.D = D; ga.C = C; ga.out = dout.p; ga.ldo = Cc;
+    ga.table = dtab.p; ga.T = T; ga.D = D; ga.C = C; ga.W = W; ga.out = dout.p; ga.ldo = Cc;
     ga.noise = nullptr; ga.dvar = nullptr; ga.jitter_abs = 0.0; ga.mirror = 1;
     G_TRY(launch_gram(ga, (int)tiles.size(), nullptr));
     G_HIP(hipDeviceSynchronize());
@@ -1036,7 +1067,7 @@ int mogp_exact_eval_sharded(mogp_model* m, const double* noise_var, const double
     int rc;
     if ((rc = use_device(m->ctx))) return rc;
     if (info) *info = 0;
-    const int C = m->C, W = 2 + 3 * m->D, T = m->T, P = C * (C + 1) / 2;
+    const int C = m->C, W = m->Wt, T = m->T, P = C * (C + 1) / 2;
     if ((rc = sharded_inverse(m, noise_var, data_var, jitter, jitter_abs))) return rc;
     if ((rc = mark(m, 5))) return rc;
     if ((rc = moment_pass_device(m, m->k.A.p, -1.0))) return rc;                       // owned rows only
@@ -1124,8 +1155,9 @@ int mogp_exact_predict_sharded(mogp_model* m, const double* noise_var, const dou
     if ((rc = m->d_kdiag.ensure(Spad))) return rc;
     if ((rc = m->d_ptiles.ensure(std::max<size_t>(pt.size(), 1)))) return rc;
     std::vector<double> kd(Spad, 0.0);
+    const bool per_point = m->Wt > 2 + 3 * D;
     for (int c = 0; c < C; ++c)
-        for (int pos = ss.off[c]; pos < ss.off[c + 1]; ++pos) kd[pos] = kss_diag[c];
+        for (int pos = ss.off[c]; pos < ss.off[c + 1]; ++pos) kd[pos] = per_point ? kss_diag[ss.perm[pos]] : kss_diag[c];
     HIP_TRY(hipMemcpyAsync(m->d_xs.p, ss.xs.data(), (size_t)D * Spad * sizeof(double), hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->d_kdiag.p, kd.data(), Spad * sizeof(double), hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->d_ptiles.p, pt.data(), pt.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
@@ -1136,7 +1168,7 @@ int mogp_exact_predict_sharded(mogp_model* m, const double* noise_var, const dou
         GramArgs ga;
         ga.tiles = m->d_ptiles.p; ga.xr = m->d_xs.p; ga.ldxr = Spad; ga.xc = m->d_x.p; ga.ldxc = Npad; ga.nrows = S; ga.ncols = m->N;
         if ((rc = m->ph_sx.prepare(ss.off, m->sx.off, C, m->T, Spad, Npad, m->st, ga.ph))) return rc;
-        ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.out = m->d_Ksf.p; ga.ldo = Npad;
+        ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = m->Wt; ga.out = m->d_Ksf.p; ga.ldo = Npad;
         ga.noise = nullptr; ga.dvar = nullptr; ga.jitter_abs = 0.0; ga.mirror = 0;
         if ((rc = launch_gram(ga, (int)pt.size(), m->st))) return rc;
         const double* Kloc = m->d_Ksf.p + row0 * Npad;

@@ -50,6 +50,8 @@ struct GramArgs {
     PhaseRef ph;
     const double* table;   // [C*C][T][W]
     int T, D, C;
+    int W;                 // width of a table row: 2 + 3 D, or 2 + 5 D when the terms carry a Gaussian envelope on the input midpoint
+                           // ([.., L_d, c_d]: K *= exp(-1/2 sum_d L_d ((x_a,d + x_b,d)/2 - c_d)^2), MOHSM); 0 -> 2 + 3 D
     double* out;           // row-major, leading dimension ldo
     int64_t ldo;
     // diagonal augmentation (symmetric training Gram only; null -> none)
@@ -72,6 +74,8 @@ struct MomentArgs {
     PhaseRef ph;
     const double* table;
     int T, D, C;
+    int W;                 // table row width = number of moments per (pair, term): 2 + 3 D, or 2 + 5 D with the envelope (two more moments
+                           // per dimension: m5_d = sum g a_d^2 E cos, m6_d = sum g a_d E cos, a_d = (x_a,d + x_b,d)/2 - c_d); 0 -> 2 + 3 D
     // adjoint source, exact mode (G == null):  g = w * 1/2 (alpha_a alpha_b - kinv_ab), symmetric weights
     const double* kinv;    // lower triangle valid, leading dimension ld
     int64_t ld;
@@ -96,7 +100,7 @@ struct MomentArgs {
 int launch_gram(const GramArgs& a, int ntiles, hipStream_t s);
 int launch_moments(const MomentArgs& a, hipStream_t s);
 // moments[P][T][W] += fixed-order sum of per-tile partials; tile_pair_lower[t] = p index, tiles grouped by pair
-int launch_moment_reduce(const double* partial, const int* pair_start, int npairs, int T, int W, double* out, hipStream_t s,
+int launch_moment_reduce(const double* partial, const int* pair_start, int npairs, int T, int W, int D, double* out, hipStream_t s,
                          int lower_pairs = 1);
 // per-channel sum of G_kk = 1/2(alpha_k^2 - kinv_kk): out[c], chan_off device array [C+1]
 int launch_diagG(const double* kinv, int64_t ld, const double* alpha, const int* chan_off, int C, double* out, hipStream_t s,

@@ -145,6 +145,8 @@ struct mogp_model {
     mogp_ctx* ctx = nullptr;
     int64_t N = 0, Npad = 0;
     int nb = 0, D = 0, C = 0, T = 0;
+    int Wt = 0;                         // width of a term-table row = moments per (pair, term): 2 + 3 D, or 2 + 5 D with an envelope (MOHSM)
+    std::vector<double> point_diag;     // K_diag per training point (channel-sorted) when the diagonal is not constant per channel
     SortedX sx;
     std::vector<GTile> tiles;
     std::vector<int> pair_start;

@@ -55,6 +55,7 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     const int C = m->C, D = m->D, W = 2 + 3 * D;
     const int64_t Npad = m->Npad;
     if (m->T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms must be called before an evaluation");
+    if (m->Wt != W) return fail(MOGP_EINVAL, "the Titsias path does not take terms with an envelope (MOHSM): exact inference only");
     if (!(sigma > 0.0)) return fail(MOGP_EINVAL, "sigma must be positive");
     RC(sort_inputs(Z, M, D, C, MOGP_TILE, sz));
     const int64_t Mpad = sz.Mpad;
@@ -244,13 +245,13 @@ int mogp_titsias_eval(mogp_model* m, int64_t M, const double* Z, double sigma, d
     ma.G = t.GB.p; ma.ldg = Npad; ma.ru = beta; ma.rw = r; ma.rcoef = 1.0; ma.sym = 0;
     ma.gzr = t.gz.p; ma.gzc = nullptr; ma.ldgz = Mpad; ma.partial = t.partial_uf.p;
     RC(launch_moments(ma, m->st));
-    RC(launch_moment_reduce(t.partial_uf.p, t.ps_uf.p, C * C, T, W, t.mom_uf.p, m->st, 0));
+    RC(launch_moment_reduce(t.partial_uf.p, t.ps_uf.p, C * C, T, W, D, t.mom_uf.p, m->st, 0));
     ma.tiles = t.tiles_uu.p; ma.ntiles = (int)tuu.size(); ma.xc = nullptr; ma.ldxc = 0; ma.ncols = M;
     RC(t.ph_zz.prepare(sz.off, sz.off, C, T, Mpad, Mpad, m->st, ma.ph));
     ma.G = t.GA.p; ma.ldg = Mpad; ma.ru = beta; ma.rw = beta; ma.rcoef = -0.5 / (s2 * s2); ma.sym = 1;
     ma.gzr = t.gz.p; ma.gzc = t.gz.p; ma.partial = t.partial_uu.p;
     RC(launch_moments(ma, m->st));
-    RC(launch_moment_reduce(t.partial_uu.p, t.ps_uu.p, P, T, W, t.mom_uu.p, m->st, 1));
+    RC(launch_moment_reduce(t.partial_uu.p, t.ps_uu.p, P, T, W, D, t.mom_uu.p, m->st, 1));
 
     std::vector<double> hgz((size_t)D * Mpad), hb(Mpad), hd(Mpad);
     HIP_TRY(hipMemcpyAsync(mom_uu, t.mom_uu.p, (size_t)P * T * W * sizeof(double), hipMemcpyDeviceToHost, m->st));

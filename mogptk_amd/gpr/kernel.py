@@ -20,6 +20,20 @@ def term_width(D):
     return 2 + 3 * D
 
 
+def env_width(D):
+    """rows with a Gaussian envelope on the input midpoint: [A, Psi, V_d, M_d, Delta_d, L_d, c_d]"""
+    return 2 + 5 * D
+
+
+def pad_width(table, width):
+    """a table of the narrow row width as one of the wide width (no envelope: L = 0)"""
+    if table.shape[3] == width:
+        return table
+    out = np.zeros(table.shape[:3] + (width,))
+    out[..., :table.shape[3]] = table
+    return out
+
+
 # One evaluation asks every kernel of a composition for its term table several times (push to the device, then again at each level
 # of the chain rule -- AddKernel even asks only to learn T) while no parameter can change.  A model evaluation opens this cache.
 _TERMS_CACHE = None
@@ -170,10 +184,43 @@ class Kernel(ParameterHolder):
         return gram(config.device, self._channels(), D, self._spectral_terms(D), X1k, X2k)
 
     def K_diag(self, X1):
-        """reference gpr/kernel.py:152-163, MO :483-495.  Constant per channel for every spectral kernel."""
+        """reference gpr/kernel.py:152-163, MO :483-495.  Constant per channel for every stationary spectral kernel; with an
+        envelope (MOHSM) it follows the points."""
         X1k = self._kernel_format(np.asarray(X1, dtype=np.float64))
         D = X1k.shape[1] - 1
+        table = self._spectral_terms(D)
+        if table.shape[3] > term_width(D):
+            return self._point_diag(table, X1k, D)
         return self._spectral_diag(D)[X1k[:, 0].astype(np.int64)]
+
+    @staticmethod
+    def _point_env(table, Xk, D):
+        """per point k (channel c) and term t: the envelope exp(-1/2 sum_d L_d (x_k,d - c_d)^2) of the diagonal pair (c, c), and x - c"""
+        c = Xk[:, 0].astype(np.int64)
+        rows = table[c, c]                                        # (N, T, W)
+        Lv, cn = rows[..., 2 + 3 * D:2 + 4 * D], rows[..., 2 + 4 * D:2 + 5 * D]
+        a = Xk[:, None, 1:] - cn                                  # (N, T, D)
+        return np.exp(-0.5 * np.sum(Lv * a * a, axis=2)), a, rows
+
+    def _point_diag(self, table, Xk, D):
+        """K_diag per point from an enveloped term table: sum_t A_cct env_t(x)   (Delta = Psi = 0 on diagonal pairs)"""
+        env, _, rows = self._point_env(table, Xk, D)
+        return np.sum(rows[..., 0] * env, axis=1)
+
+    def _point_diag_table_grad(self, table, Xk, D):
+        """d [ sum_k K_diag(x_k) ] / d table: what the relative jitter (gpr/model.py:244) contributes per unit of d/d mean(diag) * N"""
+        env, a, rows = self._point_env(table, Xk, D)
+        c = Xk[:, 0].astype(np.int64)
+        gt = np.zeros_like(table)
+        A, Lv = rows[..., 0], rows[..., 2 + 3 * D:2 + 4 * D]
+        for ch in range(table.shape[0]):
+            k = c == ch
+            if not np.any(k):
+                continue
+            gt[ch, ch, :, 0] = np.sum(env[k], axis=0)
+            gt[ch, ch, :, 2 + 3 * D:2 + 4 * D] = np.sum((A[k] * env[k])[..., None] * (-0.5 * a[k] * a[k]), axis=0)
+            gt[ch, ch, :, 2 + 4 * D:2 + 5 * D] = np.sum((A[k] * env[k])[..., None] * (Lv[k] * a[k]), axis=0)
+        return gt
 
     def __add__(self, other):
         return AddKernel(self, other)
@@ -227,14 +274,17 @@ class AddKernel(Kernels):
 
     @cached_terms
     def _spectral_terms(self, D):
-        return np.concatenate([k._spectral_terms(D) for k in self.kernels], axis=2)
+        tabs = [k._spectral_terms(D) for k in self.kernels]
+        width = max(t.shape[3] for t in tabs)                     # a sum with an enveloped kernel: everything in the wide rows
+        return np.concatenate([pad_width(t, width) for t in tabs], axis=2)
 
     def _spectral_backward(self, gtable):
         t0 = 0
-        D = (gtable.shape[3] - 2) // 3
+        D = self.input_dims if self.input_dims is not None else (gtable.shape[3] - 2) // 3
         for k in self.kernels:
-            T = k._spectral_terms(D).shape[2]
-            k._spectral_backward(gtable[:, :, t0:t0 + T, :])
+            tab = k._spectral_terms(D)
+            T = tab.shape[2]
+            k._spectral_backward(gtable[:, :, t0:t0 + T, :tab.shape[3]])
             t0 += T
 
 

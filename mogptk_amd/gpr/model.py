@@ -37,7 +37,7 @@ def _gtable_from_moments(table, mom, D, lower=True):
     lower=True: mom is indexed by lower channel pairs p = i(i+1)/2 + j (symmetric Gram, double count already
     included); lower=False: mom is indexed by all ordered pairs i*C + j (rectangular Gram)."""
     C, T = table.shape[0], table.shape[2]
-    gt = np.zeros((C, C, T, 2 + 3 * D))
+    gt = np.zeros((C, C, T, table.shape[3]))
     if lower:
         ii, jj = np.tril_indices(C)                     # row-major lower pairs: exactly p = i(i+1)/2 + j
     else:
@@ -47,13 +47,17 @@ def _gtable_from_moments(table, mom, D, lower=True):
     V = tb[..., 2:2 + D]
     M = tb[..., 2 + D:2 + 2 * D]
     m0, m4 = mom[..., 0], mom[..., 1]
-    m1, m2, m3 = mom[..., 2:2 + D], mom[..., 2 + D:2 + 2 * D], mom[..., 2 + 2 * D:]
+    m1, m2, m3 = mom[..., 2:2 + D], mom[..., 2 + D:2 + 2 * D], mom[..., 2 + 2 * D:2 + 3 * D]
     g = np.empty_like(tb)
     g[..., 0] = m0
     g[..., 1] = -2.0 * np.pi * A * m4
     g[..., 2:2 + D] = -0.5 * A[..., None] * m1
     g[..., 2 + D:2 + 2 * D] = -2.0 * np.pi * A[..., None] * m3
-    g[..., 2 + 2 * D:] = -V * A[..., None] * m2 - 2.0 * np.pi * M * (A * m4)[..., None]
+    g[..., 2 + 2 * D:2 + 3 * D] = -V * A[..., None] * m2 - 2.0 * np.pi * M * (A * m4)[..., None]
+    if tb.shape[-1] > 2 + 3 * D:          # envelope exp(-1/2 L a^2), a = midpoint - c:  dL = -1/2 A m5,  dc = L A m6
+        Lv = tb[..., 2 + 3 * D:2 + 4 * D]
+        g[..., 2 + 3 * D:2 + 4 * D] = -0.5 * A[..., None] * mom[..., 2 + 3 * D:2 + 4 * D]
+        g[..., 2 + 4 * D:2 + 5 * D] = Lv * A[..., None] * mom[..., 2 + 4 * D:2 + 5 * D]
     gt[ii, jj] = g
     return gt
 
@@ -226,6 +230,8 @@ class Exact(Model):
         D = self.X.shape[1] - (0 if self.kernel.output_dims is None else 1)
         table = self.kernel._spectral_terms(D)
         h.set_terms(table)
+        if table.shape[3] > 2 + 3 * D:        # envelope: the diagonal varies from point to point and enters the relative jitter (:244)
+            h.set_point_diag(self.kernel._point_diag(table, self.kernel._kernel_format(self.X), D))
         return h, table, D
 
     def _eval(self, grad):
@@ -264,8 +270,11 @@ class Exact(Model):
 
         # d LML / d table for the lower channel pairs (i >= j); zero elsewhere
         gt = _gtable_from_moments(table, mom, D, lower=True)
-        for i in range(C):
-            gt[i, i, :, 0] += jit_rel * counts[i]
+        if table.shape[3] > 2 + 3 * D:
+            gt += jit_rel * self.kernel._point_diag_table_grad(table, self.kernel._kernel_format(self.X), D)
+        else:
+            for i in range(C):
+                gt[i, i, :, 0] += jit_rel * counts[i]
         self.kernel._spectral_backward(-gt)                    # loss = -LML
 
         # noise: d LML / d sigma_c = 2 sigma_c (sum_{k in c} G_kk + jitter n_c/N tr G)
@@ -283,10 +292,11 @@ class Exact(Model):
         """reference gpr/model.py:455-483"""
         from .._lib import MogpError, MOGP_ENOTPD, MOGP_ENONFINITE
         X = self._check_input(X)
-        h, _, D = self._push_terms()
+        h, table, D = self._push_terms()
+        Xk = self.kernel._kernel_format(X)
+        kss = self.kernel._point_diag(table, Xk, D) if table.shape[3] > 2 + 3 * D else self.kernel._spectral_diag(D)
         try:
-            mu, var = h.predict(self._noise_var(), self.jitter, self.kernel._spectral_diag(D),
-                                self.kernel._kernel_format(X), full=full,
+            mu, var = h.predict(self._noise_var(), self.jitter, kss, Xk, full=full,
                                 data_var=self.data_variance)
         except MogpError as e:
             if e.code in (MOGP_ENOTPD, MOGP_ENONFINITE):

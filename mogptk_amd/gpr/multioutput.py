@@ -92,6 +92,10 @@ class MultiOutputSpectralMixtureKernel(MultiOutputKernel):
         """(C,C,Q) magnitude of every channel pair: w_i w_j (reference :184,:192)"""
         return w[:, None] * w[None, :]
 
+    def _amp_scale(self):
+        """extra factor of every pair amplitude that does not depend on (weight, mean, variance, delay, phase); (C,C,Q) or a scalar"""
+        return 1.0
+
     def _magnitude_backward(self, w, gmag):
         """gmag: d loss / d magnitude for pairs i >= j (zero above the diagonal) -> gradient of the constrained weight"""
         return np.sum(gmag * w[None, :], axis=1) + np.sum(gmag * w[:, None], axis=0)
@@ -155,13 +159,13 @@ class MultiOutputSpectralMixtureKernel(MultiOutputKernel):
         mag = self._magnitude(w) * np.exp(-PI ** 2 * np.sum(dmu * inv * dmu, axis=3))           # :192
         M = inv * (vi * mj + vj * mi)                                                           # :194
         V = 2.0 * vi * inv * vj                                                                 # :195
-        table[..., 0] = mag * self.twopi * np.sqrt(np.prod(V, axis=3))                          # :199
+        table[..., 0] = mag * self.twopi * np.sqrt(np.prod(V, axis=3)) * self._amp_scale()      # :199
         table[..., 1] = self._phase_scale * (ph[:, None] - ph[None, :])                         # :197
         table[..., 2:2 + D] = V
         table[..., 2 + D:2 + 2 * D] = M
         table[..., 2 + 2 * D:] = th[:, None] - th[None, :]                                      # :196
         for c in range(C):                                                                      # i == j branch :183-187
-            table[c, c, :, 0] = self._magnitude(w)[c, c] * self.twopi * np.sqrt(np.prod(v[c], axis=1))
+            table[c, c, :, 0] = self._magnitude(w)[c, c] * self.twopi * np.sqrt(np.prod(v[c], axis=1)) * (np.asarray(self._amp_scale()) * np.ones((C, C, Q)))[c, c]
             table[c, c, :, 1] = 0.0
             table[c, c, :, 2:2 + D] = v[c]
             table[c, c, :, 2 + D:2 + 2 * D] = mu[c]
@@ -179,14 +183,14 @@ class MultiOutputSpectralMixtureKernel(MultiOutputKernel):
         V = table[..., 2:2 + D]
         M = table[..., 2 + D:2 + 2 * D]
         gA, gPsi = gtable[..., 0], gtable[..., 1]
-        gV, gM, gDl = gtable[..., 2:2 + D], gtable[..., 2 + D:2 + 2 * D], gtable[..., 2 + 2 * D:]
+        gV, gM, gDl = gtable[..., 2:2 + D], gtable[..., 2 + D:2 + 2 * D], gtable[..., 2 + 2 * D:2 + 3 * D]
 
         off = ~np.eye(C, dtype=bool)
         o2 = off[:, :, None]
         o3 = off[:, :, None, None]
         gAA = np.where(o2, gA * A, 0.0)                                     # (C,C,Q)
         # d A / d magnitude = everything but the magnitude (kept explicit: a magnitude may be zero or negative for the uncoupled kernel)
-        Fm = np.exp(-PI ** 2 * np.sum(dmu * inv * dmu, axis=3)) * self.twopi * np.sqrt(np.prod(V, axis=3))
+        Fm = np.exp(-PI ** 2 * np.sum(dmu * inv * dmu, axis=3)) * self.twopi * np.sqrt(np.prod(V, axis=3)) * self._amp_scale()
         gmag = gA * Fm                                                       # gtable is zero above the diagonal already
         gw = self._magnitude_backward(w, gmag)
         gph = self._phase_scale * (np.sum(np.where(o2, gPsi, 0.0), axis=1) - np.sum(np.where(o2, gPsi, 0.0), axis=0))
@@ -446,3 +450,77 @@ class GaussianConvolutionProcessKernel(MultiOutputKernel):
         _accumulate(self.weight, (np.sum(gAA, axis=1) + np.sum(gAA, axis=0)) / w)
         _accumulate(self.variance, np.sum(gs, axis=1) + np.sum(gs, axis=0))   # s_ij depends on v_i and on v_j (twice on v_i when i == j)
         _accumulate(self.base_variance, np.sum(gs, axis=(0, 1)) + 0.5 * np.sum(gAA) / b)
+
+
+class MultiOutputHarmonizableSpectralKernel(MultiOutputSpectralKernel):
+    """
+    MOHSM component (reference gpr/multioutput.py:295-395): a MultiOutputSpectralKernel pair term times a Gaussian envelope on the input
+    MIDPOINT, exp(-1/2 l_ij sum_d ((x_d + x'_d)/2 - c_d)^2) -- non-stationary.  Use `MixtureKernel(MultiOutputHarmonizableSpectralKernel(...), Q)`.
+    Parameters: weight (C,), mean / variance (C,D), lengthscale (C,), center (D,), delay (C,D), phase (C,).  As in the reference: the
+    amplitude carries (2 pi)^D (not ^(D/2)) and l_ij^(D/2), the envelope precision is lengthscale^2 (harmonic mean over a channel pair), and
+    the phase difference enters the cosine without the 2 pi factor.
+    On the device this is a term row of width 2 + 5 D: [A, Psi, V_d, M_d, Delta_d, L_d = l_ij, c_d].
+    """
+    _phase_scale = 1.0 / (2.0 * np.pi)
+
+    def __init__(self, output_dims, input_dims=1, active_dims=None):
+        super().__init__(output_dims, input_dims, active_dims)
+        # registration order of the reference: weight, mean, variance, lengthscale, center, delay, phase
+        order = self.__dict__["_order"]
+        delay, phase = self.__dict__.pop("delay"), self.__dict__.pop("phase")
+        order.remove("delay"); order.remove("phase")
+        self.lengthscale = Parameter(np.ones(output_dims), lower=config.positive_minimum)
+        self.center = Parameter(np.zeros(input_dims))
+        self.delay = delay
+        self.phase = phase
+        self.twopi = np.power(2.0 * np.pi, float(self.input_dims))
+
+    def _memo_key(self):
+        parts = [super()._memo_key()]
+        for p in (self.lengthscale, self.center):
+            parts.append(p.data.tobytes())
+            for b in (p.lower, p.upper):
+                parts.append(b"-" if b is None else np.asarray(b, dtype=np.float64).tobytes())
+            if p.pegged:
+                parts.append(p.pegged_parameter.data.tobytes())
+        return b"|".join(parts)
+
+    def _pair_precision(self):
+        """l_ij (C,C): lengthscale_i^2 on the diagonal, 2 l_i l_j / (l_i + l_j) off it (reference :349, :357-366)"""
+        l = np.square(self.lengthscale())
+        li, lj = l[:, None], l[None, :]
+        Lp = 2.0 * li * lj / (li + lj)
+        Lp[np.diag_indices(self.output_dims)] = l
+        return Lp, li, lj
+
+    def _amp_scale(self):
+        Lp, _, _ = self._pair_precision()
+        return np.power(Lp, 0.5 * self.input_dims)[:, :, None]
+
+    def _spectral_terms_compute(self, D):
+        narrow = super()._spectral_terms_compute(D)
+        C = self.output_dims
+        Lp, _, _ = self._pair_precision()
+        table = np.zeros((C, C, 1, 2 + 5 * D))
+        table[..., :2 + 3 * D] = narrow
+        table[..., 2 + 3 * D:2 + 4 * D] = Lp[:, :, None, None]
+        table[..., 2 + 4 * D:2 + 5 * D] = self.center()[None, None, None, :]
+        return table
+
+    def _spectral_diag(self, D):
+        raise NotImplementedError("the diagonal of a harmonizable kernel follows the points: use K_diag(X)")
+
+    def _spectral_backward(self, gtable):
+        C, D = self.output_dims, self.input_dims
+        table = self._spectral_terms(D)
+        super()._spectral_backward(gtable)                        # weight, mean, variance, delay, phase (the amplitude scale is in Fm / A)
+        Lp, li, lj = self._pair_precision()
+        l = self.lengthscale()
+        gA, A = gtable[..., 0, 0], table[..., 0, 0]               # one term per component
+        gLp = np.sum(gtable[..., 0, 2 + 3 * D:2 + 4 * D], axis=2) + gA * A * (0.5 * D) / Lp          # zero above the diagonal already
+        off = ~np.eye(C, dtype=bool)
+        dLi = 2.0 * lj * lj / np.square(li + lj)                  # d l_ij / d l_i  (l_i = lengthscale_i^2), i != j
+        dLj = 2.0 * li * li / np.square(li + lj)
+        g_l2 = np.sum(np.where(off, gLp * dLi, 0.0), axis=1) + np.sum(np.where(off, gLp * dLj, 0.0), axis=0) + np.diagonal(gLp)
+        _accumulate(self.lengthscale, g_l2 * 2.0 * l)
+        _accumulate(self.center, np.sum(gtable[..., 0, 2 + 4 * D:2 + 5 * D], axis=(0, 1)))

@@ -1,5 +1,5 @@
 """
-Model wrappers MOSM / SM / CSM / SM_LMC / CONV -- host-side mirror of mogptk/models/{mosm,sm,csm,sm_lmc,conv}.py constructors.
+Model wrappers MOSM / SM / CSM / SM_LMC / CONV / MOHSM -- host-side mirror of mogptk/models/{mosm,sm,csm,sm_lmc,conv,mohsm}.py constructors.
 
 Constructor semantics are part of the drop-in boundary and are reproduced including quirk Q2
 (SURVEY.md 8b): the Nyquist re-bounding `mean.assign(upper=...)` at mosm.py:60 / sm.py:60 / csm.py:64
@@ -12,7 +12,7 @@ from .dataset import DataSet
 from .model import Model, Exact, logger
 from .gpr import (MultiOutputSpectralMixtureKernel, IndependentMultiOutputKernel, SpectralMixtureKernel,
                   CrossSpectralKernel, MixtureKernel, LinearModelOfCoregionalizationKernel, SpectralKernel,
-                  GaussianConvolutionProcessKernel)
+                  GaussianConvolutionProcessKernel, MultiOutputHarmonizableSpectralKernel)
 
 
 def _rand(*shape):
@@ -273,4 +273,69 @@ class CONV(Model):
         for q in range(self.Q):
             self.gpr.kernel[q].weight.assign([5.0 * amplitude[q, :].mean() for amplitude in amplitudes])
             self.gpr.kernel[q].variance.assign([10.0 * variance[q, :] for variance in variances])
+        _init_noise(self)
+
+
+class MOHSM(Model):
+    """Multi-output harmonizable spectral mixture with P components of Q sub-components (reference models/mohsm.py:8-60): a mixture of
+    P Q MultiOutputHarmonizableSpectralKernel terms (non-stationary: Gaussian envelopes on the input midpoint), exact inference on the
+    device through the wide (2 + 5 D) term rows."""
+
+    def __init__(self, dataset, P=1, Q=1, inference=Exact(), mean=None, name="MOHSM"):
+        if not isinstance(dataset, DataSet):
+            dataset = DataSet(dataset)
+        output_dims = dataset.get_output_dims()
+        input_dims = dataset.get_input_dims()[0]
+        for input_dim in dataset.get_input_dims()[1:]:
+            if input_dim != input_dims:
+                raise ValueError("input dimensions for all channels must match")
+
+        spectral = MultiOutputHarmonizableSpectralKernel(output_dims=output_dims, input_dims=input_dims)
+        kernel = MixtureKernel(spectral, P * Q)
+        for p in range(P):
+            for q in range(Q):
+                kernel[p * Q + q].weight.assign(_rand(output_dims))
+                kernel[p * Q + q].mean.assign(_rand(output_dims, input_dims))
+                kernel[p * Q + q].variance.assign(_rand(output_dims, input_dims))
+                kernel[p * Q + q].lengthscale.assign(_rand(output_dims))
+
+        super().__init__(dataset, kernel, inference, mean, name)
+        self.Q = Q
+        self.P = P
+
+    def init_parameters(self, method="BNSE", iters=500):
+        """reference models/mohsm.py:62-145: centres / lengthscales spread over [0, 1000] when P > 1, spectrum peaks per channel (BNSE,
+        'LS' or 'SM') for mean and variance (variance x (4 + 20 (D - 1))), weights normalised to the channel variances and divided by
+        sqrt(lengthscale), noise from the spread of every channel"""
+        input_dims = self.dataset.get_input_dims()
+        output_dims = self.dataset.get_output_dims()
+        if method.lower() not in ("bnse", "ls", "sm"):
+            raise ValueError("valid methods of estimation are BNSE, LS, and SM")
+        for p in range(self.P):
+            for q in range(self.Q):
+                if self.P != 1:
+                    self.gpr.kernel[p * self.Q + q].center.assign((1000 * p / (self.P - 1)) * np.ones(input_dims[0]))
+                    self.gpr.kernel[p * self.Q + q].lengthscale.assign(((self.P + 1) / 1000) * np.ones(output_dims))
+            est = _estimate(self, method, iters, "MOHSM")
+            if est is None:
+                return
+            amplitudes, means, variances = est
+            weight = np.zeros((output_dims, self.Q))
+            for q in range(self.Q):
+                mean = np.zeros((output_dims, input_dims[0]))
+                variance = np.zeros((output_dims, input_dims[0]))
+                for j in range(output_dims):
+                    if q < amplitudes[j].shape[0]:
+                        weight[j, q] = amplitudes[j][q, :].mean()
+                        mean[j, :] = means[j][q, :]
+                        variance[j, :] = variances[j][q, :] * (4 + 20 * (max(input_dims) - 1))
+                self.gpr.kernel[p * self.Q + q].mean.assign(mean)
+                self.gpr.kernel[p * self.Q + q].variance.assign(variance)
+            for j, channel in enumerate(self.dataset):
+                _, y = channel.get_train_data(transformed=True)
+                if 0.0 < weight[j, :].sum():
+                    weight[j, :] = (np.sqrt(weight[j, :] / weight[j, :].sum() * y.var())) * 2
+            for q in range(self.Q):
+                k = self.gpr.kernel[p * self.Q + q]
+                k.weight.assign(weight[:, q] / np.sqrt(k.lengthscale.numpy()))
         _init_noise(self)

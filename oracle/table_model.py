@@ -11,15 +11,23 @@ import numpy as np
 TWO_PI = 2.0 * np.pi
 
 
-def table_block(tab, x1, x2, sin=False):
-    """one channel-pair block from T term rows [A, Psi, V_d, M_d, Delta_d]; x1 (n1,D), x2 (n2,D).
-    returns per-term arrays E*cos (or E*sin) WITHOUT the amplitude, and u (T,n1,n2,D)."""
+def table_block(tab, x1, x2, sin=False, with_mid=False):
+    """one channel-pair block from T term rows [A, Psi, V_d, M_d, Delta_d (, L_d, c_d)]; x1 (n1,D), x2 (n2,D).
+    returns per-term arrays E*cos (or E*sin) WITHOUT the amplitude, and u (T,n1,n2,D); rows of width 2+5D carry a Gaussian envelope
+    exp(-1/2 sum_d L_d a_d^2) on the midpoint offset a_d = (x1_d + x2_d)/2 - c_d (with_mid: also return a)."""
     D = x1.shape[1]
     A, Psi = tab[:, 0], tab[:, 1]
-    V, M, Dl = tab[:, 2:2 + D], tab[:, 2 + D:2 + 2 * D], tab[:, 2 + 2 * D:]
+    V, M, Dl = tab[:, 2:2 + D], tab[:, 2 + D:2 + 2 * D], tab[:, 2 + 2 * D:2 + 3 * D]
     u = (x1[None, :, None, :] - x2[None, None, :, :]) + Dl[:, None, None, :]
     E = np.exp(-0.5 * np.einsum("tnmd,td->tnm", u * u, V))
+    a = None
+    if tab.shape[1] > 2 + 3 * D:
+        Lv, cn = tab[:, 2 + 3 * D:2 + 4 * D], tab[:, 2 + 4 * D:2 + 5 * D]
+        a = 0.5 * (x1[None, :, None, :] + x2[None, None, :, :]) - cn[:, None, None, :]
+        E = E * np.exp(-0.5 * np.einsum("tnmd,td->tnm", a * a, Lv))
     ph = TWO_PI * (np.einsum("tnmd,td->tnm", u, M) + Psi[:, None, None])
+    if with_mid:
+        return E * np.cos(ph), E * np.sin(ph), u, a
     return E * np.cos(ph), E * np.sin(ph), u
 
 
@@ -60,6 +68,9 @@ class TableDevice:
         self.table = np.array(table, dtype=np.float64)
         self.T = table.shape[2]
 
+    def set_point_diag(self, kdiag):
+        pass                         # the twin takes the diagonal from its own Gram matrix
+
     def _Kj(self, noise_var, jitter, data_var):
         K = gram_from_table(self.table, self.X)
         c = self.X[:, 0].astype(np.int64)
@@ -82,21 +93,25 @@ class TableDevice:
         G = 0.5 * (alpha @ alpha.T - Li.T @ Li)
         C, T, D = self.C, self.T, self.D
         c = self.X[:, 0].astype(np.int64)
-        mom = np.zeros((C * (C + 1) // 2, T, 2 + 3 * D))
+        W = self.table.shape[3]
+        mom = np.zeros((C * (C + 1) // 2, T, W))
         for i in range(C):
             ri = np.nonzero(c == i)[0]
             for j in range(i + 1):
                 rj = np.nonzero(c == j)[0]
                 if len(ri) == 0 or len(rj) == 0:
                     continue
-                Ec, Es, u = table_block(self.table[i, j], self.X[ri, 1:], self.X[rj, 1:])
+                Ec, Es, u, a = table_block(self.table[i, j], self.X[ri, 1:], self.X[rj, 1:], with_mid=True)
                 g = G[np.ix_(ri, rj)] * (1.0 if i == j else 2.0)
                 m = mom[i * (i + 1) // 2 + j]
                 m[:, 0] = np.einsum("nm,tnm->t", g, Ec)
                 m[:, 1] = np.einsum("nm,tnm->t", g, Es)
                 m[:, 2:2 + D] = np.einsum("nm,tnm,tnmd->td", g, Ec, u * u)
                 m[:, 2 + D:2 + 2 * D] = np.einsum("nm,tnm,tnmd->td", g, Ec, u)
-                m[:, 2 + 2 * D:] = np.einsum("nm,tnm,tnmd->td", g, Es, u)
+                m[:, 2 + 2 * D:2 + 3 * D] = np.einsum("nm,tnm,tnmd->td", g, Es, u)
+                if a is not None:
+                    m[:, 2 + 3 * D:2 + 4 * D] = np.einsum("nm,tnm,tnmd->td", g, Ec, a * a)
+                    m[:, 2 + 4 * D:2 + 5 * D] = np.einsum("nm,tnm,tnmd->td", g, Ec, a)
         dG = np.diagonal(G)
         diagG = np.array([np.sum(dG[c == k]) for k in range(C)])
         return dict(lml=lml, moments=mom, diagG=diagG, trG=float(np.sum(dG)), jitter_abs=jit)
@@ -124,7 +139,7 @@ class TableDevice:
         if full:
             return mu, gram_from_table(self.table, Xs) - v.T @ v
         cs = Xs[:, 0].astype(np.int64)
-        kdiag = np.asarray(kss_diag)[cs]
+        kdiag = np.asarray(kss_diag) if self.table.shape[3] > 2 + 3 * self.D else np.asarray(kss_diag)[cs]      # enveloped terms: per test point
         return mu, (kdiag - np.sum(v * v, axis=0)).reshape(-1, 1)
 
 

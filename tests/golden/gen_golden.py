@@ -15,6 +15,7 @@ nothing of the reference travels.  Re-run:  python tests/golden/gen_golden.py [-
   transformers.npz Y transformers alone and chained; the raw airline series of configs[0]
   opt_traces.npz train('SGD' | 'AdaGrad') traces, the per-iteration error= path and a continued train() call on the cfg1 model
   peg.npz        loss + gradients of a model with pegged parameters (identity and 2x transforms)
+  kernels_mohsm.npz / lml_mohsm_* / mohsm.npz  MultiOutputHarmonizableSpectralKernel and the MOHSM wrapper (SURVEY 8f-2 remainder)
   lbfgs_cfg1.npz the same model under train('LBFGS'): fixed-step and strong-Wolfe loss traces by function evaluation
   cfg2.npz      [--full] MOSM C=4 Q=3 N=8192 LML + gradient (BASELINE.json configs[1]; ~20 s, 10 GB)
   cfg4.npz      [--full] CSM C=4 Q=3 N=16384 predict_f at 64 probe rows of S=4096 (configs[3]; ~40 s, 16 GB)
@@ -111,6 +112,16 @@ def build_kernel(kind, C, Q, D, Rq, rng):
             k[q].magnitude.assign(rng.uniform(0.5, 1.5, 3))
             k[q].mean.assign(rng.uniform(0.05, 0.5, (3, D)))
             k[q].variance.assign(rng.uniform(0.01, 0.1, (3, D)))
+    elif kind == "mohsm":      # MixtureKernel(MultiOutputHarmonizableSpectralKernel): Gaussian envelope on the input midpoint
+        k = g.MixtureKernel(g.MultiOutputHarmonizableSpectralKernel(output_dims=C, input_dims=D), Q)
+        for q in range(Q):
+            k[q].weight.assign(rng.uniform(0.5, 1.5, C))
+            k[q].mean.assign(rng.uniform(0.05, 0.5, (C, D)))
+            k[q].variance.assign(rng.uniform(0.05, 0.5, (C, D)))
+            k[q].lengthscale.assign(rng.uniform(0.1, 0.4, C))
+            k[q].center.assign(rng.uniform(2.0, 8.0, D))
+            k[q].delay.assign(rng.normal(0, 0.3, (C, D)))
+            k[q].phase.assign(rng.normal(0, 0.3, C))
     elif kind == "conv":       # MixtureKernel(GaussianConvolutionProcessKernel)
         k = g.MixtureKernel(g.GaussianConvolutionProcessKernel(output_dims=C, input_dims=D), Q)
         for q in range(Q):
@@ -160,6 +171,55 @@ KERNEL_CASES_8F2 = [  # the multi-output kernels that share MOSM's 
 
 def gen_kernels_8f2():
     gen_kernels(KERNEL_CASES_8F2, "kernels_8f2.npz", 1100)
+
+
+KERNEL_CASES_MOHSM = [
+    ("mohsm", 3, 2, 1, 1, 45, 16, False),
+    ("mohsm", 2, 1, 2, 1, 36, 13, True),
+    ("mohsm", 1, 2, 1, 1, 25, 9, False),
+]
+LML_CASES_MOHSM = [
+    ("mohsm_c3q2", "mohsm", 3, 2, 1, 1, 84, False, False),
+    ("mohsm_c2q1_d2", "mohsm", 2, 1, 2, 1, 60, True, False),
+    ("mohsm_c1q2", "mohsm", 1, 2, 1, 1, 50, False, False),
+]
+
+
+def gen_mohsm():
+    """SURVEY 8f-2 remainder: MultiOutputHarmonizableSpectralKernel (kernels, LML + autograd gradients, prediction) and the MOHSM wrapper
+    (constructor state, init_parameters('LS'), a short Adam run)"""
+    gen_kernels(KERNEL_CASES_MOHSM, "kernels_mohsm.npz", 1300)
+    gen_lml(LML_CASES_MOHSM, 4300, synth_case=False)
+    out = {}
+    rng = np.random.default_rng(6300)
+    C, Q, D, N, S = 2, 2, 1, 70, 27
+    X, y = small_data(N, C, D, 7300)
+    Xs, _ = small_data(S, C, D, 8300)
+    Xs[:, 1:] = Xs[:, 1:] * 1.2
+    m, lml, loss = lml_case("mohsm", C, Q, D, 1, X, y, rng)
+    out["meta"] = np.array([C, Q, D, 1]); out["kind"] = np.array("mohsm")
+    out["X"] = X; out["y"] = y; out["Xs"] = Xs; out["jitter"] = np.array(m.jitter)
+    dump_params("", list(m.parameters()), out)
+    mu, var = m.predict_f(T(Xs))
+    out["mu"] = mu.numpy(); out["var"] = var.numpy()
+    # the wrapper
+    t = np.linspace(0, 10, 50)
+    ds = mogptk.DataSet(t, [np.sin(0.5 * t), 2.0 * np.sin(0.2 * t) + 0.1 * np.cos(3 * t)])
+    torch.manual_seed(5)
+    mm = mogptk.MOHSM(ds, P=1, Q=2)
+    out["w_t"] = t; out["w_Y"] = np.stack([ds[j].Y for j in range(2)])
+    dump_params("w_ctor_", list(mm.gpr.parameters()), out)
+    out["w_num_parameters"] = np.array(mm.num_parameters())
+    mm.init_parameters("LS")
+    dump_params("w_init_", list(mm.gpr.parameters()), out)
+    out["w_lml"] = np.array(mm.log_marginal_likelihood())
+    mm.gpr.zero_grad(); l0 = mm.gpr.loss()
+    out["w_loss"] = np.array(float(l0))
+    dump_params("w_", list(mm.gpr.parameters()), out, with_grad=True)
+    losses, _ = mm.train("Adam", iters=8, lr=0.05, jit=False)
+    out["w_adam_losses"] = np.array(losses)
+    np.savez_compressed(os.path.join(HERE, "mohsm.npz"), **out)
+    print("mohsm.npz lml=%.10f wrapper lml=%.10f params=%d" % (lml, out["w_lml"], out["w_num_parameters"]))
 
 
 def gen_kernels(cases=None, fname="kernels.npz", seed0=1000):
@@ -643,7 +703,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "lbfgs": gen_lbfgs_cfg1, "quirks": gen_quirks,
              "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2, "smlmc": gen_smlmc, "init_ls": gen_init_ls, "bnse": gen_bnse, "transformers": gen_transformers,
-             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg}
+             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm}
     full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:
         {**steps, **full}[a.only]()

@@ -96,6 +96,8 @@ def product_kernel(kind, C, Q, D, Rq):
         return g.LinearModelOfCoregionalizationKernel(g.SpectralMixtureKernel(Q=3, input_dims=D), output_dims=C, input_dims=D, Q=Q, Rq=Rq)
     if kind == "conv":
         return g.MixtureKernel(g.GaussianConvolutionProcessKernel(output_dims=C, input_dims=D), Q)
+    if kind == "mohsm":
+        return g.MixtureKernel(g.MultiOutputHarmonizableSpectralKernel(output_dims=C, input_dims=D), Q)
     if kind == "umosm":
         return g.MixtureKernel(g.UncoupledMultiOutputSpectralKernel(output_dims=C, input_dims=D), Q)
     raise ValueError(kind)

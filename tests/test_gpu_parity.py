@@ -24,7 +24,7 @@ def test_native_library_is_the_path():
     assert "gfx950" in _lib.device_name(0)
 
 
-@pytest.mark.parametrize("fixture", ["kernels.npz", "kernels_8f2.npz"])
+@pytest.mark.parametrize("fixture", ["kernels.npz", "kernels_8f2.npz", "kernels_mohsm.npz"])
 def test_gram_matches_reference_fixtures(fixture):
     fx = load(fixture)
     for n in range(int(fx["ncases"])):
@@ -42,7 +42,8 @@ def test_gram_matches_reference_fixtures(fixture):
 
 LML = ["mosm_c3q2", "mosm_c2q3_shuf", "mosm_c3q2_d2", "mosm_c1q2", "mosm_scalarvar", "sm_c1q3", "sm_c2q2_d2",
        "csm_c3q2", "csm_c2q2r2",
-       "mosk_c3q2", "mosk_c2q1_d2", "umosm_c3q2", "umosm_c2q2_d2", "lmc_c3q2r2", "lmc_c2q3_d2", "lmcsm_c2q2", "conv_c3q2", "conv_c2q1_d2"]          # same term table, other parameter algebra
+       "mosk_c3q2", "mosk_c2q1_d2", "umosm_c3q2", "umosm_c2q2_d2", "lmc_c3q2r2", "lmc_c2q3_d2", "lmcsm_c2q2", "conv_c3q2", "conv_c2q1_d2",          # same term table, other parameter algebra
+       "mohsm_c3q2", "mohsm_c2q1_d2", "mohsm_c1q2"]                                # ... and the enveloped (2 + 5 D) rows of MOHSM
 
 
 @pytest.mark.parametrize("name", LML)
@@ -474,3 +475,9 @@ def test_sgd_adagrad_error_path_and_pegging_on_device():
     check_opt_traces(tol_loss=1e-8, tol_raw=1e-7)
     check_error_path(tol=1e-6)
     check_pegged_parameters()
+
+
+def test_mohsm_predict_and_wrapper_on_device():
+    """MOHSM end to end on the device: predict_f with the per-point diagonal, the wrapper's loss / gradient / Adam trace"""
+    from test_host_logic import check_mohsm_predict_and_wrapper
+    check_mohsm_predict_and_wrapper(tol_pred=1e-7, tol_loss=1e-9, tol_grad=1e-7, tol_trace=1e-7)

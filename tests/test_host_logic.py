@@ -21,7 +21,7 @@ def fake_device(monkeypatch):
     monkeypatch.setattr(L, "gram", lambda device, C, D, table, X1, X2=None: gram_from_table(np.asarray(table), X1, X2))
 
 
-@pytest.mark.parametrize("fixture", ["kernels.npz", "kernels_8f2.npz"])
+@pytest.mark.parametrize("fixture", ["kernels.npz", "kernels_8f2.npz", "kernels_mohsm.npz"])
 def test_term_tables_reproduce_reference_kernels(fixture):
     fx = load(fixture)
     for n in range(int(fx["ncases"])):
@@ -37,7 +37,8 @@ def test_term_tables_reproduce_reference_kernels(fixture):
 
 LML = ["mosm_c3q2", "mosm_c2q3_shuf", "mosm_c3q2_d2", "mosm_c1q2", "mosm_scalarvar", "sm_c1q3", "sm_c2q2_d2",
        "csm_c3q2", "csm_c2q2r2",
-       "mosk_c3q2", "mosk_c2q1_d2", "umosm_c3q2", "umosm_c2q2_d2", "lmc_c3q2r2", "lmc_c2q3_d2", "lmcsm_c2q2", "conv_c3q2", "conv_c2q1_d2"]          # same term table, other parameter algebra
+       "mosk_c3q2", "mosk_c2q1_d2", "umosm_c3q2", "umosm_c2q2_d2", "lmc_c3q2r2", "lmc_c2q3_d2", "lmcsm_c2q2", "conv_c3q2", "conv_c2q1_d2",          # same term table, other parameter algebra
+       "mohsm_c3q2", "mohsm_c2q1_d2", "mohsm_c1q2"]                                # ... and the enveloped (2 + 5 D) rows of MOHSM
 
 
 @pytest.mark.parametrize("name", LML)
@@ -473,3 +474,40 @@ def check_pegged_parameters(tol_loss=1e-9, tol_grad=1e-7):
 
 def test_pegged_parameters_route_gradients_like_autograd():
     check_pegged_parameters()
+
+
+def check_mohsm_predict_and_wrapper(tol_pred=1e-8, tol_loss=1e-9, tol_grad=1e-8, tol_trace=1e-8):
+    """MOHSM (SURVEY 8f-2 remainder): predict_f of a harmonizable mixture (non-constant K_diag -> per-point kss), then the wrapper:
+    constructor state, init_parameters('LS'), loss + gradient and an Adam trace against recordings of the reference"""
+    fx = load("mohsm.npz")
+    m, fp = product_exact(fx)
+    mu, var = m.predict_f(fx["Xs"])
+    assert relerr(mu, fx["mu"]) < tol_pred and np.max(np.abs(var - fx["var"])) < tol_pred * max(1.0, np.max(np.abs(fx["var"])))
+    ds = mogptk_amd.DataSet(fx["w_t"], [fx["w_Y"][j] for j in range(2)])
+    w = mogptk_amd.MOHSM(ds, P=1, Q=2)
+    params = list(w.gpr.parameters())
+    ctor = fixture_params(fx, "w_ctor_")
+    assert [p._name for p in params] == [str(n) for n in fx["w_ctor_names"]]
+    assert w.num_parameters() == int(fx["w_num_parameters"])
+    for p, f in zip(params, ctor):
+        for mine, ref in ((p.lower, f["lower"]), (p.upper, f["upper"])):
+            assert (mine is None) == (ref is None), p._name
+    load_raw(params, ctor)                       # the random draws of the reference's constructor
+    w.init_parameters("LS")
+    for p, f in zip(params, fixture_params(fx, "w_init_")):
+        assert np.max(np.abs(p() - f["cons"])) <= 1e-8 * max(1.0, np.max(np.abs(f["cons"]))), (p._name, p(), f["cons"])
+    wp = fixture_params(fx, "w_")
+    load_raw(params, wp)
+    assert abs(w.log_marginal_likelihood() - float(fx["w_lml"])) < tol_loss * abs(float(fx["w_lml"]))
+    assert abs(float(w.gpr.loss()) - float(fx["w_loss"])) < tol_loss * abs(float(fx["w_loss"]))
+    for p, f in zip(params, wp):
+        if f["grad"] is None:
+            assert p.grad is None, p._name
+        else:
+            assert np.max(np.abs(p.grad - f["grad"])) <= tol_grad * max(1.0, np.max(np.abs(f["grad"]))), (p._name, p.grad, f["grad"])
+    losses, _ = w.train("Adam", iters=8, lr=0.05)
+    assert relerr(losses, fx["w_adam_losses"]) < tol_trace
+
+
+def test_mohsm_predict_and_wrapper_match_reference():
+    check_mohsm_predict_and_wrapper()
