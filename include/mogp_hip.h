@@ -179,7 +179,9 @@ int  mogp_dev_copy(void* dst, const void* src, int64_t bytes, int to_device);
 /* ---- measurement ------------------------------------------------------------------------------- */
 /* stage ids for mogp_stage_ms (HIP-event time of the last mogp_exact_eval on this model's stream) */
 enum { MOGP_ST_GRAM = 0, MOGP_ST_POTRF = 1, MOGP_ST_TRTRI = 2, MOGP_ST_LAUUM = 3, MOGP_ST_SOLVE = 4,
-       MOGP_ST_MOMENTS = 5, MOGP_ST_TOTAL = 6, MOGP_ST_GEMM_KERNEL = 7, MOGP_ST_COUNT = 8 };
+       MOGP_ST_MOMENTS = 5, MOGP_ST_TOTAL = 6, MOGP_ST_GEMM_KERNEL = 7,
+       MOGP_ST_GRAM_KERNEL = 8, MOGP_ST_MOMENT_KERNEL = 9,   /* the Gram / moment kernel alone (the stage also has the phase-table pre-pass) */
+       MOGP_ST_COUNT = 10 };
 int  mogp_set_profiling(mogp_model* m, int on);
 /* ms[MOGP_ST_COUNT]; MOGP_ST_GEMM_KERNEL = summed duration of every launch of the fp64 MFMA GEMM kernel;
  * *gemm_launches / *gemm_flops = their count and algorithmic flop total in the last eval. */

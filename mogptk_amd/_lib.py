@@ -16,7 +16,7 @@ MOGP_EVAL_GRAD = 1
 COMM_ID_BYTES = 128
 ALLGATHER_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
 ALLREDUCE_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
-ST_GRAM, ST_POTRF, ST_TRTRI, ST_LAUUM, ST_SOLVE, ST_MOMENTS, ST_TOTAL, ST_GEMM_KERNEL, ST_COUNT = range(9)
+ST_GRAM, ST_POTRF, ST_TRTRI, ST_LAUUM, ST_SOLVE, ST_MOMENTS, ST_TOTAL, ST_GEMM_KERNEL, ST_GRAM_KERNEL, ST_MOMENT_KERNEL, ST_COUNT = range(11)
 
 _lib = None
 _lock = threading.RLock()

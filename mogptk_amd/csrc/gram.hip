@@ -504,12 +504,14 @@ int launch_gram(const GramArgs& a0, int ntiles, hipStream_t s) {
     const size_t tab_bytes = (size_t)a.C * a.C * a.T * a.W * sizeof(double);
     a.tab_lds = tab_bytes <= 24 * 1024;                      // the term table rides in LDS when small (it is read by every staging item)
     const size_t dyn = a.tab_lds ? tab_bytes : 0;
+    if (a.ev0) HIP_TRY(hipEventRecord(a.ev0, s));
     switch (a.D) {
         case 1: hipLaunchKernelGGL(k_gram<1>, dim3(grid), dim3(256), dyn, s, a, ntiles); break;
         case 2: hipLaunchKernelGGL(k_gram<2>, dim3(grid), dim3(256), dyn, s, a, ntiles); break;
         case 3: hipLaunchKernelGGL(k_gram<3>, dim3(grid), dim3(256), dyn, s, a, ntiles); break;
         default: hipLaunchKernelGGL(k_gram<0>, dim3(grid), dim3(256), dyn, s, a, ntiles); break;
     }
+    if (a.ev1) HIP_TRY(hipEventRecord(a.ev1, s));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -743,7 +745,12 @@ int launch_moments(const MomentArgs& a0, hipStream_t s) {
     const int64_t ldxc = a.xc ? a.ldxc : a.ldx;
     int rc = launch_phase_tables(a.ph, a.x, a.ldx, a.nrows, xc, ldxc, a.xc ? a.ncols : a.nrows, a.table, a.T, a.D, a.C, a.W, s);
     if (rc) return rc;
-    if (a.G == nullptr) return env ? launch_moments_t<false, false, true>(a, s) : launch_moments_t<false, false, false>(a, s);
+    if (a.G == nullptr) {
+        if (a.ev0) HIP_TRY(hipEventRecord(a.ev0, s));
+        rc = env ? launch_moments_t<false, false, true>(a, s) : launch_moments_t<false, false, false>(a, s);
+        if (!rc && a.ev1) HIP_TRY(hipEventRecord(a.ev1, s));
+        return rc;
+    }
     if (env) { set_error("the dense-adjoint moment pass (Titsias) does not take terms with an envelope"); return -1; }
     if (a.gzr || a.gzc) return launch_moments_t<true, true, false>(a, s);
     return launch_moments_t<true, false, false>(a, s);

@@ -205,6 +205,12 @@ namespace mogp { int mark(mogp_model* m, int idx) {
     HIP_TRY(hipEventRecord(m->ev[idx], m->st));
     return 0;
 }
+// events 7 .. 10 bracket the Gram and the moment tile kernels alone (handed to the launchers)
+static hipEvent_t prof_event(mogp_model* m, int idx) {
+    if (!m->profiling) return nullptr;
+    while ((int)m->ev.size() <= idx) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; m->ev.push_back(e); }
+    return m->ev[idx];
+}
 }  // namespace mogp
 
 // Cholesky of w.A (lower) in place; w.invd gets the inverses of the diagonal 128-tiles, w.logdet the per-tile sums of
@@ -395,13 +401,15 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
 
     int rc;
     if ((rc = mark(m, 0))) return rc;
-    GramArgs ga;
+    GramArgs ga{};
     ga.tiles = m->d_tiles.p; ga.xr = m->d_x.p; ga.xc = m->d_x.p; ga.ldxr = ga.ldxc = Npad; ga.nrows = ga.ncols = N;
     if ((rc = m->ph_xx.prepare(m->sx.off, m->sx.off, C, m->T, Npad, Npad, m->st, ga.ph))) return rc;
     ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = m->Wt;
     ga.out = m->k.A.p; ga.ldo = Npad; ga.noise = m->d_noise.p; ga.dvar = data_var ? m->d_dvar.p : nullptr;
     ga.jitter_abs = jabs; ga.mirror = 0;
+    ga.ev0 = prof_event(m, 7); ga.ev1 = prof_event(m, 8);
     if ((rc = launch_gram(ga, (int)m->tiles.size(), m->st))) return rc;
+    ga.ev0 = ga.ev1 = nullptr;
     if ((rc = launch_pad_identity(m->k.A.p, Npad, N, Npad, m->st))) return rc;
     if ((rc = mark(m, 1))) return rc;
 
@@ -471,6 +479,8 @@ static void collect_timing(mogp_model* m, int last_mark) {
     m->ms[MOGP_ST_SOLVE] = el(3, 4);
     if (last_mark >= 6) { m->ms[MOGP_ST_LAUUM] = el(4, 5); m->ms[MOGP_ST_MOMENTS] = el(5, 6); }
     m->ms[MOGP_ST_TOTAL] = el(0, last_mark);
+    if ((int)m->ev.size() > 8) m->ms[MOGP_ST_GRAM_KERNEL] = el(7, 8);
+    if (last_mark >= 6 && (int)m->ev.size() > 10) m->ms[MOGP_ST_MOMENT_KERNEL] = el(9, 10);
     double gsum = 0.0;
     for (size_t i = 0; i + 1 < m->gemm_ev_used; i += 2) {
         float t = 0.f;
@@ -572,6 +582,7 @@ static int moment_pass_device(mogp_model* m, const double* kinv, double ksign) {
     ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C; ma.W = W; ma.kinv = kinv; ma.kinv_sign = ksign; ma.ld = Npad; ma.alpha = m->d_alpha.p;
     ma.row_mod = rm; ma.row_rem = m->sh_rank;
     ma.partial = m->d_partial.p;
+    ma.ev0 = prof_event(m, 9); ma.ev1 = prof_event(m, 10);
     if ((rc = launch_moments(ma, m->st))) return rc;
     if ((rc = launch_moment_reduce(m->d_partial.p, own ? m->d_pair_start_own.p : m->d_pair_start.p, P, T, W, D, m->d_moments.p, m->st))) return rc;
     if ((rc = launch_diagG(kinv, Npad, m->d_alpha.p, m->d_chan_off.p, C, m->d_diagG.p, m->st, ksign, rm, m->sh_rank))) return rc;
@@ -842,7 +853,7 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
     HIP_TRY(hipMemsetAsync(m->d_Ksf.p, 0, (size_t)Spad * Npad * sizeof(double), m->st));
 
     // K_sf = K(Xs, X)   (rows: test points, columns: training points; all C*C pairs, reference kernel.py:468-479 transposed)
-    GramArgs ga;
+    GramArgs ga{};
     ga.tiles = m->d_ptiles.p; ga.xr = m->d_xs.p; ga.ldxr = Spad; ga.xc = m->d_x.p; ga.ldxc = Npad; ga.nrows = S; ga.ncols = m->N;
     if ((rc = m->ph_sx.prepare(ss.off, m->sx.off, C, m->T, Spad, Npad, m->st, ga.ph))) return rc;
     ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = m->Wt; ga.out = m->d_Ksf.p; ga.ldo = Npad;
@@ -931,7 +942,7 @@ int mogp_gram_ex(mogp_ctx* ctx, int C, int D, int T, int width, const double* ta
     }
     G_HIP(hipMemcpy(dtab.p, table, (size_t)C * C * T * W * sizeof(double), hipMemcpyHostToDevice));
     G_HIP(hipMemcpy(dt.p, tiles.data(), tiles.size() * sizeof(GTile), hipMemcpyHostToDevice));
-    GramArgs ga;
+    GramArgs ga{};
     ga.tiles = dt.p; ga.xr = dx1.p; ga.ldxr = s1.Mpad; ga.xc = sym ? dx1.p : dx2.p; ga.ldxc = sc.Mpad; ga.nrows = R; ga.ncols = Cc;
     G_TRY(ph.prepare(s1.off, sc.off, C, T, s1.Mpad, sc.Mpad, nullptr, ga.ph));
     ga.table = dtab.p; ga.T = T; ga.D = D; ga.C = C; ga.W = W; ga.out = dout.p; ga.ldo = Cc;
@@ -1165,7 +1176,7 @@ int mogp_exact_predict_sharded(mogp_model* m, const double* noise_var, const dou
     HIP_TRY(hipMemsetAsync(m->d_var.p, 0, Spad * sizeof(double), m->st));
     if (rows > 0) {
         HIP_TRY(hipMemsetAsync(m->d_Ksf.p + row0 * Npad, 0, (size_t)rows * Npad * sizeof(double), m->st));   // padded rows / columns stay zero
-        GramArgs ga;
+        GramArgs ga{};
         ga.tiles = m->d_ptiles.p; ga.xr = m->d_xs.p; ga.ldxr = Spad; ga.xc = m->d_x.p; ga.ldxc = Npad; ga.nrows = S; ga.ncols = m->N;
         if ((rc = m->ph_sx.prepare(ss.off, m->sx.off, C, m->T, Spad, Npad, m->st, ga.ph))) return rc;
         ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = m->Wt; ga.out = m->d_Ksf.p; ga.ldo = Npad;

@@ -59,6 +59,7 @@ struct GramArgs {
     const double* dvar;    // [N] per-point variance or null
     double jitter_abs;
     int mirror;            // write the transpose of GT_MIRROR tiles too (full symmetric Gram for Kernel.K)
+    hipEvent_t ev0, ev1;   // when non-null: recorded around the tile kernel alone (profiling)
     int dbg;               // measurement only (MOGP_GRAM_DBG): 1 = no stores, 2 = no terms (stores only)
     int tab_lds;           // set by the launcher: the term table is copied to LDS
 };
@@ -94,6 +95,7 @@ struct MomentArgs {
     double* gzc;
     int64_t ldgz;
     double* partial;       // [ntiles][T][W] per-tile partial moments (reduced in fixed order afterwards)
+    hipEvent_t ev0, ev1;   // when non-null: recorded around the tile kernel alone (profiling)
     int tab_lds;           // set by the launcher: the term table is copied to LDS
 };
 

@@ -1,8 +1,11 @@
 """
 Global configuration singleton, mirroring mogptk/gpr/config.py:3-73 for the HIP path.
 
-`config.dtype` is numpy float64 (the only precision the HIP path computes in); `config.device`
-is the HIP device ordinal the C-ABI contexts bind to.
+`config.dtype` is the dtype of everything the host holds -- parameters (raw values, Adam state), X, y, losses, gradients, predictions --
+float64 by default, float32 after use_single_precision(), with the reference's jitter floor per dtype (gpr/model.py:106-110).  The
+device arithmetic itself is fp64 in both cases (the fp64 MFMA path is the product; there is no fp32 kernel set): single precision is
+honoured at the boundary -- float32-rounded inputs and parameters go in, float32 results come out -- which is at least as accurate as
+the reference's float32 run.  `config.device` is the HIP device ordinal the C-ABI contexts bind to.
 """
 import numpy as np
 
@@ -23,13 +26,15 @@ def use_double_precision():
 
 
 def use_single_precision():
-    """mogptk/gpr/config.py:20-24.  The gfx950 path is fp64 end to end (parity 1e-5 on a gradient that
-    contains the cancellation 1/2(alpha alpha^T - K^-1)); fp32 is refused rather than silently upcast."""
-    raise NotImplementedError("the MI355X exact-GP path computes in float64 only")
+    """mogptk/gpr/config.py:20-24: float32 for all host tensors created from now on (and the 1e-6 jitter floor); the device still
+    factorises in fp64 (see the module docstring)."""
+    config.dtype = np.float32
 
 
 def use_half_precision():
-    raise NotImplementedError("the MI355X exact-GP path computes in float64 only")
+    """mogptk/gpr/config.py:12-18.  float16 host tensors cannot carry the spectral hyper-parameters (variances of 1e-3 .. 1e-2 next to
+    positive_minimum = 1e-8): refused rather than silently widened."""
+    raise NotImplementedError("half precision is not on the MI355X exact-GP path")
 
 
 def use_gpu(n=None):

@@ -28,7 +28,7 @@ class CholeskyException(Exception):
 def _to_array(X):
     if hasattr(X, "detach"):
         X = X.detach().cpu().numpy()
-    return np.array(X, dtype=np.float64)
+    return np.array(X, dtype=config.dtype)
 
 
 def _gtable_from_moments(table, mom, D, lower=True):
@@ -82,7 +82,7 @@ class Model(ParameterHolder):
         likelihood.validate_y(X, y)
 
         # limit to number of significant digits (reference gpr/model.py:106-110)
-        jitter = max(jitter, 1e-15)
+        jitter = max(jitter, 1e-6 if config.dtype == np.float32 else 1e-15)
 
         self.kernel = kernel
         self.X = X
@@ -251,7 +251,7 @@ class Exact(Model):
     def log_marginal_likelihood(self):
         """reference gpr/model.py:438-453 -- one forward-only device evaluation"""
         res, _, _ = self._eval(grad=False)
-        return np.float64(res["lml"])
+        return config.dtype(res["lml"])
 
     def _loss_impl(self):
         """reference gpr/model.py:279-292: zero grads, loss = -LML - log prior, fresh `.grad` on every
@@ -286,7 +286,7 @@ class Exact(Model):
         else:
             gsc = np.reshape(2.0 * sc * np.sum(gnoise), sc.shape)
         scale.accumulate_grad(-gsc)
-        return np.float64(-res["lml"] - self.log_prior())
+        return config.dtype(-res["lml"] - self.log_prior())
 
     def predict_f(self, X, full=False):
         """reference gpr/model.py:455-483"""
@@ -306,7 +306,7 @@ class Exact(Model):
             raise
         if self.mean is not None:
             mu = mu + np.asarray(self.mean(X)).reshape(-1, 1)
-        return mu, var
+        return mu.astype(config.dtype, copy=False), var.astype(config.dtype, copy=False)
 
 
 # ---- inducing-point initialisation (reference gpr/model.py:11-69) ---------------------------------------------------
@@ -413,7 +413,7 @@ class Titsias(Model):
 
     def elbo(self):
         res, _, _, _ = self._run(grad=False)
-        return np.float64(res["elbo"])
+        return config.dtype(res["elbo"])
 
     def log_marginal_likelihood(self):
         """maximise the lower bound (reference gpr/model.py:726-728)"""
@@ -439,7 +439,7 @@ class Titsias(Model):
         off = 0 if self.kernel.output_dims is None else 1
         gz[:, off:] = -res["gZ"]
         self.Z.accumulate_grad(gz)
-        return np.float64(-res["elbo"] - self.log_prior())
+        return config.dtype(-res["elbo"] - self.log_prior())
 
     def predict_f(self, X, full=False):
         """reference gpr/model.py:730-765"""

@@ -20,11 +20,12 @@ from .config import config
 
 
 def _asarray(value):
+    """host tensor in config.dtype (float64, or float32 after use_single_precision(): reference parameter.py:206-218 `to_tensor`)"""
     if isinstance(value, Parameter):
-        return np.array(value.constrained, dtype=np.float64)
+        return np.array(value.constrained, dtype=config.dtype)
     if hasattr(value, "detach"):            # torch tensors are accepted at the boundary
         value = value.detach().cpu().numpy()
-    return np.array(value, dtype=np.float64)
+    return np.array(value, dtype=config.dtype)
 
 
 class Transform:
@@ -206,7 +207,7 @@ class Parameter:
                 g = _vjp(self.pegged_transform, other.constrained, g)
             other.accumulate_grad(np.reshape(g, other.data.shape))
             return
-        g = g * self.dconstrained()
+        g = (g * self.dconstrained()).astype(self.data.dtype, copy=False)       # .grad lives in the parameter's own dtype, like autograd's
         self.grad = g if self.grad is None else self.grad + g
 
     def numpy(self):
@@ -282,7 +283,7 @@ class Parameter:
             value = transform.inverse(value)
 
         self._name = name
-        self.data = np.array(value, dtype=np.float64)
+        self.data = np.array(value, dtype=config.dtype)
         self.lower = lower
         self.upper = upper
         self.prior = prior

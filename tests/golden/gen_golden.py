@@ -16,6 +16,7 @@ nothing of the reference travels.  Re-run:  python tests/golden/gen_golden.py [-
   opt_traces.npz train('SGD' | 'AdaGrad') traces, the per-iteration error= path and a continued train() call on the cfg1 model
   peg.npz        loss + gradients of a model with pegged parameters (identity and 2x transforms)
   kernels_mohsm.npz / lml_mohsm_* / mohsm.npz  MultiOutputHarmonizableSpectralKernel and the MOHSM wrapper (SURVEY 8f-2 remainder)
+  fp32.npz       config.use_single_precision(): float32 tensors, jitter floor 1e-6, loss / gradients / prediction of the reference's float32 run
   lbfgs_cfg1.npz the same model under train('LBFGS'): fixed-step and strong-Wolfe loss traces by function evaluation
   cfg2.npz      [--full] MOSM C=4 Q=3 N=8192 LML + gradient (BASELINE.json configs[1]; ~20 s, 10 GB)
   cfg4.npz      [--full] CSM C=4 Q=3 N=16384 predict_f at 64 probe rows of S=4096 (configs[3]; ~40 s, 16 GB)
@@ -482,6 +483,35 @@ def gen_peg():
     np.savez_compressed(os.path.join(HERE, "peg.npz"), **out)
     print("peg.npz lml=%.10f" % out["lml"], [None if p.grad is None else p.grad.shape for p in m.parameters()])
 
+def gen_fp32():
+    """config.use_single_precision() (gpr/config.py:20-24): float32 host tensors and the 1e-6 jitter floor (gpr/model.py:106-110); the
+    reference then ALSO factorises in float32, so its loss / gradients carry float32 rounding (recorded next to a float64 run of the same
+    float32-rounded inputs for scale)"""
+    out = {}
+    rng = np.random.default_rng(7700)
+    C, Q, D, N = 2, 2, 1, 64
+    X, y = small_data(N, C, D, 7701)
+    g.use_single_precision()
+    try:
+        T32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
+        k = build_kernel("mosm", C, Q, D, 1, rng)
+        scale = rng.uniform(0.2, 0.4, C)
+        m = g.Exact(k, T32(X), T32(y), variance=list(scale ** 2), jitter=1e-8)
+        m.likelihood.scale.assign(scale)
+        out["jitter"] = np.array(m.jitter)
+        out["loss"] = np.array(float(m.loss()))
+        out["loss_dtype"] = np.array(str(m.loss().dtype))
+        dump_params("", list(m.parameters()), out, with_grad=True)
+        Xs, _ = small_data(21, C, D, 7702)
+        mu, var = m.predict_f(T32(Xs))
+        out["Xs"] = Xs; out["mu"] = mu.numpy(); out["var"] = var.numpy()
+    finally:
+        g.use_double_precision()
+    out["meta"] = np.array([C, Q, D, 1]); out["X"] = X; out["y"] = y
+    np.savez_compressed(os.path.join(HERE, "fp32.npz"), **out)
+    print("fp32.npz loss=%.6f jitter=%g dtype=%s" % (out["loss"], out["jitter"], out["loss_dtype"]))
+
+
 def gen_quirks():
     """Q1/Q2 of SURVEY.md 8b as data."""
     out = {}
@@ -703,7 +733,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "lbfgs": gen_lbfgs_cfg1, "quirks": gen_quirks,
              "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2, "smlmc": gen_smlmc, "init_ls": gen_init_ls, "bnse": gen_bnse, "transformers": gen_transformers,
-             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm}
+             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32}
     full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:
         {**steps, **full}[a.only]()

@@ -110,7 +110,7 @@ def load_raw(params_iter, fxparams):
     for p, f in zip(plist, fxparams):
         assert p.data.shape == f["raw"].shape, (p._name, f["name"], p.data.shape, f["raw"].shape)
         p.assign(f["cons"], lower=f["lower"], upper=f["upper"])
-        p.data = np.array(f["raw"], dtype=np.float64)      # exact raw values (assign() round-trips inexactly: quirk Q1)
+        p.data = np.array(f["raw"], dtype=p.data.dtype)    # exact raw values (assign() round-trips inexactly: quirk Q1); config.dtype
     return plist
 
 

@@ -481,3 +481,8 @@ def test_mohsm_predict_and_wrapper_on_device():
     """MOHSM end to end on the device: predict_f with the per-point diagonal, the wrapper's loss / gradient / Adam trace"""
     from test_host_logic import check_mohsm_predict_and_wrapper
     check_mohsm_predict_and_wrapper(tol_pred=1e-7, tol_loss=1e-9, tol_grad=1e-7, tol_trace=1e-7)
+
+
+def test_single_precision_switch_on_device():
+    from test_host_logic import check_single_precision_switch
+    check_single_precision_switch()

@@ -323,9 +323,41 @@ def test_transformers_match_reference_and_cfg1_end_to_end():
     assert np.all(np.isfinite(mu)) and mu.shape == (len(gold["pred_X"]),)
 
 
+def check_single_precision_switch(tol=2e-3):
+    """config.use_single_precision() (reference gpr/config.py:20-24, jitter floor gpr/model.py:106-110): float32 host tensors in and
+    out, the 1e-6 jitter floor; the device still computes in fp64, so against the reference's own float32 run only float32-level
+    agreement can be asked for (its Cholesky runs in float32)."""
+    fx = load("fp32.npz")
+    C, Q, D, Rq = [int(v) for v in fx["meta"]]
+    fp = fixture_params(fx)
+    gpr.use_single_precision()
+    try:
+        k = product_kernel("mosm", C, Q, D, Rq)
+        m = gpr.Exact(k, fx["X"], fx["y"], variance=np.square(fp[-1]["cons"]), jitter=1e-8)
+        assert m.jitter == float(fx["jitter"]) == 1e-6
+        load_raw(m.parameters(), fp)
+        assert all(p.data.dtype == np.float32 for p in m.parameters()) and m.X.dtype == np.float32
+        loss = m.loss()
+        assert loss.dtype == np.float32 and str(fx["loss_dtype"]) == "torch.float32"
+        assert abs(float(loss) - float(fx["loss"])) < tol * abs(float(fx["loss"]))
+        for p, f in zip(m.parameters(), fp):
+            assert p.grad.dtype == np.float32
+            assert np.max(np.abs(p.grad - f["grad"])) <= 10 * tol * max(1.0, np.max(np.abs(f["grad"]))), (p._name, p.grad, f["grad"])
+        mu, var = m.predict_f(fx["Xs"])
+        assert mu.dtype == np.float32 and var.dtype == np.float32
+        assert relerr(mu, fx["mu"]) < 10 * tol and np.max(np.abs(var - fx["var"])) < 10 * tol * max(1.0, np.max(np.abs(fx["var"])))
+    finally:
+        gpr.use_double_precision()
+    assert gpr.Parameter(1.0).data.dtype == np.float64
+
+
+def test_single_precision_switch_matches_reference_semantics():
+    check_single_precision_switch()
+
+
 def test_unsupported_paths_fail_loudly():
     with pytest.raises(NotImplementedError):
-        gpr.use_single_precision()
+        gpr.use_half_precision()
     with pytest.raises(NotImplementedError):
         gpr.use_cpu()
     k = gpr.MultiOutputSpectralMixtureKernel(Q=1, output_dims=2) * gpr.MultiOutputSpectralMixtureKernel(Q=1, output_dims=2)
