@@ -141,8 +141,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
         for (int q = 0; q < NQ_A; ++q) *reinterpret_cast<d2_t*>(sa + a_l + 2 * q) = ra[q];
 #pragma unroll
         for (int q = 0; q < NQ_B; ++q) *reinterpret_cast<d2_t*>(sb + b_l + 2 * q) = rb[q];
+#if !defined(GEMM_EXP) || GEMM_EXP < 2
         __syncthreads();
+#endif
+#if defined(GEMM_EXP) && GEMM_EXP >= 1
+        if (false) {
+#else
         if (kb + 1 < kt) {
+#endif
             const d2_t* pa = reinterpret_cast<const d2_t*>(Ap + a_g + (int64_t)(kb + 1) * a_step);
             const d2_t* pb = reinterpret_cast<const d2_t*>(Bp + b_g + (int64_t)(kb + 1) * b_step);
 #pragma unroll
@@ -153,10 +159,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
 #pragma unroll
         for (int k4 = 0; k4 < GEMM_BK / 4; ++k4) {
             double av[WTM], bv[WTN];
+#if defined(GEMM_EXP) && GEMM_EXP >= 3
+#pragma unroll
+            for (int m = 0; m < WTM; ++m) av[m] = ra[0][0] + m + k4;
+#pragma unroll
+            for (int n = 0; n < WTN; ++n) bv[n] = rb[0][1] + n;
+#else
 #pragma unroll
             for (int m = 0; m < WTM; ++m) av[m] = sa[fa + m * fa_m + k4 * fa_k];
 #pragma unroll
             for (int n = 0; n < WTN; ++n) bv[n] = sb[fb + n * fb_n + k4 * fb_k];
+#endif
 #pragma unroll
             for (int m = 0; m < WTM; ++m)
 #pragma unroll

@@ -128,7 +128,7 @@ int mogp_ctx_create(int device, mogp_ctx** out) {
 
 int mogp_ctx_destroy(mogp_ctx* ctx) {
     if (!ctx) return MOGP_OK;
-    for (hipStream_t q : {ctx->st, ctx->st2, ctx->st2u, ctx->st3, ctx->st_priv}) if (q) { hipError_t e = hipStreamSynchronize(q); (void)e; e = hipStreamDestroy(q); (void)e; }
+    for (hipStream_t q : {ctx->st, ctx->st2, ctx->st2u, ctx->st3, ctx->st4, ctx->st_priv}) if (q) { hipError_t e = hipStreamSynchronize(q); (void)e; e = hipStreamDestroy(q); (void)e; }
     delete ctx;
     return MOGP_OK;
 }
@@ -636,9 +636,11 @@ static int ctx_streams(mogp_ctx* ctx) {
             HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st_priv, (uint32_t)priv.size(), priv.data()));
             HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st2, (uint32_t)bulk.size(), bulk.data()));
             HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st3, (uint32_t)bulk.size(), bulk.data()));
+            HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st4, (uint32_t)bulk.size(), bulk.data()));
         } else {
             HIP_TRY(hipStreamCreateWithPriority(&ctx->st2, hipStreamNonBlocking, (lo + hi) / 2));
             HIP_TRY(hipStreamCreateWithPriority(&ctx->st3, hipStreamNonBlocking, lo));
+            HIP_TRY(hipStreamCreateWithPriority(&ctx->st4, hipStreamNonBlocking, lo));
         }
     }
     {   // bulk stream over ALL CUs (full mask), used once an evaluation is flop-bound
@@ -671,7 +673,7 @@ int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, c
 #define TRY_RC(x) do { int r__ = (x); if (r__) { mogp_model_destroy(m); return r__; } } while (0)
 #define TRY_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { int r__ = hip_fail(e__, #x, __FILE__, __LINE__); mogp_model_destroy(m); return r__; } } while (0)
     TRY_RC(ctx_streams(ctx));
-    m->st = ctx->st; m->st2 = ctx->st2; m->st2u = ctx->st2u; m->st3 = ctx->st3; m->st_priv = ctx->st_priv;
+    m->st = ctx->st; m->st2 = ctx->st2; m->st2u = ctx->st2u; m->st3 = ctx->st3; m->st4 = ctx->st4; m->st_priv = ctx->st_priv;
     TRY_RC(spd_alloc(m->k, Npad));
     TRY_RC(m->d_x.ensure((size_t)D * Npad));
     TRY_RC(m->d_y.ensure(Npad));
@@ -702,7 +704,7 @@ int mogp_model_destroy(mogp_model* m) {
     if (m->st) { hipError_t e = hipStreamSynchronize(m->st); (void)e; }
     for (auto e : m->ev) { hipError_t r = hipEventDestroy(e); (void)r; }
     for (auto e : m->gemm_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
-    for (hipStream_t q : {m->st2, m->st2u, m->st3, m->st_priv}) if (q) { hipError_t e = hipStreamSynchronize(q); (void)e; }
+    for (hipStream_t q : {m->st2, m->st2u, m->st3, m->st4, m->st_priv}) if (q) { hipError_t e = hipStreamSynchronize(q); (void)e; }
     m->k.release(); m->ws.release(); m->ws_tail.release();
     for (int b = 0; b < 2; ++b) { m->swU[b].release(); m->swUr[b].release(); }
     for (auto e : m->sw_ev) { hipError_t r = hipEventDestroy(e); (void)r; }

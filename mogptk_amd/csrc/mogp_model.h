@@ -85,7 +85,7 @@ struct mogp_ctx {
     mogp_comm comm;
     std::string name;
     // streams shared by every model of the context (created once: a CU-masked stream owns a hardware queue, and models come and go)
-    hipStream_t st = nullptr, st2 = nullptr, st3 = nullptr, st_priv = nullptr, st2u = nullptr;
+    hipStream_t st = nullptr, st2 = nullptr, st3 = nullptr, st4 = nullptr, st_priv = nullptr, st2u = nullptr;
     bool streams_ready = false;
 };
 
@@ -107,7 +107,7 @@ struct Spd {
     std::vector<TrtriLevel> levels;
     std::vector<hipEvent_t> sync_ev;    // cross-stream dependencies of the look-ahead schedule
     std::vector<hipEvent_t> inv_ev;     // events of the fused schedule (potri.hip)
-    hipEvent_t fused_last_inv = nullptr;
+    hipEvent_t fused_last_inv = nullptr, fused_last_wt = nullptr;
     DevBuf<double> Wd;                  // W_KK = L_KK^-1 of every outer block of the fused schedule (512 x 512 each, wkk.hip)
     DevBuf<double> Pb[MOGP_NPANEL];     // rotating panel buffers L[>K, K] of the fused schedule (Npad x 512 each)
     void release() {
@@ -155,6 +155,7 @@ struct mogp_model {
     hipStream_t st2 = nullptr;          // bulk trailing updates of the fused schedule (CU-masked: everything but the reserved CUs)
     hipStream_t st2u = nullptr;         // bulk trailing updates over ALL CUs, for flop-bound sizes (MOGP_CHAIN_BOUND_TILES)
     hipStream_t st3 = nullptr;          // inverse streamed behind the factorisation (lowest priority)
+    hipStream_t st4 = nullptr;          // the inverse's rank-512 accumulations W[K,:]^T W[K,:] (nothing but the result depends on them)
     hipStream_t st_priv = nullptr;      // intra-block chain of the fused factorisation, on the reserved CUs only
     Spd k;                              // the N x N system
     Spd ws, ws_tail;                    // Schur-block workspaces of the sweep inversion (outer block / last partial block)

@@ -42,7 +42,7 @@ int launch_potrf_trtri_tile(double* A, int64_t ld, int t, double* invd, double* 
 
 namespace {
 
-enum { EV_BLK = 0, EV_DIAG = 1, EV_PANEL = 2, EV_BULK = 3, EV_INV = 4, EV_REST = 5, EV_PER_BLOCK = 6 };
+enum { EV_BLK = 0, EV_DIAG = 1, EV_PANEL = 2, EV_BULK = 3, EV_INV = 4, EV_REST = 5, EV_WROW = 6, EV_ACC = 7, EV_PER_BLOCK = 8 };
 
 // factor the diagonal block [k0, k1) of w.A in place (L_KK) and put W_KK = L_KK^-1 (lower; zeros above) into Wk (leading dimension FZ_KD)
 int intra_block_chain(mogp_model* m, Spd& w, double* Wk, int k0, int k1, hipStream_t q) {
@@ -80,7 +80,8 @@ int panel_rows(mogp_model* m, Spd& w, double* P, const double* Wk, int k0, int n
 }
 
 // the inverse stream's share of block K (see the header); Lp = P[k1 tile row], leading dimension FZ_KD
-int inverse_step(mogp_model* m, Spd& w, const double* Wkk, int k0, int k1, const double* Lp, hipStream_t q, hipEvent_t w_final) {
+int inverse_step(mogp_model* m, Spd& w, const double* Wkk, int k0, int k1, const double* Lp, hipStream_t q, hipStream_t qacc, hipEvent_t w_row,
+                 hipEvent_t w_final) {
     const int64_t ld = w.Npad;
     const int nk = k1 - k0, rem = w.nb - k1;
     const int64_t Kd = (int64_t)nk * MOGP_TILE, c0 = (int64_t)k0 * MOGP_TILE;
@@ -96,6 +97,7 @@ int inverse_step(mogp_model* m, Spd& w, const double* Wkk, int k0, int k1, const
     }
     RC(launch_copy2d(Wrow + c0, ld, Wkk, FZ_KD, Kd, Kd, 1.0, q));
     if (w_final) HIP_TRY(hipEventRecord(w_final, q));           // the last row block: W = L^-1 is complete
+    HIP_TRY(hipEventRecord(w_row, q));                          // W[K, <=K] is final: its accumulation into the inverse may start
     if (rem > 0) {
         double* Wt = w.Wm.p + (int64_t)k1 * MOGP_TILE * ld;                    // Wt[>K, 0]
         GemmArgs g{};
@@ -111,12 +113,15 @@ int inverse_step(mogp_model* m, Spd& w, const double* Wkk, int k0, int k1, const
             RC(gemm_call(m, u, gemm_flops(u, nullptr), q));
         }
     }
+    // Kinv[<=K, <=K] += W[K, <=K]^T W[K, <=K] on its own stream: the big launch runs next to the small, serial launches of the
+    // following row blocks instead of in front of them (the accumulations only order among themselves)
+    HIP_TRY(hipStreamWaitEvent(qacc, w_row, 0));
     GemmArgs g{};
     g.A = Wrow; g.lda = ld; g.a_kmajor = 1; g.B = Wrow; g.ldb = ld; g.b_kmajor = 1;
     g.C = w.B.p; g.ldc = ld; g.alpha = 1.0; g.beta = 1.0;
     g.mode = GM_LOWER; g.mt = g.nt = k1; g.K = (int)Kd;
     g.beta0_from = k0 + 1;                         // the row block K of the inverse is new (it held scratch): written, not accumulated -- no memset
-    return gemm_call(m, g, gemm_flops(g, nullptr), q);
+    return gemm_call(m, g, gemm_flops(g, nullptr), qacc);
 }
 
 }  // namespace
@@ -129,6 +134,8 @@ int spd_potri_fused(mogp_model* m, Spd& w) {
     const int nouter = (nb + FZ_OB - 1) / FZ_OB;
     const auto t_host0 = std::chrono::steady_clock::now();
     hipStream_t crit = m->st, priv = m->st_priv ? m->st_priv : m->st, bulk = m->st2, inv = m->st3;
+    static const bool split_acc = !(std::getenv("MOGP_ACC_STREAM") && std::atoi(std::getenv("MOGP_ACC_STREAM")) == 0);
+    hipStream_t acc = (m->st4 && split_acc) ? m->st4 : m->st3;
 
     if (w.Wm.n < (size_t)ld * ld) {                      // nothing ever writes above the block diagonal of W: keep it finite
         RC(w.Wm.ensure((size_t)ld * ld));
@@ -227,8 +234,9 @@ int spd_potri_fused(mogp_model* m, Spd& w) {
         // 6. inv
         HIP_TRY(hipStreamWaitEvent(inv, ev(kb, EV_BLK), 0));
         if (rem > 0) HIP_TRY(hipStreamWaitEvent(inv, ev(kb, EV_REST), 0));
-        RC(inverse_step(m, w, Wk(kb), k0, k1, P + (int64_t)k1 * MOGP_TILE * FZ_KD, inv, kb == nouter - 1 ? w_ready : nullptr));
+        RC(inverse_step(m, w, Wk(kb), k0, k1, P + (int64_t)k1 * MOGP_TILE * FZ_KD, inv, acc, ev(kb, EV_WROW), kb == nouter - 1 ? w_ready : nullptr));
         HIP_TRY(hipEventRecord(ev(kb, EV_INV), inv));
+        HIP_TRY(hipEventRecord(ev(kb, EV_ACC), acc));
     }
     HIP_TRY(hipEventRecord(ev(nouter - 1, EV_DIAG), bulk));                              // reuse: everything on the bulk stream
     HIP_TRY(hipStreamWaitEvent(crit, ev(nouter - 1, EV_BLK), 0));
@@ -236,7 +244,8 @@ int spd_potri_fused(mogp_model* m, Spd& w) {
     // W is complete one step before the inverse: the caller's W y / W^T z run next to the last accumulate of the inverse and
     // spd_potri_fused_finish() joins the inverse stream afterwards
     HIP_TRY(hipStreamWaitEvent(crit, w_ready, 0));
-    w.fused_last_inv = ev(nouter - 1, EV_INV);
+    w.fused_last_inv = ev(nouter - 1, EV_ACC);
+    w.fused_last_wt = ev(nouter - 1, EV_INV);
     if (std::getenv("MOGP_DEBUG_HOST")) {
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count();
         fprintf(stderr, "spd_potri_fused: host enqueue %.0f us, %d outer blocks\n", us, nouter);
@@ -248,6 +257,7 @@ int spd_potri_fused(mogp_model* m, Spd& w) {
 // the inverse (w.B) is complete on the critical stream after this
 int spd_potri_fused_finish(mogp_model* m, Spd& w) {
     if (w.fused_last_inv) HIP_TRY(hipStreamWaitEvent(m->st, w.fused_last_inv, 0));
+    if (w.fused_last_wt) HIP_TRY(hipStreamWaitEvent(m->st, w.fused_last_wt, 0));
     return 0;
 }
 
