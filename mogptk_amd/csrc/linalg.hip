@@ -35,8 +35,15 @@ template <int WTM, int WTN> struct GemmCfg {
 // C(TMR x TNC tile) = alpha * sum_k A[i,k] B[j,k] + beta * C on v_mfma_f64_16x16x4_f64.
 // <4,4>: 128x128 tiles (throughput shape).  <2,4> / <2,2>: 64x128 / 64x64 tiles for the latency-bound launches of the
 // Cholesky chain (more workgroups, less MFMA work each); 64x128 keeps the panel solve in place (a workgroup owns its rows).
+#ifdef GEMM_TIMING
+__device__ unsigned long long g_gemm_tim[8 * 8192];       // per workgroup: entry, loop start, loop end, exit (wall clock, 100 MHz), HW_ID, XCC_ID
+#define GEMM_STAMP(i) do { if (threadIdx.x == 0) g_gemm_tim[8 * blockIdx.x + (i)] = wall_clock64(); } while (0)
+#else
+#define GEMM_STAMP(i)
+#endif
 template <int AKM, int BKM, int WTM, int WTN>
 __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
+    GEMM_STAMP(0);
     using Cfg = GemmCfg<WTM, WTN>;
     constexpr int TMR = Cfg::TMR, TNC = Cfg::TNC, COLK_A = Cfg::COLK_A, COLK_B = Cfg::COLK_B;
     constexpr int OPER_A = Cfg::OPER_A, OPER_B = Cfg::OPER_B, EPT_A = Cfg::EPT_A, EPT_B = Cfg::EPT_B;
@@ -90,6 +97,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
         Cp = g.C + (int64_t)ti * TMR * g.ldc + (int64_t)tj * TNC + (int64_t)ks * g.c_split;
     }
 
+#ifdef GEMM_TIMING
+    if (kt >= 0) GEMM_STAMP(6);              // the kernel arguments have arrived
+#endif
     // ---- global -> register staging map: EPT doubles (16-byte loads) per thread per operand ----
     // k-contiguous operand: thread -> (row = tid / TPR, EPT k's);  k-major operand: thread -> (k row = tid / 16, EPT i's)
     const int64_t a_g = AKM ? (int64_t)(tid >> 4) * g.lda + (tid & 15) * EPT_A : (int64_t)(tid / TPR_A) * g.lda + (tid % TPR_A) * EPT_A;
@@ -117,6 +127,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
 #pragma unroll
             for (int n = 0; n < WTN; ++n) acc[m][n] = (d4_t){0.0, 0.0, 0.0, 0.0};
     }
+#ifdef GEMM_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GEMM_STAMP(7);                           // C has arrived
+#endif
     if (WTM < 4) __builtin_amdgcn_s_setprio(2);      // chain (latency-bound) variants outrank co-resident bulk waves
 
     d2_t ra[NQ_A], rb[NQ_B];
@@ -134,49 +148,78 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     constexpr int fa_m = AKM ? 16 : 16 * LDS_ROWK, fa_k = AKM ? 4 * COLK_A : 4;
     constexpr int fb_n = BKM ? 16 : 16 * LDS_ROWK, fb_k = BKM ? 4 * COLK_B : 4;
 
-    for (int kb = 0; kb < kt; ++kb) {
-        double* sa = gemm_lds + (kb & 1) * (OPER_A + OPER_B);
+    // ---- k loop, software pipelined so that nothing but the MFMAs sits on the issue path of a wave:
+    //   * fragments are read one k4 step ahead (two register sets), the first step of a block right behind the barrier of the block before
+    //     it and under that block's last 16 MFMAs;
+    //   * block kb + 1 goes registers -> LDS in the MIDDLE of block kb (its loads were issued a whole block earlier), followed at once by
+    //     the global loads of block kb + 2: the ds_write latency and the barrier skew hide under the third MFMA group;
+    //   * the barrier waits for LDS traffic only (lgkmcnt) -- __syncthreads() would also drain the global loads just issued.
+    // Before: write, barrier, first fragment read were exposed in every block (a lone workgroup on a CU reached 0.79 of the MFMA rate).
+    auto load_block = [&](int kb) {
+        const d2_t* pa = reinterpret_cast<const d2_t*>(Ap + a_g + (int64_t)kb * a_step);
+        const d2_t* pb = reinterpret_cast<const d2_t*>(Bp + b_g + (int64_t)kb * b_step);
+#pragma unroll
+        for (int q = 0; q < NQ_A; ++q) ra[q] = pa[q];
+#pragma unroll
+        for (int q = 0; q < NQ_B; ++q) rb[q] = pb[q];
+    };
+    auto write_block = [&](int buf) {
+        double* sa = gemm_lds + buf * (OPER_A + OPER_B);
         double* sb = sa + OPER_A;
 #pragma unroll
         for (int q = 0; q < NQ_A; ++q) *reinterpret_cast<d2_t*>(sa + a_l + 2 * q) = ra[q];
 #pragma unroll
         for (int q = 0; q < NQ_B; ++q) *reinterpret_cast<d2_t*>(sb + b_l + 2 * q) = rb[q];
-#if !defined(GEMM_EXP) || GEMM_EXP < 2
-        __syncthreads();
-#endif
-#if defined(GEMM_EXP) && GEMM_EXP >= 1
-        if (false) {
-#else
-        if (kb + 1 < kt) {
-#endif
-            const d2_t* pa = reinterpret_cast<const d2_t*>(Ap + a_g + (int64_t)(kb + 1) * a_step);
-            const d2_t* pb = reinterpret_cast<const d2_t*>(Bp + b_g + (int64_t)(kb + 1) * b_step);
+    };
+    auto read_frag = [&](double (&av)[WTM], double (&bv)[WTN], int buf, int k4) {
+        const double* sa = gemm_lds + buf * (OPER_A + OPER_B);
+        const double* sb = sa + OPER_A;
 #pragma unroll
-            for (int q = 0; q < NQ_A; ++q) ra[q] = pa[q];
+        for (int m = 0; m < WTM; ++m) av[m] = sa[fa + m * fa_m + k4 * fa_k];
 #pragma unroll
-            for (int q = 0; q < NQ_B; ++q) rb[q] = pb[q];
-        }
+        for (int n = 0; n < WTN; ++n) bv[n] = sb[fb + n * fb_n + k4 * fb_k];
+    };
+    auto mma = [&](const double (&av)[WTM], const double (&bv)[WTN]) {
 #pragma unroll
-        for (int k4 = 0; k4 < GEMM_BK / 4; ++k4) {
-            double av[WTM], bv[WTN];
-#if defined(GEMM_EXP) && GEMM_EXP >= 3
+        for (int m = 0; m < WTM; ++m)
 #pragma unroll
-            for (int m = 0; m < WTM; ++m) av[m] = ra[0][0] + m + k4;
-#pragma unroll
-            for (int n = 0; n < WTN; ++n) bv[n] = rb[0][1] + n;
-#else
-#pragma unroll
-            for (int m = 0; m < WTM; ++m) av[m] = sa[fa + m * fa_m + k4 * fa_k];
-#pragma unroll
-            for (int n = 0; n < WTN; ++n) bv[n] = sb[fb + n * fb_n + k4 * fb_k];
-#endif
-#pragma unroll
-            for (int m = 0; m < WTM; ++m)
-#pragma unroll
-                for (int n = 0; n < WTN; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < WTN; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[n], acc[m][n], 0, 0, 0);
+    };
+#define GEMM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    static_assert(GEMM_BK == 16, "the pipeline below is written for four k4 steps per block");
+    if (kt > 0) {
+        write_block(0);
+        load_block(min(1, kt - 1));
+        GEMM_LDS_BARRIER();
+        GEMM_STAMP(1);
+        double a0[WTM], b0[WTN], a1[WTM], b1[WTN];
+        read_frag(a0, b0, 0, 0);
+        for (int kb = 0; kb < kt; ++kb) {
+            const int buf = kb & 1;
+            read_frag(a1, b1, buf, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frag(a0, b0, buf, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            write_block(buf ^ 1);                      // unconditional (the last block rewrites what nobody reads; its loads are clamped):
+            load_block(min(kb + 2, kt - 1));           // the compiler then counts the LDS queue exactly and waits for the fragments only
+            read_frag(a1, b1, buf, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            GEMM_LDS_BARRIER();
+            read_frag(a0, b0, buf ^ 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+#undef GEMM_LDS_BARRIER
+    GEMM_STAMP(2);
 
     // ---- epilogue: C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg ----
 #pragma unroll
@@ -186,6 +229,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 Cp[(int64_t)(crow + m * 16 + 4 * r) * g.ldc + ccol + n * 16] = g.alpha * acc[m][n][r];
+#ifdef GEMM_TIMING
+    __builtin_amdgcn_s_waitcnt(0);          // the stores are acknowledged
+    GEMM_STAMP(3);
+    if (threadIdx.x == 0) { g_gemm_tim[8 * blockIdx.x + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4); g_gemm_tim[8 * blockIdx.x + 5] = __builtin_amdgcn_s_getreg((3 << 11) | 20); }
+#endif
 }
 
 template <int AKM, int BKM, int WTM, int WTN>

@@ -23,13 +23,13 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, A, (size_t)n * n, 1e-3);
     hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, C, (size_t)n * n, 1.0);
     CK(hipDeviceSynchronize());
-#ifdef GEMM_EXP
-    printf("GEMM_EXP %d\n", GEMM_EXP);
-    for (int nt : {8, 16, 32, 64})  {
+    {
+    for (int nt : {8, 16, 32, 64, 65})  {
         GemmArgs g{};
         g.A = A; g.lda = K; g.a_kmajor = 0; g.B = A; g.ldb = K; g.b_kmajor = 0;
         g.C = C; g.ldc = n; g.alpha = -1.0; g.beta = 1.0; g.mode = GM_RECT; g.mt = 32; g.nt = nt; g.K = K;
         if (nt == 8) g.mt = 31;
+        if (nt == 65) { g.nt = 64; g.beta = 0.0; printf("beta = 0: "); }
         const float ms = timeit(g, 10);
         printf("rect %dx%d tiles %d : %8.1f us %6.1f TF\n", g.mt, nt, g.mt * nt, ms * 1e3, gemm_flops(g, nullptr) / ms / 1e9);
     }
@@ -43,8 +43,7 @@ int main(int argc, char** argv) {
         ms = timeit(g, 5);
         printf("rect 16x32 K=4096 tiles 512 : %8.1f us %6.1f TF\n", ms * 1e3, gemm_flops(g, nullptr) / ms / 1e9);
     }
-    return 0;
-#endif
+    }
     const int mts[] = {64, 60, 48, 32, 22, 16};
     for (int layout = 0; layout < 2; ++layout)
         for (int mt : mts)
