@@ -20,6 +20,7 @@
 #include "mogp_internal.h"
 
 #include <algorithm>
+#include <vector>
 #include <cstdlib>
 
 namespace mogp {
@@ -491,6 +492,193 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a, int ntiles) {
     }
 }
 
+// ---- strip kernel: D = 1, no envelope, runs of full interior tiles ---------------------------------------------------------------
+// The general kernel above pays two dependent global round trips per tile (descriptor -> inputs and phase factors) or, software
+// pipelined, the registers to hide them (it spills).  Training data are channel-sorted series: almost every tile is a full 64 x 64
+// interior tile, and consecutive tiles of the list share their 64 rows.  One workgroup takes a RUN of such tiles: the rows' inputs and
+// phase factors are read once, the next tile's 64 columns (input + 2 T phase factors: at most five doubles per thread) are fetched under
+// the current tile's arithmetic, and the tile-centred factors are staged from LDS.  Same arithmetic as the general kernel, term by term.
+// TC = terms a launch may carry (LDS is sized by it); raw rows of a block of 64 points: x | cos_t | sin_t.  Two workgroups per CU: the
+// arithmetic needs ~200 VGPRs, and three or four waves per SIMD bought with spills ran 1.3x / 2x slower.
+#define GS_TC_MAX 8
+template <int TC>
+struct StripLds {
+    static constexpr int RAW = 1 + 2 * TC, PF = (RAW * MOGP_GT + 255) / 256;      // PF: prefetch registers per thread
+    double rowraw[RAW][MOGP_GT];
+    double colraw[2][RAW][MOGP_GT];
+    double cu[TC][MOGP_GT], su[TC][MOGP_GT], cw[TC][MOGP_GT], sw[TC][MOGP_GT];
+    double tab[TC][3];                            // A, V, Delta of the pair's terms
+    double V[TC], s[TC];
+    int deg[TC];
+};
+
+template <int N>
+__device__ __forceinline__ void strip_term(double (&acc)[4][4], const double (&p)[4], const double (&q)[4], double V, double s,
+                                           const double (&cu)[4], const double (&su)[4], const double (&cw)[4], const double (&sw)[4]) {
+    double vp[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) vp[m] = V * p[m];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        if (m == 2) __builtin_amdgcn_sched_barrier(0);      // two groups of eight independent Horner chains (see gram_term)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            double e;
+            if (N > 0) {
+                e = exp_taylor<N>(vp[m] * q[n]);
+            } else {
+                const double u = (p[m] - q[n]) + s;
+                e = fast_exp(fmax(-0.5 * (V * u) * u, -745.0));
+            }
+            acc[m][n] = fma(e, fma(cu[m], cw[n], su[m] * sw[n]), acc[m][n]);
+        }
+    }
+}
+
+template <int TC>
+__global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* __restrict__ segs) {
+    constexpr int GS_TC = TC, GS_PF = StripLds<TC>::PF;
+    __shared__ StripLds<TC> L;
+    const int tid = threadIdx.x, cg = tid & 15, rg = tid >> 4;
+    const GSeg sg = segs[blockIdx.x];
+    const int T = a.T, W = a.W;
+    const int ci = sg.pair / a.C, cj = sg.pair - ci * a.C;
+    const PhaseView v = phase_view(a.ph.ws, a.C, T, 1, a.ldxr, a.ldxc);
+    const double* __restrict__ tab = a.table + (size_t)sg.pair * T * W;
+    const int nraw = (1 + 2 * T) * MOGP_GT;
+    // raw row k of a block of points: 0 = input, 1 .. T = cos of term k - 1, T + 1 .. 2 T = sin of term k - 1 - T; LDS slot of row k
+    auto slot = [&](int k) { return k <= T ? k : k - T + GS_TC; };
+
+    for (int e = tid; e < nraw; e += 256) {               // the row block, once per run (rows take the table of the COLUMN channel)
+        const int k = e >> 6, pnt = e & 63;
+        const int64_t gp = sg.r0 + pnt;
+        double val;
+        if (k == 0) val = a.xr[gp];
+        else if (k <= T) val = v.rcs[((size_t)cj * T + (k - 1)) * a.ldxr + gp];
+        else val = v.rsn[((size_t)cj * T + (k - 1 - T)) * a.ldxr + gp];
+        L.rowraw[slot(k)][pnt] = val;
+    }
+    if (tid < 3 * T) { const int t = tid / 3, k = tid - 3 * t; L.tab[t][k] = tab[(size_t)t * W + (k == 0 ? 0 : 2 * k)]; }      // columns 0, 2, 4
+    const double cr = v.rcen[sg.r0], hr = v.rhalf[sg.r0];
+    double pf[GS_PF], cc_n, hc_n;
+    auto col_fetch = [&](int c0) {                        // columns take the table of the ROW channel
+#pragma unroll
+        for (int k5 = 0; k5 < GS_PF; ++k5) {
+            const int e = tid + 256 * k5;
+            if (e < nraw) {
+                const int k = e >> 6, pnt = e & 63;
+                const int64_t gp = c0 + pnt;
+                if (k == 0) pf[k5] = a.xc[gp];
+                else if (k <= T) pf[k5] = v.ccs[((size_t)ci * T + (k - 1)) * a.ldxc + gp];
+                else pf[k5] = v.csn[((size_t)ci * T + (k - 1 - T)) * a.ldxc + gp];
+            }
+        }
+        cc_n = v.ccen[c0]; hc_n = v.chalf[c0];
+    };
+    // gfx9 counts loads and stores in ONE counter and the compiler, seeing both kinds pending, waits for all of them (vmcnt(0)): the next
+    // tile's columns go to LDS BEFORE the current tile is stored, so that wait never includes a store just issued.
+    auto col_commit = [&](int b) {
+#pragma unroll
+        for (int k5 = 0; k5 < GS_PF; ++k5) {
+            const int e = tid + 256 * k5;
+            if (e < nraw) L.colraw[b][slot(e >> 6)][e & 63] = pf[k5];
+        }
+    };
+    col_fetch(sg.c0);
+    col_commit(0);
+    double cc = cc_n, hc = hc_n;
+    __syncthreads();
+    if (sg.n > 1) col_fetch(sg.c0 + MOGP_GT);
+    double p[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) p[m] = L.rowraw[0][rg * 4 + m] - cr;
+
+    for (int u = 0; u < sg.n; ++u) {
+        const int b = u & 1, c0 = sg.c0 + u * MOGP_GT;
+        // ---- stage the tile-centred factors: (rows | columns) x term x point ----
+        for (int e = tid; e < 2 * T * MOGP_GT; e += 256) {
+            const int which = e >= T * MOGP_GT, rem = e - which * T * MOGP_GT, t = rem >> 6, pnt = rem & 63;
+            const double A = L.tab[t][0], V = L.tab[t][1], s = (cr - cc) + L.tab[t][2];
+            const double zmax = fabs(V) * hr * hc, es = V * s * s;
+            const double mu = fmax(0.0, fabs(s) - hr - hc), emin = V * mu * mu;
+            const double efac = fabs(V) * (hr * hr + hc * hc + 2.0 * (hr + hc) * fabs(s));
+            int deg;
+            if (A == 0.0 || 0.5 * emin > GT_SKIP_EXPONENT) deg = GT_SKIP;
+            else if (!(zmax <= 0.45) || !(0.5 * es < 600.0) || !(0.5 * efac < 600.0)) deg = GT_GENERAL;
+            else deg = zmax <= 1.19e-3 ? 4 : (zmax <= 0.0139 ? 6 : (zmax <= 0.0578 ? 8 : (zmax <= 0.2147 ? 11 : 14)));
+            if (pnt == 0 && which == 0) { L.deg[t] = deg; L.V[t] = V; L.s[t] = s; }
+            if (deg == GT_SKIP) continue;
+            double f = 1.0;
+            if (a.dbg & 4) { L.cu[t][pnt] = 1.0; L.su[t][pnt] = 0.5; L.cw[t][pnt] = 0.25; L.sw[t][pnt] = 2.0; continue; }
+            if (which == 0) {
+                if (deg != GT_GENERAL) {
+                    const double pp = L.rowraw[0][pnt] - cr;
+                    f = fast_exp(-0.5 * (V * (fma(pp, pp, s * s) + 2.0 * pp * s)));
+                }
+                f *= A;
+                L.cu[t][pnt] = f * L.rowraw[1 + t][pnt]; L.su[t][pnt] = f * L.rowraw[1 + GS_TC + t][pnt];
+            } else {
+                if (deg != GT_GENERAL) {
+                    const double qq = L.colraw[b][0][pnt] - cc;
+                    f = fast_exp(-0.5 * (V * (qq * qq - 2.0 * qq * s)));
+                }
+                L.cw[t][pnt] = f * L.colraw[b][1 + t][pnt]; L.sw[t][pnt] = f * L.colraw[b][1 + GS_TC + t][pnt];
+            }
+        }
+        __syncthreads();
+        double q[4], acc[4][4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) q[n] = L.colraw[b][0][cg * 4 + n] - cc;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = 0.0;
+        for (int t = 0; t < T; ++t) {
+            const int deg = __builtin_amdgcn_readfirstlane(L.deg[t]);
+            if (deg == GT_SKIP || (a.dbg & 2)) continue;
+            const double V = L.V[t], s = L.s[t];
+            double cu[4], su[4], cw[4], sw[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                cu[m] = L.cu[t][rg * 4 + m]; su[m] = L.su[t][rg * 4 + m];
+                cw[m] = L.cw[t][cg * 4 + m]; sw[m] = L.sw[t][cg * 4 + m];
+            }
+            switch (deg) {
+                case 4: strip_term<4>(acc, p, q, V, s, cu, su, cw, sw); break;
+                case 6: strip_term<6>(acc, p, q, V, s, cu, su, cw, sw); break;
+                case 8: strip_term<8>(acc, p, q, V, s, cu, su, cw, sw); break;
+                case 11: strip_term<11>(acc, p, q, V, s, cu, su, cw, sw); break;
+                case 14: strip_term<14>(acc, p, q, V, s, cu, su, cw, sw); break;
+                default: strip_term<0>(acc, p, q, V, s, cu, su, cw, sw); break;
+            }
+        }
+        if (u + 1 < sg.n) { col_commit(b ^ 1); cc = cc_n; hc = hc_n; }
+        if (!((a.dbg & 1) && acc[0][0] != 12345.678)) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                double* o = a.out + (int64_t)(sg.r0 + rg * 4 + m) * a.ldo + c0 + cg * 4;
+                *reinterpret_cast<d2_t*>(o) = (d2_t){acc[m][0], acc[m][1]};
+                *reinterpret_cast<d2_t*>(o + 2) = (d2_t){acc[m][2], acc[m][3]};
+            }
+        }
+        __syncthreads();                                   // the next tile's columns are in LDS; this tile's factors are consumed
+        if (u + 2 < sg.n) col_fetch(c0 + 2 * MOGP_GT);
+    }
+}
+
+void split_strip_tiles(const std::vector<GTile>& tiles, int maxrun, std::vector<GSeg>& segs, std::vector<GTile>& rest) {
+    segs.clear(); rest.clear();
+    for (const GTile& t : tiles) {
+        const bool fast = t.nr == MOGP_GT && t.nc == MOGP_GT && !(t.flags & GT_DIAG) && (t.c0 & 1) == 0;
+        if (!fast) { rest.push_back(t); continue; }
+        if (!segs.empty()) {
+            GSeg& g = segs.back();
+            if (g.pair == t.pair && g.r0 == t.r0 && g.c0 + g.n * MOGP_GT == t.c0 && g.n < maxrun) { ++g.n; continue; }
+        }
+        segs.push_back(GSeg{t.r0, t.c0, 1, t.pair});
+    }
+}
+
 int launch_gram(const GramArgs& a0, int ntiles, hipStream_t s) {
     if (ntiles <= 0) return 0;
     GramArgs a = a0;
@@ -505,6 +693,18 @@ int launch_gram(const GramArgs& a0, int ntiles, hipStream_t s) {
     a.tab_lds = tab_bytes <= 24 * 1024;                      // the term table rides in LDS when small (it is read by every staging item)
     const size_t dyn = a.tab_lds ? tab_bytes : 0;
     if (a.ev0) HIP_TRY(hipEventRecord(a.ev0, s));
+    static const bool strip_on = !(std::getenv("MOGP_GRAM_STRIP") && std::atoi(std::getenv("MOGP_GRAM_STRIP")) == 0);
+    if (strip_on && a.segs && a.nsegs > 0 && a.D == 1 && a.W == 5 && a.T <= GS_TC_MAX && !a.mirror && (a.ldo & 1) == 0) {
+        if (a.T <= 4) hipLaunchKernelGGL(k_gram_strip<4>, dim3(a.nsegs), dim3(256), 0, s, a, a.segs);
+        else hipLaunchKernelGGL(k_gram_strip<8>, dim3(a.nsegs), dim3(256), 0, s, a, a.segs);
+        if (a.nrest > 0) {
+            a.tiles = a.rest;
+            hipLaunchKernelGGL(k_gram<1>, dim3(std::min(a.nrest, 2 * ncu)), dim3(256), dyn, s, a, a.nrest);
+        }
+        if (a.ev1) HIP_TRY(hipEventRecord(a.ev1, s));
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     switch (a.D) {
         case 1: hipLaunchKernelGGL(k_gram<1>, dim3(grid), dim3(256), dyn, s, a, ntiles); break;
         case 2: hipLaunchKernelGGL(k_gram<2>, dim3(grid), dim3(256), dyn, s, a, ntiles); break;

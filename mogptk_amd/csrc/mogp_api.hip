@@ -95,6 +95,17 @@ void build_rect_tiles(const std::vector<int>& offr, const std::vector<int>& offc
 
 using namespace mogp;
 
+int StripTiles::build(const std::vector<GTile>& tiles) {
+    static const int maxrun = []() { const char* e = std::getenv("MOGP_STRIP_RUN"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 4; }();
+    split_strip_tiles(tiles, maxrun, segs, rest);
+    int rc;
+    if ((rc = d_segs.ensure(std::max<size_t>(segs.size(), 1)))) return rc;
+    if ((rc = d_rest.ensure(std::max<size_t>(rest.size(), 1)))) return rc;
+    if (!segs.empty()) HIP_TRY(hipMemcpy(d_segs.p, segs.data(), segs.size() * sizeof(GSeg), hipMemcpyHostToDevice));
+    if (!rest.empty()) HIP_TRY(hipMemcpy(d_rest.p, rest.data(), rest.size() * sizeof(GTile), hipMemcpyHostToDevice));
+    return 0;
+}
+
 static int g_outer = 4;    // outer Cholesky block in tiles (x128 columns); MOGP_OUTER env var overrides (tuning)
 #define MOGP_OUTER g_outer
 
@@ -408,6 +419,7 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     ga.out = m->k.A.p; ga.ldo = Npad; ga.noise = m->d_noise.p; ga.dvar = data_var ? m->d_dvar.p : nullptr;
     ga.jitter_abs = jabs; ga.mirror = 0;
     ga.ev0 = prof_event(m, 7); ga.ev1 = prof_event(m, 8);
+    m->strip.attach(ga);
     if ((rc = launch_gram(ga, (int)m->tiles.size(), m->st))) return rc;
     ga.ev0 = ga.ev1 = nullptr;
     if ((rc = launch_pad_identity(m->k.A.p, Npad, N, Npad, m->st))) return rc;
@@ -525,6 +537,7 @@ static int sweep_eval_begin(mogp_model* m, const double* noise_var, const double
     ga.jitter_abs = m->sh_jabs; ga.mirror = 0;
     const bool own = m->sh_n > 1 && m->own_n == m->sh_n && m->own_rank == m->sh_rank;
     if (own) ga.tiles = m->d_tiles_own.p;
+    (own ? m->strip_own : m->strip).attach(ga);
     if ((rc = launch_gram(ga, (int)(own ? m->tiles_own.size() : m->tiles.size()), m->st))) return rc;
     if ((rc = launch_pad_identity(m->k.A.p, Npad, N, Npad, m->st))) return rc;
     if ((rc = mark(m, 1))) return rc;
@@ -689,6 +702,7 @@ int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, c
     TRY_RC(m->d_chan_off.ensure(C + 1));
     TRY_HIP(hipMemcpy(m->d_x.p, m->sx.xs.data(), (size_t)D * Npad * sizeof(double), hipMemcpyHostToDevice));
     TRY_HIP(hipMemcpy(m->d_tiles.p, m->tiles.data(), m->tiles.size() * sizeof(GTile), hipMemcpyHostToDevice));
+    TRY_RC(m->strip.build(m->tiles));
     TRY_HIP(hipMemcpy(m->d_pair_start.p, m->pair_start.data(), m->pair_start.size() * sizeof(int), hipMemcpyHostToDevice));
     TRY_HIP(hipMemcpy(m->d_chan_off.p, m->sx.off.data(), (C + 1) * sizeof(int), hipMemcpyHostToDevice));
     TRY_RC(mogp_model_set_y(m, y));
@@ -712,7 +726,7 @@ int mogp_model_destroy(mogp_model* m) {
     if (m->tw) { m->tw->release(); delete m->tw; m->tw = nullptr; }
     m->d_x.release(); m->d_y.release(); m->d_table.release();
     m->d_noise.release(); m->d_dvar.release(); m->d_z.release(); m->d_alpha.release(); m->d_zz.release();
-    m->d_partial.release(); m->d_moments.release(); m->d_diagG.release(); m->d_tiles.release(); m->d_pair_start.release();
+    m->d_partial.release(); m->d_moments.release(); m->d_diagG.release(); m->d_tiles.release(); m->d_pair_start.release(); m->strip.release(); m->strip_own.release();
     m->d_chan_off.release(); m->d_flag.release(); m->d_info.release();
     m->d_xs.release(); m->d_Ksf.release(); m->d_Vt.release(); m->d_mu.release(); m->d_var.release(); m->d_kdiag.release();
     m->d_Kss.release(); m->d_ptiles.release();
@@ -987,6 +1001,7 @@ int mogp_shard_config(mogp_model* m, int rank, int nranks) {
         if ((rc = m->d_tiles_own.ensure(std::max<size_t>(m->tiles_own.size(), 1)))) return rc;
         if ((rc = m->d_pair_start_own.ensure(m->pair_start_own.size()))) return rc;
         HIP_TRY(hipMemcpy(m->d_tiles_own.p, m->tiles_own.data(), m->tiles_own.size() * sizeof(GTile), hipMemcpyHostToDevice));
+        if ((rc = m->strip_own.build(m->tiles_own))) return rc;
         HIP_TRY(hipMemcpy(m->d_pair_start_own.p, m->pair_start_own.data(), m->pair_start_own.size() * sizeof(int), hipMemcpyHostToDevice));
         m->own_rank = rank; m->own_n = nranks;
     }

@@ -29,6 +29,8 @@ struct GTile {
     int pair;        // i*C + j : row channel i, column channel j
     int flags;       // GT_* bits
 };
+// a run of n consecutive FULL interior tiles of one row block: columns c0, c0 + 64, ... (the strip kernel of gram.hip)
+struct GSeg { int r0, c0, n, pair; };
 enum { GT_MIRROR = 1,     // also write the transpose to (c, r)   (off-diagonal tile of the symmetric Gram)
        GT_DIAG = 2 };     // tile sits on the matrix diagonal (r0 == c0)
 
@@ -60,6 +62,8 @@ struct GramArgs {
     double jitter_abs;
     int mirror;            // write the transpose of GT_MIRROR tiles too (full symmetric Gram for Kernel.K)
     hipEvent_t ev0, ev1;   // when non-null: recorded around the tile kernel alone (profiling)
+    const GSeg* segs; int nsegs;      // optional split of `tiles`: runs of full interior tiles (strip kernel: D = 1, no envelope, no mirror) ...
+    const GTile* rest; int nrest;     // ... and everything else (diagonal, ragged and odd-aligned tiles) for the general kernel
     int dbg;               // measurement only (MOGP_GRAM_DBG): 1 = no stores, 2 = no terms (stores only)
     int tab_lds;           // set by the launcher: the term table is copied to LDS
 };
@@ -100,6 +104,8 @@ struct MomentArgs {
 };
 
 int launch_gram(const GramArgs& a, int ntiles, hipStream_t s);
+// split a tile list into runs of at most `maxrun` full interior tiles (same pair and row block, consecutive columns) and the rest
+void split_strip_tiles(const std::vector<GTile>& tiles, int maxrun, std::vector<GSeg>& segs, std::vector<GTile>& rest);
 int launch_moments(const MomentArgs& a, hipStream_t s);
 // moments[P][T][W] += fixed-order sum of per-tile partials; tile_pair_lower[t] = p index, tiles grouped by pair
 int launch_moment_reduce(const double* partial, const int* pair_start, int npairs, int T, int W, int D, double* out, hipStream_t s,

@@ -141,6 +141,17 @@ struct TitsiasWork {
     }
 };
 
+// a tile list split into runs of full interior tiles (strip kernel) and the rest; see split_strip_tiles
+struct StripTiles {
+    std::vector<mogp::GSeg> segs;
+    std::vector<mogp::GTile> rest;
+    mogp::DevBuf<mogp::GSeg> d_segs;
+    mogp::DevBuf<mogp::GTile> d_rest;
+    int build(const std::vector<mogp::GTile>& tiles);      // host split + upload
+    void attach(mogp::GramArgs& ga) const { ga.segs = d_segs.p; ga.nsegs = (int)segs.size(); ga.rest = d_rest.p; ga.nrest = (int)rest.size(); }
+    void release() { d_segs.release(); d_rest.release(); }
+};
+
 struct mogp_model {
     mogp_ctx* ctx = nullptr;
     int64_t N = 0, Npad = 0;
@@ -165,6 +176,7 @@ struct mogp_model {
     std::vector<GTile> tiles_own;       // the Gram / moment tiles that touch an owned tile row (grouped by pair like `tiles`)
     std::vector<int> pair_start_own;
     DevBuf<GTile> d_tiles_own;
+    StripTiles strip, strip_own;        // the same tile lists (all / owned) split for the Gram strip kernel
     DevBuf<int> d_pair_start_own;
     int own_rank = -1, own_n = 0;       // (rank, nranks) the owned lists were built for
     DevBuf<double> sh_send, sh_recv;

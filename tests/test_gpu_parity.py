@@ -60,10 +60,12 @@ def test_lml_and_gradient_match_reference_autograd(name):
             assert np.max(np.abs(p.grad - f["grad"])) <= 1e-7 * max(1.0, np.max(np.abs(f["grad"]))), (p._name, p.grad, f["grad"])
 
 
-@pytest.mark.parametrize("N,C,Q,D", [(300, 3, 2, 1), (517, 4, 3, 1), (260, 2, 9, 1), (200, 3, 2, 2), (129, 1, 2, 1), (1350, 3, 2, 1), (2900, 4, 1, 1)])
-def test_device_raw_outputs_against_numpy_model(N, C, Q, D):
+@pytest.mark.parametrize("N,C,Q,D,vmax", [(300, 3, 2, 1, 0.05), (517, 4, 3, 1, 0.05), (260, 2, 9, 1, 0.05), (200, 3, 2, 2, 0.05), (129, 1, 2, 1, 0.05),
+                                          (1350, 3, 2, 1, 0.05), (2900, 4, 1, 1, 0.05), (1500, 2, 6, 1, 0.05), (1100, 2, 2, 1, 3.0)])
+def test_device_raw_outputs_against_numpy_model(N, C, Q, D, vmax):
     """moments / diagG / trG / alpha / L^-1 / K^-1 of the device against the numpy restatement: ragged channel sizes,
-    N not a multiple of the 128 tile, more terms than one LDS chunk (Q=9), D=2."""
+    N not a multiple of the 128 tile, more terms than one LDS chunk (Q=9), D=2; runs of full interior tiles (the Gram strip kernel) with
+    up to four terms, with six, and with spectral variances so large that tiles take the exp-per-entry path (vmax = 3)."""
     rng = np.random.default_rng(N)
     sizes = rng.multinomial(N - C, np.ones(C) / C) + 1
     X = np.concatenate([np.concatenate([np.full((s, 1), float(c)), rng.uniform(0, 30, (s, D))], axis=1) for c, s in enumerate(sizes)])
@@ -71,7 +73,7 @@ def test_device_raw_outputs_against_numpy_model(N, C, Q, D):
     y = rng.standard_normal(N)
     k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=D)
     k.weight.assign(rng.uniform(0.5, 1.5, (C, Q))); k.mean.assign(rng.uniform(0.02, 0.4, (C, Q, D)))
-    k.variance.assign(rng.uniform(0.005, 0.05, (C, Q, D))); k.delay.assign(rng.normal(0, 0.3, (C, Q, D)))
+    k.variance.assign(rng.uniform(0.1 * vmax, vmax, (C, Q, D))); k.delay.assign(rng.normal(0, 0.3, (C, Q, D)))
     k.phase.assign(rng.normal(0, 0.3, (C, Q)))
     table = k._spectral_terms(D)
     noise = rng.uniform(0.05, 0.2, C)
