@@ -31,6 +31,16 @@ def _to_array(X):
     return np.array(X, dtype=config.dtype)
 
 
+_PAIR_INDEX = {}
+
+
+def _pair_index(C, lower):
+    key = (C, lower)
+    if key not in _PAIR_INDEX:
+        _PAIR_INDEX[key] = np.tril_indices(C) if lower else tuple(np.divmod(np.arange(C * C), C))
+    return _PAIR_INDEX[key]
+
+
 def _gtable_from_moments(table, mom, D, lower=True):
     """d(objective)/d(term table) from the device's gradient moments [m0, m4, m1_d, m2_d, m3_d]:
     dA = m0, dPsi = -2 pi A m4, dV_d = -1/2 A m1_d, dM_d = -2 pi A m3_d, dDelta_d = -V_d A m2_d - 2 pi M_d A m4.
@@ -38,10 +48,7 @@ def _gtable_from_moments(table, mom, D, lower=True):
     included); lower=False: mom is indexed by all ordered pairs i*C + j (rectangular Gram)."""
     C, T = table.shape[0], table.shape[2]
     gt = np.zeros((C, C, T, table.shape[3]))
-    if lower:
-        ii, jj = np.tril_indices(C)                     # row-major lower pairs: exactly p = i(i+1)/2 + j
-    else:
-        ii, jj = np.divmod(np.arange(C * C), C)
+    ii, jj = _pair_index(C, lower)                      # lower: row-major lower pairs, exactly p = i(i+1)/2 + j
     tb = table[ii, jj]                                  # (P, T, W)
     A = tb[..., 0]
     V = tb[..., 2:2 + D]

@@ -151,21 +151,40 @@ class MultiOutputSpectralMixtureKernel(MultiOutputKernel):
         self.__dict__["_terms_memo"] = (key, table)
         return table
 
+    def _derived(self):
+        """what the term table and its chain rule share beyond _pairs(): E = exp(-pi^2 sum dmu^2 / s), V, M, sqrt(prod V) and the masks of the
+        off-diagonal channel pairs (memoised with the pairs: one evaluation builds them once)"""
+        memo = self.__dict__.get("_derived_memo")
+        pairs = self._pairs()
+        if memo is not None and memo[0] is pairs:
+            return memo[1]
+        w, mu, v, th, ph, vi, vj, mi, mj, s, inv, dmu = pairs
+        C = self.output_dims
+        E = np.exp(-PI ** 2 * np.sum(dmu * inv * dmu, axis=3))                                  # :192
+        M = inv * (vi * mj + vj * mi)                                                           # :194
+        V = 2.0 * vi * inv * vj                                                                 # :195
+        rootV = np.sqrt(np.prod(V, axis=3))
+        off2 = (1.0 - np.eye(C))[:, :, None]
+        out = (E, M, V, rootV, off2, off2[..., None])
+        self.__dict__["_derived_memo"] = (pairs, out)
+        return out
+
     def _spectral_terms_compute(self, D):
         C = self.output_dims
         w, mu, v, th, ph, vi, vj, mi, mj, s, inv, dmu = self._pairs()
+        E, M, V, rootV, off2, off3 = self._derived()
         Q = mu.shape[1]
         table = np.empty((C, C, Q, term_width(D)))
-        mag = self._magnitude(w) * np.exp(-PI ** 2 * np.sum(dmu * inv * dmu, axis=3))           # :192
-        M = inv * (vi * mj + vj * mi)                                                           # :194
-        V = 2.0 * vi * inv * vj                                                                 # :195
-        table[..., 0] = mag * self.twopi * np.sqrt(np.prod(V, axis=3)) * self._amp_scale()      # :199
+        magw = self._magnitude(w)
+        amp = self._amp_scale()
+        table[..., 0] = magw * E * (self.twopi * rootV) * amp                                   # :192, :199
         table[..., 1] = self._phase_scale * (ph[:, None] - ph[None, :])                         # :197
         table[..., 2:2 + D] = V
         table[..., 2 + D:2 + 2 * D] = M
         table[..., 2 + 2 * D:] = th[:, None] - th[None, :]                                      # :196
+        ampd = (np.asarray(amp) * np.ones((C, C, Q)))
         for c in range(C):                                                                      # i == j branch :183-187
-            table[c, c, :, 0] = self._magnitude(w)[c, c] * self.twopi * np.sqrt(np.prod(v[c], axis=1)) * (np.asarray(self._amp_scale()) * np.ones((C, C, Q)))[c, c]
+            table[c, c, :, 0] = magw[c, c] * self.twopi * np.sqrt(np.prod(v[c], axis=1)) * ampd[c, c]
             table[c, c, :, 1] = 0.0
             table[c, c, :, 2:2 + D] = v[c]
             table[c, c, :, 2 + D:2 + 2 * D] = mu[c]
@@ -178,34 +197,30 @@ class MultiOutputSpectralMixtureKernel(MultiOutputKernel):
         C = self.output_dims
         D = self.input_dims
         w, mu, v, th, ph, vi, vj, mi, mj, s, inv, dmu = self._pairs()
-        table = self._spectral_terms(D)
-        A = table[..., 0]
-        V = table[..., 2:2 + D]
-        M = table[..., 2 + D:2 + 2 * D]
+        A = self._spectral_terms(D)[..., 0]
         gA, gPsi = gtable[..., 0], gtable[..., 1]
         gV, gM, gDl = gtable[..., 2:2 + D], gtable[..., 2 + D:2 + 2 * D], gtable[..., 2 + 2 * D:2 + 3 * D]
 
-        off = ~np.eye(C, dtype=bool)
-        o2 = off[:, :, None]
-        o3 = off[:, :, None, None]
-        gAA = np.where(o2, gA * A, 0.0)                                     # (C,C,Q)
+        E, M, V, rootV, o2, o3 = self._derived()                            # o2 / o3: 1 on off-diagonal channel pairs, 0 on the diagonal
+        gAA3 = (gA * A * o2)[..., None]                                     # (C,C,Q,1)
         # d A / d magnitude = everything but the magnitude (kept explicit: a magnitude may be zero or negative for the uncoupled kernel)
-        Fm = np.exp(-PI ** 2 * np.sum(dmu * inv * dmu, axis=3)) * self.twopi * np.sqrt(np.prod(V, axis=3)) * self._amp_scale()
-        gmag = gA * Fm                                                       # gtable is zero above the diagonal already
+        gmag = gA * (E * (self.twopi * rootV) * self._amp_scale())          # gtable is zero above the diagonal already
         gw = self._magnitude_backward(w, gmag)
-        gph = self._phase_scale * (np.sum(np.where(o2, gPsi, 0.0), axis=1) - np.sum(np.where(o2, gPsi, 0.0), axis=0))
-        gDlo = np.where(o3, gDl, 0.0)
+        gPo = gPsi * o2
+        gph = self._phase_scale * (np.sum(gPo, axis=1) - np.sum(gPo, axis=0))
+        gDlo = gDl * o3
         gth = np.sum(gDlo, axis=1) - np.sum(gDlo, axis=0)
-        gMo = np.where(o3, gM, 0.0)
-        gVo = np.where(o3, gV, 0.0)
-        gAA3 = gAA[..., None]
-        dA_dmu_i = gAA3 * (-2.0 * PI ** 2 * dmu * inv)
-        gmu = np.sum(dA_dmu_i + gMo * vj * inv, axis=1) + np.sum(-dA_dmu_i + gMo * vi * inv, axis=0)
-        dVi = 2.0 * vj * vj * inv * inv
-        dVj = 2.0 * vi * vi * inv * inv
-        common = PI ** 2 * dmu * dmu * inv * inv
-        gv_i = gAA3 * (common + 0.5 * dVi / V) + gVo * dVi + gMo * (mj - M) * inv
-        gv_j = gAA3 * (common + 0.5 * dVj / V) + gVo * dVj + gMo * (mi - M) * inv
+        gMi = gM * (o3 * inv)                                               # gM / s on the off-diagonal pairs
+        gVo = gV * o3
+        inv2 = inv * inv
+        dA_dmu_i = gAA3 * (-2.0 * PI ** 2) * (dmu * inv)
+        gmu = np.sum(dA_dmu_i + gMi * vj, axis=1) + np.sum(gMi * vi - dA_dmu_i, axis=0)
+        dVi = 2.0 * (vj * vj) * inv2
+        dVj = 2.0 * (vi * vi) * inv2
+        common = gAA3 * (PI ** 2 * (dmu * dmu) * inv2)
+        half = 0.5 * gAA3 / V
+        gv_i = common + (half + gVo) * dVi + gMi * (mj - M)
+        gv_j = common + (half + gVo) * dVj + gMi * (mi - M)
         gv = np.sum(gv_i, axis=1) + np.sum(gv_j, axis=0)
         for c in range(C):                                                  # i == j blocks (their magnitude part is in gmag already)
             gv[c] += (gA[c, c] * A[c, c])[:, None] / (2.0 * v[c]) + gV[c, c]
