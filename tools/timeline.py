@@ -12,7 +12,11 @@ for r in csv.DictReader(open(src)):
     rows.append((r["Kernel_Name"].split("(")[0].replace("void ", "").replace("mogp::", ""), int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
                  int(r["Queue_Id"]), int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)))
 rows.sort(key=lambda r: r[1])
-idx = [i for i, r in enumerate(rows) if r[0].startswith("k_gram")]
+idx, last_gram = [], -10 ** 18
+for i, r in enumerate(rows):                      # an evaluation starts at its first Gram launch (the strip kernel and the general one follow each other)
+    if r[0].startswith("k_gram"):
+        if r[1] - last_gram > 1000000: idx.append(i)
+        last_gram = r[1]
 ev = rows[idx[-2]:idx[-1]] if len(idx) >= 2 else rows[idx[-1]:]
 t0 = ev[0][1]
 span = (max(r[2] for r in ev) - t0) / 1e3
