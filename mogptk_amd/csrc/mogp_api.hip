@@ -381,12 +381,14 @@ static int factorize_finish(mogp_model* m, const GramArgs& ga, double* lml, int6
 // defer: enqueue only -- the scalars travel to the pinned block asynchronously and factorize_finish() (after the caller's ONE stream sync)
 // turns them into the LML / the failure report
 static int factorize(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
-                     double* lml, double* jitter_abs, int64_t* info, bool fuse_inverse = false, bool defer = false, GramArgs* ga_out = nullptr) {
+                     double* lml, double* jitter_abs, int64_t* info, bool fuse_inverse = false, bool defer = false, GramArgs* ga_out = nullptr,
+                     bool factor_only = false) {
     const int C = m->C, D = m->D;
     const int64_t N = m->N, Npad = m->Npad;
     if (m->T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms must be called before an evaluation");
     if (!noise_var) return fail(MOGP_EINVAL, "noise_var is null");
     m->have_W = m->have_Kinv = false;
+    m->factor_only = factor_only;
     m->gemm_ev_used = 0; m->gemm_launches = 0; m->gemm_flops = 0.0;
 
     // host scalars: mean of the diagonal for the relative jitter (reference gpr/model.py:244)
@@ -428,14 +430,19 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     if ((rc = fuse_inverse ? spd_potri_fused(m, m->k) : spd_potrf(m, m->k))) return rc;
     if ((rc = mark(m, 2))) return rc;
 
-    if (!fuse_inverse && (rc = spd_trtri(m, m->k))) return rc;
+    if (!fuse_inverse && !factor_only && (rc = spd_trtri(m, m->k))) return rc;
     if ((rc = mark(m, 3))) return rc;
 
-    // ---- z = W y, alpha = W^T z
-    const double* Wp = fuse_inverse ? m->k.Wm.p : m->k.A.p;
-    m->w_in_Wm = fuse_inverse;
-    if ((rc = launch_trmv_lower(Wp, Npad, Npad, m->d_y.p, m->d_z.p, m->d_zz.p, m->st))) return rc;
-    if ((rc = launch_trmv_lower_t(Wp, Npad, Npad, m->d_z.p, m->d_alpha.p, m->st))) return rc;
+    // ---- z = W y, alpha = W^T z   (factor_only: the caller solves with L itself; the LML is not formed)
+    const int nzz_clear = (int)((Npad + 3) / 4);
+    if (factor_only) {
+        HIP_TRY(hipMemsetAsync(m->d_zz.p, 0, nzz_clear * sizeof(double), m->st));
+    } else {
+        const double* Wp = fuse_inverse ? m->k.Wm.p : m->k.A.p;
+        m->w_in_Wm = fuse_inverse;
+        if ((rc = launch_trmv_lower(Wp, Npad, Npad, m->d_y.p, m->d_z.p, m->d_zz.p, m->st))) return rc;
+        if ((rc = launch_trmv_lower_t(Wp, Npad, Npad, m->d_z.p, m->d_alpha.p, m->st))) return rc;
+    }
     if (fuse_inverse && (rc = spd_potri_fused_finish(m, m->k))) return rc;
     if ((rc = mark(m, 4))) return rc;
 
@@ -477,7 +484,7 @@ static int factorize_finish(mogp_model* m, const GramArgs& ga, double* lml, int6
     for (int i = 0; i < nb; ++i) logdet += m->h_pin[i];
     for (int i = 0; i < nzz; ++i) zz += m->h_pin[nb + i];
     if (lml) *lml = -0.5 * (double)N * std::log(2.0 * M_PI) - logdet - 0.5 * zz;
-    m->have_W = true;
+    m->have_W = !m->factor_only;
     return 0;
 }
 
@@ -841,19 +848,20 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
     int rc;
     if ((rc = use_device(m->ctx))) return rc;
     if (info) *info = 0;
-    double lml = 0.0;
-    if ((rc = factorize(m, noise_var, data_var, jitter, &lml, nullptr, info))) return rc;
+    // Cholesky factor only: the predictive equations need V = L^-1 K_fs and z = L^-1 y, never L^-1 itself (reference gpr/model.py:470-472 solves).
+    // Round 1 / 2a formed W = L^-1 (N^3/3 flop) and multiplied; here [V | z] comes from ONE blocked forward substitution, N^2 (S+1) flop.
+    if ((rc = factorize(m, noise_var, data_var, jitter, nullptr, nullptr, info, false, false, nullptr, true))) return rc;
 
-    const int C = m->C, D = m->D;
+    const int C = m->C, D = m->D, nb = m->nb;
     const int64_t Npad = m->Npad;
     SortedX ss;
     if ((rc = sort_inputs(Xs, S, D, C, MOGP_TILE, ss))) return rc;
-    const int64_t Spad = ss.Mpad;
+    const int64_t Spad = ss.Mpad, Srow = Spad + MOGP_TILE;          // one more tile row: its first row carries y^T through the same solve
     std::vector<GTile> pt;
     build_rect_tiles(ss.off, m->sx.off, C, pt);
     if ((rc = m->d_xs.ensure((size_t)D * Spad))) return rc;
-    if ((rc = m->d_Ksf.ensure((size_t)Spad * Npad))) return rc;
-    if ((rc = m->d_Vt.ensure((size_t)Spad * Npad))) return rc;
+    if ((rc = m->d_Ksf.ensure((size_t)Srow * Npad))) return rc;
+    if ((rc = m->d_Vt.ensure((size_t)Srow * Npad))) return rc;
     if ((rc = m->d_mu.ensure(Spad))) return rc;
     if ((rc = m->d_var.ensure(Spad))) return rc;
     if ((rc = m->d_kdiag.ensure(Spad))) return rc;
@@ -866,7 +874,8 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
     HIP_TRY(hipMemcpyAsync(m->d_kdiag.p, kd.data(), Spad * sizeof(double), hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->d_ptiles.p, pt.data(), pt.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
     // padded rows/columns of Ksf must be zero: rows >= S and columns >= N are never written by the Gram kernel
-    HIP_TRY(hipMemsetAsync(m->d_Ksf.p, 0, (size_t)Spad * Npad * sizeof(double), m->st));
+    HIP_TRY(hipMemsetAsync(m->d_Ksf.p, 0, (size_t)Srow * Npad * sizeof(double), m->st));
+    HIP_TRY(hipMemcpyAsync(m->d_Ksf.p + Spad * Npad, m->d_y.p, Npad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
 
     // K_sf = K(Xs, X)   (rows: test points, columns: training points; all C*C pairs, reference kernel.py:468-479 transposed)
     GramArgs ga{};
@@ -875,14 +884,42 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
     ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = m->Wt; ga.out = m->d_Ksf.p; ga.ldo = Npad;
     ga.noise = nullptr; ga.dvar = nullptr; ga.jitter_abs = 0.0; ga.mirror = 0;
     if ((rc = launch_gram(ga, (int)pt.size(), m->st))) return rc;
-    // mu = K_sf alpha
-    if ((rc = launch_gemv_rows(m->d_Ksf.p, Npad, Spad, Npad, m->d_alpha.p, m->d_mu.p, m->st))) return rc;
-    // V^T = K_sf W^T  (W lower triangular: k <= j)
-    GemmArgs g{};
-    g.A = m->d_Ksf.p; g.lda = Npad; g.a_kmajor = 0; g.B = m->k.A.p; g.ldb = Npad; g.b_kmajor = 0;
-    g.C = m->d_Vt.p; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
-    g.mode = GM_KHI_J; g.mt = (int)(Spad / MOGP_TILE); g.nt = m->nb; g.K = (int)Npad; g.tasks = nullptr; g.ntasks = 0;
-    if ((rc = gemm_call(m, g, gemm_flops(g, nullptr)))) return rc;
+
+    // X L^T = [K_sf ; y^T]  by block columns of 512 (right-looking):  X[:, K] = T[:, K] W_KK^T,  T[:, > K] -= X[:, K] L[> K, K]^T.
+    // W_KK = L_KK^-1 of the 512 x 512 diagonal blocks comes from the tile inverses the factorisation left behind (wkk.hip).
+    {
+        constexpr int OB = 4, KD = OB * MOGP_TILE;
+        const int nouter = (nb + OB - 1) / OB, mt = (int)(Srow / MOGP_TILE);
+        Spd& w = m->k;
+        if (w.Wd.n < (size_t)nouter * KD * KD) {             // tiles above the diagonal of a W_KK are never written and must be zero
+            if ((rc = w.Wd.ensure((size_t)nouter * KD * KD))) return rc;
+            HIP_TRY(hipMemsetAsync(w.Wd.p, 0, (size_t)nouter * KD * KD * sizeof(double), m->st));
+        }
+        for (int kb = 0; kb < nouter; ++kb) {
+            const int k0 = kb * OB, nk = std::min(OB, nb - k0);
+            if ((rc = launch_wkk(w.A.p + (int64_t)k0 * MOGP_TILE * (Npad + 1), Npad, w.invd.p + (int64_t)k0 * MOGP_TILE * MOGP_TILE, nk,
+                                 w.Wd.p + (int64_t)kb * KD * KD, KD, m->st))) return rc;
+        }
+        for (int kb = 0; kb < nouter; ++kb) {
+            const int k0 = kb * OB, nk = std::min(OB, nb - k0), k1 = k0 + nk, rem = nb - k1;
+            const int64_t c0 = (int64_t)k0 * MOGP_TILE;
+            GemmArgs g{};
+            g.A = m->d_Ksf.p + c0; g.lda = Npad; g.a_kmajor = 0; g.B = w.Wd.p + (int64_t)kb * KD * KD; g.ldb = KD; g.b_kmajor = 0;
+            g.C = m->d_Vt.p + c0; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
+            g.mode = GM_KHI_J; g.mt = mt; g.nt = nk; g.K = nk * MOGP_TILE;
+            if ((rc = gemm_call(m, g, gemm_flops(g, nullptr)))) return rc;
+            if (rem > 0) {
+                GemmArgs u{};
+                u.A = m->d_Vt.p + c0; u.lda = Npad; u.a_kmajor = 0;
+                u.B = w.A.p + (int64_t)k1 * MOGP_TILE * Npad + c0; u.ldb = Npad; u.b_kmajor = 0;
+                u.C = m->d_Ksf.p + (int64_t)k1 * MOGP_TILE; u.ldc = Npad; u.alpha = -1.0; u.beta = 1.0;
+                u.mode = GM_RECT; u.mt = mt; u.nt = rem; u.K = nk * MOGP_TILE;
+                if ((rc = gemm_call(m, u, gemm_flops(u, nullptr)))) return rc;
+            }
+        }
+    }
+    // mu = V^T z: the rows of X against its last row (z^T)
+    if ((rc = launch_gemv_rows(m->d_Vt.p, Npad, Spad, Npad, m->d_Vt.p + Spad * Npad, m->d_mu.p, m->st))) return rc;
 
     std::vector<double> hmu(Spad);
     HIP_TRY(hipMemcpyAsync(hmu.data(), m->d_mu.p, Spad * sizeof(double), hipMemcpyDeviceToHost, m->st));

@@ -176,6 +176,7 @@ struct mogp_model {
     std::vector<GTile> tiles_own;       // the Gram / moment tiles that touch an owned tile row (grouped by pair like `tiles`)
     std::vector<int> pair_start_own;
     DevBuf<GTile> d_tiles_own;
+    bool factor_only = false;           // the last factorisation stopped at L (prediction): no W, no alpha
     StripTiles strip, strip_own;        // the same tile lists (all / owned) split for the Gram strip kernel
     DevBuf<int> d_pair_start_own;
     int own_rank = -1, own_n = 0;       // (rank, nranks) the owned lists were built for
