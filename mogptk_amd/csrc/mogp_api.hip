@@ -725,6 +725,7 @@ int mogp_model_destroy(mogp_model* m) {
     if (m->st) { hipError_t e = hipStreamSynchronize(m->st); (void)e; }
     for (auto e : m->ev) { hipError_t r = hipEventDestroy(e); (void)r; }
     for (auto e : m->gemm_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
+    for (auto& e : m->pred_ev) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
     for (hipStream_t q : {m->st2, m->st2u, m->st3, m->st4, m->st_priv}) if (q) { hipError_t e = hipStreamSynchronize(q); (void)e; }
     m->k.release(); m->ws.release(); m->ws_tail.release();
     for (int b = 0; b < 2; ++b) { m->swU[b].release(); m->swUr[b].release(); }
@@ -854,6 +855,11 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
 
     const int C = m->C, D = m->D, nb = m->nb;
     const int64_t Npad = m->Npad;
+    // the W_KK of the substitution below are built on a second stream, next to the test Gram
+    hipStream_t side = m->st2 ? m->st2 : m->st;
+    for (auto& e : m->pred_ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(m->pred_ev[0], m->st));
+    HIP_TRY(hipStreamWaitEvent(side, m->pred_ev[0], 0));
     SortedX ss;
     if ((rc = sort_inputs(Xs, S, D, C, MOGP_TILE, ss))) return rc;
     const int64_t Spad = ss.Mpad, Srow = Spad + MOGP_TILE;          // one more tile row: its first row carries y^T through the same solve
@@ -893,20 +899,22 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
         Spd& w = m->k;
         if (w.Wd.n < (size_t)nouter * KD * KD) {             // tiles above the diagonal of a W_KK are never written and must be zero
             if ((rc = w.Wd.ensure((size_t)nouter * KD * KD))) return rc;
-            HIP_TRY(hipMemsetAsync(w.Wd.p, 0, (size_t)nouter * KD * KD * sizeof(double), m->st));
+            HIP_TRY(hipMemsetAsync(w.Wd.p, 0, (size_t)nouter * KD * KD * sizeof(double), side));
         }
         for (int kb = 0; kb < nouter; ++kb) {
             const int k0 = kb * OB, nk = std::min(OB, nb - k0);
             if ((rc = launch_wkk(w.A.p + (int64_t)k0 * MOGP_TILE * (Npad + 1), Npad, w.invd.p + (int64_t)k0 * MOGP_TILE * MOGP_TILE, nk,
-                                 w.Wd.p + (int64_t)kb * KD * KD, KD, m->st))) return rc;
+                                 w.Wd.p + (int64_t)kb * KD * KD, KD, side))) return rc;
         }
+        HIP_TRY(hipEventRecord(m->pred_ev[1], side));
+        HIP_TRY(hipStreamWaitEvent(m->st, m->pred_ev[1], 0));
         for (int kb = 0; kb < nouter; ++kb) {
             const int k0 = kb * OB, nk = std::min(OB, nb - k0), k1 = k0 + nk, rem = nb - k1;
             const int64_t c0 = (int64_t)k0 * MOGP_TILE;
             GemmArgs g{};
             g.A = m->d_Ksf.p + c0; g.lda = Npad; g.a_kmajor = 0; g.B = w.Wd.p + (int64_t)kb * KD * KD; g.ldb = KD; g.b_kmajor = 0;
             g.C = m->d_Vt.p + c0; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
-            g.mode = GM_KHI_J; g.mt = mt; g.nt = nk; g.K = nk * MOGP_TILE;
+            g.mode = GM_KHI_J; g.small = 1; g.mt = 2 * mt; g.nt = nk; g.K = nk * MOGP_TILE;        // 64 x 128 tiles: twice the workgroups of a launch that fills a quarter of the chip
             if ((rc = gemm_call(m, g, gemm_flops(g, nullptr)))) return rc;
             if (rem > 0) {
                 GemmArgs u{};

@@ -177,6 +177,7 @@ struct mogp_model {
     std::vector<int> pair_start_own;
     DevBuf<GTile> d_tiles_own;
     bool factor_only = false;           // the last factorisation stopped at L (prediction): no W, no alpha
+    hipEvent_t pred_ev[2] = {nullptr, nullptr};      // fork / join of the prediction's side stream
     StripTiles strip, strip_own;        // the same tile lists (all / owned) split for the Gram strip kernel
     DevBuf<int> d_pair_start_own;
     int own_rank = -1, own_n = 0;       // (rank, nranks) the owned lists were built for
