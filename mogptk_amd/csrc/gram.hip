@@ -943,7 +943,7 @@ int launch_moments(const MomentArgs& a0, hipStream_t s) {
     const bool env = a.W > 2 + 3 * a.D;
     const double* xc = a.xc ? a.xc : a.x;
     const int64_t ldxc = a.xc ? a.ldxc : a.ldx;
-    int rc = launch_phase_tables(a.ph, a.x, a.ldx, a.nrows, xc, ldxc, a.xc ? a.ncols : a.nrows, a.table, a.T, a.D, a.C, a.W, s);
+    int rc = a.phases_ready ? 0 : launch_phase_tables(a.ph, a.x, a.ldx, a.nrows, xc, ldxc, a.xc ? a.ncols : a.nrows, a.table, a.T, a.D, a.C, a.W, s);
     if (rc) return rc;
     if (a.G == nullptr) {
         if (a.ev0) HIP_TRY(hipEventRecord(a.ev0, s));

@@ -602,6 +602,7 @@ static int moment_pass_device(mogp_model* m, const double* kinv, double ksign) {
     ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C; ma.W = W; ma.kinv = kinv; ma.kinv_sign = ksign; ma.ld = Npad; ma.alpha = m->d_alpha.p;
     ma.row_mod = rm; ma.row_rem = m->sh_rank;
     ma.partial = m->d_partial.p;
+    ma.phases_ready = 1;                       // ph_xx was filled by this evaluation's Gram launch: same inputs, same table
     ma.ev0 = prof_event(m, 9); ma.ev1 = prof_event(m, 10);
     if ((rc = launch_moments(ma, m->st))) return rc;
     if ((rc = launch_moment_reduce(m->d_partial.p, own ? m->d_pair_start_own.p : m->d_pair_start.p, P, T, W, D, m->d_moments.p, m->st))) return rc;

@@ -101,6 +101,7 @@ struct MomentArgs {
     double* partial;       // [ntiles][T][W] per-tile partial moments (reduced in fixed order afterwards)
     hipEvent_t ev0, ev1;   // when non-null: recorded around the tile kernel alone (profiling)
     int tab_lds;           // set by the launcher: the term table is copied to LDS
+    int phases_ready;      // the phase workspace still holds this table's phases and block centres (the Gram launch of the same evaluation filled it)
 };
 
 int launch_gram(const GramArgs& a, int ntiles, hipStream_t s);
