@@ -23,10 +23,15 @@ logger = logging.getLogger("mogptk")
 
 
 def LoadModel(filename):
-    """reference mogptk/model.py:62-74"""
+    """reference mogptk/model.py:62-74.  Reads this package's own checkpoints and -- through mogptk_amd.compat, without the reference
+    installed -- files written by the reference's `Model.save()`."""
     filename += ".npy"
     with open(filename, "rb") as r:
-        return pickle.load(r)
+        raw = r.read()
+    from . import compat
+    if compat.is_reference_checkpoint(raw):
+        return compat.load_reference_model(raw)
+    return pickle.loads(raw)
 
 
 class Exact:

@@ -726,6 +726,79 @@ def gen_cfg5():
     print("cfg5.npz loss=%.10f (%.1f s)" % (loss, dt))
 
 
+def gen_checkpoints():
+    """Files written by the reference's own Model.save() (model.py:320-336) -- the whole pickled model: MOSM with a fitted transformer
+    chain, removed points and a pegged + a fixed parameter; the SM, CSM, SM-LMC and CONV wrappers; a Titsias MOSM -- stored as bytes next to what
+    the reference computes on the loaded object: constrained parameter values, loss, predictions at the stored prediction inputs."""
+    import tempfile
+    rng = np.random.default_rng(77)
+    out = {}
+
+    def dataset(C, n, transform=False):
+        ds = mogptk.DataSet()
+        for c in range(C):
+            x = np.sort(rng.uniform(0, 10, n))
+            y = np.sin(x * (1 + 0.5 * c)) + 0.05 * x + 0.1 * rng.standard_normal(n)
+            d = mogptk.Data(x, y, name="ch%d" % c)
+            if transform:
+                d.transform(mogptk.TransformDetrend(degree=1))
+                d.transform(mogptk.TransformStandard())
+            d.mask[rng.permutation(n)[:n // 5]] = False
+            d.set_prediction_data(np.linspace(0, 11, 7))
+            ds.append(d)
+        return ds
+
+    def randomise(model):
+        for p in model.gpr.parameters():
+            if p.pegged or (p._name or "").endswith("induction_points"):      # the channel column of Z must stay integral
+                continue
+            v = p.constrained.detach().numpy()
+            lo = None if p.lower is None else np.broadcast_to(p.lower.detach().numpy(), v.shape)
+            hi = None if p.upper is None else np.broadcast_to(p.upper.detach().numpy(), v.shape)
+            new = v * rng.uniform(0.8, 1.2, v.shape) + (rng.normal(0, 0.05, v.shape) if lo is None else 0.0)
+            if hi is not None:
+                new = np.minimum(new, lo + 0.9 * (hi - lo))
+            if lo is not None:
+                new = np.maximum(new, lo + 1e-3 * (1 + np.abs(lo)))
+            p.assign(new)
+
+    def record(tag, model):
+        with tempfile.TemporaryDirectory() as d:
+            model.save(os.path.join(d, "m"))
+            raw = open(os.path.join(d, "m.npy"), "rb").read()
+            loaded = mogptk.LoadModel(os.path.join(d, "m"))
+        out[tag + "_file"] = np.frombuffer(raw, dtype=np.uint8)
+        out[tag + "_names"] = np.array([p._name for p in loaded.gpr.parameters()])
+        for i, p in enumerate(loaded.gpr.parameters()):
+            out["%s_p%d" % (tag, i)] = p.constrained.detach().numpy()
+            out["%s_train%d" % (tag, i)] = np.array(bool(p.train))
+        out[tag + "_loss"] = np.array(float(loaded.loss()))
+        for i, p in enumerate(loaded.gpr.parameters()):
+            out["%s_g%d" % (tag, i)] = np.zeros(0) if p.grad is None else p.grad.detach().numpy()
+        X, mu, lower, upper = loaded.predict(transformed=False)
+        out[tag + "_mu"] = np.concatenate([np.asarray(m).reshape(-1) for m in mu])
+        out[tag + "_lower"] = np.concatenate([np.asarray(m).reshape(-1) for m in lower])
+        out[tag + "_upper"] = np.concatenate([np.asarray(m).reshape(-1) for m in upper])
+        out[tag + "_history"] = np.array([loaded.iters, len(loaded.times), len(loaded.losses)])
+
+    m = mogptk.MOSM(dataset(2, 40, transform=True), Q=2)
+    randomise(m)
+    m.gpr.kernel.phase.train = False
+    m.gpr.likelihood.scale.assign([0.2, 0.3])
+    m.train(method="Adam", lr=0.01, iters=3, verbose=False)
+    record("mosm", m)
+    m = mogptk.SM(dataset(2, 30), Q=2); randomise(m)
+    import functools, operator
+    m.gpr.kernel[1].mean.peg(m.gpr.kernel[0].mean, functools.partial(operator.mul, 2.0))      # a transform that pickles (a lambda does not)
+    record("sm", m)
+    m = mogptk.CSM(dataset(2, 30), Q=2, Rq=2); randomise(m); record("csm", m)
+    m = mogptk.SM_LMC(dataset(3, 25), Q=2, Rq=1); randomise(m); record("smlmc", m)
+    m = mogptk.CONV(dataset(2, 30), Q=2); randomise(m); record("conv", m)
+    m = mogptk.MOSM(dataset(2, 60), Q=1, inference=mogptk.Titsias(inducing_points=8)); randomise(m); record("titsias", m)
+    np.savez_compressed(os.path.join(HERE, "checkpoints.npz"), **out)
+    print("checkpoints.npz", {k: v.shape for k, v in out.items() if k.endswith("_file")})
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -733,7 +806,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "lbfgs": gen_lbfgs_cfg1, "quirks": gen_quirks,
              "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2, "smlmc": gen_smlmc, "init_ls": gen_init_ls, "bnse": gen_bnse, "transformers": gen_transformers,
-             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32}
+             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints}
     full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:
         {**steps, **full}[a.only]()

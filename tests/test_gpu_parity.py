@@ -488,3 +488,11 @@ def test_mohsm_predict_and_wrapper_on_device():
 def test_single_precision_switch_on_device():
     from test_host_logic import check_single_precision_switch
     check_single_precision_switch()
+
+
+def test_reference_checkpoints_on_device(tmp_path):
+    """files written by the reference's Model.save() load without the reference and evaluate on the device like the
+    reference evaluates them (loss, gradients, predictions incl. the transformer chain) -- Exact wrappers and a Titsias model"""
+    pytest.importorskip("torch")
+    from test_host_logic import check_reference_checkpoints
+    check_reference_checkpoints(tmp_path, tol_loss=1e-8, tol_grad=1e-6, tol_pred=1e-6)

@@ -543,3 +543,46 @@ def check_mohsm_predict_and_wrapper(tol_pred=1e-8, tol_loss=1e-9, tol_grad=1e-8,
 
 def test_mohsm_predict_and_wrapper_match_reference():
     check_mohsm_predict_and_wrapper()
+
+
+# ---- checkpoints written by the reference's Model.save() load without the reference ----------------------------------
+def check_reference_checkpoints(tmp_path, tol_value=1e-12, tol_loss=1e-8, tol_grad=1e-6, tol_pred=1e-6, tags=("mosm", "sm", "csm", "smlmc", "conv", "titsias")):
+    """checkpoints.npz: the bytes of files the reference wrote, and what the reference itself computes after loading them"""
+    fx = load("checkpoints.npz")
+    for tag in tags:
+        path = tmp_path / ("ref_%s" % tag)
+        (tmp_path / ("ref_%s.npy" % tag)).write_bytes(fx[tag + "_file"].tobytes())
+        m = mogptk_amd.LoadModel(str(path))
+        assert type(m).__name__ == {"mosm": "MOSM", "sm": "SM", "csm": "CSM", "smlmc": "SM_LMC", "conv": "CONV", "titsias": "MOSM"}[tag]
+        ps = list(m.gpr.parameters())
+        assert [p._name for p in ps] == [str(n) for n in fx[tag + "_names"]]
+        for i, p in enumerate(ps):
+            ref = fx["%s_p%d" % (tag, i)]
+            assert np.max(np.abs(np.asarray(p()) - ref)) <= tol_value * max(1.0, np.max(np.abs(ref))), (tag, p._name)
+            assert bool(p.train) == bool(fx["%s_train%d" % (tag, i)])
+        assert list(fx[tag + "_history"]) == [m.iters, len(m.times), len(m.losses)]
+        loss = m.loss()
+        ref_loss = float(fx[tag + "_loss"])
+        assert abs(loss - ref_loss) <= tol_loss * max(1.0, abs(ref_loss)), (tag, loss, ref_loss)
+        for i, p in enumerate(ps):
+            g = fx["%s_g%d" % (tag, i)]
+            if g.size == 0:
+                assert p.grad is None, (tag, p._name)
+            else:
+                assert np.max(np.abs(p.grad - g)) <= tol_grad * max(1.0, np.max(np.abs(g))), (tag, p._name)
+        _, mu, lower, upper = m.predict(transformed=False)
+        cat = lambda parts: np.concatenate([np.asarray(v).reshape(-1) for v in (parts if isinstance(parts, list) else [parts])])
+        for got, key in ((mu, "_mu"), (lower, "_lower"), (upper, "_upper")):
+            ref = fx[tag + key]
+            assert np.max(np.abs(cat(got) - ref)) <= tol_pred * max(1.0, np.max(np.abs(ref))), (tag, key)
+        # and back out through this package's own save / load
+        m.save(str(tmp_path / ("own_%s" % tag)))
+        m2 = mogptk_amd.LoadModel(str(tmp_path / ("own_%s" % tag)))
+        assert abs(m2.loss() - loss) <= 1e-12 * max(1.0, abs(loss))
+
+
+def test_reference_checkpoints_load_without_the_reference(tmp_path):
+    pytest.importorskip("torch")
+    import sys
+    assert "mogptk" not in sys.modules
+    check_reference_checkpoints(tmp_path)
