@@ -540,6 +540,20 @@ int launch_axpby(int64_t n, double a, const double* x, double b, const double* y
     return 0;
 }
 
+// out[i] = sum_k slices[k * stride + i]   (split-K partial results, fixed order)
+__global__ void k_sum_slices(const double* __restrict__ slices, int64_t n, int ks, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int k = 0; k < ks; ++k) s += slices[(int64_t)k * n + i];
+    out[i] = s;
+}
+int launch_sum_slices(const double* slices, int64_t n, int ks, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slices, n, ks, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 __global__ void k_nonfinite_scan(const double* __restrict__ A, int64_t ld, int64_t n, int* flag) {
     const int64_t r = blockIdx.x;
     int f = 0;

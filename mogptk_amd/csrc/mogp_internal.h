@@ -183,6 +183,8 @@ int launch_combine(double* out, const double* P, const double* Q, int64_t ld, in
 int launch_gemv_cols(const double* M, int64_t ld, int64_t rows, int64_t n, const double* v, double* out, double* scratch, hipStream_t s);
 int launch_get_diag(const double* A, int64_t ld, int64_t n, double* out, hipStream_t s);
 int launch_axpby(int64_t n, double a, const double* x, double b, const double* y, double* out, hipStream_t s);
+// out[i] = sum over ks slices of n doubles each (split-K partial results, summed in slice order)
+int launch_sum_slices(const double* slices, int64_t n, int ks, double* out, hipStream_t s);
 // non-finite scan of the lower triangle: flag[0] |= 1 if NaN seen, |= 2 if Inf seen
 int launch_nonfinite_scan(const double* A, int64_t ld, int64_t n, int* flag, hipStream_t s);
 

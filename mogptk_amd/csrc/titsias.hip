@@ -114,13 +114,30 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     HIP_TRY(hipMemcpyAsync(t.v.p, t.B.p, (size_t)Mpad * Npad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.v.p, Npad, Npad, false));              // v = L^-1 B   (reference gpr/model.py:711)
     (void)nt;
-    // Qs = v v^T / s2 + I: mt (mt + 1) / 2 = 136 tiles at configs[4] would leave half the chip idle over K = N, so K is cut in two
-    // (272 workgroups), the second half into the scratch matrix t.q.B, and the halves are added with the identity
+    // Qs = v v^T / s2 + I
     GemmArgs g = gemm(t.v.p, Npad, 0, t.v.p, Npad, 0, t.q.A.p, Mpad, 1.0 / s2, GM_LOWER, mt, mt, Npad);
-    const bool split = mt * (mt + 1) / 2 < 256 && Npad >= 4096;
-    if (split) { g.ksplit = 2; g.c_split = t.q.B.p - t.q.A.p; }
+    // mt (mt + 1) / 2 = 136 tiles at configs[4] would leave half the chip idle over K = N: K is cut into ks slices, each slice into a block of
+    // its own, and the blocks are summed.  ks minimises rounds(tiles ks / 512 slots) / ks: 136 tiles -> ks = 15, 2040 workgroups = four
+    // full rounds (two slices left every second CU with two workgroups and the rest with one: 12.5 ms; fifteen: see DESIGN 4b)
+    const int tiles_q = mt * (mt + 1) / 2;
+    int ks = 1;
+    if (tiles_q < 512 && Npad >= 4096) {
+        double best = 1e30;
+        for (int c = 1; c <= 16; ++c) {
+            if (Npad / c < 2048) break;
+            const double cost = std::ceil((double)tiles_q * c / 512.0) / c;
+            if (cost < best - 1e-12) { best = cost; ks = c; }
+        }
+    }
+    if (ks > 1) {
+        if (t.kslices.n < (size_t)ks * Mpad * Mpad) {         // the upper tiles are never written: keep them finite
+            RC(t.kslices.ensure((size_t)ks * Mpad * Mpad));
+            HIP_TRY(hipMemsetAsync(t.kslices.p, 0, (size_t)ks * Mpad * Mpad * sizeof(double), m->st));
+        }
+        g.C = t.kslices.p; g.ksplit = ks; g.c_split = (int64_t)Mpad * Mpad;
+    }
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
-    if (split) RC(launch_axpby((int64_t)Mpad * Mpad, 1.0, t.q.A.p, 1.0, t.q.B.p, t.q.A.p, m->st));
+    if (ks > 1) RC(launch_sum_slices(t.kslices.p, (int64_t)Mpad * Mpad, ks, t.q.A.p, m->st));
     RC(launch_add_diag(t.q.A.p, Mpad, Mpad, 1.0, m->st));
     HIP_TRY(hipMemcpyAsync(t.Qs.p, t.q.A.p, (size_t)Mpad * Mpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->d_info.p, &big, sizeof(big), hipMemcpyHostToDevice, m->st));
