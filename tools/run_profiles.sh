@@ -18,7 +18,7 @@ cd $GRAFT_REPO_ROOT
 for c in cfg2 cfg3 cfg4 cfg5; do python tools/ktrace.py $O/kt_$c --csv $O/${c}_kernel_stats.csv > /dev/null 2>&1; done
 python tools/timeline.py $O/kt_cfg2 > $O/cfg2_timeline.txt 2>&1
 python tools/gemm_rate.py $O/kt_cfg2 >> $O/cfg2_timeline.txt 2>&1
-python tools/pmc_summary.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv") $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv") 4 $O/pmc_traffic.json > $O/pmc_hbm_traffic.csv 2>&1
+python tools/pmc_summary.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv") $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv") 5 $O/pmc_traffic.json > $O/pmc_hbm_traffic.csv 2>&1
 python - $O <<'PY' > $O/pmc_counters.txt 2>&1
 import csv, glob, collections, sys
 O = sys.argv[1]
