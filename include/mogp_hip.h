@@ -192,6 +192,16 @@ int  mogp_stage_ms(mogp_model* m, double* ms, int64_t* gemm_launches, double* ge
  *        2 = alpha (N).  Output in the caller's original row order, full N x N (symmetrised / lower-filled). */
 int  mogp_model_fetch(mogp_model* m, int which, double* out);
 
+/* Host-side pair algebra of the MOSM kernel in native code (no device work): the cross-spectral term table of every channel pair
+ * (reference gpr/multioutput.py:178-204) and the reverse-mode gradient autograd takes through it.
+ * w (C,Q), mu / v / th (C,Q,D), ph (C,Q) are the CONSTRAINED weight, mean, variance, delay, phase; table is [C][C][Q][2+3D];
+ * gtable (same shape) is zero for channel pairs i < j and already carries the double count of the off-diagonal pairs. */
+int  mogp_mosm_terms(int C, int Q, int D, const double* w, const double* mu, const double* v, const double* th, const double* ph,
+                     double twopi, double phase_scale, double* table);
+int  mogp_mosm_terms_backward(int C, int Q, int D, const double* w, const double* mu, const double* v, const double* th, const double* ph,
+                              double twopi, double phase_scale, const double* gtable, double* gw, double* gmu, double* gv, double* gth,
+                              double* gph);
+
 #ifdef __cplusplus
 }
 #endif

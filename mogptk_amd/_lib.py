@@ -70,6 +70,9 @@ SIGNATURES = {
     "mogp_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "mogp_stage_ms": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i64p, c_dp]),
     "mogp_model_fetch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_dp]),
+    "mogp_mosm_terms": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, ctypes.c_double, ctypes.c_double, c_dp]),
+    "mogp_mosm_terms_backward": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, ctypes.c_double,
+                                                ctypes.c_double, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
 }
 
 

@@ -7,6 +7,8 @@ UncoupledMultiOutputSpectralKernel (uMOSM, :212-293).
 Each class maps its constrained parameters to the unified spectral term table and back-propagates the
 table gradient to its raw parameters; see gpr/kernel.py (this package) for the protocol.
 """
+import ctypes
+
 import numpy as np
 
 from .config import config
@@ -169,8 +171,42 @@ class MultiOutputSpectralMixtureKernel(MultiOutputKernel):
         self.__dict__["_derived_memo"] = (pairs, out)
         return out
 
+    def _native(self):
+        """the library's native pair algebra (csrc/hostalg.hip) -- for the plain MOSM kernel only: its siblings override pieces of it"""
+        if type(self) is not MultiOutputSpectralMixtureKernel or config.dtype != np.float64:
+            return None
+        from .. import _lib
+        try:
+            return _lib.lib()
+        except OSError:
+            return None
+
+    @staticmethod
+    def _c(a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+    def _native_values(self):
+        """constrained values as contiguous arrays + pointers, once per parameter set (the table push and the chain rule share them)"""
+        key = self._memo_key()
+        memo = self.__dict__.get("_native_memo")
+        if memo is None or memo[0] != key:
+            memo = (key, [np.ascontiguousarray(x, dtype=np.float64) for x in self._values()])       # arrays only: the memo is pickled with the kernel
+            self.__dict__["_native_memo"] = memo
+        return [(a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) for a in memo[1]]
+
     def _spectral_terms_compute(self, D):
         C = self.output_dims
+        lib = self._native()
+        if lib is not None:
+            vals = self._native_values()
+            Q = vals[1][0].shape[1]
+            table = np.empty((C, C, Q, term_width(D)))
+            rc = lib.mogp_mosm_terms(C, Q, D, *[p for _, p in vals], float(self.twopi), float(self._phase_scale),
+                                     table.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+            if rc != 0:
+                raise RuntimeError("mogp_mosm_terms failed (%d)" % rc)
+            return table
         w, mu, v, th, ph, vi, vj, mi, mj, s, inv, dmu = self._pairs()
         E, M, V, rootV, off2, off3 = self._derived()
         Q = mu.shape[1]
@@ -196,6 +232,20 @@ class MultiOutputSpectralMixtureKernel(MultiOutputKernel):
         carries the symmetric double count of off-diagonal channel blocks."""
         C = self.output_dims
         D = self.input_dims
+        lib = self._native()
+        if lib is not None:
+            vals = self._native_values()
+            Q = vals[1][0].shape[1]
+            gt, gtp = self._c(gtable)
+            gw, gph = np.empty((C, Q)), np.empty((C, Q))
+            gmu, gv, gth = np.empty((C, Q, D)), np.empty((C, Q, D)), np.empty((C, Q, D))
+            ptr = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+            rc = lib.mogp_mosm_terms_backward(C, Q, D, *[p for _, p in vals], float(self.twopi), float(self._phase_scale), gtp,
+                                              ptr(gw), ptr(gmu), ptr(gv), ptr(gth), ptr(gph))
+            if rc != 0:
+                raise RuntimeError("mogp_mosm_terms_backward failed (%d)" % rc)
+            self._store(gw, gmu, gv, gth, gph)
+            return
         w, mu, v, th, ph, vi, vj, mi, mj, s, inv, dmu = self._pairs()
         A = self._spectral_terms(D)[..., 0]
         gA, gPsi = gtable[..., 0], gtable[..., 1]
