@@ -851,16 +851,14 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
     if ((rc = use_device(m->ctx))) return rc;
     if (info) *info = 0;
     // Cholesky factor only: the predictive equations need V = L^-1 K_fs and z = L^-1 y, never L^-1 itself (reference gpr/model.py:470-472 solves).
-    // Round 1 / 2a formed W = L^-1 (N^3/3 flop) and multiplied; here [V | z] comes from ONE blocked forward substitution, N^2 (S+1) flop.
-    if ((rc = factorize(m, noise_var, data_var, jitter, nullptr, nullptr, info, false, false, nullptr, true))) return rc;
-
+    // Round 1 / 2a formed W = L^-1 (N^3/3 flop) and multiplied; here [V | z] comes from ONE blocked forward substitution, N^2 (S+1) flop,
+    // streamed behind the factorisation: block column K is solved as soon as the factorisation's chain has finished block K.
     const int C = m->C, D = m->D, nb = m->nb;
     const int64_t Npad = m->Npad;
-    // the W_KK of the substitution below are built on a second stream, next to the test Gram
-    hipStream_t side = m->st2 ? m->st2 : m->st;
+    hipStream_t sv = m->st3 ? m->st3 : m->st;                       // test Gram + substitution (bulk CUs, lowest priority)
     for (auto& e : m->pred_ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(m->pred_ev[0], m->st));
-    HIP_TRY(hipStreamWaitEvent(side, m->pred_ev[0], 0));
+    HIP_TRY(hipEventRecord(m->pred_ev[0], m->st));                  // whatever the model's stream still holds comes first
+    HIP_TRY(hipStreamWaitEvent(sv, m->pred_ev[0], 0));
     SortedX ss;
     if ((rc = sort_inputs(Xs, S, D, C, MOGP_TILE, ss))) return rc;
     const int64_t Spad = ss.Mpad, Srow = Spad + MOGP_TILE;          // one more tile row: its first row carries y^T through the same solve
@@ -877,55 +875,62 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
     const bool per_point = m->Wt > 2 + 3 * D;          // terms with an envelope: kss_diag holds one value per test point (caller order)
     for (int c = 0; c < C; ++c)
         for (int pos = ss.off[c]; pos < ss.off[c + 1]; ++pos) kd[pos] = per_point ? kss_diag[ss.perm[pos]] : kss_diag[c];
-    HIP_TRY(hipMemcpyAsync(m->d_xs.p, ss.xs.data(), (size_t)D * Spad * sizeof(double), hipMemcpyHostToDevice, m->st));
-    HIP_TRY(hipMemcpyAsync(m->d_kdiag.p, kd.data(), Spad * sizeof(double), hipMemcpyHostToDevice, m->st));
-    HIP_TRY(hipMemcpyAsync(m->d_ptiles.p, pt.data(), pt.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemcpyAsync(m->d_xs.p, ss.xs.data(), (size_t)D * Spad * sizeof(double), hipMemcpyHostToDevice, sv));
+    HIP_TRY(hipMemcpyAsync(m->d_kdiag.p, kd.data(), Spad * sizeof(double), hipMemcpyHostToDevice, sv));
+    HIP_TRY(hipMemcpyAsync(m->d_ptiles.p, pt.data(), pt.size() * sizeof(GTile), hipMemcpyHostToDevice, sv));
     // padded rows/columns of Ksf must be zero: rows >= S and columns >= N are never written by the Gram kernel
-    HIP_TRY(hipMemsetAsync(m->d_Ksf.p, 0, (size_t)Srow * Npad * sizeof(double), m->st));
-    HIP_TRY(hipMemcpyAsync(m->d_Ksf.p + Spad * Npad, m->d_y.p, Npad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
+    HIP_TRY(hipMemsetAsync(m->d_Ksf.p, 0, (size_t)Srow * Npad * sizeof(double), sv));
+    HIP_TRY(hipMemcpyAsync(m->d_Ksf.p + Spad * Npad, m->d_y.p, Npad * sizeof(double), hipMemcpyDeviceToDevice, sv));
 
     // K_sf = K(Xs, X)   (rows: test points, columns: training points; all C*C pairs, reference kernel.py:468-479 transposed)
     GramArgs ga{};
     ga.tiles = m->d_ptiles.p; ga.xr = m->d_xs.p; ga.ldxr = Spad; ga.xc = m->d_x.p; ga.ldxc = Npad; ga.nrows = S; ga.ncols = m->N;
-    if ((rc = m->ph_sx.prepare(ss.off, m->sx.off, C, m->T, Spad, Npad, m->st, ga.ph))) return rc;
+    if ((rc = m->ph_sx.prepare(ss.off, m->sx.off, C, m->T, Spad, Npad, sv, ga.ph))) return rc;
     ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = m->Wt; ga.out = m->d_Ksf.p; ga.ldo = Npad;
     ga.noise = nullptr; ga.dvar = nullptr; ga.jitter_abs = 0.0; ga.mirror = 0;
-    if ((rc = launch_gram(ga, (int)pt.size(), m->st))) return rc;
+    if ((rc = launch_gram(ga, (int)pt.size(), sv))) return rc;
+
+    // the factorisation: enqueued on the model's streams, not waited for
+    GramArgs gaK{};
+    if ((rc = factorize(m, noise_var, data_var, jitter, nullptr, nullptr, info, false, true, &gaK, true))) return rc;
 
     // X L^T = [K_sf ; y^T]  by block columns of 512 (right-looking):  X[:, K] = T[:, K] W_KK^T,  T[:, > K] -= X[:, K] L[> K, K]^T.
-    // W_KK = L_KK^-1 of the 512 x 512 diagonal blocks comes from the tile inverses the factorisation left behind (wkk.hip).
+    // W_KK = L_KK^-1 of the 512 x 512 diagonal blocks comes from the tile inverses the factorisation leaves behind (wkk.hip).
     {
         constexpr int OB = 4, KD = OB * MOGP_TILE;
         const int nouter = (nb + OB - 1) / OB, mt = (int)(Srow / MOGP_TILE);
         Spd& w = m->k;
+        const bool streamed = MOGP_OUTER == OB && (int)w.sync_ev.size() >= 2 * nouter;     // spd_potrf's outer blocks are these blocks
+        if (!streamed) {                                       // other blocking (MOGP_OUTER override): after the whole factorisation
+            HIP_TRY(hipEventRecord(m->pred_ev[1], m->st));
+            HIP_TRY(hipStreamWaitEvent(sv, m->pred_ev[1], 0));
+        }
         if (w.Wd.n < (size_t)nouter * KD * KD) {             // tiles above the diagonal of a W_KK are never written and must be zero
             if ((rc = w.Wd.ensure((size_t)nouter * KD * KD))) return rc;
-            HIP_TRY(hipMemsetAsync(w.Wd.p, 0, (size_t)nouter * KD * KD * sizeof(double), side));
+            HIP_TRY(hipMemsetAsync(w.Wd.p, 0, (size_t)nouter * KD * KD * sizeof(double), sv));
         }
-        for (int kb = 0; kb < nouter; ++kb) {
-            const int k0 = kb * OB, nk = std::min(OB, nb - k0);
-            if ((rc = launch_wkk(w.A.p + (int64_t)k0 * MOGP_TILE * (Npad + 1), Npad, w.invd.p + (int64_t)k0 * MOGP_TILE * MOGP_TILE, nk,
-                                 w.Wd.p + (int64_t)kb * KD * KD, KD, side))) return rc;
-        }
-        HIP_TRY(hipEventRecord(m->pred_ev[1], side));
-        HIP_TRY(hipStreamWaitEvent(m->st, m->pred_ev[1], 0));
         for (int kb = 0; kb < nouter; ++kb) {
             const int k0 = kb * OB, nk = std::min(OB, nb - k0), k1 = k0 + nk, rem = nb - k1;
             const int64_t c0 = (int64_t)k0 * MOGP_TILE;
+            if (streamed) HIP_TRY(hipStreamWaitEvent(sv, w.sync_ev[2 * kb], 0));             // chain(kb): L[>= K, K] and the tile inverses of block K are final
+            double* Wk = w.Wd.p + (int64_t)kb * KD * KD;
+            if ((rc = launch_wkk(w.A.p + c0 * (Npad + 1), Npad, w.invd.p + (int64_t)k0 * MOGP_TILE * MOGP_TILE, nk, Wk, KD, sv))) return rc;
             GemmArgs g{};
-            g.A = m->d_Ksf.p + c0; g.lda = Npad; g.a_kmajor = 0; g.B = w.Wd.p + (int64_t)kb * KD * KD; g.ldb = KD; g.b_kmajor = 0;
+            g.A = m->d_Ksf.p + c0; g.lda = Npad; g.a_kmajor = 0; g.B = Wk; g.ldb = KD; g.b_kmajor = 0;
             g.C = m->d_Vt.p + c0; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
             g.mode = GM_KHI_J; g.small = 1; g.mt = 2 * mt; g.nt = nk; g.K = nk * MOGP_TILE;        // 64 x 128 tiles: twice the workgroups of a launch that fills a quarter of the chip
-            if ((rc = gemm_call(m, g, gemm_flops(g, nullptr)))) return rc;
+            if ((rc = gemm_call(m, g, gemm_flops(g, nullptr), sv))) return rc;
             if (rem > 0) {
                 GemmArgs u{};
                 u.A = m->d_Vt.p + c0; u.lda = Npad; u.a_kmajor = 0;
                 u.B = w.A.p + (int64_t)k1 * MOGP_TILE * Npad + c0; u.ldb = Npad; u.b_kmajor = 0;
                 u.C = m->d_Ksf.p + (int64_t)k1 * MOGP_TILE; u.ldc = Npad; u.alpha = -1.0; u.beta = 1.0;
                 u.mode = GM_RECT; u.mt = mt; u.nt = rem; u.K = nk * MOGP_TILE;
-                if ((rc = gemm_call(m, u, gemm_flops(u, nullptr)))) return rc;
+                if ((rc = gemm_call(m, u, gemm_flops(u, nullptr), sv))) return rc;
             }
         }
+        HIP_TRY(hipEventRecord(m->pred_ev[1], sv));
+        HIP_TRY(hipStreamWaitEvent(m->st, m->pred_ev[1], 0));
     }
     // mu = V^T z: the rows of X against its last row (z^T)
     if ((rc = launch_gemv_rows(m->d_Vt.p, Npad, Spad, Npad, m->d_Vt.p + Spad * Npad, m->d_mu.p, m->st))) return rc;
@@ -937,6 +942,7 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
         std::vector<double> hv(Spad);
         HIP_TRY(hipMemcpyAsync(hv.data(), m->d_var.p, Spad * sizeof(double), hipMemcpyDeviceToHost, m->st));
         HIP_TRY(hipStreamSynchronize(m->st));
+        if ((rc = factorize_finish(m, gaK, nullptr, info))) return rc;                  // the pivot report of the factorisation
         for (int64_t pos = 0; pos < S; ++pos) { mu[ss.perm[pos]] = hmu[pos]; var[ss.perm[pos]] = hv[pos]; }
         return MOGP_OK;
     }
@@ -959,6 +965,7 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
     std::vector<double> hc((size_t)Spad * Spad);
     HIP_TRY(hipMemcpyAsync(hc.data(), m->d_Kss.p, hc.size() * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
+    if ((rc = factorize_finish(m, gaK, nullptr, info))) return rc;
     for (int64_t a = 0; a < S; ++a) {
         mu[ss.perm[a]] = hmu[a];
         for (int64_t b = 0; b < S; ++b) var[ss.perm[a] * S + ss.perm[b]] = hc[(size_t)a * Spad + b];
