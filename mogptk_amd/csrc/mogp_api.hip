@@ -95,6 +95,18 @@ void build_rect_tiles(const std::vector<int>& offr, const std::vector<int>& offc
 
 using namespace mogp;
 
+// The ONE wait of an evaluation.  hipStreamSynchronize sleeps on an interrupt; on a shared, loaded host the wake-up is what the wall clock
+// of a 13 ms evaluation then waits for.  Polling the stream costs one busy core for the duration and returns within microseconds.
+static int wait_stream(hipStream_t st) {
+    static const bool spin = !(std::getenv("MOGP_SPIN_WAIT") && std::atoi(std::getenv("MOGP_SPIN_WAIT")) == 0);
+    if (!spin) { HIP_TRY(hipStreamSynchronize(st)); return 0; }
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return hip_fail(e, "hipStreamQuery", __FILE__, __LINE__);
+    }
+}
+
 int StripTiles::build(const std::vector<GTile>& tiles) {
     static const int maxrun = []() { const char* e = std::getenv("MOGP_STRIP_RUN"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 4; }();
     split_strip_tiles(tiles, maxrun, segs, rest);
@@ -829,7 +841,7 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
         const size_t off = (size_t)m->nb + (size_t)((m->Npad + 3) / 4) + 1;
         HIP_TRY(hipMemcpyAsync(m->h_pin + off, m->d_moments.p, (size_t)P * T * W * sizeof(double), hipMemcpyDeviceToHost, m->st));
         HIP_TRY(hipMemcpyAsync(m->h_pin + off + (size_t)P * T * W, m->d_diagG.p, C * sizeof(double), hipMemcpyDeviceToHost, m->st));
-        HIP_TRY(hipStreamSynchronize(m->st));
+        if ((rc = wait_stream(m->st))) return rc;
         if ((rc = factorize_finish(m, ga, lml, info))) return rc;
         std::memcpy(moments, m->h_pin + off, (size_t)P * T * W * sizeof(double));
         std::memcpy(diagG, m->h_pin + off + (size_t)P * T * W, C * sizeof(double));
