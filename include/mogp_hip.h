@@ -192,6 +192,16 @@ int  mogp_stage_ms(mogp_model* m, double* ms, int64_t* gemm_launches, double* ge
  *        2 = alpha (N).  Output in the caller's original row order, full N x N (symmetrised / lower-filled). */
 int  mogp_model_fetch(mogp_model* m, int which, double* out);
 
+/* The pseudo-input sparse GP of Snelson & Ghahramani (FITC) on the model's data: reference gpr/model.py:516-541
+ * (Snelson.log_marginal_likelihood) + the autograd backward through it, and :543-576 (Snelson.predict_f).
+ * Z: M x (1 + D) inducing inputs in kernel format (channel id first); noise_var[C] = sigma_c^2; kff_diag[C] / kss_diag[C] = K_diag per channel.
+ * Gradient outputs as for mogp_titsias_eval (moments of the adjoints of Kuu and Kuf, d/dZ, tr dp/dKuu for the jitter term), and
+ * hsum[C] = sum over the points of a channel of dp/dKff_nn = dp/dsigma_n^2. */
+int  mogp_snelson_eval(mogp_model* m, int64_t M, const double* Z, const double* noise_var, double jitter, const double* kff_diag, int flags,
+                       double* lml, double* mom_uu, double* mom_uf, double* gZ, double* trGA, double* hsum, double* jitter_abs, int64_t* info);
+int  mogp_snelson_predict(mogp_model* m, int64_t M, const double* Z, const double* noise_var, double jitter, const double* kff_diag,
+                          const double* kss_diag, int64_t S, const double* Xs, double* mu, double* var, int64_t* info);
+
 /* Host-side pair algebra of the MOSM kernel in native code (no device work): the cross-spectral term table of every channel pair
  * (reference gpr/multioutput.py:178-204) and the reverse-mode gradient autograd takes through it.
  * w (C,Q), mu / v / th (C,Q,D), ph (C,Q) are the CONSTRAINED weight, mean, variance, delay, phase; table is [C][C][Q][2+3D];

@@ -70,6 +70,11 @@ SIGNATURES = {
     "mogp_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "mogp_stage_ms": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i64p, c_dp]),
     "mogp_model_fetch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_dp]),
+    "mogp_snelson_eval": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_double), c_dp, c_dp, c_dp, ctypes.POINTER(ctypes.c_double), c_dp,
+                                         ctypes.POINTER(ctypes.c_double), c_i64p]),
+    "mogp_snelson_predict": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, c_dp, ctypes.c_double, c_dp, c_dp, ctypes.c_int64, c_dp,
+                                            c_dp, c_dp, c_i64p]),
     "mogp_mosm_terms": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, ctypes.c_double, ctypes.c_double, c_dp]),
     "mogp_mosm_terms_backward": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, ctypes.c_double,
                                                 ctypes.c_double, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
@@ -306,6 +311,33 @@ class ExactHandle:
         mu, var = np.empty(S), np.empty(S)
         info = ctypes.c_int64(0)
         code = lib().mogp_titsias_predict(self._h, Z.shape[0], _dp(Z), float(sigma), float(jitter), _dp(kss_diag), S, _dp(Xs),
+                                          _dp(mu), _dp(var), ctypes.byref(info))
+        check(code, info.value)
+        return mu.reshape(-1, 1), var.reshape(-1, 1)
+
+    def snelson_eval(self, Z, noise_var, jitter, kff_diag, grad=True):
+        """Snelson (FITC) marginal likelihood (+ gradient outputs) through mogp_snelson_eval"""
+        Z, noise_var, kff_diag = _f64(Z), _f64(noise_var), _f64(kff_diag)
+        M = Z.shape[0]
+        C, T, W, D = self.C, self.T, 2 + 3 * self.D, self.D
+        lml, trGA, jit = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        info = ctypes.c_int64(0)
+        mom_uu = np.zeros((C * (C + 1) // 2, T, W)) if grad else None
+        mom_uf = np.zeros((C * C, T, W)) if grad else None
+        gZ = np.zeros((M, D)) if grad else None
+        hsum = np.zeros(C) if grad else None
+        code = lib().mogp_snelson_eval(self._h, M, _dp(Z), _dp(noise_var), float(jitter), _dp(kff_diag), MOGP_EVAL_GRAD if grad else 0,
+                                       ctypes.byref(lml), _dp(mom_uu), _dp(mom_uf), _dp(gZ), ctypes.byref(trGA), _dp(hsum),
+                                       ctypes.byref(jit), ctypes.byref(info))
+        check(code, info.value)
+        return dict(lml=lml.value, mom_uu=mom_uu, mom_uf=mom_uf, gZ=gZ, trGA=trGA.value, hsum=hsum, jitter_abs=jit.value)
+
+    def snelson_predict(self, Z, noise_var, jitter, Xs, kff_diag, kss_diag):
+        Z, Xs, noise_var, kff_diag, kss_diag = _f64(Z), _f64(Xs), _f64(noise_var), _f64(kff_diag), _f64(kss_diag)
+        S = Xs.shape[0]
+        mu, var = np.empty(S), np.empty(S)
+        info = ctypes.c_int64(0)
+        code = lib().mogp_snelson_predict(self._h, Z.shape[0], _dp(Z), _dp(noise_var), float(jitter), _dp(kff_diag), _dp(kss_diag), S, _dp(Xs),
                                           _dp(mu), _dp(var), ctypes.byref(info))
         check(code, info.value)
         return mu.reshape(-1, 1), var.reshape(-1, 1)

@@ -131,6 +131,7 @@ struct TitsiasWork {
     DevBuf<double> Kus, Aus, Bus;                       // prediction panels (Mpad x Spad)
     DevBuf<double> zero_col;                            // Mpad zeros
     DevBuf<double> kslices;                             // split-K partial sums of the Qs SYRK (ks x Mpad x Mpad)
+    DevBuf<double> nvec;                                // Snelson: per-point vectors (g, G, G y, sqrt G, v^T r / w, alpha, h) + per-channel inputs
     PhaseWs ph_zz, ph_zx, ph_zs;                        // phase tables: (Z, Z), (Z, X), (Z, Xs)
     void release() {
         ph_zz.release(); ph_zx.release(); ph_zs.release();
@@ -138,7 +139,7 @@ struct TitsiasWork {
         zx.release(); B.release(); v.release(); GB.release(); Qs.release(); E.release(); R.release(); T1.release(); GA.release(); Hm.release();
         vec.release(); scratch.release(); gz.release(); partial_uu.release(); partial_uf.release(); mom_uu.release(); mom_uf.release();
         zero_noise.release(); tiles_uu.release(); tiles_uf.release(); ps_uu.release(); ps_uf.release();
-        Kus.release(); Aus.release(); Bus.release(); zero_col.release(); kslices.release();
+        Kus.release(); Aus.release(); Bus.release(); zero_col.release(); kslices.release(); nvec.release();
     }
 };
 

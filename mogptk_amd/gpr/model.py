@@ -461,3 +461,100 @@ class Titsias(Model):
         if self.mean is not None:
             mu = mu + np.asarray(self.mean(X)).reshape(-1, 1)
         return mu, var
+
+
+class Snelson(Model):
+    """
+    Sparse GP regression with pseudo-inputs, Snelson & Ghahramani 2005 (reference gpr/model.py:485-576): the FITC marginal likelihood
+        p = log N(y | 0, Qff + diag(Kff - Qff) + sigma^2 I),   Qff = Kfu Kuu^-1 Kuf,
+    with trainable inducing inputs `Z` (their channel column carries no gradient) and a scalar or per-channel noise variance.
+    """
+
+    def __init__(self, kernel, X, y, Z=10, Z_init="grid", variance=1.0, jitter=1e-8, mean=None):
+        variance = np.squeeze(Parameter.to_tensor(variance))
+        if 1 < variance.ndim or variance.ndim == 1 and variance.shape[0] != kernel.output_dims:
+            raise ValueError("variance must be float or have shape (channels,)")
+        super().__init__(kernel, X, y, GaussianLikelihood(np.sqrt(variance)), jitter, mean)
+        Z = init_inducing_points(Z, self.X, method=Z_init, output_dims=kernel.output_dims)
+        Z = self._check_input(Z)
+        self.log_marginal_likelihood_constant = 0.5 * self.X.shape[0] * np.log(2.0 * np.pi)
+        self.Z = Parameter(Z, name="induction_points")
+        if kernel.output_dims is not None:
+            self.Z.num_parameters -= self.Z().shape[0]
+
+    def _device_handle(self):
+        if self._handle is None:
+            from .._lib import ExactHandle
+            y = self.y if self.mean is None else self.y - np.asarray(self.mean(self.X)).reshape(-1, 1)
+            self._handle = ExactHandle(config.device, self.kernel._kernel_format(self.X), y, self.kernel._channels())
+        return self._handle
+
+    def _noise_vector(self):
+        """sigma_c^2 per channel (a scalar scale is shared by all channels: reference _index_channel, gpr/model.py:183-186)"""
+        s = np.asarray(self.likelihood.scale(), dtype=np.float64)
+        C = self.kernel._channels()
+        if s.ndim == 1 and s.shape[0] == C and self.kernel.output_dims is not None:
+            return s * s
+        return np.repeat(s.reshape(-1)[0] ** 2, C)
+
+    def _run(self, grad):
+        from .._lib import MogpError, MOGP_ENOTPD, MOGP_ENONFINITE
+        h = self._device_handle()
+        D = self.X.shape[1] - (0 if self.kernel.output_dims is None else 1)
+        table = self.kernel._spectral_terms(D)
+        h.set_terms(table)
+        Zk = self.kernel._kernel_format(self.Z())
+        try:
+            res = h.snelson_eval(Zk, self._noise_vector(), self.jitter, self.kernel._spectral_diag(D), grad=grad)
+        except MogpError as e:
+            if e.code in (MOGP_ENOTPD, MOGP_ENONFINITE):
+                print("ERROR:", str(e), file=sys.__stdout__)
+                self.print_parameters()
+                raise CholeskyException(str(e), None, self)
+            raise
+        return res, table, D, Zk
+
+    def log_marginal_likelihood(self):
+        """reference gpr/model.py:516-541"""
+        res, _, _, _ = self._run(grad=False)
+        return config.dtype(res["lml"])
+
+    def _loss_impl(self):
+        self.zero_grad(set_to_none=True)
+        res, table, D, Zk = self._run(grad=True)
+        C = table.shape[0]
+        M = Zk.shape[0]
+        zc = np.bincount(Zk[:, 0].astype(np.int64), minlength=C).astype(np.float64)
+        gt = _gtable_from_moments(table, res["mom_uu"], D, lower=True) + _gtable_from_moments(table, res["mom_uf"], D, lower=False)
+        for i in range(C):
+            gt[i, i, :, 0] += self.jitter * res["trGA"] * zc[i] / M          # jitter * mean(diag Kuu), gpr/model.py:244
+        self.kernel._spectral_backward(-gt)
+        hsum = np.asarray(res["hsum"], dtype=np.float64)                     # d p / d Kff_diag = d p / d sigma^2, summed per channel
+        self.kernel._spectral_diag_backward(-hsum, D)
+        scale = self.likelihood.scale
+        sc = np.asarray(scale(), dtype=np.float64)
+        if sc.ndim == 1 and sc.shape[0] == C and self.kernel.output_dims is not None:
+            gsc = 2.0 * sc * hsum
+        else:
+            gsc = np.reshape(2.0 * sc * np.sum(hsum), sc.shape)
+        scale.accumulate_grad(-gsc)
+        gz = np.zeros(self.Z.data.shape)
+        off = 0 if self.kernel.output_dims is None else 1
+        gz[:, off:] = -res["gZ"]
+        self.Z.accumulate_grad(gz)
+        return config.dtype(-res["lml"] - self.log_prior())
+
+    def predict_f(self, X, full=False):
+        """reference gpr/model.py:543-576 (its full=True branch uses undefined names; not on this path either)"""
+        if full:
+            raise NotImplementedError("full predictive covariance for Snelson is not on the HIP path")
+        X = self._check_input(X)
+        h = self._device_handle()
+        D = self.X.shape[1] - (0 if self.kernel.output_dims is None else 1)
+        h.set_terms(self.kernel._spectral_terms(D))
+        kd = self.kernel._spectral_diag(D)
+        mu, var = h.snelson_predict(self.kernel._kernel_format(self.Z()), self._noise_vector(), self.jitter,
+                                    self.kernel._kernel_format(X), kd, kd)
+        if self.mean is not None:
+            mu = mu + np.asarray(self.mean(X)).reshape(-1, 1)
+        return mu, var

@@ -84,6 +84,30 @@ class Titsias:
                            variance=self.variance, jitter=self.jitter, mean=mean)
 
 
+class Snelson:
+    """
+    Sparse inference of Snelson & Ghahramani 2005 (reference mogptk/model.py:102-120).
+
+    Args:
+        inducing_points (int, list): number of inducing points (PER CHANNEL for multi-output kernels) or locations.
+        init_inducing_points (str): `grid`, `random`, or `density`.
+        variance (float, array): variance of the Gaussian likelihood (a float: one trained variance; (channels,): one per channel).
+        jitter (float): relative jitter added before the Cholesky.
+    """
+
+    def __init__(self, inducing_points=10, init_inducing_points="grid", variance=None, jitter=1e-6):
+        self.inducing_points = inducing_points
+        self.init_inducing_points = init_inducing_points
+        self.variance = variance
+        self.jitter = jitter
+
+    def _build(self, kernel, x, y, y_err=None, mean=None):
+        variance = self.variance
+        if variance is None:
+            variance = [1.0] * kernel.output_dims if kernel.output_dims is not None else 1.0
+        return gpr.Snelson(kernel, x, y, Z=self.inducing_points, Z_init=self.init_inducing_points, variance=variance, jitter=self.jitter, mean=mean)
+
+
 # ---- optimisers over raw parameters (torch.optim semantics) -----------------------------------------
 class _Adam:
     """torch.optim.Adam(params, lr=1e-3, betas=(0.9,0.999), eps=1e-8, weight_decay=0, amsgrad=False)"""

@@ -726,6 +726,39 @@ def gen_cfg5():
     print("cfg5.npz loss=%.10f (%.1f s)" % (loss, dt))
 
 
+def gen_snelson():
+    """small Snelson (FITC) fixtures, reference gpr/model.py:485-576: marginal likelihood, gradients of every parameter (kernel, scalar and
+    per-channel noise scale, inducing points incl. the gradient-free channel column), predict_f"""
+    out = {}
+    cases = [(3, 2, 90, [4, 5, 3], False, "vector"), (2, 3, 120, 6, True, "scalar"), (1, 2, 60, [7], False, "scalar"), (2, 2, 80, 5, False, "vector")]
+    out["ncases"] = np.array(len(cases))
+    for n, (C, Q, N, Zspec, shuffle, noise) in enumerate(cases):
+        rng = np.random.default_rng(9500 + n)
+        X, y = small_data(N, C, 1, 9600 + n, shuffle)
+        k = g.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=1)
+        k.weight.assign(rng.uniform(0.5, 1.5, (C, Q))); k.mean.assign(rng.uniform(0.05, 0.5, (C, Q, 1)))
+        k.variance.assign(rng.uniform(0.05, 0.5, (C, Q, 1))); k.delay.assign(rng.normal(0, 0.3, (C, Q, 1))); k.phase.assign(rng.normal(0, 0.3, (C, Q)))
+        var = rng.uniform(0.02, 0.15, C) if noise == "vector" else float(rng.uniform(0.02, 0.15))
+        Z = Zspec if isinstance(Zspec, int) else None
+        if Z is None:
+            Z = np.concatenate([np.stack([np.full(z, float(c)), np.sort(rng.uniform(0, 10, z))], axis=1) for c, z in enumerate(Zspec)])
+        m = g.Snelson(k, T(X), T(y), Z=(Z if isinstance(Z, int) else T(Z)), variance=(T(var) if noise == "vector" else var), jitter=1e-6)
+        pre = "c%d_" % n
+        out[pre + "meta"] = np.array([C, Q, 1, 1]); out[pre + "X"] = X; out[pre + "y"] = y
+        out[pre + "Z"] = m.Z().detach().numpy(); out[pre + "variance"] = np.asarray(var); out[pre + "jitter"] = np.array(m.jitter)
+        out[pre + "kparams"] = np.array(0)
+        for name in ("weight", "mean", "variance", "delay", "phase"):
+            out[pre + "k_" + name] = getattr(k, name)().detach().numpy()
+        out[pre + "lml"] = np.array(float(m.log_marginal_likelihood()))
+        out[pre + "loss"] = np.array(float(m.loss()))
+        dump_params(pre, list(m.parameters()), out, with_grad=True)
+        Xs, _ = small_data(23, C, 1, 9700 + n, shuffle)
+        mu, var_p = m.predict_f(T(Xs))
+        out[pre + "Xs"] = Xs; out[pre + "mu"] = mu.numpy(); out[pre + "var"] = var_p.numpy()
+    np.savez_compressed(os.path.join(HERE, "snelson.npz"), **out)
+    print("snelson.npz written")
+
+
 def gen_checkpoints():
     """Files written by the reference's own Model.save() (model.py:320-336) -- the whole pickled model: MOSM with a fitted transformer
     chain, removed points and a pegged + a fixed parameter; the SM, CSM, SM-LMC and CONV wrappers; a Titsias MOSM -- stored as bytes next to what
@@ -795,6 +828,7 @@ def gen_checkpoints():
     m = mogptk.SM_LMC(dataset(3, 25), Q=2, Rq=1); randomise(m); record("smlmc", m)
     m = mogptk.CONV(dataset(2, 30), Q=2); randomise(m); record("conv", m)
     m = mogptk.MOSM(dataset(2, 60), Q=1, inference=mogptk.Titsias(inducing_points=8)); randomise(m); record("titsias", m)
+    m = mogptk.MOSM(dataset(2, 60), Q=1, inference=mogptk.Snelson(inducing_points=7)); randomise(m); record("snelson", m)
     np.savez_compressed(os.path.join(HERE, "checkpoints.npz"), **out)
     print("checkpoints.npz", {k: v.shape for k, v in out.items() if k.endswith("_file")})
 
@@ -806,7 +840,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "lbfgs": gen_lbfgs_cfg1, "quirks": gen_quirks,
              "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2, "smlmc": gen_smlmc, "init_ls": gen_init_ls, "bnse": gen_bnse, "transformers": gen_transformers,
-             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints}
+             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints, "snelson": gen_snelson}
     full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:
         {**steps, **full}[a.only]()

@@ -496,3 +496,44 @@ def test_reference_checkpoints_on_device(tmp_path):
     pytest.importorskip("torch")
     from test_host_logic import check_reference_checkpoints
     check_reference_checkpoints(tmp_path, tol_loss=1e-8, tol_grad=1e-6, tol_pred=1e-6)
+
+
+def test_snelson_on_device():
+    """the Snelson (FITC) model on the device against the reference -- marginal likelihood, gradients of kernel / noise /
+    inducing inputs (scalar and per-channel noise), predict_f"""
+    from test_host_logic import check_snelson
+    check_snelson(tol_lml=1e-9, tol_grad=1e-6, tol_pred=1e-7)
+
+
+@pytest.mark.parametrize("N,M", [(699, 150), (1024, 300), (2048, 520)])
+def test_snelson_device_raw_outputs_against_numpy_model(N, M):
+    """the device against the numpy twin at sizes with several tile rows of inducing points, N both a multiple of 128 (beta rides in a panel
+    of its own) and not (in the padding column), shuffled rows, per-channel noise; and the prediction"""
+    rng = np.random.default_rng(N)
+    C, Q = 3, 2
+    X, _ = synth.make_data(N - N % C + (3 if N % C else 0), C)
+    X = X[rng.permutation(X.shape[0])][:N]
+    X = X[np.argsort(rng.random(N))]
+    y = rng.standard_normal(N)
+    Z = np.concatenate([np.stack([np.full(M // C, float(c)), np.sort(rng.uniform(0, 100, M // C))], axis=1) for c in range(C)])
+    Z = Z[rng.permutation(Z.shape[0])]
+    h = synth.mosm_hypers(C, Q)
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
+    for name in ("weight", "mean", "variance", "delay", "phase"):
+        getattr(k, name).assign(h[name])
+    table = k._spectral_terms(1)
+    kd = k._spectral_diag(1)
+    noise = rng.uniform(0.05, 0.3, C)
+    dev = _lib.ExactHandle(0, X, y, C)
+    ref = TableDevice(0, X, y, C)
+    dev.set_terms(table); ref.set_terms(table)
+    a = dev.snelson_eval(Z, noise, 1e-6, kd, grad=True)
+    b = ref.snelson_eval(Z, noise, 1e-6, kd, grad=True)
+    assert abs(a["lml"] - b["lml"]) < 1e-9 * abs(b["lml"])
+    for key in ("mom_uu", "mom_uf", "gZ", "hsum"):
+        assert np.max(np.abs(a[key] - b[key])) < 1e-6 * np.max(np.abs(b[key])), (key, np.max(np.abs(a[key] - b[key])) / np.max(np.abs(b[key])))
+    assert abs(a["trGA"] - b["trGA"]) < 1e-6 * abs(b["trGA"])
+    Xs = np.concatenate([np.stack([np.full(37, float(c)), np.linspace(0, 105, 37)], axis=1) for c in range(C)])
+    mu, var = dev.snelson_predict(Z, noise, 1e-6, Xs, kd, kd)
+    mu_r, var_r = ref.snelson_predict(Z, noise, 1e-6, Xs, kd, kd)
+    assert relerr(mu, mu_r) < 1e-8 and np.max(np.abs(var - var_r)) < 1e-8

@@ -546,14 +546,14 @@ def test_mohsm_predict_and_wrapper_match_reference():
 
 
 # ---- checkpoints written by the reference's Model.save() load without the reference ----------------------------------
-def check_reference_checkpoints(tmp_path, tol_value=1e-12, tol_loss=1e-8, tol_grad=1e-6, tol_pred=1e-6, tags=("mosm", "sm", "csm", "smlmc", "conv", "titsias")):
+def check_reference_checkpoints(tmp_path, tol_value=1e-12, tol_loss=1e-8, tol_grad=1e-6, tol_pred=1e-6, tags=("mosm", "sm", "csm", "smlmc", "conv", "titsias", "snelson")):
     """checkpoints.npz: the bytes of files the reference wrote, and what the reference itself computes after loading them"""
     fx = load("checkpoints.npz")
     for tag in tags:
         path = tmp_path / ("ref_%s" % tag)
         (tmp_path / ("ref_%s.npy" % tag)).write_bytes(fx[tag + "_file"].tobytes())
         m = mogptk_amd.LoadModel(str(path))
-        assert type(m).__name__ == {"mosm": "MOSM", "sm": "SM", "csm": "CSM", "smlmc": "SM_LMC", "conv": "CONV", "titsias": "MOSM"}[tag]
+        assert type(m).__name__ == {"mosm": "MOSM", "sm": "SM", "csm": "CSM", "smlmc": "SM_LMC", "conv": "CONV", "titsias": "MOSM", "snelson": "MOSM"}[tag]
         ps = list(m.gpr.parameters())
         assert [p._name for p in ps] == [str(n) for n in fx[tag + "_names"]]
         for i, p in enumerate(ps):
@@ -586,3 +586,46 @@ def test_reference_checkpoints_load_without_the_reference(tmp_path):
     import sys
     assert "mogptk" not in sys.modules
     check_reference_checkpoints(tmp_path)
+
+
+# ---- the Snelson (FITC) model, pinned on the reference (gpr/model.py:485-576) -----------------------------------------
+def check_snelson(tol_lml=1e-9, tol_grad=1e-7, tol_pred=1e-8):
+    fx = load("snelson.npz")
+    for n in range(int(fx["ncases"])):
+        pre = "c%d_" % n
+        C, Q, D, _ = [int(v) for v in fx[pre + "meta"]]
+        fp = fixture_params(fx, pre)
+        k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=D)
+        var = fx[pre + "variance"]
+        m = gpr.Snelson(k, fx[pre + "X"], fx[pre + "y"], Z=fx[pre + "Z"], variance=(var if var.ndim else float(var)), jitter=float(fx[pre + "jitter"]))
+        assert [p._name.split(".")[-1] for p in m.parameters()] == [f["name"].split(".")[-1] for f in fp]
+        load_raw(m.parameters(), fp)
+        lml, ref = float(m.log_marginal_likelihood()), float(fx[pre + "lml"])
+        assert abs(lml - ref) < tol_lml * max(1.0, abs(ref)), (n, lml, ref)
+        loss, ref = float(m.loss()), float(fx[pre + "loss"])
+        assert abs(loss - ref) < tol_lml * max(1.0, abs(ref)), (n, loss, ref)
+        for p, f in zip(m.parameters(), fp):
+            if f["grad"] is None:
+                assert p.grad is None, p._name
+            else:
+                assert np.max(np.abs(p.grad - f["grad"])) <= tol_grad * max(1.0, np.max(np.abs(f["grad"]))), (n, p._name, p.grad, f["grad"])
+        assert np.all(m.Z.grad[:, 0] == 0.0)
+        mu, var_p = m.predict_f(fx[pre + "Xs"])
+        assert relerr(mu, fx[pre + "mu"]) < tol_pred and np.max(np.abs(var_p - fx[pre + "var"])) < tol_pred, n
+
+
+def test_snelson_matches_reference():
+    check_snelson()
+
+
+def test_snelson_through_the_model_wrapper():
+    t = np.linspace(0, 10, 40)
+    ds = mogptk_amd.DataSet(t, [np.sin(t), np.cos(t)])
+    m = mogptk_amd.MOSM(ds, Q=2, inference=mogptk_amd.Snelson(inducing_points=5))
+    assert type(m.gpr).__name__ == "Snelson" and m.gpr.Z().shape == (10, 2)          # 5 per channel, like the reference (quirk Q5)
+    assert m.gpr.likelihood.scale().shape == (2,)                                      # variance None -> one per channel (model.py:114-118)
+    m.gpr.kernel.mean.assign(np.full((2, 2, 1), 0.1))
+    losses, _ = m.train("Adam", iters=3, lr=0.05)
+    assert losses.shape == (4,) and np.all(np.isfinite(losses))
+    _, mu, lower, upper = m.predict(transformed=False)
+    assert all(np.all(np.isfinite(v)) for v in mu) and all(np.all(lo <= up) for lo, up in zip(lower, upper))
