@@ -262,7 +262,7 @@ def main():
         run_step()
     stage = np.zeros(_lib.ST_COUNT)
     acc = dict(flops=0.0, launches=0, nprof=0)
-    PROFILE_EVERY = 10          # HIP events around every GEMM launch cost ~5 % of a step: sample one step in ten, inside the timed region
+    PROFILE_EVERY = max(20, steps)          # HIP events around every GEMM launch cost ~5 % of a step: ONE timed step (the first) carries them
 
     def step(i):
         prof = i >= 0 and (i % PROFILE_EVERY) == 0 and kind == "exact" and not sharded_mode
