@@ -202,6 +202,18 @@ int  mogp_snelson_eval(mogp_model* m, int64_t M, const double* Z, const double* 
 int  mogp_snelson_predict(mogp_model* m, int64_t M, const double* Z, const double* noise_var, double jitter, const double* kff_diag,
                           const double* kss_diag, int64_t S, const double* Xs, double* mu, double* var, int64_t* info);
 
+/* The variational GP of Hensman et al. (whitened; reference gpr/model.py:767-886), the O(N M^2) algebra around ANY likelihood, in two calls
+ * per evaluation.  forward: mean and variance of q(f) at the training inputs (S = 0; the state for the backward call is kept in the handle)
+ * or at S test inputs -- SparseHensman._predict_f (:851-868); q_mu[M], q_sqrt[M x M] (its lower triangle is used) in the order of Z's rows;
+ * dense != 0: the non-sparse model at its own inputs (:834-840; M = N, Z = the data points).  The caller evaluates its likelihood's
+ * expectation E(mu, var) and hands e = dE/dmu, f = dE/dvar (per training point, caller order) to backward, which returns the moments of
+ * the adjoints of Kuu / Kuf (as mogp_titsias_eval), d/dZ, tr dE/dKuu (jitter term), dE/dq_mu[M] and dE/dS[M x M] (take its lower triangle). */
+int  mogp_svgp_forward(mogp_model* m, int64_t M, const double* Z, const double* q_mu, const double* q_sqrt, double jitter,
+                       const double* kff_diag, int dense, int64_t S, const double* Xs, const double* kss_diag,
+                       double* mu, double* var, double* jitter_abs, int64_t* info);
+int  mogp_svgp_backward(mogp_model* m, const double* e, const double* f, double* mom_uu, double* mom_uf, double* gZ, double* trGA,
+                        double* g_qmu, double* g_qsqrt);
+
 /* Host-side pair algebra of the MOSM kernel in native code (no device work): the cross-spectral term table of every channel pair
  * (reference gpr/multioutput.py:178-204) and the reverse-mode gradient autograd takes through it.
  * w (C,Q), mu / v / th (C,Q,D), ph (C,Q) are the CONSTRAINED weight, mean, variance, delay, phase; table is [C][C][Q][2+3D];

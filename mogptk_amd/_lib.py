@@ -75,6 +75,9 @@ SIGNATURES = {
                                          ctypes.POINTER(ctypes.c_double), c_i64p]),
     "mogp_snelson_predict": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, c_dp, ctypes.c_double, c_dp, c_dp, ctypes.c_int64, c_dp,
                                             c_dp, c_dp, c_i64p]),
+    "mogp_svgp_forward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.c_int, ctypes.c_int64,
+                                         c_dp, c_dp, c_dp, c_dp, ctypes.POINTER(ctypes.c_double), c_i64p]),
+    "mogp_svgp_backward": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp, ctypes.POINTER(ctypes.c_double), c_dp, c_dp]),
     "mogp_mosm_terms": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, ctypes.c_double, ctypes.c_double, c_dp]),
     "mogp_mosm_terms_backward": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, ctypes.c_double,
                                                 ctypes.c_double, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
@@ -341,6 +344,32 @@ class ExactHandle:
                                           _dp(mu), _dp(var), ctypes.byref(info))
         check(code, info.value)
         return mu.reshape(-1, 1), var.reshape(-1, 1)
+
+    def svgp_forward(self, Z, q_mu, q_sqrt, jitter, kff_diag, Xs=None, kss_diag=None, dense=False):
+        """mean / variance of q(f) of the Hensman models at the training inputs (Xs None) or at Xs, through mogp_svgp_forward"""
+        Z, q_mu, q_sqrt, kff_diag = _f64(Z), _f64(np.reshape(q_mu, -1)), _f64(q_sqrt), _f64(kff_diag)
+        M = Z.shape[0]
+        S = 0 if Xs is None else int(np.shape(Xs)[0])
+        Xs = None if Xs is None else _f64(Xs)
+        kss = None if kss_diag is None else _f64(kss_diag)
+        n = self.N if Xs is None else S
+        mu, var = np.empty(n), np.empty(n)
+        jit = ctypes.c_double()
+        info = ctypes.c_int64(0)
+        code = lib().mogp_svgp_forward(self._h, M, _dp(Z), _dp(q_mu), _dp(q_sqrt), float(jitter), _dp(kff_diag), 1 if dense else 0, S,
+                                       _dp(Xs), _dp(kss), _dp(mu), _dp(var), ctypes.byref(jit), ctypes.byref(info))
+        check(code, info.value)
+        self._svgp_M = M
+        return dict(mu=mu, var=var, jitter_abs=jit.value)
+
+    def svgp_backward(self, e, f):
+        e, f = _f64(np.reshape(e, -1)), _f64(np.reshape(f, -1))
+        C, T, W, D, M = self.C, self.T, 2 + 3 * self.D, self.D, self._svgp_M
+        mom_uu, mom_uf = np.zeros((C * (C + 1) // 2, T, W)), np.zeros((C * C, T, W))
+        gZ, g_qmu, g_S = np.zeros((M, D)), np.zeros(M), np.zeros((M, M))
+        trGA = ctypes.c_double()
+        check(lib().mogp_svgp_backward(self._h, _dp(e), _dp(f), _dp(mom_uu), _dp(mom_uf), _dp(gZ), ctypes.byref(trGA), _dp(g_qmu), _dp(g_S)))
+        return dict(mom_uu=mom_uu, mom_uf=mom_uf, gZ=gZ, trGA=trGA.value, g_qmu=g_qmu, g_qsqrt=g_S)
 
     def set_profiling(self, on=True):
         check(lib().mogp_set_profiling(self._h, 1 if on else 0))

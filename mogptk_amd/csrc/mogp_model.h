@@ -131,6 +131,8 @@ struct TitsiasWork {
     DevBuf<double> Kus, Aus, Bus;                       // prediction panels (Mpad x Spad)
     DevBuf<double> zero_col;                            // Mpad zeros
     DevBuf<double> kslices;                             // split-K partial sums of the Qs SYRK (ks x Mpad x Mpad)
+    // svgp.hip: what the forward pass at the training inputs leaves for the backward pass
+    SortedX sv_sz; std::vector<GTile> sv_tuu, sv_tuf; std::vector<int> sv_psuu, sv_psuf; int64_t sv_M = 0; bool sv_dense = false, sv_valid = false;
     DevBuf<double> nvec;                                // Snelson: per-point vectors (g, G, G y, sqrt G, v^T r / w, alpha, h) + per-channel inputs
     PhaseWs ph_zz, ph_zx, ph_zs;                        // phase tables: (Z, Z), (Z, X), (Z, Xs)
     void release() {

@@ -35,6 +35,22 @@ class GaussianLikelihood(Likelihood):
         c = X[:, 0].astype(np.int64)
         return [np.nonzero(c == i)[0] for i in range(self.output_dims)]
 
+    def variational_expectation(self, X, y, mu, var, grad=False):
+        """E_q[log p(y | f)] summed over the points, q(f_n) = N(mu_n, var_n) -- closed form for the Gaussian (reference likelihood.py:338-343).
+        grad=True also returns dE/dmu, dE/dvar (per point) and dE/dscale.  Scalar scale only: the reference's formula broadcasts a
+        per-channel scale against the points (N x C terms) instead of indexing it."""
+        s = np.asarray(self.scale(), dtype=np.float64)
+        if s.size != 1:
+            raise NotImplementedError("variational_expectation with a per-channel Gaussian scale follows a defective reference formula "
+                                      "(likelihood.py:338-343 broadcasts (N,1) against (channels,)); use a scalar scale")
+        s = float(s.reshape(-1)[0])
+        y, mu, var = np.reshape(y, -1), np.reshape(mu, -1), np.reshape(var, -1)
+        r2 = (y - mu) ** 2 + var
+        ve = 0.5 * np.sum(-r2 / s ** 2 - np.log(2.0 * np.pi) - 2.0 * np.log(s))
+        if not grad:
+            return ve
+        return ve, (y - mu) / s ** 2, np.full(y.shape, -0.5 / s ** 2), np.sum(r2) / s ** 3 - y.size / s
+
     def predict(self, X, mu, var, ci=None, sigma=None, n=10000):
         """reference likelihood.py:351-378, quirk Q4 included: with a per-channel scale the interval is
         mu -/+ sigma*scale_c and ignores the GP variance; the single-output branch adds scale^2 to var."""

@@ -558,3 +558,131 @@ class Snelson(Model):
         if self.mean is not None:
             mu = mu + np.asarray(self.mean(X)).reshape(-1, 1)
         return mu, var
+
+
+class SparseHensman(Model):
+    """
+    Sparse variational GP of Hensman et al. 2015, whitened (reference gpr/model.py:767-878): q(u) = N(L q_mu, L S S^T L^T), L L^T = Kuu,
+    S = tril(q_sqrt);  ELBO = E_q[log p(y | f)] - KL(q || p).  The O(N M^2) algebra runs on the device in two calls around the
+    likelihood: forward -> per-point mu, var of q(f) at the training inputs; the likelihood (host, O(N)) returns its expectation and
+    dE/dmu, dE/dvar; backward -> the gradients of kernel, inducing inputs, q_mu, q_sqrt.  On this path: the Gaussian likelihood.
+    The KL term mirrors the reference's (:816-822), which counts only the DIAGONAL of q_sqrt in the trace and the determinant.
+    """
+
+    def __init__(self, kernel, X, y, Z=None, Z_init="grid", likelihood=None, jitter=1e-8, mean=None):
+        if likelihood is None:
+            likelihood = GaussianLikelihood(1.0)
+        super().__init__(kernel, X, y, likelihood, jitter, mean)
+        n = self.X.shape[0]
+        self.is_sparse = Z is not None
+        if self.is_sparse:
+            Z = init_inducing_points(Z, self.X, method=Z_init, output_dims=kernel.output_dims)
+            Z = self._check_input(Z)
+            n = Z.shape[0]
+        self.log_marginal_likelihood_constant = 0.5 * self.X.shape[0] * np.log(2.0 * np.pi)
+        self.q_mu = Parameter(np.zeros((n, 1)))
+        self.q_sqrt = Parameter(np.eye(n))
+        self.q_sqrt.num_parameters = int((n * n + n) / 2)
+        if self.is_sparse:
+            self.Z = Parameter(Z, name="induction_points")
+            if kernel.output_dims is not None:
+                self.Z.num_parameters -= self.Z().shape[0]
+        else:
+            self.Z = Parameter(self.X, train=False)         # the data points themselves, not trained (reference :812)
+
+    def _device_handle(self):
+        if self._handle is None:
+            from .._lib import ExactHandle
+            y = self.y if self.mean is None else self.y - np.asarray(self.mean(self.X)).reshape(-1, 1)
+            self._handle = ExactHandle(config.device, self.kernel._kernel_format(self.X), y, self.kernel._channels())
+        return self._handle
+
+    def kl_gaussian(self, q_mu, q_sqrt):
+        """reference gpr/model.py:816-822"""
+        S_diag = np.diagonal(q_sqrt) ** 2
+        return 0.5 * (float(np.sum(q_mu * q_mu)) - np.sum(np.log(S_diag)) + np.sum(S_diag) - q_mu.shape[0])
+
+    def _forward(self):
+        from .._lib import MogpError, MOGP_ENOTPD, MOGP_ENONFINITE
+        h = self._device_handle()
+        D = self.X.shape[1] - (0 if self.kernel.output_dims is None else 1)
+        table = self.kernel._spectral_terms(D)
+        h.set_terms(table)
+        Zk = self.kernel._kernel_format(self.Z())
+        try:
+            res = h.svgp_forward(Zk, self.q_mu(), self.q_sqrt(), self.jitter, self.kernel._spectral_diag(D), dense=not self.is_sparse)
+        except MogpError as e:
+            if e.code in (MOGP_ENOTPD, MOGP_ENONFINITE):
+                print("ERROR:", str(e), file=sys.__stdout__)
+                self.print_parameters()
+                raise CholeskyException(str(e), None, self)
+            raise
+        return h, res, table, D, Zk
+
+    def _y(self):
+        return self.y if self.mean is None else self.y - np.asarray(self.mean(self.X)).reshape(-1, 1)
+
+    def elbo(self):
+        h, res, _, _, _ = self._forward()
+        ve = self.likelihood.variational_expectation(self.X, self._y(), res["mu"], res["var"])
+        return config.dtype(ve - self.kl_gaussian(self.q_mu(), self.q_sqrt()))
+
+    def log_marginal_likelihood(self):
+        """maximise the lower bound (reference gpr/model.py:847-849)"""
+        return self.elbo()
+
+    def _loss_impl(self):
+        self.zero_grad(set_to_none=True)
+        h, res, table, D, Zk = self._forward()
+        ve, e, f, dscale = self.likelihood.variational_expectation(self.X, self._y(), res["mu"], res["var"], grad=True)
+        q_mu, q_sqrt = np.asarray(self.q_mu(), dtype=np.float64), np.asarray(self.q_sqrt(), dtype=np.float64)
+        elbo = ve - self.kl_gaussian(q_mu, q_sqrt)
+        bw = h.svgp_backward(e, f)
+        C = table.shape[0]
+        M = Zk.shape[0]
+        zc = np.bincount(Zk[:, 0].astype(np.int64), minlength=C).astype(np.float64)
+        xc = self.kernel._kernel_format(self.X)[:, 0].astype(np.int64)
+        gt = _gtable_from_moments(table, bw["mom_uu"], D, lower=True) + _gtable_from_moments(table, bw["mom_uf"], D, lower=False)
+        for i in range(C):
+            gt[i, i, :, 0] += self.jitter * bw["trGA"] * zc[i] / M          # jitter * mean(diag Kuu), gpr/model.py:244
+        self.kernel._spectral_backward(-gt)
+        if self.is_sparse:                          # var_n = K_diag[c(n)] - ... (the dense model's variance at its own inputs has no such term)
+            self.kernel._spectral_diag_backward(-np.bincount(xc, weights=f, minlength=C), D)
+        scale = self.likelihood.scale
+        scale.accumulate_grad(np.reshape(-dscale, scale.data.shape))
+        self.q_mu.accumulate_grad(-(np.reshape(bw["g_qmu"], q_mu.shape) - q_mu))
+        s = np.diagonal(q_sqrt)
+        self.q_sqrt.accumulate_grad(-(np.tril(bw["g_qsqrt"]) - np.diag(s - 1.0 / s)))
+        if self.is_sparse:
+            gz = np.zeros(self.Z.data.shape)
+            off = 0 if self.kernel.output_dims is None else 1
+            gz[:, off:] = -bw["gZ"]
+            self.Z.accumulate_grad(gz)
+        return config.dtype(-elbo - self.log_prior())
+
+    def predict_f(self, X, full=False):
+        """reference gpr/model.py:851-878"""
+        if full:
+            raise NotImplementedError("full predictive covariance for the Hensman models is not on the HIP path")
+        X = self._check_input(X)
+        h = self._device_handle()
+        D = self.X.shape[1] - (0 if self.kernel.output_dims is None else 1)
+        h.set_terms(self.kernel._spectral_terms(D))
+        kd = self.kernel._spectral_diag(D)
+        res = h.svgp_forward(self.kernel._kernel_format(self.Z()), self.q_mu(), self.q_sqrt(), self.jitter, kd,
+                             Xs=self.kernel._kernel_format(X), kss_diag=kd)
+        mu = np.reshape(res["mu"], (-1, 1))
+        if self.mean is not None:
+            mu = mu + np.asarray(self.mean(X)).reshape(-1, 1)
+        return mu, np.reshape(res["var"], (-1, 1))
+
+
+class Hensman(SparseHensman):
+    """
+    The non-sparse variational GP (reference gpr/model.py:880-886): the inducing inputs ARE the data points and are not trained; at the
+    training inputs q(f) = N(L q_mu, L S S^T L^T) with L the factor of K_ff itself (reference :834-840) -- the same device algebra with
+    a = L^T instead of L^-1 K_uf.  Predictions at new inputs take the sparse formula with Z = X, like the reference (:851-868).
+    """
+
+    def __init__(self, kernel, X, y, likelihood=None, jitter=1e-8, mean=None):
+        super().__init__(kernel, X, y, None, "grid", likelihood, jitter, mean)

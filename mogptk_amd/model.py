@@ -108,6 +108,31 @@ class Snelson:
         return gpr.Snelson(kernel, x, y, Z=self.inducing_points, Z_init=self.init_inducing_points, variance=variance, jitter=self.jitter, mean=mean)
 
 
+class Hensman:
+    """
+    Variational inference of Hensman et al. 2015 (reference mogptk/model.py:159-178).  On this path with the Gaussian likelihood.
+
+    Args:
+        inducing_points (int, list): number of inducing points (PER CHANNEL for multi-output kernels) or locations; None (default): the
+            non-sparse model, whose variational distribution lives on the data points.
+        init_inducing_points (str): `grid`, `random`, or `density`.
+        likelihood (gpr.Likelihood): likelihood p(y|f) (default: Gaussian with unit scale).
+        jitter (float): relative jitter added before the Cholesky.
+    """
+
+    def __init__(self, inducing_points=None, init_inducing_points="grid", likelihood=None, jitter=1e-6):
+        self.inducing_points = inducing_points
+        self.init_inducing_points = init_inducing_points
+        self.likelihood = likelihood
+        self.jitter = jitter
+
+    def _build(self, kernel, x, y, y_err=None, mean=None):
+        likelihood = self.likelihood if self.likelihood is not None else gpr.GaussianLikelihood(1.0)
+        if self.inducing_points is None:
+            return gpr.Hensman(kernel, x, y, likelihood=likelihood, jitter=self.jitter, mean=mean)
+        return gpr.SparseHensman(kernel, x, y, Z=self.inducing_points, Z_init=self.init_inducing_points, likelihood=likelihood, jitter=self.jitter, mean=mean)
+
+
 # ---- optimisers over raw parameters (torch.optim semantics) -----------------------------------------
 class _Adam:
     """torch.optim.Adam(params, lr=1e-3, betas=(0.9,0.999), eps=1e-8, weight_decay=0, amsgrad=False)"""

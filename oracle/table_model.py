@@ -346,6 +346,84 @@ TableDevice.snelson_eval = snelson_eval
 TableDevice.snelson_predict = snelson_predict
 
 
+def svgp_forward(self, Z, q_mu, q_sqrt, jitter, kff_diag, Xs=None, kss_diag=None, dense=False):
+    """numpy twin of mogp_svgp_forward -- reference gpr/model.py:851-868 (SparseHensman._predict_f, whitened q(u) = N(L q_mu, L S S^T L^T)):
+        a = L^-1 K(Z, X*),  b = tril(q_sqrt)^T a,  mu = a^T q_mu,  var = K_diag - colsum(a^2) + colsum(b^2)
+    at the training inputs (Xs None; the state for svgp_backward is kept) or at test inputs.  dense (the non-sparse model, :834-840, at its
+    own training inputs): Z = X, a = L^T exactly and var = colsum(b^2)."""
+    from scipy.linalg import solve_triangular
+    table = self.table
+    M = Z.shape[0]
+    Kuu = gram_from_table(table, Z)
+    jit = jitter * np.mean(np.diagonal(Kuu))
+    Luu = np.linalg.cholesky(Kuu + jit * np.eye(M))
+    Xq = self.X if Xs is None else Xs
+    kd = np.asarray(kff_diag if Xs is None else kss_diag)[Xq[:, 0].astype(np.int64)]
+    S = np.tril(np.asarray(q_sqrt, dtype=np.float64))
+    qm = np.asarray(q_mu, dtype=np.float64).reshape(-1)
+    if dense and Xs is None:
+        a = Luu.T.copy()
+        b = S.T @ a
+        mu, var = a.T @ qm, np.sum(b * b, axis=0)
+    else:
+        a = solve_triangular(Luu, gram_from_table(table, Z, Xq), lower=True)
+        b = S.T @ a
+        mu = a.T @ qm
+        var = kd - np.sum(a * a, axis=0) + np.sum(b * b, axis=0)
+    if Xs is None:
+        self._svgp = dict(Z=np.array(Z), Luu=Luu, v=a, S=S, q_mu=qm, dense=bool(dense))
+    return dict(mu=mu, var=var, jitter_abs=jit)
+
+
+def svgp_backward(self, e, f):
+    """adjoints of  E(mu, var)  with  e = dE/dmu, f = dE/dvar  (any likelihood: the caller differentiates its own expectation):
+        Gv = q_mu e^T + 2 (S S^T - I) v diag f,   dE/dB = L^-T Gv,   dE/dA = -1/2 L^-T Psi(Gv v^T) L^-1   (Psi(Y) = tril(Y) mirrored),
+        dE/dq_mu = v e,   dE/dS = 2 (v diag(f) v^T) S  (lower part);
+    dense (v = L^T, a function of A alone):  Gv = q_mu e^T + 2 S S^T v diag f,   dE/dA = +1/2 L^-T Psi(v Gv^T) L^-1."""
+    from scipy.linalg import solve_triangular
+    st = self._svgp
+    X, table, C, D = self.X, self.table, self.C, self.D
+    Z, Luu, v, S, q_mu, dense = st["Z"], st["Luu"], st["v"], st["S"], st["q_mu"], st["dense"]
+    M = Z.shape[0]
+    e = np.asarray(e, dtype=np.float64).reshape(-1)
+    f = np.asarray(f, dtype=np.float64).reshape(-1)
+    cz = Z[:, 0].astype(np.int64)
+    cx = X[:, 0].astype(np.int64)
+    W = solve_triangular(Luu, np.eye(M), lower=True)
+    psi = lambda Y: np.tril(Y) + np.tril(Y, -1).T
+    if dense:
+        Gv = np.outer(q_mu, e) + 2.0 * (S @ (S.T @ v)) * f
+        GB = np.zeros((M, X.shape[0]))
+        GA = 0.5 * W.T @ psi(v @ Gv.T) @ W
+    else:
+        Gv = np.outer(q_mu, e) + 2.0 * (S @ (S.T @ v) - v) * f
+        GB = W.T @ Gv
+        GA = -0.5 * W.T @ psi(Gv @ v.T) @ W
+    GA = 0.5 * (GA + GA.T)
+    mom_uu = moments_dense(table, GA, Z, Z, sym=True)
+    mom_uf = moments_dense(table, GB, Z, X, sym=False)
+    gZ = np.zeros((M, D))
+    if not dense:
+        for i in range(C):
+            ri = np.nonzero(cz == i)[0]
+            if len(ri) == 0:
+                continue
+            for j in range(C):
+                rj = np.nonzero(cx == j)[0]
+                if len(rj):
+                    gZ[ri] += np.einsum("nm,nmd->nd", GB[np.ix_(ri, rj)], _jr_block(table[i, j], Z[ri, 1:], X[rj, 1:]))
+                zj = np.nonzero(cz == j)[0]
+                if len(zj):
+                    gZ[ri] += 2.0 * np.einsum("nm,nmd->nd", GA[np.ix_(ri, zj)], _jr_block(table[i, j], Z[ri, 1:], Z[zj, 1:]))
+    g_qmu = v @ e
+    g_S = np.tril(2.0 * ((v * f) @ v.T) @ S)
+    return dict(mom_uu=mom_uu, mom_uf=mom_uf, gZ=gZ, trGA=float(np.trace(GA)), g_qmu=g_qmu, g_qsqrt=g_S)
+
+
+TableDevice.svgp_forward = svgp_forward
+TableDevice.svgp_backward = svgp_backward
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # numpy twin of the SHARDED evaluation stages (mogp_shard_*, mogptk_amd/csrc/sweep.hip): single-sweep blocked
 # inversion with 128-row tiles owned cyclically (tile row i -> rank i % world), 512-wide pivot blocks, the panel of

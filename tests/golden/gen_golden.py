@@ -759,6 +759,41 @@ def gen_snelson():
     print("snelson.npz written")
 
 
+def gen_hensman():
+    """small SparseHensman / Hensman fixtures with the Gaussian likelihood (reference gpr/model.py:767-886): ELBO, gradients of every
+    parameter (q_mu, q_sqrt, inducing points, kernel, scale), predict_f; q_mu / q_sqrt away from their initial values"""
+    out = {}
+    cases = [(3, 2, 90, [4, 5, 3]), (2, 3, 120, 6), (1, 2, 60, [7]), (2, 1, 40, None)]
+    out["ncases"] = np.array(len(cases))
+    for n, (C, Q, N, Zspec) in enumerate(cases):
+        rng = np.random.default_rng(9800 + n)
+        X, y = small_data(N, C, 1, 9900 + n, False)
+        k = g.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=1)
+        k.weight.assign(rng.uniform(0.5, 1.5, (C, Q))); k.mean.assign(rng.uniform(0.05, 0.5, (C, Q, 1)))
+        k.variance.assign(rng.uniform(0.05, 0.5, (C, Q, 1))); k.delay.assign(rng.normal(0, 0.3, (C, Q, 1))); k.phase.assign(rng.normal(0, 0.3, (C, Q)))
+        lik = g.GaussianLikelihood(float(rng.uniform(0.1, 0.4)))
+        if Zspec is None:
+            m = g.Hensman(k, T(X), T(y), likelihood=lik, jitter=1e-6)
+        else:
+            Z = Zspec if isinstance(Zspec, int) else T(np.concatenate([np.stack([np.full(z, float(c)), np.sort(rng.uniform(0, 10, z))], axis=1) for c, z in enumerate(Zspec)]))
+            m = g.SparseHensman(k, T(X), T(y), Z=Z, likelihood=lik, jitter=1e-6)
+        M = m.q_mu().shape[0]
+        m.q_mu.assign(rng.normal(0, 0.5, (M, 1)))
+        m.q_sqrt.assign(np.tril(rng.normal(0, 0.2, (M, M))) + np.diag(rng.uniform(0.5, 1.2, M)) + np.triu(rng.normal(0, 0.1, (M, M)), 1))
+        pre = "c%d_" % n
+        out[pre + "meta"] = np.array([C, Q, 1, 1]); out[pre + "X"] = X; out[pre + "y"] = y
+        out[pre + "sparse"] = np.array(Zspec is not None)
+        out[pre + "Z"] = m.Z().detach().numpy(); out[pre + "jitter"] = np.array(m.jitter)
+        out[pre + "elbo"] = np.array(float(m.log_marginal_likelihood()))
+        out[pre + "loss"] = np.array(float(m.loss()))
+        dump_params(pre, list(m.parameters()), out, with_grad=True)
+        Xs, _ = small_data(23, C, 1, 9950 + n, False)
+        mu, var_p = m.predict_f(T(Xs))
+        out[pre + "Xs"] = Xs; out[pre + "mu"] = mu.numpy(); out[pre + "var"] = var_p.numpy()
+    np.savez_compressed(os.path.join(HERE, "hensman.npz"), **out)
+    print("hensman.npz written")
+
+
 def gen_checkpoints():
     """Files written by the reference's own Model.save() (model.py:320-336) -- the whole pickled model: MOSM with a fitted transformer
     chain, removed points and a pegged + a fixed parameter; the SM, CSM, SM-LMC and CONV wrappers; a Titsias MOSM -- stored as bytes next to what
@@ -783,7 +818,7 @@ def gen_checkpoints():
 
     def randomise(model):
         for p in model.gpr.parameters():
-            if p.pegged or (p._name or "").endswith("induction_points"):      # the channel column of Z must stay integral
+            if p.pegged or (p._name or "").endswith("induction_points") or (p._name or "").endswith("q_mu") or (p._name or "").endswith("q_sqrt"):      # the channel column of Z must stay integral; the variational parameters are moved by the training steps below
                 continue
             v = p.constrained.detach().numpy()
             lo = None if p.lower is None else np.broadcast_to(p.lower.detach().numpy(), v.shape)
@@ -829,6 +864,8 @@ def gen_checkpoints():
     m = mogptk.CONV(dataset(2, 30), Q=2); randomise(m); record("conv", m)
     m = mogptk.MOSM(dataset(2, 60), Q=1, inference=mogptk.Titsias(inducing_points=8)); randomise(m); record("titsias", m)
     m = mogptk.MOSM(dataset(2, 60), Q=1, inference=mogptk.Snelson(inducing_points=7)); randomise(m); record("snelson", m)
+    m = mogptk.MOSM(dataset(2, 60), Q=1, inference=mogptk.Hensman(inducing_points=6)); randomise(m)
+    m.train(method="Adam", lr=0.02, iters=4, verbose=False); record("hensman", m)
     np.savez_compressed(os.path.join(HERE, "checkpoints.npz"), **out)
     print("checkpoints.npz", {k: v.shape for k, v in out.items() if k.endswith("_file")})
 
@@ -840,7 +877,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "lbfgs": gen_lbfgs_cfg1, "quirks": gen_quirks,
              "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2, "smlmc": gen_smlmc, "init_ls": gen_init_ls, "bnse": gen_bnse, "transformers": gen_transformers,
-             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints, "snelson": gen_snelson}
+             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints, "snelson": gen_snelson, "hensman": gen_hensman}
     full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:
         {**steps, **full}[a.only]()

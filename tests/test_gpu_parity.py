@@ -537,3 +537,58 @@ def test_snelson_device_raw_outputs_against_numpy_model(N, M):
     mu, var = dev.snelson_predict(Z, noise, 1e-6, Xs, kd, kd)
     mu_r, var_r = ref.snelson_predict(Z, noise, 1e-6, Xs, kd, kd)
     assert relerr(mu, mu_r) < 1e-8 and np.max(np.abs(var - var_r)) < 1e-8
+
+
+def test_hensman_on_device():
+    """SparseHensman and the dense Hensman model (Gaussian likelihood) on the device against the reference -- ELBO, gradients of
+    q_mu / q_sqrt / inducing inputs / kernel / noise scale, predict_f"""
+    from test_host_logic import check_hensman
+    check_hensman(tol_elbo=1e-9, tol_grad=1e-6, tol_pred=1e-7)
+
+
+@pytest.mark.parametrize("N,M,dense", [(699, 150, False), (1024, 300, False), (2048, 520, False), (640, 640, True), (500, 500, True)])
+def test_svgp_device_raw_outputs_against_numpy_model(N, M, dense):
+    """the two device calls of the Hensman models against the numpy twin at sizes with several tile rows of inducing points, sparse and dense,
+    with arbitrary dE/dmu, dE/dvar (the likelihood is the caller's); and the forward pass at test inputs"""
+    rng = np.random.default_rng(N + M)
+    C, Q = 3, 2
+    X, _ = synth.make_data(N - N % C + (3 if N % C else 0), C)
+    X = X[rng.permutation(X.shape[0])][:N]
+    if dense:
+        X = X[np.argsort(X[:, 0], kind="stable")]            # the whitened parameters depend on the order: inputs grouped by channel
+    y = rng.standard_normal(N)
+    if dense:
+        Z = X.copy()
+    else:
+        Z = np.concatenate([np.stack([np.full(M // C, float(c)), rng.uniform(0, 100, M // C)], axis=1) for c in range(C)])
+    M = Z.shape[0]
+    h = synth.mosm_hypers(C, Q)
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
+    for name in ("weight", "mean", "variance", "delay", "phase"):
+        getattr(k, name).assign(h[name])
+    table = k._spectral_terms(1)
+    kd = k._spectral_diag(1)
+    q_mu = rng.normal(0, 0.5, M)
+    q_sqrt = np.tril(rng.normal(0, 0.05, (M, M))) + np.diag(rng.uniform(0.5, 1.2, M)) + np.triu(rng.normal(0, 1.0, (M, M)), 1)
+    jitter = 1e-4 if dense else 1e-6
+    dev = _lib.ExactHandle(0, X, y, C)
+    ref = TableDevice(0, X, y, C)
+    dev.set_terms(table); ref.set_terms(table)
+    a = dev.svgp_forward(Z, q_mu, q_sqrt, jitter, kd, dense=dense)
+    b = ref.svgp_forward(Z, q_mu, q_sqrt, jitter, kd, dense=dense)
+    assert relerr(a["mu"], b["mu"]) < 1e-8 and relerr(a["var"], b["var"]) < 1e-8
+    e, f = rng.standard_normal(N), -rng.uniform(0.5, 2.0, N)
+    ga = dev.svgp_backward(e, f)
+    gb = ref.svgp_backward(e, f)
+    for key in ("mom_uu", "mom_uf", "gZ", "g_qmu", "g_qsqrt"):
+        scale = np.max(np.abs(gb[key]))
+        if scale == 0.0:
+            assert np.max(np.abs(ga[key])) == 0.0, key
+        else:
+            got = np.tril(ga[key]) if key == "g_qsqrt" else ga[key]
+            assert np.max(np.abs(got - gb[key])) < 1e-6 * scale, (key, np.max(np.abs(got - gb[key])) / scale)
+    assert abs(ga["trGA"] - gb["trGA"]) < 1e-6 * abs(gb["trGA"])
+    Xs = np.concatenate([np.stack([np.full(37, float(c)), np.linspace(0, 105, 37)], axis=1) for c in range(C)])
+    p1 = dev.svgp_forward(Z, q_mu, q_sqrt, jitter, kd, Xs=Xs, kss_diag=kd, dense=dense)
+    p2 = ref.svgp_forward(Z, q_mu, q_sqrt, jitter, kd, Xs=Xs, kss_diag=kd, dense=dense)
+    assert relerr(p1["mu"], p2["mu"]) < 1e-7 and np.max(np.abs(p1["var"] - p2["var"])) < 1e-7 * max(1.0, np.max(np.abs(p2["var"])))
