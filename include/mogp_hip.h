@@ -214,6 +214,19 @@ int  mogp_svgp_forward(mogp_model* m, int64_t M, const double* Z, const double* 
 int  mogp_svgp_backward(mogp_model* m, const double* e, const double* f, double* mom_uu, double* mom_uf, double* gZ, double* trGA,
                         double* g_qmu, double* g_qsqrt);
 
+/* The variational Gaussian approximation of Opper & Archambeau at the data points (reference gpr/model.py:578-668, OpperArchambeau):
+ * q(f) = N(K nu, (K^-1 + diag(lambda^2))^-1), one nu and one lambda > 0 per data point (caller order, like y).  Like the Hensman
+ * pair, the likelihood sits between two calls.
+ *   forward:   mu[N] = K nu, var[N] = diag of the covariance of q(f), *kl = nu^T K nu + log det B + tr B^-1 - N with
+ *              B = Lambda K Lambda + I (the reference's `kl`: ELBO = E(mu, var) - kl / 2).  No jitter, as in the reference (:613).
+ *   backward:  e = dE/dmu, f = dE/dvar per point -> the gradient of E - kl / 2: moments[P][T][2+3D] of the adjoint of K (contract with
+ *              the term table's derivatives like mogp_exact_eval's), g_nu[N], g_lambda[N].  Consumes the forward call's state.
+ *   predict:   OpperArchambeau.predict_f (:640-668): mu = K_sf nu, var = K_ss - K_sf (K + diag(1 / lambda^2))^-1 K_fs (full: S x S). */
+int  mogp_oa_forward(mogp_model* m, const double* q_nu, const double* q_lambda, double* mu, double* var, double* kl, int64_t* info);
+int  mogp_oa_backward(mogp_model* m, const double* e, const double* f, double* moments, double* g_nu, double* g_lambda);
+int  mogp_oa_predict(mogp_model* m, const double* q_nu, const double* q_lambda, const double* kss_diag, int64_t S, const double* Xs,
+                     int full, double* mu, double* var, int64_t* info);
+
 /* Host-side pair algebra of the MOSM kernel in native code (no device work): the cross-spectral term table of every channel pair
  * (reference gpr/multioutput.py:178-204) and the reverse-mode gradient autograd takes through it.
  * w (C,Q), mu / v / th (C,Q,D), ph (C,Q) are the CONSTRAINED weight, mean, variance, delay, phase; table is [C][C][Q][2+3D];

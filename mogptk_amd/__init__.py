@@ -12,7 +12,7 @@ from .util import *
 from .dataset import Data, DataSet
 from .transformer import (Transformer, TransformBase, TransformDetrend, TransformLinear, TransformNormalize, TransformLog,
                           TransformStandard)
-from .model import Model, Exact, Titsias, Snelson, Hensman, LoadModel
+from .model import Model, Exact, Titsias, Snelson, OpperArchambeau, Hensman, LoadModel
 from .wrappers import MOSM, SM, CSM, SM_LMC, CONV, MOHSM
 from .init import BNSE
 from . import gpr

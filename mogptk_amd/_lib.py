@@ -78,6 +78,9 @@ SIGNATURES = {
     "mogp_svgp_forward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.c_int, ctypes.c_int64,
                                          c_dp, c_dp, c_dp, c_dp, ctypes.POINTER(ctypes.c_double), c_i64p]),
     "mogp_svgp_backward": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp, ctypes.POINTER(ctypes.c_double), c_dp, c_dp]),
+    "mogp_oa_forward": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp, ctypes.POINTER(ctypes.c_double), c_i64p]),
+    "mogp_oa_backward": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "mogp_oa_predict": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, ctypes.c_int64, c_dp, ctypes.c_int, c_dp, c_dp, c_i64p]),
     "mogp_mosm_terms": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, ctypes.c_double, ctypes.c_double, c_dp]),
     "mogp_mosm_terms_backward": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, ctypes.c_double,
                                                 ctypes.c_double, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
@@ -370,6 +373,31 @@ class ExactHandle:
         trGA = ctypes.c_double()
         check(lib().mogp_svgp_backward(self._h, _dp(e), _dp(f), _dp(mom_uu), _dp(mom_uf), _dp(gZ), ctypes.byref(trGA), _dp(g_qmu), _dp(g_S)))
         return dict(mom_uu=mom_uu, mom_uf=mom_uf, gZ=gZ, trGA=trGA.value, g_qmu=g_qmu, g_qsqrt=g_S)
+
+    def oa_forward(self, q_nu, q_lambda):
+        """mean / variance of q(f) of the Opper-Archambeau model at the training inputs and its `kl` term, through mogp_oa_forward"""
+        q_nu, q_lambda = _f64(np.reshape(q_nu, -1)), _f64(np.reshape(q_lambda, -1))
+        mu, var = np.empty(self.N), np.empty(self.N)
+        kl = ctypes.c_double()
+        info = ctypes.c_int64(0)
+        check(lib().mogp_oa_forward(self._h, _dp(q_nu), _dp(q_lambda), _dp(mu), _dp(var), ctypes.byref(kl), ctypes.byref(info)), info.value)
+        return dict(mu=mu, var=var, kl=kl.value)
+
+    def oa_backward(self, e, f):
+        e, f = _f64(np.reshape(e, -1)), _f64(np.reshape(f, -1))
+        mom = np.zeros((self.C * (self.C + 1) // 2, self.T, 2 + 3 * self.D))
+        g_nu, g_lambda = np.zeros(self.N), np.zeros(self.N)
+        check(lib().mogp_oa_backward(self._h, _dp(e), _dp(f), _dp(mom), _dp(g_nu), _dp(g_lambda)))
+        return dict(mom=mom, g_nu=g_nu, g_lambda=g_lambda)
+
+    def oa_predict(self, q_nu, q_lambda, kss_diag, Xs, full=False):
+        q_nu, q_lambda, kss_diag, Xs = _f64(np.reshape(q_nu, -1)), _f64(np.reshape(q_lambda, -1)), _f64(kss_diag), _f64(Xs)
+        S = Xs.shape[0]
+        mu, var = np.empty(S), np.empty((S, S) if full else S)
+        info = ctypes.c_int64(0)
+        check(lib().mogp_oa_predict(self._h, _dp(q_nu), _dp(q_lambda), _dp(kss_diag), S, _dp(Xs), 1 if full else 0, _dp(mu), _dp(var),
+                                    ctypes.byref(info)), info.value)
+        return mu.reshape(-1, 1), (var if full else var.reshape(-1, 1))
 
     def set_profiling(self, on=True):
         check(lib().mogp_set_profiling(self._h, 1 if on else 0))

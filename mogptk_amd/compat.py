@@ -7,7 +7,7 @@ numpy arrays; `Parameter.__reduce_ex__` / `_rebuild` carry name, bounds, prior, 
 unpickled without the reference package, and unpickled with it it is a torch model.  `load_reference_model` reads it WITHOUT the reference:
 every `mogptk.*` class is replaced by a bag that only records its state, torch rebuilds its own tensors (torch must be importable), and the
 bags are turned into the objects of this package -- data set (points, masks, prediction inputs, fitted transformers), wrapper class and
-kernel structure, inference (Exact, Titsias, Snelson, Hensman with the Gaussian likelihood), every parameter's raw value / bounds / train flag / pegging in `parameters()` order, and the
+kernel structure, inference (Exact, Titsias, Snelson, OpperArchambeau, Hensman with the Gaussian likelihood), every parameter's raw value / bounds / train flag / pegging in `parameters()` order, and the
 training history.  `mogptk_amd.LoadModel` calls it when a file is not one of its own.
 """
 import io
@@ -218,8 +218,10 @@ def _convert_model(bag):
     elif inference_name in ("SparseHensman", "Hensman"):
         sparse = bool(g.get("is_sparse", inference_name == "SparseHensman"))
         inference = _model.Hensman(inducing_points=(np.array(g["_parameters"]["Z"].data) if sparse else None), jitter=float(g["jitter"]))
+    elif inference_name == "OpperArchambeau":
+        inference = _model.OpperArchambeau(jitter=float(g["jitter"]))
     else:
-        raise NotImplementedError("inference %s is not part of this package (Exact, Titsias, Snelson and Hensman are)" % inference_name)
+        raise NotImplementedError("inference %s is not part of this package" % inference_name)
     kernel = _convert_kernel(g["_modules"]["kernel"])
     wrapper = getattr(_wrappers, bag.cls(), None)
     m = _model.Model(dataset, kernel, inference=inference, name=st.get("name"))

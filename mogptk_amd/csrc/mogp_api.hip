@@ -745,6 +745,7 @@ int mogp_model_destroy(mogp_model* m) {
     for (auto e : m->sw_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
     m->d_symv.release(); m->sh_send.release(); m->sh_recv.release();
     if (m->tw) { m->tw->release(); delete m->tw; m->tw = nullptr; }
+    m->oa.release();
     m->d_x.release(); m->d_y.release(); m->d_table.release();
     m->d_noise.release(); m->d_dvar.release(); m->d_z.release(); m->d_alpha.release(); m->d_zz.release();
     m->d_partial.release(); m->d_moments.release(); m->d_diagG.release(); m->d_tiles.release(); m->d_pair_start.release(); m->strip.release(); m->strip_own.release();
@@ -855,10 +856,11 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     return MOGP_OK;
 }
 
-int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
-                       const double* kss_diag, int64_t S, const double* Xs, int full,
-                       double* mu, double* var, int64_t* info) {
-    if (!m || !Xs || !mu || !var || !kss_diag || S <= 0) return fail(MOGP_EINVAL, "mogp_exact_predict: bad argument");
+// mean_w (caller order, may be null): the predictive mean is K_sf mean_w instead of K_sf Kj^-1 y (the Opper-Archambeau model, whose mean
+// weights are variational parameters; its variance is the exact one with the per-point variances 1 / lambda^2)
+static int predict_core(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
+                        const double* kss_diag, int64_t S, const double* Xs, int full,
+                        double* mu, double* var, int64_t* info, const double* mean_w) {
     int rc;
     if ((rc = use_device(m->ctx))) return rc;
     if (info) *info = 0;
@@ -901,6 +903,13 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
     ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = m->Wt; ga.out = m->d_Ksf.p; ga.ldo = Npad;
     ga.noise = nullptr; ga.dvar = nullptr; ga.jitter_abs = 0.0; ga.mirror = 0;
     if ((rc = launch_gram(ga, (int)pt.size(), sv))) return rc;
+    if (mean_w) {                                                    // mu = K_sf w, before the substitution consumes K_sf
+        std::vector<double> hw(Npad, 0.0);
+        for (int64_t pos = 0; pos < m->N; ++pos) hw[pos] = mean_w[m->sx.perm[pos]];
+        if ((rc = m->d_z.ensure(Npad))) return rc;
+        HIP_TRY(hipMemcpy(m->d_z.p, hw.data(), Npad * sizeof(double), hipMemcpyHostToDevice));
+        if ((rc = launch_gemv_rows(m->d_Ksf.p, Npad, Spad, Npad, m->d_z.p, m->d_mu.p, sv))) return rc;
+    }
 
     // the factorisation: enqueued on the model's streams, not waited for
     GramArgs gaK{};
@@ -945,7 +954,7 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
         HIP_TRY(hipStreamWaitEvent(m->st, m->pred_ev[1], 0));
     }
     // mu = V^T z: the rows of X against its last row (z^T)
-    if ((rc = launch_gemv_rows(m->d_Vt.p, Npad, Spad, Npad, m->d_Vt.p + Spad * Npad, m->d_mu.p, m->st))) return rc;
+    if (!mean_w && (rc = launch_gemv_rows(m->d_Vt.p, Npad, Spad, Npad, m->d_Vt.p + Spad * Npad, m->d_mu.p, m->st))) return rc;
 
     std::vector<double> hmu(Spad);
     HIP_TRY(hipMemcpyAsync(hmu.data(), m->d_mu.p, Spad * sizeof(double), hipMemcpyDeviceToHost, m->st));
@@ -983,6 +992,25 @@ int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* dat
         for (int64_t b = 0; b < S; ++b) var[ss.perm[a] * S + ss.perm[b]] = hc[(size_t)a * Spad + b];
     }
     return MOGP_OK;
+}
+
+int mogp_exact_predict(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
+                       const double* kss_diag, int64_t S, const double* Xs, int full,
+                       double* mu, double* var, int64_t* info) {
+    if (!m || !Xs || !mu || !var || !kss_diag || S <= 0) return fail(MOGP_EINVAL, "mogp_exact_predict: bad argument");
+    return predict_core(m, noise_var, data_var, jitter, kss_diag, S, Xs, full, mu, var, info, nullptr);
+}
+
+// OpperArchambeau.predict_f (reference gpr/model.py:640-668):  mu = K_sf nu,  var = K_ss - K_sf (K + diag(1 / lambda^2))^-1 K_fs, no jitter
+int mogp_oa_predict(mogp_model* m, const double* q_nu, const double* q_lambda, const double* kss_diag, int64_t S, const double* Xs, int full,
+                    double* mu, double* var, int64_t* info) {
+    if (!m || !q_nu || !q_lambda || !Xs || !mu || !var || !kss_diag || S <= 0) return fail(MOGP_EINVAL, "mogp_oa_predict: bad argument");
+    std::vector<double> dv(m->N), zero(m->C, 0.0);
+    for (int64_t i = 0; i < m->N; ++i) {
+        if (!(q_lambda[i] > 0.0)) return fail(MOGP_EINVAL, "mogp_oa_predict: q_lambda must be positive");
+        dv[i] = 1.0 / (q_lambda[i] * q_lambda[i]);
+    }
+    return predict_core(m, zero.data(), dv.data(), 0.0, kss_diag, S, Xs, full, mu, var, info, q_nu);
 }
 
 int mogp_gram(mogp_ctx* ctx, int C, int D, int T, const double* table, int64_t M1, const double* X1,

@@ -146,6 +146,13 @@ struct TitsiasWork {
 };
 
 // a tile list split into runs of full interior tiles (strip kernel) and the rest; see split_strip_tiles
+// workspaces of the Opper-Archambeau model (oa.hip): K itself, two N x N temporaries, the per-point vectors
+struct OaWork {
+    mogp::DevBuf<double> K, Sc, Y, vec;
+    bool valid = false;                 // a forward pass left its state for the backward call
+    void release() { K.release(); Sc.release(); Y.release(); vec.release(); valid = false; }
+};
+
 struct StripTiles {
     std::vector<mogp::GSeg> segs;
     std::vector<mogp::GTile> rest;
@@ -214,6 +221,7 @@ struct mogp_model {
     double gemm_flops = 0.0;
     bool have_W = false, have_Kinv = false, kinv_in_A = false, w_in_Wm = false;
     TitsiasWork* tw = nullptr;
+    OaWork oa;
 };
 
 

@@ -560,6 +560,86 @@ class Snelson(Model):
         return mu, var
 
 
+class OpperArchambeau(Model):
+    """
+    Variational Gaussian approximation of Opper & Archambeau 2009 (reference gpr/model.py:578-668): q(f) = N(K nu, (K^-1 + diag(lambda^2))^-1)
+    with one `q_nu` and one positive `q_lambda` per data point;  ELBO = E_q[log p(y | f)] - kl / 2.  The O(N^3) algebra runs on the device in
+    two calls around the likelihood (like the Hensman models): forward -> per-point mu, var of q(f) and the kl term; the likelihood (host,
+    O(N)) returns its expectation and dE/dmu, dE/dvar; backward -> the gradients of kernel, q_nu, q_lambda.  On this path: the Gaussian likelihood.
+    No jitter enters (the reference's Cholesky calls here pass add_jitter=False); `jitter` is kept for the signature.
+    """
+
+    def __init__(self, kernel, X, y, likelihood=None, jitter=1e-8, mean=None):
+        if likelihood is None:
+            likelihood = GaussianLikelihood(1.0)
+        super().__init__(kernel, X, y, likelihood, jitter, mean)
+        n = self.X.shape[0]
+        self.q_nu = Parameter(np.zeros((n, 1)))
+        self.q_lambda = Parameter(np.ones((n, 1)), lower=config.positive_minimum)
+
+    def _device_handle(self):
+        if self._handle is None:
+            from .._lib import ExactHandle
+            self._handle = ExactHandle(config.device, self.kernel._kernel_format(self.X), self.y, self.kernel._channels())
+        return self._handle
+
+    def _forward(self):
+        from .._lib import MogpError, MOGP_ENOTPD, MOGP_ENONFINITE
+        h = self._device_handle()
+        D = self.X.shape[1] - (0 if self.kernel.output_dims is None else 1)
+        table = self.kernel._spectral_terms(D)
+        h.set_terms(table)
+        try:
+            res = h.oa_forward(self.q_nu(), self.q_lambda())
+        except MogpError as e:
+            if e.code in (MOGP_ENOTPD, MOGP_ENONFINITE):
+                print("ERROR:", str(e), file=sys.__stdout__)
+                self.print_parameters()
+                raise CholeskyException(str(e), None, self)
+            raise
+        return h, res, table, D
+
+    def _targets(self, mu):
+        """reference :604-607, :625-626: with a mean function both the targets and the mean of q(f) have it subtracted"""
+        if self.mean is None:
+            return self.y, mu
+        mean = np.asarray(self.mean(self.X)).reshape(-1)
+        return self.y - mean.reshape(-1, 1), mu - mean
+
+    def elbo(self):
+        h, res, _, _ = self._forward()
+        y, mu = self._targets(res["mu"])
+        return config.dtype(self.likelihood.variational_expectation(self.X, y, mu, res["var"]) - 0.5 * res["kl"])
+
+    def log_marginal_likelihood(self):
+        """maximise the lower bound (reference gpr/model.py:636-638)"""
+        return self.elbo()
+
+    def _loss_impl(self):
+        self.zero_grad(set_to_none=True)
+        h, res, table, D = self._forward()
+        y, mu = self._targets(res["mu"])
+        ve, e, f, dscale = self.likelihood.variational_expectation(self.X, y, mu, res["var"], grad=True)
+        bw = h.oa_backward(e, f)
+        self.kernel._spectral_backward(-_gtable_from_moments(table, bw["mom"], D, lower=True))
+        scale = self.likelihood.scale
+        scale.accumulate_grad(np.reshape(-dscale, scale.data.shape))
+        self.q_nu.accumulate_grad(-np.reshape(bw["g_nu"], self.q_nu.data.shape))
+        self.q_lambda.accumulate_grad(-np.reshape(bw["g_lambda"], self.q_lambda.data.shape))
+        return config.dtype(-(ve - 0.5 * res["kl"]) - self.log_prior())
+
+    def predict_f(self, X, full=False):
+        """reference gpr/model.py:640-668"""
+        X = self._check_input(X)
+        h = self._device_handle()
+        D = self.X.shape[1] - (0 if self.kernel.output_dims is None else 1)
+        h.set_terms(self.kernel._spectral_terms(D))
+        mu, var = h.oa_predict(self.q_nu(), self.q_lambda(), self.kernel._spectral_diag(D), self.kernel._kernel_format(X), full=full)
+        if self.mean is not None:
+            mu = mu + np.asarray(self.mean(X)).reshape(-1, 1)
+        return mu, var
+
+
 class SparseHensman(Model):
     """
     Sparse variational GP of Hensman et al. 2015, whitened (reference gpr/model.py:767-878): q(u) = N(L q_mu, L S S^T L^T), L L^T = Kuu,

@@ -108,6 +108,24 @@ class Snelson:
         return gpr.Snelson(kernel, x, y, Z=self.inducing_points, Z_init=self.init_inducing_points, variance=variance, jitter=self.jitter, mean=mean)
 
 
+class OpperArchambeau:
+    """
+    Variational inference of Opper & Archambeau 2009 (reference mogptk/model.py:125-138).  On this path with the Gaussian likelihood.
+
+    Args:
+        likelihood (gpr.Likelihood): likelihood p(y|f) (default: Gaussian with unit scale).
+        jitter (float): kept for the signature (the reference's model adds none).
+    """
+
+    def __init__(self, likelihood=None, jitter=1e-6):
+        self.likelihood = likelihood
+        self.jitter = jitter
+
+    def _build(self, kernel, x, y, y_err=None, mean=None):
+        likelihood = self.likelihood if self.likelihood is not None else gpr.GaussianLikelihood(1.0)
+        return gpr.OpperArchambeau(kernel, x, y, likelihood=likelihood, jitter=self.jitter, mean=mean)
+
+
 class Hensman:
     """
     Variational inference of Hensman et al. 2015 (reference mogptk/model.py:159-178).  On this path with the Gaussian likelihood.

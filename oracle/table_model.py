@@ -424,6 +424,68 @@ TableDevice.svgp_forward = svgp_forward
 TableDevice.svgp_backward = svgp_backward
 
 
+def oa_forward(self, q_nu, q_lambda):
+    """numpy twin of mogp_oa_forward -- reference gpr/model.py:613-634 (OpperArchambeau.elbo): q(f) = N(K nu, (K^-1 + diag(lambda^2))^-1),
+        B = Lambda K Lambda + I = L L^T,   mu = K nu,   var = (1 - diag(B^-1)) / lambda^2,
+        kl = nu^T K nu + log det B + tr(B^-1) - N        (the reference's `kl`: the ELBO is  E(mu, var) - kl / 2)
+    No jitter anywhere (the reference's _cholesky is called with add_jitter False here)."""
+    K = gram_from_table(self.table, self.X)
+    nu = np.asarray(q_nu, dtype=np.float64).reshape(-1)
+    lam = np.asarray(q_lambda, dtype=np.float64).reshape(-1)
+    N = K.shape[0]
+    B = lam[:, None] * lam[None, :] * K + np.eye(N)
+    L = np.linalg.cholesky(B)
+    Binv = np.linalg.inv(B)
+    Binv = 0.5 * (Binv + Binv.T)
+    mu = K @ nu
+    var = (1.0 - np.diagonal(Binv)) / lam ** 2
+    kl = float(nu @ mu + 2.0 * np.sum(np.log(np.diagonal(L))) + np.trace(Binv) - N)
+    self._oa = dict(K=K, Binv=Binv, nu=nu, lam=lam)
+    return dict(mu=mu, var=var, kl=kl)
+
+
+def oa_backward(self, e, f):
+    """gradient of  E(mu, var) - kl / 2  given  e = dE/dmu, f = dE/dvar  per point:
+        dK  = 1/2 (e nu^T + nu e^T) - 1/2 nu nu^T + Lambda (B^-1 diag(w) B^-1 - 1/2 B^-1) Lambda,   w = f / lambda^2 + 1/2
+        dnu = K (e - nu)
+        dlambda_m = -2 f_m (1 - b_m) / lambda_m^3 + (2 / lambda_m) (f_m b_m / lambda_m^2 - r_m) - (1 - b_m) / lambda_m + (b_m - s_m) / lambda_m
+                    with b = diag(B^-1), s = diag(B^-2), r = diag(B^-1 diag(f / lambda^2) B^-1)
+    (only the diagonals of the matrix products enter the lambda gradient, through  K Lambda = Lambda^-1 (B - I))."""
+    st = self._oa
+    K, Binv, nu, lam = st["K"], st["Binv"], st["nu"], st["lam"]
+    e = np.asarray(e, dtype=np.float64).reshape(-1)
+    f = np.asarray(f, dtype=np.float64).reshape(-1)
+    d = f / lam ** 2
+    Y = (Binv * (d + 0.5)) @ Binv
+    GK = 0.5 * (np.outer(e, nu) + np.outer(nu, e)) - 0.5 * np.outer(nu, nu) + lam[:, None] * (Y - 0.5 * Binv) * lam[None, :]
+    GK = 0.5 * (GK + GK.T)
+    b = np.diagonal(Binv)
+    s = np.sum(Binv * Binv, axis=1)
+    r = np.sum(Binv * Binv * d[None, :], axis=1)
+    g_lam = -2.0 * f * (1.0 - b) / lam ** 3 + (2.0 / lam) * (d * b - r) - (1.0 - b) / lam + (b - s) / lam
+    return dict(mom=moments_dense(self.table, GK, self.X, self.X, sym=True), g_nu=K @ (e - nu), g_lambda=g_lam)
+
+
+def oa_predict(self, q_nu, q_lambda, kss_diag, Xs, full=False):
+    """reference gpr/model.py:640-668:  mu = K_sf nu,  var = K_ss - K_sf (K + diag(1 / lambda^2))^-1 K_fs  (no jitter)"""
+    from scipy.linalg import solve_triangular
+    nu = np.asarray(q_nu, dtype=np.float64).reshape(-1)
+    lam = np.asarray(q_lambda, dtype=np.float64).reshape(-1)
+    Kfs = gram_from_table(self.table, self.X, Xs)
+    L = np.linalg.cholesky(gram_from_table(self.table, self.X) + np.diag(1.0 / lam ** 2))
+    a = solve_triangular(L, Kfs, lower=True)
+    mu = (Kfs.T @ nu).reshape(-1, 1)
+    if full:
+        return mu, gram_from_table(self.table, Xs) - a.T @ a
+    kd = np.asarray(kss_diag)[Xs[:, 0].astype(np.int64)]
+    return mu, (kd - np.sum(a * a, axis=0)).reshape(-1, 1)
+
+
+TableDevice.oa_forward = oa_forward
+TableDevice.oa_backward = oa_backward
+TableDevice.oa_predict = oa_predict
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # numpy twin of the SHARDED evaluation stages (mogp_shard_*, mogptk_amd/csrc/sweep.hip): single-sweep blocked
 # inversion with 128-row tiles owned cyclically (tile row i -> rank i % world), 512-wide pivot blocks, the panel of

@@ -794,6 +794,35 @@ def gen_hensman():
     print("hensman.npz written")
 
 
+def gen_oa():
+    """small OpperArchambeau fixtures with the Gaussian likelihood (reference gpr/model.py:578-668): ELBO, gradients of every parameter
+    (q_nu, q_lambda, kernel, scale), predict_f (diagonal and full); q_nu / q_lambda away from their initial values, inputs NOT grouped by channel"""
+    out = {}
+    cases = [(3, 2, 90), (2, 3, 150), (1, 2, 60)]
+    out["ncases"] = np.array(len(cases))
+    for n, (C, Q, N) in enumerate(cases):
+        rng = np.random.default_rng(9600 + n)
+        X, y = small_data(N, C, 1, 9700 + n, n != 1)
+        k = g.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=1)
+        k.weight.assign(rng.uniform(0.5, 1.5, (C, Q))); k.mean.assign(rng.uniform(0.05, 0.5, (C, Q, 1)))
+        k.variance.assign(rng.uniform(0.05, 0.5, (C, Q, 1))); k.delay.assign(rng.normal(0, 0.3, (C, Q, 1))); k.phase.assign(rng.normal(0, 0.3, (C, Q)))
+        lik = g.GaussianLikelihood(float(rng.uniform(0.1, 0.4)))
+        m = g.OpperArchambeau(k, T(X), T(y), likelihood=lik, jitter=1e-6)
+        m.q_nu.assign(rng.normal(0, 0.5, (N, 1)))
+        m.q_lambda.assign(rng.uniform(0.5, 3.0, (N, 1)))
+        pre = "c%d_" % n
+        out[pre + "meta"] = np.array([C, Q, 1, 1]); out[pre + "X"] = X; out[pre + "y"] = y
+        out[pre + "elbo"] = np.array(float(m.log_marginal_likelihood()))
+        out[pre + "loss"] = np.array(float(m.loss()))
+        dump_params(pre, list(m.parameters()), out, with_grad=True)
+        Xs, _ = small_data(23, C, 1, 9750 + n, True)
+        mu, var_p = m.predict_f(T(Xs))
+        _, cov = m.predict_f(T(Xs), full=True)
+        out[pre + "Xs"] = Xs; out[pre + "mu"] = mu.numpy(); out[pre + "var"] = var_p.numpy(); out[pre + "cov"] = cov.numpy()
+    np.savez_compressed(os.path.join(HERE, "oa.npz"), **out)
+    print("oa.npz written")
+
+
 def gen_checkpoints():
     """Files written by the reference's own Model.save() (model.py:320-336) -- the whole pickled model: MOSM with a fitted transformer
     chain, removed points and a pegged + a fixed parameter; the SM, CSM, SM-LMC and CONV wrappers; a Titsias MOSM -- stored as bytes next to what
@@ -818,7 +847,7 @@ def gen_checkpoints():
 
     def randomise(model):
         for p in model.gpr.parameters():
-            if p.pegged or (p._name or "").endswith("induction_points") or (p._name or "").endswith("q_mu") or (p._name or "").endswith("q_sqrt"):      # the channel column of Z must stay integral; the variational parameters are moved by the training steps below
+            if p.pegged or (p._name or "").endswith("induction_points") or (p._name or "").split(".")[-1] in ("q_mu", "q_sqrt", "q_nu", "q_lambda"):      # the channel column of Z must stay integral; the variational parameters are moved by the training steps below
                 continue
             v = p.constrained.detach().numpy()
             lo = None if p.lower is None else np.broadcast_to(p.lower.detach().numpy(), v.shape)
@@ -866,6 +895,8 @@ def gen_checkpoints():
     m = mogptk.MOSM(dataset(2, 60), Q=1, inference=mogptk.Snelson(inducing_points=7)); randomise(m); record("snelson", m)
     m = mogptk.MOSM(dataset(2, 60), Q=1, inference=mogptk.Hensman(inducing_points=6)); randomise(m)
     m.train(method="Adam", lr=0.02, iters=4, verbose=False); record("hensman", m)
+    m = mogptk.MOSM(dataset(2, 40), Q=1, inference=mogptk.OpperArchambeau()); randomise(m)
+    m.train(method="Adam", lr=0.02, iters=4, verbose=False); record("oa", m)
     np.savez_compressed(os.path.join(HERE, "checkpoints.npz"), **out)
     print("checkpoints.npz", {k: v.shape for k, v in out.items() if k.endswith("_file")})
 
@@ -877,7 +908,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "lbfgs": gen_lbfgs_cfg1, "quirks": gen_quirks,
              "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2, "smlmc": gen_smlmc, "init_ls": gen_init_ls, "bnse": gen_bnse, "transformers": gen_transformers,
-             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints, "snelson": gen_snelson, "hensman": gen_hensman}
+             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints, "snelson": gen_snelson, "hensman": gen_hensman, "oa": gen_oa}
     full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:
         {**steps, **full}[a.only]()

@@ -592,3 +592,55 @@ def test_svgp_device_raw_outputs_against_numpy_model(N, M, dense):
     p1 = dev.svgp_forward(Z, q_mu, q_sqrt, jitter, kd, Xs=Xs, kss_diag=kd, dense=dense)
     p2 = ref.svgp_forward(Z, q_mu, q_sqrt, jitter, kd, Xs=Xs, kss_diag=kd, dense=dense)
     assert relerr(p1["mu"], p2["mu"]) < 1e-7 and np.max(np.abs(p1["var"] - p2["var"])) < 1e-7 * max(1.0, np.max(np.abs(p2["var"])))
+
+
+def test_opper_archambeau_on_device():
+    """the Opper-Archambeau model (Gaussian likelihood) on the device against the reference -- ELBO, gradients of q_nu / q_lambda /
+    kernel / noise scale, predict_f (diagonal and full)"""
+    from test_host_logic import check_oa
+    check_oa(tol_elbo=1e-9, tol_grad=1e-6, tol_pred=1e-7)
+
+
+@pytest.mark.parametrize("N", [700, 1500, 2304])
+def test_oa_device_raw_outputs_against_numpy_model(N):
+    """the device calls of the Opper-Archambeau model against the numpy twin at sizes with several tile rows and outer blocks, inputs NOT grouped
+    by channel, with arbitrary dE/dmu, dE/dvar (the likelihood is the caller's); and the prediction at test inputs"""
+    rng = np.random.default_rng(N)
+    C, Q = 3, 2
+    X, _ = synth.make_data(N - N % C + (3 if N % C else 0), C)
+    X = X[rng.permutation(X.shape[0])][:N]
+    y = rng.standard_normal(N)
+    h = synth.mosm_hypers(C, Q)
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
+    for name in ("weight", "mean", "variance", "delay", "phase"):
+        getattr(k, name).assign(h[name])
+    table = k._spectral_terms(1)
+    kd = k._spectral_diag(1)
+    nu, lam = rng.normal(0, 0.5, N), rng.uniform(0.5, 3.0, N)
+    dev = _lib.ExactHandle(0, X, y, C)
+    ref = TableDevice(0, X, y, C)
+    dev.set_terms(table); ref.set_terms(table)
+    a = dev.oa_forward(nu, lam)
+    b = ref.oa_forward(nu, lam)
+    assert relerr(a["mu"], b["mu"]) < 1e-9 and relerr(a["var"], b["var"]) < 1e-8 and abs(a["kl"] - b["kl"]) < 1e-9 * abs(b["kl"])
+    e, f = rng.standard_normal(N), -rng.uniform(0.5, 2.0, N)
+    ga = dev.oa_backward(e, f)
+    gb = ref.oa_backward(e, f)
+    for key in ("mom", "g_nu", "g_lambda"):
+        scale = np.max(np.abs(gb[key]))
+        assert np.max(np.abs(ga[key] - gb[key])) < 1e-7 * scale, (key, np.max(np.abs(ga[key] - gb[key])) / scale)
+    with pytest.raises(_lib.MogpError):                        # the forward pass's state is consumed
+        dev.oa_backward(e, f)
+    Xs = np.concatenate([np.stack([np.full(37, float(c)), np.linspace(0, 105, 37)], axis=1) for c in range(C)])[rng.permutation(37 * C)]
+    mu1, v1 = dev.oa_predict(nu, lam, kd, Xs)
+    mu2, v2 = ref.oa_predict(nu, lam, kd, Xs)
+    assert relerr(mu1, mu2) < 1e-9 and np.max(np.abs(v1 - v2)) < 1e-8 * max(1.0, np.max(np.abs(v2)))
+    mu1, c1 = dev.oa_predict(nu, lam, kd, Xs, full=True)
+    _, c2 = ref.oa_predict(nu, lam, kd, Xs, full=True)
+    assert relerr(mu1, mu2) < 1e-9 and np.max(np.abs(c1 - c2)) < 1e-8 * max(1.0, np.max(np.abs(c2)))
+    ye = rng.standard_normal(N)                                 # the exact model's own predictions are untouched by the shared code path
+    dev.set_y(ye); ref.set_y(ye)
+    nv = np.full(C, 0.3)
+    m1, s1 = dev.predict(nv, 1e-8, kd, Xs)
+    m2, s2 = ref.predict(nv, 1e-8, kd, Xs)
+    assert relerr(m1, m2) < 1e-8 and np.max(np.abs(s1 - s2)) < 1e-8

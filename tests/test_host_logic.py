@@ -546,14 +546,14 @@ def test_mohsm_predict_and_wrapper_match_reference():
 
 
 # ---- checkpoints written by the reference's Model.save() load without the reference ----------------------------------
-def check_reference_checkpoints(tmp_path, tol_value=1e-12, tol_loss=1e-8, tol_grad=1e-6, tol_pred=1e-6, tags=("mosm", "sm", "csm", "smlmc", "conv", "titsias", "snelson", "hensman")):
+def check_reference_checkpoints(tmp_path, tol_value=1e-12, tol_loss=1e-8, tol_grad=1e-6, tol_pred=1e-6, tags=("mosm", "sm", "csm", "smlmc", "conv", "titsias", "snelson", "hensman", "oa")):
     """checkpoints.npz: the bytes of files the reference wrote, and what the reference itself computes after loading them"""
     fx = load("checkpoints.npz")
     for tag in tags:
         path = tmp_path / ("ref_%s" % tag)
         (tmp_path / ("ref_%s.npy" % tag)).write_bytes(fx[tag + "_file"].tobytes())
         m = mogptk_amd.LoadModel(str(path))
-        assert type(m).__name__ == {"mosm": "MOSM", "sm": "SM", "csm": "CSM", "smlmc": "SM_LMC", "conv": "CONV", "titsias": "MOSM", "snelson": "MOSM", "hensman": "MOSM"}[tag]
+        assert type(m).__name__ == {"mosm": "MOSM", "sm": "SM", "csm": "CSM", "smlmc": "SM_LMC", "conv": "CONV", "titsias": "MOSM", "snelson": "MOSM", "hensman": "MOSM", "oa": "MOSM"}[tag]
         ps = list(m.gpr.parameters())
         assert [p._name for p in ps] == [str(n) for n in fx[tag + "_names"]]
         for i, p in enumerate(ps):
@@ -664,6 +664,47 @@ def check_hensman(tol_elbo=1e-9, tol_grad=1e-7, tol_pred=1e-8):
 
 def test_hensman_matches_reference():
     check_hensman()
+
+
+def check_oa(tol_elbo=1e-9, tol_grad=1e-7, tol_pred=1e-8):
+    fx = load("oa.npz")
+    for n in range(int(fx["ncases"])):
+        pre = "c%d_" % n
+        C, Q, D, _ = [int(v) for v in fx[pre + "meta"]]
+        fp = fixture_params(fx, pre)
+        k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=D)
+        m = gpr.OpperArchambeau(k, fx[pre + "X"], fx[pre + "y"], likelihood=gpr.GaussianLikelihood(1.0), jitter=1e-6)
+        assert [p._name.split(".")[-1] for p in m.parameters()] == [f["name"].split(".")[-1] for f in fp]
+        load_raw(m.parameters(), fp)
+        elbo, ref = float(m.log_marginal_likelihood()), float(fx[pre + "elbo"])
+        assert abs(elbo - ref) < tol_elbo * max(1.0, abs(ref)), (n, elbo, ref)
+        loss, ref = float(m.loss()), float(fx[pre + "loss"])
+        assert abs(loss - ref) < tol_elbo * max(1.0, abs(ref)), (n, loss, ref)
+        for p, f in zip(m.parameters(), fp):
+            if f["grad"] is None:
+                assert p.grad is None, (n, p._name)
+            else:
+                assert p.grad is not None, (n, p._name)
+                assert np.max(np.abs(p.grad - f["grad"])) <= tol_grad * max(1.0, np.max(np.abs(f["grad"]))), (n, p._name, np.max(np.abs(p.grad - f["grad"])))
+        mu, var_p = m.predict_f(fx[pre + "Xs"])
+        assert relerr(mu, fx[pre + "mu"]) < tol_pred and np.max(np.abs(var_p - fx[pre + "var"])) < tol_pred * max(1.0, np.max(np.abs(fx[pre + "var"]))), n
+        mu, cov = m.predict_f(fx[pre + "Xs"], full=True)
+        assert relerr(mu, fx[pre + "mu"]) < tol_pred and np.max(np.abs(cov - fx[pre + "cov"])) < tol_pred * max(1.0, np.max(np.abs(fx[pre + "cov"]))), n
+
+
+def test_opper_archambeau_matches_reference():
+    check_oa()
+
+
+def test_opper_archambeau_through_the_model_wrapper():
+    t = np.linspace(0, 10, 30)
+    ds = mogptk_amd.DataSet(t, [np.sin(t), np.cos(t)])
+    m = mogptk_amd.MOSM(ds, Q=1, inference=mogptk_amd.OpperArchambeau())
+    assert type(m.gpr).__name__ == "OpperArchambeau" and m.gpr.q_nu().shape == (60, 1) and m.gpr.q_lambda().shape == (60, 1)
+    losses, _ = m.train("Adam", iters=3, lr=0.05)
+    assert losses.shape == (4,) and np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+    _, mu, lower, upper = m.predict(transformed=False)
+    assert all(np.all(np.isfinite(v)) for v in mu)
 
 
 def test_hensman_through_the_model_wrapper():
