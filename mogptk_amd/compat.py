@@ -7,7 +7,7 @@ numpy arrays; `Parameter.__reduce_ex__` / `_rebuild` carry name, bounds, prior, 
 unpickled without the reference package, and unpickled with it it is a torch model.  `load_reference_model` reads it WITHOUT the reference:
 every `mogptk.*` class is replaced by a bag that only records its state, torch rebuilds its own tensors (torch must be importable), and the
 bags are turned into the objects of this package -- data set (points, masks, prediction inputs, fitted transformers), wrapper class and
-kernel structure, inference (Exact, Titsias, Snelson, OpperArchambeau, Hensman with the Gaussian likelihood), every parameter's raw value / bounds / train flag / pegging in `parameters()` order, and the
+kernel structure, inference (Exact, Titsias, Snelson; OpperArchambeau and Hensman with any of the reference's likelihoods), every parameter's raw value / bounds / train flag / pegging in `parameters()` order, and the
 training history.  `mogptk_amd.LoadModel` calls it when a file is not one of its own.
 """
 import io
@@ -193,6 +193,34 @@ def _assign_parameters(ours, theirs):
             mine.pegged_parameter, mine.pegged_transform = ours[j], ref.pegged_transform
 
 
+# ---- likelihoods ---------------------------------------------------------------------------------------------------------------------
+def _convert_likelihood(bag):
+    """same class, same link / degrees of freedom / quadrature degree, default parameter values (overwritten afterwards, in order)"""
+    name, st = bag.cls(), bag.state()
+    cls = getattr(_gpr, name, None)
+    if cls is None or not isinstance(cls, type) or not issubclass(cls, _gpr.Likelihood):
+        raise NotImplementedError("checkpoint uses the likelihood %s, which this package does not have" % name)
+    if name == "MultiOutputLikelihood":
+        return cls(*[_convert_likelihood(l) for l in _module_children(st["_modules"]["likelihoods"])])
+    kw = {}
+    if "link" in st:                                           # pickled by name: the unpickler turned `mogptk.gpr.likelihood.exp` into a bag TYPE
+        link = getattr(_gpr, getattr(st["link"], "_cls", None) or getattr(st["link"], "__name__", ""), None)
+        if link is None:
+            raise NotImplementedError("likelihood %s: the link function of the checkpoint is not one of the reference's own" % name)
+        kw["link"] = link
+    quad = st.get("quadrature")
+    if quad is not None and name not in ("GaussianLikelihood", "BernoulliLikelihood"):
+        kw["quadratures"] = int(quad.state()["deg"])
+    if name == "StudentTLikelihood":
+        kw["dof"] = float(_num(st["dof"]))
+    lik = cls(**kw)
+    params = st.get("_parameters", {})
+    for pname, ref in params.items():                          # shapes: a per-channel Gaussian scale changes output_dims
+        if ref is not None and pname == "scale" and name == "GaussianLikelihood" and ref.data.ndim == 1:
+            lik = cls(np.ones(ref.data.shape[0]))
+    return lik
+
+
 # ---- the model -----------------------------------------------------------------------------------------------------------------------
 def _convert_model(bag):
     from . import model as _model
@@ -204,8 +232,8 @@ def _convert_model(bag):
         raise NotImplementedError("the checkpoint's model has a mean function object of the reference; not converted")
     inference_name = st["gpr"].cls()
     lik = g["_modules"]["likelihood"]
-    if lik.cls() != "GaussianLikelihood":
-        raise NotImplementedError("likelihood %s: only the Gaussian likelihood is on this path" % lik.cls())
+    if lik.cls() != "GaussianLikelihood" and inference_name not in ("SparseHensman", "Hensman", "OpperArchambeau"):
+        raise NotImplementedError("likelihood %s with %s inference: only the variational models take a non-Gaussian likelihood" % (lik.cls(), inference_name))
     if inference_name == "Exact":
         dv = g.get("data_variance")
         inference = _model.Exact(data_variance=None if dv is None else _num(dv), jitter=float(g["jitter"]))
@@ -217,9 +245,10 @@ def _convert_model(bag):
         inference = _model.Snelson(inducing_points=np.array(Z.data), jitter=float(g["jitter"]))
     elif inference_name in ("SparseHensman", "Hensman"):
         sparse = bool(g.get("is_sparse", inference_name == "SparseHensman"))
-        inference = _model.Hensman(inducing_points=(np.array(g["_parameters"]["Z"].data) if sparse else None), jitter=float(g["jitter"]))
+        inference = _model.Hensman(inducing_points=(np.array(g["_parameters"]["Z"].data) if sparse else None), likelihood=_convert_likelihood(lik),
+                                   jitter=float(g["jitter"]))
     elif inference_name == "OpperArchambeau":
-        inference = _model.OpperArchambeau(jitter=float(g["jitter"]))
+        inference = _model.OpperArchambeau(likelihood=_convert_likelihood(lik), jitter=float(g["jitter"]))
     else:
         raise NotImplementedError("inference %s is not part of this package" % inference_name)
     kernel = _convert_kernel(g["_modules"]["kernel"])

@@ -609,7 +609,7 @@ class OpperArchambeau(Model):
     def elbo(self):
         h, res, _, _ = self._forward()
         y, mu = self._targets(res["mu"])
-        return config.dtype(self.likelihood.variational_expectation(self.X, y, mu, res["var"]) - 0.5 * res["kl"])
+        return config.dtype(self.likelihood.variational_expectation(self._likelihood_X(self.X), y, mu, res["var"]) - 0.5 * res["kl"])
 
     def log_marginal_likelihood(self):
         """maximise the lower bound (reference gpr/model.py:636-638)"""
@@ -619,11 +619,11 @@ class OpperArchambeau(Model):
         self.zero_grad(set_to_none=True)
         h, res, table, D = self._forward()
         y, mu = self._targets(res["mu"])
-        ve, e, f, dscale = self.likelihood.variational_expectation(self.X, y, mu, res["var"], grad=True)
+        ve, e, f, pgrads = self.likelihood.variational_expectation(self._likelihood_X(self.X), y, mu, res["var"], grad=True)
         bw = h.oa_backward(e, f)
         self.kernel._spectral_backward(-_gtable_from_moments(table, bw["mom"], D, lower=True))
-        scale = self.likelihood.scale
-        scale.accumulate_grad(np.reshape(-dscale, scale.data.shape))
+        for p, g in pgrads:
+            p.accumulate_grad(np.reshape(-np.asarray(g, dtype=np.float64), p.data.shape))
         self.q_nu.accumulate_grad(-np.reshape(bw["g_nu"], self.q_nu.data.shape))
         self.q_lambda.accumulate_grad(-np.reshape(bw["g_lambda"], self.q_lambda.data.shape))
         return config.dtype(-(ve - 0.5 * res["kl"]) - self.log_prior())
@@ -704,7 +704,7 @@ class SparseHensman(Model):
 
     def elbo(self):
         h, res, _, _, _ = self._forward()
-        ve = self.likelihood.variational_expectation(self.X, self._y(), res["mu"], res["var"])
+        ve = self.likelihood.variational_expectation(self._likelihood_X(self.X), self._y(), res["mu"], res["var"])
         return config.dtype(ve - self.kl_gaussian(self.q_mu(), self.q_sqrt()))
 
     def log_marginal_likelihood(self):
@@ -714,7 +714,7 @@ class SparseHensman(Model):
     def _loss_impl(self):
         self.zero_grad(set_to_none=True)
         h, res, table, D, Zk = self._forward()
-        ve, e, f, dscale = self.likelihood.variational_expectation(self.X, self._y(), res["mu"], res["var"], grad=True)
+        ve, e, f, pgrads = self.likelihood.variational_expectation(self._likelihood_X(self.X), self._y(), res["mu"], res["var"], grad=True)
         q_mu, q_sqrt = np.asarray(self.q_mu(), dtype=np.float64), np.asarray(self.q_sqrt(), dtype=np.float64)
         elbo = ve - self.kl_gaussian(q_mu, q_sqrt)
         bw = h.svgp_backward(e, f)
@@ -728,8 +728,8 @@ class SparseHensman(Model):
         self.kernel._spectral_backward(-gt)
         if self.is_sparse:                          # var_n = K_diag[c(n)] - ... (the dense model's variance at its own inputs has no such term)
             self.kernel._spectral_diag_backward(-np.bincount(xc, weights=f, minlength=C), D)
-        scale = self.likelihood.scale
-        scale.accumulate_grad(np.reshape(-dscale, scale.data.shape))
+        for p, g in pgrads:
+            p.accumulate_grad(np.reshape(-np.asarray(g, dtype=np.float64), p.data.shape))
         self.q_mu.accumulate_grad(-(np.reshape(bw["g_qmu"], q_mu.shape) - q_mu))
         s = np.diagonal(q_sqrt)
         self.q_sqrt.accumulate_grad(-(np.tril(bw["g_qsqrt"]) - np.diag(s - 1.0 / s)))

@@ -823,6 +823,150 @@ def gen_oa():
     print("oa.npz written")
 
 
+def _likelihood_zoo(L):
+    """(tag, constructor) for every likelihood of the reference, default links plus a few others"""
+    return [
+        ("gaussian", lambda: L.GaussianLikelihood(0.7)),
+        ("studentt", lambda: L.StudentTLikelihood(dof=4, scale=0.6)),
+        ("exponential", lambda: L.ExponentialLikelihood()),
+        ("laplace", lambda: L.LaplaceLikelihood(scale=0.8)),
+        ("bernoulli", lambda: L.BernoulliLikelihood()),
+        ("bernoulli_sigmoid", lambda: L.BernoulliLikelihood(link=L.sigmoid)),
+        ("beta", lambda: L.BetaLikelihood(scale=3.0)),
+        ("beta_sigmoid", lambda: L.BetaLikelihood(scale=2.5, link=L.sigmoid)),
+        ("gamma", lambda: L.GammaLikelihood(shape=1.7)),
+        ("poisson", lambda: L.PoissonLikelihood()),
+        ("weibull", lambda: L.WeibullLikelihood(shape=1.4)),
+        ("weibull_square", lambda: L.WeibullLikelihood(shape=0.8, link=L.square)),
+        ("loglogistic", lambda: L.LogLogisticLikelihood(shape=2.2)),
+        ("loggaussian", lambda: L.LogGaussianLikelihood(scale=0.5)),
+        ("chisquared", lambda: L.ChiSquaredLikelihood()),
+    ]
+
+
+def _likelihood_targets(tag, rng, n):
+    if tag.startswith("bernoulli"):
+        return (rng.uniform(size=n) < 0.5).astype(np.float64)
+    if tag.startswith("beta"):
+        return rng.uniform(0.05, 0.95, n)
+    if tag == "poisson":
+        return rng.poisson(2.0, n).astype(np.float64)
+    if tag in ("gaussian", "studentt", "laplace"):
+        return rng.normal(0, 1.0, n)
+    return rng.uniform(0.2, 3.0, n)
+
+
+def gen_likelihoods():
+    """every likelihood of the reference (gpr/likelihood.py): log_prob on a grid of f, the variational expectation with the reference's autograd
+    gradients with respect to mu, var and the likelihood's own parameters, conditional_mean, predict (mean; and quantiles under a fixed torch
+    seed); a MultiOutputLikelihood of three different members; SparseHensman and OpperArchambeau models with non-Gaussian likelihoods
+    (loss, every gradient, predict_f, predict_y)"""
+    L = g
+    out = {}
+    n = 17
+    tags = []
+    for tag, make in _likelihood_zoo(L):
+        rng = np.random.default_rng(sum(ord(c) for c in tag))
+        lik = make()
+        y = _likelihood_targets(tag, rng, n).reshape(-1, 1)
+        mu = rng.normal(0.2, 0.6, (n, 1)); var = rng.uniform(0.05, 0.6, (n, 1))
+        X = np.stack([np.zeros(n), np.linspace(0, 1, n)], axis=1)
+        lik.validate_y(T(X), T(y))
+        f = rng.normal(0.2, 0.8, (n, 5))
+        tmu = torch.tensor(mu, dtype=torch.float64, requires_grad=True); tvar = torch.tensor(var, dtype=torch.float64, requires_grad=True)
+        ve = lik.variational_expectation(T(X), T(y), tmu, tvar)
+        ve.backward()
+        out[tag + "_y"] = y; out[tag + "_mu"] = mu; out[tag + "_var"] = var; out[tag + "_f"] = f; out[tag + "_X"] = X
+        out[tag + "_logp"] = lik.log_prob(T(X), T(y), T(f)).detach().numpy()
+        out[tag + "_ve"] = np.array(float(ve))
+        out[tag + "_dmu"] = tmu.grad.numpy().reshape(-1)
+        out[tag + "_dvar"] = np.zeros(n) if tvar.grad is None else tvar.grad.numpy().reshape(-1)
+        dump_params(tag + "_lik_", list(lik.parameters()), out, with_grad=True)
+        with torch.no_grad():
+            out[tag + "_cmean"] = lik.conditional_mean(T(X), T(f)).numpy()
+            out[tag + "_pmean"] = np.asarray(lik.predict(T(X), T(mu), T(var))).reshape(-1)
+            if tag not in ("gaussian",):
+                torch.manual_seed(1234)
+                try:
+                    _, lo, hi = lik.predict(T(X), T(mu), T(var), ci=[0.1, 0.9], n=500)
+                    out[tag + "_lo"] = np.asarray(lo).reshape(-1); out[tag + "_hi"] = np.asarray(hi).reshape(-1)
+                except Exception as e:                      # a sampler the reference itself cannot run for this configuration
+                    out[tag + "_ci_error"] = np.array(type(e).__name__)
+        tags.append(tag)
+    out["tags"] = np.array(tags)
+
+    # MultiOutputLikelihood: three members, shuffled channels
+    rng = np.random.default_rng(4242)
+    n = 30
+    X = np.stack([rng.integers(0, 3, n).astype(np.float64), rng.uniform(0, 1, n)], axis=1)
+    y = np.where(X[:, 0] == 0, rng.normal(0, 1, n), np.where(X[:, 0] == 1, rng.poisson(2.0, n), rng.uniform(0.2, 3.0, n))).reshape(-1, 1)
+    lik = L.MultiOutputLikelihood(L.StudentTLikelihood(dof=5, scale=0.5), L.PoissonLikelihood(), L.WeibullLikelihood(shape=1.3))
+    lik.validate_y(T(X), T(y))
+    mu = rng.normal(0.2, 0.6, (n, 1)); var = rng.uniform(0.05, 0.6, (n, 1))
+    tmu = torch.tensor(mu, dtype=torch.float64, requires_grad=True); tvar = torch.tensor(var, dtype=torch.float64, requires_grad=True)
+    ve = lik.variational_expectation(T(X), T(y), tmu, tvar)
+    ve.backward()
+    out["multi_X"] = X; out["multi_y"] = y; out["multi_mu"] = mu; out["multi_var"] = var
+    out["multi_ve"] = np.array(float(ve)); out["multi_dmu"] = tmu.grad.numpy().reshape(-1); out["multi_dvar"] = tvar.grad.numpy().reshape(-1)
+    dump_params("multi_lik_", list(lik.parameters()), out, with_grad=True)
+    with torch.no_grad():
+        out["multi_pmean"] = lik.predict(T(X), T(mu), T(var)).numpy().reshape(-1)
+        out["multi_name"] = np.array(lik.name())
+
+    # models: SparseHensman + StudentT, SparseHensman + multi-output [Poisson, Gaussian], OpperArchambeau + Bernoulli, Hensman + Laplace
+    def kernel(C, Q, rng):
+        k = g.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=1)
+        k.weight.assign(rng.uniform(0.5, 1.5, (C, Q))); k.mean.assign(rng.uniform(0.05, 0.5, (C, Q, 1)))
+        k.variance.assign(rng.uniform(0.05, 0.5, (C, Q, 1))); k.delay.assign(rng.normal(0, 0.3, (C, Q, 1))); k.phase.assign(rng.normal(0, 0.3, (C, Q)))
+        return k
+
+    specs = [("svgp_studentt", 2, "sparse"), ("svgp_multi", 2, "sparse"), ("oa_bernoulli", 2, "oa"), ("hensman_laplace", 1, "dense"), ("oa_gamma", 1, "oa")]
+    out["model_tags"] = np.array([sp[0] for sp in specs])
+    for tag, C, kind in specs:
+        rng = np.random.default_rng(sum(ord(c) for c in tag))
+        N = 60
+        X, y = small_data(N, C, 1, 5100 + len(tag), False)
+        if tag == "svgp_studentt":
+            lik = L.StudentTLikelihood(dof=4, scale=0.4)
+        elif tag == "svgp_multi":
+            y = np.where(X[:, 0] == 0, rng.poisson(np.exp(0.5 * y)), y).astype(np.float64)
+            lik = L.MultiOutputLikelihood(L.PoissonLikelihood(), L.GaussianLikelihood(0.3))
+        elif tag == "oa_bernoulli":
+            y = (y > 0).astype(np.float64)
+            lik = L.BernoulliLikelihood()
+        elif tag == "hensman_laplace":
+            lik = L.LaplaceLikelihood(scale=0.3)
+        else:
+            y = np.exp(0.5 * y) * rng.gamma(2.0, 0.5, N)
+            lik = L.GammaLikelihood(shape=2.0)
+        k = kernel(C, 2, rng)
+        if kind == "sparse":
+            Z = T(np.concatenate([np.stack([np.full(5, float(c)), np.sort(rng.uniform(0, 10, 5))], axis=1) for c in range(C)]))
+            m = g.SparseHensman(k, T(X), T(y), Z=Z, likelihood=lik, jitter=1e-6)
+        elif kind == "dense":
+            m = g.Hensman(k, T(X), T(y), likelihood=lik, jitter=1e-6)
+        else:
+            m = g.OpperArchambeau(k, T(X), T(y), likelihood=lik, jitter=1e-6)
+        if kind == "oa":
+            m.q_nu.assign(rng.normal(0, 0.3, (N, 1))); m.q_lambda.assign(rng.uniform(0.5, 2.0, (N, 1)))
+        else:
+            M = m.q_mu().shape[0]
+            m.q_mu.assign(rng.normal(0, 0.5, (M, 1)))
+            m.q_sqrt.assign(np.tril(rng.normal(0, 0.2, (M, M))) + np.diag(rng.uniform(0.5, 1.2, M)))
+        pre = tag + "_"
+        out[pre + "meta"] = np.array([C, 2, 1, 1]); out[pre + "X"] = X; out[pre + "y"] = y
+        if kind == "sparse":
+            out[pre + "Z"] = m.Z().detach().numpy()
+        out[pre + "loss"] = np.array(float(m.loss()))
+        dump_params(pre, list(m.parameters()), out, with_grad=True)
+        Xs, _ = small_data(15, C, 1, 5200 + len(tag), False)
+        mu_f, var_f = m.predict_f(T(Xs))
+        out[pre + "Xs"] = Xs; out[pre + "mu_f"] = mu_f.numpy(); out[pre + "var_f"] = var_f.numpy()
+        out[pre + "mu_y"] = np.asarray(m.predict_y(T(Xs))).reshape(-1)
+    np.savez_compressed(os.path.join(HERE, "likelihoods.npz"), **out)
+    print("likelihoods.npz written", len(tags), "likelihoods")
+
+
 def gen_checkpoints():
     """Files written by the reference's own Model.save() (model.py:320-336) -- the whole pickled model: MOSM with a fitted transformer
     chain, removed points and a pegged + a fixed parameter; the SM, CSM, SM-LMC and CONV wrappers; a Titsias MOSM -- stored as bytes next to what
@@ -872,6 +1016,7 @@ def gen_checkpoints():
         out[tag + "_loss"] = np.array(float(loaded.loss()))
         for i, p in enumerate(loaded.gpr.parameters()):
             out["%s_g%d" % (tag, i)] = np.zeros(0) if p.grad is None else p.grad.detach().numpy()
+        torch.manual_seed(4321)                               # the intervals of non-Gaussian likelihoods are sampled from torch's generator
         X, mu, lower, upper = loaded.predict(transformed=False)
         out[tag + "_mu"] = np.concatenate([np.asarray(m).reshape(-1) for m in mu])
         out[tag + "_lower"] = np.concatenate([np.asarray(m).reshape(-1) for m in lower])
@@ -897,6 +1042,11 @@ def gen_checkpoints():
     m.train(method="Adam", lr=0.02, iters=4, verbose=False); record("hensman", m)
     m = mogptk.MOSM(dataset(2, 40), Q=1, inference=mogptk.OpperArchambeau()); randomise(m)
     m.train(method="Adam", lr=0.02, iters=4, verbose=False); record("oa", m)
+    ds = dataset(2, 40)
+    ds[0].Y = np.round(np.exp(ds[0].Y)).astype(np.float64)           # counts for the Poisson channel
+    lik = mogptk.gpr.MultiOutputLikelihood(mogptk.gpr.PoissonLikelihood(), mogptk.gpr.StudentTLikelihood(dof=5, scale=0.4, quadratures=12))
+    m = mogptk.MOSM(ds, Q=1, inference=mogptk.Hensman(inducing_points=5, likelihood=lik)); randomise(m)
+    m.train(method="Adam", lr=0.02, iters=3, verbose=False); record("hensman_lik", m)
     np.savez_compressed(os.path.join(HERE, "checkpoints.npz"), **out)
     print("checkpoints.npz", {k: v.shape for k, v in out.items() if k.endswith("_file")})
 
@@ -908,7 +1058,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "lbfgs": gen_lbfgs_cfg1, "quirks": gen_quirks,
              "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2, "smlmc": gen_smlmc, "init_ls": gen_init_ls, "bnse": gen_bnse, "transformers": gen_transformers,
-             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints, "snelson": gen_snelson, "hensman": gen_hensman, "oa": gen_oa}
+             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints, "snelson": gen_snelson, "hensman": gen_hensman, "oa": gen_oa, "likelihoods": gen_likelihoods}
     full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:
         {**steps, **full}[a.only]()

@@ -644,3 +644,10 @@ def test_oa_device_raw_outputs_against_numpy_model(N):
     m1, s1 = dev.predict(nv, 1e-8, kd, Xs)
     m2, s2 = ref.predict(nv, 1e-8, kd, Xs)
     assert relerr(m1, m2) < 1e-8 and np.max(np.abs(s1 - s2)) < 1e-8
+
+
+def test_variational_models_with_non_gaussian_likelihoods_on_device():
+    """SparseHensman / Hensman / OpperArchambeau with Student-t, Poisson + Gaussian per channel, Bernoulli, Laplace, Gamma
+    likelihoods -- the device algebra around the host's likelihood, against the reference's loss and autograd gradients"""
+    from test_host_logic import check_likelihood_models
+    check_likelihood_models(tol_loss=1e-9, tol_grad=1e-6, tol_pred=1e-7)

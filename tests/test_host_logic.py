@@ -546,14 +546,14 @@ def test_mohsm_predict_and_wrapper_match_reference():
 
 
 # ---- checkpoints written by the reference's Model.save() load without the reference ----------------------------------
-def check_reference_checkpoints(tmp_path, tol_value=1e-12, tol_loss=1e-8, tol_grad=1e-6, tol_pred=1e-6, tags=("mosm", "sm", "csm", "smlmc", "conv", "titsias", "snelson", "hensman", "oa")):
+def check_reference_checkpoints(tmp_path, tol_value=1e-12, tol_loss=1e-8, tol_grad=1e-6, tol_pred=1e-6, tags=("mosm", "sm", "csm", "smlmc", "conv", "titsias", "snelson", "hensman", "oa", "hensman_lik")):
     """checkpoints.npz: the bytes of files the reference wrote, and what the reference itself computes after loading them"""
     fx = load("checkpoints.npz")
     for tag in tags:
         path = tmp_path / ("ref_%s" % tag)
         (tmp_path / ("ref_%s.npy" % tag)).write_bytes(fx[tag + "_file"].tobytes())
         m = mogptk_amd.LoadModel(str(path))
-        assert type(m).__name__ == {"mosm": "MOSM", "sm": "SM", "csm": "CSM", "smlmc": "SM_LMC", "conv": "CONV", "titsias": "MOSM", "snelson": "MOSM", "hensman": "MOSM", "oa": "MOSM"}[tag]
+        assert type(m).__name__ == {"mosm": "MOSM", "sm": "SM", "csm": "CSM", "smlmc": "SM_LMC", "conv": "CONV", "titsias": "MOSM", "snelson": "MOSM", "hensman": "MOSM", "oa": "MOSM", "hensman_lik": "MOSM"}[tag]
         ps = list(m.gpr.parameters())
         assert [p._name for p in ps] == [str(n) for n in fx[tag + "_names"]]
         for i, p in enumerate(ps):
@@ -570,11 +570,15 @@ def check_reference_checkpoints(tmp_path, tol_value=1e-12, tol_loss=1e-8, tol_gr
                 assert p.grad is None, (tag, p._name)
             else:
                 assert np.max(np.abs(p.grad - g)) <= tol_grad * max(1.0, np.max(np.abs(g))), (tag, p._name)
+        if tag == "hensman_lik":
+            import torch
+            torch.manual_seed(4321)                              # sampled intervals: same generator, same seed, same sequence of draws as the reference
         _, mu, lower, upper = m.predict(transformed=False)
         cat = lambda parts: np.concatenate([np.asarray(v).reshape(-1) for v in (parts if isinstance(parts, list) else [parts])])
         for got, key in ((mu, "_mu"), (lower, "_lower"), (upper, "_upper")):
             ref = fx[tag + key]
-            assert np.max(np.abs(cat(got) - ref)) <= tol_pred * max(1.0, np.max(np.abs(ref))), (tag, key)
+            fin = np.isfinite(ref)                               # (the log of a zero Poisson count is -inf on both sides)
+            assert np.array_equal(cat(got)[~fin], ref[~fin]) and np.max(np.abs(cat(got)[fin] - ref[fin])) <= tol_pred * max(1.0, np.max(np.abs(ref[fin]))), (tag, key)
         # and back out through this package's own save / load
         m.save(str(tmp_path / ("own_%s" % tag)))
         m2 = mogptk_amd.LoadModel(str(tmp_path / ("own_%s" % tag)))
@@ -705,6 +709,63 @@ def test_opper_archambeau_through_the_model_wrapper():
     assert losses.shape == (4,) and np.all(np.isfinite(losses)) and losses[-1] < losses[0]
     _, mu, lower, upper = m.predict(transformed=False)
     assert all(np.all(np.isfinite(v)) for v in mu)
+
+
+def check_likelihood_models(tol_loss=1e-9, tol_grad=1e-7, tol_pred=1e-8):
+    """likelihoods.npz: SparseHensman / Hensman / OpperArchambeau with non-Gaussian likelihoods, pinned on the reference's loss, autograd
+    gradients of every parameter (likelihood parameters included), predict_f and the mean of predict_y"""
+    fx = load("likelihoods.npz")
+    L = gpr
+    for tag in [str(t) for t in fx["model_tags"]]:
+        pre = tag + "_"
+        C, Q, D, _ = [int(v) for v in fx[pre + "meta"]]
+        lik = {"svgp_studentt": lambda: L.StudentTLikelihood(dof=4, scale=0.4),
+               "svgp_multi": lambda: L.MultiOutputLikelihood(L.PoissonLikelihood(), L.GaussianLikelihood(0.3)),
+               "oa_bernoulli": lambda: L.BernoulliLikelihood(),
+               "hensman_laplace": lambda: L.LaplaceLikelihood(scale=0.3),
+               "oa_gamma": lambda: L.GammaLikelihood(shape=2.0)}[tag]()
+        k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=D)
+        X, y = fx[pre + "X"], fx[pre + "y"]
+        if tag.startswith("svgp"):
+            m = gpr.SparseHensman(k, X, y, Z=fx[pre + "Z"], likelihood=lik, jitter=1e-6)
+        elif tag.startswith("hensman"):
+            m = gpr.Hensman(k, X, y, likelihood=lik, jitter=1e-6)
+        else:
+            m = gpr.OpperArchambeau(k, X, y, likelihood=lik, jitter=1e-6)
+        fp = fixture_params(fx, pre)
+        assert [p._name for p in m.parameters()] == [f["name"] for f in fp], tag
+        load_raw(m.parameters(), fp)
+        loss, ref = float(m.loss()), float(fx[pre + "loss"])
+        assert abs(loss - ref) < tol_loss * max(1.0, abs(ref)), (tag, loss, ref)
+        for p, f in zip(m.parameters(), fp):
+            if f["grad"] is None:
+                assert p.grad is None, (tag, p._name)
+            else:
+                assert p.grad is not None, (tag, p._name)
+                assert np.max(np.abs(p.grad - f["grad"])) <= tol_grad * max(1.0, np.max(np.abs(f["grad"]))), (tag, p._name, np.max(np.abs(p.grad - f["grad"])))
+        mu, var_p = m.predict_f(fx[pre + "Xs"])
+        assert relerr(mu, fx[pre + "mu_f"]) < tol_pred and np.max(np.abs(var_p - fx[pre + "var_f"])) < tol_pred * max(1.0, np.max(np.abs(fx[pre + "var_f"]))), tag
+        assert relerr(np.reshape(m.predict_y(fx[pre + "Xs"]), -1), fx[pre + "mu_y"]) < tol_pred, tag
+
+
+def test_variational_models_with_non_gaussian_likelihoods_match_reference():
+    check_likelihood_models()
+
+
+def test_non_gaussian_likelihood_through_the_model_wrapper():
+    rng = np.random.default_rng(5)
+    t = np.linspace(0, 10, 40)
+    counts = rng.poisson(np.exp(0.8 * np.sin(t))).astype(np.float64)
+    ds = mogptk_amd.DataSet(t, [counts, np.cos(t)])
+    lik = gpr.MultiOutputLikelihood(gpr.PoissonLikelihood(), gpr.StudentTLikelihood(dof=4, scale=0.3))
+    m = mogptk_amd.MOSM(ds, Q=1, inference=mogptk_amd.Hensman(inducing_points=6, likelihood=lik))
+    losses, _ = m.train("Adam", iters=5, lr=0.05)
+    assert losses.shape == (6,) and np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+    _, mu, lower, upper = m.predict(transformed=False)
+    assert all(np.all(np.isfinite(v)) for v in mu) and np.all(np.asarray(mu[0]) > 0)          # the Poisson channel predicts a rate
+    m.save("/tmp/_mogp_lik_model")
+    m2 = mogptk_amd.LoadModel("/tmp/_mogp_lik_model")
+    assert abs(m2.loss() - m.loss()) < 1e-12 * abs(m.loss()) and m2.gpr.likelihood.name() == "[PoissonLikelihood,StudentTLikelihood]"
 
 
 def test_hensman_through_the_model_wrapper():
