@@ -200,6 +200,19 @@ def sharded_probe(m, dist, sync, world, cfg3=True, reps=5):
             out["cfg3_mosm_c8_q5_n32768"] = run(m3, 2)
         except Exception as e:
             out["cfg3_mosm_c8_q5_n32768"] = {"error": repr(e)}
+        # the sparse bound (configs[4]) DATA-PARALLEL: every rank holds every world-th training point, the sums over points are all-reduced
+        # inside the library (mogp_titsias_eval_sharded: M^2 + M + 3 doubles, then the (Z, X) moments); strong scaling at N = 100 000 and
+        # weak scaling at 100 000 points per rank, each next to the one-GPU evaluation of the same model
+        for tag, n5 in (("cfg5_titsias_n100000_m2048", 100000), ("cfg5_weak_%d_points_per_rank" % 100000, 100000 * world)):
+            if tag.startswith("cfg5_weak") and world == 1:
+                continue
+            try:
+                m5, _, _ = build_model("cfg5", None, n_override=n5)
+                out[tag] = run(m5, 3)
+                out[tag]["N"] = n5
+                del m5
+            except Exception as e:
+                out[tag] = {"error": repr(e)}
     return out
 
 
@@ -238,9 +251,7 @@ def main():
     from mogptk_amd import _lib
 
     m, run_step, algo_flops = build_model(a.config, local_rank, a.n)
-    sharded_mode = a.mode == "sharded" and kind in ("exact", "predict")
-    if a.mode == "sharded" and not sharded_mode:
-        raise SystemExit("--mode sharded applies to the exact-GP configurations (cfg2, cfg3, cfg4)")
+    sharded_mode = a.mode == "sharded"       # exact / predict: one evaluation's tiles over the ranks; titsias: its data points over the ranks
 
     def sync():
         if torch.cuda.is_available():
@@ -314,7 +325,8 @@ def main():
             metric = METRICS[kind][0] % (C, N, extra)
         if a.config == "cfg2":
             metric = "log-marginal-likelihood+grad evals/sec, MOSM C=4 N=8192; 1/2/4/8 GPU"      # BASELINE.json's wording
-        par = "1 gpu" if world == 1 and not sharded_mode else ("sharded x%d (tile rows cyclic, RCCL all-gather per pivot block)" % world if sharded_mode else "replicas x%d" % world)
+        par = "1 gpu" if world == 1 and not sharded_mode else (("data-parallel x%d (points cyclic over the ranks, RCCL all-reduce of the M x M sums)" % world if kind == "titsias" else
+                                                                       "sharded x%d (tile rows cyclic, RCCL all-gather per pivot block)" % world) if sharded_mode else "replicas x%d" % world)
         out = {
             "metric": metric, "value": value, "unit": METRICS[kind][1], "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if sharded_mode else "weak", "vs_baseline": None,

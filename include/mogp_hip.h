@@ -127,6 +127,18 @@ int  mogp_titsias_eval(mogp_model* m, int64_t M, const double* Z, double sigma, 
 /* replaces Titsias.predict_f (gpr/model.py:730-765), diagonal variance: mu[S], var[S]. */
 int  mogp_titsias_predict(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kss_diag,
                           int64_t S, const double* Xs, double* mu, double* var, int64_t* info);
+/* The same two calls DATA-PARALLEL over the ranks of the context's communicator (mogp_comm_init_*; new design, the reference has no
+ * multi-device path): each rank's handle was created on ITS OWN SHARD of the training points (any split; Z, sigma, the terms and the
+ * arguments are the same on every rank).  The sparse bound touches the data only through sums over points: K_uf and v = L^-1 K_uf are built
+ * for the local columns, v v^T (M x M), v y, y^T y, N and sum K_ff,nn are all-reduced (M^2 + M + 3 doubles), every M x M stage then runs
+ * replicated, the adjoint of K_uf and its moments are local again and the (C C T W) moments and the D x M inducing-input gradient of that
+ * part are all-reduced.  Every rank returns the FULL model's ELBO and gradient (mom_uf / gZ already summed over ranks).  The O(N M^2) work
+ * is divided by the number of ranks; the O(M^3) work is not.  With one rank (or no communicator) they equal the plain calls. */
+int  mogp_titsias_eval_sharded(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kff_diag, int flags,
+                               double* elbo, double* mom_uu, double* mom_uf, double* gZ, double* trGA, double* dsigma,
+                               double* jitter_abs, int64_t* info);
+int  mogp_titsias_predict_sharded(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kss_diag,
+                                  int64_t S, const double* Xs, double* mu, double* var, int64_t* info);
 
 /* ---- sharded exact evaluation / prediction across the GPUs of one node -------------------------------------------
  * The reference has no distributed code at all (no torch.distributed / NCCL call site: SURVEY.md section 5); this is new design behind the

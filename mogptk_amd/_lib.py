@@ -52,6 +52,10 @@ SIGNATURES = {
                                          c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_i64p]),
     "mogp_titsias_predict": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, ctypes.c_double, ctypes.c_double, c_dp,
                                             ctypes.c_int64, c_dp, c_dp, c_dp, c_i64p]),
+    "mogp_titsias_eval_sharded": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, ctypes.c_double, ctypes.c_double, c_dp, ctypes.c_int,
+                                                 c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_i64p]),
+    "mogp_titsias_predict_sharded": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, ctypes.c_double, ctypes.c_double, c_dp,
+                                                    ctypes.c_int64, c_dp, c_dp, c_dp, c_i64p]),
     "mogp_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "mogp_comm_init_rccl": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "mogp_comm_init_external": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
@@ -293,8 +297,9 @@ class ExactHandle:
         arr = np.ascontiguousarray(arr, dtype=np.float64)
         check(lib().mogp_dev_copy(ctypes.c_void_p(ptr), arr.ctypes.data_as(ctypes.c_void_p), 8 * arr.size, 1))
 
-    def titsias_eval(self, Z, sigma, jitter, kff_diag, grad=True):
-        """Titsias bound (+ gradient outputs) through mogp_titsias_eval"""
+    def titsias_eval(self, Z, sigma, jitter, kff_diag, grad=True, sharded=False):
+        """Titsias bound (+ gradient outputs) through mogp_titsias_eval, or -- this handle holding one shard of the data -- through
+        mogp_titsias_eval_sharded (the same result on every rank: the full model's)"""
         Z = _f64(Z)
         kff_diag = _f64(kff_diag)
         M = Z.shape[0]
@@ -304,20 +309,21 @@ class ExactHandle:
         mom_uu = np.zeros((C * (C + 1) // 2, T, W)) if grad else None
         mom_uf = np.zeros((C * C, T, W)) if grad else None
         gZ = np.zeros((M, D)) if grad else None
-        code = lib().mogp_titsias_eval(self._h, M, _dp(Z), float(sigma), float(jitter), _dp(kff_diag),
-                                       MOGP_EVAL_GRAD if grad else 0, ctypes.byref(elbo), _dp(mom_uu), _dp(mom_uf), _dp(gZ),
-                                       ctypes.byref(trGA), ctypes.byref(dsig), ctypes.byref(jit), ctypes.byref(info))
+        fn = lib().mogp_titsias_eval_sharded if sharded else lib().mogp_titsias_eval
+        code = fn(self._h, M, _dp(Z), float(sigma), float(jitter), _dp(kff_diag),
+                  MOGP_EVAL_GRAD if grad else 0, ctypes.byref(elbo), _dp(mom_uu), _dp(mom_uf), _dp(gZ),
+                  ctypes.byref(trGA), ctypes.byref(dsig), ctypes.byref(jit), ctypes.byref(info))
         check(code, info.value)
         return dict(elbo=elbo.value, mom_uu=mom_uu, mom_uf=mom_uf, gZ=gZ, trGA=trGA.value, dsigma=dsig.value,
                     jitter_abs=jit.value)
 
-    def titsias_predict(self, Z, sigma, jitter, Xs, kss_diag):
+    def titsias_predict(self, Z, sigma, jitter, Xs, kss_diag, sharded=False):
         Z, Xs, kss_diag = _f64(Z), _f64(Xs), _f64(kss_diag)
         S = Xs.shape[0]
         mu, var = np.empty(S), np.empty(S)
         info = ctypes.c_int64(0)
-        code = lib().mogp_titsias_predict(self._h, Z.shape[0], _dp(Z), float(sigma), float(jitter), _dp(kss_diag), S, _dp(Xs),
-                                          _dp(mu), _dp(var), ctypes.byref(info))
+        fn = lib().mogp_titsias_predict_sharded if sharded else lib().mogp_titsias_predict
+        code = fn(self._h, Z.shape[0], _dp(Z), float(sigma), float(jitter), _dp(kss_diag), S, _dp(Xs), _dp(mu), _dp(var), ctypes.byref(info))
         check(code, info.value)
         return mu.reshape(-1, 1), var.reshape(-1, 1)
 

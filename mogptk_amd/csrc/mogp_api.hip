@@ -399,6 +399,7 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     const int64_t N = m->N, Npad = m->Npad;
     if (m->T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms must be called before an evaluation");
     if (!noise_var) return fail(MOGP_EINVAL, "noise_var is null");
+    { int r__ = ensure_system(m); if (r__) return r__; }
     m->have_W = m->have_Kinv = false;
     m->factor_only = factor_only;
     m->gemm_ev_used = 0; m->gemm_launches = 0; m->gemm_flops = 0.0;
@@ -527,6 +528,7 @@ static int sweep_eval_begin(mogp_model* m, const double* noise_var, const double
     const int64_t N = m->N, Npad = m->Npad;
     if (m->T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms must be called before an evaluation");
     if (!noise_var) return fail(MOGP_EINVAL, "noise_var is null");
+    { int r__ = ensure_system(m); if (r__) return r__; }
     m->have_W = m->have_Kinv = false;
     m->gemm_ev_used = 0; m->gemm_launches = 0; m->gemm_flops = 0.0;
     double dsum = 0.0;
@@ -707,7 +709,8 @@ int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, c
 #define TRY_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { int r__ = hip_fail(e__, #x, __FILE__, __LINE__); mogp_model_destroy(m); return r__; } } while (0)
     TRY_RC(ctx_streams(ctx));
     m->st = ctx->st; m->st2 = ctx->st2; m->st2u = ctx->st2u; m->st3 = ctx->st3; m->st4 = ctx->st4; m->st_priv = ctx->st_priv;
-    TRY_RC(spd_alloc(m->k, Npad));
+    // the N x N system (two Npad^2 matrices: 160 GB at N = 100 000) is allocated by the first call that factorises it (ensure_system): the
+    // sparse and variational models never do
     TRY_RC(m->d_x.ensure((size_t)D * Npad));
     TRY_RC(m->d_y.ensure(Npad));
     TRY_RC(m->d_noise.ensure(C));

@@ -131,6 +131,7 @@ struct TitsiasWork {
     DevBuf<double> Kus, Aus, Bus;                       // prediction panels (Mpad x Spad)
     DevBuf<double> zero_col;                            // Mpad zeros
     DevBuf<double> kslices;                             // split-K partial sums of the Qs SYRK (ks x Mpad x Mpad)
+    DevBuf<double> red;                                 // data-sharded evaluation: [v y | y^T y, N, sum K_ff,nn] for the all-reduce
     // svgp.hip: what the forward pass at the training inputs leaves for the backward pass
     SortedX sv_sz; std::vector<GTile> sv_tuu, sv_tuf; std::vector<int> sv_psuu, sv_psuf; int64_t sv_M = 0; bool sv_dense = false, sv_valid = false;
     DevBuf<double> nvec;                                // Snelson: per-point vectors (g, G, G y, sqrt G, v^T r / w, alpha, h) + per-channel inputs
@@ -141,7 +142,7 @@ struct TitsiasWork {
         zx.release(); B.release(); v.release(); GB.release(); Qs.release(); E.release(); R.release(); T1.release(); GA.release(); Hm.release();
         vec.release(); scratch.release(); gz.release(); partial_uu.release(); partial_uf.release(); mom_uu.release(); mom_uf.release();
         zero_noise.release(); tiles_uu.release(); tiles_uf.release(); ps_uu.release(); ps_uf.release();
-        Kus.release(); Aus.release(); Bus.release(); zero_col.release(); kslices.release(); nvec.release();
+        Kus.release(); Aus.release(); Bus.release(); zero_col.release(); kslices.release(); nvec.release(); red.release();
     }
 };
 
@@ -231,6 +232,7 @@ int gemm_call(mogp_model* m, const GemmArgs& g, double flops, hipStream_t st = n
 int mark(mogp_model* m, int idx);
 double table_diag(const mogp_model* m, int c);
 int spd_alloc(Spd& w, int64_t Npad);
+inline int ensure_system(mogp_model* m) { return spd_alloc(m->k, m->Npad); }     // the N x N system of the exact / OA paths, on first use
 int spd_potrf(mogp_model* m, Spd& w, long long info_base = 0);
 int spd_potri_fused(mogp_model* m, Spd& w);
 int spd_potri_fused_finish(mogp_model* m, Spd& w);   // joins the inverse stream: call before reading w.B   // potri.hip: w.A (SPD, lower) -> w.Wm = L^-1, w.B = inverse (lower); w.logdet per tile

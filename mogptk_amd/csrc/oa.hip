@@ -104,6 +104,7 @@ int mogp_oa_forward(mogp_model* m, const double* q_nu, const double* q_lambda, d
         if (!(q_lambda[i] > 0.0)) return fail(MOGP_EINVAL, "mogp_oa_forward: q_lambda must be positive");
     OaWork& o = m->oa;
     o.valid = false;
+    RC(ensure_system(m));
     m->have_W = m->have_Kinv = false;
     m->gemm_ev_used = 0; m->gemm_launches = 0; m->gemm_flops = 0.0;
     RC(o.K.ensure((size_t)Npad * Npad));

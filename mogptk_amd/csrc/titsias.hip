@@ -47,11 +47,14 @@ static int check_info(mogp_model* m, const char* which, int64_t* info) {
 
 // Common front end: sort Z, build tiles, Kuu -> W (in tw.a.A), Kuf -> tw.B, v -> tw.v, Qs -> tw.Qs, Wq (tw.q.A), Pq (tw.q.B, full),
 // vy, t1 in tw.vec[0 : Mpad], tw.vec[Mpad : 2 Mpad].  Host scalars through `sc`.
-struct TitsiasScalars { double logdet_q, yy, t1vy, t1t1, trPq, trQs, jit; };
+struct TitsiasScalars { double logdet_q, yy, t1vy, t1t1, trPq, trQs, jit, ntot, kff; };
 
+// sharded: this handle holds ONE SHARD of the training points (the ranks of the context's communicator hold the others; Z, sigma and the
+// terms are the same everywhere).  Everything that sums over data points -- v v^T, v y, y^T y, N, sum K_ff,nn -- is all-reduced, after which
+// every M x M quantity is the full model's on every rank (two collectives: Mpad^2 doubles and Mpad + 3).
 static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, SortedX& sz,
                          std::vector<GTile>& tuu, std::vector<int>& psuu, std::vector<GTile>& tuf, std::vector<int>& psuf,
-                         TitsiasScalars& sc, int64_t* info, bool need_moment_tiles) {
+                         TitsiasScalars& sc, int64_t* info, bool need_moment_tiles, bool sharded = false, const double* kff_diag = nullptr) {
     const int C = m->C, D = m->D, W = 2 + 3 * D;
     const int64_t Npad = m->Npad;
     if (m->T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms must be called before an evaluation");
@@ -138,6 +141,25 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     }
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
     if (ks > 1) RC(launch_sum_slices(t.kslices.p, (int64_t)Mpad * Mpad, ks, t.q.A.p, m->st));
+    double* vy = t.vec.p;
+    RC(launch_gemv_rows(t.v.p, Npad, Mpad, Npad, m->d_y.p, vy, m->st));
+    sc.yy = 0.0; for (int64_t i = 0; i < m->N; ++i) sc.yy += m->hy[i] * m->hy[i];
+    sc.ntot = (double)m->N;
+    sc.kff = 0.0;
+    if (kff_diag) for (int c = 0; c < C; ++c) sc.kff += (double)(m->sx.off[c + 1] - m->sx.off[c]) * kff_diag[c];
+    if (sharded) {
+        RC(comm_allreduce(m->ctx, t.q.A.p, Mpad * Mpad, m->st));
+        RC(t.red.ensure((size_t)Mpad + 4));
+        double hs[3] = {sc.yy, sc.ntot, sc.kff};
+        HIP_TRY(hipMemcpyAsync(t.red.p, vy, Mpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
+        HIP_TRY(hipMemcpyAsync(t.red.p + Mpad, hs, sizeof(hs), hipMemcpyHostToDevice, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));                                   // hs is a stack buffer
+        RC(comm_allreduce(m->ctx, t.red.p, Mpad + 3, m->st));
+        HIP_TRY(hipMemcpyAsync(vy, t.red.p, Mpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
+        HIP_TRY(hipMemcpyAsync(hs, t.red.p + Mpad, sizeof(hs), hipMemcpyDeviceToHost, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));
+        sc.yy = hs[0]; sc.ntot = hs[1]; sc.kff = hs[2];
+    }
     RC(launch_add_diag(t.q.A.p, Mpad, Mpad, 1.0, m->st));
     HIP_TRY(hipMemcpyAsync(t.Qs.p, t.q.A.p, (size_t)Mpad * Mpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->d_info.p, &big, sizeof(big), hipMemcpyHostToDevice, m->st));
@@ -146,10 +168,8 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     RC(spd_trtri(m, t.q));                                                      // t.q.A = Wq
     RC(spd_lauum(m, t.q));                                                      // t.q.B = Pq (lower)
     RC(launch_symmetrize(t.q.B.p, Mpad, Mpad, m->st));
-    double* vy = t.vec.p;
     double* t1 = t.vec.p + Mpad;
     double* dg = t.vec.p + 2 * Mpad;                                            // diag Pq, diag Qs
-    RC(launch_gemv_rows(t.v.p, Npad, Mpad, Npad, m->d_y.p, vy, m->st));
     // t1 = Pq (v y): the explicit inverse plus ONE step of iterative refinement against Qs.  Of the three places Pq enters the gradient,
     // this vector is the one where the explicitly formed inverse costs accuracy on dELBO/dZ (tools/titsias_numerics.py: 1.3e-4 -> 7e-5, the
     // same as two triangular solves with Lq), and three M x M mat-vecs are far cheaper than 2 nb dependent launches of a vector solve
@@ -166,13 +186,11 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     RC(launch_get_diag(t.q.B.p, Mpad, Mpad, dg, m->st));
     RC(launch_get_diag(t.Qs.p, Mpad, Mpad, dg + Mpad, m->st));
     const int nbq = t.q.nb;
-    std::vector<double> hv((size_t)4 * Mpad), hl(nbq), hy(Npad);
+    std::vector<double> hv((size_t)4 * Mpad), hl(nbq);
     HIP_TRY(hipMemcpyAsync(hv.data(), t.vec.p, (size_t)4 * Mpad * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(hl.data(), t.q.logdet.p, nbq * sizeof(double), hipMemcpyDeviceToHost, m->st));
-    HIP_TRY(hipMemcpyAsync(hy.data(), m->d_y.p, Npad * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
     sc.logdet_q = 0.0; for (double x : hl) sc.logdet_q += x;
-    sc.yy = 0.0; for (double x : hy) sc.yy += x * x;
     sc.t1vy = sc.t1t1 = sc.trPq = sc.trQs = 0.0;
     for (int64_t i = 0; i < M; ++i) {
         sc.t1vy += hv[Mpad + i] * hv[i]; sc.t1t1 += hv[Mpad + i] * hv[Mpad + i];
@@ -181,11 +199,9 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     return 0;
 }
 
-extern "C" {
-
-int mogp_titsias_eval(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kff_diag, int flags,
-                      double* elbo, double* mom_uu, double* mom_uf, double* gZ, double* trGA, double* dsigma,
-                      double* jitter_abs, int64_t* info) {
+static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kff_diag, int flags,
+                             double* elbo, double* mom_uu, double* mom_uf, double* gZ, double* trGA, double* dsigma,
+                             double* jitter_abs, int64_t* info, bool sharded) {
     if (!m || !Z || !kff_diag || !elbo || M <= 0) return fail(MOGP_EINVAL, "mogp_titsias_eval: bad argument");
     RC(use_device(m->ctx));
     if (info) *info = 0;
@@ -196,22 +212,21 @@ int mogp_titsias_eval(mogp_model* m, int64_t M, const double* Z, double sigma, d
     std::vector<GTile> tuu, tuf;
     std::vector<int> psuu, psuf;
     TitsiasScalars sc;
-    RC(titsias_front(m, M, Z, sigma, jitter, sz, tuu, psuu, tuf, psuf, sc, info, grad));
+    RC(titsias_front(m, M, Z, sigma, jitter, sz, tuu, psuu, tuf, psuf, sc, info, grad, sharded, kff_diag));
     TitsiasWork& t = *m->tw;
     const int64_t Mpad = t.Mpad;
     const int mt = (int)(Mpad / MOGP_TILE), nt = (int)(Npad / MOGP_TILE);
     const double s2 = sigma * sigma;
-    double kff = 0.0;
-    for (int c = 0; c < C; ++c) kff += (double)(m->sx.off[c + 1] - m->sx.off[c]) * kff_diag[c];
+    const double kff = sc.kff, Ntot = sc.ntot;                   // sums over ALL data points (all-reduced when the data is sharded)
     const double trQ = s2 * (sc.trQs - (double)M);
-    *elbo = -0.5 * (double)N * std::log(2.0 * M_PI) - sc.logdet_q - (double)N * std::log(sigma) - 0.5 * sc.yy / s2
+    *elbo = -0.5 * Ntot * std::log(2.0 * M_PI) - sc.logdet_q - Ntot * std::log(sigma) - 0.5 * sc.yy / s2
             + 0.5 * sc.t1vy / (s2 * s2) - 0.5 * (kff - trQ) / s2;
     if (jitter_abs) *jitter_abs = sc.jit;
     if (!grad) return MOGP_OK;
     if (!mom_uu || !mom_uf || !gZ || !trGA || !dsigma) return fail(MOGP_EINVAL, "mogp_titsias_eval: gradient outputs are null");
 
     // d ELBO / d s2, then d sigma  (tr(Pq Q) = s2 (M - tr Pq);  vy^T Pq Q Pq vy = s2 (t1.vy - t1.t1))
-    const double ds2 = -0.5 * (double)N / s2 + 0.5 * ((double)M - sc.trPq) / s2 + 0.5 * sc.yy / (s2 * s2) - sc.t1vy / (s2 * s2 * s2)
+    const double ds2 = -0.5 * Ntot / s2 + 0.5 * ((double)M - sc.trPq) / s2 + 0.5 * sc.yy / (s2 * s2) - sc.t1vy / (s2 * s2 * s2)
                        + 0.5 * (sc.t1vy - sc.t1t1) / (s2 * s2 * s2) + 0.5 * (kff - trQ) / (s2 * s2);
     *dsigma = 2.0 * sigma * ds2;
 
@@ -263,6 +278,10 @@ int mogp_titsias_eval(mogp_model* m, int64_t M, const double* Z, double sigma, d
     ma.gzr = t.gz.p; ma.gzc = nullptr; ma.ldgz = Mpad; ma.partial = t.partial_uf.p;
     RC(launch_moments(ma, m->st));
     RC(launch_moment_reduce(t.partial_uf.p, t.ps_uf.p, C * C, T, W, D, t.mom_uf.p, m->st, 0));
+    if (sharded) {                       // the (Z, X) moments and their share of d/dZ are sums over data points; the (Z, Z) pass below is not
+        RC(comm_allreduce(m->ctx, t.mom_uf.p, (int64_t)C * C * T * W, m->st));
+        RC(comm_allreduce(m->ctx, t.gz.p, (int64_t)D * Mpad, m->st));
+    }
     ma.tiles = t.tiles_uu.p; ma.ntiles = (int)tuu.size(); ma.xc = nullptr; ma.ldxc = 0; ma.ncols = M;
     RC(t.ph_zz.prepare(sz.off, sz.off, C, T, Mpad, Mpad, m->st, ma.ph));
     ma.G = t.GA.p; ma.ldg = Mpad; ma.ru = beta; ma.rw = beta; ma.rcoef = -0.5 / (s2 * s2); ma.sym = 1;
@@ -282,11 +301,41 @@ int mogp_titsias_eval(mogp_model* m, int64_t M, const double* Z, double sigma, d
     double tr = 0.0;
     for (int64_t i = 0; i < M; ++i) tr += hd[i] - 0.5 * hb[i] * hb[i] / (s2 * s2);
     *trGA = tr;
+    (void)N;
     return MOGP_OK;
+}
+
+static int titsias_predict_impl(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kss_diag,
+                                int64_t S, const double* Xs, double* mu, double* var, int64_t* info, bool sharded);
+
+extern "C" {
+
+int mogp_titsias_eval(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kff_diag, int flags,
+                      double* elbo, double* mom_uu, double* mom_uf, double* gZ, double* trGA, double* dsigma,
+                      double* jitter_abs, int64_t* info) {
+    return titsias_eval_impl(m, M, Z, sigma, jitter, kff_diag, flags, elbo, mom_uu, mom_uf, gZ, trGA, dsigma, jitter_abs, info, false);
+}
+
+int mogp_titsias_eval_sharded(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kff_diag, int flags,
+                              double* elbo, double* mom_uu, double* mom_uf, double* gZ, double* trGA, double* dsigma,
+                              double* jitter_abs, int64_t* info) {
+    return titsias_eval_impl(m, M, Z, sigma, jitter, kff_diag, flags, elbo, mom_uu, mom_uf, gZ, trGA, dsigma, jitter_abs, info, true);
 }
 
 int mogp_titsias_predict(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kss_diag,
                          int64_t S, const double* Xs, double* mu, double* var, int64_t* info) {
+    return titsias_predict_impl(m, M, Z, sigma, jitter, kss_diag, S, Xs, mu, var, info, false);
+}
+
+int mogp_titsias_predict_sharded(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kss_diag,
+                                 int64_t S, const double* Xs, double* mu, double* var, int64_t* info) {
+    return titsias_predict_impl(m, M, Z, sigma, jitter, kss_diag, S, Xs, mu, var, info, true);
+}
+
+}  // extern "C"
+
+static int titsias_predict_impl(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kss_diag,
+                                int64_t S, const double* Xs, double* mu, double* var, int64_t* info, bool sharded) {
     if (!m || !Z || !kss_diag || !Xs || !mu || !var || M <= 0 || S <= 0) return fail(MOGP_EINVAL, "mogp_titsias_predict: bad argument");
     RC(use_device(m->ctx));
     if (info) *info = 0;
@@ -295,7 +344,7 @@ int mogp_titsias_predict(mogp_model* m, int64_t M, const double* Z, double sigma
     std::vector<GTile> tuu, tuf, tus;
     std::vector<int> psuu, psuf;
     TitsiasScalars sc;
-    RC(titsias_front(m, M, Z, sigma, jitter, sz, tuu, psuu, tuf, psuf, sc, info, false));
+    RC(titsias_front(m, M, Z, sigma, jitter, sz, tuu, psuu, tuf, psuf, sc, info, false, sharded));
     TitsiasWork& t = *m->tw;
     const int64_t Mpad = t.Mpad;
     const double s2 = sigma * sigma;
@@ -335,5 +384,3 @@ int mogp_titsias_predict(mogp_model* m, int64_t M, const double* Z, double sigma
         }
     return MOGP_OK;
 }
-
-}  // extern "C"

@@ -388,11 +388,26 @@ class Titsias(Model):
         if kernel.output_dims is not None:
             self.Z.num_parameters -= self.Z().shape[0]
 
+    def _data_shard(self):
+        """the communicator this process shards its training points over (mogptk_amd.use_distributed), or None"""
+        comm = getattr(config, "comm", None)
+        if comm is not None and getattr(comm, "native", False) and (comm.world > 1 or comm.force):
+            return comm
+        return None
+
     def _device_handle(self):
-        if self._handle is None:
+        """the device model of this process's training points: all of them, or -- data-parallel over the ranks of the communicator -- every
+        world-th point starting at this rank (the bound touches the data only through sums over points: mogp_titsias_eval_sharded)"""
+        comm = self._data_shard()
+        key = None if comm is None else (comm.rank, comm.world)
+        if self._handle is None or self.__dict__.get("_handle_key") != key:
             from .._lib import ExactHandle
             y = self.y if self.mean is None else self.y - np.asarray(self.mean(self.X)).reshape(-1, 1)
-            self._handle = ExactHandle(config.device, self.kernel._kernel_format(self.X), y, self.kernel._channels())
+            Xk = self.kernel._kernel_format(self.X)
+            if comm is not None:
+                Xk, y = Xk[comm.rank::comm.world], y[comm.rank::comm.world]
+            self._handle = ExactHandle(config.device, Xk, y, self.kernel._channels())
+            self.__dict__["_handle_key"] = key
         return self._handle
 
     def _sigma(self):
@@ -409,7 +424,7 @@ class Titsias(Model):
         h.set_terms(table)
         Zk = self.kernel._kernel_format(self.Z())
         try:
-            res = h.titsias_eval(Zk, self._sigma(), self.jitter, self.kernel._spectral_diag(D), grad=grad)
+            res = h.titsias_eval(Zk, self._sigma(), self.jitter, self.kernel._spectral_diag(D), grad=grad, sharded=self._data_shard() is not None)
         except MogpError as e:
             if e.code in (MOGP_ENOTPD, MOGP_ENONFINITE):
                 print("ERROR:", str(e), file=sys.__stdout__)
@@ -457,7 +472,7 @@ class Titsias(Model):
         D = self.X.shape[1] - (0 if self.kernel.output_dims is None else 1)
         h.set_terms(self.kernel._spectral_terms(D))
         mu, var = h.titsias_predict(self.kernel._kernel_format(self.Z()), self._sigma(), self.jitter,
-                                    self.kernel._kernel_format(X), self.kernel._spectral_diag(D))
+                                    self.kernel._kernel_format(X), self.kernel._spectral_diag(D), sharded=self._data_shard() is not None)
         if self.mean is not None:
             mu = mu + np.asarray(self.mean(X)).reshape(-1, 1)
         return mu, var

@@ -185,10 +185,23 @@ def moments_dense(table, G, X1, X2, sym):
     return out
 
 
-def titsias_eval(self, Z, sigma, jitter, kff_diag, grad=True):
+def _all_reduce(self, sharded):
+    """sum over the ranks holding the other shards of the data: `TableDevice.reduce` is set by the test to the group's all-reduce"""
+    if not sharded:
+        return lambda a: a
+    red = getattr(self, "reduce", None)
+    if red is None:
+        raise RuntimeError("sharded evaluation of the numpy twin: set TableDevice.reduce to an all-reduce over the ranks")
+    return lambda a: red(np.ascontiguousarray(a, dtype=np.float64))
+
+
+def titsias_eval(self, Z, sigma, jitter, kff_diag, grad=True, sharded=False):
+    """numpy twin of mogp_titsias_eval; sharded: of mogp_titsias_eval_sharded -- this object holds one shard of the data, the sums over data
+    points (v v^T, v y, y^T y, N, sum K_ff,nn; then the (Z, X) moments and their share of d/dZ) are all-reduced at the same places"""
     from scipy.linalg import solve_triangular
     X, y, table, C = self.X, self.y, self.table, self.C
-    N, M, D = X.shape[0], Z.shape[0], self.D
+    M, D = Z.shape[0], self.D
+    red = _all_reduce(self, sharded)
     s2 = sigma * sigma
     cz = Z[:, 0].astype(np.int64)
     cx = X[:, 0].astype(np.int64)
@@ -199,12 +212,12 @@ def titsias_eval(self, Z, sigma, jitter, kff_diag, grad=True):
     Luu = np.linalg.cholesky(A)
     W = solve_triangular(Luu, np.eye(M), lower=True)
     v = W @ B
-    Q = v @ v.T
+    Q = red(v @ v.T)
+    vy = red(v @ y)
+    yy, N, kff = red(np.array([(y.T @ y).item(), float(X.shape[0]), float(np.sum(np.asarray(kff_diag)[cx]))]))
     Lq = np.linalg.cholesky(Q / s2 + np.eye(M))
-    vy = v @ y
     c = solve_triangular(Lq, vy, lower=True) / s2
-    kff = float(np.sum(np.asarray(kff_diag)[cx]))
-    elbo = (-0.5 * N * np.log(TWO_PI) - np.sum(np.log(np.diagonal(Lq))) - N * np.log(sigma) - 0.5 * (y.T @ y).item() / s2
+    elbo = (-0.5 * N * np.log(TWO_PI) - np.sum(np.log(np.diagonal(Lq))) - N * np.log(sigma) - 0.5 * yy / s2
             + 0.5 * (c.T @ c).item() - 0.5 * (kff - np.trace(Q)) / s2)
     if not grad:
         return dict(elbo=elbo, jitter_abs=jit)
@@ -216,12 +229,12 @@ def titsias_eval(self, Z, sigma, jitter, kff_diag, grad=True):
     GB = W.T @ (R @ v) / s2 + beta @ r.T
     GA = 0.5 * W.T @ (R - Q / s2) @ W - 0.5 * (beta @ beta.T) / s2 ** 2
     GA = 0.5 * (GA + GA.T)
-    ds2 = (-0.5 * N / s2 + 0.5 * np.trace(Pq @ Q) / s2 ** 2 + 0.5 * (y.T @ y).item() / s2 ** 2
+    ds2 = (-0.5 * N / s2 + 0.5 * np.trace(Pq @ Q) / s2 ** 2 + 0.5 * yy / s2 ** 2
            - (vy.T @ Pq @ vy).item() / s2 ** 3 + 0.5 * (vy.T @ Pq @ Q @ Pq @ vy).item() / s2 ** 4
            + 0.5 * (kff - np.trace(Q)) / s2 ** 2)
     mom_uu = moments_dense(table, GA, Z, Z, sym=True)
-    mom_uf = moments_dense(table, GB, Z, X, sym=False)
-    gZ = np.zeros((M, D))
+    mom_uf = red(moments_dense(table, GB, Z, X, sym=False))
+    gZ_uf, gZ_uu = np.zeros((M, D)), np.zeros((M, D))
     for i in range(C):
         ri = np.nonzero(cz == i)[0]
         if len(ri) == 0:
@@ -229,28 +242,29 @@ def titsias_eval(self, Z, sigma, jitter, kff_diag, grad=True):
         for j in range(C):
             rj = np.nonzero(cx == j)[0]
             if len(rj):
-                gZ[ri] += np.einsum("nm,nmd->nd", GB[np.ix_(ri, rj)], _jr_block(table[i, j], Z[ri, 1:], X[rj, 1:]))
+                gZ_uf[ri] += np.einsum("nm,nmd->nd", GB[np.ix_(ri, rj)], _jr_block(table[i, j], Z[ri, 1:], X[rj, 1:]))
             zj = np.nonzero(cz == j)[0]
             if len(zj):
-                gZ[ri] += 2.0 * np.einsum("nm,nmd->nd", GA[np.ix_(ri, zj)], _jr_block(table[i, j], Z[ri, 1:], Z[zj, 1:]))
-    return dict(elbo=elbo, jitter_abs=jit, mom_uu=mom_uu, mom_uf=mom_uf, gZ=gZ, trGA=float(np.trace(GA)),
+                gZ_uu[ri] += 2.0 * np.einsum("nm,nmd->nd", GA[np.ix_(ri, zj)], _jr_block(table[i, j], Z[ri, 1:], Z[zj, 1:]))
+    return dict(elbo=elbo, jitter_abs=jit, mom_uu=mom_uu, mom_uf=mom_uf, gZ=red(gZ_uf) + gZ_uu, trGA=float(np.trace(GA)),
                 dsigma=2.0 * sigma * ds2)
 
 
-def titsias_predict(self, Z, sigma, jitter, Xs, kss_diag):
+def titsias_predict(self, Z, sigma, jitter, Xs, kss_diag, sharded=False):
     """reference gpr/model.py:730-765"""
     from scipy.linalg import solve_triangular
     X, y, table = self.X, self.y, self.table
+    red = _all_reduce(self, sharded)
     s2 = sigma * sigma
     M = Z.shape[0]
     Kuu = gram_from_table(table, Z)
     A = Kuu + jitter * np.mean(np.diagonal(Kuu)) * np.eye(M)
     Luu = np.linalg.cholesky(A)
     v = solve_triangular(Luu, gram_from_table(table, Z, X), lower=True)
-    Lq = np.linalg.cholesky(v @ v.T / s2 + np.eye(M))
+    Lq = np.linalg.cholesky(red(v @ v.T) / s2 + np.eye(M))
     a = solve_triangular(Luu, gram_from_table(table, Z, Xs), lower=True)
     b = solve_triangular(Lq, a, lower=True)
-    c = solve_triangular(Lq, v @ y, lower=True) / s2
+    c = solve_triangular(Lq, red(v @ y), lower=True) / s2
     mu = b.T @ c
     var = np.asarray(kss_diag)[Xs[:, 0].astype(np.int64)] - np.sum(a * a, axis=0) + np.sum(b * b, axis=0)
     return mu, var.reshape(-1, 1)

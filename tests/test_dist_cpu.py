@@ -78,3 +78,64 @@ def test_sharded_evaluation_gloo_ranks(tmp_path, ranks):
     assert abs(r["loss"] - r["ref_loss"]) < 1e-10 * abs(r["ref_loss"]) and r["err"] < 1e-9      # sharded == single process
     assert r["gold"] < 1e-8                                                                      # == reference autograd
     assert abs(r["l_shard"] - r["l_single"]) < 1e-10 * abs(r["l_single"]) and r["err2"] < 1e-8
+
+
+TITSIAS_WORKER = textwrap.dedent('''
+    import sys, json
+    sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+    import numpy as np
+    import torch.distributed as dist
+    import mogptk_amd, mogptk_amd._lib as L
+    from mogptk_amd import gpr, synth
+    from mogptk_amd import dist as D
+    from oracle.table_model import TableDevice
+    from helpers import load, fixture_params, load_raw
+    L.ExactHandle = TableDevice
+    dist.init_process_group("gloo")
+    # the reference's Titsias golden (titsias.npz, case 0) evaluated DATA-PARALLEL: every rank holds every world-th point
+    fx = load("titsias.npz")
+    pre = "c0_"
+    C, Q, Dm, _ = [int(v) for v in fx[pre + "meta"]]
+    fp = fixture_params(fx, pre)
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=Dm)
+    Zspec = fx[pre + "Zspec"]
+    Zspec = int(Zspec[0]) if bool(fx[pre + "Zspec_is_int"]) else [int(z) for z in Zspec]
+    m = gpr.Titsias(k, fx[pre + "X"], fx[pre + "y"], Z=Zspec, variance=float(fp[-1]["cons"]) ** 2, jitter=float(fx[pre + "jitter"]))
+    load_raw(m.parameters(), fp)
+    l0 = float(m.loss()); g0 = [None if p.grad is None else p.grad.copy() for p in m.parameters()]
+    Xs = fx[pre + "Xs"]
+    mu0, var0 = m.predict_f(Xs)
+    comm = D.Comm(None, native=True)                      # the twin has no native library: its reductions go through the group directly
+    comm.force = True
+    TableDevice.reduce = staticmethod(lambda a: comm.all_reduce_host(a))
+    gpr.config.comm = comm
+    l1 = float(m.loss()); g1 = [None if p.grad is None else p.grad.copy() for p in m.parameters()]
+    n_local = m._handle.X.shape[0]
+    mu1, var1 = m.predict_f(Xs)
+    err = max(float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))) for a, b in zip(g1, g0) if b is not None)
+    gold = max(float(np.max(np.abs(p.grad - f["grad"])) / max(1.0, np.max(np.abs(f["grad"])))) for p, f in zip(m.parameters(), fp) if f["grad"] is not None)
+    perr = max(float(np.max(np.abs(mu1 - mu0))), float(np.max(np.abs(var1 - var0))))
+    gpr.config.comm = None
+    l2 = float(m.loss())                                  # and back: the handle is rebuilt on all points
+    if dist.get_rank() == 0:
+        print(json.dumps(dict(l0=l0, l1=l1, l2=l2, err=err, gold=gold, perr=perr, n_local=n_local, n=int(fx[pre + "X"].shape[0]),
+                              world=dist.get_world_size(), ref=float(fx[pre + "loss"]))))
+    dist.destroy_process_group()
+''')
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_data_parallel_titsias_gloo_ranks(tmp_path, ranks):
+    """SURVEY 8e for the sparse bound: the training points split over the ranks, the sums over points all-reduced (numpy twin of
+    mogp_titsias_eval_sharded / _predict_sharded through the product's own gpr.Titsias): equal to one process, and to the reference"""
+    script = tmp_path / "worker_titsias.py"
+    script.write_text(TITSIAS_WORKER % dict(root=ROOT, tests=os.path.join(ROOT, "tests")))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % ranks,
+                          "--master-addr", "127.0.0.1", "--master-port", str(29640 + ranks), str(script)],
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["world"] == ranks and r["n_local"] == (r["n"] + ranks - 1) // ranks          # rank 0 holds every world-th point
+    assert abs(r["l1"] - r["l0"]) < 1e-10 * abs(r["l0"]) and r["err"] < 1e-9 and r["perr"] < 1e-9
+    assert abs(r["l0"] - r["ref"]) < 1e-8 * abs(r["ref"]) and r["gold"] < 1e-6
+    assert r["l2"] == r["l0"]

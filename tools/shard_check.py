@@ -17,6 +17,8 @@ ap.add_argument("--channels", type=int, default=4)
 ap.add_argument("--q", type=int, default=3)
 ap.add_argument("--backend", default="gloo")
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--titsias-points", type=int, default=6000)
+ap.add_argument("--inducing", type=int, default=96, help="inducing points per channel of the Titsias check")
 a = ap.parse_args()
 
 import torch
@@ -67,12 +69,44 @@ mu0, var0 = m.predict_f(Xs)
 perr = max(float(np.max(np.abs(mu1 - mu0)) / np.max(np.abs(mu0))), float(np.max(np.abs(var1 - var0)) / np.max(np.abs(var0))))
 
 err = max(float(np.max(np.abs(b - c)) / np.max(np.abs(c))) for b, c in zip(g1, g0))
-errs = torch.tensor([abs(l1 - l0) / abs(l0), err, perr], dtype=torch.float64)
+
+# the sparse (Titsias) bound DATA-PARALLEL: every rank holds every world-th training point, the sums over points are all-reduced inside the
+# library (mogp_titsias_eval_sharded / _predict_sharded); bound, every gradient and the prediction against the one-GPU evaluation
+Xt, yt = synth.make_data(a.titsias_points, a.channels)
+kt = gpr.MultiOutputSpectralMixtureKernel(Q=a.q, output_dims=a.channels)
+for name in ("weight", "mean", "variance", "delay", "phase"):
+    getattr(kt, name).assign(h[name])
+mt = gpr.Titsias(kt, Xt, yt, Z=a.inducing, variance=float(np.mean(h["scale"])) ** 2, jitter=1e-6)
+tl0 = float(mt.loss())
+tg0 = [p.grad.copy() for p in mt.parameters()]
+tmu0, tvar0 = mt.predict_f(Xs)
+t = time.perf_counter()
+for _ in range(a.reps):
+    mt.loss()
+tt_single = (time.perf_counter() - t) / a.reps
+comm = mogptk_amd.use_distributed()
+comm.force = True
+tl1 = float(mt.loss())
+tg1 = [p.grad.copy() for p in mt.parameters()]
+dist.barrier()
+t = time.perf_counter()
+for _ in range(a.reps):
+    mt.loss()
+dist.barrier()
+tt_shard = (time.perf_counter() - t) / a.reps
+tmu1, tvar1 = mt.predict_f(Xs)
+mogptk_amd.use_single_device()
+terr = max(float(np.max(np.abs(b - c)) / max(1e-300, np.max(np.abs(c)))) for b, c in zip(tg1, tg0))
+tperr = max(float(np.max(np.abs(tmu1 - tmu0)) / np.max(np.abs(tmu0))), float(np.max(np.abs(tvar1 - tvar0)) / np.max(np.abs(tvar0))))
+
+errs = torch.tensor([abs(l1 - l0) / abs(l0), err, perr, abs(tl1 - tl0) / abs(tl0), terr, tperr], dtype=torch.float64)
 if a.backend == "nccl":
     errs = errs.cuda()
 dist.all_reduce(errs, op=dist.ReduceOp.MAX)
 if rank == 0:
     print(json.dumps(dict(world=world, backend=a.backend, N=a.points, loss=l0, loss_sharded=l1, rel_loss=float(errs[0]), rel_grad=float(errs[1]), rel_predict=float(errs[2]),
-                          transport=comm.transport, ms_single=1e3 * t_single, ms_sharded=1e3 * t_shard)))
+                          transport=comm.transport, ms_single=1e3 * t_single, ms_sharded=1e3 * t_shard,
+                          titsias=dict(N=a.titsias_points, M=int(mt.Z().shape[0]), loss=tl0, rel_loss=float(errs[3]), rel_grad=float(errs[4]),
+                                       rel_predict=float(errs[5]), ms_single=1e3 * tt_single, ms_sharded=1e3 * tt_shard))))
 mogptk_amd.shutdown_distributed()
 dist.destroy_process_group()
