@@ -654,3 +654,48 @@ def test_variational_models_with_non_gaussian_likelihoods_on_device():
     likelihoods -- the device algebra around the host's likelihood, against the reference's loss and autograd gradients"""
     from test_host_logic import check_likelihood_models
     check_likelihood_models(tol_loss=1e-9, tol_grad=1e-6, tol_pred=1e-7)
+
+
+def test_sparse_and_variational_edge_cases():
+    """the models added for SURVEY 8f-4 at the edges: one training point, an empty channel, N below / at / above a tile edge, more inducing
+    points than data points -- device against the numpy twin"""
+    rng = np.random.default_rng(3)
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=1, output_dims=2)
+    k.mean.assign(np.full((2, 1, 1), 0.1))
+    t = k._spectral_terms(1)
+    kd = k._spectral_diag(1)
+    Xs = np.stack([np.array([0.0, 1.0, 0.0]), np.array([0.5, 2.5, 4.0])], axis=1)       # test points also in the channel without data
+    for N in (1, 2, 127, 128, 129):
+        X = np.stack([np.zeros(N), np.linspace(0, 5, N)], axis=1)                        # channel 1 has no data
+        y = np.sin(X[:, 1])
+        dev = _lib.ExactHandle(0, X, y, 2)
+        ref = TableDevice(0, X, y, 2)
+        dev.set_terms(t); ref.set_terms(t)
+        # Opper-Archambeau
+        nu, lam = rng.normal(0, 0.5, N), rng.uniform(0.5, 2.0, N)
+        a, b = dev.oa_forward(nu, lam), ref.oa_forward(nu, lam)
+        assert relerr(a["mu"], b["mu"]) < 1e-10 and np.max(np.abs(a["var"] - b["var"])) < 1e-10 and abs(a["kl"] - b["kl"]) < 1e-9 * max(1.0, abs(b["kl"])), N
+        e, f = rng.standard_normal(N), -rng.uniform(0.5, 2.0, N)
+        ga, gb = dev.oa_backward(e, f), ref.oa_backward(e, f)
+        for key in ("mom", "g_nu", "g_lambda"):
+            assert np.max(np.abs(ga[key] - gb[key])) < 1e-8 * max(1.0, np.max(np.abs(gb[key]))), (N, key)
+        m1, v1 = dev.oa_predict(nu, lam, kd, Xs)
+        m2, v2 = ref.oa_predict(nu, lam, kd, Xs)
+        assert np.max(np.abs(m1 - m2)) < 1e-10 and np.max(np.abs(v1 - v2)) < 1e-10, N
+        # sparse models: 3 inducing points in channel 0, 2 in the channel without data
+        Z = np.array([[0.0, 0.3], [0.0, 2.2], [0.0, 4.1], [1.0, 1.0], [1.0, 3.0]])
+        a, b = dev.titsias_eval(Z, 0.3, 1e-6, kd), ref.titsias_eval(Z, 0.3, 1e-6, kd)
+        assert abs(a["elbo"] - b["elbo"]) < 1e-9 * max(1.0, abs(b["elbo"])), N
+        for key in ("mom_uu", "mom_uf", "gZ"):
+            assert np.max(np.abs(a[key] - b[key])) < 1e-7 * max(1.0, np.max(np.abs(b[key]))), (N, key)
+        a, b = dev.snelson_eval(Z, np.array([0.1, 0.2]), 1e-6, kd), ref.snelson_eval(Z, np.array([0.1, 0.2]), 1e-6, kd)
+        assert abs(a["lml"] - b["lml"]) < 1e-9 * max(1.0, abs(b["lml"])), N
+        for key in ("mom_uu", "mom_uf", "gZ"):
+            assert np.max(np.abs(a[key] - b[key])) < 1e-7 * max(1.0, np.max(np.abs(b[key]))), (N, key)
+        q_mu, q_sqrt = rng.normal(0, 0.5, 5), np.tril(rng.normal(0, 0.2, (5, 5))) + np.eye(5)
+        a, b = dev.svgp_forward(Z, q_mu, q_sqrt, 1e-6, kd), ref.svgp_forward(Z, q_mu, q_sqrt, 1e-6, kd)
+        assert np.max(np.abs(a["mu"] - b["mu"])) < 1e-9 and np.max(np.abs(a["var"] - b["var"])) < 1e-9, N
+        ga, gb = dev.svgp_backward(e, f), ref.svgp_backward(e, f)
+        for key in ("mom_uu", "mom_uf", "gZ", "g_qmu"):
+            assert np.max(np.abs(ga[key] - gb[key])) < 1e-7 * max(1.0, np.max(np.abs(gb[key]))), (N, key)
+        assert np.max(np.abs(np.tril(ga["g_qsqrt"]) - gb["g_qsqrt"])) < 1e-7 * max(1.0, np.max(np.abs(gb["g_qsqrt"]))), N
