@@ -225,6 +225,12 @@ int  mogp_svgp_forward(mogp_model* m, int64_t M, const double* Z, const double* 
                        double* mu, double* var, double* jitter_abs, int64_t* info);
 int  mogp_svgp_backward(mogp_model* m, const double* e, const double* f, double* mom_uu, double* mom_uf, double* gZ, double* trGA,
                         double* g_qmu, double* g_qsqrt);
+/* The sparse model DATA-PARALLEL (cf. mogp_titsias_eval_sharded): each rank's handle holds its own shard of the training points, the forward
+ * call is the plain one (mu / var of the LOCAL points; the caller evaluates its likelihood on them and all-reduces the expectation and the
+ * likelihood parameters' gradients, O(1) numbers); this backward call all-reduces what sums over points -- the two M x M products, v e, the
+ * (Z, X) moments and their share of d/dZ -- and returns the FULL model's gradients on every rank.  Not for the dense model (M = N). */
+int  mogp_svgp_backward_sharded(mogp_model* m, const double* e, const double* f, double* mom_uu, double* mom_uf, double* gZ, double* trGA,
+                                double* g_qmu, double* g_qsqrt);
 
 /* The variational Gaussian approximation of Opper & Archambeau at the data points (reference gpr/model.py:578-668, OpperArchambeau):
  * q(f) = N(K nu, (K^-1 + diag(lambda^2))^-1), one nu and one lambda > 0 per data point (caller order, like y).  Like the Hensman

@@ -82,6 +82,7 @@ SIGNATURES = {
     "mogp_svgp_forward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.c_int, ctypes.c_int64,
                                          c_dp, c_dp, c_dp, c_dp, ctypes.POINTER(ctypes.c_double), c_i64p]),
     "mogp_svgp_backward": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp, ctypes.POINTER(ctypes.c_double), c_dp, c_dp]),
+    "mogp_svgp_backward_sharded": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp, ctypes.POINTER(ctypes.c_double), c_dp, c_dp]),
     "mogp_oa_forward": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp, ctypes.POINTER(ctypes.c_double), c_i64p]),
     "mogp_oa_backward": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "mogp_oa_predict": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, ctypes.c_int64, c_dp, ctypes.c_int, c_dp, c_dp, c_i64p]),
@@ -371,13 +372,14 @@ class ExactHandle:
         self._svgp_M = M
         return dict(mu=mu, var=var, jitter_abs=jit.value)
 
-    def svgp_backward(self, e, f):
+    def svgp_backward(self, e, f, sharded=False):
         e, f = _f64(np.reshape(e, -1)), _f64(np.reshape(f, -1))
         C, T, W, D, M = self.C, self.T, 2 + 3 * self.D, self.D, self._svgp_M
         mom_uu, mom_uf = np.zeros((C * (C + 1) // 2, T, W)), np.zeros((C * C, T, W))
         gZ, g_qmu, g_S = np.zeros((M, D)), np.zeros(M), np.zeros((M, M))
         trGA = ctypes.c_double()
-        check(lib().mogp_svgp_backward(self._h, _dp(e), _dp(f), _dp(mom_uu), _dp(mom_uf), _dp(gZ), ctypes.byref(trGA), _dp(g_qmu), _dp(g_S)))
+        fn = lib().mogp_svgp_backward_sharded if sharded else lib().mogp_svgp_backward
+        check(fn(self._h, _dp(e), _dp(f), _dp(mom_uu), _dp(mom_uf), _dp(gZ), ctypes.byref(trGA), _dp(g_qmu), _dp(g_S)))
         return dict(mom_uu=mom_uu, mom_uf=mom_uf, gZ=gZ, trGA=trGA.value, g_qmu=g_qmu, g_qsqrt=g_S)
 
     def oa_forward(self, q_nu, q_lambda):

@@ -238,8 +238,12 @@ int mogp_svgp_forward(mogp_model* m, int64_t M, const double* Z, const double* q
     return MOGP_OK;
 }
 
-int mogp_svgp_backward(mogp_model* m, const double* e, const double* f, double* mom_uu, double* mom_uf, double* gZ, double* trGA,
-                       double* g_qmu, double* g_qsqrt) {
+}  // extern "C"
+
+// sharded: this handle holds ONE SHARD of the training points (see mogp_titsias_eval_sharded): everything that sums over data points -- the two
+// M x M products over N, v e, the (Z, X) moments and their share of d/dZ -- is all-reduced; e, f are those of the local points
+static int svgp_backward_impl(mogp_model* m, const double* e, const double* f, double* mom_uu, double* mom_uf, double* gZ, double* trGA,
+                              double* g_qmu, double* g_qsqrt, bool sharded) {
     if (!m || !e || !f || !mom_uu || !mom_uf || !gZ || !trGA || !g_qmu || !g_qsqrt) return fail(MOGP_EINVAL, "mogp_svgp_backward: bad argument");
     RC(use_device(m->ctx));
     if (!m->tw || !m->tw->sv_valid) return fail(MOGP_EINVAL, "mogp_svgp_backward: no forward pass at the training inputs precedes it");
@@ -273,6 +277,10 @@ int mogp_svgp_backward(mogp_model* m, const double* e, const double* f, double* 
     const dim3 gmn((unsigned)((Npad + 255) / 256), (unsigned)Mpad);
     // dE/dq_mu = v e
     RC(launch_gemv_rows(t.v.p, Npad, Mpad, Npad, de, gq, m->st));
+    if (sharded) {
+        if (dense) return fail(MOGP_EINVAL, "the dense Hensman model lives on ALL data points: it cannot be sharded over them");
+        RC(comm_allreduce(m->ctx, gq, Mpad, m->st));
+    }
     // Gv = q e^T + 2 (S b - v) diag f   (t.B; b = S^T v is in t.GB from the forward pass)
     GemmArgs g = gemm(t.R.p, Mpad, 0, t.GB.p, Npad, 1, t.B.p, Npad, 1.0, GM_RECT, mt, nt, Mpad);
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
@@ -280,6 +288,7 @@ int mogp_svgp_backward(mogp_model* m, const double* e, const double* f, double* 
     HIP_TRY(hipGetLastError());
     // Psi: tril(Gv v^T) (dense: tril(v Gv^T)) mirrored;  GA = -/+ 1/2 L^-T Psi L^-1
     RC(mm_lower_splitk(m, t, dense ? t.v.p : t.B.p, dense ? t.B.p : t.v.p, t.E.p, mt, Mpad, Npad, Npad));
+    if (sharded) RC(comm_allreduce(m->ctx, t.E.p, Mpad * Mpad, m->st));
     RC(launch_symmetrize(t.E.p, Mpad, Mpad, m->st));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.E.p, Mpad, Mpad, true));
     RC(launch_transpose(t.GA.p, t.E.p, Mpad, Mpad, m->st));
@@ -290,6 +299,7 @@ int mogp_svgp_backward(mogp_model* m, const double* e, const double* f, double* 
     hipLaunchKernelGGL(k_sv_scale_cols, gmn, dim3(256), 0, m->st, t.v.p, t.GB.p, Npad, Npad, df);
     HIP_TRY(hipGetLastError());
     RC(mm_lower_splitk(m, t, t.GB.p, t.v.p, t.Qs.p, mt, Mpad, Npad, Npad));
+    if (sharded) RC(comm_allreduce(m->ctx, t.Qs.p, Mpad * Mpad, m->st));
     RC(launch_symmetrize(t.Qs.p, Mpad, Mpad, m->st));
     g = gemm(t.Qs.p, Mpad, 0, t.R.p, Mpad, 1, t.q.A.p, Mpad, 2.0, GM_RECT, mt, mt, Mpad);
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
@@ -308,6 +318,10 @@ int mogp_svgp_backward(mogp_model* m, const double* e, const double* f, double* 
         ma.gzr = t.gz.p; ma.gzc = nullptr; ma.partial = t.partial_uf.p;
         RC(launch_moments(ma, m->st));
         RC(launch_moment_reduce(t.partial_uf.p, t.ps_uf.p, C * C, T, W, D, t.mom_uf.p, m->st, 0));
+        if (sharded) {
+            RC(comm_allreduce(m->ctx, t.mom_uf.p, (int64_t)C * C * T * W, m->st));
+            RC(comm_allreduce(m->ctx, t.gz.p, (int64_t)D * Mpad, m->st));
+        }
     } else {
         HIP_TRY(hipMemsetAsync(t.mom_uf.p, 0, (size_t)C * C * T * W * sizeof(double), m->st));
     }
@@ -336,6 +350,18 @@ int mogp_svgp_backward(mogp_model* m, const double* e, const double* f, double* 
     }
     *trGA = tr;
     return MOGP_OK;
+}
+
+extern "C" {
+
+int mogp_svgp_backward(mogp_model* m, const double* e, const double* f, double* mom_uu, double* mom_uf, double* gZ, double* trGA,
+                       double* g_qmu, double* g_qsqrt) {
+    return svgp_backward_impl(m, e, f, mom_uu, mom_uf, gZ, trGA, g_qmu, g_qsqrt, false);
+}
+
+int mogp_svgp_backward_sharded(mogp_model* m, const double* e, const double* f, double* mom_uu, double* mom_uf, double* gZ, double* trGA,
+                               double* g_qmu, double* g_qsqrt) {
+    return svgp_backward_impl(m, e, f, mom_uu, mom_uf, gZ, trGA, g_qmu, g_qsqrt, true);
 }
 
 }  // extern "C"

@@ -90,8 +90,14 @@ class Comm:
         h.mem_put(buf, t.numpy())
 
     def all_reduce_host(self, arr):
+        """sum a small host array over the ranks, in place (a device round trip when the group's backend only takes device tensors)"""
         t = self.torch.from_numpy(arr)
-        self.dist.all_reduce(t, group=self.group)
+        if self.dist.get_backend(self.group) == "nccl":
+            d = t.cuda()
+            self.dist.all_reduce(d, group=self.group)
+            t.copy_(d.cpu())
+        else:
+            self.dist.all_reduce(t, group=self.group)
         return arr
 
 

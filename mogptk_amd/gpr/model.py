@@ -685,12 +685,36 @@ class SparseHensman(Model):
         else:
             self.Z = Parameter(self.X, train=False)         # the data points themselves, not trained (reference :812)
 
+    def _data_shard(self):
+        """the communicator this process shards its training points over (mogptk_amd.use_distributed), or None; the non-sparse model lives
+        on all data points and is never sharded"""
+        comm = getattr(config, "comm", None)
+        if self.is_sparse and comm is not None and getattr(comm, "native", False) and (comm.world > 1 or comm.force):
+            return comm
+        return None
+
+    def _local(self, a):
+        """this rank's share of a per-point array: every world-th point starting at the rank (all of it without a communicator)"""
+        comm = self._data_shard()
+        return a if comm is None else a[comm.rank::comm.world]
+
     def _device_handle(self):
-        if self._handle is None:
+        comm = self._data_shard()
+        key = None if comm is None else (comm.rank, comm.world)
+        if self._handle is None or self.__dict__.get("_handle_key") != key:
             from .._lib import ExactHandle
-            y = self.y if self.mean is None else self.y - np.asarray(self.mean(self.X)).reshape(-1, 1)
-            self._handle = ExactHandle(config.device, self.kernel._kernel_format(self.X), y, self.kernel._channels())
+            self._handle = ExactHandle(config.device, self._local(self.kernel._kernel_format(self.X)), self._local(self._y()), self.kernel._channels())
+            self.__dict__["_handle_key"] = key
         return self._handle
+
+    def _reduce(self, value):
+        """sum of a host scalar / small array over the ranks holding the other shards"""
+        comm = self._data_shard()
+        if comm is None:
+            return value
+        a = np.atleast_1d(np.array(value, dtype=np.float64))
+        comm.all_reduce_host(a)
+        return a if np.ndim(value) else float(a[0])
 
     def kl_gaussian(self, q_mu, q_sqrt):
         """reference gpr/model.py:816-822"""
@@ -719,8 +743,8 @@ class SparseHensman(Model):
 
     def elbo(self):
         h, res, _, _, _ = self._forward()
-        ve = self.likelihood.variational_expectation(self._likelihood_X(self.X), self._y(), res["mu"], res["var"])
-        return config.dtype(ve - self.kl_gaussian(self.q_mu(), self.q_sqrt()))
+        ve = self.likelihood.variational_expectation(self._local(self._likelihood_X(self.X)), self._local(self._y()), res["mu"], res["var"])
+        return config.dtype(self._reduce(ve) - self.kl_gaussian(self.q_mu(), self.q_sqrt()))
 
     def log_marginal_likelihood(self):
         """maximise the lower bound (reference gpr/model.py:847-849)"""
@@ -729,20 +753,23 @@ class SparseHensman(Model):
     def _loss_impl(self):
         self.zero_grad(set_to_none=True)
         h, res, table, D, Zk = self._forward()
-        ve, e, f, pgrads = self.likelihood.variational_expectation(self._likelihood_X(self.X), self._y(), res["mu"], res["var"], grad=True)
+        sharded = self._data_shard() is not None            # data-parallel: mu / var, e, f are those of this rank's points
+        ve, e, f, pgrads = self.likelihood.variational_expectation(self._local(self._likelihood_X(self.X)), self._local(self._y()), res["mu"], res["var"], grad=True)
+        ve = self._reduce(ve)
+        pgrads = [(p, self._reduce(g)) for p, g in pgrads]
         q_mu, q_sqrt = np.asarray(self.q_mu(), dtype=np.float64), np.asarray(self.q_sqrt(), dtype=np.float64)
         elbo = ve - self.kl_gaussian(q_mu, q_sqrt)
-        bw = h.svgp_backward(e, f)
+        bw = h.svgp_backward(e, f, sharded=sharded)
         C = table.shape[0]
         M = Zk.shape[0]
         zc = np.bincount(Zk[:, 0].astype(np.int64), minlength=C).astype(np.float64)
-        xc = self.kernel._kernel_format(self.X)[:, 0].astype(np.int64)
+        xc = self._local(self.kernel._kernel_format(self.X))[:, 0].astype(np.int64)
         gt = _gtable_from_moments(table, bw["mom_uu"], D, lower=True) + _gtable_from_moments(table, bw["mom_uf"], D, lower=False)
         for i in range(C):
             gt[i, i, :, 0] += self.jitter * bw["trGA"] * zc[i] / M          # jitter * mean(diag Kuu), gpr/model.py:244
         self.kernel._spectral_backward(-gt)
         if self.is_sparse:                          # var_n = K_diag[c(n)] - ... (the dense model's variance at its own inputs has no such term)
-            self.kernel._spectral_diag_backward(-np.bincount(xc, weights=f, minlength=C), D)
+            self.kernel._spectral_diag_backward(-self._reduce(np.bincount(xc, weights=f, minlength=C)), D)
         for p, g in pgrads:
             p.accumulate_grad(np.reshape(-np.asarray(g, dtype=np.float64), p.data.shape))
         self.q_mu.accumulate_grad(-(np.reshape(bw["g_qmu"], q_mu.shape) - q_mu))

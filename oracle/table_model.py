@@ -389,7 +389,7 @@ def svgp_forward(self, Z, q_mu, q_sqrt, jitter, kff_diag, Xs=None, kss_diag=None
     return dict(mu=mu, var=var, jitter_abs=jit)
 
 
-def svgp_backward(self, e, f):
+def svgp_backward(self, e, f, sharded=False):
     """adjoints of  E(mu, var)  with  e = dE/dmu, f = dE/dvar  (any likelihood: the caller differentiates its own expectation):
         Gv = q_mu e^T + 2 (S S^T - I) v diag f,   dE/dB = L^-T Gv,   dE/dA = -1/2 L^-T Psi(Gv v^T) L^-1   (Psi(Y) = tril(Y) mirrored),
         dE/dq_mu = v e,   dE/dS = 2 (v diag(f) v^T) S  (lower part);
@@ -405,6 +405,7 @@ def svgp_backward(self, e, f):
     cx = X[:, 0].astype(np.int64)
     W = solve_triangular(Luu, np.eye(M), lower=True)
     psi = lambda Y: np.tril(Y) + np.tril(Y, -1).T
+    red = _all_reduce(self, sharded)          # sharded: this object holds one shard of the data; sums over points are all-reduced
     if dense:
         Gv = np.outer(q_mu, e) + 2.0 * (S @ (S.T @ v)) * f
         GB = np.zeros((M, X.shape[0]))
@@ -412,11 +413,12 @@ def svgp_backward(self, e, f):
     else:
         Gv = np.outer(q_mu, e) + 2.0 * (S @ (S.T @ v) - v) * f
         GB = W.T @ Gv
-        GA = -0.5 * W.T @ psi(Gv @ v.T) @ W
+        GA = -0.5 * W.T @ psi(red(np.tril(Gv @ v.T))) @ W
     GA = 0.5 * (GA + GA.T)
     mom_uu = moments_dense(table, GA, Z, Z, sym=True)
-    mom_uf = moments_dense(table, GB, Z, X, sym=False)
+    mom_uf = red(moments_dense(table, GB, Z, X, sym=False))
     gZ = np.zeros((M, D))
+    gZ_uu = np.zeros((M, D))
     if not dense:
         for i in range(C):
             ri = np.nonzero(cz == i)[0]
@@ -428,10 +430,10 @@ def svgp_backward(self, e, f):
                     gZ[ri] += np.einsum("nm,nmd->nd", GB[np.ix_(ri, rj)], _jr_block(table[i, j], Z[ri, 1:], X[rj, 1:]))
                 zj = np.nonzero(cz == j)[0]
                 if len(zj):
-                    gZ[ri] += 2.0 * np.einsum("nm,nmd->nd", GA[np.ix_(ri, zj)], _jr_block(table[i, j], Z[ri, 1:], Z[zj, 1:]))
-    g_qmu = v @ e
-    g_S = np.tril(2.0 * ((v * f) @ v.T) @ S)
-    return dict(mom_uu=mom_uu, mom_uf=mom_uf, gZ=gZ, trGA=float(np.trace(GA)), g_qmu=g_qmu, g_qsqrt=g_S)
+                    gZ_uu[ri] += 2.0 * np.einsum("nm,nmd->nd", GA[np.ix_(ri, zj)], _jr_block(table[i, j], Z[ri, 1:], Z[zj, 1:]))
+    g_qmu = red(v @ e)
+    g_S = np.tril(2.0 * red((v * f) @ v.T) @ S)
+    return dict(mom_uu=mom_uu, mom_uf=mom_uf, gZ=red(gZ) + gZ_uu, trGA=float(np.trace(GA)), g_qmu=g_qmu, g_qsqrt=g_S)
 
 
 TableDevice.svgp_forward = svgp_forward

@@ -139,3 +139,65 @@ def test_data_parallel_titsias_gloo_ranks(tmp_path, ranks):
     assert abs(r["l1"] - r["l0"]) < 1e-10 * abs(r["l0"]) and r["err"] < 1e-9 and r["perr"] < 1e-9
     assert abs(r["l0"] - r["ref"]) < 1e-8 * abs(r["ref"]) and r["gold"] < 1e-6
     assert r["l2"] == r["l0"]
+
+
+SVGP_WORKER = textwrap.dedent('''
+    import sys, json
+    sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+    import numpy as np
+    import torch.distributed as dist
+    import mogptk_amd, mogptk_amd._lib as L
+    from mogptk_amd import gpr
+    from mogptk_amd import dist as D
+    from oracle.table_model import TableDevice
+    from helpers import load, fixture_params, load_raw
+    L.ExactHandle = TableDevice
+    dist.init_process_group("gloo")
+    # the reference's SparseHensman goldens with non-Gaussian likelihoods (likelihoods.npz) evaluated DATA-PARALLEL
+    fx = load("likelihoods.npz")
+    res = {}
+    for tag in ("svgp_studentt", "svgp_multi"):
+        pre = tag + "_"
+        C, Q, Dm, _ = [int(v) for v in fx[pre + "meta"]]
+        lik = gpr.StudentTLikelihood(dof=4, scale=0.4) if tag == "svgp_studentt" else gpr.MultiOutputLikelihood(gpr.PoissonLikelihood(), gpr.GaussianLikelihood(0.3))
+        k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=Dm)
+        m = gpr.SparseHensman(k, fx[pre + "X"], fx[pre + "y"], Z=fx[pre + "Z"], likelihood=lik, jitter=1e-6)
+        fp = fixture_params(fx, pre)
+        load_raw(m.parameters(), fp)
+        gpr.config.comm = None
+        l0 = float(m.loss()); g0 = [None if p.grad is None else p.grad.copy() for p in m.parameters()]
+        comm = D.Comm(None, native=True)
+        comm.force = True
+        TableDevice.reduce = staticmethod(lambda a: comm.all_reduce_host(a))
+        gpr.config.comm = comm
+        l1 = float(m.loss()); g1 = [None if p.grad is None else p.grad.copy() for p in m.parameters()]
+        e1 = float(m.log_marginal_likelihood())
+        mu, var = m.predict_f(fx[pre + "Xs"])
+        res[tag] = dict(l0=l0, l1=l1, e1=e1, ref=float(fx[pre + "loss"]), n_local=int(m._handle.X.shape[0]),
+                        err=max(float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))) for a, b in zip(g1, g0) if b is not None),
+                        gold=max(float(np.max(np.abs(p.grad - f["grad"])) / max(1.0, np.max(np.abs(f["grad"])))) for p, f in zip(m.parameters(), fp) if f["grad"] is not None),
+                        perr=float(max(np.max(np.abs(mu - fx[pre + "mu_f"])), np.max(np.abs(var - fx[pre + "var_f"])))))
+    if dist.get_rank() == 0:
+        print(json.dumps(dict(world=dist.get_world_size(), **res)))
+    dist.destroy_process_group()
+''')
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_data_parallel_sparse_hensman_gloo_ranks(tmp_path, ranks):
+    """the variational sparse model with non-Gaussian likelihoods, its training points split over the ranks: the device algebra's sums over
+    points (numpy twin of mogp_svgp_backward_sharded) and the likelihood's expectation / parameter gradients all-reduced -- equal to one
+    process and to the reference's autograd"""
+    script = tmp_path / "worker_svgp.py"
+    script.write_text(SVGP_WORKER % dict(root=ROOT, tests=os.path.join(ROOT, "tests")))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % ranks,
+                          "--master-addr", "127.0.0.1", "--master-port", str(29650 + ranks), str(script)],
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["world"] == ranks
+    for tag in ("svgp_studentt", "svgp_multi"):
+        t = r[tag]
+        assert t["n_local"] == (60 + ranks - 1) // ranks
+        assert abs(t["l1"] - t["l0"]) < 1e-10 * abs(t["l0"]) and t["err"] < 1e-9 and abs(t["e1"] + t["l1"]) < 1e-10 * abs(t["l1"]), t
+        assert abs(t["l0"] - t["ref"]) < 1e-9 * abs(t["ref"]) and t["gold"] < 1e-7 and t["perr"] < 1e-8, t

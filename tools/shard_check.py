@@ -99,7 +99,36 @@ mogptk_amd.use_single_device()
 terr = max(float(np.max(np.abs(b - c)) / max(1e-300, np.max(np.abs(c)))) for b, c in zip(tg1, tg0))
 tperr = max(float(np.max(np.abs(tmu1 - tmu0)) / np.max(np.abs(tmu0))), float(np.max(np.abs(tvar1 - tvar0)) / np.max(np.abs(tvar0))))
 
-errs = torch.tensor([abs(l1 - l0) / abs(l0), err, perr, abs(tl1 - tl0) / abs(tl0), terr, tperr], dtype=torch.float64)
+# the variational sparse model (SparseHensman, Student-t likelihood) data-parallel the same way: mogp_svgp_backward_sharded + the
+# likelihood's expectation and parameter gradients all-reduced on the host
+kh = gpr.MultiOutputSpectralMixtureKernel(Q=a.q, output_dims=a.channels)
+for name in ("weight", "mean", "variance", "delay", "phase"):
+    getattr(kh, name).assign(h[name])
+mh = gpr.SparseHensman(kh, Xt, yt, Z=a.inducing, likelihood=gpr.StudentTLikelihood(dof=4, scale=0.3), jitter=1e-6)
+rng = np.random.default_rng(7)
+Mh = mh.q_mu().shape[0]
+mh.q_mu.assign(rng.normal(0, 0.3, (Mh, 1)))
+mh.q_sqrt.assign(np.tril(rng.normal(0, 0.02, (Mh, Mh))) + np.diag(rng.uniform(0.5, 1.0, Mh)))
+hl0 = float(mh.loss())
+hg0 = [p.grad.copy() for p in mh.parameters()]
+t = time.perf_counter()
+for _ in range(a.reps):
+    mh.loss()
+ht_single = (time.perf_counter() - t) / a.reps
+comm = mogptk_amd.use_distributed()
+comm.force = True
+hl1 = float(mh.loss())
+hg1 = [p.grad.copy() for p in mh.parameters()]
+dist.barrier()
+t = time.perf_counter()
+for _ in range(a.reps):
+    mh.loss()
+dist.barrier()
+ht_shard = (time.perf_counter() - t) / a.reps
+mogptk_amd.use_single_device()
+herr = max(float(np.max(np.abs(b - c)) / max(1e-300, np.max(np.abs(c)))) for b, c in zip(hg1, hg0))
+
+errs = torch.tensor([abs(l1 - l0) / abs(l0), err, perr, abs(tl1 - tl0) / abs(tl0), terr, tperr, abs(hl1 - hl0) / abs(hl0), herr], dtype=torch.float64)
 if a.backend == "nccl":
     errs = errs.cuda()
 dist.all_reduce(errs, op=dist.ReduceOp.MAX)
@@ -107,6 +136,8 @@ if rank == 0:
     print(json.dumps(dict(world=world, backend=a.backend, N=a.points, loss=l0, loss_sharded=l1, rel_loss=float(errs[0]), rel_grad=float(errs[1]), rel_predict=float(errs[2]),
                           transport=comm.transport, ms_single=1e3 * t_single, ms_sharded=1e3 * t_shard,
                           titsias=dict(N=a.titsias_points, M=int(mt.Z().shape[0]), loss=tl0, rel_loss=float(errs[3]), rel_grad=float(errs[4]),
-                                       rel_predict=float(errs[5]), ms_single=1e3 * tt_single, ms_sharded=1e3 * tt_shard))))
+                                       rel_predict=float(errs[5]), ms_single=1e3 * tt_single, ms_sharded=1e3 * tt_shard),
+                          hensman=dict(N=a.titsias_points, M=int(Mh), likelihood="StudentT", loss=hl0, rel_loss=float(errs[6]), rel_grad=float(errs[7]),
+                                       ms_single=1e3 * ht_single, ms_sharded=1e3 * ht_shard))))
 mogptk_amd.shutdown_distributed()
 dist.destroy_process_group()
