@@ -190,6 +190,40 @@ class Model(ParameterHolder):
     def _likelihood_X(self, X):
         return X
 
+    def sample_f(self, Z, n=None, prior=False):
+        """Samples of f at Z (reference gpr/model.py:346-376): from the posterior (`predict_f(Z, full=True)`, the device path) or the prior,
+        drawn by torch's MultivariateNormal from torch's global generator exactly as the reference does -- the same seed gives the same
+        samples.  Shape as the reference returns it: (n, data_points), or (data_points,) without n."""
+        from .likelihood import _torch
+        torch = _torch()
+        Z = self._check_input(Z)
+        S = 1 if n is None else n
+        if prior:
+            if self.mean is None:
+                raise TypeError("sampling from the prior needs a mean function (the reference calls self.mean(Z), gpr/model.py:364)")
+            mu, var = np.asarray(self.mean(Z), dtype=np.float64), np.array(self.kernel(Z), dtype=np.float64)
+        else:
+            mu, var = self.predict_f(Z, full=True)
+        var = np.array(var, dtype=np.float64)
+        var += self.jitter * np.mean(np.diagonal(var)) * np.eye(var.shape[0])
+        dist = torch.distributions.multivariate_normal.MultivariateNormal(torch.tensor(np.reshape(mu, -1), dtype=torch.float64), torch.tensor(var))
+        samples = dist.sample([S])
+        if n is None:
+            samples = samples.squeeze()
+        return samples.numpy()
+
+    def sample_y(self, Z, n=None):
+        """Samples of y at Z (reference gpr/model.py:378-401): samples of f pushed through the likelihood's sampler"""
+        from .likelihood import _torch
+        torch = _torch()
+        Z = self._check_input(Z)
+        S = 1 if n is None else n
+        samples_f = torch.tensor(self.sample_f(Z, n=S))
+        samples_y = self.likelihood.conditional_sample(self._likelihood_X(Z), samples_f)
+        if n is None:
+            samples_y = samples_y.squeeze()
+        return samples_y.numpy()
+
 
 class Exact(Model):
     """

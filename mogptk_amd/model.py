@@ -719,6 +719,36 @@ class Model:
             return X[0], Mu[0], Lower[0], Upper[0]
         return X, Mu, Lower, Upper
 
+    def sample(self, X=None, n=None, prior=False, transformed=False):
+        """Samples of y at X (reference mogptk/model.py:692-734; the posterior's full covariance comes from the device).  Mirrors the reference
+        as written: `prior` is accepted and not used, and with n given the samples come as (n, data_points) while the channels are cut along
+        the FIRST axis -- n=None is the form that works for every shape there, and here."""
+        if X is None:
+            X = self.dataset.get_prediction_data()
+        else:
+            X = self.dataset._format_X(X)
+        x = self._to_kernel_format(X)
+        samples = self.gpr.sample_y(Z=x, n=n)
+        i = 0
+        Samples = []
+        for j in range(self.dataset.get_output_dims()):
+            N = X[j].shape[0]
+            if n is None:
+                sample = np.squeeze(samples[i:i + N])
+                if not transformed:
+                    sample = self.dataset[j].Y_transformer.backward(sample, X[j])
+                Samples.append(sample)
+            else:
+                sample = samples[i:i + N, :]
+                for k in range(n):
+                    if not transformed:
+                        sample[:, k] = self.dataset[j].Y_transformer.backward(sample[:, k], X[j])
+                Samples.append(sample)
+            i += N
+        if self.dataset.get_output_dims() == 1:
+            return Samples[0]
+        return Samples
+
     def K(self, X1, X2=None):
         """reference mogptk/model.py:666-700"""
         X1 = self._to_kernel_format(self.dataset._format_X(X1))

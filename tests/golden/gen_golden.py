@@ -967,6 +967,41 @@ def gen_likelihoods():
     print("likelihoods.npz written", len(tags), "likelihoods")
 
 
+def gen_samples():
+    """sample_f / sample_y / Model.sample under a fixed torch seed (reference gpr/model.py:346-401, model.py:692-734): a multi-output exact
+    model's posterior samples of f, and a single-output model's samples of y through Model.sample"""
+    out = {}
+    rng = np.random.default_rng(31)
+    X, y = small_data(40, 2, 1, 3100, True)
+    k = build_kernel("mosm", 2, 2, 1, 1, rng)
+    m = g.Exact(k, T(X), T(y), variance=[0.2, 0.3], jitter=1e-8)
+    Z, _ = small_data(9, 2, 1, 3101, False)
+    torch.manual_seed(99)
+    out["f_single"] = m.sample_f(T(Z)).numpy()
+    torch.manual_seed(99)
+    out["f_many"] = m.sample_f(T(Z), n=4).numpy()
+    out["X"] = X; out["y"] = y; out["Z"] = Z
+    dump_params("exact_", list(m.parameters()), out)
+    t = np.linspace(0, 10, 35)
+    d = mogptk.Data(t, np.sin(t) + 0.05 * t + 0.1 * rng.standard_normal(35))
+    d.transform(mogptk.TransformDetrend(degree=1))
+    d.set_prediction_data(np.linspace(0, 11, 8))
+    ms = mogptk.SM(mogptk.DataSet(d), Q=2)
+    for p in ms.gpr.parameters():
+        v = p.constrained.detach().numpy()
+        p.assign(v * rng.uniform(0.8, 1.2, v.shape))
+    torch.manual_seed(7)
+    out["sm_sample"] = np.asarray(ms.sample())
+    torch.manual_seed(7)
+    out["sm_sample_transformed"] = np.asarray(ms.sample(transformed=True))
+    out["sm_t"] = t; out["sm_y"] = d.Y.copy() if hasattr(d, "Y") else None
+    out["sm_y_raw"] = np.sin(t) + 0.05 * t
+    dump_params("sm_", list(ms.gpr.parameters()), out)
+    out["sm_Y"] = np.asarray(ms.dataset[0].Y)
+    np.savez_compressed(os.path.join(HERE, "samples.npz"), **{k2: v for k2, v in out.items() if v is not None})
+    print("samples.npz written")
+
+
 def gen_checkpoints():
     """Files written by the reference's own Model.save() (model.py:320-336) -- the whole pickled model: MOSM with a fitted transformer
     chain, removed points and a pegged + a fixed parameter; the SM, CSM, SM-LMC and CONV wrappers; a Titsias MOSM -- stored as bytes next to what
@@ -1058,7 +1093,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "lbfgs": gen_lbfgs_cfg1, "quirks": gen_quirks,
              "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2, "smlmc": gen_smlmc, "init_ls": gen_init_ls, "bnse": gen_bnse, "transformers": gen_transformers,
-             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints, "snelson": gen_snelson, "hensman": gen_hensman, "oa": gen_oa, "likelihoods": gen_likelihoods}
+             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints, "snelson": gen_snelson, "hensman": gen_hensman, "oa": gen_oa, "likelihoods": gen_likelihoods, "samples": gen_samples}
     full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:
         {**steps, **full}[a.only]()

@@ -701,3 +701,10 @@ def test_sparse_and_variational_edge_cases():
         for key in ("mom_uu", "mom_uf", "gZ", "g_qmu"):
             assert np.max(np.abs(ga[key] - gb[key])) < 1e-7 * max(1.0, np.max(np.abs(gb[key]))), (N, key)
         assert np.max(np.abs(np.tril(ga["g_qsqrt"]) - gb["g_qsqrt"])) < 1e-7 * max(1.0, np.max(np.abs(gb["g_qsqrt"]))), N
+
+
+def test_posterior_samples_on_device():
+    """sample_f / Model.sample: the posterior's full covariance from the device, the draws from torch's generator like the reference --
+    the reference's own samples under the same seed"""
+    from test_host_logic import check_samples
+    check_samples(tol=1e-6)

@@ -768,6 +768,38 @@ def test_non_gaussian_likelihood_through_the_model_wrapper():
     assert abs(m2.loss() - m.loss()) < 1e-12 * abs(m.loss()) and m2.gpr.likelihood.name() == "[PoissonLikelihood,StudentTLikelihood]"
 
 
+def check_samples(tol=1e-8):
+    """samples.npz: sample_f of a multi-output exact model and Model.sample of a single-output one, drawn by the reference under a fixed torch
+    seed; this package draws from the same generator with the same calls, so the samples are the same numbers"""
+    torch = pytest.importorskip("torch")
+    fx = load("samples.npz")
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=2, output_dims=2, input_dims=1)
+    m = gpr.Exact(k, fx["X"], fx["y"], variance=[0.2, 0.3], jitter=1e-8)
+    load_raw(m.parameters(), fixture_params(fx, "exact_"))
+    torch.manual_seed(99)
+    f1 = m.sample_f(fx["Z"])
+    torch.manual_seed(99)
+    f4 = m.sample_f(fx["Z"], n=4)
+    assert f1.shape == fx["f_single"].shape and f4.shape == (4, 9)
+    assert np.max(np.abs(f1 - fx["f_single"])) < tol and np.max(np.abs(f4 - fx["f_many"])) < tol
+    with pytest.raises(TypeError):
+        m.sample_f(fx["Z"], prior=True)                     # the reference calls a mean function that is not there
+    d = mogptk_amd.Data(fx["sm_t"], fx["sm_Y"])
+    d.transform(mogptk_amd.TransformDetrend(degree=1))
+    d.set_prediction_data(np.linspace(0, 11, 8))
+    ms = mogptk_amd.SM(mogptk_amd.DataSet(d), Q=2)
+    load_raw(ms.gpr.parameters(), fixture_params(fx, "sm_"))
+    torch.manual_seed(7)
+    s1 = np.asarray(ms.sample())
+    torch.manual_seed(7)
+    s2 = np.asarray(ms.sample(transformed=True))
+    assert np.max(np.abs(s1 - fx["sm_sample"])) < tol and np.max(np.abs(s2 - fx["sm_sample_transformed"])) < tol
+
+
+def test_posterior_samples_match_reference():
+    check_samples()
+
+
 def test_hensman_through_the_model_wrapper():
     t = np.linspace(0, 10, 30)
     ds = mogptk_amd.DataSet(t, [np.sin(t), np.cos(t)])
