@@ -379,6 +379,20 @@ namespace mogp { double table_diag(const mogp_model* m, int c) {
 }
 }  // namespace mogp
 
+namespace mogp { int ensure_system(mogp_model* m) {
+    int rc;
+    if (m->tiles.empty()) {
+        build_sym_tiles(m->sx.off, m->C, m->tiles, m->pair_start);
+        if ((rc = m->d_tiles.ensure(m->tiles.size()))) return rc;
+        if ((rc = m->d_pair_start.ensure(m->pair_start.size()))) return rc;
+        HIP_TRY(hipMemcpy(m->d_tiles.p, m->tiles.data(), m->tiles.size() * sizeof(GTile), hipMemcpyHostToDevice));
+        if ((rc = m->strip.build(m->tiles))) return rc;
+        HIP_TRY(hipMemcpy(m->d_pair_start.p, m->pair_start.data(), m->pair_start.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    if ((rc = m->d_partial.ensure(m->tiles.size() * (size_t)std::max(m->T, 1) * (size_t)std::max(m->Wt, 1)))) return rc;
+    return spd_alloc(m->k, m->Npad);
+} }
+
 // Gram + factorisation + inverse factor + alpha.  On return d_A holds W = L^-1, d_alpha = Kj^-1 y.
 static int pin_ensure(mogp_model* m, size_t n) {
     if (n <= m->h_pin_n) return 0;
@@ -701,7 +715,6 @@ int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, c
     if ((rc = sort_inputs(X, N, D, C, MOGP_TILE, m->sx))) { delete m; return rc; }
     m->Npad = m->sx.Mpad;
     m->nb = (int)(m->Npad / MOGP_TILE);
-    build_sym_tiles(m->sx.off, C, m->tiles, m->pair_start);
     const int64_t Npad = m->Npad;
     const int nchunks = (int)((Npad + 511) / 512);
 #define MOGP_OUTER_DEFINED 1
@@ -709,8 +722,8 @@ int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, c
 #define TRY_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { int r__ = hip_fail(e__, #x, __FILE__, __LINE__); mogp_model_destroy(m); return r__; } } while (0)
     TRY_RC(ctx_streams(ctx));
     m->st = ctx->st; m->st2 = ctx->st2; m->st2u = ctx->st2u; m->st3 = ctx->st3; m->st4 = ctx->st4; m->st_priv = ctx->st_priv;
-    // the N x N system (two Npad^2 matrices: 160 GB at N = 100 000) is allocated by the first call that factorises it (ensure_system): the
-    // sparse and variational models never do
+    // the N x N system (two Npad^2 matrices: 160 GB at N = 100 000), the tile lists over (X, X) and their partial-moment buffer (N^2 / 4096
+    // tiles) are set up by the first call that needs them (ensure_system): the sparse and variational models never do
     TRY_RC(m->d_x.ensure((size_t)D * Npad));
     TRY_RC(m->d_y.ensure(Npad));
     TRY_RC(m->d_noise.ensure(C));
@@ -720,13 +733,8 @@ int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, c
     TRY_RC(m->d_diagG.ensure(C));
     TRY_RC(m->d_info.ensure(1));
     TRY_RC(m->d_flag.ensure(1));
-    TRY_RC(m->d_tiles.ensure(m->tiles.size()));
-    TRY_RC(m->d_pair_start.ensure(m->pair_start.size()));
     TRY_RC(m->d_chan_off.ensure(C + 1));
     TRY_HIP(hipMemcpy(m->d_x.p, m->sx.xs.data(), (size_t)D * Npad * sizeof(double), hipMemcpyHostToDevice));
-    TRY_HIP(hipMemcpy(m->d_tiles.p, m->tiles.data(), m->tiles.size() * sizeof(GTile), hipMemcpyHostToDevice));
-    TRY_RC(m->strip.build(m->tiles));
-    TRY_HIP(hipMemcpy(m->d_pair_start.p, m->pair_start.data(), m->pair_start.size() * sizeof(int), hipMemcpyHostToDevice));
     TRY_HIP(hipMemcpy(m->d_chan_off.p, m->sx.off.data(), (C + 1) * sizeof(int), hipMemcpyHostToDevice));
     TRY_RC(mogp_model_set_y(m, y));
 #undef TRY_RC
@@ -786,7 +794,6 @@ int mogp_model_set_terms_ex(mogp_model* m, int T, int width, const double* table
     m->Wt = W;
     m->table.assign(table, table + n);
     if ((rc = m->d_table.ensure(n))) return rc;
-    if ((rc = m->d_partial.ensure(m->tiles.size() * (size_t)T * W))) return rc;
     if ((rc = m->d_moments.ensure((size_t)(m->C * (m->C + 1) / 2) * T * W))) return rc;
     HIP_TRY(hipMemcpyAsync(m->d_table.p, m->table.data(), n * sizeof(double), hipMemcpyHostToDevice, m->st));
     return MOGP_OK;
@@ -1079,6 +1086,7 @@ int mogp_gram_ex(mogp_ctx* ctx, int C, int D, int T, int width, const double* ta
 int mogp_shard_config(mogp_model* m, int rank, int nranks) {
     if (!m || nranks < 1 || rank < 0 || rank >= nranks) return fail(MOGP_EINVAL, "mogp_shard_config: bad argument");
     m->sh_rank = rank; m->sh_n = nranks;
+    { int r__ = use_device(m->ctx); if (r__) return r__; r__ = ensure_system(m); if (r__) return r__; }
     if (nranks > 1 && (m->own_rank != rank || m->own_n != nranks)) {
         // each rank generates exactly the Gram / moment tiles it owns: a 64-row tile is kept if one of the (at most two)
         // 128-row tile rows it touches belongs to this rank; nothing else of the work matrix is ever read on this rank (sweep.hip)

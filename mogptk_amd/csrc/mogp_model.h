@@ -232,7 +232,7 @@ int gemm_call(mogp_model* m, const GemmArgs& g, double flops, hipStream_t st = n
 int mark(mogp_model* m, int idx);
 double table_diag(const mogp_model* m, int c);
 int spd_alloc(Spd& w, int64_t Npad);
-inline int ensure_system(mogp_model* m) { return spd_alloc(m->k, m->Npad); }     // the N x N system of the exact / OA paths, on first use
+int ensure_system(mogp_model* m);     // the N x N system of the exact / OA paths and the tile lists over (X, X), on first use (mogp_api.hip)
 int spd_potrf(mogp_model* m, Spd& w, long long info_base = 0);
 int spd_potri_fused(mogp_model* m, Spd& w);
 int spd_potri_fused_finish(mogp_model* m, Spd& w);   // joins the inverse stream: call before reading w.B   // potri.hip: w.A (SPD, lower) -> w.Wm = L^-1, w.B = inverse (lower); w.logdet per tile
