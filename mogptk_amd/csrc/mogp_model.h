@@ -232,6 +232,18 @@ int gemm_call(mogp_model* m, const GemmArgs& g, double flops, hipStream_t st = n
 int mark(mogp_model* m, int idx);
 double table_diag(const mogp_model* m, int c);
 int spd_alloc(Spd& w, int64_t Npad);
+// helpers shared by the sparse / variational models (titsias.hip)
+inline GemmArgs make_gemm(const double* A, int64_t lda, int akm, const double* B, int64_t ldb, int bkm, double* C, int64_t ldc,
+                          double alpha, int mode, int mt, int nt, int64_t K) {
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.a_kmajor = akm; g.B = B; g.ldb = ldb; g.b_kmajor = bkm; g.C = C; g.ldc = ldc;
+    g.alpha = alpha; g.beta = 0.0; g.mode = mode; g.mt = mt; g.nt = nt; g.K = (int)K;
+    return g;
+}
+int spd_check_info(mogp_model* m, const char* which, int64_t* info);   // the pivot report of the last factorisation -> MOGP_ENOTPD naming `which`
+// out (Mpad x Mpad, lower tiles) = alpha A B^T over K (leading dimension ldk), K cut into slices so that the launch fills the chip
+int mm_lower_splitk(mogp_model* m, TitsiasWork& t, const double* A, const double* B, double* out, int mt, int64_t Mpad, int64_t ldk, int64_t K,
+                    double alpha = 1.0);
 int ensure_system(mogp_model* m);     // the N x N system of the exact / OA paths and the tile lists over (X, X), on first use (mogp_api.hip)
 int spd_potrf(mogp_model* m, Spd& w, long long info_base = 0);
 int spd_potri_fused(mogp_model* m, Spd& w);

@@ -70,13 +70,6 @@ __global__ void k_oa_adjoint(double* __restrict__ Y, const double* __restrict__ 
     Y[i * ld + j] = lam[i] * lam[j] * (Y[i * ld + j] - 0.5 * Binv[i * ld + j]) + 0.5 * (e[i] * nu[j] + nu[i] * e[j] - nu[i] * nu[j]);
 }
 
-GemmArgs gemm(const double* A, int64_t lda, int akm, const double* B, int64_t ldb, int bkm, double* C, int64_t ldc,
-              double alpha, int mode, int mt, int nt, int64_t K) {
-    GemmArgs g{};
-    g.A = A; g.lda = lda; g.a_kmajor = akm; g.B = B; g.ldb = ldb; g.b_kmajor = bkm; g.C = C; g.ldc = ldc;
-    g.alpha = alpha; g.beta = 0.0; g.mode = mode; g.mt = mt; g.nt = nt; g.K = (int)K;
-    return g;
-}
 
 // vector slots of OaWork::vec (each Npad)
 enum { V_NU = 0, V_LAM, V_MU, V_B, V_E, V_F, V_D, V_W, V_S, V_R, V_EN, V_GNU, V_COUNT };
@@ -204,7 +197,7 @@ int mogp_oa_backward(mogp_model* m, const double* e, const double* f, double* mo
     const dim3 gnn((unsigned)((Npad + 255) / 256), (unsigned)Npad);
     hipLaunchKernelGGL(k_oa_scale_cols, gnn, dim3(256), 0, m->st, Binv, o.Sc.p, Npad, Npad, dw);
     HIP_TRY(hipGetLastError());
-    GemmArgs g = gemm(o.Sc.p, Npad, 0, Binv, Npad, 0, o.Y.p, Npad, 1.0, GM_LOWER, nt, nt, Npad);
+    GemmArgs g = make_gemm(o.Sc.p, Npad, 0, Binv, Npad, 0, o.Y.p, Npad, 1.0, GM_LOWER, nt, nt, Npad);
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
     RC(launch_symmetrize(o.Y.p, Npad, Npad, m->st));
     hipLaunchKernelGGL(k_oa_adjoint, gnn, dim3(256), 0, m->st, o.Y.p, Binv, Npad, Npad, lam, nu, de);

@@ -23,25 +23,7 @@ using namespace mogp;
 
 namespace {
 
-GemmArgs gemm(const double* A, int64_t lda, int akm, const double* B, int64_t ldb, int bkm, double* C, int64_t ldc,
-              double alpha, int mode, int mt, int nt, int64_t K) {
-    GemmArgs g{};
-    g.A = A; g.lda = lda; g.a_kmajor = akm; g.B = B; g.ldb = ldb; g.b_kmajor = bkm; g.C = C; g.ldc = ldc;
-    g.alpha = alpha; g.beta = 0.0; g.mode = mode; g.mt = mt; g.nt = nt; g.K = (int)K;
-    return g;
-}
 
-int check_info(mogp_model* m, const char* which, int64_t* info) {
-    unsigned long long hinfo = 0;
-    HIP_TRY(hipMemcpyAsync(&hinfo, m->d_info.p, sizeof(hinfo), hipMemcpyDeviceToHost, m->st));
-    HIP_TRY(hipStreamSynchronize(m->st));
-    if (hinfo != std::numeric_limits<unsigned long long>::max()) {
-        if (info) *info = (int64_t)hinfo;
-        return fail(MOGP_ENOTPD, std::string("linalg.cholesky: ") + which + " is not positive-definite (the leading minor of order " +
-                                 std::to_string(hinfo) + " is not positive-definite).");
-    }
-    return 0;
-}
 
 // per point (channel-sorted order): g = Kff_diag[c] - q + s2[c], G = 1/g, Gy = G y, sg = sqrt(G); zero on the padding
 __global__ void k_sn_point(const double* __restrict__ q, const double* __restrict__ y, const int* __restrict__ off, int C,
@@ -105,30 +87,6 @@ __global__ void k_sn_adjoint(double* __restrict__ T, const double* __restrict__ 
 
 struct SnScalars { double logdet_q, sumlogg, yGy, rvGy, jit; };
 
-// C = A B^T over K = Npad for the M x M lower tiles, K cut into slices so that the launch fills the chip (see titsias.hip), + optional identity
-int mm_lower_splitk(mogp_model* m, TitsiasWork& t, const double* A, const double* B, double* out, int mt, int64_t Mpad, int64_t Npad) {
-    GemmArgs g = gemm(A, Npad, 0, B, Npad, 0, out, Mpad, 1.0, GM_LOWER, mt, mt, Npad);
-    const int tiles_q = mt * (mt + 1) / 2;
-    int ks = 1;
-    if (tiles_q < 512 && Npad >= 4096) {
-        double best = 1e30;
-        for (int c = 1; c <= 16; ++c) {
-            if (Npad / c < 2048) break;
-            const double cost = std::ceil((double)tiles_q * c / 512.0) / c;
-            if (cost < best - 1e-12) { best = cost; ks = c; }
-        }
-    }
-    if (ks > 1) {
-        if (t.kslices.n < (size_t)ks * Mpad * Mpad) {
-            RC(t.kslices.ensure((size_t)ks * Mpad * Mpad));
-            HIP_TRY(hipMemsetAsync(t.kslices.p, 0, (size_t)ks * Mpad * Mpad * sizeof(double), m->st));
-        }
-        g.C = t.kslices.p; g.ksplit = ks; g.c_split = (int64_t)Mpad * Mpad;
-    }
-    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
-    if (ks > 1) RC(launch_sum_slices(t.kslices.p, (int64_t)Mpad * Mpad, ks, out, m->st));
-    return 0;
-}
 
 // Front end shared by the evaluation and the prediction: everything up to r = Pq (v G y) and the scalars of p.
 // On return: t.a = L (Kuu), t.v = v, t.q.A = Wq = Lq^-1, t.q.B = Pq (full), t.Qs = Bq (full), t.nvec = [g | G | Gy | sqrt G | ...],
@@ -194,7 +152,7 @@ int snelson_front(mogp_model* m, int64_t M, const double* Z, const double* noise
 
     t.a.keep_L = true;
     RC(spd_potrf(m, t.a));
-    RC(check_info(m, "Kuu", info));
+    RC(spd_check_info(m, "Kuu", info));
     HIP_TRY(hipMemcpyAsync(t.v.p, t.B.p, (size_t)Mpad * Npad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.v.p, Npad, Npad, false));              // v = L^-1 B   (reference gpr/model.py:525)
 
@@ -216,7 +174,7 @@ int snelson_front(mogp_model* m, int64_t M, const double* Z, const double* noise
     // Bq = I + (v sqrt G)(v sqrt G)^T
     hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((Npad + 255) / 256), (unsigned)Mpad), dim3(256), 0, m->st, t.v.p, t.B.p, Npad, Npad, sg);
     HIP_TRY(hipGetLastError());
-    RC(mm_lower_splitk(m, t, t.B.p, t.B.p, t.q.A.p, mt, Mpad, Npad));
+    RC(mm_lower_splitk(m, t, t.B.p, t.B.p, t.q.A.p, mt, Mpad, Npad, Npad));
     RC(launch_add_diag(t.q.A.p, Mpad, Mpad, 1.0, m->st));
     HIP_TRY(hipMemcpyAsync(t.Qs.p, t.q.A.p, (size_t)Mpad * Mpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->d_info.p, &big, sizeof(big), hipMemcpyHostToDevice, m->st));
@@ -224,7 +182,7 @@ int snelson_front(mogp_model* m, int64_t M, const double* Z, const double* noise
     for (int64_t n = 0; n < N; ++n)
         if (!(hg[n] > 0.0)) return fail(MOGP_ENOTPD, "Snelson: Kff - Qff + sigma^2 has a non-positive entry (point " + std::to_string(n) + " in channel-sorted order)");
     RC(spd_potrf(m, t.q));
-    RC(check_info(m, "v G v^T + I", info));
+    RC(spd_check_info(m, "v G v^T + I", info));
     RC(spd_trtri(m, t.q));                                                      // t.q.A = Wq
     RC(spd_lauum(m, t.q));                                                      // t.q.B = Pq (lower)
     RC(launch_symmetrize(t.q.B.p, Mpad, Mpad, m->st));
@@ -293,7 +251,7 @@ int mogp_snelson_eval(mogp_model* m, int64_t M, const double* Z, const double* n
     RC(launch_gemv_cols(t.v.p, Npad, Mpad, Npad, r, vtr, t.scratch.p, m->st));
     hipLaunchKernelGGL(k_sn_alpha, gn, dim3(256), 0, m->st, G, m->d_y.p, vtr, N, Npad, alpha);
     // R1 = Pq v
-    GemmArgs g = gemm(t.q.B.p, Mpad, 0, t.v.p, Npad, 1, t.GB.p, Npad, 1.0, GM_RECT, mt, nt, Mpad);
+    GemmArgs g = make_gemm(t.q.B.p, Mpad, 0, t.v.p, Npad, 1, t.GB.p, Npad, 1.0, GM_RECT, mt, nt, Mpad);
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
     {
         const int nparts = (int)((Mpad + 255) / 256);
@@ -320,7 +278,7 @@ int mogp_snelson_eval(mogp_model* m, int64_t M, const double* Z, const double* n
     // E = I - Pq + 2 (v diag h) v^T;  GA = 1/2 L^-T E L^-1 (the - 1/2 beta beta^T goes through the moment kernel's rank-one term)
     hipLaunchKernelGGL(k_scale_cols, gmn, dim3(256), 0, m->st, t.v.p, t.B.p, Npad, Npad, h);
     HIP_TRY(hipGetLastError());
-    RC(mm_lower_splitk(m, t, t.B.p, t.v.p, t.R.p, mt, Mpad, Npad));
+    RC(mm_lower_splitk(m, t, t.B.p, t.v.p, t.R.p, mt, Mpad, Npad, Npad));
     RC(launch_symmetrize(t.R.p, Mpad, Mpad, m->st));
     RC(launch_combine(t.E.p, t.q.B.p, t.R.p, Mpad, Mpad, 1.0, 1.0, -2.0, m->st));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.E.p, Mpad, Mpad, true));
@@ -398,7 +356,7 @@ int mogp_snelson_predict(mogp_model* m, int64_t M, const double* Z, const double
     RC(launch_gram(ga, (int)tus.size(), m->st));
     HIP_TRY(hipMemcpyAsync(t.Aus.p, t.Kus.p, (size_t)Mpad * Spad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.Aus.p, Spad, Spad, false));                                      // a = L^-1 Kus
-    GemmArgs g = gemm(t.q.A.p, Mpad, 0, t.Aus.p, Spad, 1, t.Bus.p, Spad, 1.0, GM_KHI_I, mt, st, Mpad);      // b = Lq^-1 a
+    GemmArgs g = make_gemm(t.q.A.p, Mpad, 0, t.Aus.p, Spad, 1, t.Bus.p, Spad, 1.0, GM_KHI_I, mt, st, Mpad);      // b = Lq^-1 a
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
     double* vGy = t.vec.p;
     double* cvec = t.vec.p + 4 * Mpad;

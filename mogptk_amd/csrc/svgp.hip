@@ -22,25 +22,7 @@ using namespace mogp;
 
 namespace {
 
-GemmArgs gemm(const double* A, int64_t lda, int akm, const double* B, int64_t ldb, int bkm, double* C, int64_t ldc,
-              double alpha, int mode, int mt, int nt, int64_t K) {
-    GemmArgs g{};
-    g.A = A; g.lda = lda; g.a_kmajor = akm; g.B = B; g.ldb = ldb; g.b_kmajor = bkm; g.C = C; g.ldc = ldc;
-    g.alpha = alpha; g.beta = 0.0; g.mode = mode; g.mt = mt; g.nt = nt; g.K = (int)K;
-    return g;
-}
 
-int check_info(mogp_model* m, const char* which, int64_t* info) {
-    unsigned long long hinfo = 0;
-    HIP_TRY(hipMemcpyAsync(&hinfo, m->d_info.p, sizeof(hinfo), hipMemcpyDeviceToHost, m->st));
-    HIP_TRY(hipStreamSynchronize(m->st));
-    if (hinfo != std::numeric_limits<unsigned long long>::max()) {
-        if (info) *info = (int64_t)hinfo;
-        return fail(MOGP_ENOTPD, std::string("linalg.cholesky: ") + which + " is not positive-definite (the leading minor of order " +
-                                 std::to_string(hinfo) + " is not positive-definite).");
-    }
-    return 0;
-}
 
 // out[m][n] = in[m][n] * s[n]
 __global__ void k_sv_scale_cols(const double* __restrict__ in, double* __restrict__ out, int64_t ld, int64_t n, const double* __restrict__ s) {
@@ -63,30 +45,6 @@ __global__ void k_sv_adjoint(double* __restrict__ Gv, const double* __restrict__
     Gv[i * ld + j] = q[i] * e[j] + 2.0 * (Gv[i * ld + j] - keep * v[i * ld + j]) * f[j];
 }
 
-// out (M x M, lower tiles) = A B^T over K = ncols, K cut into slices so that the launch fills the chip (see titsias.hip)
-int mm_lower_splitk(mogp_model* m, TitsiasWork& t, const double* A, const double* B, double* out, int mt, int64_t Mpad, int64_t ldk, int64_t K) {
-    GemmArgs g = gemm(A, ldk, 0, B, ldk, 0, out, Mpad, 1.0, GM_LOWER, mt, mt, K);
-    const int tiles_q = mt * (mt + 1) / 2;
-    int ks = 1;
-    if (tiles_q < 512 && K >= 4096) {
-        double best = 1e30;
-        for (int c = 1; c <= 16; ++c) {
-            if (K / c < 2048) break;
-            const double cost = std::ceil((double)tiles_q * c / 512.0) / c;
-            if (cost < best - 1e-12) { best = cost; ks = c; }
-        }
-    }
-    if (ks > 1) {
-        if (t.kslices.n < (size_t)ks * Mpad * Mpad) {
-            RC(t.kslices.ensure((size_t)ks * Mpad * Mpad));
-            HIP_TRY(hipMemsetAsync(t.kslices.p, 0, (size_t)ks * Mpad * Mpad * sizeof(double), m->st));
-        }
-        g.C = t.kslices.p; g.ksplit = ks; g.c_split = (int64_t)Mpad * Mpad;
-    }
-    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
-    if (ks > 1) RC(launch_sum_slices(t.kslices.p, (int64_t)Mpad * Mpad, ks, out, m->st));
-    return 0;
-}
 
 // Kuu -> L (t.a), q_mu and S = tril(q_sqrt) onto the device in the sorted order of Z (t.vec[0:Mpad], t.R with rows permuted)
 int svgp_setup(mogp_model* m, int64_t M, const double* Z, const double* q_mu, const double* q_sqrt, double jitter, SortedX& sz,
@@ -137,7 +95,7 @@ int svgp_setup(mogp_model* m, int64_t M, const double* Z, const double* q_mu, co
     RC(launch_pad_identity(t.a.A.p, Mpad, M, Mpad, m->st));
     t.a.keep_L = true;
     RC(spd_potrf(m, t.a));
-    RC(check_info(m, "Kuu", info));
+    RC(spd_check_info(m, "Kuu", info));
     // q_mu and S in the device's order of the inducing points: row pos of the device = row sz.perm[pos] of the caller
     std::vector<double> hq(Mpad, 0.0), hS((size_t)Mpad * Mpad, 0.0);
     for (int64_t pos = 0; pos < M; ++pos) {
@@ -215,7 +173,7 @@ int mogp_svgp_forward(mogp_model* m, int64_t M, const double* Z, const double* q
         RC(trsm_lower(m, t.a.A.p, Mpad, mt, a, Qpad, Qpad, false));               // a = L^-1 K(Z, .)
     }
     // b = S^T a;  mu = a^T q_mu;  column sums of squares
-    GemmArgs g = gemm(t.R.p, Mpad, 1, a, Qpad, 1, b, Qpad, 1.0, GM_RECT, mt, (int)(Qpad / MOGP_TILE), Mpad);
+    GemmArgs g = make_gemm(t.R.p, Mpad, 1, a, Qpad, 1, b, Qpad, 1.0, GM_RECT, mt, (int)(Qpad / MOGP_TILE), Mpad);
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
     RC(m->d_mu.ensure(Qpad)); RC(m->d_var.ensure(2 * Qpad));
     RC(launch_gemv_cols(a, Qpad, Mpad, Qpad, q, m->d_mu.p, t.scratch.p, m->st));
@@ -282,7 +240,7 @@ static int svgp_backward_impl(mogp_model* m, const double* e, const double* f, d
         RC(comm_allreduce(m->ctx, gq, Mpad, m->st));
     }
     // Gv = q e^T + 2 (S b - v) diag f   (t.B; b = S^T v is in t.GB from the forward pass)
-    GemmArgs g = gemm(t.R.p, Mpad, 0, t.GB.p, Npad, 1, t.B.p, Npad, 1.0, GM_RECT, mt, nt, Mpad);
+    GemmArgs g = make_gemm(t.R.p, Mpad, 0, t.GB.p, Npad, 1, t.B.p, Npad, 1.0, GM_RECT, mt, nt, Mpad);
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
     hipLaunchKernelGGL(k_sv_adjoint, gmn, dim3(256), 0, m->st, t.B.p, t.v.p, Npad, Npad, q, de, df, dense ? 0.0 : 1.0);
     HIP_TRY(hipGetLastError());
@@ -301,7 +259,7 @@ static int svgp_backward_impl(mogp_model* m, const double* e, const double* f, d
     RC(mm_lower_splitk(m, t, t.GB.p, t.v.p, t.Qs.p, mt, Mpad, Npad, Npad));
     if (sharded) RC(comm_allreduce(m->ctx, t.Qs.p, Mpad * Mpad, m->st));
     RC(launch_symmetrize(t.Qs.p, Mpad, Mpad, m->st));
-    g = gemm(t.Qs.p, Mpad, 0, t.R.p, Mpad, 1, t.q.A.p, Mpad, 2.0, GM_RECT, mt, mt, Mpad);
+    g = make_gemm(t.Qs.p, Mpad, 0, t.R.p, Mpad, 1, t.q.A.p, Mpad, 2.0, GM_RECT, mt, mt, Mpad);
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
     HIP_TRY(hipMemsetAsync(t.gz.p, 0, (size_t)D * Mpad * sizeof(double), m->st));
 

@@ -25,15 +25,11 @@ using namespace mogp;
 
 #define RC(x) do { int r__ = (x); if (r__) return r__; } while (0)
 
-static GemmArgs gemm(const double* A, int64_t lda, int akm, const double* B, int64_t ldb, int bkm, double* C, int64_t ldc,
-                     double alpha, int mode, int mt, int nt, int64_t K) {
-    GemmArgs g{};
-    g.A = A; g.lda = lda; g.a_kmajor = akm; g.B = B; g.ldb = ldb; g.b_kmajor = bkm; g.C = C; g.ldc = ldc;
-    g.alpha = alpha; g.beta = 0.0; g.mode = mode; g.mt = mt; g.nt = nt; g.K = (int)K;
-    return g;
-}
 
-static int check_info(mogp_model* m, const char* which, int64_t* info) {
+
+namespace mogp {
+
+int spd_check_info(mogp_model* m, const char* which, int64_t* info) {
     unsigned long long hinfo = 0;
     HIP_TRY(hipMemcpyAsync(&hinfo, m->d_info.p, sizeof(hinfo), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
@@ -44,6 +40,36 @@ static int check_info(mogp_model* m, const char* which, int64_t* info) {
     }
     return 0;
 }
+
+// mt (mt + 1) / 2 = 136 tiles at configs[4] would leave half the chip idle over K = N: K is cut into ks slices, each slice into a block of
+// its own, and the blocks are summed.  ks minimises rounds(tiles ks / 512 slots) / ks: 136 tiles -> ks = 15, 2040 workgroups = four
+// full rounds (two slices left every second CU with two workgroups and the rest with one: 12.5 ms; fifteen: see DESIGN 4b)
+int mm_lower_splitk(mogp_model* m, TitsiasWork& t, const double* A, const double* B, double* out, int mt, int64_t Mpad, int64_t ldk, int64_t K,
+                    double alpha) {
+    GemmArgs g = make_gemm(A, ldk, 0, B, ldk, 0, out, Mpad, alpha, GM_LOWER, mt, mt, K);
+    const int tiles_q = mt * (mt + 1) / 2;
+    int ks = 1;
+    if (tiles_q < 512 && K >= 4096) {
+        double best = 1e30;
+        for (int c = 1; c <= 16; ++c) {
+            if (K / c < 2048) break;
+            const double cost = std::ceil((double)tiles_q * c / 512.0) / c;
+            if (cost < best - 1e-12) { best = cost; ks = c; }
+        }
+    }
+    if (ks > 1) {
+        if (t.kslices.n < (size_t)ks * Mpad * Mpad) {         // the upper tiles are never written: keep them finite
+            RC(t.kslices.ensure((size_t)ks * Mpad * Mpad));
+            HIP_TRY(hipMemsetAsync(t.kslices.p, 0, (size_t)ks * Mpad * Mpad * sizeof(double), m->st));
+        }
+        g.C = t.kslices.p; g.ksplit = ks; g.c_split = (int64_t)Mpad * Mpad;
+    }
+    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
+    if (ks > 1) RC(launch_sum_slices(t.kslices.p, (int64_t)Mpad * Mpad, ks, out, m->st));
+    return 0;
+}
+
+}  // namespace mogp
 
 // Common front end: sort Z, build tiles, Kuu -> W (in tw.a.A), Kuf -> tw.B, v -> tw.v, Qs -> tw.Qs, Wq (tw.q.A), Pq (tw.q.B, full),
 // vy, t1 in tw.vec[0 : Mpad], tw.vec[Mpad : 2 Mpad].  Host scalars through `sc`.
@@ -112,35 +138,13 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
 
     t.a.keep_L = true;                                                          // the solves below need L itself, diagonal tiles included
     RC(spd_potrf(m, t.a));
-    RC(check_info(m, "Kuu", info));
+    RC(spd_check_info(m, "Kuu", info));
     const double s2 = sigma * sigma;
     HIP_TRY(hipMemcpyAsync(t.v.p, t.B.p, (size_t)Mpad * Npad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.v.p, Npad, Npad, false));              // v = L^-1 B   (reference gpr/model.py:711)
     (void)nt;
     // Qs = v v^T / s2 + I
-    GemmArgs g = gemm(t.v.p, Npad, 0, t.v.p, Npad, 0, t.q.A.p, Mpad, 1.0 / s2, GM_LOWER, mt, mt, Npad);
-    // mt (mt + 1) / 2 = 136 tiles at configs[4] would leave half the chip idle over K = N: K is cut into ks slices, each slice into a block of
-    // its own, and the blocks are summed.  ks minimises rounds(tiles ks / 512 slots) / ks: 136 tiles -> ks = 15, 2040 workgroups = four
-    // full rounds (two slices left every second CU with two workgroups and the rest with one: 12.5 ms; fifteen: see DESIGN 4b)
-    const int tiles_q = mt * (mt + 1) / 2;
-    int ks = 1;
-    if (tiles_q < 512 && Npad >= 4096) {
-        double best = 1e30;
-        for (int c = 1; c <= 16; ++c) {
-            if (Npad / c < 2048) break;
-            const double cost = std::ceil((double)tiles_q * c / 512.0) / c;
-            if (cost < best - 1e-12) { best = cost; ks = c; }
-        }
-    }
-    if (ks > 1) {
-        if (t.kslices.n < (size_t)ks * Mpad * Mpad) {         // the upper tiles are never written: keep them finite
-            RC(t.kslices.ensure((size_t)ks * Mpad * Mpad));
-            HIP_TRY(hipMemsetAsync(t.kslices.p, 0, (size_t)ks * Mpad * Mpad * sizeof(double), m->st));
-        }
-        g.C = t.kslices.p; g.ksplit = ks; g.c_split = (int64_t)Mpad * Mpad;
-    }
-    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
-    if (ks > 1) RC(launch_sum_slices(t.kslices.p, (int64_t)Mpad * Mpad, ks, t.q.A.p, m->st));
+    RC(mm_lower_splitk(m, t, t.v.p, t.v.p, t.q.A.p, mt, Mpad, Npad, Npad, 1.0 / s2));
     double* vy = t.vec.p;
     RC(launch_gemv_rows(t.v.p, Npad, Mpad, Npad, m->d_y.p, vy, m->st));
     sc.yy = 0.0; for (int64_t i = 0; i < m->N; ++i) sc.yy += m->hy[i] * m->hy[i];
@@ -164,7 +168,7 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     HIP_TRY(hipMemcpyAsync(t.Qs.p, t.q.A.p, (size_t)Mpad * Mpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->d_info.p, &big, sizeof(big), hipMemcpyHostToDevice, m->st));
     RC(spd_potrf(m, t.q));
-    RC(check_info(m, "Q/sigma^2 + I", info));
+    RC(spd_check_info(m, "Q/sigma^2 + I", info));
     RC(spd_trtri(m, t.q));                                                      // t.q.A = Wq
     RC(spd_lauum(m, t.q));                                                      // t.q.B = Pq (lower)
     RC(launch_symmetrize(t.q.B.p, Mpad, Mpad, m->st));
@@ -243,7 +247,7 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
     // GB = L^-T (R v) / s2, and beta = L^-T t1 riding along: when N is not a multiple of 128 the right-hand side has zero padding columns,
     // and t1 travels through the blocked solve in the first of them (a vector solve of its own is 2 nb dependent, almost empty launches)
     RC(launch_combine(t.R.p, t.q.B.p, nullptr, Mpad, Mpad, 1.0, 1.0, 0.0, m->st));           // R = I - Pq
-    GemmArgs g = gemm(t.R.p, Mpad, 0, t.v.p, Npad, 1, t.GB.p, Npad, 1.0 / s2, GM_RECT, mt, nt, Mpad);
+    GemmArgs g = make_gemm(t.R.p, Mpad, 0, t.v.p, Npad, 1, t.GB.p, Npad, 1.0 / s2, GM_RECT, mt, nt, Mpad);
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
     const bool ride = Npad > N;
     if (ride) RC(launch_copy2d(t.GB.p + N, Npad, t1, 1, Mpad, 1, 1.0, m->st));
@@ -365,7 +369,7 @@ static int titsias_predict_impl(mogp_model* m, int64_t M, const double* Z, doubl
     RC(launch_gram(ga, (int)tus.size(), m->st));
     HIP_TRY(hipMemcpyAsync(t.Aus.p, t.Kus.p, (size_t)Mpad * Spad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.Aus.p, Spad, Spad, false));                                      // a = L^-1 Kus
-    GemmArgs g = gemm(t.q.A.p, Mpad, 0, t.Aus.p, Spad, 1, t.Bus.p, Spad, 1.0, GM_KHI_I, mt, st, Mpad);                // b = Wq a
+    GemmArgs g = make_gemm(t.q.A.p, Mpad, 0, t.Aus.p, Spad, 1, t.Bus.p, Spad, 1.0, GM_KHI_I, mt, st, Mpad);                // b = Wq a
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
     double* vy = t.vec.p;
     double* cvec = t.vec.p + 4 * Mpad;
