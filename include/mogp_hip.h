@@ -213,6 +213,14 @@ int  mogp_snelson_eval(mogp_model* m, int64_t M, const double* Z, const double* 
                        double* lml, double* mom_uu, double* mom_uf, double* gZ, double* trGA, double* hsum, double* jitter_abs, int64_t* info);
 int  mogp_snelson_predict(mogp_model* m, int64_t M, const double* Z, const double* noise_var, double jitter, const double* kff_diag,
                           const double* kss_diag, int64_t S, const double* Xs, double* mu, double* var, int64_t* info);
+/* The same two calls DATA-PARALLEL (cf. mogp_titsias_eval_sharded below): each rank's handle holds its own shard of the training points;
+ * v G v^T and (v diag h) v^T (M x M), v G y, sum log g, y^T G y, N, the (Z, X) moments with their share of d/dZ and hsum are all-reduced
+ * inside the library; every rank returns the full model's value and gradient. */
+int  mogp_snelson_eval_sharded(mogp_model* m, int64_t M, const double* Z, const double* noise_var, double jitter, const double* kff_diag,
+                               int flags, double* lml, double* mom_uu, double* mom_uf, double* gZ, double* trGA, double* hsum,
+                               double* jitter_abs, int64_t* info);
+int  mogp_snelson_predict_sharded(mogp_model* m, int64_t M, const double* Z, const double* noise_var, double jitter, const double* kff_diag,
+                                  const double* kss_diag, int64_t S, const double* Xs, double* mu, double* var, int64_t* info);
 
 /* The variational GP of Hensman et al. (whitened; reference gpr/model.py:767-886), the O(N M^2) algebra around ANY likelihood, in two calls
  * per evaluation.  forward: mean and variance of q(f) at the training inputs (S = 0; the state for the backward call is kept in the handle)

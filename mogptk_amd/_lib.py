@@ -79,6 +79,11 @@ SIGNATURES = {
                                          ctypes.POINTER(ctypes.c_double), c_i64p]),
     "mogp_snelson_predict": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, c_dp, ctypes.c_double, c_dp, c_dp, ctypes.c_int64, c_dp,
                                             c_dp, c_dp, c_i64p]),
+    "mogp_snelson_eval_sharded": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_double), c_dp, c_dp, c_dp, ctypes.POINTER(ctypes.c_double), c_dp,
+                                         ctypes.POINTER(ctypes.c_double), c_i64p]),
+    "mogp_snelson_predict_sharded": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, c_dp, ctypes.c_double, c_dp, c_dp, ctypes.c_int64, c_dp,
+                                            c_dp, c_dp, c_i64p]),
     "mogp_svgp_forward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.c_int, ctypes.c_int64,
                                          c_dp, c_dp, c_dp, c_dp, ctypes.POINTER(ctypes.c_double), c_i64p]),
     "mogp_svgp_backward": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp, ctypes.POINTER(ctypes.c_double), c_dp, c_dp]),
@@ -328,7 +333,7 @@ class ExactHandle:
         check(code, info.value)
         return mu.reshape(-1, 1), var.reshape(-1, 1)
 
-    def snelson_eval(self, Z, noise_var, jitter, kff_diag, grad=True):
+    def snelson_eval(self, Z, noise_var, jitter, kff_diag, grad=True, sharded=False):
         """Snelson (FITC) marginal likelihood (+ gradient outputs) through mogp_snelson_eval"""
         Z, noise_var, kff_diag = _f64(Z), _f64(noise_var), _f64(kff_diag)
         M = Z.shape[0]
@@ -339,19 +344,20 @@ class ExactHandle:
         mom_uf = np.zeros((C * C, T, W)) if grad else None
         gZ = np.zeros((M, D)) if grad else None
         hsum = np.zeros(C) if grad else None
-        code = lib().mogp_snelson_eval(self._h, M, _dp(Z), _dp(noise_var), float(jitter), _dp(kff_diag), MOGP_EVAL_GRAD if grad else 0,
-                                       ctypes.byref(lml), _dp(mom_uu), _dp(mom_uf), _dp(gZ), ctypes.byref(trGA), _dp(hsum),
-                                       ctypes.byref(jit), ctypes.byref(info))
+        fn = lib().mogp_snelson_eval_sharded if sharded else lib().mogp_snelson_eval
+        code = fn(self._h, M, _dp(Z), _dp(noise_var), float(jitter), _dp(kff_diag), MOGP_EVAL_GRAD if grad else 0,
+                  ctypes.byref(lml), _dp(mom_uu), _dp(mom_uf), _dp(gZ), ctypes.byref(trGA), _dp(hsum), ctypes.byref(jit), ctypes.byref(info))
         check(code, info.value)
         return dict(lml=lml.value, mom_uu=mom_uu, mom_uf=mom_uf, gZ=gZ, trGA=trGA.value, hsum=hsum, jitter_abs=jit.value)
 
-    def snelson_predict(self, Z, noise_var, jitter, Xs, kff_diag, kss_diag):
+    def snelson_predict(self, Z, noise_var, jitter, Xs, kff_diag, kss_diag, sharded=False):
         Z, Xs, noise_var, kff_diag, kss_diag = _f64(Z), _f64(Xs), _f64(noise_var), _f64(kff_diag), _f64(kss_diag)
         S = Xs.shape[0]
         mu, var = np.empty(S), np.empty(S)
         info = ctypes.c_int64(0)
-        code = lib().mogp_snelson_predict(self._h, Z.shape[0], _dp(Z), _dp(noise_var), float(jitter), _dp(kff_diag), _dp(kss_diag), S, _dp(Xs),
-                                          _dp(mu), _dp(var), ctypes.byref(info))
+        fn = lib().mogp_snelson_predict_sharded if sharded else lib().mogp_snelson_predict
+        code = fn(self._h, Z.shape[0], _dp(Z), _dp(noise_var), float(jitter), _dp(kff_diag), _dp(kss_diag), S, _dp(Xs),
+                  _dp(mu), _dp(var), ctypes.byref(info))
         check(code, info.value)
         return mu.reshape(-1, 1), var.reshape(-1, 1)
 

@@ -85,15 +85,17 @@ __global__ void k_sn_adjoint(double* __restrict__ T, const double* __restrict__ 
     T[i * ld + j] = r[i] * alpha[j] - T[i * ld + j] * G[j] - 2.0 * v[i * ld + j] * h[j];
 }
 
-struct SnScalars { double logdet_q, sumlogg, yGy, rvGy, jit; };
+struct SnScalars { double logdet_q, sumlogg, yGy, rvGy, jit, ntot; };
 
 
 // Front end shared by the evaluation and the prediction: everything up to r = Pq (v G y) and the scalars of p.
 // On return: t.a = L (Kuu), t.v = v, t.q.A = Wq = Lq^-1, t.q.B = Pq (full), t.Qs = Bq (full), t.nvec = [g | G | Gy | sqrt G | ...],
 // t.vec[0:Mpad] = v G y, t.vec[Mpad:2Mpad] = r.
+// sharded: this handle holds ONE SHARD of the training points (cf. mogp_titsias_eval_sharded): v G v^T, v G y, sum log g, y^T G y and N are
+// all-reduced (and the per-point positivity check with them, so that every rank takes the same exit).
 int snelson_front(mogp_model* m, int64_t M, const double* Z, const double* noise_var, double jitter, const double* kff_diag, SortedX& sz,
                   std::vector<GTile>& tuu, std::vector<int>& psuu, std::vector<GTile>& tuf, std::vector<int>& psuf, SnScalars& sc,
-                  int64_t* info, bool need_moment_tiles) {
+                  int64_t* info, bool need_moment_tiles, bool sharded) {
     const int C = m->C, D = m->D, W = 2 + 3 * D;
     const int64_t N = m->N, Npad = m->Npad;
     if (m->T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms must be called before an evaluation");
@@ -175,21 +177,43 @@ int snelson_front(mogp_model* m, int64_t M, const double* Z, const double* noise
     hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((Npad + 255) / 256), (unsigned)Mpad), dim3(256), 0, m->st, t.v.p, t.B.p, Npad, Npad, sg);
     HIP_TRY(hipGetLastError());
     RC(mm_lower_splitk(m, t, t.B.p, t.B.p, t.q.A.p, mt, Mpad, Npad, Npad));
+    double* vGy = t.vec.p;
+    RC(launch_gemv_rows(t.v.p, Npad, Mpad, Npad, Gy, vGy, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    int64_t bad = -1;
+    sc.sumlogg = sc.yGy = 0.0;
+    for (int64_t n = 0; n < N; ++n) {
+        if (!(hg[n] > 0.0)) { if (bad < 0) bad = n; continue; }
+        sc.sumlogg += std::log(hg[n]); sc.yGy += m->hy[n] * m->hy[n] / hg[n];
+    }
+    sc.ntot = (double)N;
+    double nbad = bad >= 0 ? 1.0 : 0.0;
+    if (sharded) {
+        RC(t.red.ensure((size_t)Mpad + 4));
+        double hs[4] = {sc.sumlogg, sc.yGy, sc.ntot, nbad};
+        HIP_TRY(hipMemcpyAsync(t.red.p, vGy, Mpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
+        HIP_TRY(hipMemcpyAsync(t.red.p + Mpad, hs, sizeof(hs), hipMemcpyHostToDevice, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));
+        RC(comm_allreduce(m->ctx, t.red.p, Mpad + 4, m->st));
+        HIP_TRY(hipMemcpyAsync(vGy, t.red.p, Mpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
+        HIP_TRY(hipMemcpyAsync(hs, t.red.p + Mpad, sizeof(hs), hipMemcpyDeviceToHost, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));
+        sc.sumlogg = hs[0]; sc.yGy = hs[1]; sc.ntot = hs[2]; nbad = hs[3];
+    }
+    if (nbad > 0.0)
+        return fail(MOGP_ENOTPD, bad >= 0 ? "Snelson: Kff - Qff + sigma^2 has a non-positive entry (point " + std::to_string(bad) + " in channel-sorted order)"
+                                          : std::string("Snelson: Kff - Qff + sigma^2 has a non-positive entry (on another rank's shard)"));
+    if (sharded) RC(comm_allreduce(m->ctx, t.q.A.p, Mpad * Mpad, m->st));
     RC(launch_add_diag(t.q.A.p, Mpad, Mpad, 1.0, m->st));
     HIP_TRY(hipMemcpyAsync(t.Qs.p, t.q.A.p, (size_t)Mpad * Mpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->d_info.p, &big, sizeof(big), hipMemcpyHostToDevice, m->st));
-    HIP_TRY(hipStreamSynchronize(m->st));
-    for (int64_t n = 0; n < N; ++n)
-        if (!(hg[n] > 0.0)) return fail(MOGP_ENOTPD, "Snelson: Kff - Qff + sigma^2 has a non-positive entry (point " + std::to_string(n) + " in channel-sorted order)");
     RC(spd_potrf(m, t.q));
     RC(spd_check_info(m, "v G v^T + I", info));
     RC(spd_trtri(m, t.q));                                                      // t.q.A = Wq
     RC(spd_lauum(m, t.q));                                                      // t.q.B = Pq (lower)
     RC(launch_symmetrize(t.q.B.p, Mpad, Mpad, m->st));
     RC(launch_symmetrize(t.Qs.p, Mpad, Mpad, m->st));
-    double* vGy = t.vec.p;
     double* r = t.vec.p + Mpad;
-    RC(launch_gemv_rows(t.v.p, Npad, Mpad, Npad, Gy, vGy, m->st));
     {   // r = Pq (v G y): the explicit inverse plus one step of iterative refinement against Bq (see titsias.hip)
         double* tmp = t.vec.p + 5 * Mpad;
         double* res = t.vec.p + 6 * Mpad;
@@ -205,18 +229,14 @@ int snelson_front(mogp_model* m, int64_t M, const double* Z, const double* noise
     HIP_TRY(hipMemcpyAsync(hl.data(), t.q.logdet.p, nbq * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
     sc.logdet_q = 0.0; for (double x : hl) sc.logdet_q += x;
-    sc.sumlogg = sc.yGy = sc.rvGy = 0.0;
-    for (int64_t n = 0; n < N; ++n) { sc.sumlogg += std::log(hg[n]); sc.yGy += m->hy[n] * m->hy[n] / hg[n]; }
+    sc.rvGy = 0.0;
     for (int64_t i = 0; i < M; ++i) sc.rvGy += hv[Mpad + i] * hv[i];
     return 0;
 }
 
-}  // namespace
-
-extern "C" {
-
-int mogp_snelson_eval(mogp_model* m, int64_t M, const double* Z, const double* noise_var, double jitter, const double* kff_diag, int flags,
-                      double* lml, double* mom_uu, double* mom_uf, double* gZ, double* trGA, double* hsum, double* jitter_abs, int64_t* info) {
+int snelson_eval_impl(mogp_model* m, int64_t M, const double* Z, const double* noise_var, double jitter, const double* kff_diag, int flags,
+                      double* lml, double* mom_uu, double* mom_uf, double* gZ, double* trGA, double* hsum, double* jitter_abs, int64_t* info,
+                      bool sharded) {
     if (!m || !Z || !noise_var || !kff_diag || !lml || M <= 0) return fail(MOGP_EINVAL, "mogp_snelson_eval: bad argument");
     RC(use_device(m->ctx));
     if (info) *info = 0;
@@ -227,11 +247,11 @@ int mogp_snelson_eval(mogp_model* m, int64_t M, const double* Z, const double* n
     std::vector<GTile> tuu, tuf;
     std::vector<int> psuu, psuf;
     SnScalars sc;
-    RC(snelson_front(m, M, Z, noise_var, jitter, kff_diag, sz, tuu, psuu, tuf, psuf, sc, info, grad));
+    RC(snelson_front(m, M, Z, noise_var, jitter, kff_diag, sz, tuu, psuu, tuf, psuf, sc, info, grad, sharded));
     TitsiasWork& t = *m->tw;
     const int64_t Mpad = t.Mpad;
     const int mt = (int)(Mpad / MOGP_TILE), nt = (int)(Npad / MOGP_TILE);
-    *lml = -0.5 * (double)N * std::log(2.0 * M_PI) - sc.logdet_q - 0.5 * sc.sumlogg - 0.5 * sc.yGy + 0.5 * sc.rvGy;
+    *lml = -0.5 * sc.ntot * std::log(2.0 * M_PI) - sc.logdet_q - 0.5 * sc.sumlogg - 0.5 * sc.yGy + 0.5 * sc.rvGy;
     if (jitter_abs) *jitter_abs = sc.jit;
     if (!grad) return MOGP_OK;
     if (!mom_uu || !mom_uf || !gZ || !trGA || !hsum) return fail(MOGP_EINVAL, "mogp_snelson_eval: gradient outputs are null");
@@ -279,6 +299,7 @@ int mogp_snelson_eval(mogp_model* m, int64_t M, const double* Z, const double* n
     hipLaunchKernelGGL(k_scale_cols, gmn, dim3(256), 0, m->st, t.v.p, t.B.p, Npad, Npad, h);
     HIP_TRY(hipGetLastError());
     RC(mm_lower_splitk(m, t, t.B.p, t.v.p, t.R.p, mt, Mpad, Npad, Npad));
+    if (sharded) RC(comm_allreduce(m->ctx, t.R.p, Mpad * Mpad, m->st));
     RC(launch_symmetrize(t.R.p, Mpad, Mpad, m->st));
     RC(launch_combine(t.E.p, t.q.B.p, t.R.p, Mpad, Mpad, 1.0, 1.0, -2.0, m->st));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.E.p, Mpad, Mpad, true));
@@ -297,6 +318,10 @@ int mogp_snelson_eval(mogp_model* m, int64_t M, const double* Z, const double* n
     ma.gzr = t.gz.p; ma.gzc = nullptr; ma.ldgz = Mpad; ma.partial = t.partial_uf.p;
     RC(launch_moments(ma, m->st));
     RC(launch_moment_reduce(t.partial_uf.p, t.ps_uf.p, C * C, T, W, D, t.mom_uf.p, m->st, 0));
+    if (sharded) {
+        RC(comm_allreduce(m->ctx, t.mom_uf.p, (int64_t)C * C * T * W, m->st));
+        RC(comm_allreduce(m->ctx, t.gz.p, (int64_t)D * Mpad, m->st));
+    }
     ma.tiles = t.tiles_uu.p; ma.ntiles = (int)tuu.size(); ma.xc = nullptr; ma.ldxc = 0; ma.ncols = M;
     RC(t.ph_zz.prepare(sz.off, sz.off, C, T, Mpad, Mpad, m->st, ma.ph));
     ma.G = t.GA.p; ma.ldg = Mpad; ma.ru = beta; ma.rw = beta; ma.rcoef = -0.5; ma.sym = 1;
@@ -322,11 +347,51 @@ int mogp_snelson_eval(mogp_model* m, int64_t M, const double* Z, const double* n
         for (int pos = m->sx.off[c]; pos < m->sx.off[c + 1]; ++pos) s += hh[pos];
         hsum[c] = s;
     }
+    if (sharded) {                               // sum of h over the points of a channel: one more small all-reduce
+        RC(t.red.ensure((size_t)Mpad + 4 + C));
+        HIP_TRY(hipMemcpyAsync(t.red.p, hsum, C * sizeof(double), hipMemcpyHostToDevice, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));
+        RC(comm_allreduce(m->ctx, t.red.p, C, m->st));
+        HIP_TRY(hipMemcpyAsync(hsum, t.red.p, C * sizeof(double), hipMemcpyDeviceToHost, m->st));
+        HIP_TRY(hipStreamSynchronize(m->st));
+    }
     return MOGP_OK;
+}
+
+int snelson_predict_impl(mogp_model* m, int64_t M, const double* Z, const double* noise_var, double jitter, const double* kff_diag,
+                         const double* kss_diag, int64_t S, const double* Xs, double* mu, double* var, int64_t* info, bool sharded);
+
+}  // namespace
+
+extern "C" {
+
+int mogp_snelson_eval(mogp_model* m, int64_t M, const double* Z, const double* noise_var, double jitter, const double* kff_diag, int flags,
+                      double* lml, double* mom_uu, double* mom_uf, double* gZ, double* trGA, double* hsum, double* jitter_abs, int64_t* info) {
+    return snelson_eval_impl(m, M, Z, noise_var, jitter, kff_diag, flags, lml, mom_uu, mom_uf, gZ, trGA, hsum, jitter_abs, info, false);
+}
+
+int mogp_snelson_eval_sharded(mogp_model* m, int64_t M, const double* Z, const double* noise_var, double jitter, const double* kff_diag, int flags,
+                              double* lml, double* mom_uu, double* mom_uf, double* gZ, double* trGA, double* hsum, double* jitter_abs,
+                              int64_t* info) {
+    return snelson_eval_impl(m, M, Z, noise_var, jitter, kff_diag, flags, lml, mom_uu, mom_uf, gZ, trGA, hsum, jitter_abs, info, true);
 }
 
 int mogp_snelson_predict(mogp_model* m, int64_t M, const double* Z, const double* noise_var, double jitter, const double* kff_diag,
                          const double* kss_diag, int64_t S, const double* Xs, double* mu, double* var, int64_t* info) {
+    return snelson_predict_impl(m, M, Z, noise_var, jitter, kff_diag, kss_diag, S, Xs, mu, var, info, false);
+}
+
+int mogp_snelson_predict_sharded(mogp_model* m, int64_t M, const double* Z, const double* noise_var, double jitter, const double* kff_diag,
+                                 const double* kss_diag, int64_t S, const double* Xs, double* mu, double* var, int64_t* info) {
+    return snelson_predict_impl(m, M, Z, noise_var, jitter, kff_diag, kss_diag, S, Xs, mu, var, info, true);
+}
+
+}  // extern "C"
+
+namespace {
+
+int snelson_predict_impl(mogp_model* m, int64_t M, const double* Z, const double* noise_var, double jitter, const double* kff_diag,
+                         const double* kss_diag, int64_t S, const double* Xs, double* mu, double* var, int64_t* info, bool sharded) {
     if (!m || !Z || !noise_var || !kff_diag || !kss_diag || !Xs || !mu || !var || M <= 0 || S <= 0)
         return fail(MOGP_EINVAL, "mogp_snelson_predict: bad argument");
     RC(use_device(m->ctx));
@@ -336,7 +401,7 @@ int mogp_snelson_predict(mogp_model* m, int64_t M, const double* Z, const double
     std::vector<GTile> tuu, tuf, tus;
     std::vector<int> psuu, psuf;
     SnScalars sc;
-    RC(snelson_front(m, M, Z, noise_var, jitter, kff_diag, sz, tuu, psuu, tuf, psuf, sc, info, false));
+    RC(snelson_front(m, M, Z, noise_var, jitter, kff_diag, sz, tuu, psuu, tuf, psuf, sc, info, false, sharded));
     TitsiasWork& t = *m->tw;
     const int64_t Mpad = t.Mpad;
     RC(sort_inputs(Xs, S, D, C, MOGP_TILE, ss));
@@ -376,4 +441,4 @@ int mogp_snelson_predict(mogp_model* m, int64_t M, const double* Z, const double
     return MOGP_OK;
 }
 
-}  // extern "C"
+}  // namespace

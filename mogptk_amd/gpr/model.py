@@ -405,7 +405,38 @@ def init_inducing_points(Z, X, method="grid", output_dims=None):
     return Z
 
 
-class Titsias(Model):
+class _DataParallel:
+    """Sparse models: the objective touches the training points only through sums over them.  Under `mogptk_amd.use_distributed()` every
+    process builds its device model on every world-th training point (starting at its rank) and the library all-reduces those sums
+    (mogp_titsias_eval_sharded, mogp_snelson_eval_sharded, mogp_svgp_backward_sharded): each rank gets the full model's value and gradient."""
+
+    def _shardable(self):
+        return True
+
+    def _data_shard(self):
+        """the communicator this process shards its training points over, or None"""
+        comm = getattr(config, "comm", None)
+        if self._shardable() and comm is not None and getattr(comm, "native", False) and (comm.world > 1 or comm.force):
+            return comm
+        return None
+
+    def _local(self, a):
+        """this rank's share of a per-point array (all of it without a communicator)"""
+        comm = self._data_shard()
+        return a if comm is None else a[comm.rank::comm.world]
+
+    def _device_handle(self):
+        comm = self._data_shard()
+        key = None if comm is None else (comm.rank, comm.world)
+        if self._handle is None or self.__dict__.get("_handle_key") != key:
+            from .._lib import ExactHandle
+            y = self.y if self.mean is None else self.y - np.asarray(self.mean(self.X)).reshape(-1, 1)
+            self._handle = ExactHandle(config.device, self._local(self.kernel._kernel_format(self.X)), self._local(y), self.kernel._channels())
+            self.__dict__["_handle_key"] = key
+        return self._handle
+
+
+class Titsias(_DataParallel, Model):
     """
     Sparse GP regression, Titsias 2009 (reference gpr/model.py:668-765): the bound
         ELBO = log N(y | 0, Kfu Kuu^-1 Kuf + s2 I) - tr(Kff - Kfu Kuu^-1 Kuf) / (2 s2)
@@ -421,28 +452,6 @@ class Titsias(Model):
         self.Z = Parameter(Z, name="induction_points")
         if kernel.output_dims is not None:
             self.Z.num_parameters -= self.Z().shape[0]
-
-    def _data_shard(self):
-        """the communicator this process shards its training points over (mogptk_amd.use_distributed), or None"""
-        comm = getattr(config, "comm", None)
-        if comm is not None and getattr(comm, "native", False) and (comm.world > 1 or comm.force):
-            return comm
-        return None
-
-    def _device_handle(self):
-        """the device model of this process's training points: all of them, or -- data-parallel over the ranks of the communicator -- every
-        world-th point starting at this rank (the bound touches the data only through sums over points: mogp_titsias_eval_sharded)"""
-        comm = self._data_shard()
-        key = None if comm is None else (comm.rank, comm.world)
-        if self._handle is None or self.__dict__.get("_handle_key") != key:
-            from .._lib import ExactHandle
-            y = self.y if self.mean is None else self.y - np.asarray(self.mean(self.X)).reshape(-1, 1)
-            Xk = self.kernel._kernel_format(self.X)
-            if comm is not None:
-                Xk, y = Xk[comm.rank::comm.world], y[comm.rank::comm.world]
-            self._handle = ExactHandle(config.device, Xk, y, self.kernel._channels())
-            self.__dict__["_handle_key"] = key
-        return self._handle
 
     def _sigma(self):
         s = np.asarray(self.likelihood.scale())
@@ -512,7 +521,7 @@ class Titsias(Model):
         return mu, var
 
 
-class Snelson(Model):
+class Snelson(_DataParallel, Model):
     """
     Sparse GP regression with pseudo-inputs, Snelson & Ghahramani 2005 (reference gpr/model.py:485-576): the FITC marginal likelihood
         p = log N(y | 0, Qff + diag(Kff - Qff) + sigma^2 I),   Qff = Kfu Kuu^-1 Kuf,
@@ -531,13 +540,6 @@ class Snelson(Model):
         if kernel.output_dims is not None:
             self.Z.num_parameters -= self.Z().shape[0]
 
-    def _device_handle(self):
-        if self._handle is None:
-            from .._lib import ExactHandle
-            y = self.y if self.mean is None else self.y - np.asarray(self.mean(self.X)).reshape(-1, 1)
-            self._handle = ExactHandle(config.device, self.kernel._kernel_format(self.X), y, self.kernel._channels())
-        return self._handle
-
     def _noise_vector(self):
         """sigma_c^2 per channel (a scalar scale is shared by all channels: reference _index_channel, gpr/model.py:183-186)"""
         s = np.asarray(self.likelihood.scale(), dtype=np.float64)
@@ -554,7 +556,7 @@ class Snelson(Model):
         h.set_terms(table)
         Zk = self.kernel._kernel_format(self.Z())
         try:
-            res = h.snelson_eval(Zk, self._noise_vector(), self.jitter, self.kernel._spectral_diag(D), grad=grad)
+            res = h.snelson_eval(Zk, self._noise_vector(), self.jitter, self.kernel._spectral_diag(D), grad=grad, sharded=self._data_shard() is not None)
         except MogpError as e:
             if e.code in (MOGP_ENOTPD, MOGP_ENONFINITE):
                 print("ERROR:", str(e), file=sys.__stdout__)
@@ -603,7 +605,7 @@ class Snelson(Model):
         h.set_terms(self.kernel._spectral_terms(D))
         kd = self.kernel._spectral_diag(D)
         mu, var = h.snelson_predict(self.kernel._kernel_format(self.Z()), self._noise_vector(), self.jitter,
-                                    self.kernel._kernel_format(X), kd, kd)
+                                    self.kernel._kernel_format(X), kd, kd, sharded=self._data_shard() is not None)
         if self.mean is not None:
             mu = mu + np.asarray(self.mean(X)).reshape(-1, 1)
         return mu, var
@@ -689,7 +691,7 @@ class OpperArchambeau(Model):
         return mu, var
 
 
-class SparseHensman(Model):
+class SparseHensman(_DataParallel, Model):
     """
     Sparse variational GP of Hensman et al. 2015, whitened (reference gpr/model.py:767-878): q(u) = N(L q_mu, L S S^T L^T), L L^T = Kuu,
     S = tril(q_sqrt);  ELBO = E_q[log p(y | f)] - KL(q || p).  The O(N M^2) algebra runs on the device in two calls around the
@@ -719,27 +721,8 @@ class SparseHensman(Model):
         else:
             self.Z = Parameter(self.X, train=False)         # the data points themselves, not trained (reference :812)
 
-    def _data_shard(self):
-        """the communicator this process shards its training points over (mogptk_amd.use_distributed), or None; the non-sparse model lives
-        on all data points and is never sharded"""
-        comm = getattr(config, "comm", None)
-        if self.is_sparse and comm is not None and getattr(comm, "native", False) and (comm.world > 1 or comm.force):
-            return comm
-        return None
-
-    def _local(self, a):
-        """this rank's share of a per-point array: every world-th point starting at the rank (all of it without a communicator)"""
-        comm = self._data_shard()
-        return a if comm is None else a[comm.rank::comm.world]
-
-    def _device_handle(self):
-        comm = self._data_shard()
-        key = None if comm is None else (comm.rank, comm.world)
-        if self._handle is None or self.__dict__.get("_handle_key") != key:
-            from .._lib import ExactHandle
-            self._handle = ExactHandle(config.device, self._local(self.kernel._kernel_format(self.X)), self._local(self._y()), self.kernel._channels())
-            self.__dict__["_handle_key"] = key
-        return self._handle
+    def _shardable(self):
+        return self.is_sparse               # the non-sparse model lives on all data points
 
     def _reduce(self, value):
         """sum of a host scalar / small array over the ranks holding the other shards"""

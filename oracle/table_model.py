@@ -274,7 +274,7 @@ TableDevice.titsias_eval = titsias_eval
 TableDevice.titsias_predict = titsias_predict
 
 
-def snelson_eval(self, Z, noise_var, jitter, kff_diag, grad=True):
+def snelson_eval(self, Z, noise_var, jitter, kff_diag, grad=True, sharded=False):
     """numpy twin of mogp_snelson_eval -- reference gpr/model.py:516-541 (Snelson & Ghahramani's pseudo-input GP, FITC):
         g_n = Kff_nn - Qff_nn + sigma_c(n)^2,   p = log N(y | 0, Qff + diag g),   Qff = Kfu Kuu^-1 Kuf,
     and the adjoints the device contracts with the kernel derivatives (A = Kuu + jitter, B = Kuf, v = L^-1 B, G = diag 1/g,
@@ -284,6 +284,7 @@ def snelson_eval(self, Z, noise_var, jitter, kff_diag, grad=True):
     from scipy.linalg import solve_triangular
     X, y, table, C = self.X, self.y, self.table, self.C
     N, M, D = X.shape[0], Z.shape[0], self.D
+    red = _all_reduce(self, sharded)          # sharded (mogp_snelson_eval_sharded): this object holds one shard; sums over points all-reduced
     cz = Z[:, 0].astype(np.int64)
     cx = X[:, 0].astype(np.int64)
     noise_var = np.asarray(noise_var, dtype=np.float64).reshape(-1)
@@ -297,11 +298,12 @@ def snelson_eval(self, Z, noise_var, jitter, kff_diag, grad=True):
     g = np.asarray(kff_diag)[cx] - np.sum(v * v, axis=0) + s2
     G = 1.0 / g
     yv = y.reshape(-1)
-    Bq = (v * G) @ v.T + np.eye(M)
+    Bq = red((v * G) @ v.T) + np.eye(M)
     Lq = np.linalg.cholesky(Bq)
-    vGy = v @ (G * yv)
+    vGy = red(v @ (G * yv))
     c = solve_triangular(Lq, vGy, lower=True)
-    p = -0.5 * N * np.log(TWO_PI) - np.sum(np.log(np.diagonal(Lq))) - 0.5 * np.sum(np.log(g)) - 0.5 * np.sum(yv * yv * G) + 0.5 * c @ c
+    slg, yGy, Nt = red(np.array([np.sum(np.log(g)), np.sum(yv * yv * G), float(N)]))
+    p = -0.5 * Nt * np.log(TWO_PI) - np.sum(np.log(np.diagonal(Lq))) - 0.5 * slg - 0.5 * yGy + 0.5 * c @ c
     if not grad:
         return dict(lml=p, jitter_abs=jit)
     Lqi = solve_triangular(Lq, np.eye(M), lower=True)
@@ -314,11 +316,12 @@ def snelson_eval(self, Z, noise_var, jitter, kff_diag, grad=True):
     W = solve_triangular(Luu, np.eye(M), lower=True)
     beta = W.T @ r
     GB = W.T @ (np.outer(r, alpha) - R1 * G - 2.0 * v * h)
-    GA = 0.5 * W.T @ (np.eye(M) - Pq + 2.0 * (v * h) @ v.T) @ W - 0.5 * np.outer(beta, beta)
+    GA = 0.5 * W.T @ (np.eye(M) - Pq + 2.0 * red((v * h) @ v.T)) @ W - 0.5 * np.outer(beta, beta)
     GA = 0.5 * (GA + GA.T)
     mom_uu = moments_dense(table, GA, Z, Z, sym=True)
-    mom_uf = moments_dense(table, GB, Z, X, sym=False)
+    mom_uf = red(moments_dense(table, GB, Z, X, sym=False))
     gZ = np.zeros((M, D))
+    gZ_uu = np.zeros((M, D))
     for i in range(C):
         ri = np.nonzero(cz == i)[0]
         if len(ri) == 0:
@@ -329,12 +332,12 @@ def snelson_eval(self, Z, noise_var, jitter, kff_diag, grad=True):
                 gZ[ri] += np.einsum("nm,nmd->nd", GB[np.ix_(ri, rj)], _jr_block(table[i, j], Z[ri, 1:], X[rj, 1:]))
             zj = np.nonzero(cz == j)[0]
             if len(zj):
-                gZ[ri] += 2.0 * np.einsum("nm,nmd->nd", GA[np.ix_(ri, zj)], _jr_block(table[i, j], Z[ri, 1:], Z[zj, 1:]))
-    hsum = np.bincount(cx, weights=h, minlength=C)           # per channel: d p / d Kff_diag[c] = d p / d sigma_c^2
-    return dict(lml=p, jitter_abs=jit, mom_uu=mom_uu, mom_uf=mom_uf, gZ=gZ, trGA=float(np.trace(GA)), hsum=hsum)
+                gZ_uu[ri] += 2.0 * np.einsum("nm,nmd->nd", GA[np.ix_(ri, zj)], _jr_block(table[i, j], Z[ri, 1:], Z[zj, 1:]))
+    hsum = red(np.bincount(cx, weights=h, minlength=C).astype(np.float64))           # per channel: d p / d Kff_diag[c] = d p / d sigma_c^2
+    return dict(lml=p, jitter_abs=jit, mom_uu=mom_uu, mom_uf=mom_uf, gZ=red(gZ) + gZ_uu, trGA=float(np.trace(GA)), hsum=hsum)
 
 
-def snelson_predict(self, Z, noise_var, jitter, Xs, kff_diag, kss_diag):
+def snelson_predict(self, Z, noise_var, jitter, Xs, kff_diag, kss_diag, sharded=False):
     """reference gpr/model.py:543-576"""
     from scipy.linalg import solve_triangular
     X, y, table = self.X, self.y, self.table
@@ -347,10 +350,11 @@ def snelson_predict(self, Z, noise_var, jitter, Xs, kff_diag, kss_diag):
     Luu = np.linalg.cholesky(A)
     v = solve_triangular(Luu, gram_from_table(table, Z, X), lower=True)
     G = 1.0 / (np.asarray(kff_diag)[cx] - np.sum(v * v, axis=0) + s2)
-    Lq = np.linalg.cholesky((v * G) @ v.T + np.eye(M))
+    red = _all_reduce(self, sharded)
+    Lq = np.linalg.cholesky(red((v * G) @ v.T) + np.eye(M))
     a = solve_triangular(Luu, gram_from_table(table, Z, Xs), lower=True)
     b = solve_triangular(Lq, a, lower=True)
-    c = solve_triangular(Lq, v @ (G * y.reshape(-1)), lower=True)
+    c = solve_triangular(Lq, red(v @ (G * y.reshape(-1))), lower=True)
     mu = b.T @ c
     var = np.asarray(kss_diag)[Xs[:, 0].astype(np.int64)] - np.sum(a * a, axis=0) + np.sum(b * b, axis=0)
     return mu.reshape(-1, 1), var.reshape(-1, 1)

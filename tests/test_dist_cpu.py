@@ -117,9 +117,26 @@ TITSIAS_WORKER = textwrap.dedent('''
     perr = max(float(np.max(np.abs(mu1 - mu0))), float(np.max(np.abs(var1 - var0))))
     gpr.config.comm = None
     l2 = float(m.loss())                                  # and back: the handle is rebuilt on all points
+    # the Snelson (FITC) model of snelson.npz, case 0 (per-channel noise), the same way
+    fs = load("snelson.npz")
+    C, Q, Dm, _ = [int(v) for v in fs["c0_meta"]]
+    ks = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=Dm)
+    ms = gpr.Snelson(ks, fs["c0_X"], fs["c0_y"], Z=fs["c0_Z"], variance=(fs["c0_variance"] if fs["c0_variance"].ndim else float(fs["c0_variance"])), jitter=float(fs["c0_jitter"]))
+    fps = fixture_params(fs, "c0_")
+    load_raw(ms.parameters(), fps)
+    s0 = float(ms.loss()); sg0 = [None if p.grad is None else p.grad.copy() for p in ms.parameters()]
+    smu0, svar0 = ms.predict_f(fs["c0_Xs"])
+    gpr.config.comm = comm
+    s1 = float(ms.loss()); sg1 = [None if p.grad is None else p.grad.copy() for p in ms.parameters()]
+    smu1, svar1 = ms.predict_f(fs["c0_Xs"])
+    gpr.config.comm = None
+    serr = max(float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))) for a, b in zip(sg1, sg0) if b is not None)
+    sgold = max(float(np.max(np.abs(p.grad - f["grad"])) / max(1.0, np.max(np.abs(f["grad"])))) for p, f in zip(ms.parameters(), fps) if f["grad"] is not None)
+    sperr = max(float(np.max(np.abs(smu1 - smu0))), float(np.max(np.abs(svar1 - svar0))))
     if dist.get_rank() == 0:
         print(json.dumps(dict(l0=l0, l1=l1, l2=l2, err=err, gold=gold, perr=perr, n_local=n_local, n=int(fx[pre + "X"].shape[0]),
-                              world=dist.get_world_size(), ref=float(fx[pre + "loss"]))))
+                              world=dist.get_world_size(), ref=float(fx[pre + "loss"]),
+                              snelson=dict(l0=s0, l1=s1, err=serr, gold=sgold, perr=sperr, ref=float(fs["c0_loss"])))))
     dist.destroy_process_group()
 ''')
 
@@ -139,6 +156,9 @@ def test_data_parallel_titsias_gloo_ranks(tmp_path, ranks):
     assert abs(r["l1"] - r["l0"]) < 1e-10 * abs(r["l0"]) and r["err"] < 1e-9 and r["perr"] < 1e-9
     assert abs(r["l0"] - r["ref"]) < 1e-8 * abs(r["ref"]) and r["gold"] < 1e-6
     assert r["l2"] == r["l0"]
+    t = r["snelson"]                                      # the FITC model data-parallel (twin of mogp_snelson_eval_sharded / _predict_sharded)
+    assert abs(t["l1"] - t["l0"]) < 1e-10 * abs(t["l0"]) and t["err"] < 1e-9 and t["perr"] < 1e-9, t
+    assert abs(t["l0"] - t["ref"]) < 1e-8 * abs(t["ref"]) and t["gold"] < 1e-6, t
 
 
 SVGP_WORKER = textwrap.dedent('''

@@ -457,6 +457,7 @@ def test_sharded_eval_ranks_sharing_one_gpu(ranks):
     t = r["titsias"]                        # the sparse bound data-parallel (every rank holds every world-th point; sums over points all-reduced)
     assert t["rel_loss"] < 1e-10 and t["rel_grad"] < 1e-6 and t["rel_predict"] < 1e-7, t
     assert r["hensman"]["rel_loss"] < 1e-10 and r["hensman"]["rel_grad"] < 1e-6, r["hensman"]          # SparseHensman + Student-t, data-parallel
+    assert r["snelson"]["rel_loss"] < 1e-10 and r["snelson"]["rel_grad"] < 1e-6 and r["snelson"]["rel_predict"] < 1e-7, r["snelson"]
 
 
 def test_rccl_communicator_single_rank():
@@ -473,6 +474,7 @@ def test_rccl_communicator_single_rank():
     assert r["rel_loss"] < 1e-10 and r["rel_grad"] < 1e-7 and r["rel_predict"] < 1e-7, r
     assert r["titsias"]["rel_loss"] < 1e-10 and r["titsias"]["rel_grad"] < 1e-6 and r["titsias"]["rel_predict"] < 1e-7, r["titsias"]
     assert r["hensman"]["rel_loss"] < 1e-10 and r["hensman"]["rel_grad"] < 1e-6, r["hensman"]
+    assert r["snelson"]["rel_loss"] < 1e-10 and r["snelson"]["rel_grad"] < 1e-6 and r["snelson"]["rel_predict"] < 1e-7, r["snelson"]
 
 
 def test_sgd_adagrad_error_path_and_pegging_on_device():

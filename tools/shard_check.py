@@ -128,7 +128,25 @@ ht_shard = (time.perf_counter() - t) / a.reps
 mogptk_amd.use_single_device()
 herr = max(float(np.max(np.abs(b - c)) / max(1e-300, np.max(np.abs(c)))) for b, c in zip(hg1, hg0))
 
-errs = torch.tensor([abs(l1 - l0) / abs(l0), err, perr, abs(tl1 - tl0) / abs(tl0), terr, tperr, abs(hl1 - hl0) / abs(hl0), herr], dtype=torch.float64)
+# the FITC (Snelson) model, data-parallel the same way (mogp_snelson_eval_sharded / _predict_sharded)
+kn = gpr.MultiOutputSpectralMixtureKernel(Q=a.q, output_dims=a.channels)
+for name in ("weight", "mean", "variance", "delay", "phase"):
+    getattr(kn, name).assign(h[name])
+mn = gpr.Snelson(kn, Xt, yt, Z=a.inducing, variance=list(np.asarray(h["scale"]) ** 2), jitter=1e-6)
+nl0 = float(mn.loss())
+ng0 = [p.grad.copy() for p in mn.parameters()]
+nmu0, nvar0 = mn.predict_f(Xs)
+comm = mogptk_amd.use_distributed()
+comm.force = True
+nl1 = float(mn.loss())
+ng1 = [p.grad.copy() for p in mn.parameters()]
+nmu1, nvar1 = mn.predict_f(Xs)
+mogptk_amd.use_single_device()
+nerr = max(float(np.max(np.abs(b - c)) / max(1e-300, np.max(np.abs(c)))) for b, c in zip(ng1, ng0))
+nperr = max(float(np.max(np.abs(nmu1 - nmu0)) / np.max(np.abs(nmu0))), float(np.max(np.abs(nvar1 - nvar0)) / np.max(np.abs(nvar0))))
+
+errs = torch.tensor([abs(l1 - l0) / abs(l0), err, perr, abs(tl1 - tl0) / abs(tl0), terr, tperr, abs(hl1 - hl0) / abs(hl0), herr,
+                     abs(nl1 - nl0) / abs(nl0), nerr, nperr], dtype=torch.float64)
 if a.backend == "nccl":
     errs = errs.cuda()
 dist.all_reduce(errs, op=dist.ReduceOp.MAX)
@@ -138,6 +156,7 @@ if rank == 0:
                           titsias=dict(N=a.titsias_points, M=int(mt.Z().shape[0]), loss=tl0, rel_loss=float(errs[3]), rel_grad=float(errs[4]),
                                        rel_predict=float(errs[5]), ms_single=1e3 * tt_single, ms_sharded=1e3 * tt_shard),
                           hensman=dict(N=a.titsias_points, M=int(Mh), likelihood="StudentT", loss=hl0, rel_loss=float(errs[6]), rel_grad=float(errs[7]),
-                                       ms_single=1e3 * ht_single, ms_sharded=1e3 * ht_shard))))
+                                       ms_single=1e3 * ht_single, ms_sharded=1e3 * ht_shard),
+                          snelson=dict(loss=nl0, rel_loss=float(errs[8]), rel_grad=float(errs[9]), rel_predict=float(errs[10])))))
 mogptk_amd.shutdown_distributed()
 dist.destroy_process_group()
