@@ -132,6 +132,8 @@ struct TitsiasWork {
     DevBuf<double> zero_col;                            // Mpad zeros
     DevBuf<double> kslices;                             // split-K partial sums of the Qs SYRK (ks x Mpad x Mpad)
     DevBuf<double> red;                                 // data-sharded evaluation: [v y | y^T y, N, sum K_ff,nn] for the all-reduce
+    const double* Wq = nullptr;                         // L_q^-1 of the inner M x M system (where spd_invert left it)
+    hipEvent_t side_ev[2] = {nullptr, nullptr};         // fork / join of the M x M adjoint chain on a side stream (side_fork / side_join)
     // svgp.hip: what the forward pass at the training inputs leaves for the backward pass
     SortedX sv_sz; std::vector<GTile> sv_tuu, sv_tuf; std::vector<int> sv_psuu, sv_psuf; int64_t sv_M = 0; bool sv_dense = false, sv_valid = false;
     DevBuf<double> nvec;                                // Snelson: per-point vectors (g, G, G y, sqrt G, v^T r / w, alpha, h) + per-channel inputs
@@ -143,6 +145,7 @@ struct TitsiasWork {
         vec.release(); scratch.release(); gz.release(); partial_uu.release(); partial_uf.release(); mom_uu.release(); mom_uf.release();
         zero_noise.release(); tiles_uu.release(); tiles_uf.release(); ps_uu.release(); ps_uf.release();
         Kus.release(); Aus.release(); Bus.release(); zero_col.release(); kslices.release(); nvec.release(); red.release();
+        for (auto& e : side_ev) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
     }
 };
 
@@ -240,7 +243,17 @@ inline GemmArgs make_gemm(const double* A, int64_t lda, int akm, const double* B
     g.alpha = alpha; g.beta = 0.0; g.mode = mode; g.mt = mt; g.nt = nt; g.K = (int)K;
     return g;
 }
-int spd_check_info(mogp_model* m, const char* which, int64_t* info);   // the pivot report of the last factorisation -> MOGP_ENOTPD naming `which`
+// The M x M part of a sparse model's backward pass (two triangular solves with 2 nb dependent, nearly empty launches: ~3 ms at M = 2048) depends
+// only on M x M inputs; side_fork returns a second stream that starts behind everything enqueued on m->st so far, side_join makes m->st wait
+// for it -- the chain then runs underneath the M x N work instead of in front of it.  MOGP_SIDE_STREAM=0: everything on m->st.
+int side_fork(mogp_model* m, TitsiasWork& t, hipStream_t* side);
+int side_join(mogp_model* m, TitsiasWork& t, hipStream_t side);
+int spd_check_info(mogp_model* m, const char* which, int64_t* info);
+// w.A (SPD, lower tiles) -> w.B = its inverse (lower tiles, full diagonal tiles) and *W = L^-1 (lower; in w.A, or in w.Wm on the fused path),
+// w.logdet per tile: POTRF, TRTRI, LAUUM.  MOGP_SPARSE_FUSED=1 takes the fused factorisation + inversion schedule of the exact path
+// (potri.hip) instead -- measured SLOWER for the 16-tile-row systems of configs[4] (52.0 vs 49.9 ms per evaluation: four outer blocks give
+// its streams nothing to overlap), kept as a switch.  A failed factorisation is reported through `info` / MOGP_ENOTPD naming `which`.
+int spd_invert(mogp_model* m, Spd& w, const char* which, int64_t* info, const double** W);   // the pivot report of the last factorisation -> MOGP_ENOTPD naming `which`
 // out (Mpad x Mpad, lower tiles) = alpha A B^T over K (leading dimension ldk), K cut into slices so that the launch fills the chip
 int mm_lower_splitk(mogp_model* m, TitsiasWork& t, const double* A, const double* B, double* out, int mt, int64_t Mpad, int64_t ldk, int64_t K,
                     double alpha = 1.0);

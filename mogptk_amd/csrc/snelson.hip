@@ -89,7 +89,7 @@ struct SnScalars { double logdet_q, sumlogg, yGy, rvGy, jit, ntot; };
 
 
 // Front end shared by the evaluation and the prediction: everything up to r = Pq (v G y) and the scalars of p.
-// On return: t.a = L (Kuu), t.v = v, t.q.A = Wq = Lq^-1, t.q.B = Pq (full), t.Qs = Bq (full), t.nvec = [g | G | Gy | sqrt G | ...],
+// On return: t.a = L (Kuu), t.v = v, t.Wq = Lq^-1, t.q.B = Pq (full), t.Qs = Bq (full), t.nvec = [g | G | Gy | sqrt G | ...],
 // t.vec[0:Mpad] = v G y, t.vec[Mpad:2Mpad] = r.
 // sharded: this handle holds ONE SHARD of the training points (cf. mogp_titsias_eval_sharded): v G v^T, v G y, sum log g, y^T G y and N are
 // all-reduced (and the per-point positivity check with them, so that every rank takes the same exit).
@@ -207,10 +207,7 @@ int snelson_front(mogp_model* m, int64_t M, const double* Z, const double* noise
     RC(launch_add_diag(t.q.A.p, Mpad, Mpad, 1.0, m->st));
     HIP_TRY(hipMemcpyAsync(t.Qs.p, t.q.A.p, (size_t)Mpad * Mpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->d_info.p, &big, sizeof(big), hipMemcpyHostToDevice, m->st));
-    RC(spd_potrf(m, t.q));
-    RC(spd_check_info(m, "v G v^T + I", info));
-    RC(spd_trtri(m, t.q));                                                      // t.q.A = Wq
-    RC(spd_lauum(m, t.q));                                                      // t.q.B = Pq (lower)
+    RC(spd_invert(m, t.q, "v G v^T + I", info, &t.Wq));                         // t.Wq = Lq^-1, t.q.B = Pq (lower)
     RC(launch_symmetrize(t.q.B.p, Mpad, Mpad, m->st));
     RC(launch_symmetrize(t.Qs.p, Mpad, Mpad, m->st));
     double* r = t.vec.p + Mpad;
@@ -281,6 +278,21 @@ int snelson_eval_impl(mogp_model* m, int64_t M, const double* Z, const double* n
     hipLaunchKernelGGL(k_sn_h, gn, dim3(256), 0, m->st, G, alpha, vtr, N, Npad, h);
     hipLaunchKernelGGL(k_sn_adjoint, gmn, dim3(256), 0, m->st, t.GB.p, t.v.p, Npad, Npad, r, alpha, G, h);
     HIP_TRY(hipGetLastError());
+    // E = I - Pq + 2 (v diag h) v^T;  GA = 1/2 L^-T E L^-1 (the - 1/2 beta beta^T goes through the moment kernel's rank-one term).  The M x M x N
+    // product first (it needs the whole chip); the two M x M solves behind it go to the side stream, underneath the M x N solve below
+    hipLaunchKernelGGL(k_scale_cols, gmn, dim3(256), 0, m->st, t.v.p, t.B.p, Npad, Npad, h);
+    HIP_TRY(hipGetLastError());
+    RC(mm_lower_splitk(m, t, t.B.p, t.v.p, t.R.p, mt, Mpad, Npad, Npad));
+    if (sharded) RC(comm_allreduce(m->ctx, t.R.p, Mpad * Mpad, m->st));
+    RC(launch_symmetrize(t.R.p, Mpad, Mpad, m->st));
+    hipStream_t side;
+    RC(side_fork(m, t, &side));
+    RC(launch_combine(t.E.p, t.q.B.p, t.R.p, Mpad, Mpad, 1.0, 1.0, -2.0, side));
+    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.E.p, Mpad, Mpad, true, side));
+    RC(launch_transpose(t.GA.p, t.E.p, Mpad, Mpad, side));
+    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.GA.p, Mpad, Mpad, true, side));
+    RC(launch_sym_lower_avg(t.GA.p, Mpad, Mpad, 0.5, side));
+    RC(launch_get_diag(t.GA.p, Mpad, Mpad, dga, side));
     // GB = L^-T T, with beta = L^-T r riding along (padding column, or a panel of its own)
     const bool ride = Npad > N;
     if (ride) RC(launch_copy2d(t.GB.p + N, Npad, r, 1, Mpad, 1, 1.0, m->st));
@@ -295,18 +307,6 @@ int snelson_eval_impl(mogp_model* m, int64_t M, const double* Z, const double* n
         RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.Hm.p, MOGP_TILE, MOGP_TILE, true));
         RC(launch_copy2d(beta, 1, t.Hm.p, MOGP_TILE, Mpad, 1, 1.0, m->st));
     }
-    // E = I - Pq + 2 (v diag h) v^T;  GA = 1/2 L^-T E L^-1 (the - 1/2 beta beta^T goes through the moment kernel's rank-one term)
-    hipLaunchKernelGGL(k_scale_cols, gmn, dim3(256), 0, m->st, t.v.p, t.B.p, Npad, Npad, h);
-    HIP_TRY(hipGetLastError());
-    RC(mm_lower_splitk(m, t, t.B.p, t.v.p, t.R.p, mt, Mpad, Npad, Npad));
-    if (sharded) RC(comm_allreduce(m->ctx, t.R.p, Mpad * Mpad, m->st));
-    RC(launch_symmetrize(t.R.p, Mpad, Mpad, m->st));
-    RC(launch_combine(t.E.p, t.q.B.p, t.R.p, Mpad, Mpad, 1.0, 1.0, -2.0, m->st));
-    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.E.p, Mpad, Mpad, true));
-    RC(launch_transpose(t.GA.p, t.E.p, Mpad, Mpad, m->st));
-    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.GA.p, Mpad, Mpad, true));
-    RC(launch_sym_lower_avg(t.GA.p, Mpad, Mpad, 0.5, m->st));
-    RC(launch_get_diag(t.GA.p, Mpad, Mpad, dga, m->st));
     HIP_TRY(hipMemsetAsync(t.gz.p, 0, (size_t)D * Mpad * sizeof(double), m->st));
 
     MomentArgs ma{};
@@ -322,6 +322,7 @@ int snelson_eval_impl(mogp_model* m, int64_t M, const double* Z, const double* n
         RC(comm_allreduce(m->ctx, t.mom_uf.p, (int64_t)C * C * T * W, m->st));
         RC(comm_allreduce(m->ctx, t.gz.p, (int64_t)D * Mpad, m->st));
     }
+    RC(side_join(m, t, side));
     ma.tiles = t.tiles_uu.p; ma.ntiles = (int)tuu.size(); ma.xc = nullptr; ma.ldxc = 0; ma.ncols = M;
     RC(t.ph_zz.prepare(sz.off, sz.off, C, T, Mpad, Mpad, m->st, ma.ph));
     ma.G = t.GA.p; ma.ldg = Mpad; ma.ru = beta; ma.rw = beta; ma.rcoef = -0.5; ma.sym = 1;
@@ -421,11 +422,11 @@ int snelson_predict_impl(mogp_model* m, int64_t M, const double* Z, const double
     RC(launch_gram(ga, (int)tus.size(), m->st));
     HIP_TRY(hipMemcpyAsync(t.Aus.p, t.Kus.p, (size_t)Mpad * Spad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.Aus.p, Spad, Spad, false));                                      // a = L^-1 Kus
-    GemmArgs g = make_gemm(t.q.A.p, Mpad, 0, t.Aus.p, Spad, 1, t.Bus.p, Spad, 1.0, GM_KHI_I, mt, st, Mpad);      // b = Lq^-1 a
+    GemmArgs g = make_gemm(t.Wq, Mpad, 0, t.Aus.p, Spad, 1, t.Bus.p, Spad, 1.0, GM_KHI_I, mt, st, Mpad);          // b = Lq^-1 a
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
     double* vGy = t.vec.p;
     double* cvec = t.vec.p + 4 * Mpad;
-    RC(launch_trmv_lower(t.q.A.p, Mpad, Mpad, vGy, cvec, t.vec.p + 6 * Mpad, m->st));                      // c = Lq^-1 v G y
+    RC(launch_trmv_lower(t.Wq, Mpad, Mpad, vGy, cvec, t.vec.p + 6 * Mpad, m->st));                         // c = Lq^-1 v G y
     RC(launch_gemv_cols(t.Bus.p, Spad, Mpad, Spad, cvec, m->d_mu.p, t.scratch.p, m->st));                  // mu = b^T c
     RC(launch_gemv_cols(t.Aus.p, Spad, Mpad, Spad, nullptr, m->d_var.p, t.scratch.p, m->st));
     RC(launch_gemv_cols(t.Bus.p, Spad, Mpad, Spad, nullptr, m->d_var.p + Spad, t.scratch.p, m->st));

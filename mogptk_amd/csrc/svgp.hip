@@ -248,11 +248,13 @@ static int svgp_backward_impl(mogp_model* m, const double* e, const double* f, d
     RC(mm_lower_splitk(m, t, dense ? t.v.p : t.B.p, dense ? t.B.p : t.v.p, t.E.p, mt, Mpad, Npad, Npad));
     if (sharded) RC(comm_allreduce(m->ctx, t.E.p, Mpad * Mpad, m->st));
     RC(launch_symmetrize(t.E.p, Mpad, Mpad, m->st));
-    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.E.p, Mpad, Mpad, true));
-    RC(launch_transpose(t.GA.p, t.E.p, Mpad, Mpad, m->st));
-    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.GA.p, Mpad, Mpad, true));
-    RC(launch_sym_lower_avg(t.GA.p, Mpad, Mpad, dense ? 0.5 : -0.5, m->st));
-    RC(launch_get_diag(t.GA.p, Mpad, Mpad, dga, m->st));
+    hipStream_t side;                              // the two M x M solves: on the side stream, underneath the M x N work below
+    RC(side_fork(m, t, &side));
+    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.E.p, Mpad, Mpad, true, side));
+    RC(launch_transpose(t.GA.p, t.E.p, Mpad, Mpad, side));
+    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.GA.p, Mpad, Mpad, true, side));
+    RC(launch_sym_lower_avg(t.GA.p, Mpad, Mpad, dense ? 0.5 : -0.5, side));
+    RC(launch_get_diag(t.GA.p, Mpad, Mpad, dga, side));
     // dE/dS = 2 (v diag(f) v^T) S: (v f) into t.GB (b is no longer needed), the M x M product into t.Qs, times S into t.q.A
     hipLaunchKernelGGL(k_sv_scale_cols, gmn, dim3(256), 0, m->st, t.v.p, t.GB.p, Npad, Npad, df);
     HIP_TRY(hipGetLastError());
@@ -283,6 +285,7 @@ static int svgp_backward_impl(mogp_model* m, const double* e, const double* f, d
     } else {
         HIP_TRY(hipMemsetAsync(t.mom_uf.p, 0, (size_t)C * C * T * W * sizeof(double), m->st));
     }
+    RC(side_join(m, t, side));
     ma.tiles = t.tiles_uu.p; ma.ntiles = (int)t.sv_tuu.size(); ma.xc = nullptr; ma.ldxc = 0; ma.ncols = M;
     RC(t.ph_zz.prepare(sz.off, sz.off, C, T, Mpad, Mpad, m->st, ma.ph));
     ma.G = t.GA.p; ma.ldg = Mpad; ma.ru = q; ma.rw = q; ma.rcoef = 0.0; ma.sym = 1;

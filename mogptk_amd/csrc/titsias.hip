@@ -14,6 +14,7 @@
 #include "mogp_model.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -28,6 +29,41 @@ using namespace mogp;
 
 
 namespace mogp {
+
+int side_fork(mogp_model* m, TitsiasWork& t, hipStream_t* side) {
+    static const bool on = !(std::getenv("MOGP_SIDE_STREAM") && std::atoi(std::getenv("MOGP_SIDE_STREAM")) == 0);
+    *side = m->st;
+    if (!on || !m->st3) return 0;
+    for (auto& e : t.side_ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(t.side_ev[0], m->st));
+    HIP_TRY(hipStreamWaitEvent(m->st3, t.side_ev[0], 0));
+    *side = m->st3;
+    return 0;
+}
+
+int side_join(mogp_model* m, TitsiasWork& t, hipStream_t side) {
+    if (side == m->st) return 0;
+    HIP_TRY(hipEventRecord(t.side_ev[1], side));
+    HIP_TRY(hipStreamWaitEvent(m->st, t.side_ev[1], 0));
+    return 0;
+}
+
+int spd_invert(mogp_model* m, Spd& w, const char* which, int64_t* info, const double** W) {
+    static const bool fused = std::getenv("MOGP_SPARSE_FUSED") && std::atoi(std::getenv("MOGP_SPARSE_FUSED")) != 0;
+    if (fused && w.nb <= 80) {
+        RC(spd_potri_fused(m, w));
+        RC(spd_potri_fused_finish(m, w));
+        RC(spd_check_info(m, which, info));
+        *W = w.Wm.p;
+        return 0;
+    }
+    RC(spd_potrf(m, w));
+    RC(spd_check_info(m, which, info));
+    RC(spd_trtri(m, w));                                                        // w.A = L^-1
+    RC(spd_lauum(m, w));                                                        // w.B = inverse (lower)
+    *W = w.A.p;
+    return 0;
+}
 
 int spd_check_info(mogp_model* m, const char* which, int64_t* info) {
     unsigned long long hinfo = 0;
@@ -132,15 +168,19 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     ga.noise = t.zero_noise.p; ga.dvar = nullptr; ga.jitter_abs = sc.jit; ga.mirror = 0;
     RC(launch_gram(ga, (int)tuu.size(), m->st));
     RC(launch_pad_identity(t.a.A.p, Mpad, M, Mpad, m->st));
+    // Kuf and its working copy on the side stream, underneath the (chain-bound) factorisation of Kuu
+    hipStream_t side;
+    RC(side_fork(m, t, &side));
     ga.tiles = t.tiles_uf.p; ga.xc = m->d_x.p; ga.ldxc = Npad; ga.ncols = m->N; ga.out = t.B.p; ga.ldo = Npad; ga.noise = nullptr; ga.jitter_abs = 0.0;
-    RC(t.ph_zx.prepare(sz.off, m->sx.off, C, m->T, Mpad, Npad, m->st, ga.ph));
-    RC(launch_gram(ga, (int)tuf.size(), m->st));
+    RC(t.ph_zx.prepare(sz.off, m->sx.off, C, m->T, Mpad, Npad, side, ga.ph));
+    RC(launch_gram(ga, (int)tuf.size(), side));
+    HIP_TRY(hipMemcpyAsync(t.v.p, t.B.p, (size_t)Mpad * Npad * sizeof(double), hipMemcpyDeviceToDevice, side));
 
     t.a.keep_L = true;                                                          // the solves below need L itself, diagonal tiles included
     RC(spd_potrf(m, t.a));
     RC(spd_check_info(m, "Kuu", info));
     const double s2 = sigma * sigma;
-    HIP_TRY(hipMemcpyAsync(t.v.p, t.B.p, (size_t)Mpad * Npad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
+    RC(side_join(m, t, side));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.v.p, Npad, Npad, false));              // v = L^-1 B   (reference gpr/model.py:711)
     (void)nt;
     // Qs = v v^T / s2 + I
@@ -167,10 +207,7 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     RC(launch_add_diag(t.q.A.p, Mpad, Mpad, 1.0, m->st));
     HIP_TRY(hipMemcpyAsync(t.Qs.p, t.q.A.p, (size_t)Mpad * Mpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->d_info.p, &big, sizeof(big), hipMemcpyHostToDevice, m->st));
-    RC(spd_potrf(m, t.q));
-    RC(spd_check_info(m, "Q/sigma^2 + I", info));
-    RC(spd_trtri(m, t.q));                                                      // t.q.A = Wq
-    RC(spd_lauum(m, t.q));                                                      // t.q.B = Pq (lower)
+    RC(spd_invert(m, t.q, "Q/sigma^2 + I", info, &t.Wq));                       // t.Wq = Lq^-1, t.q.B = Pq (lower)
     RC(launch_symmetrize(t.q.B.p, Mpad, Mpad, m->st));
     double* t1 = t.vec.p + Mpad;
     double* dg = t.vec.p + 2 * Mpad;                                            // diag Pq, diag Qs
@@ -244,6 +281,16 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
     double* dga = t.vec.p + 2 * Mpad;             // reuse: diag of GA
     double* btb = t.vec.p + 8 * Mpad;             // [Npad]
     double* r = btb + Npad;                       // [Npad]
+    // GA = 1/2 L^-T E L^-1 (symmetric), E = 2I - Pq - Qs: T1 = L^-T E in place, then L^-T T1^T, then the lower triangle of the symmetrised half.
+    // M x M only: on the side stream, underneath the M x N work below
+    hipStream_t side;
+    RC(side_fork(m, t, &side));
+    RC(launch_combine(t.E.p, t.q.B.p, t.Qs.p, Mpad, Mpad, 2.0, 1.0, 1.0, side));
+    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.E.p, Mpad, Mpad, true, side));
+    RC(launch_transpose(t.GA.p, t.E.p, Mpad, Mpad, side));
+    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.GA.p, Mpad, Mpad, true, side));
+    RC(launch_sym_lower_avg(t.GA.p, Mpad, Mpad, 0.5, side));
+    RC(launch_get_diag(t.GA.p, Mpad, Mpad, dga, side));
     // GB = L^-T (R v) / s2, and beta = L^-T t1 riding along: when N is not a multiple of 128 the right-hand side has zero padding columns,
     // and t1 travels through the blocked solve in the first of them (a vector solve of its own is 2 nb dependent, almost empty launches)
     RC(launch_combine(t.R.p, t.q.B.p, nullptr, Mpad, Mpad, 1.0, 1.0, 0.0, m->st));           // R = I - Pq
@@ -262,15 +309,8 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
         RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.Hm.p, MOGP_TILE, MOGP_TILE, true));
         RC(launch_copy2d(beta, 1, t.Hm.p, MOGP_TILE, Mpad, 1, 1.0, m->st));
     }
-    RC(launch_combine(t.E.p, t.q.B.p, t.Qs.p, Mpad, Mpad, 2.0, 1.0, 1.0, m->st));            // E = 2I - Pq - Qs
-    // GA = 1/2 L^-T E L^-1 (symmetric): T1 = L^-T E in place, then L^-T T1^T, then the lower triangle of the symmetrised half
-    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.E.p, Mpad, Mpad, true));
-    RC(launch_transpose(t.GA.p, t.E.p, Mpad, Mpad, m->st));
-    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.GA.p, Mpad, Mpad, true));
-    RC(launch_sym_lower_avg(t.GA.p, Mpad, Mpad, 0.5, m->st));
     RC(launch_gemv_cols(t.B.p, Npad, Mpad, Npad, beta, btb, t.scratch.p, m->st));                           // B^T beta
     RC(launch_axpby(Npad, 1.0 / (s2 * s2), m->d_y.p, -1.0 / (s2 * s2 * s2), btb, r, m->st));
-    RC(launch_get_diag(t.GA.p, Mpad, Mpad, dga, m->st));
     HIP_TRY(hipMemsetAsync(t.gz.p, 0, (size_t)D * Mpad * sizeof(double), m->st));
 
     MomentArgs ma{};
@@ -286,6 +326,7 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
         RC(comm_allreduce(m->ctx, t.mom_uf.p, (int64_t)C * C * T * W, m->st));
         RC(comm_allreduce(m->ctx, t.gz.p, (int64_t)D * Mpad, m->st));
     }
+    RC(side_join(m, t, side));
     ma.tiles = t.tiles_uu.p; ma.ntiles = (int)tuu.size(); ma.xc = nullptr; ma.ldxc = 0; ma.ncols = M;
     RC(t.ph_zz.prepare(sz.off, sz.off, C, T, Mpad, Mpad, m->st, ma.ph));
     ma.G = t.GA.p; ma.ldg = Mpad; ma.ru = beta; ma.rw = beta; ma.rcoef = -0.5 / (s2 * s2); ma.sym = 1;
@@ -369,11 +410,11 @@ static int titsias_predict_impl(mogp_model* m, int64_t M, const double* Z, doubl
     RC(launch_gram(ga, (int)tus.size(), m->st));
     HIP_TRY(hipMemcpyAsync(t.Aus.p, t.Kus.p, (size_t)Mpad * Spad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.Aus.p, Spad, Spad, false));                                      // a = L^-1 Kus
-    GemmArgs g = make_gemm(t.q.A.p, Mpad, 0, t.Aus.p, Spad, 1, t.Bus.p, Spad, 1.0, GM_KHI_I, mt, st, Mpad);                // b = Wq a
+    GemmArgs g = make_gemm(t.Wq, Mpad, 0, t.Aus.p, Spad, 1, t.Bus.p, Spad, 1.0, GM_KHI_I, mt, st, Mpad);                    // b = Wq a
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
     double* vy = t.vec.p;
     double* cvec = t.vec.p + 4 * Mpad;
-    RC(launch_trmv_lower(t.q.A.p, Mpad, Mpad, vy, cvec, t.vec.p + 6 * Mpad, m->st));                          // c s2 = Wq vy
+    RC(launch_trmv_lower(t.Wq, Mpad, Mpad, vy, cvec, t.vec.p + 6 * Mpad, m->st));                             // c s2 = Wq vy
     RC(launch_gemv_cols(t.Bus.p, Spad, Mpad, Spad, cvec, m->d_mu.p, t.scratch.p, m->st));                    // mu s2 = b^T (Wq vy)
     RC(launch_gemv_cols(t.Aus.p, Spad, Mpad, Spad, nullptr, m->d_var.p, t.scratch.p, m->st));               // colsum a^2
     RC(launch_gemv_cols(t.Bus.p, Spad, Mpad, Spad, nullptr, m->d_var.p + Spad, t.scratch.p, m->st));        // colsum b^2
