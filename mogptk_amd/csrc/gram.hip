@@ -349,9 +349,14 @@ __device__ __forceinline__ void gram_store(const GramArgs& a, const GTile& tl, c
     if (full) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            double* o = a.out + (int64_t)(tl.r0 + rg * 4 + m) * a.ldo + tl.c0 + cg * 4;
+            const int64_t at = (int64_t)(tl.r0 + rg * 4 + m) * a.ldo + tl.c0 + cg * 4;
+            double* o = a.out + at;
             *reinterpret_cast<d2_t*>(o) = (d2_t){acc[m][0], acc[m][1]};
             *reinterpret_cast<d2_t*>(o + 2) = (d2_t){acc[m][2], acc[m][3]};
+            if (a.out2) {
+                *reinterpret_cast<d2_t*>(a.out2 + at) = (d2_t){acc[m][0], acc[m][1]};
+                *reinterpret_cast<d2_t*>(a.out2 + at + 2) = (d2_t){acc[m][2], acc[m][3]};
+            }
         }
         if (a.mirror && (tl.flags & GT_MIRROR)) {
 #pragma unroll
@@ -378,6 +383,7 @@ __device__ __forceinline__ void gram_store(const GramArgs& a, const GTile& tl, c
                 if (a.dvar != nullptr) v += a.dvar[r];
             }
             a.out[r * a.ldo + c] = v;
+            if (a.out2) a.out2[r * a.ldo + c] = v;
             if (a.mirror && ((tl.flags & GT_MIRROR) || ((tl.flags & GT_DIAG) && lr > lc))) a.out[c * a.ldo + r] = v;
         }
     }
@@ -694,7 +700,7 @@ int launch_gram(const GramArgs& a0, int ntiles, hipStream_t s) {
     const size_t dyn = a.tab_lds ? tab_bytes : 0;
     if (a.ev0) HIP_TRY(hipEventRecord(a.ev0, s));
     static const bool strip_on = !(std::getenv("MOGP_GRAM_STRIP") && std::atoi(std::getenv("MOGP_GRAM_STRIP")) == 0);
-    if (strip_on && a.segs && a.nsegs > 0 && a.D == 1 && a.W == 5 && a.T <= GS_TC_MAX && !a.mirror && (a.ldo & 1) == 0) {
+    if (strip_on && a.segs && a.nsegs > 0 && a.D == 1 && a.W == 5 && a.T <= GS_TC_MAX && !a.mirror && !a.out2 && (a.ldo & 1) == 0) {
         if (a.T <= 4) hipLaunchKernelGGL(k_gram_strip<4>, dim3(a.nsegs), dim3(256), 0, s, a, a.segs);
         else hipLaunchKernelGGL(k_gram_strip<8>, dim3(a.nsegs), dim3(256), 0, s, a, a.segs);
         if (a.nrest > 0) {

@@ -56,6 +56,8 @@ struct GramArgs {
                            // ([.., L_d, c_d]: K *= exp(-1/2 sum_d L_d ((x_a,d + x_b,d)/2 - c_d)^2), MOHSM); 0 -> 2 + 3 D
     double* out;           // row-major, leading dimension ldo
     int64_t ldo;
+    double* out2;          // when non-null: a second copy of every stored element, same layout (rectangular Grams: K_uf and the working copy the
+                           // triangular solve overwrites, instead of a 1.6 GB device-to-device copy at configs[4])
     // diagonal augmentation (symmetric training Gram only; null -> none)
     const double* noise;   // [C] sigma_c^2
     const double* dvar;    // [N] per-point variance or null

@@ -67,6 +67,7 @@ int svgp_setup(mogp_model* m, int64_t M, const double* Z, const double* q_mu, co
         RC(spd_alloc(t.a, Mpad)); RC(spd_alloc(t.q, Mpad));
         RC(t.zx.ensure((size_t)D * Mpad));
         RC(t.B.ensure((size_t)Mpad * Npad)); RC(t.v.ensure((size_t)Mpad * Npad));
+        HIP_TRY(hipMemset(t.v.p, 0, (size_t)Mpad * Npad * sizeof(double)));      // its padding is zero from here on (titsias.hip relies on it)
         RC(t.Qs.ensure((size_t)Mpad * Mpad));
         RC(t.vec.ensure((size_t)8 * Mpad + 4 * Npad));
         RC(t.scratch.ensure((size_t)(Mpad / 256 + 2) * std::max(Npad, Mpad) + (size_t)(Mpad / 512 + 2) * Mpad));

@@ -138,6 +138,7 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
         RC(t.zero_noise.ensure(C));
         HIP_TRY(hipMemset(t.zero_noise.p, 0, C * sizeof(double)));
         HIP_TRY(hipMemset(t.B.p, 0, (size_t)Mpad * Npad * sizeof(double)));      // padding of Kuf stays zero: the Gram kernel never writes it
+        HIP_TRY(hipMemset(t.v.p, 0, (size_t)Mpad * Npad * sizeof(double)));      // ... nor that of its working copy (the solves keep zeros zero)
     }
     m->gemm_ev_used = 0; m->gemm_launches = 0; m->gemm_flops = 0.0;
     build_sym_tiles(sz.off, C, tuu, psuu);
@@ -172,9 +173,9 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     hipStream_t side;
     RC(side_fork(m, t, &side));
     ga.tiles = t.tiles_uf.p; ga.xc = m->d_x.p; ga.ldxc = Npad; ga.ncols = m->N; ga.out = t.B.p; ga.ldo = Npad; ga.noise = nullptr; ga.jitter_abs = 0.0;
+    ga.out2 = t.v.p;                                                            // the copy the solve below works in, written by the same kernel
     RC(t.ph_zx.prepare(sz.off, m->sx.off, C, m->T, Mpad, Npad, side, ga.ph));
     RC(launch_gram(ga, (int)tuf.size(), side));
-    HIP_TRY(hipMemcpyAsync(t.v.p, t.B.p, (size_t)Mpad * Npad * sizeof(double), hipMemcpyDeviceToDevice, side));
 
     t.a.keep_L = true;                                                          // the solves below need L itself, diagonal tiles included
     RC(spd_potrf(m, t.a));
