@@ -169,9 +169,10 @@ def aggregate_value(world, steps, dt, sharded=False):
     return (1 if sharded else world) * steps / dt
 
 
-def sharded_probe(m, dist, sync, world, cfg3=True, reps=5):
+def sharded_probe(m, dist, sync, world, cfg3=True, reps=5, out=None):
     """Extra, outside the timed region: the SAME evaluation sharded over all ranks (mogp_exact_eval_sharded) next
-    to the one-GPU evaluation, at the bench workload and at configs[2] (MOSM C=8 Q=5 N=32768).  Reported as `sharded`."""
+    to the one-GPU evaluation, at the bench workload and at configs[2] (MOSM C=8 Q=5 N=32768); and configs[4] data-parallel.  Reported as
+    `sharded`; `out` is filled entry by entry, so that a watchdog firing in a later entry still has the earlier ones."""
     import mogptk_amd
 
     def run(model, reps):
@@ -193,13 +194,11 @@ def sharded_probe(m, dist, sync, world, cfg3=True, reps=5):
         return dict(ms_one_gpu=1e3 * t_single, ms_sharded=1e3 * t_shard, speedup=t_single / t_shard, evals_per_s_sharded=1.0 / t_shard,
                     rel_loss=abs(l1 - l0) / abs(l0), rel_grad=err, transport=comm.transport)
 
-    out = {"ranks": world, "bench_workload": run(m, reps)}
+    if out is None:
+        out = {}
+    out["ranks"] = world
+    out["bench_workload"] = run(m, reps)
     if cfg3:
-        try:                                           # kept apart: a failure here must not cost the numbers above
-            m3 = build_mosm(32768, 8, 5, None)         # gpr.config.device is already this rank's GPU
-            out["cfg3_mosm_c8_q5_n32768"] = run(m3, 2)
-        except Exception as e:
-            out["cfg3_mosm_c8_q5_n32768"] = {"error": repr(e)}
         # the sparse bound (configs[4]) DATA-PARALLEL: every rank holds every world-th training point, the sums over points are all-reduced
         # inside the library (mogp_titsias_eval_sharded: M^2 + M + 3 doubles, then the (Z, X) moments); strong scaling at N = 100 000 and
         # weak scaling at 100 000 points per rank, each next to the one-GPU evaluation of the same model
@@ -213,6 +212,11 @@ def sharded_probe(m, dist, sync, world, cfg3=True, reps=5):
                 del m5
             except Exception as e:
                 out[tag] = {"error": repr(e)}
+        try:                                           # last: the largest exchange (one 134 MB all-gather per pivot block)
+            m3 = build_mosm(32768, 8, 5, None)         # gpr.config.device is already this rank's GPU
+            out["cfg3_mosm_c8_q5_n32768"] = run(m3, 2)
+        except Exception as e:
+            out["cfg3_mosm_c8_q5_n32768"] = {"error": repr(e)}
     return out
 
 
@@ -378,18 +382,19 @@ def main():
     want_probe = (world > 1 or a.shard_probe) and not a.no_shard_probe and kind == "exact" and not sharded_mode
     if want_probe:
         done = threading.Event()
+        sharded = {}
 
         def watchdog():
             if not done.wait(a.probe_timeout):
-                if out is not None:
-                    out["sharded"] = {"error": "the sharded probe did not finish within %.0f s (watchdog)" % a.probe_timeout}
+                if out is not None:                 # whatever entries were finished, plus the reason the rest is missing
+                    out["sharded"] = dict(sharded, error="the sharded probe did not finish within %.0f s (watchdog)" % a.probe_timeout)
                 emit()
                 os._exit(0)
         threading.Thread(target=watchdog, daemon=True).start()
         try:
-            sharded = sharded_probe(m, pd, sync, world, cfg3=not a.no_cfg3_probe)
+            sharded_probe(m, pd, sync, world, cfg3=not a.no_cfg3_probe, out=sharded)
         except Exception as e:              # symmetric across ranks (same code, same inputs); the measurement above stands
-            sharded = {"error": repr(e)}
+            sharded["error"] = repr(e)
         done.set()
         if out is not None:
             out["sharded"] = sharded
