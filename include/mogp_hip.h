@@ -253,6 +253,11 @@ int  mogp_oa_backward(mogp_model* m, const double* e, const double* f, double* m
 int  mogp_oa_predict(mogp_model* m, const double* q_nu, const double* q_lambda, const double* kss_diag, int64_t S, const double* Xs,
                      int full, double* mu, double* var, int64_t* info);
 
+/* Full predictive covariance of the sparse models (Titsias.predict_f / SparseHensman._predict_f with full=True, reference
+ * gpr/model.py:758-760, 870-872): K_ss - a^T a + b^T b for the S test points of the LAST mogp_titsias_predict(_sharded) or
+ * mogp_svgp_forward(S > 0) call on this handle (a = L^-1 K_us and b stay on the device), cov[S][S] in the caller's order. */
+int  mogp_sparse_predict_cov(mogp_model* m, int64_t S, double* cov);
+
 /* Host-side pair algebra of the MOSM kernel in native code (no device work): the cross-spectral term table of every channel pair
  * (reference gpr/multioutput.py:178-204) and the reverse-mode gradient autograd takes through it.
  * w (C,Q), mu / v / th (C,Q,D), ph (C,Q) are the CONSTRAINED weight, mean, variance, delay, phase; table is [C][C][Q][2+3D];

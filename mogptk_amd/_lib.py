@@ -91,6 +91,7 @@ SIGNATURES = {
     "mogp_oa_forward": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp, ctypes.POINTER(ctypes.c_double), c_i64p]),
     "mogp_oa_backward": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "mogp_oa_predict": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, c_dp, ctypes.c_int64, c_dp, ctypes.c_int, c_dp, c_dp, c_i64p]),
+    "mogp_sparse_predict_cov": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp]),
     "mogp_mosm_terms": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, ctypes.c_double, ctypes.c_double, c_dp]),
     "mogp_mosm_terms_backward": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, ctypes.c_double,
                                                 ctypes.c_double, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
@@ -412,6 +413,12 @@ class ExactHandle:
         check(lib().mogp_oa_predict(self._h, _dp(q_nu), _dp(q_lambda), _dp(kss_diag), S, _dp(Xs), 1 if full else 0, _dp(mu), _dp(var),
                                     ctypes.byref(info)), info.value)
         return mu.reshape(-1, 1), (var if full else var.reshape(-1, 1))
+
+    def sparse_predict_cov(self, S):
+        """full S x S covariance of the last sparse prediction on this handle (Titsias / Hensman), through mogp_sparse_predict_cov"""
+        cov = np.empty((int(S), int(S)))
+        check(lib().mogp_sparse_predict_cov(self._h, int(S), _dp(cov)))
+        return cov
 
     def set_profiling(self, on=True):
         check(lib().mogp_set_profiling(self._h, 1 if on else 0))

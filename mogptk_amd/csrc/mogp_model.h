@@ -133,6 +133,8 @@ struct TitsiasWork {
     DevBuf<double> kslices;                             // split-K partial sums of the Qs SYRK (ks x Mpad x Mpad)
     DevBuf<double> red;                                 // data-sharded evaluation: [v y | y^T y, N, sum K_ff,nn] for the all-reduce
     const double* Wq = nullptr;                         // L_q^-1 of the inner M x M system (where spd_invert left it)
+    SortedX pred_ss;                                    // the test inputs of the last sparse prediction (a = L^-1 Kus in Aus, b in Bus): what
+    bool pred_valid = false;                            // mogp_sparse_predict_cov needs for the full covariance K_ss - a^T a + b^T b
     hipEvent_t side_ev[2] = {nullptr, nullptr};         // fork / join of the M x M adjoint chain on a side stream (side_fork / side_join)
     // svgp.hip: what the forward pass at the training inputs leaves for the backward pass
     SortedX sv_sz; std::vector<GTile> sv_tuu, sv_tuf; std::vector<int> sv_psuu, sv_psuf; int64_t sv_M = 0; bool sv_dense = false, sv_valid = false;

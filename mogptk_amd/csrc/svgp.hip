@@ -147,6 +147,7 @@ int mogp_svgp_forward(mogp_model* m, int64_t M, const double* Z, const double* q
     std::vector<GTile> tuf;
     std::vector<int> psuf;
     if (!train) {
+        t.pred_valid = false;
         RC(sort_inputs(Xs, S, D, C, MOGP_TILE, ss));
         sp = &ss; Qpad = ss.Mpad; Qn = S;
         RC(t.Kus.ensure((size_t)Mpad * Qpad)); RC(t.Aus.ensure((size_t)Mpad * Qpad)); RC(t.Bus.ensure((size_t)Mpad * Qpad));
@@ -193,6 +194,8 @@ int mogp_svgp_forward(mogp_model* m, int64_t M, const double* Z, const double* q
     if (train) {
         t.sv_sz = sz; t.sv_tuu = tuu; t.sv_psuu = psuu; t.sv_tuf = tuf; t.sv_psuf = psuf;
         t.sv_M = M; t.sv_dense = dense != 0; t.sv_valid = true;
+    } else {
+        t.pred_ss = ss; t.pred_valid = true;             // a, b stay in t.Aus / t.Bus for mogp_sparse_predict_cov
     }
     return MOGP_OK;
 }

@@ -395,6 +395,7 @@ static int titsias_predict_impl(mogp_model* m, int64_t M, const double* Z, doubl
     const int64_t Mpad = t.Mpad;
     const double s2 = sigma * sigma;
     RC(sort_inputs(Xs, S, D, C, MOGP_TILE, ss));
+    t.pred_valid = false;
     const int64_t Spad = ss.Mpad;
     const int mt = (int)(Mpad / MOGP_TILE), st = (int)(Spad / MOGP_TILE);
     build_rect_tiles(sz.off, ss.off, C, tus);
@@ -428,5 +429,48 @@ static int titsias_predict_impl(mogp_model* m, int64_t M, const double* Z, doubl
             mu[ss.perm[pos]] = hmu[pos] / s2;
             var[ss.perm[pos]] = kss_diag[c] - hv[pos] + hv[Spad + pos];
         }
+    t.pred_ss = ss; t.pred_valid = true;
     return MOGP_OK;
 }
+
+extern "C" {
+
+// Full predictive covariance of the LAST sparse prediction on this handle (mogp_titsias_predict, mogp_svgp_forward at test inputs; their
+// sharded forms): K_ss - a^T a + b^T b with a = L^-1 K_us and b as that call left them (reference gpr/model.py:758-760, 870-872), S x S in
+// the caller's order of the test points.  One Gram over the test inputs and two S x S x M products.
+int mogp_sparse_predict_cov(mogp_model* m, int64_t S, double* cov) {
+    if (!m || !cov || S <= 0) return fail(MOGP_EINVAL, "mogp_sparse_predict_cov: bad argument");
+    RC(use_device(m->ctx));
+    if (!m->tw || !m->tw->pred_valid || m->tw->pred_ss.M != S)
+        return fail(MOGP_EINVAL, "mogp_sparse_predict_cov: no sparse prediction at S test points precedes it on this handle");
+    TitsiasWork& t = *m->tw;
+    const SortedX& ss = t.pred_ss;
+    const int C = m->C, D = m->D;
+    const int64_t Mpad = t.Mpad, Spad = ss.Mpad;
+    std::vector<GTile> st_tiles;
+    std::vector<int> ps;
+    build_sym_tiles(ss.off, C, st_tiles, ps);
+    RC(m->d_Kss.ensure((size_t)Spad * Spad)); RC(m->d_ptiles.ensure(st_tiles.size()));
+    HIP_TRY(hipMemsetAsync(m->d_Kss.p, 0, (size_t)Spad * Spad * sizeof(double), m->st));
+    HIP_TRY(hipMemcpyAsync(m->d_ptiles.p, st_tiles.data(), st_tiles.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
+    GramArgs ga{};
+    ga.tiles = m->d_ptiles.p; ga.xr = m->d_xs.p; ga.ldxr = Spad; ga.xc = m->d_xs.p; ga.ldxc = Spad; ga.nrows = S; ga.ncols = S;
+    RC(m->ph_ss.prepare(ss.off, ss.off, C, m->T, Spad, Spad, m->st, ga.ph));
+    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = m->Wt; ga.out = m->d_Kss.p; ga.ldo = Spad; ga.mirror = 1;
+    RC(launch_gram(ga, (int)st_tiles.size(), m->st));
+    const int st = (int)(Spad / MOGP_TILE);
+    GemmArgs g = make_gemm(t.Aus.p, Spad, 1, t.Aus.p, Spad, 1, m->d_Kss.p, Spad, -1.0, GM_RECT, st, st, Mpad);
+    g.beta = 1.0;
+    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
+    g = make_gemm(t.Bus.p, Spad, 1, t.Bus.p, Spad, 1, m->d_Kss.p, Spad, 1.0, GM_RECT, st, st, Mpad);
+    g.beta = 1.0;
+    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
+    std::vector<double> hc((size_t)Spad * Spad);
+    HIP_TRY(hipMemcpyAsync(hc.data(), m->d_Kss.p, hc.size() * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    HIP_TRY(hipStreamSynchronize(m->st));
+    for (int64_t a = 0; a < S; ++a)
+        for (int64_t b = 0; b < S; ++b) cov[ss.perm[a] * S + ss.perm[b]] = hc[(size_t)a * Spad + b];
+    return MOGP_OK;
+}
+
+}  // extern "C"

@@ -508,14 +508,14 @@ class Titsias(_DataParallel, Model):
 
     def predict_f(self, X, full=False):
         """reference gpr/model.py:730-765"""
-        if full:
-            raise NotImplementedError("full predictive covariance for Titsias is not on the HIP path")
         X = self._check_input(X)
         h = self._device_handle()
         D = self.X.shape[1] - (0 if self.kernel.output_dims is None else 1)
         h.set_terms(self.kernel._spectral_terms(D))
         mu, var = h.titsias_predict(self.kernel._kernel_format(self.Z()), self._sigma(), self.jitter,
                                     self.kernel._kernel_format(X), self.kernel._spectral_diag(D), sharded=self._data_shard() is not None)
+        if full:                                        # K_ss - a^T a + b^T b with the a, b this prediction left on the device (reference :758-760)
+            var = h.sparse_predict_cov(X.shape[0])
         if self.mean is not None:
             mu = mu + np.asarray(self.mean(X)).reshape(-1, 1)
         return mu, var
@@ -801,8 +801,6 @@ class SparseHensman(_DataParallel, Model):
 
     def predict_f(self, X, full=False):
         """reference gpr/model.py:851-878"""
-        if full:
-            raise NotImplementedError("full predictive covariance for the Hensman models is not on the HIP path")
         X = self._check_input(X)
         h = self._device_handle()
         D = self.X.shape[1] - (0 if self.kernel.output_dims is None else 1)
@@ -813,6 +811,8 @@ class SparseHensman(_DataParallel, Model):
         mu = np.reshape(res["mu"], (-1, 1))
         if self.mean is not None:
             mu = mu + np.asarray(self.mean(X)).reshape(-1, 1)
+        if full:                                        # reference :870-872
+            return mu, h.sparse_predict_cov(X.shape[0])
         return mu, np.reshape(res["var"], (-1, 1))
 
 

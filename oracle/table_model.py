@@ -267,9 +267,18 @@ def titsias_predict(self, Z, sigma, jitter, Xs, kss_diag, sharded=False):
     c = solve_triangular(Lq, red(v @ y), lower=True) / s2
     mu = b.T @ c
     var = np.asarray(kss_diag)[Xs[:, 0].astype(np.int64)] - np.sum(a * a, axis=0) + np.sum(b * b, axis=0)
+    self._sparse_pred = (np.array(Xs), a, b)
     return mu, var.reshape(-1, 1)
 
 
+def sparse_predict_cov(self, S):
+    """twin of mogp_sparse_predict_cov: K_ss - a^T a + b^T b of the last sparse prediction (reference gpr/model.py:758-760, 870-872)"""
+    Xs, a, b = self._sparse_pred
+    assert Xs.shape[0] == S
+    return gram_from_table(self.table, Xs) - a.T @ a + b.T @ b
+
+
+TableDevice.sparse_predict_cov = sparse_predict_cov
 TableDevice.titsias_eval = titsias_eval
 TableDevice.titsias_predict = titsias_predict
 
@@ -390,6 +399,8 @@ def svgp_forward(self, Z, q_mu, q_sqrt, jitter, kff_diag, Xs=None, kss_diag=None
         var = kd - np.sum(a * a, axis=0) + np.sum(b * b, axis=0)
     if Xs is None:
         self._svgp = dict(Z=np.array(Z), Luu=Luu, v=a, S=S, q_mu=qm, dense=bool(dense))
+    else:
+        self._sparse_pred = (np.array(Xs), a, b)
     return dict(mu=mu, var=var, jitter_abs=jit)
 
 

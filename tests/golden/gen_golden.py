@@ -1002,6 +1002,37 @@ def gen_samples():
     print("samples.npz written")
 
 
+def gen_sparse_cov():
+    """full predictive covariance of the sparse models (Titsias / SparseHensman / Hensman predict_f(full=True), reference
+    gpr/model.py:758-760, 870-872) and posterior samples of f drawn from it under a fixed seed"""
+    out = {}
+    rng = np.random.default_rng(616)
+    C, Q, N = 2, 2, 80
+    X, y = small_data(N, C, 1, 6160, False)
+    Xs, _ = small_data(11, C, 1, 6161, True)
+    Z = np.concatenate([np.stack([np.full(6, float(c)), np.sort(rng.uniform(0, 10, 6))], axis=1) for c in range(C)])
+    out["X"] = X; out["y"] = y; out["Xs"] = Xs; out["Z"] = Z
+    for tag in ("titsias", "sparse_hensman", "hensman"):
+        k = build_kernel("mosm", C, Q, 1, 1, rng)
+        if tag == "titsias":
+            m = g.Titsias(k, T(X), T(y), Z=T(Z), variance=0.09, jitter=1e-6)
+        elif tag == "sparse_hensman":
+            m = g.SparseHensman(k, T(X), T(y), Z=T(Z), likelihood=g.GaussianLikelihood(0.3), jitter=1e-6)
+        else:
+            m = g.Hensman(k, T(X), T(y), likelihood=g.GaussianLikelihood(0.3), jitter=1e-6)
+        if tag != "titsias":
+            M = m.q_mu().shape[0]
+            m.q_mu.assign(rng.normal(0, 0.5, (M, 1)))
+            m.q_sqrt.assign(np.tril(rng.normal(0, 0.1, (M, M))) + np.diag(rng.uniform(0.5, 1.0, M)))
+        dump_params(tag + "_", list(m.parameters()), out)
+        mu, cov = m.predict_f(T(Xs), full=True)
+        out[tag + "_mu"] = mu.numpy(); out[tag + "_cov"] = cov.numpy()
+        torch.manual_seed(5)
+        out[tag + "_sample"] = m.sample_f(T(Xs)).numpy()
+    np.savez_compressed(os.path.join(HERE, "sparse_cov.npz"), **out)
+    print("sparse_cov.npz written")
+
+
 def gen_checkpoints():
     """Files written by the reference's own Model.save() (model.py:320-336) -- the whole pickled model: MOSM with a fitted transformer
     chain, removed points and a pegged + a fixed parameter; the SM, CSM, SM-LMC and CONV wrappers; a Titsias MOSM -- stored as bytes next to what
@@ -1093,7 +1124,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "lbfgs": gen_lbfgs_cfg1, "quirks": gen_quirks,
              "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2, "smlmc": gen_smlmc, "init_ls": gen_init_ls, "bnse": gen_bnse, "transformers": gen_transformers,
-             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints, "snelson": gen_snelson, "hensman": gen_hensman, "oa": gen_oa, "likelihoods": gen_likelihoods, "samples": gen_samples}
+             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints, "snelson": gen_snelson, "hensman": gen_hensman, "oa": gen_oa, "likelihoods": gen_likelihoods, "samples": gen_samples, "sparse_cov": gen_sparse_cov}
     full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:
         {**steps, **full}[a.only]()

@@ -710,3 +710,9 @@ def test_posterior_samples_on_device():
     the reference's own samples under the same seed"""
     from test_host_logic import check_samples
     check_samples(tol=1e-6)
+
+
+def test_sparse_models_full_covariance_on_device():
+    """predict_f(full=True) of Titsias / SparseHensman / Hensman (mogp_sparse_predict_cov) and posterior samples drawn from it"""
+    from test_host_logic import check_sparse_cov
+    check_sparse_cov(tol=1e-7, tol_sample=1e-5)

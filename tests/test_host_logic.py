@@ -800,6 +800,34 @@ def test_posterior_samples_match_reference():
     check_samples()
 
 
+def check_sparse_cov(tol=1e-8, tol_sample=1e-6):
+    """sparse_cov.npz: predict_f(full=True) of Titsias, SparseHensman and Hensman against the reference, and a posterior sample of f drawn from
+    it under the reference's seed"""
+    torch = pytest.importorskip("torch")
+    fx = load("sparse_cov.npz")
+    X, y, Xs, Z = fx["X"], fx["y"], fx["Xs"], fx["Z"]
+    for tag in ("titsias", "sparse_hensman", "hensman"):
+        k = gpr.MultiOutputSpectralMixtureKernel(Q=2, output_dims=2, input_dims=1)
+        if tag == "titsias":
+            m = gpr.Titsias(k, X, y, Z=Z, variance=0.09, jitter=1e-6)
+        elif tag == "sparse_hensman":
+            m = gpr.SparseHensman(k, X, y, Z=Z, likelihood=gpr.GaussianLikelihood(0.3), jitter=1e-6)
+        else:
+            m = gpr.Hensman(k, X, y, likelihood=gpr.GaussianLikelihood(0.3), jitter=1e-6)
+        load_raw(m.parameters(), fixture_params(fx, tag + "_"))
+        mu, cov = m.predict_f(Xs, full=True)
+        assert cov.shape == (11, 11)
+        assert relerr(mu, fx[tag + "_mu"]) < tol and np.max(np.abs(cov - fx[tag + "_cov"])) < tol * max(1.0, np.max(np.abs(fx[tag + "_cov"]))), tag
+        mu1, var = m.predict_f(Xs)
+        assert np.max(np.abs(np.reshape(var, -1) - np.diagonal(cov))) < tol, tag
+        torch.manual_seed(5)
+        assert np.max(np.abs(m.sample_f(Xs) - fx[tag + "_sample"])) < tol_sample, tag
+
+
+def test_sparse_models_full_covariance_matches_reference():
+    check_sparse_cov()
+
+
 def test_hensman_through_the_model_wrapper():
     t = np.linspace(0, 10, 30)
     ds = mogptk_amd.DataSet(t, [np.sin(t), np.cos(t)])
