@@ -286,17 +286,18 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
     // M x M only: on the side stream, underneath the M x N work below
     hipStream_t side;
     RC(side_fork(m, t, &side));
+    // GB = L^-T (R v) / s2, and beta = L^-T t1 riding along: when N is not a multiple of 128 the right-hand side has zero padding columns,
+    // and t1 travels through the blocked solve in the first of them (a vector solve of its own is 2 nb dependent, almost empty launches).
+    // The large product is ENQUEUED before the side chain's ~70 launches, so that a slow host does not hold it back.
+    RC(launch_combine(t.R.p, t.q.B.p, nullptr, Mpad, Mpad, 1.0, 1.0, 0.0, m->st));           // R = I - Pq
+    GemmArgs g = make_gemm(t.R.p, Mpad, 0, t.v.p, Npad, 1, t.GB.p, Npad, 1.0 / s2, GM_RECT, mt, nt, Mpad);
+    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
     RC(launch_combine(t.E.p, t.q.B.p, t.Qs.p, Mpad, Mpad, 2.0, 1.0, 1.0, side));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.E.p, Mpad, Mpad, true, side));
     RC(launch_transpose(t.GA.p, t.E.p, Mpad, Mpad, side));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.GA.p, Mpad, Mpad, true, side));
     RC(launch_sym_lower_avg(t.GA.p, Mpad, Mpad, 0.5, side));
     RC(launch_get_diag(t.GA.p, Mpad, Mpad, dga, side));
-    // GB = L^-T (R v) / s2, and beta = L^-T t1 riding along: when N is not a multiple of 128 the right-hand side has zero padding columns,
-    // and t1 travels through the blocked solve in the first of them (a vector solve of its own is 2 nb dependent, almost empty launches)
-    RC(launch_combine(t.R.p, t.q.B.p, nullptr, Mpad, Mpad, 1.0, 1.0, 0.0, m->st));           // R = I - Pq
-    GemmArgs g = make_gemm(t.R.p, Mpad, 0, t.v.p, Npad, 1, t.GB.p, Npad, 1.0 / s2, GM_RECT, mt, nt, Mpad);
-    RC(gemm_call(m, g, gemm_flops(g, nullptr)));
     const bool ride = Npad > N;
     if (ride) RC(launch_copy2d(t.GB.p + N, Npad, t1, 1, Mpad, 1, 1.0, m->st));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.GB.p, Npad, Npad, true));
