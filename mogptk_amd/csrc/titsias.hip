@@ -184,10 +184,12 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     RC(side_join(m, t, side));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.v.p, Npad, Npad, false));              // v = L^-1 B   (reference gpr/model.py:711)
     (void)nt;
-    // Qs = v v^T / s2 + I
-    RC(mm_lower_splitk(m, t, t.v.p, t.v.p, t.q.A.p, mt, Mpad, Npad, Npad, 1.0 / s2));
+    // Qs = v v^T / s2 + I, with v y (one memory-bound pass over v) underneath the compute-bound product
     double* vy = t.vec.p;
-    RC(launch_gemv_rows(t.v.p, Npad, Mpad, Npad, m->d_y.p, vy, m->st));
+    RC(side_fork(m, t, &side));
+    RC(launch_gemv_rows(t.v.p, Npad, Mpad, Npad, m->d_y.p, vy, side));
+    RC(mm_lower_splitk(m, t, t.v.p, t.v.p, t.q.A.p, mt, Mpad, Npad, Npad, 1.0 / s2));
+    RC(side_join(m, t, side));
     sc.yy = 0.0; for (int64_t i = 0; i < m->N; ++i) sc.yy += m->hy[i] * m->hy[i];
     sc.ntot = (double)m->N;
     sc.kff = 0.0;
