@@ -716,3 +716,48 @@ def test_sparse_models_full_covariance_on_device():
     """predict_f(full=True) of Titsias / SparseHensman / Hensman (mogp_sparse_predict_cov) and posterior samples drawn from it"""
     from test_host_logic import check_sparse_cov
     check_sparse_cov(tol=1e-7, tol_sample=1e-5)
+
+
+def test_side_stream_schedule_equals_the_serial_one(tmp_path):
+    """the sparse models' M x M chains, K_uf and v y run on a side stream underneath the large products (titsias.hip:side_fork); with
+    MOGP_SIDE_STREAM=0 everything is enqueued on one stream -- same kernels, same arithmetic: the results must agree to rounding of the
+    atomically accumulated d/dZ (a missing dependency between the streams would show up here)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "side.py"
+    script.write_text('''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from mogptk_amd import gpr, synth, _lib
+C, Q, N, M = 3, 2, 30000, 640
+X, y = synth.make_data(N, C)
+h = synth.mosm_hypers(C, Q)
+k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
+for name in ("weight", "mean", "variance", "delay", "phase"):
+    getattr(k, name).assign(h[name])
+rng = np.random.default_rng(2)
+Z = np.concatenate([np.stack([np.full(M // C, float(c)), np.sort(rng.uniform(0, 100, M // C))], axis=1) for c in range(C)])
+dev = _lib.ExactHandle(0, X, y, C); dev.set_terms(k._spectral_terms(1))
+kd = k._spectral_diag(1)
+out = {}
+for rep in range(3):
+    a = dev.titsias_eval(Z, 0.3, 1e-6, kd)
+    b = dev.snelson_eval(Z, np.full(C, 0.09), 1e-6, kd)
+    q_mu, q_sqrt = rng.normal(0, 0.3, Z.shape[0]), np.eye(Z.shape[0]) * 0.8
+    f = dev.svgp_forward(Z, q_mu, q_sqrt, 1e-6, kd)
+    c = dev.svgp_backward(np.cos(np.arange(N)), -np.ones(N))
+    rng = np.random.default_rng(2)
+out = dict(t_elbo=a["elbo"], t_uu=a["mom_uu"], t_uf=a["mom_uf"], t_gz=a["gZ"], s_lml=b["lml"], s_uu=b["mom_uu"], s_uf=b["mom_uf"], s_gz=b["gZ"],
+           h_mu=f["mu"], h_uu=c["mom_uu"], h_uf=c["mom_uf"], h_gz=c["gZ"], h_gs=c["g_qsqrt"])
+np.savez(sys.argv[1], **out)
+''' % root)
+    res = []
+    for mode in ("0", "1"):
+        path = str(tmp_path / ("out%s.npz" % mode))
+        out = subprocess.run([sys.executable, str(script), path], capture_output=True, text=True, timeout=600, env=dict(os.environ, MOGP_SIDE_STREAM=mode))
+        assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-2000:]
+        res.append(np.load(path))
+    for key in res[0].files:
+        a, b = res[0][key], res[1][key]
+        assert np.max(np.abs(a - b)) <= 1e-9 * max(1.0, np.max(np.abs(a))), (key, float(np.max(np.abs(a - b))))      # measured: <= 2e-11 (atomics)
