@@ -493,6 +493,8 @@ static int factorize_finish(mogp_model* m, const GramArgs& ga, double* lml, int6
     unsigned long long hinfo = 0;
     std::memcpy(&hinfo, m->h_pin + nb + nzz, sizeof(hinfo));
     int rc;
+    if (hinfo == MOGP_INFO_CHAIN_TIMEOUT)
+        return fail(MOGP_EHIP, "chain kernel: a hand-off between its workgroups timed out (chain.hip; MOGP_CHAIN=0 selects the launch-per-step form)");
     if (hinfo != big) {
         if (info) *info = (int64_t)hinfo;
         // distinguish NaN / Inf in the Gram from a plain indefinite matrix (reference prints which, gpr/model.py:249-252)

@@ -159,6 +159,13 @@ int launch_trtri_tiles(const double* A, int64_t ld, int t0, int nt, double* invd
 // copy the batch of inverted diagonal tiles into the diagonal tiles of A
 int launch_put_diag_tiles(double* A, int64_t ld, int nt, const double* invd, hipStream_t s);
 int launch_wkk(const double* Ablk, int64_t ld, const double* invd, int nk, double* Wk, int64_t ldw, hipStream_t s);
+// chain.hip: the whole serial chain of one outer block (tiles t0 .. t0 + nk - 1, nk <= 4) in ONE persistent launch: the leaves, the panels
+// and updates inside the block and W_KK = L_KK^-1 (-> Wk, as launch_wkk leaves it).  flags: MOGP_CHAIN_FLAGS zeroed words of this block;
+// err: one zeroed word per evaluation.  A hand-off that times out is reported as MOGP_INFO_CHAIN_TIMEOUT through *info.
+#define MOGP_CHAIN_FLAGS 32
+#define MOGP_INFO_CHAIN_TIMEOUT (1ull << 62)
+int launch_chain(double* A, int64_t ld, int t0, int nk, double* invd, double* logdet, unsigned long long* info, long long info_base,
+                 double* Wk, int64_t ldw, unsigned* flags, unsigned* err, hipStream_t s);
 // rows >= N of the padded matrix: identity (lower part)
 int launch_pad_identity(double* A, int64_t ld, int64_t N, int64_t Npad, hipStream_t s);
 // z = W y (W lower triangular), and partial[blk] = sum z^2 over the block's rows

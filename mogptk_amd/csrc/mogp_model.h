@@ -110,11 +110,12 @@ struct Spd {
     hipEvent_t fused_last_inv = nullptr, fused_last_wt = nullptr;
     DevBuf<double> Wd;                  // W_KK = L_KK^-1 of every outer block of the fused schedule (512 x 512 each, wkk.hip)
     DevBuf<double> Pb[MOGP_NPANEL];     // rotating panel buffers L[>K, K] of the fused schedule (Npad x 512 each)
+    DevBuf<unsigned> chain_flags;       // hand-off words of the persistent chain kernel (chain.hip): MOGP_CHAIN_FLAGS per outer block + the error word
     void release() {
         for (auto& lv : levels) { lv.d1.release(); lv.d2.release(); }
         for (auto e : sync_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
         for (auto e : inv_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
-        inv_ev.clear(); Wm.release(); Wd.release(); for (auto& b : Pb) b.release();
+        inv_ev.clear(); Wm.release(); Wd.release(); chain_flags.release(); for (auto& b : Pb) b.release();
         levels.clear(); sync_ev.clear();
         A.release(); B.release(); invd.release(); logdet.release();
     }

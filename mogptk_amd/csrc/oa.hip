@@ -142,6 +142,7 @@ int mogp_oa_forward(mogp_model* m, const double* q_nu, const double* q_lambda, d
     HIP_TRY(hipMemcpyAsync(hl.data(), m->k.logdet.p, m->nb * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(&hinfo, m->d_info.p, sizeof(hinfo), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
+    if (hinfo == MOGP_INFO_CHAIN_TIMEOUT) return fail(MOGP_EHIP, "chain kernel: a hand-off between its workgroups timed out (chain.hip)");
     if (hinfo != big) {
         if (info) *info = (int64_t)hinfo;
         return fail(MOGP_ENOTPD, "linalg.cholesky: The factorization could not be completed because the input is not "

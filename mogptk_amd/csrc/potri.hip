@@ -45,8 +45,15 @@ namespace {
 enum { EV_BLK = 0, EV_DIAG = 1, EV_PANEL = 2, EV_BULK = 3, EV_INV = 4, EV_REST = 5, EV_WROW = 6, EV_ACC = 7, EV_PER_BLOCK = 8 };
 
 // factor the diagonal block [k0, k1) of w.A in place (L_KK) and put W_KK = L_KK^-1 (lower; zeros above) into Wk (leading dimension FZ_KD)
-int intra_block_chain(mogp_model* m, Spd& w, double* Wk, int k0, int k1, hipStream_t q) {
+int intra_block_chain(mogp_model* m, Spd& w, double* Wk, int k0, int k1, hipStream_t q, int kb) {
     const int64_t ld = w.Npad;
+    // MOGP_CHAIN=0: the launch-per-step form below (4 leaves, 6 small GEMMs, k_wkk) instead of the persistent kernel of chain.hip
+    static const bool persistent = !(std::getenv("MOGP_CHAIN") && std::atoi(std::getenv("MOGP_CHAIN")) == 0);
+    if (persistent) {
+        const int nouter = (w.nb + FZ_OB - 1) / FZ_OB;
+        return launch_chain(w.A.p, ld, k0, k1 - k0, w.invd.p, w.logdet.p, m->d_info.p, 0, Wk, FZ_KD,
+                            w.chain_flags.p + (size_t)kb * MOGP_CHAIN_FLAGS, w.chain_flags.p + (size_t)nouter * MOGP_CHAIN_FLAGS, q);
+    }
     for (int k = k0; k < k1; ++k) {
         RC(launch_potrf_trtri_tile(w.A.p, ld, k, w.invd.p, w.logdet.p, m->d_info.p, q, 0));
         const int ri = k1 - k - 1;                       // tile rows below, inside the block
@@ -146,6 +153,8 @@ int spd_potri_fused(mogp_model* m, Spd& w) {
         RC(w.Wd.ensure((size_t)nouter * FZ_KD * FZ_KD));
         HIP_TRY(hipMemsetAsync(w.Wd.p, 0, (size_t)nouter * FZ_KD * FZ_KD * sizeof(double), crit));
     }
+    RC(w.chain_flags.ensure((size_t)(nouter + 1) * MOGP_CHAIN_FLAGS));          // hand-off words of the persistent chain kernels: zero per evaluation
+    HIP_TRY(hipMemsetAsync(w.chain_flags.p, 0, (size_t)(nouter + 1) * MOGP_CHAIN_FLAGS * sizeof(unsigned), crit));
     auto Wk = [&](int kb) { return w.Wd.p + (int64_t)kb * FZ_KD * FZ_KD; };
     while ((int)w.inv_ev.size() < EV_PER_BLOCK * nouter + 2) {
         hipEvent_t e;
@@ -163,7 +172,7 @@ int spd_potri_fused(mogp_model* m, Spd& w) {
     };
     auto chain = [&](int kb) -> int {                    // priv: factor D_KK, W_KK (its inputs are ordered by the stream itself)
         int k0, k1, nk, rem, na, k2; geom(kb, k0, k1, nk, rem, na, k2);
-        RC(intra_block_chain(m, w, Wk(kb), k0, k1, priv));
+        RC(intra_block_chain(m, w, Wk(kb), k0, k1, priv, kb));
         HIP_TRY(hipEventRecord(ev(kb, EV_BLK), priv));
         return 0;
     };

@@ -69,6 +69,8 @@ int spd_check_info(mogp_model* m, const char* which, int64_t* info) {
     unsigned long long hinfo = 0;
     HIP_TRY(hipMemcpyAsync(&hinfo, m->d_info.p, sizeof(hinfo), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
+    if (hinfo == MOGP_INFO_CHAIN_TIMEOUT)
+        return fail(MOGP_EHIP, "chain kernel: a hand-off between its workgroups timed out (chain.hip; MOGP_CHAIN=0 selects the launch-per-step form)");
     if (hinfo != std::numeric_limits<unsigned long long>::max()) {
         if (info) *info = (int64_t)hinfo;
         return fail(MOGP_ENOTPD, std::string("linalg.cholesky: ") + which + " is not positive-definite (the leading minor of order " +

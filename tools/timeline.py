@@ -30,9 +30,10 @@ busy = collections.defaultdict(float); last = collections.defaultdict(float)
 for r in ev:
     busy[r[3]] += (r[2] - r[1]) / 1e3; last[r[3]] = max(last[r[3]], (r[2] - t0) / 1e3)
 print("busy us per queue", {q: round(b) for q, b in busy.items()}, "| last end", {q: round(b) for q, b in last.items()})
-wk = [(r[1] - t0) / 1e3 for r in ev if r[0].startswith("k_wkk")]
+mark = "k_chain" if any(r[0].startswith("k_chain") for r in ev) else "k_wkk"      # one per outer block either way
+wk = [(r[1] - t0) / 1e3 for r in ev if r[0].startswith(mark)]
 if wk:
-    print("outer-block (k_wkk) start times us:", [round(x) for x in wk])
+    print("outer-block (%s) start times us:" % mark, [round(x) for x in wk])
     print("periods us:", [round(b - a) for a, b in zip(wk, wk[1:])])
 ints = sorted((r[1], r[2]) for r in ev if r[0].startswith("k_gemm"))
 union = 0; cur_s, cur_e = ints[0]
@@ -42,6 +43,6 @@ for s, e in ints[1:]:
 union += cur_e - cur_s
 print("k_gemm: sum %.0f us, union %.0f us" % (sum(e - s for s, e in ints) / 1e3, union / 1e3))
 if "--list" in sys.argv:
-    q = max(busy, key=lambda k: sum(1 for r in ev if r[3] == k and r[0].startswith("k_leaf")))
+    q = max(busy, key=lambda k: sum(1 for r in ev if r[3] == k and (r[0].startswith("k_leaf") or r[0].startswith("k_chain"))))
     for r in ev:
         if r[3] == q: print("%9.1f %8.1f  %-26s grid %d" % ((r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, r[0], r[4]))
