@@ -36,17 +36,21 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
         child(int(sys.argv[2]), sys.argv[3], int(sys.argv[4]))
         sys.exit(0)
+    # which switch is A/B-ed: AB="MOGP_CHAIN:0,1" (default) or e.g. AB="MOGP_LOOKAHEAD:1,2"; the first value is the reference
+    AB_VAR, vals = os.environ.get("AB", "MOGP_CHAIN:0,1").split(":")
+    AB_VALUES = vals.split(",")
     sizes = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "100,128,300,512,600,900,1500,2048,4097,8192").split(",")]
     bad = 0
     for n in sizes:
         res = {}
         for mode in ("0", "1"):
             f = tempfile.mktemp(suffix=".npz")
-            env = dict(os.environ, MOGP_CHAIN=mode, MOGP_GRAD_PATH="fused")
+            env = dict(os.environ, MOGP_GRAD_PATH="fused")
+            env[AB_VAR] = AB_VALUES[int(mode)]
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(n), f, "30" if n <= 4097 else "20"], env=env,
                                capture_output=True, text=True, timeout=600)
             if r.returncode != 0:
-                print("N=%d MOGP_CHAIN=%s FAILED rc=%d: %s" % (n, mode, r.returncode, (r.stderr or r.stdout)[-600:]))
+                print("N=%d %s=%s FAILED rc=%d: %s" % (n, AB_VAR, AB_VALUES[int(mode)], r.returncode, (r.stderr or r.stdout)[-600:]))
                 res[mode] = None
                 continue
             res[mode] = dict(np.load(f))
@@ -59,8 +63,8 @@ if __name__ == "__main__":
         dg = np.max(np.abs(a["grads"] - b["grads"])) / max(1e-300, np.max(np.abs(a["grads"])))
         dW = np.max(np.abs(a["W"] - b["W"])) / max(1e-300, np.max(np.abs(a["W"])))
         ok = dl < 1e-9 and dg < 1e-6
-        print("N=%5d  loss %.10g vs %.10g  rel %.1e | grad rel %.1e | W rel %.1e | ms/eval launches %.3f  persistent %.3f  %s"
-              % (n, a["loss"], b["loss"], dl, dg, dW, a["ms"], b["ms"], "ok" if ok else "MISMATCH"))
+        print("N=%5d  loss %.10g vs %.10g  rel %.1e | grad rel %.1e | W rel %.1e | ms/eval %s=%s %.3f  %s=%s %.3f  %s"
+              % (n, a["loss"], b["loss"], dl, dg, dW, AB_VAR, AB_VALUES[0], a["ms"], AB_VAR, AB_VALUES[1], b["ms"], "ok" if ok else "MISMATCH"))
         if not ok:
             bad += 1
             nb = (a["W"].shape[0] + 127) // 128
