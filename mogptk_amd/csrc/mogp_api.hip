@@ -151,7 +151,7 @@ int mogp_ctx_create(int device, mogp_ctx** out) {
 
 int mogp_ctx_destroy(mogp_ctx* ctx) {
     if (!ctx) return MOGP_OK;
-    for (hipStream_t q : {ctx->st, ctx->st2, ctx->st2u, ctx->st3, ctx->st4, ctx->st_priv}) if (q) { hipError_t e = hipStreamSynchronize(q); (void)e; e = hipStreamDestroy(q); (void)e; }
+    for (hipStream_t q : {ctx->st, ctx->st2, ctx->st2u, ctx->st3, ctx->st4, ctx->st5, ctx->st_priv}) if (q) { hipError_t e = hipStreamSynchronize(q); (void)e; e = hipStreamDestroy(q); (void)e; }
     delete ctx;
     return MOGP_OK;
 }
@@ -404,6 +404,19 @@ static int pin_ensure(mogp_model* m, size_t n) {
 
 static int factorize_finish(mogp_model* m, const GramArgs& ga, double* lml, int64_t* info);
 
+// A hand-off inside the persistent chain kernel (chain.hip) timed out: its 13 workgroups were not all resident -- another process sharing the
+// GPU holds part of the reserved CUs with its own chain kernel (two such kernels can each hold some of the 16 CUs and wait for the rest).
+// Nothing is wrong with the data: drain the streams and repeat the evaluation on the launch-per-step chain, which this model keeps from now on.
+#define MOGP_RETRY_NO_CHAIN 0x7e7e
+namespace mogp { int chain_fallback(mogp_model* m) {
+    if (m->no_chain) return fail(MOGP_EHIP, "chain kernel: a hand-off timed out although the model is on the launch-per-step chain");
+    m->no_chain = true;
+    for (hipStream_t q : {m->st, m->st2, m->st3, m->st4, m->ctx->st5, m->st_priv}) if (q) HIP_TRY(hipStreamSynchronize(q));
+    static bool said = false;
+    if (!said) { said = true; fprintf(stderr, "mogp: the persistent chain kernel timed out (GPU shared with another process?); using the launch-per-step chain\n"); }
+    return 0;
+} }
+
 // defer: enqueue only -- the scalars travel to the pinned block asynchronously and factorize_finish() (after the caller's ONE stream sync)
 // turns them into the LML / the failure report
 static int factorize(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
@@ -493,8 +506,7 @@ static int factorize_finish(mogp_model* m, const GramArgs& ga, double* lml, int6
     unsigned long long hinfo = 0;
     std::memcpy(&hinfo, m->h_pin + nb + nzz, sizeof(hinfo));
     int rc;
-    if (hinfo == MOGP_INFO_CHAIN_TIMEOUT)
-        return fail(MOGP_EHIP, "chain kernel: a hand-off between its workgroups timed out (chain.hip; MOGP_CHAIN=0 selects the launch-per-step form)");
+    if (hinfo == MOGP_INFO_CHAIN_TIMEOUT) return MOGP_RETRY_NO_CHAIN;      // the caller repeats the evaluation on the launch-per-step chain
     if (hinfo != big) {
         if (info) *info = (int64_t)hinfo;
         // distinguish NaN / Inf in the Gram from a plain indefinite matrix (reference prints which, gpr/model.py:249-252)
@@ -682,12 +694,17 @@ static int ctx_streams(mogp_ctx* ctx) {
         const int ncu = prop.multiProcessorCount;
         const bool masked = reserve > 0 && 16 * reserve < ncu;
         if (masked) {
-            std::vector<uint32_t> bulk((ncu + 31) / 32, 0u), priv((ncu + 31) / 32, 0u);
+            std::vector<uint32_t> bulk((ncu + 31) / 32, 0u), priv((ncu + 31) / 32, 0u), invm((ncu + 31) / 32, 0u);
             for (int i = 0; i < ncu; ++i) (i < 8 * reserve ? priv : bulk)[i / 32] |= 1u << (i % 32);
+            // MOGP_INV_CUS = n (experiment): the inverse's two streams see only the first n CUs of the bulk set (bit order = round robin over
+            // the XCDs), so that the Cholesky's trailing updates -- which pace the chain -- get the other CUs to themselves
+            const char* ei = std::getenv("MOGP_INV_CUS");
+            const int ninv = ei ? std::atoi(ei) : 0;
+            for (int i = 8 * reserve; i < ncu; ++i) if (ninv <= 0 || i < 8 * reserve + ninv) invm[i / 32] |= 1u << (i % 32);
             HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st_priv, (uint32_t)priv.size(), priv.data()));
             HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st2, (uint32_t)bulk.size(), bulk.data()));
-            HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st3, (uint32_t)bulk.size(), bulk.data()));
-            HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st4, (uint32_t)bulk.size(), bulk.data()));
+            HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st3, (uint32_t)invm.size(), invm.data()));
+            HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st4, (uint32_t)invm.size(), invm.data()));
         } else {
             HIP_TRY(hipStreamCreateWithPriority(&ctx->st2, hipStreamNonBlocking, (lo + hi) / 2));
             HIP_TRY(hipStreamCreateWithPriority(&ctx->st3, hipStreamNonBlocking, lo));
@@ -752,7 +769,7 @@ int mogp_model_destroy(mogp_model* m) {
     for (auto e : m->ev) { hipError_t r = hipEventDestroy(e); (void)r; }
     for (auto e : m->gemm_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
     for (auto& e : m->pred_ev) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
-    for (hipStream_t q : {m->st2, m->st2u, m->st3, m->st4, m->st_priv}) if (q) { hipError_t e = hipStreamSynchronize(q); (void)e; }
+    for (hipStream_t q : {m->st2, m->st2u, m->st3, m->st4, m->ctx->st5, m->st_priv}) if (q) { hipError_t e = hipStreamSynchronize(q); (void)e; }
     m->k.release(); m->ws.release(); m->ws_tail.release();
     for (int b = 0; b < 2; ++b) { m->swU[b].release(); m->swUr[b].release(); }
     for (auto e : m->sw_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
@@ -835,7 +852,11 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     const bool grad = (flags & MOGP_EVAL_GRAD) != 0;
     GramArgs ga{};
     if (sweep) { if ((rc = eval_sweep(m, noise_var, data_var, jitter, lml, jitter_abs, info))) return rc; }
-    else if ((rc = factorize(m, noise_var, data_var, jitter, lml, jitter_abs, info, fused, grad, &ga))) return rc;
+    else if ((rc = factorize(m, noise_var, data_var, jitter, lml, jitter_abs, info, fused, grad, &ga))) {
+        if (rc != MOGP_RETRY_NO_CHAIN) return rc;
+        if ((rc = chain_fallback(m))) return rc;
+        return mogp_exact_eval(m, noise_var, data_var, jitter, flags, lml, moments, diagG, trG, jitter_abs, info);
+    }
     if (!grad) { collect_timing(m, 4); return MOGP_OK; }
     if (!moments || !diagG || !trG) return fail(MOGP_EINVAL, "mogp_exact_eval: gradient outputs are null");
 
@@ -855,7 +876,11 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
         HIP_TRY(hipMemcpyAsync(m->h_pin + off, m->d_moments.p, (size_t)P * T * W * sizeof(double), hipMemcpyDeviceToHost, m->st));
         HIP_TRY(hipMemcpyAsync(m->h_pin + off + (size_t)P * T * W, m->d_diagG.p, C * sizeof(double), hipMemcpyDeviceToHost, m->st));
         if ((rc = wait_stream(m->st))) return rc;
-        if ((rc = factorize_finish(m, ga, lml, info))) return rc;
+        if ((rc = factorize_finish(m, ga, lml, info))) {
+            if (rc != MOGP_RETRY_NO_CHAIN) return rc;
+            if ((rc = chain_fallback(m))) return rc;
+            return mogp_exact_eval(m, noise_var, data_var, jitter, flags, lml, moments, diagG, trG, jitter_abs, info);
+        }
         std::memcpy(moments, m->h_pin + off, (size_t)P * T * W * sizeof(double));
         std::memcpy(diagG, m->h_pin + off + (size_t)P * T * W, C * sizeof(double));
     }

@@ -85,7 +85,7 @@ struct mogp_ctx {
     mogp_comm comm;
     std::string name;
     // streams shared by every model of the context (created once: a CU-masked stream owns a hardware queue, and models come and go)
-    hipStream_t st = nullptr, st2 = nullptr, st3 = nullptr, st4 = nullptr, st_priv = nullptr, st2u = nullptr;
+    hipStream_t st = nullptr, st2 = nullptr, st3 = nullptr, st4 = nullptr, st5 = nullptr, st_priv = nullptr, st2u = nullptr;
     bool streams_ready = false;
 };
 
@@ -227,6 +227,7 @@ struct mogp_model {
     int64_t gemm_launches = 0;
     double gemm_flops = 0.0;
     bool have_W = false, have_Kinv = false, kinv_in_A = false, w_in_Wm = false;
+    bool no_chain = false;              // the persistent chain kernel timed out once on this model (another process's chain kernel held the reserved CUs): launch-per-step chain from now on
     TitsiasWork* tw = nullptr;
     OaWork oa;
 };
@@ -252,6 +253,7 @@ inline GemmArgs make_gemm(const double* A, int64_t lda, int akm, const double* B
 int side_fork(mogp_model* m, TitsiasWork& t, hipStream_t* side);
 int side_join(mogp_model* m, TitsiasWork& t, hipStream_t side);
 int spd_check_info(mogp_model* m, const char* which, int64_t* info);
+int chain_fallback(mogp_model* m);     // mogp_api.hip: after MOGP_INFO_CHAIN_TIMEOUT -- drain, switch the model to the launch-per-step chain; the caller repeats the evaluation
 // w.A (SPD, lower tiles) -> w.B = its inverse (lower tiles, full diagonal tiles) and *W = L^-1 (lower; in w.A, or in w.Wm on the fused path),
 // w.logdet per tile: POTRF, TRTRI, LAUUM.  MOGP_SPARSE_FUSED=1 takes the fused factorisation + inversion schedule of the exact path
 // (potri.hip) instead -- measured SLOWER for the 16-tile-row systems of configs[4] (52.0 vs 49.9 ms per evaluation: four outer blocks give

@@ -142,7 +142,10 @@ int mogp_oa_forward(mogp_model* m, const double* q_nu, const double* q_lambda, d
     HIP_TRY(hipMemcpyAsync(hl.data(), m->k.logdet.p, m->nb * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(&hinfo, m->d_info.p, sizeof(hinfo), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
-    if (hinfo == MOGP_INFO_CHAIN_TIMEOUT) return fail(MOGP_EHIP, "chain kernel: a hand-off between its workgroups timed out (chain.hip)");
+    if (hinfo == MOGP_INFO_CHAIN_TIMEOUT) {                 // see chain_fallback: repeat on the launch-per-step chain
+        RC(chain_fallback(m));
+        return mogp_oa_forward(m, q_nu, q_lambda, mu, var, kl, info);
+    }
     if (hinfo != big) {
         if (info) *info = (int64_t)hinfo;
         return fail(MOGP_ENOTPD, "linalg.cholesky: The factorization could not be completed because the input is not "

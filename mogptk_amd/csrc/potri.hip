@@ -42,14 +42,14 @@ int launch_potrf_trtri_tile(double* A, int64_t ld, int t, double* invd, double* 
 
 namespace {
 
-enum { EV_BLK = 0, EV_DIAG = 1, EV_PANEL = 2, EV_BULK = 3, EV_INV = 4, EV_REST = 5, EV_WROW = 6, EV_ACC = 7, EV_NEAR = 8, EV_PER_BLOCK = 9 };
+enum { EV_BLK = 0, EV_DIAG = 1, EV_PANEL = 2, EV_BULK = 3, EV_INV = 4, EV_REST = 5, EV_WROW = 6, EV_ACC = 7, EV_PER_BLOCK = 8 };
 
 // factor the diagonal block [k0, k1) of w.A in place (L_KK) and put W_KK = L_KK^-1 (lower; zeros above) into Wk (leading dimension FZ_KD)
 int intra_block_chain(mogp_model* m, Spd& w, double* Wk, int k0, int k1, hipStream_t q, int kb) {
     const int64_t ld = w.Npad;
     // MOGP_CHAIN=0: the launch-per-step form below (4 leaves, 6 small GEMMs, k_wkk) instead of the persistent kernel of chain.hip
     static const bool persistent = !(std::getenv("MOGP_CHAIN") && std::atoi(std::getenv("MOGP_CHAIN")) == 0);
-    if (persistent) {
+    if (persistent && !m->no_chain) {
         const int nouter = (w.nb + FZ_OB - 1) / FZ_OB;
         return launch_chain(w.A.p, ld, k0, k1 - k0, w.invd.p, w.logdet.p, m->d_info.p, 0, Wk, FZ_KD,
                             w.chain_flags.p + (size_t)kb * MOGP_CHAIN_FLAGS, w.chain_flags.p + (size_t)nouter * MOGP_CHAIN_FLAGS, q);
@@ -194,115 +194,17 @@ int spd_potri_fused(mogp_model* m, Spd& w) {
         return 0;
     };
     HIP_TRY(hipStreamWaitEvent(priv, start, 0));
-    // ---- look-ahead of TWO outer blocks (default; MOGP_LOOKAHEAD=1 keeps the one-block schedule below) --------------------------------
-    // With the chain of a block in one persistent launch (chain.hip, ~245 us) the one-block schedule is paced by a cycle the chain is not
-    // part of: the mini-panel of block b needs A[b+1, b] and D_{b+1} with panel b-1 applied, and those were rows of two N-tall launches
-    // (rest of panel b-1, then its next-column update / first trailing columns) that each wait ~200 us for slots on a chip full of bulk
-    // workgroups: 650 us per block whatever the chain takes (profiles/r3_c1_timeline.txt).  Here panel b is applied to the rows of blocks
-    // b+1 AND b+2 by small launches of their own ("near": the 3 blocks (b+1,b+1) | (b+2,b+1), (b+2,b+2)), and the tall launches cover
-    // rows > b+2 only, so what the chain needs from block b-1's tall launches is needed one block LATER: two periods to finish them.
-    //   priv   chain(b);  mini(b):  P_b[b+1] = A[b+1, b] W_b^T,  D_{b+1} -= P_b[b+1] P_b[b+1]^T                 [after near(b-1)]
-    //   crit   near(b):   P_b[b+2] = A[b+2, b] W_b^T,  A[b+2, b+1] -= P_b[b+2] P_b[b+1]^T,  D_{b+2} -= P_b[b+2] P_b[b+2]^T
-    //                                                                                                   [after mini(b), bulk1(b-1)]
-    //          far(b):    P_b[>b+2] = A[>b+2, b] W_b^T;  A[>b+2, b+1 .. b+2] -= P_b[>b+2] P_b[b+1 .. b+2]^T
-    //   bulk   bulk1(b):  A[>b+2, b+3] -= ...  (the columns near(b+1) and far(b+1) touch next);  bulk2(b): the rest
-    static const bool lookahead2 = !(std::getenv("MOGP_LOOKAHEAD") && std::atoi(std::getenv("MOGP_LOOKAHEAD")) == 1);
-    if (lookahead2) {
-        auto geo = [&](int b, int& k0, int& k1, int& k2, int& k3) {
-            k0 = b * FZ_OB; k1 = std::min(k0 + FZ_OB, nb); k2 = std::min(k1 + FZ_OB, nb); k3 = std::min(k2 + FZ_OB, nb);
-        };
-        auto mini = [&](int b) -> int {                  // priv
-            int k0, k1, k2, k3; geo(b, k0, k1, k2, k3);
-            const int nk = k1 - k0, na = k2 - k1;
-            if (na <= 0) return 0;
-            double* P = w.Pb[b % MOGP_NPANEL].p;
-            if (b >= MOGP_NPANEL) HIP_TRY(hipStreamWaitEvent(priv, ev(b - MOGP_NPANEL, EV_INV), 0));    // the panel buffer is free again
-            if (b >= 1) HIP_TRY(hipStreamWaitEvent(priv, ev(b - 1, EV_NEAR), 0));                      // panel b-1 is in A[b+1, b] and D_{b+1}
-            RC(panel_rows(m, w, P, Wk(b), k0, nk, k1, na, true, priv));
-            const double* Pn = P + (int64_t)k1 * MOGP_TILE * FZ_KD;
-            GemmArgs u{};
-            u.A = Pn; u.lda = FZ_KD; u.a_kmajor = 0; u.B = Pn; u.ldb = FZ_KD; u.b_kmajor = 0;
-            u.C = w.A.p + (int64_t)k1 * MOGP_TILE * (ld + 1); u.ldc = ld; u.alpha = -1.0; u.beta = 1.0;
-            u.mode = GM_RECT_LOWER; u.small = 2; u.mt = 2 * na; u.nt = 2 * na; u.K = nk * MOGP_TILE;
-            RC(gemm_call(m, u, gemm_flops(u, nullptr), priv));
-            HIP_TRY(hipEventRecord(ev(b, EV_DIAG), priv));
-            return 0;
-        };
-        RC(chain(0));
-        RC(mini(0));
-        for (int b = 0; b < nouter; ++b) {
-            int k0, k1, k2, k3; geo(b, k0, k1, k2, k3);
-            const int nk = k1 - k0, na = k2 - k1, nc = k3 - k2, nf = nb - k3;
-            const int Kd = nk * MOGP_TILE;
-            double* P = w.Pb[b % MOGP_NPANEL].p;
-            const double* P1 = P + (int64_t)k1 * MOGP_TILE * FZ_KD;       // P_b[b+1]
-            const double* P2 = P + (int64_t)k2 * MOGP_TILE * FZ_KD;       // P_b[b+2]
-            const double* Pf = P + (int64_t)k3 * MOGP_TILE * FZ_KD;       // P_b[> b+2]
-            if (b + 1 < nouter) RC(chain(b + 1));                          // priv: needs D_{b+1}, which mini(b) left ahead of it in the stream
-            if (na > 0) {
-                HIP_TRY(hipStreamWaitEvent(crit, ev(b, EV_DIAG), 0));      // W_b, P_b[b+1], a free panel buffer
-                if (nc > 0) {                                              // near(b)
-                    if (b >= 1) HIP_TRY(hipStreamWaitEvent(crit, ev(b - 1, EV_BULK), 0));   // bulk1(b-1): panel b-1 in D_{b+2} (and in A[>b+2, b+2])
-                    RC(panel_rows(m, w, P, Wk(b), k0, nk, k2, nc, true, crit));
-                    GemmArgs u{};
-                    u.A = P2; u.lda = FZ_KD; u.a_kmajor = 0; u.B = P1; u.ldb = FZ_KD; u.b_kmajor = 0;
-                    u.C = w.A.p + (int64_t)k2 * MOGP_TILE * ld + (int64_t)k1 * MOGP_TILE; u.ldc = ld; u.alpha = -1.0; u.beta = 1.0;
-                    u.mode = GM_RECT; u.small = 1; u.mt = 2 * nc; u.nt = na; u.K = Kd;
-                    RC(gemm_call(m, u, gemm_flops(u, nullptr), crit));
-                    GemmArgs v{};
-                    v.A = P2; v.lda = FZ_KD; v.a_kmajor = 0; v.B = P2; v.ldb = FZ_KD; v.b_kmajor = 0;
-                    v.C = w.A.p + (int64_t)k2 * MOGP_TILE * (ld + 1); v.ldc = ld; v.alpha = -1.0; v.beta = 1.0;
-                    v.mode = GM_RECT_LOWER; v.small = 2; v.mt = 2 * nc; v.nt = 2 * nc; v.K = Kd;
-                    RC(gemm_call(m, v, gemm_flops(v, nullptr), crit));
-                }
-                HIP_TRY(hipEventRecord(ev(b, EV_NEAR), crit));
-            }
-            if (b + 1 < nouter) RC(mini(b + 1));                           // priv: right behind chain(b+1)
-            if (nf > 0) {                                                  // far(b), crit
-                RC(panel_rows(m, w, P, Wk(b), k0, nk, k3, nf, false, crit));
-                HIP_TRY(hipEventRecord(ev(b, EV_REST), crit));
-                GemmArgs u{};
-                u.A = Pf; u.lda = FZ_KD; u.a_kmajor = 0; u.B = P1; u.ldb = FZ_KD; u.b_kmajor = 0;      // P_b[b+1 .. b+2]: consecutive rows of the buffer
-                u.C = w.A.p + (int64_t)k3 * MOGP_TILE * ld + (int64_t)k1 * MOGP_TILE; u.ldc = ld; u.alpha = -1.0; u.beta = 1.0;
-                u.mode = GM_RECT; u.mt = nf; u.nt = na + nc; u.K = Kd;
-                RC(gemm_call(m, u, gemm_flops(u, nullptr), crit));
-                HIP_TRY(hipEventRecord(ev(b, EV_PANEL), crit));
-                // bulk: trailing update of the rows and columns > b+2, block b+3's columns first
-                HIP_TRY(hipStreamWaitEvent(bulk, ev(b, EV_REST), 0));
-                const int n1 = std::min(FZ_OB, nf);
-                GemmArgs t{};
-                t.A = Pf; t.lda = FZ_KD; t.a_kmajor = 0; t.B = Pf; t.ldb = FZ_KD; t.b_kmajor = 0;
-                t.C = w.A.p + (int64_t)k3 * MOGP_TILE * (ld + 1); t.ldc = ld; t.alpha = -1.0; t.beta = 1.0;
-                t.mode = GM_RECT_LOWER; t.mt = nf; t.nt = n1; t.K = Kd;
-                RC(gemm_call(m, t, gemm_flops(t, nullptr), bulk));
-                HIP_TRY(hipEventRecord(ev(b, EV_BULK), bulk));
-                if (nf > n1) {
-                    const double* Pq = Pf + (int64_t)n1 * MOGP_TILE * FZ_KD;
-                    GemmArgs v{};
-                    v.A = Pq; v.lda = FZ_KD; v.a_kmajor = 0; v.B = Pq; v.ldb = FZ_KD; v.b_kmajor = 0;
-                    v.C = w.A.p + (int64_t)(k3 + n1) * MOGP_TILE * (ld + 1); v.ldc = ld; v.alpha = -1.0; v.beta = 1.0;
-                    v.mode = GM_LOWER; v.mt = v.nt = nf - n1; v.K = Kd;
-                    RC(gemm_call(m, v, gemm_flops(v, nullptr), bulk));
-                }
-            } else {
-                HIP_TRY(hipEventRecord(ev(b, EV_BULK), bulk));             // nothing of panel b on the bulk stream: the event still orders what follows
-            }
-            // inv: needs W_b and every row of panel b below the block
-            HIP_TRY(hipStreamWaitEvent(inv, ev(b, EV_BLK), 0));
-            if (nf > 0) HIP_TRY(hipStreamWaitEvent(inv, ev(b, EV_REST), 0));
-            else if (na > 0) HIP_TRY(hipStreamWaitEvent(inv, ev(b, EV_NEAR), 0));
-            RC(inverse_step(m, w, Wk(b), k0, k1, P1, inv, acc, ev(b, EV_WROW), b == nouter - 1 ? w_ready : nullptr));
-            HIP_TRY(hipEventRecord(ev(b, EV_INV), inv));
-            HIP_TRY(hipEventRecord(ev(b, EV_ACC), acc));
-        }
-        HIP_TRY(hipEventRecord(ev(nouter - 1, EV_DIAG), bulk));                              // reuse: everything on the bulk stream
-        HIP_TRY(hipStreamWaitEvent(crit, ev(nouter - 1, EV_BLK), 0));
-        HIP_TRY(hipStreamWaitEvent(crit, ev(nouter - 1, EV_DIAG), 0));
-        HIP_TRY(hipStreamWaitEvent(crit, w_ready, 0));
-        w.fused_last_inv = ev(nouter - 1, EV_ACC);
-        w.fused_last_wt = ev(nouter - 1, EV_INV);
-        return 0;
-    }
+    // Tried on top of the persistent chain kernel (245 us per block instead of 490) and measured SLOWER than this schedule, round 3:
+    //   * a look-ahead of two outer blocks (panel b applied to the rows of blocks b+1 and b+2 by small launches of their own, the tall
+    //     launches covering rows > b+2): 14.8 vs 13.4 ms -- the small launches queue on the critical stream behind its tall ones;
+    //   * the trailing update in three pieces (columns of block K+2, of block K+3, remainder on a stream of its own): 14.1-14.9 vs 13.4 ms,
+    //     and a FIFTH CU-masked stream slows everything on the reserved CUs (chain kernel 520-680 us instead of 245);
+    //   * the inverse's streams confined to a subset of the CUs: 15.7 ms (160 CUs) ... 54 ms (48 CUs) -- the panel buffers couple the chain
+    //     to the inverse.
+    // What the traces say (profiles/r3_c1_timeline.txt): a block period is mini-panel (140 us) -> rest of the panel (~200) -> columns of the
+    // block after next (~200) -> mini-panel, plus ~45 us per cross-stream event; the chain kernel runs next to the two tall launches, off
+    // that cycle.  And the chip is busy with GEMM tiles throughout (47-58 TFLOP/s in every 500 us window): the evaluation is bound by what
+    // five interleaved GEMM streams deliver, not by the chain.
     RC(chain(0));
     RC(next_diag(0));
     for (int kb = 0; kb < nouter; ++kb) {
