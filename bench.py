@@ -3,36 +3,38 @@
 bench.py -- BASELINE.json's headline metric on MI355X:
     log-marginal-likelihood + gradient evaluations per second, MOSM C=4 Q=3 N=8192 (configs[1]), exact GP, fp64.
 
-A "step" is one `gpr.Exact.loss()`-equivalent: term table upload, Gram build (+noise +jitter), Cholesky, triangular
-inverse, alpha / log-det, K^-1, gradient-moment pass, moments back to the host, host chain rule to the raw-parameter
-gradient.  X and y are resident in HBM before the timed region (model creation); only the O(C^2 Q) parameter table
-goes host->device per step.
+A "step" is one iteration of the reference's training loop (mogptk/model.py:563-566): `gpr.Exact.loss()` -- term table upload, Gram build
+(+noise +jitter), Cholesky, triangular inverse, alpha / log-det, K^-1, gradient-moment pass, moments back to the host, host chain rule to
+the raw-parameter gradient -- followed by an Adam update of the raw parameters (lr 1e-6: the parameters CHANGE every step, so nothing the
+host memoises between evaluations at equal parameters can hit).  X and y are resident in HBM before the timed region (model creation); only
+the O(C^2 Q) parameter table goes host->device per step.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4|cfg5] [--mode replicas|sharded]
 
---config picks the BASELINE.json configuration a step runs: cfg2 (default, the metric's own), cfg3 = the same evaluation
-at MOSM C=8 Q=5 N=32768, cfg4 = one `predict_f` of 4096 test points on CSM C=4 Q=3 N=16384, cfg5 = one Titsias ELBO+gradient
-evaluation at N=100000, M=2048.  Every config reports the same JSON line; `roofline` prices the algorithmic flops of one step
- over `ms_per_step`.
+The default line (cfg2) also carries, outside its timed region:
+  configs       the other BASELINE.json configurations on this GPU: cfg3 (MOSM C=8 Q=5 N=32768 LML+gradient), cfg4 (CSM C=4 Q=3 N=16384
+                predict_f at 4096 points), cfg5 (Titsias N=100000 M=2048 ELBO+gradient): ms_per_step, roofline fraction, steps
+  cpu_baseline  the torch-CPU port of the reference's op sequence (oracle/torch_port.py) timed on this box's host cores AT N = 8192
+  roofline / gram_hbm / moments_hbm / stages_ms_per_eval from HIP events inside the timed region
+`--config cfgN` makes that configuration the timed step instead (same JSON shape).
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU).  Two modes:
-  replicas (default)  `value` = aggregate evals/s of N independent replicas of the workload: one 15 ms evaluation does not pay for an
-                      exchange per pivot block, N GPUs are best used as N evaluations (restarts, models); scaling "weak".
-  sharded             `value` = evals/s of ONE evaluation spread over all ranks (mogp_exact_eval_sharded: owned Gram / moment tiles,
-                      one RCCL all-gather per 512-wide pivot block issued by the library on its own streams); scaling "strong".
-                      This is the mode configs[2] (`--config cfg3 --mode sharded`) is meant for.
-In replicas mode at N > 1 the sharded numbers still ride along in the extra `sharded` object (this workload and cfg3, each next to its
-one-GPU time), measured outside the timed region under a watchdog so that a stuck collective cannot cost the line.
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU):
+  replicas (default)  `value` = aggregate evals/s of N independent replicas of the workload (one 13 ms evaluation does not pay for an
+                      exchange per pivot block; N GPUs are best used as N evaluations: restarts, models); scaling "weak".  BEFORE the timed
+                      region every rank runs the `sharded` probes -- the north_star's split of ONE evaluation over the GPUs
+                      (mogp_exact_eval_sharded: owned Gram / moment tiles, one RCCL all-gather per 512-wide pivot block issued by the
+                      library on its own stream): cfg3 first, then cfg2 and the data-parallel sparse bound (cfg5).  Each probe is a child
+                      process group of its own under its own watchdog, so a stuck collective costs that probe, not the line.
+  sharded             `value` = evals/s of ONE evaluation spread over all ranks; scaling "strong" (`--config cfg3 --mode sharded` is
+                      configs[2] as BASELINE.json words it).
 
-Prints ONE JSON line (rank 0).  `roofline.frac` = algorithmic flops of a step / ms_per_step / fp64-MFMA peak; `span` / `per_launch`
-price the dominant kernel (k_gemm) from HIP events around each of its launches inside the timed region; `cpu_baseline` times the
-torch-CPU port of the reference's op sequence (oracle/torch_port.py) on this box's host cores.
+Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
-import threading
 import time
 
 import numpy as np
@@ -55,6 +57,12 @@ METRICS = {
     "predict": ("predict_f (mean+variance, %d test points) calls/sec, CSM C=%d N=%d", "calls/s"),
     "titsias": ("Titsias ELBO+grad evals/sec, MOSM C=%d N=%d M=%d", "evals/s"),
 }
+STEP_NOTE = {
+    "exact": "loss() = LML + gradient of every raw parameter, then one Adam update (lr 1e-6) of the raw parameters: the reference's training iteration (mogptk/model.py:563-566)",
+    "titsias": "loss() = ELBO + gradient of every raw parameter and of the inducing inputs, then one Adam update (lr 1e-6): the reference's training iteration",
+    "predict": "one predict_f call (factorisation + predictive mean and variance); no parameters change",
+}
+PROBES = ("cfg3", "cfg2", "cfg5", "cfg5_weak")
 
 
 def build_mosm(N, C, Q, device):
@@ -107,9 +115,24 @@ def build_model(cfg, device, n_override=None):
     return m, (lambda: m.loss()), 5.0 * float(M) ** 2 * N + 4.0 * float(M) ** 3
 
 
-def cpu_baseline(N, C, Q, budget_s=45.0):
-    """torch-CPU port of the reference op sequence, one evaluation of the same workload when it fits the time
-    budget, otherwise the largest power-of-two N that does (stated in `sample`)."""
+def training_step(m, run_step, kind):
+    """the timed step: the evaluation, then -- where there is a gradient -- one Adam update of the raw parameters (reference
+    mogptk/model.py:563-566: loss, backward, optimizer.step), so that every step sees new parameters"""
+    if kind == "predict":
+        return run_step
+    from mogptk_amd.model import _Adam
+    opt = _Adam(list(m.parameters()), lr=1e-6)
+
+    def step():
+        run_step()
+        opt.step()
+    return step
+
+
+def cpu_baseline(N, C, Q, budget_s=240.0):
+    """torch-CPU port of the reference op sequence (oracle/torch_port.py), ONE evaluation of the same workload at the same N, timed
+    directly.  Only when a probe at N = 2048 predicts more than `budget_s` for it (a very slow or very busy host) is the largest
+    power-of-two N that fits timed instead and scaled by N^3 -- `extrapolated` says which."""
     import torch
     from oracle import torch_port
     from mogptk_amd import synth, gpr
@@ -126,18 +149,24 @@ def cpu_baseline(N, C, Q, budget_s=45.0):
         torch_port.mosm_loss_and_grad(X, y, raws, C)
         return time.perf_counter() - t
 
-    n = 2048
+    n = min(2048, N)
     t = one(n)
-    while n < N and t * 8.5 < budget_s:       # ~cubic growth per doubling
-        n *= 2
-        t = one(n)
+    predicted = t * (N / n) ** 3 * 1.3            # the reference grows 6.4-8.8x per doubling here
+    if n < N and predicted <= budget_s:
+        n = N
+        t = one(N)
+    else:
+        while n * 2 <= N and t * 8.5 * 1.3 <= budget_s:
+            n *= 2
+            t = one(n)
     if n == N:
-        return dict(value=1.0 / t, unit="evals/s", cores=cores, kind="port",
+        return dict(value=1.0 / t, unit="evals/s", cores=cores, kind="port", extrapolated=False, seconds=t,
                     sample="1 LML+grad eval of the same workload (MOSM C=%d Q=%d N=%d), torch-CPU fp64 port of the "
-                           "reference op sequence, %.1f s" % (C, Q, N, t))
+                           "reference op sequence, timed directly: %.1f s" % (C, Q, N, t))
     scale = (N / n) ** 3
-    return dict(value=1.0 / (t * scale), unit="evals/s", cores=cores, kind="port",
-                sample="1 eval at N=%d took %.1f s; extrapolated to N=%d by N^3 (x%.0f)" % (n, t, N, scale))
+    return dict(value=1.0 / (t * scale), unit="evals/s", cores=cores, kind="port", extrapolated=True, seconds=t * scale,
+                sample="1 eval at N=%d took %.1f s; a direct evaluation at N=%d was predicted to exceed %.0f s on this host; "
+                       "extrapolated by N^3 (x%.0f)" % (n, t, N, budget_s, scale))
 
 
 def timed_region(step, steps, warmup, dist=None, sync=lambda: None, device="cpu"):
@@ -169,54 +198,158 @@ def aggregate_value(world, steps, dt, sharded=False):
     return (1 if sharded else world) * steps / dt
 
 
-def sharded_probe(m, dist, sync, world, cfg3=True, reps=5, out=None):
-    """Extra, outside the timed region: the SAME evaluation sharded over all ranks (mogp_exact_eval_sharded) next
-    to the one-GPU evaluation, at the bench workload and at configs[2] (MOSM C=8 Q=5 N=32768); and configs[4] data-parallel.  Reported as
-    `sharded`; `out` is filled entry by entry, so that a watchdog firing in a later entry still has the earlier ones."""
+def config_entry(cfg, ms_per_step, steps, algo_flops):
+    """one entry of the `configs` object: a BASELINE.json configuration timed on this GPU outside the headline's timed region"""
+    kind, C, Q, N, extra, desc = CONFIGS[cfg]
+    tflops = algo_flops / (ms_per_step * 1e-3) / 1e12
+    return {"workload": desc, "ms_per_step": ms_per_step, "steps": steps, "value": 1e3 / ms_per_step, "unit": METRICS[kind][1],
+            "achieved_tflops": tflops, "frac": tflops / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops": algo_flops, "step": STEP_NOTE[kind]}
+
+
+def extra_configs(device, names=("cfg3", "cfg4", "cfg5"), steps=None):
+    """the other BASELINE.json configurations on this GPU (SURVEY.md 8d asks for predict_f time at cfg4 and ELBO+gradient at cfg5 next to the
+    headline): one warm-up step, then `steps` timed steps each; the models are freed again before the next one is built"""
+    import gc
+    out = {}
+    for cfg in names:
+        kind = CONFIGS[cfg][0]
+        k = (steps or {}).get(cfg, 3 if cfg == "cfg3" else 5)
+        try:
+            m, run_step, flops = build_model(cfg, device)
+            step = training_step(m, run_step, kind)
+            step()                                     # device handle, workspaces, first-call allocations
+            step()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                step()
+            ms = 1e3 * (time.perf_counter() - t0) / k   # every call returns after its one stream sync: wall clock is device-complete
+            out[cfg] = config_entry(cfg, ms, k, flops)
+            h = getattr(m, "_handle", None)
+            if h is not None:
+                h.close()
+            del m, run_step, step
+        except Exception as e:          # a report, never a reason to lose the headline
+            out[cfg] = {"error": repr(e)}
+        gc.collect()
+    return out
+
+
+# ---- sharded probes: each one a process group of its own (one child per rank), so that a collective that never returns is killed with
+# ---- its processes and costs one entry of the line -------------------------------------------------------------------------------------
+def probe_child(name, reps):
+    """runs inside the child: rank / world from the environment, a fresh NCCL group on MASTER_PORT; rank 0 prints one JSON line"""
+    import datetime
+    import torch
+    import torch.distributed as dist
     import mogptk_amd
+    from mogptk_amd import gpr, _lib
+    rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if name in ("dummy", "hang"):                 # CPU self-test of the orchestration (tests/test_bench_dist_cpu.py): no GPU, gloo
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
+        t = torch.tensor([1.0, rank + 1.0], dtype=torch.float64)
+        dist.all_reduce(t)
+        if name == "hang" and rank == world - 1:
+            time.sleep(3600)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"rccl_ranks": int(t[0].item()), "rank_sum_ok": int(t[1].item()) == world * (world + 1) // 2}), flush=True)
+        dist.destroy_process_group()
+        return
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=180))
+    gpr.config.device = local_rank
+    if name == "cfg3":
+        m = build_mosm(32768, 8, 5, local_rank)
+    elif name == "cfg2":
+        m = build_mosm(8192, 4, 3, local_rank)
+    elif name == "cfg5":
+        m, _, _ = build_model("cfg5", local_rank)
+    elif name == "cfg5_weak":
+        m, _, _ = build_model("cfg5", local_rank, n_override=100000 * world)
+    else:
+        raise ValueError(name)
 
-    def run(model, reps):
-        mogptk_amd.use_single_device()
-        l0 = float(model.loss()); g0 = [p.grad.copy() for p in model.parameters()]
-        sync(); t = time.perf_counter()
-        for _ in range(reps):
-            model.loss()
-        sync(); t_single = (time.perf_counter() - t) / reps
-        comm = mogptk_amd.use_distributed()
-        comm.force = True
-        l1 = float(model.loss()); g1 = [p.grad.copy() for p in model.parameters()]
-        dist.barrier(); sync(); t = time.perf_counter()
-        for _ in range(reps):
-            model.loss()
-        sync(); dist.barrier(); t_shard = (time.perf_counter() - t) / reps
-        mogptk_amd.use_single_device()
-        err = max(float(np.max(np.abs(b - c)) / np.max(np.abs(c))) for b, c in zip(g1, g0))
-        return dict(ms_one_gpu=1e3 * t_single, ms_sharded=1e3 * t_shard, speedup=t_single / t_shard, evals_per_s_sharded=1.0 / t_shard,
-                    rel_loss=abs(l1 - l0) / abs(l0), rel_grad=err, transport=comm.transport)
+    def sync():
+        torch.cuda.synchronize()
 
-    if out is None:
-        out = {}
-    out["ranks"] = world
-    out["bench_workload"] = run(m, reps)
-    if cfg3:
-        # the sparse bound (configs[4]) DATA-PARALLEL: every rank holds every world-th training point, the sums over points are all-reduced
-        # inside the library (mogp_titsias_eval_sharded: M^2 + M + 3 doubles, then the (Z, X) moments); strong scaling at N = 100 000 and
-        # weak scaling at 100 000 points per rank, each next to the one-GPU evaluation of the same model
-        for tag, n5 in (("cfg5_titsias_n100000_m2048", 100000), ("cfg5_weak_%d_points_per_rank" % 100000, 100000 * world)):
-            if tag.startswith("cfg5_weak") and world == 1:
-                continue
-            try:
-                m5, _, _ = build_model("cfg5", None, n_override=n5)
-                out[tag] = run(m5, 3)
-                out[tag]["N"] = n5
-                del m5
-            except Exception as e:
-                out[tag] = {"error": repr(e)}
-        try:                                           # last: the largest exchange (one 134 MB all-gather per pivot block)
-            m3 = build_mosm(32768, 8, 5, None)         # gpr.config.device is already this rank's GPU
-            out["cfg3_mosm_c8_q5_n32768"] = run(m3, 2)
-        except Exception as e:
-            out["cfg3_mosm_c8_q5_n32768"] = {"error": repr(e)}
+    mogptk_amd.use_single_device()
+    l0 = float(m.loss()); g0 = [p.grad.copy() for p in m.parameters()]
+    sync(); t = time.perf_counter()
+    for _ in range(reps):
+        m.loss()
+    sync(); t_single = (time.perf_counter() - t) / reps
+    comm = mogptk_amd.use_distributed()
+    comm.force = True
+    seen, rsum = _lib.comm_selftest(local_rank)            # one all-reduce issued by the library over ITS communicator
+    l1 = float(m.loss()); g1 = [p.grad.copy() for p in m.parameters()]
+    dist.barrier(); sync(); t = time.perf_counter()
+    for _ in range(reps):
+        m.loss()
+    sync(); dist.barrier(); t_shard = (time.perf_counter() - t) / reps
+    res = dict(ms_one_gpu=1e3 * t_single, ms_sharded=1e3 * t_shard, speedup=t_single / t_shard, evals_per_s_sharded=1.0 / t_shard,
+               rccl_ranks=seen, rank_sum_ok=(rsum == world * (world + 1) // 2), transport=comm.transport,
+               rel_loss=abs(l1 - l0) / abs(l0),
+               rel_grad=max(float(np.max(np.abs(b - c)) / np.max(np.abs(c))) for b, c in zip(g1, g0)))
+    h = getattr(m, "_handle", None)
+    if name in ("cfg3", "cfg2") and h is not None:         # where one sharded evaluation spends its time (HIP events, summed over the pivot blocks)
+        h.set_profiling(True)
+        m.loss()
+        ex, ser, nxt, blk = [float(v) for v in h.shard_stage_ms()]
+        h.set_profiling(False)
+        res.update(exchange_ms=ex, serial_ms=ser, next_cols_ms=nxt, bulk_ms=blk,
+                   split_note="critical stream: exchange (pack, all-gather, unpack) + serial (Schur block inversion and panels, repeated on every "
+                              "rank) + next_cols; the rank's share of the bulk update runs on the bulk stream underneath")
+    if name.startswith("cfg5"):
+        res["N"] = 100000 * (world if name == "cfg5_weak" else 1)
+    mogptk_amd.use_single_device()
+    mogptk_amd.shutdown_distributed()
+    if rank == 0:
+        sys.stdout.flush()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(res), flush=True)
+    dist.destroy_process_group()
+
+
+def run_probe(name, port, timeout_s, reps):
+    """parent side, on every rank: start this rank's child of probe `name`, wait at most timeout_s, kill its process group otherwise;
+    -> the child's JSON (rank 0; other ranks get {}) or {"error": ...}"""
+    import signal
+    env = dict(os.environ, MASTER_PORT=str(port))
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("RANK", "0"); env.setdefault("LOCAL_RANK", "0"); env.setdefault("WORLD_SIZE", "1")     # a plain `python bench.py --shard-probe`
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # the child group's rank 0 hosts its own store on `port`
+    env.pop("TORCHELASTIC_RUN_ID", None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--probe-child", name, "--probe-reps", str(reps)]
+    t0 = time.perf_counter()
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        so, se = p.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except Exception:
+            p.kill()
+        try:
+            p.communicate(timeout=10)
+        except Exception:
+            pass
+        return {"error": "the probe did not finish within %.0f s (watchdog); its processes were killed" % timeout_s}
+    took = time.perf_counter() - t0
+    if p.returncode != 0:
+        return {"error": "probe exited with code %d: %s" % (p.returncode, (se or "")[-400:])}
+    lines = [l for l in (so or "").splitlines() if l.startswith("{")]
+    if not lines:
+        return {}
+    r = json.loads(lines[-1])
+    r["probe_wall_s"] = took
+    return r
+
+
+def run_probes(names, base_port, timeout_s, reps=None):
+    out = {}
+    for i, name in enumerate(names):
+        out[name] = run_probe(name, base_port + 1 + i, timeout_s, (reps or {}).get(name, 2 if name in ("cfg3", "cfg5_weak") else 3))
     return out
 
 
@@ -229,11 +362,17 @@ def main():
     ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"])
     ap.add_argument("--n", type=int, default=None, help="override the configuration's N (development)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--shard-probe", action="store_true", help="also run the sharded-evaluation probe at --gpus 1 (1-rank RCCL group)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (cfg3 / cfg4 / cfg5 on this GPU)")
+    ap.add_argument("--shard-probe", action="store_true", help="also run the sharded probes at --gpus 1 (1-rank RCCL group)")
     ap.add_argument("--no-shard-probe", action="store_true")
-    ap.add_argument("--no-cfg3-probe", action="store_true")
-    ap.add_argument("--probe-timeout", type=float, default=420.0, help="watchdog of the sharded probe in seconds")
+    ap.add_argument("--probes", default=",".join(PROBES), help="which sharded probes, in order")
+    ap.add_argument("--probe-timeout", type=float, default=240.0, help="watchdog of EACH sharded probe in seconds")
+    ap.add_argument("--probe-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--probe-reps", type=int, default=3, help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.probe_child:
+        probe_child(a.probe_child, a.probe_reps)
+        return
     kind, C, Q, N, extra, desc = CONFIGS[a.config]
     if a.n:
         N = a.n
@@ -244,6 +383,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    sharded_mode = a.mode == "sharded"       # exact / predict: one evaluation's tiles over the ranks; titsias: its data points over the ranks
+
+    # ---- the sharded probes FIRST (N > 1, replicas mode): nothing of this process is on the GPU yet, every probe is a group of child
+    # ---- processes with a watchdog of its own; a probe that hangs is killed and the line goes on
+    sharded = None
+    want_probe = (world > 1 or a.shard_probe) and not a.no_shard_probe and kind == "exact" and not sharded_mode
+    if want_probe:
+        base_port = int(os.environ.get("MASTER_PORT", "29655")) + 20
+        names = [n for n in a.probes.split(",") if n and not (n == "cfg5_weak" and world == 1)]
+        sharded = run_probes(names, base_port, a.probe_timeout)
+        sharded["ranks"] = world
+
     dist = None
     if world > 1:
         import torch
@@ -255,25 +406,26 @@ def main():
     from mogptk_amd import _lib
 
     m, run_step, algo_flops = build_model(a.config, local_rank, a.n)
-    sharded_mode = a.mode == "sharded"       # exact / predict: one evaluation's tiles over the ranks; titsias: its data points over the ranks
+    train_step = training_step(m, run_step, kind)
 
     def sync():
         if torch.cuda.is_available():
             torch.cuda.synchronize()
 
     pd = dist
-    if sharded_mode or ((world > 1 or a.shard_probe) and not a.no_shard_probe and kind == "exact"):
-        if dist is None:                    # one GPU: a 1-rank RCCL group exercises the same code path
-            import torch.distributed as dist1
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29655")
-            dist1.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-            pd = dist1
+    if sharded_mode and dist is None:           # one GPU: a 1-rank RCCL group exercises the same code path
+        import torch.distributed as dist1
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29655")
+        dist1.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        pd = dist1
 
     run_step()                    # creates the device handle (X, y resident in HBM) before anything is timed
     h = m._handle
+    rccl = None
     if sharded_mode:
         comm = mogptk_amd.use_distributed()
         comm.force = True
+        rccl = _lib.comm_selftest(local_rank)
         run_step()
     stage = np.zeros(_lib.ST_COUNT)
     acc = dict(flops=0.0, launches=0, nprof=0)
@@ -282,7 +434,7 @@ def main():
     def step(i):
         prof = i >= 0 and (i % PROFILE_EVERY) == 0 and kind == "exact" and not sharded_mode
         h.set_profiling(prof)
-        run_step()
+        train_step()
         if prof:
             ms, nl, fl = h.stage_ms()
             stage[:] += ms
@@ -296,12 +448,11 @@ def main():
     if sharded_mode:
         mogptk_amd.use_single_device()
 
-    # ---- the line without the probe: what the watchdog prints if the probe below does not come back -------------------------------
     out = None
     if rank == 0:
         ms_per_step = 1e3 * dt / steps
         value = aggregate_value(world, steps, dt, sharded_mode)
-        # The GEMM launches of one evaluation run on up to four streams at once (potri.hip), so the sum of their durations exceeds the
+        # The GEMM launches of one evaluation run on up to five streams at once (potri.hip), so the sum of their durations exceeds the
         # wall-clock time they occupy: `span` prices them over the factorisation + inversion stage, `per_launch` over the sum of their
         # own durations (what a kernel trace averages to); `frac` -- the headline -- prices the ALGORITHMIC flops over the whole step.
         gemm_s = stage[_lib.ST_GEMM_KERNEL] * 1e-3
@@ -314,13 +465,15 @@ def main():
         gram_gbs = gram_bytes * nprof / (stage[_lib.ST_GRAM_KERNEL] * 1e-3) / 1e9 if stage[_lib.ST_GRAM_KERNEL] > 0 else None
         mom_gbs = gram_bytes * nprof / (stage[_lib.ST_MOMENT_KERNEL] * 1e-3) / 1e9 if stage[_lib.ST_MOMENT_KERNEL] > 0 else None
         traffic, traffic_src = None, None
-        try:        # L2<->fabric bytes per k_gemm launch from the committed rocprofv3 --pmc passes of this same command (profiles/)
-            with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as f:
-                t = json.load(f)
-            if a.config == "cfg2" and not sharded_mode:
-                traffic, traffic_src = t["bytes_per_launch"], "profiles/r2_pmc_traffic.json: " + t["source"]
-        except Exception:
-            pass
+        for tf in ("r3_pmc_traffic.json", "r2_pmc_traffic.json"):     # L2<->fabric bytes per k_gemm launch from the committed rocprofv3 --pmc passes of this command
+            try:
+                with open(os.path.join(ROOT, "profiles", tf)) as f:
+                    t = json.load(f)
+                if a.config == "cfg2" and not sharded_mode:
+                    traffic, traffic_src = t["bytes_per_launch"], "profiles/%s: %s" % (tf, t["source"])
+                break
+            except Exception:
+                continue
         if kind == "exact":
             metric = METRICS[kind][0] % (C, N)
         elif kind == "predict":
@@ -329,19 +482,27 @@ def main():
             metric = METRICS[kind][0] % (C, N, extra)
         if a.config == "cfg2":
             metric = "log-marginal-likelihood+grad evals/sec, MOSM C=4 N=8192; 1/2/4/8 GPU"      # BASELINE.json's wording
-        par = "1 gpu" if world == 1 and not sharded_mode else (("data-parallel x%d (points cyclic over the ranks, RCCL all-reduce of the M x M sums)" % world if kind == "titsias" else
-                                                                       "sharded x%d (tile rows cyclic, RCCL all-gather per pivot block)" % world) if sharded_mode else "replicas x%d" % world)
+        if world == 1 and not sharded_mode:
+            par = "1 gpu"
+        elif sharded_mode:
+            par = ("data-parallel x%d (points cyclic over the ranks, RCCL all-reduce of the M x M sums)" % world if kind == "titsias" else
+                   "sharded x%d (tile rows cyclic, RCCL all-gather per pivot block)" % world)
+        else:
+            par = ("replicas x%d: `value` is the aggregate of %d INDEPENDENT evaluations streams, one per GPU, no collective on the data path; "
+                   "ONE evaluation split over the GPUs (the north_star's distributed Cholesky) is measured in `sharded`" % (world, world))
         out = {
             "metric": metric, "value": value, "unit": METRICS[kind][1], "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if sharded_mode else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc if not a.n else desc + " [N overridden: %d]" % N, "channels": C, "Q": Q, "N": N, "parallelism": par,
-                       "device": _lib.device_name(local_rank)},
+                       "step": STEP_NOTE[kind], "device": _lib.device_name(local_rank)},
             "roofline": {"bound": "mfma", "kernel": "k_gemm (fp64 v_mfma_f64_16x16x4_f64)", "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "basis": "algorithmic flops of one step (SURVEY.md 8d: %.3e) / ms_per_step%s" % (algo_flops, " / ranks" if sharded_mode else ""),
                          "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src},
         }
+        if rccl is not None:
+            out["config"]["rccl_ranks"] = rccl[0]
         if kind == "exact" and not sharded_mode and acc["nprof"] > 0:
             out["roofline"].update({
                 "algorithmic_bytes_per_launch": 8.0 * N * N * (N / 512.0) / max(gemm_launches / nprof, 1.0),
@@ -360,44 +521,22 @@ def main():
                                "bytes_per_launch": gram_bytes}
             out["moments_hbm"] = {"bound": "hbm", "achieved": mom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mom_gbs / HBM_PEAK_GBS if mom_gbs else None,
                                   "bytes_per_launch": gram_bytes}
-
-    def emit():
-        if rank == 0:
-            import ctypes
-            sys.stdout.flush()
-            ctypes.CDLL(None).fflush(None)      # RCCL's start-up banner sits in the C stdio buffer: get it out BEFORE the result line
-            print(json.dumps(out), flush=True)
-
-    # the CPU baseline runs BEFORE any communicator exists (RCCL proxy threads would compete with it for the host cores)
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and not sharded_mode:
-        try:
-            if a.config == "cfg2":
-                out["cpu_baseline"] = cpu_baseline(N, C, Q)
-            else:
-                out["cpu_baseline"] = {"value": None, "note": "cpu_baseline is timed on the headline configuration (cfg2) only; reference CPU timings of the "
-                                                              "other configurations are in BASELINE.md / DESIGN.md section 5"}
-        except Exception as e:      # the baseline is a report, never a reason to lose the GPU measurement
-            out["cpu_baseline"] = {"value": None, "error": repr(e)}
-    # ---- extras that may not come back: the sharded probe (collectives on hardware this code has never seen) under a watchdog --------
-    want_probe = (world > 1 or a.shard_probe) and not a.no_shard_probe and kind == "exact" and not sharded_mode
-    if want_probe:
-        done = threading.Event()
-        sharded = {}
-
-        def watchdog():
-            if not done.wait(a.probe_timeout):
-                if out is not None:                 # whatever entries were finished, plus the reason the rest is missing
-                    out["sharded"] = dict(sharded, error="the sharded probe did not finish within %.0f s (watchdog)" % a.probe_timeout)
-                emit()
-                os._exit(0)
-        threading.Thread(target=watchdog, daemon=True).start()
-        try:
-            sharded_probe(m, pd, sync, world, cfg3=not a.no_cfg3_probe, out=sharded)
-        except Exception as e:              # symmetric across ranks (same code, same inputs); the measurement above stands
-            sharded["error"] = repr(e)
-        done.set()
-        if out is not None:
+        if sharded is not None:
             out["sharded"] = sharded
+
+    # ---- the other configurations on this GPU, then the CPU baseline: outside the timed region, rank 0 at N = 1 only -----------------------
+    if rank == 0 and world == 1 and not sharded_mode and a.config == "cfg2" and not a.n:
+        if not a.no_configs:
+            h.close()                   # the headline model's 1.5 GB of workspaces are not needed any more
+            out["configs"] = extra_configs(local_rank)
+        if not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(N, C, Q)
+            except Exception as e:      # the baseline is a report, never a reason to lose the GPU measurement
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    elif rank == 0 and world == 1 and not a.no_cpu_baseline and not sharded_mode:
+        out["cpu_baseline"] = {"value": None, "note": "cpu_baseline is timed on the headline configuration (cfg2) only; reference CPU timings of the "
+                                                      "other configurations are in BASELINE.md / DESIGN.md section 5"}
 
     try:
         mogptk_amd.shutdown_distributed()
@@ -408,7 +547,11 @@ def main():
             pd.destroy_process_group()
         except Exception:
             pass
-    emit()
+    if rank == 0:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)      # RCCL's start-up banner sits in the C stdio buffer: get it out BEFORE the result line
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -164,6 +164,15 @@ int  mogp_comm_init_external(mogp_ctx* ctx, int rank, int nranks, mogp_allgather
 int  mogp_comm_destroy(mogp_ctx* ctx);
 /* kind: 0 none, 1 RCCL, 2 external */
 int  mogp_comm_info(mogp_ctx* ctx, int* kind, int* rank, int* nranks);
+/* One all-reduce ISSUED BY THE LIBRARY over the context's communicator (the call every sharded evaluation makes): every rank contributes
+ * (1, rank + 1); *ranks_seen = the number of ranks that took part, *rank_sum = n (n + 1) / 2 when they are the ranks 0 .. n-1.  A context
+ * without a communicator reports (1, 1).  What bench.py prints as `rccl_ranks` (there is no reference counterpart: the reference has no
+ * multi-GPU path). */
+int  mogp_comm_selftest(mogp_ctx* ctx, int* ranks_seen, int* rank_sum);
+/* HIP-event times (ms, summed over the pivot blocks) of the last mogp_exact_eval_sharded on this model with profiling on (mogp_set_profiling):
+ * ms[0] exchange (pack, all-gather, unpack), ms[1] the part every rank repeats (Schur block inversion and panels), ms[2] the update of the
+ * next pivot block's columns (critical stream), ms[3] the rank's share of the bulk update (bulk stream, overlaps the others). */
+int  mogp_shard_stage_ms(mogp_model* m, double* ms);
 /* mogp_exact_eval(..., MOGP_EVAL_GRAD) sharded over the context's communicator: same outputs, identical on every rank. */
 int  mogp_exact_eval_sharded(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
                              double* lml, double* moments, double* diagG, double* trG, double* jitter_abs, int64_t* info);

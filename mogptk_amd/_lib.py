@@ -61,6 +61,8 @@ SIGNATURES = {
     "mogp_comm_init_external": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "mogp_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "mogp_comm_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "mogp_comm_selftest": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "mogp_shard_stage_ms": (ctypes.c_int, [ctypes.c_void_p, c_dp]),
     "mogp_exact_eval_sharded": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, c_dp, c_dp, c_dp, c_dp, c_dp, c_i64p]),
     "mogp_exact_predict_sharded": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.c_int64, c_dp, c_dp, c_dp, c_i64p]),
     "mogp_shard_config": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
@@ -146,6 +148,13 @@ def context(device=0):
             check(l.mogp_ctx_create(int(device), ctypes.byref(h)))
             _ctx[device] = h
         return _ctx[device]
+
+
+def comm_selftest(device=0):
+    """-> (ranks_seen, rank_sum) of one library-issued all-reduce over the context's communicator (mogp_comm_selftest)"""
+    seen, rsum = ctypes.c_int(0), ctypes.c_int(0)
+    check(lib().mogp_comm_selftest(context(device), ctypes.byref(seen), ctypes.byref(rsum)))
+    return seen.value, rsum.value
 
 
 def device_name(device=0):
@@ -429,6 +438,12 @@ class ExactHandle:
         fl = ctypes.c_double(0)
         check(lib().mogp_stage_ms(self._h, _dp(ms), ctypes.byref(n), ctypes.byref(fl)))
         return ms, n.value, fl.value
+
+    def shard_stage_ms(self):
+        """(exchange, serial, next_cols, bulk) ms of the last profiled sharded evaluation"""
+        ms = np.zeros(4)
+        check(lib().mogp_shard_stage_ms(self._h, _dp(ms)))
+        return ms
 
     def fetch(self, which):
         out = np.empty(self.N if which == 2 else (self.N, self.N))

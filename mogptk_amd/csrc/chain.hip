@@ -19,6 +19,8 @@
 #include "mogp_model.h"
 #include "leaf_dev.h"
 
+#include <cstdlib>
+
 namespace mogp {
 
 #define CH_NWORK 12
@@ -275,6 +277,13 @@ __global__ __launch_bounds__(256, 1) void k_chain(ChainArgs g) {
     // a timed-out wait anywhere: the results are garbage -- say so through the pivot report (a real pivot failure, being smaller, wins)
     if (tid == 0 && __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
         atomicMin(g.info, (unsigned long long)MOGP_INFO_CHAIN_TIMEOUT);
+}
+
+// MOGP_CHAIN=0: the launch-per-step chain everywhere.  Otherwise the persistent kernel, unless this model fell back (chain_fallback) or the
+// private stream has fewer CUs than the kernel has workgroups.
+bool chain_enabled(const mogp_model* m) {
+    static const bool on = !(std::getenv("MOGP_CHAIN") && std::atoi(std::getenv("MOGP_CHAIN")) == 0);
+    return on && !m->no_chain && m->ctx->chain_ok;
 }
 
 int launch_chain(double* A, int64_t ld, int t0, int nk, double* invd, double* logdet, unsigned long long* info, long long info_base,

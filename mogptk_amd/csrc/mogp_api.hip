@@ -618,6 +618,7 @@ static int sweep_eval_scalars(mogp_model* m, double* lml, int64_t* info) {
     HIP_TRY(hipMemcpyAsync(ha.data(), m->d_alpha.p, Npad * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(&hinfo, m->d_info.p, sizeof(hinfo), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
+    if (hinfo == MOGP_INFO_CHAIN_TIMEOUT) return MOGP_RETRY_NO_CHAIN;
     if (hinfo != big) {
         if (info) *info = (int64_t)hinfo;
         return fail(MOGP_ENOTPD, "linalg.cholesky: The factorization could not be completed because the input is not "
@@ -693,18 +694,14 @@ static int ctx_streams(mogp_ctx* ctx) {
         HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
         const int ncu = prop.multiProcessorCount;
         const bool masked = reserve > 0 && 16 * reserve < ncu;
+        ctx->chain_ok = !masked || 8 * reserve >= 13;        // one 128 KB workgroup per CU: fewer reserved CUs than workgroups would never all be resident
         if (masked) {
-            std::vector<uint32_t> bulk((ncu + 31) / 32, 0u), priv((ncu + 31) / 32, 0u), invm((ncu + 31) / 32, 0u);
+            std::vector<uint32_t> bulk((ncu + 31) / 32, 0u), priv((ncu + 31) / 32, 0u);
             for (int i = 0; i < ncu; ++i) (i < 8 * reserve ? priv : bulk)[i / 32] |= 1u << (i % 32);
-            // MOGP_INV_CUS = n (experiment): the inverse's two streams see only the first n CUs of the bulk set (bit order = round robin over
-            // the XCDs), so that the Cholesky's trailing updates -- which pace the chain -- get the other CUs to themselves
-            const char* ei = std::getenv("MOGP_INV_CUS");
-            const int ninv = ei ? std::atoi(ei) : 0;
-            for (int i = 8 * reserve; i < ncu; ++i) if (ninv <= 0 || i < 8 * reserve + ninv) invm[i / 32] |= 1u << (i % 32);
             HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st_priv, (uint32_t)priv.size(), priv.data()));
             HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st2, (uint32_t)bulk.size(), bulk.data()));
-            HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st3, (uint32_t)invm.size(), invm.data()));
-            HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st4, (uint32_t)invm.size(), invm.data()));
+            HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st3, (uint32_t)bulk.size(), bulk.data()));
+            HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->st4, (uint32_t)bulk.size(), bulk.data()));
         } else {
             HIP_TRY(hipStreamCreateWithPriority(&ctx->st2, hipStreamNonBlocking, (lo + hi) / 2));
             HIP_TRY(hipStreamCreateWithPriority(&ctx->st3, hipStreamNonBlocking, lo));
@@ -773,6 +770,7 @@ int mogp_model_destroy(mogp_model* m) {
     m->k.release(); m->ws.release(); m->ws_tail.release();
     for (int b = 0; b < 2; ++b) { m->swU[b].release(); m->swUr[b].release(); }
     for (auto e : m->sw_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
+    for (auto e : m->sh_prof) { hipError_t r = hipEventDestroy(e); (void)r; }
     m->d_symv.release(); m->sh_send.release(); m->sh_recv.release();
     if (m->tw) { m->tw->release(); delete m->tw; m->tw = nullptr; }
     m->oa.release();
@@ -851,7 +849,13 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     const bool fused = !sweep && (flags & MOGP_EVAL_GRAD) && (grad_path == "fused" || (grad_path != "phases" && m->nb <= 80));
     const bool grad = (flags & MOGP_EVAL_GRAD) != 0;
     GramArgs ga{};
-    if (sweep) { if ((rc = eval_sweep(m, noise_var, data_var, jitter, lml, jitter_abs, info))) return rc; }
+    if (sweep) {
+        if ((rc = eval_sweep(m, noise_var, data_var, jitter, lml, jitter_abs, info))) {
+            if (rc != MOGP_RETRY_NO_CHAIN) return rc;
+            if ((rc = chain_fallback(m))) return rc;
+            return mogp_exact_eval(m, noise_var, data_var, jitter, flags, lml, moments, diagG, trG, jitter_abs, info);
+        }
+    }
     else if ((rc = factorize(m, noise_var, data_var, jitter, lml, jitter_abs, info, fused, grad, &ga))) {
         if (rc != MOGP_RETRY_NO_CHAIN) return rc;
         if ((rc = chain_fallback(m))) return rc;
@@ -1109,6 +1113,14 @@ int mogp_gram_ex(mogp_ctx* ctx, int C, int D, int T, int width, const double* ta
     return MOGP_OK;
 }
 
+// A chain-kernel time-out inside a sharded evaluation cannot be repeated here (the other ranks are past their collectives).  One GPU per
+// rank means nothing else competes for the reserved CUs, so it is not expected; the rank switches to the launch-per-step chain and reports.
+static int sharded_rc(mogp_model* m, int rc) {
+    if (rc != MOGP_RETRY_NO_CHAIN) return rc;
+    if ((rc = chain_fallback(m))) return rc;
+    return fail(MOGP_EHIP, "chain kernel: a hand-off timed out inside a sharded evaluation; this rank uses the launch-per-step chain from now on -- repeat the call on every rank");
+}
+
 // ---- sharded evaluation (one process per GPU; collectives are issued by the caller between these calls) --------------------
 int mogp_shard_config(mogp_model* m, int rank, int nranks) {
     if (!m || nranks < 1 || rank < 0 || rank >= nranks) return fail(MOGP_EINVAL, "mogp_shard_config: bad argument");
@@ -1191,7 +1203,7 @@ int mogp_shard_finish(mogp_model* m, double* lml, double* moments, double* diagG
     int rc;
     if ((rc = use_device(m->ctx))) return rc;
     if (info) *info = 0;
-    if ((rc = sweep_eval_scalars(m, lml, info))) return rc;
+    if ((rc = sweep_eval_scalars(m, lml, info))) return sharded_rc(m, rc);
     if ((rc = mark(m, 5))) return rc;
     if ((rc = moment_pass(m, m->k.A.p, -1.0, moments, diagG))) return rc;
     m->have_Kinv = true; m->kinv_in_A = true;
@@ -1207,13 +1219,21 @@ static int sharded_inverse(mogp_model* m, const double* noise_var, const double*
     if ((rc = sweep_prepare(m, m->k))) return rc;
     if (jitter_abs) *jitter_abs = m->sh_jabs;
     const int nblocks = sweep_nblocks(m->k);
+    m->sh_prof_blocks = 0;
+    if (m->profiling) {
+        while ((int)m->sh_prof.size() < 6 * nblocks) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); m->sh_prof.push_back(e); }
+        m->sh_prof_blocks = nblocks;
+    }
     for (int kb = 0; kb < nblocks; ++kb) {
         double *send = nullptr, *recv = nullptr;
         int64_t count = 0;
+        hipEvent_t* pe = m->profiling ? m->sh_prof.data() + 6 * kb : nullptr;
+        if (pe) HIP_TRY(hipEventRecord(pe[0], m->st));
         if ((rc = shard_pack(m, m->k, kb, &send, &recv, &count))) return rc;
         if ((rc = comm_allgather(m->ctx, send, recv, count, m->st))) return rc;       // stream ordered: no host round trip with RCCL
         if ((rc = shard_unpack(m, m->k, kb))) return rc;
-        if ((rc = sweep_block(m, m->k, kb))) return rc;
+        if (pe) HIP_TRY(hipEventRecord(pe[1], m->st));
+        if ((rc = sweep_block(m, m->k, kb, pe ? pe + 2 : nullptr))) return rc;
     }
     if ((rc = sweep_finish(m, m->k))) return rc;
     if ((rc = sweep_eval_alpha(m))) return rc;                                         // owned-row partial sums of alpha
@@ -1234,7 +1254,17 @@ int mogp_exact_eval_sharded(mogp_model* m, const double* noise_var, const double
     if ((rc = comm_allreduce(m->ctx, m->d_diagG.p, C, m->st))) return rc;
     HIP_TRY(hipMemcpyAsync(moments, m->d_moments.p, (size_t)P * T * W * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(diagG, m->d_diagG.p, C * sizeof(double), hipMemcpyDeviceToHost, m->st));
-    if ((rc = sweep_eval_scalars(m, lml, info))) return rc;                            // syncs the stream
+    if ((rc = sweep_eval_scalars(m, lml, info))) return sharded_rc(m, rc);             // syncs the stream
+    if (m->sh_prof_blocks > 0) {
+        for (hipStream_t q : {m->st2, m->st2u}) if (q) HIP_TRY(hipStreamSynchronize(q));
+        double acc4[4] = {0, 0, 0, 0};
+        for (int kb = 0; kb < m->sh_prof_blocks; ++kb) {
+            hipEvent_t* pe = m->sh_prof.data() + 6 * kb;
+            const int a_[4] = {0, 1, 2, 4}, b_[4] = {1, 2, 3, 5};       // exchange | serial part (inversion + panels) | next-block columns | bulk
+            for (int i = 0; i < 4; ++i) { float t = 0.f; if (hipEventElapsedTime(&t, pe[a_[i]], pe[b_[i]]) == hipSuccess) acc4[i] += t; }
+        }
+        for (int i = 0; i < 4; ++i) m->sh_ms[i] = acc4[i];
+    }
     double tr = 0.0;
     for (int c = 0; c < C; ++c) tr += diagG[c];
     *trG = tr;
@@ -1284,7 +1314,7 @@ int mogp_exact_predict_sharded(mogp_model* m, const double* noise_var, const dou
     // 1. the inversion, sharded exactly like the gradient evaluation: owned rows of -Kj^-1 in k.A, alpha complete on every rank
     if ((rc = sharded_inverse(m, noise_var, data_var, jitter, nullptr))) return rc;
     double lml = 0.0;
-    if ((rc = sweep_eval_scalars(m, &lml, info))) return rc;                           // failure report (not positive definite)
+    if ((rc = sweep_eval_scalars(m, &lml, info))) return sharded_rc(m, rc);            // failure report (not positive definite)
     // 2. ONE all-gather of the owned tile rows -> the full Kj^-1 (lower) in k.B on every rank, then mirrored
     const int maxrows = (nb + P - 1) / P;
     const int64_t chunk = (int64_t)maxrows * MOGP_TILE * Npad;
@@ -1350,6 +1380,34 @@ int mogp_exact_predict_sharded(mogp_model* m, const double* noise_var, const dou
     HIP_TRY(hipStreamSynchronize(m->st));
     for (int64_t pos = 0; pos < S; ++pos) { mu[ss.perm[pos]] = hmu[pos]; var[ss.perm[pos]] = hv[pos]; }
     m->have_Kinv = false; m->have_W = false;
+    return MOGP_OK;
+}
+
+int mogp_shard_stage_ms(mogp_model* m, double* ms) {
+    if (!m || !ms) return fail(MOGP_EINVAL, "mogp_shard_stage_ms: bad argument");
+    for (int i = 0; i < 4; ++i) ms[i] = m->sh_ms[i];
+    return MOGP_OK;
+}
+
+int mogp_comm_selftest(mogp_ctx* ctx, int* ranks_seen, int* rank_sum) {
+    if (!ctx || !ranks_seen || !rank_sum) return fail(MOGP_EINVAL, "mogp_comm_selftest: bad argument");
+    int rc;
+    if ((rc = use_device(ctx))) return rc;
+    if ((rc = ctx_streams(ctx))) return rc;
+    double h[2] = {1.0, (double)(ctx->comm.rank + 1)};
+    double* d = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), sizeof(h)));
+    hipError_t e = hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, ctx->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->st);
+    if (e == hipSuccess && (rc = comm_allreduce(ctx, d, 2, ctx->st)) == 0) {
+        e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->st);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->st);
+    }
+    hipError_t e2 = hipFree(d); (void)e2;
+    if (rc) return rc;
+    HIP_TRY(e);
+    *ranks_seen = (int)(h[0] + 0.5);
+    *rank_sum = (int)(h[1] + 0.5);
     return MOGP_OK;
 }
 

@@ -87,6 +87,7 @@ struct mogp_ctx {
     // streams shared by every model of the context (created once: a CU-masked stream owns a hardware queue, and models come and go)
     hipStream_t st = nullptr, st2 = nullptr, st3 = nullptr, st4 = nullptr, st5 = nullptr, st_priv = nullptr, st2u = nullptr;
     bool streams_ready = false;
+    bool chain_ok = true;               // the private stream has room for the 13 workgroups of the persistent chain kernel (chain.hip)
 };
 
 struct TrtriLevel {
@@ -200,6 +201,9 @@ struct mogp_model {
     DevBuf<int> d_pair_start_own;
     int own_rank = -1, own_n = 0;       // (rank, nranks) the owned lists were built for
     DevBuf<double> sh_send, sh_recv;
+    std::vector<hipEvent_t> sh_prof;    // profiling (mogp_set_profiling) of a sharded evaluation: 6 timing events per pivot block
+    double sh_ms[4] = {0, 0, 0, 0};     // ... summed over the blocks: exchange, serial part, next-block columns, bulk update (mogp_shard_stage_ms)
+    int sh_prof_blocks = 0;
     double sh_jabs = 0.0;
     bool sh_dvar = false;
 
@@ -253,6 +257,7 @@ inline GemmArgs make_gemm(const double* A, int64_t lda, int akm, const double* B
 int side_fork(mogp_model* m, TitsiasWork& t, hipStream_t* side);
 int side_join(mogp_model* m, TitsiasWork& t, hipStream_t side);
 int spd_check_info(mogp_model* m, const char* which, int64_t* info);
+bool chain_enabled(const mogp_model* m);   // chain.hip
 int chain_fallback(mogp_model* m);     // mogp_api.hip: after MOGP_INFO_CHAIN_TIMEOUT -- drain, switch the model to the launch-per-step chain; the caller repeats the evaluation
 // w.A (SPD, lower tiles) -> w.B = its inverse (lower tiles, full diagonal tiles) and *W = L^-1 (lower; in w.A, or in w.Wm on the fused path),
 // w.logdet per tile: POTRF, TRTRI, LAUUM.  MOGP_SPARSE_FUSED=1 takes the fused factorisation + inversion schedule of the exact path
@@ -271,7 +276,7 @@ int spd_lauum(mogp_model* m, Spd& w);
 int spd_sweep(mogp_model* m, Spd& w);
 int sweep_prepare(mogp_model* m, Spd& w);
 int sweep_nblocks(const Spd& w);
-int sweep_block(mogp_model* m, Spd& w, int kb);
+int sweep_block(mogp_model* m, Spd& w, int kb, hipEvent_t* prof = nullptr);   // prof (4 timing events or null): panels ready / next-block columns done (critical stream), bulk start / end
 int sweep_finish(mogp_model* m, Spd& w);
 // B (nb*128 rows x ncols, leading dimension ldb, ncols a multiple of 128) <- L^-1 B  (trans: L^-T B) by blocked substitution, in place;
 // L lower triangular nb*128 square with leading dimension ldl, diagonal tiles included (Spd::keep_L).  trsm.hip

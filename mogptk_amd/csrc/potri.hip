@@ -48,8 +48,7 @@ enum { EV_BLK = 0, EV_DIAG = 1, EV_PANEL = 2, EV_BULK = 3, EV_INV = 4, EV_REST =
 int intra_block_chain(mogp_model* m, Spd& w, double* Wk, int k0, int k1, hipStream_t q, int kb) {
     const int64_t ld = w.Npad;
     // MOGP_CHAIN=0: the launch-per-step form below (4 leaves, 6 small GEMMs, k_wkk) instead of the persistent kernel of chain.hip
-    static const bool persistent = !(std::getenv("MOGP_CHAIN") && std::atoi(std::getenv("MOGP_CHAIN")) == 0);
-    if (persistent && !m->no_chain) {
+    if (chain_enabled(m)) {
         const int nouter = (w.nb + FZ_OB - 1) / FZ_OB;
         return launch_chain(w.A.p, ld, k0, k1 - k0, w.invd.p, w.logdet.p, m->d_info.p, 0, Wk, FZ_KD,
                             w.chain_flags.p + (size_t)kb * MOGP_CHAIN_FLAGS, w.chain_flags.p + (size_t)nouter * MOGP_CHAIN_FLAGS, q);

@@ -12,6 +12,7 @@
 // be written in place.
 #include "mogp_model.h"
 
+#include <cstdlib>
 #include <limits>
 
 using namespace mogp;
@@ -51,11 +52,13 @@ int sweep_nblocks(const Spd& w) { return (w.nb + SW_OB - 1) / SW_OB; }
 
 // one pivot block.  With m->sh_n > 1 (sharded evaluation) the chain (P, panels) is repeated by every rank from the assembled
 // authoritative panel and the rank-Kd update touches only the tile rows this rank owns (row i is owned by rank i % sh_n).
-int sweep_block(mogp_model* m, Spd& w, int kb) {
+int sweep_block(mogp_model* m, Spd& w, int kb, hipEvent_t* prof) {
     const int nb = w.nb;
     const int64_t ld = w.Npad;
     const int rm = m->sh_n > 1 ? m->sh_n : 0, rr = m->sh_rank;
-    hipStream_t q1 = m->st, q2 = (w.nb > MOGP_CHAIN_BOUND_TILES && m->st2u) ? m->st2u : m->st2;      // see spd_potrf
+    // bulk stream: see spd_potrf; a rank of a sharded evaluation updates 1 / sh_n of the rows, so its chain matters at every size
+    static const int force_masked = std::getenv("MOGP_SWEEP_MASKED") ? std::atoi(std::getenv("MOGP_SWEEP_MASKED")) : 0;    // measurement switch
+    hipStream_t q1 = m->st, q2 = (rm == 0 && !force_masked && w.nb > MOGP_CHAIN_BOUND_TILES && m->st2u) ? m->st2u : m->st2;
     double* A = w.A.p;
     const int k0 = kb * SW_OB, k1 = std::min(k0 + SW_OB, nb), nk = k1 - k0;
     const int64_t Kd = (int64_t)nk * MOGP_TILE;
@@ -64,12 +67,34 @@ int sweep_block(mogp_model* m, Spd& w, int kb) {
     double* Akk = A + (int64_t)k0 * MOGP_TILE * (ld + 1);
     double* Acol = A + (int64_t)k1 * MOGP_TILE * ld + (int64_t)k0 * MOGP_TILE;      // A[O>][K]
     double* Arow = A + (int64_t)k0 * MOGP_TILE * ld;                                  // A[K][O<]
-    // ---- P = S^-1 on the critical stream
-    RC(launch_copy2d(s.A.p, Kd, Akk, ld, Kd, Kd, 1.0, q1));
-    RC(spd_potrf(m, s, (long long)k0 * MOGP_TILE));
-    HIP_TRY(hipMemcpyAsync(w.logdet.p + k0, s.logdet.p, nk * sizeof(double), hipMemcpyDeviceToDevice, q1));
-    RC(spd_trtri(m, s));
-    RC(spd_lauum(m, s));
+    // ---- P = S^-1 on the critical stream.  With the persistent chain kernel (chain.hip): ONE launch factors the block in place and leaves
+    // W = L^-1, then P = W^T W -- instead of a copy, 4 leaves + 6 small GEMMs, 5 launches of the triangular inverse and the LAUUM product
+    // (~0.8 ms of dependent launches per block: the part of a sharded evaluation that every rank repeats).  The kernel's workgroups need
+    // CUs with 128 KB of LDS free: they find them on the reserved CUs as long as the bulk stream is masked off those (q2 == st2) and the
+    // ranks do not share a GPU (external communicator = the test suite's ranks on one device: two such kernels would starve each other).
+    const bool chain = chain_enabled(m) && q2 == m->st2 && m->st_priv && m->ctx->comm.kind != MOGP_COMM_EXTERNAL;
+    if (chain) {
+        const int nouter = (nb + SW_OB - 1) / SW_OB;
+        if (s.Wm.n < (size_t)Kd * Kd) {
+            RC(s.Wm.ensure((size_t)Kd * Kd));
+            HIP_TRY(hipMemsetAsync(s.Wm.p, 0, (size_t)Kd * Kd * sizeof(double), q1));     // the tiles above the diagonal are never written
+        }
+        RC(w.chain_flags.ensure((size_t)(nouter + 1) * MOGP_CHAIN_FLAGS));
+        if (kb == 0) HIP_TRY(hipMemsetAsync(w.chain_flags.p, 0, (size_t)(nouter + 1) * MOGP_CHAIN_FLAGS * sizeof(unsigned), q1));
+        RC(launch_chain(A, ld, k0, nk, w.invd.p, w.logdet.p, m->d_info.p, 0, s.Wm.p, Kd, w.chain_flags.p + (size_t)kb * MOGP_CHAIN_FLAGS,
+                        w.chain_flags.p + (size_t)nouter * MOGP_CHAIN_FLAGS, q1));
+        GemmArgs g{};
+        g.A = s.Wm.p; g.lda = Kd; g.a_kmajor = 1; g.B = s.Wm.p; g.ldb = Kd; g.b_kmajor = 1;
+        g.C = s.B.p; g.ldc = Kd; g.alpha = 1.0; g.beta = 0.0;
+        g.mode = GM_LAUUM; g.mt = g.nt = nk; g.K = (int)Kd;
+        RC(gemm_call(m, g, gemm_flops(g, nullptr), q1));
+    } else {
+        RC(launch_copy2d(s.A.p, Kd, Akk, ld, Kd, Kd, 1.0, q1));
+        RC(spd_potrf(m, s, (long long)k0 * MOGP_TILE));
+        HIP_TRY(hipMemcpyAsync(w.logdet.p + k0, s.logdet.p, nk * sizeof(double), hipMemcpyDeviceToDevice, q1));
+        RC(spd_trtri(m, s));
+        RC(spd_lauum(m, s));
+    }
     RC(launch_symmetrize(s.B.p, Kd, Kd, q1));
     const double* P = s.B.p;
     // ---- old panels out, new panels X = U P in place, diagonal block = -P
@@ -90,6 +115,7 @@ int sweep_block(mogp_model* m, Spd& w, int kb) {
     }
     RC(launch_copy2d(Akk, ld, P, Kd, Kd, Kd, -1.0, q1));
     HIP_TRY(hipEventRecord(m->sw_ev[2 * kb], q1));                                     // X(kb) ready
+    if (prof) HIP_TRY(hipEventRecord(prof[0], q1));
     // ---- rank-Kd update of everything outside the pivot block
     const int nk2 = std::min(SW_OB, below);                                            // tile columns of the next pivot block
     if (kb > 0) HIP_TRY(hipStreamWaitEvent(q1, m->sw_ev[2 * (kb - 1) + 1], 0));        // a1/b1 share tiles with bulk(kb-1)
@@ -103,7 +129,9 @@ int sweep_block(mogp_model* m, Spd& w, int kb) {
             RC(gemm_call(m, b1, gemm_flops(b1, nullptr), q1));
         }
     }
+    if (prof) HIP_TRY(hipEventRecord(prof[1], q1));
     HIP_TRY(hipStreamWaitEvent(q2, m->sw_ev[2 * kb], 0));
+    if (prof) HIP_TRY(hipEventRecord(prof[2], q2));
     const int rest = below - nk2;
     if (rest > 0) {
         const int64_t r0 = (int64_t)(k1 + nk2) * MOGP_TILE;
@@ -122,6 +150,7 @@ int sweep_block(mogp_model* m, Spd& w, int kb) {
         c.row_mod = rm; c.row_rem = rr; c.row_off = 0;
         RC(gemm_call(m, c, gemm_flops(c, nullptr), q2));
     }
+    if (prof) HIP_TRY(hipEventRecord(prof[3], q2));
     HIP_TRY(hipEventRecord(m->sw_ev[2 * kb + 1], q2));                                 // bulk(kb) done
     return 0;
 }

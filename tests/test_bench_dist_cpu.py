@@ -40,3 +40,46 @@ def test_two_rank_timing_and_aggregate(tmp_path):
     assert r["world"] == 2
     assert r["dt"] >= 5 * 0.02 * 0.9                       # the slow rank (20 ms/step) sets the time
     assert abs(r["value"] - 2 * 5 / r["dt"]) < 1e-9        # whole-job aggregate over both ranks
+
+
+PROBE_WORKER = textwrap.dedent('''
+    import os, sys, json
+    sys.path.insert(0, %r)
+    import bench
+    rank = int(os.environ["RANK"])
+    base = int(os.environ["MASTER_PORT"]) + 20
+    out = bench.run_probes(["dummy", "hang"], base, timeout_s=25.0)
+    if rank == 0:
+        print(json.dumps(out))
+''')
+
+
+def test_sharded_probes_are_child_groups_with_their_own_watchdog(tmp_path):
+    """bench.py at N > 1 runs every sharded probe as a process group of its own BEFORE the timed region: two ranks each start a child, the
+    children rendezvous on a port of their own (gloo here), rank 0's child reports through stdout; a probe whose collective never returns
+    is killed by its watchdog and costs that entry only (`dummy` = one all-reduce of (1, rank + 1), `hang` = a rank that never arrives)."""
+    import json
+    script = tmp_path / "probe_worker.py"
+    script.write_text(PROBE_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29641", str(script)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["dummy"]["rccl_ranks"] == 2 and r["dummy"]["rank_sum_ok"] is True, r
+    assert r["dummy"]["probe_wall_s"] > 0
+    assert "watchdog" in r["hang"]["error"], r
+
+
+def test_line_objects_have_the_keys_the_driver_reads():
+    """`configs` entries (cfg3 / cfg4 / cfg5 on the GPU of the default line) and the cpu_baseline flag, without a GPU"""
+    sys.path.insert(0, ROOT)
+    import bench
+    e = bench.config_entry("cfg3", 550.0, 3, float(32768) ** 3)
+    assert set(["ms_per_step", "frac", "steps", "workload", "value", "unit"]) <= set(e)
+    assert abs(e["frac"] - (32768.0 ** 3 / 0.55 / 1e12) / bench.FP64_MFMA_PEAK_TFLOPS) < 1e-12
+    assert bench.config_entry("cfg4", 49.0, 5, 2.57e12)["unit"] == "calls/s"
+    assert set(bench.PROBES) >= {"cfg3", "cfg2", "cfg5"} and bench.PROBES[0] == "cfg3"       # the cfg3 probe runs first
+    b = bench.cpu_baseline(256, 2, 2)              # tiny: timed directly at its own N
+    assert b["extrapolated"] is False and b["kind"] == "port" and b["value"] > 0 and "N=256" in b["sample"]
