@@ -56,13 +56,44 @@ def _num(v):
     return np.array(v, dtype=np.float64)
 
 
+# What a checkpoint written by the reference's Model.save() needs besides its own classes: torch's tensor / storage rebuilders, the containers
+# torch.nn.Module state uses, numpy's array rebuilders and a few builtins.  Nothing else is resolved: a crafted "checkpoint" naming os.system
+# (the reference's plain pickle.load would run it) raises instead.
+_ALLOWED_MODULE_PREFIXES = ("torch._utils", "torch.nn.modules.", "torch.nn.parameter", "torch._tensor", "torch.storage", "torch.serialization",
+                            "numpy.core.multiarray", "numpy._core.multiarray", "numpy.core.numeric", "numpy._core.numeric")
+_ALLOWED_NAMES = {
+    "torch": {"FloatStorage", "DoubleStorage", "LongStorage", "IntStorage", "BoolStorage", "HalfStorage", "ByteStorage", "Size", "device", "dtype",
+              "float32", "float64", "int64", "int32", "bool", "Tensor", "UntypedStorage"},
+    "numpy": {"dtype", "ndarray", "float64", "float32", "int64", "int32", "bool_"},
+    "collections": {"OrderedDict"},
+    "builtins": {"set", "frozenset", "slice", "complex", "list", "dict", "tuple", "bytearray", "range", "object", "int", "float", "bool", "str", "bytes"},
+    "copyreg": {"_reconstructor"},
+    "functools": {"partial"},
+    "_operator": {"mul", "add", "sub", "truediv", "neg", "pow"},     # what peg transforms are made of                  # harmless by itself: whatever it wraps is resolved through this same list
+    "datetime": {"datetime", "timedelta", "date"},
+    "pandas._libs.tslibs.timestamps": {"_unpickle_timestamp", "Timestamp"},
+}
+
+
+def _load_storage_bytes(b):
+    """torch.storage._load_from_bytes is torch.load(bytes) -- a second, unrestricted pickle inside the first.  A storage needs no more than
+    torch's weights-only loader."""
+    import io
+    import torch
+    return torch.load(io.BytesIO(b), weights_only=True)
+
+
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if module == "mogptk.gpr.parameter" and name == "Parameter._rebuild":
             return _RefParameter
         if module == "mogptk" or module.startswith("mogptk."):
             return type(name.split(".")[-1], (_Bag,), {"_mod": module, "_cls": name.split(".")[-1]})
-        return super().find_class(module, name)
+        if module == "torch.storage" and name == "_load_from_bytes":
+            return _load_storage_bytes
+        if name in _ALLOWED_NAMES.get(module, ()) or any(module == p.rstrip(".") or module.startswith(p) for p in _ALLOWED_MODULE_PREFIXES):
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError("reference checkpoint names %s.%s, which a mogptk checkpoint has no use for: refused" % (module, name))
 
 
 def is_reference_checkpoint(raw):
@@ -194,14 +225,14 @@ def _assign_parameters(ours, theirs):
 
 
 # ---- likelihoods ---------------------------------------------------------------------------------------------------------------------
-def _convert_likelihood(bag):
+def _convert_likelihood(bag, variational=False):
     """same class, same link / degrees of freedom / quadrature degree, default parameter values (overwritten afterwards, in order)"""
     name, st = bag.cls(), bag.state()
     cls = getattr(_gpr, name, None)
     if cls is None or not isinstance(cls, type) or not issubclass(cls, _gpr.Likelihood):
         raise NotImplementedError("checkpoint uses the likelihood %s, which this package does not have" % name)
     if name == "MultiOutputLikelihood":
-        return cls(*[_convert_likelihood(l) for l in _module_children(st["_modules"]["likelihoods"])])
+        return cls(*[_convert_likelihood(l, variational) for l in _module_children(st["_modules"]["likelihoods"])])
     kw = {}
     if "link" in st:                                           # pickled by name: the unpickler turned `mogptk.gpr.likelihood.exp` into a bag TYPE
         link = getattr(_gpr, getattr(st["link"], "_cls", None) or getattr(st["link"], "__name__", ""), None)
@@ -217,6 +248,10 @@ def _convert_likelihood(bag):
     params = st.get("_parameters", {})
     for pname, ref in params.items():                          # shapes: a per-channel Gaussian scale changes output_dims
         if ref is not None and pname == "scale" and name == "GaussianLikelihood" and ref.data.ndim == 1:
+            if variational:
+                # GaussianLikelihood.variational_expectation takes a scalar scale only: such a model would load and then fail on its first loss()
+                raise NotImplementedError("the checkpoint's variational model has a per-channel Gaussian noise scale; its variational expectation "
+                                          "is not implemented here (use MultiOutputLikelihood of Gaussian likelihoods)")
             lik = cls(np.ones(ref.data.shape[0]))
     return lik
 
@@ -245,10 +280,10 @@ def _convert_model(bag):
         inference = _model.Snelson(inducing_points=np.array(Z.data), jitter=float(g["jitter"]))
     elif inference_name in ("SparseHensman", "Hensman"):
         sparse = bool(g.get("is_sparse", inference_name == "SparseHensman"))
-        inference = _model.Hensman(inducing_points=(np.array(g["_parameters"]["Z"].data) if sparse else None), likelihood=_convert_likelihood(lik),
+        inference = _model.Hensman(inducing_points=(np.array(g["_parameters"]["Z"].data) if sparse else None), likelihood=_convert_likelihood(lik, True),
                                    jitter=float(g["jitter"]))
     elif inference_name == "OpperArchambeau":
-        inference = _model.OpperArchambeau(likelihood=_convert_likelihood(lik), jitter=float(g["jitter"]))
+        inference = _model.OpperArchambeau(likelihood=_convert_likelihood(lik, True), jitter=float(g["jitter"]))
     else:
         raise NotImplementedError("inference %s is not part of this package" % inference_name)
     kernel = _convert_kernel(g["_modules"]["kernel"])

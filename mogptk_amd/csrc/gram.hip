@@ -909,24 +909,54 @@ __global__ __launch_bounds__(256) void k_moments(MomentArgs a) {
     }
 
     if (ZG) {
-        // rows: the 16 threads of a row group (cg = 0..15) are consecutive lanes -> butterfly, then one LDS add;
-        // columns: LDS atomics; finally one global atomic per point and dimension
-        __syncthreads();
+        // rows: the 16 threads of a row group (cg = 0..15) are consecutive lanes -> butterfly; columns: the 16 row groups' values of a column
+        // go through LDS and are added in row-group order.  The tile's sums land in ITS slot of the scratch (no atomics anywhere: the order
+        // of every sum is fixed); k_gz_reduce adds the slots of a block.
+        double* stage = s_red[0];                              // [16 row groups][64 columns]
+        for (int d = 0; d < D; ++d) {
+            __syncthreads();
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-            for (int d = 0; d < D; ++d) {
+            for (int m = 0; m < 4; ++m) {
                 double v = zr[m][d];
 #pragma unroll
                 for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
                 if (cg == 0) s_gr[d][rg * 4 + m] = v;
-                atomicAdd(&s_gc[d][cg * 4 + m], zc[m][d]);
+                stage[rg * MOGP_GT + cg * 4 + m] = zc[m][d];
             }
+            __syncthreads();
+            if (tid < MOGP_GT) {
+                double v = 0.0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v += stage[r * MOGP_GT + tid];
+                s_gc[d][tid] = v;
+            }
+        }
         __syncthreads();
+        double* slot_r = a.gzp + ((size_t)tl.rb * a.ncb + tl.cb) * D * MOGP_GT;
+        double* slot_c = a.gzp + (size_t)a.nrb * a.ncb * D * MOGP_GT + ((size_t)tl.cb * a.nrb + tl.rb) * D * MOGP_GT;
         for (int idx = tid; idx < D * MOGP_GT; idx += 256) {
             const int d = idx / MOGP_GT, pnt = idx - d * MOGP_GT;
-            if (a.gzr && pnt < tl.nr) atomicAdd(&a.gzr[(size_t)d * a.ldgz + tl.r0 + pnt], s_gr[d][pnt]);
-            if (a.gzc && pnt < tl.nc) atomicAdd(&a.gzc[(size_t)d * a.ldgz + tl.c0 + pnt], s_gc[d][pnt]);
+            if (a.gzr) slot_r[idx] = pnt < tl.nr ? s_gr[d][pnt] : 0.0;
+            if (a.gzc) slot_c[idx] = pnt < tl.nc ? s_gc[d][pnt] : 0.0;
         }
+    }
+}
+
+// out[d][first + pnt] += sum over the `nminor` slots of block b (slot layout [block][minor][d][64]), in slot order: four interleaved partial
+// sums per point, combined as (s0 + s1) + (s2 + s3).  Slots no tile wrote are zero (the scratch is cleared per launch).
+__global__ __launch_bounds__(256) void k_gz_reduce(const double* __restrict__ gzp, int nminor, int D, const int* __restrict__ blk,
+                                                   double* __restrict__ out, int64_t ld) {
+    const int b = blockIdx.x, pnt = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int first = blk[2 * b], n = blk[2 * b + 1];
+    __shared__ double red[4][MOGP_GT];
+    const double* base = gzp + (size_t)b * nminor * D * MOGP_GT;
+    for (int d = 0; d < D; ++d) {
+        double s = 0.0;
+        for (int k = part; k < nminor; k += 4) s += base[((size_t)k * D + d) * MOGP_GT + pnt];
+        __syncthreads();
+        red[part][pnt] = s;
+        __syncthreads();
+        if (part == 0 && pnt < n) out[(size_t)d * ld + first + pnt] += (red[0][pnt] + red[1][pnt]) + (red[2][pnt] + red[3][pnt]);
     }
 }
 
@@ -958,7 +988,16 @@ int launch_moments(const MomentArgs& a0, hipStream_t s) {
         return rc;
     }
     if (env) { set_error("the dense-adjoint moment pass (Titsias) does not take terms with an envelope"); return -1; }
-    if (a.gzr || a.gzc) return launch_moments_t<true, true, false>(a, s);
+    if (a.gzr || a.gzc) {
+        if (!a.gzp || !a.rblk || !a.cblk || a.nrb <= 0 || a.ncb <= 0) { set_error("launch_moments: the input-gradient pass needs its scratch and block tables"); return -1; }
+        const size_t half = (size_t)a.nrb * a.ncb * a.D * MOGP_GT;
+        HIP_TRY(hipMemsetAsync(a.gzp, 0, 2 * half * sizeof(double), s));
+        if ((rc = launch_moments_t<true, true, false>(a, s))) return rc;
+        if (a.gzr) hipLaunchKernelGGL(k_gz_reduce, dim3(a.nrb), dim3(256), 0, s, a.gzp, a.ncb, a.D, a.rblk, a.gzr, a.ldgz);
+        if (a.gzc) hipLaunchKernelGGL(k_gz_reduce, dim3(a.ncb), dim3(256), 0, s, a.gzp + half, a.nrb, a.D, a.cblk, a.gzc, a.ldgz);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     return launch_moments_t<true, false, false>(a, s);
 }
 

@@ -51,9 +51,24 @@ int sort_inputs(const double* X, int64_t M, int D, int C, int64_t pad_to, Sorted
 }
 
 // tiles of the symmetric Gram (lower channel pairs, lower tiles inside diagonal channel blocks), grouped by pair
+void tile_blocks(const std::vector<int>& off, int C, std::vector<int>& blk) {
+    blk.clear();
+    for (int c = 0; c < C; ++c)
+        for (int b = 0; b * MOGP_GT < off[c + 1] - off[c]; ++b) {
+            blk.push_back(off[c] + b * MOGP_GT);
+            blk.push_back(std::min(MOGP_GT, off[c + 1] - off[c] - b * MOGP_GT));
+        }
+}
+static std::vector<int> block_base(const std::vector<int>& off, int C) {         // index of channel c's first block
+    std::vector<int> base(C + 1, 0);
+    for (int c = 0; c < C; ++c) base[c + 1] = base[c] + (off[c + 1] - off[c] + MOGP_GT - 1) / MOGP_GT;
+    return base;
+}
+
 void build_sym_tiles(const std::vector<int>& off, int C, std::vector<GTile>& tiles, std::vector<int>& pair_start) {
     tiles.clear();
     pair_start.assign(1, 0);
+    const std::vector<int> rbase = block_base(off, C), cbase = rbase;
     for (int i = 0; i < C; ++i)
         for (int j = 0; j <= i; ++j) {
             const int ni = off[i + 1] - off[i], nj = off[j + 1] - off[j];
@@ -65,6 +80,7 @@ void build_sym_tiles(const std::vector<int>& off, int C, std::vector<GTile>& til
                     t.nr = std::min(MOGP_GT, ni - bi * MOGP_GT); t.nc = std::min(MOGP_GT, nj - bj * MOGP_GT);
                     t.pair = i * C + j;
                     t.flags = (i == j && bi == bj) ? GT_DIAG : GT_MIRROR;
+                    t.rb = rbase[i] + bi; t.cb = cbase[j] + bj;
                     tiles.push_back(t);
                 }
             pair_start.push_back((int)tiles.size());
@@ -75,6 +91,7 @@ void build_rect_tiles(const std::vector<int>& offr, const std::vector<int>& offc
                       std::vector<int>* pair_start) {
     tiles.clear();
     if (pair_start) pair_start->assign(1, 0);
+    const std::vector<int> rbase = block_base(offr, C), cbase = block_base(offc, C);
     for (int i = 0; i < C; ++i)
         for (int j = 0; j < C; ++j) {
             const int ni = offr[i + 1] - offr[i], nj = offc[j + 1] - offc[j];
@@ -85,6 +102,7 @@ void build_rect_tiles(const std::vector<int>& offr, const std::vector<int>& offc
                     t.nr = std::min(MOGP_GT, ni - bi * MOGP_GT); t.nc = std::min(MOGP_GT, nj - bj * MOGP_GT);
                     t.pair = i * C + j;
                     t.flags = 0;
+                    t.rb = rbase[i] + bi; t.cb = cbase[j] + bj;
                     tiles.push_back(t);
                 }
             if (pair_start) pair_start->push_back((int)tiles.size());
@@ -809,6 +827,7 @@ int mogp_model_set_terms_ex(mogp_model* m, int T, int width, const double* table
         if (!std::isfinite(table[i])) return fail(MOGP_ENONFINITE, "spectral term table has non-finite entries (kernel parameters diverged)");
     m->T = T;
     m->Wt = W;
+    if (m->tw) m->tw->pred_valid = false;       // mogp_sparse_predict_cov combines the last prediction's panels with the CURRENT table: a new table ends that
     m->table.assign(table, table + n);
     if ((rc = m->d_table.ensure(n))) return rc;
     if ((rc = m->d_moments.ensure((size_t)(m->C * (m->C + 1) / 2) * T * W))) return rc;

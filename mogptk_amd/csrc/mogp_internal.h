@@ -28,7 +28,8 @@ struct GTile {
     int nr, nc;      // valid rows / columns (<= MOGP_GT)
     int pair;        // i*C + j : row channel i, column channel j
     int flags;       // GT_* bits
-};
+    int rb, cb;      // index of the tile's 64-point row / column block among all row / column blocks (channel by channel): the slot of its
+};                   // per-point input gradients in the fixed-order reduction (k_gz_reduce)
 // a run of n consecutive FULL interior tiles of one row block: columns c0, c0 + 64, ... (the strip kernel of gram.hip)
 struct GSeg { int r0, c0, n, pair; };
 enum { GT_MIRROR = 1,     // also write the transpose to (c, r)   (off-diagonal tile of the symmetric Gram)
@@ -97,9 +98,15 @@ struct MomentArgs {
     double rcoef;
     int sym;               // dense mode: 1 = lower tiles of a symmetric adjoint (weights 2 / 1 on the diagonal / 0 above), 0 = weight 1
     // per-point input gradients (dense mode only, null = skip): gzr[d][row] += sum_b g dK_ab/dx_a,d ; gzc[d][col] -= ...
+    // Every tile stores its 64 row sums / column sums in a slot of its own (gzp), a second kernel adds the slots of a block in fixed order:
+    // bit-reproducible (round 2 used fp64 atomics here, and the Titsias d/dZ changed from run to run).
     double* gzr;
     double* gzc;
     int64_t ldgz;
+    double* gzp;           // scratch, gz_scratch_doubles(nrb, ncb, D) doubles
+    int nrb, ncb;          // 64-point blocks of the row / column inputs (tile_blocks)
+    const int* rblk;       // device [nrb][2]: first point and number of points of each row block;
+    const int* cblk;       //        [ncb][2]: the same for the column blocks
     double* partial;       // [ntiles][T][W] per-tile partial moments (reduced in fixed order afterwards)
     hipEvent_t ev0, ev1;   // when non-null: recorded around the tile kernel alone (profiling)
     int tab_lds;           // set by the launcher: the term table is copied to LDS
@@ -110,6 +117,9 @@ int launch_gram(const GramArgs& a, int ntiles, hipStream_t s);
 // split a tile list into runs of at most `maxrun` full interior tiles (same pair and row block, consecutive columns) and the rest
 void split_strip_tiles(const std::vector<GTile>& tiles, int maxrun, std::vector<GSeg>& segs, std::vector<GTile>& rest);
 int launch_moments(const MomentArgs& a, hipStream_t s);
+inline size_t gz_scratch_doubles(int nrb, int ncb, int D) { return (size_t)2 * nrb * ncb * D * MOGP_GT; }
+// [first point, number of points] of every 64-point block, channel by channel: the enumeration GTile::rb / cb refers to
+void tile_blocks(const std::vector<int>& off, int C, std::vector<int>& blk);
 // moments[P][T][W] += fixed-order sum of per-tile partials; tile_pair_lower[t] = p index, tiles grouped by pair
 int launch_moment_reduce(const double* partial, const int* pair_start, int npairs, int T, int W, int D, double* out, hipStream_t s,
                          int lower_pairs = 1);

@@ -138,6 +138,9 @@ struct TitsiasWork {
     SortedX pred_ss;                                    // the test inputs of the last sparse prediction (a = L^-1 Kus in Aus, b in Bus): what
     bool pred_valid = false;                            // mogp_sparse_predict_cov needs for the full covariance K_ss - a^T a + b^T b
     hipEvent_t side_ev[2] = {nullptr, nullptr};         // fork / join of the M x M adjoint chain on a side stream (side_fork / side_join)
+    DevBuf<int> blk_z, blk_x;                           // [first point, count] of the 64-point blocks of Z and of X (tile_blocks): the slots of
+    std::vector<int> hblk_z, hblk_x;                    // the fixed-order reduction of d/dZ (gz_prepare / gz_attach)
+    DevBuf<double> gzp;
     // svgp.hip: what the forward pass at the training inputs leaves for the backward pass
     SortedX sv_sz; std::vector<GTile> sv_tuu, sv_tuf; std::vector<int> sv_psuu, sv_psuf; int64_t sv_M = 0; bool sv_dense = false, sv_valid = false;
     DevBuf<double> nvec;                                // Snelson: per-point vectors (g, G, G y, sqrt G, v^T r / w, alpha, h) + per-channel inputs
@@ -149,6 +152,7 @@ struct TitsiasWork {
         vec.release(); scratch.release(); gz.release(); partial_uu.release(); partial_uf.release(); mom_uu.release(); mom_uf.release();
         zero_noise.release(); tiles_uu.release(); tiles_uf.release(); ps_uu.release(); ps_uf.release();
         Kus.release(); Aus.release(); Bus.release(); zero_col.release(); kslices.release(); nvec.release(); red.release();
+        blk_z.release(); blk_x.release(); gzp.release(); hblk_z.clear(); hblk_x.clear();
         for (auto& e : side_ev) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
     }
 };
@@ -256,6 +260,10 @@ inline GemmArgs make_gemm(const double* A, int64_t lda, int akm, const double* B
 // for it -- the chain then runs underneath the M x N work instead of in front of it.  MOGP_SIDE_STREAM=0: everything on m->st.
 int side_fork(mogp_model* m, TitsiasWork& t, hipStream_t* side);
 int side_join(mogp_model* m, TitsiasWork& t, hipStream_t side);
+// d/dZ of a sparse model: block tables of Z and X and the scratch of the fixed-order reduction (gram.hip: k_gz_reduce); gz_attach points a
+// moment pass at them -- zx: rows Z, columns X (the (Z, X) pass); otherwise rows and columns Z
+int gz_prepare(mogp_model* m, TitsiasWork& t, const std::vector<int>& offz, int D);
+void gz_attach(const TitsiasWork& t, MomentArgs& ma, bool zx);
 int spd_check_info(mogp_model* m, const char* which, int64_t* info);
 bool chain_enabled(const mogp_model* m);   // chain.hip
 int chain_fallback(mogp_model* m);     // mogp_api.hip: after MOGP_INFO_CHAIN_TIMEOUT -- drain, switch the model to the launch-per-step chain; the caller repeats the evaluation

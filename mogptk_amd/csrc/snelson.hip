@@ -309,6 +309,7 @@ int snelson_eval_impl(mogp_model* m, int64_t M, const double* Z, const double* n
         RC(launch_copy2d(beta, 1, t.Hm.p, MOGP_TILE, Mpad, 1, 1.0, m->st));
     }
     HIP_TRY(hipMemsetAsync(t.gz.p, 0, (size_t)D * Mpad * sizeof(double), m->st));
+    RC(gz_prepare(m, t, sz.off, D));
 
     MomentArgs ma{};
     ma.tiles = t.tiles_uf.p; ma.ntiles = (int)tuf.size(); ma.x = t.zx.p; ma.ldx = Mpad; ma.xc = m->d_x.p; ma.ldxc = Npad;
@@ -317,6 +318,7 @@ int snelson_eval_impl(mogp_model* m, int64_t M, const double* Z, const double* n
     ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C;
     ma.G = t.GB.p; ma.ldg = Npad; ma.ru = beta; ma.rw = alpha; ma.rcoef = 0.0; ma.sym = 0;
     ma.gzr = t.gz.p; ma.gzc = nullptr; ma.ldgz = Mpad; ma.partial = t.partial_uf.p;
+    gz_attach(t, ma, true);
     RC(launch_moments(ma, m->st));
     RC(launch_moment_reduce(t.partial_uf.p, t.ps_uf.p, C * C, T, W, D, t.mom_uf.p, m->st, 0));
     if (sharded) {
@@ -328,6 +330,7 @@ int snelson_eval_impl(mogp_model* m, int64_t M, const double* Z, const double* n
     RC(t.ph_zz.prepare(sz.off, sz.off, C, T, Mpad, Mpad, m->st, ma.ph));
     ma.G = t.GA.p; ma.ldg = Mpad; ma.ru = beta; ma.rw = beta; ma.rcoef = -0.5; ma.sym = 1;
     ma.gzr = t.gz.p; ma.gzc = t.gz.p; ma.partial = t.partial_uu.p;
+    gz_attach(t, ma, false);
     RC(launch_moments(ma, m->st));
     RC(launch_moment_reduce(t.partial_uu.p, t.ps_uu.p, P, T, W, D, t.mom_uu.p, m->st, 1));
 

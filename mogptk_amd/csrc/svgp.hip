@@ -268,6 +268,7 @@ static int svgp_backward_impl(mogp_model* m, const double* e, const double* f, d
     g = make_gemm(t.Qs.p, Mpad, 0, t.R.p, Mpad, 1, t.q.A.p, Mpad, 2.0, GM_RECT, mt, mt, Mpad);
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
     HIP_TRY(hipMemsetAsync(t.gz.p, 0, (size_t)D * Mpad * sizeof(double), m->st));
+    RC(gz_prepare(m, t, sz.off, D));
 
     MomentArgs ma{};
     ma.x = t.zx.p; ma.ldx = Mpad; ma.nrows = M;
@@ -280,6 +281,7 @@ static int svgp_backward_impl(mogp_model* m, const double* e, const double* f, d
         RC(t.ph_zx.prepare(sz.off, m->sx.off, C, T, Mpad, Npad, m->st, ma.ph));
         ma.G = t.B.p; ma.ldg = Npad; ma.rw = de; ma.sym = 0;
         ma.gzr = t.gz.p; ma.gzc = nullptr; ma.partial = t.partial_uf.p;
+        gz_attach(t, ma, true);
         RC(launch_moments(ma, m->st));
         RC(launch_moment_reduce(t.partial_uf.p, t.ps_uf.p, C * C, T, W, D, t.mom_uf.p, m->st, 0));
         if (sharded) {
@@ -294,6 +296,7 @@ static int svgp_backward_impl(mogp_model* m, const double* e, const double* f, d
     RC(t.ph_zz.prepare(sz.off, sz.off, C, T, Mpad, Mpad, m->st, ma.ph));
     ma.G = t.GA.p; ma.ldg = Mpad; ma.ru = q; ma.rw = q; ma.rcoef = 0.0; ma.sym = 1;
     ma.gzr = dense ? nullptr : t.gz.p; ma.gzc = dense ? nullptr : t.gz.p; ma.partial = t.partial_uu.p;      // dense: the inputs are the data, not parameters
+    gz_attach(t, ma, false);
     RC(launch_moments(ma, m->st));
     RC(launch_moment_reduce(t.partial_uu.p, t.ps_uu.p, P, T, W, D, t.mom_uu.p, m->st, 1));
 

@@ -65,6 +65,30 @@ int spd_invert(mogp_model* m, Spd& w, const char* which, int64_t* info, const do
     return 0;
 }
 
+int gz_prepare(mogp_model* m, TitsiasWork& t, const std::vector<int>& offz, int D) {
+    std::vector<int> hz, hx;
+    tile_blocks(offz, m->C, hz);
+    tile_blocks(m->sx.off, m->C, hx);
+    if (hz != t.hblk_z) {
+        RC(t.blk_z.ensure(hz.size()));
+        t.hblk_z = hz;
+        HIP_TRY(hipMemcpyAsync(t.blk_z.p, t.hblk_z.data(), hz.size() * sizeof(int), hipMemcpyHostToDevice, m->st));
+    }
+    if (hx != t.hblk_x) {
+        RC(t.blk_x.ensure(hx.size()));
+        t.hblk_x = hx;
+        HIP_TRY(hipMemcpyAsync(t.blk_x.p, t.hblk_x.data(), hx.size() * sizeof(int), hipMemcpyHostToDevice, m->st));
+    }
+    const int nbz = (int)hz.size() / 2, nbx = (int)hx.size() / 2;
+    return t.gzp.ensure(gz_scratch_doubles(nbz, std::max(nbz, nbx), D));
+}
+
+void gz_attach(const TitsiasWork& t, MomentArgs& ma, bool zx) {
+    ma.gzp = t.gzp.p;
+    ma.nrb = (int)t.hblk_z.size() / 2; ma.rblk = t.blk_z.p;
+    ma.ncb = zx ? (int)t.hblk_x.size() / 2 : ma.nrb; ma.cblk = zx ? t.blk_x.p : t.blk_z.p;
+}
+
 int spd_check_info(mogp_model* m, const char* which, int64_t* info) {
     unsigned long long hinfo = 0;
     HIP_TRY(hipMemcpyAsync(&hinfo, m->d_info.p, sizeof(hinfo), hipMemcpyDeviceToHost, m->st));
@@ -318,8 +342,10 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
     RC(launch_gemv_cols(t.B.p, Npad, Mpad, Npad, beta, btb, t.scratch.p, m->st));                           // B^T beta
     RC(launch_axpby(Npad, 1.0 / (s2 * s2), m->d_y.p, -1.0 / (s2 * s2 * s2), btb, r, m->st));
     HIP_TRY(hipMemsetAsync(t.gz.p, 0, (size_t)D * Mpad * sizeof(double), m->st));
+    RC(gz_prepare(m, t, sz.off, D));
 
     MomentArgs ma{};
+    gz_attach(t, ma, true);
     ma.tiles = t.tiles_uf.p; ma.ntiles = (int)tuf.size(); ma.x = t.zx.p; ma.ldx = Mpad; ma.xc = m->d_x.p; ma.ldxc = Npad;
     ma.nrows = M; ma.ncols = N;
     RC(t.ph_zx.prepare(sz.off, m->sx.off, C, T, Mpad, Npad, m->st, ma.ph));
@@ -337,6 +363,7 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
     RC(t.ph_zz.prepare(sz.off, sz.off, C, T, Mpad, Mpad, m->st, ma.ph));
     ma.G = t.GA.p; ma.ldg = Mpad; ma.ru = beta; ma.rw = beta; ma.rcoef = -0.5 / (s2 * s2); ma.sym = 1;
     ma.gzr = t.gz.p; ma.gzc = t.gz.p; ma.partial = t.partial_uu.p;
+    gz_attach(t, ma, false);
     RC(launch_moments(ma, m->st));
     RC(launch_moment_reduce(t.partial_uu.p, t.ps_uu.p, P, T, W, D, t.mom_uu.p, m->st, 1));
 

@@ -616,7 +616,7 @@ class OpperArchambeau(Model):
     Variational Gaussian approximation of Opper & Archambeau 2009 (reference gpr/model.py:578-668): q(f) = N(K nu, (K^-1 + diag(lambda^2))^-1)
     with one `q_nu` and one positive `q_lambda` per data point;  ELBO = E_q[log p(y | f)] - kl / 2.  The O(N^3) algebra runs on the device in
     two calls around the likelihood (like the Hensman models): forward -> per-point mu, var of q(f) and the kl term; the likelihood (host,
-    O(N)) returns its expectation and dE/dmu, dE/dvar; backward -> the gradients of kernel, q_nu, q_lambda.  On this path: the Gaussian likelihood.
+    O(N)) returns its expectation and dE/dmu, dE/dvar; backward -> the gradients of kernel, q_nu, q_lambda.  Any likelihood of gpr/likelihood.py (its expectation and derivatives are the host's; the device algebra never sees it).
     No jitter enters (the reference's Cholesky calls here pass add_jitter=False); `jitter` is kept for the signature.
     """
 
@@ -696,7 +696,7 @@ class SparseHensman(_DataParallel, Model):
     Sparse variational GP of Hensman et al. 2015, whitened (reference gpr/model.py:767-878): q(u) = N(L q_mu, L S S^T L^T), L L^T = Kuu,
     S = tril(q_sqrt);  ELBO = E_q[log p(y | f)] - KL(q || p).  The O(N M^2) algebra runs on the device in two calls around the
     likelihood: forward -> per-point mu, var of q(f) at the training inputs; the likelihood (host, O(N)) returns its expectation and
-    dE/dmu, dE/dvar; backward -> the gradients of kernel, inducing inputs, q_mu, q_sqrt.  On this path: the Gaussian likelihood.
+    dE/dmu, dE/dvar; backward -> the gradients of kernel, inducing inputs, q_mu, q_sqrt.  Any likelihood of gpr/likelihood.py (its expectation and derivatives are the host's; the device algebra never sees it).
     The KL term mirrors the reference's (:816-822), which counts only the DIAGONAL of q_sqrt in the trace and the determinant.
     """
 
@@ -758,9 +758,16 @@ class SparseHensman(_DataParallel, Model):
     def _y(self):
         return self.y if self.mean is None else self.y - np.asarray(self.mean(self.X)).reshape(-1, 1)
 
+    def _mu(self, res):
+        """q(f)'s mean at the training inputs as the likelihood sees it.  The dense model (reference gpr/model.py:834-837) subtracts the mean
+        function from BOTH y and q(f)'s mean, so that it cancels out of the bound -- reproduced; the sparse model (:861) shifts y only."""
+        if self.is_sparse or self.mean is None:
+            return res["mu"]
+        return res["mu"] - self._local(np.asarray(self.mean(self.X)).reshape(-1))
+
     def elbo(self):
         h, res, _, _, _ = self._forward()
-        ve = self.likelihood.variational_expectation(self._local(self._likelihood_X(self.X)), self._local(self._y()), res["mu"], res["var"])
+        ve = self.likelihood.variational_expectation(self._local(self._likelihood_X(self.X)), self._local(self._y()), self._mu(res), res["var"])
         return config.dtype(self._reduce(ve) - self.kl_gaussian(self.q_mu(), self.q_sqrt()))
 
     def log_marginal_likelihood(self):
@@ -771,7 +778,7 @@ class SparseHensman(_DataParallel, Model):
         self.zero_grad(set_to_none=True)
         h, res, table, D, Zk = self._forward()
         sharded = self._data_shard() is not None            # data-parallel: mu / var, e, f are those of this rank's points
-        ve, e, f, pgrads = self.likelihood.variational_expectation(self._local(self._likelihood_X(self.X)), self._local(self._y()), res["mu"], res["var"], grad=True)
+        ve, e, f, pgrads = self.likelihood.variational_expectation(self._local(self._likelihood_X(self.X)), self._local(self._y()), self._mu(res), res["var"], grad=True)
         ve = self._reduce(ve)
         pgrads = [(p, self._reduce(g)) for p, g in pgrads]
         q_mu, q_sqrt = np.asarray(self.q_mu(), dtype=np.float64), np.asarray(self.q_sqrt(), dtype=np.float64)

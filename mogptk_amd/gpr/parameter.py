@@ -116,7 +116,7 @@ def _vjp(fn, x, g):
             col = np.imag(np.asarray(fn(z.reshape(x.shape)))).reshape(-1) / 1e-30
             if not np.all(np.isfinite(col)):
                 raise ValueError
-        except Exception:
+        except (TypeError, ValueError):            # the transform does not take complex input (or is not analytic there); anything else is a bug in it
             h = 1e-6 * max(1.0, abs(flat[k]))
             a, b = flat.copy(), flat.copy()
             a[k] += h

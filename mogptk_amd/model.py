@@ -110,7 +110,7 @@ class Snelson:
 
 class OpperArchambeau:
     """
-    Variational inference of Opper & Archambeau 2009 (reference mogptk/model.py:125-138).  On this path with the Gaussian likelihood.
+    Variational inference of Opper & Archambeau 2009 (reference mogptk/model.py:125-138).  Any likelihood of gpr/likelihood.py (Gaussian by default; the non-Gaussian ones through Gauss-Hermite quadrature on the host).
 
     Args:
         likelihood (gpr.Likelihood): likelihood p(y|f) (default: Gaussian with unit scale).
@@ -128,7 +128,7 @@ class OpperArchambeau:
 
 class Hensman:
     """
-    Variational inference of Hensman et al. 2015 (reference mogptk/model.py:159-178).  On this path with the Gaussian likelihood.
+    Variational inference of Hensman et al. 2015 (reference mogptk/model.py:159-178).  Any likelihood of gpr/likelihood.py (Gaussian by default; the non-Gaussian ones through Gauss-Hermite quadrature on the host).
 
     Args:
         inducing_points (int, list): number of inducing points (PER CHANNEL for multi-output kernels) or locations; None (default): the

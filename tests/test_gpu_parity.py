@@ -380,24 +380,29 @@ def test_cfg5_titsias_golden():
         p.data = np.array(f["raw"])
     loss = float(m.loss())
     assert abs(loss - float(fx["loss"])) < 1e-7 * abs(float(fx["loss"])), (loss, float(fx["loss"]))
-    gscale = max(np.max(np.abs(f["grad"])) for f in fp)
     for p, f in zip(m.parameters(), fp):
         err = np.max(np.abs(p.grad - f["grad"])) / np.max(np.abs(f["grad"]))
         if p._name.endswith("induction_points"):
             # dELBO/dZ is O(1e-2) here, the residue of O(1e4) terms cancelling through a K_uu with condition number ~1e11 (512 grid points
             # per channel, 0.2 apart): the reference's OWN value moves by 2.35e-3 of this tensor when only its thread count changes
             # (8 vs 3 torch threads, tests/golden/gen_golden.py docstring), so 1e-5 against one of its runs is below its noise floor.
-            # With every K_uu^-1 a triangular solve (trsm.hip) the device sits at 3.6e-3 .. 4.8e-3 of the tensor (run to run: fp64
-            # atomics in the per-point accumulation), 1.5 - 2 x the reference's own spread; an 80-bit evaluation at the same
-            # conditioning puts the solve formulation at 5e-5 of the truth and the explicit-inverse one of round 1 at 12-19 %
-            # (tools/titsias_numerics.py).  Asserted: within 4 x the reference's own spread, and the direction to five nines.
-            assert err < 1e-2, (p._name, err)
-            assert np.max(np.abs(p.grad - f["grad"])) < 1e-7 * gscale, (p._name, err)
+            # With every K_uu^-1 a triangular solve (trsm.hip) the device sits at 3.6e-3 .. 4.8e-3 of the tensor, 1.5 - 2 x the
+            # reference's own spread; an 80-bit evaluation at the same conditioning puts the solve formulation at 5e-5 of the truth and
+            # the explicit-inverse one of round 1 at 12-19 % (tools/titsias_numerics.py).  Asserted: within 2.6 x the reference's own
+            # spread, and the direction to five nines.  (The per-point accumulation has a fixed order since round 3 -- every tile's
+            # sums in a slot of their own, added by k_gz_reduce -- so the value no longer changes from run to run: checked below.)
+            assert err < 6e-3, (p._name, err)
             g, r = p.grad[:, 1], f["grad"][:, 1]
             assert np.dot(g, r) / (np.linalg.norm(g) * np.linalg.norm(r)) > 0.9999
             assert np.all(p.grad[:, 0] == 0.0)
         else:
             assert err < 1e-6, (p._name, err)          # measured <= 6.4e-8
+    # bitwise repeatability of the sparse bound and of EVERY gradient, d/dZ included: no floating-point atomics on this path
+    g1 = [p.grad.copy() for p in m.parameters()]
+    loss2 = float(m.loss())
+    assert loss2 == loss
+    for p, g in zip(m.parameters(), g1):
+        assert np.array_equal(p.grad, g), p._name
 
 
 @pytest.mark.parametrize("path", ["sweep", "phases", "fused"])

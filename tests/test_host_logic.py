@@ -840,3 +840,19 @@ def test_hensman_through_the_model_wrapper():
         assert losses.shape == (4,) and np.all(np.isfinite(losses)) and losses[-1] < losses[0]
         _, mu, lower, upper = m.predict(transformed=False)
         assert all(np.all(np.isfinite(v)) for v in mu)
+
+
+def test_reference_checkpoint_loader_refuses_names_a_checkpoint_has_no_use_for(tmp_path):
+    """a "reference checkpoint" that names os.system (the reference's plain pickle.load would call it) is refused by class resolution"""
+    import pickle
+    from mogptk_amd import compat
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("true",))
+    raw = pickle.dumps({"model": Evil(), "tag": "mogptk.model"})          # contains b"mogptk." -> routed through the reference loader
+    assert compat.is_reference_checkpoint(raw)
+    import io
+    with pytest.raises(pickle.UnpicklingError):
+        compat._Unpickler(io.BytesIO(raw)).load()
