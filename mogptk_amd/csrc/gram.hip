@@ -948,15 +948,34 @@ __global__ __launch_bounds__(256) void k_gz_reduce(const double* __restrict__ gz
                                                    double* __restrict__ out, int64_t ld) {
     const int b = blockIdx.x, pnt = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int first = blk[2 * b], n = blk[2 * b + 1];
-    __shared__ double red[4][MOGP_GT];
+    __shared__ double red[4][MOGP_GT], redc[4][MOGP_GT];
     const double* base = gzp + (size_t)b * nminor * D * MOGP_GT;
+    // The slots of one inducing point cancel to a small fraction of their size (at configs[4] the derivative with respect to an inducing input
+    // is O(1e-2), the residue of sums many orders larger), so the long sums here are compensated (Neumaier): the result is the correctly
+    // rounded sum of the slots to within a few ulp of the RESULT, whatever the number of slots.
     for (int d = 0; d < D; ++d) {
-        double s = 0.0;
-        for (int k = part; k < nminor; k += 4) s += base[((size_t)k * D + d) * MOGP_GT + pnt];
+        double s = 0.0, c = 0.0;
+        for (int k = part; k < nminor; k += 4) {
+            const double x = base[((size_t)k * D + d) * MOGP_GT + pnt];
+            const double t = s + x;
+            c += fabs(s) >= fabs(x) ? (s - t) + x : (x - t) + s;
+            s = t;
+        }
         __syncthreads();
-        red[part][pnt] = s;
+        red[part][pnt] = s; redc[part][pnt] = c;
         __syncthreads();
-        if (part == 0 && pnt < n) out[(size_t)d * ld + first + pnt] += (red[0][pnt] + red[1][pnt]) + (red[2][pnt] + red[3][pnt]);
+        if (part == 0 && pnt < n) {
+            double hs = 0.0, hc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double x = red[q][pnt];
+                const double t = hs + x;
+                hc += fabs(hs) >= fabs(x) ? (hs - t) + x : (x - t) + hs;
+                hs = t;
+                hc += redc[q][pnt];
+            }
+            out[(size_t)d * ld + first + pnt] += hs + hc;
+        }
     }
 }
 
