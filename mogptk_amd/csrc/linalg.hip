@@ -7,6 +7,8 @@
 // the O(N^3) dense solves of their autograd backward nodes.
 #include "mogp_internal.h"
 
+#include <cstdlib>
+
 namespace mogp {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -22,14 +24,15 @@ __device__ __forceinline__ int tri_row(int b) {
     return r;
 }
 
-template <int WTM, int WTN> struct GemmCfg {
-    // workgroup tile TMR x TNC: 2x2 waves, each WTM x WTN MFMA tiles of 16x16
-    static constexpr int TMR = 32 * WTM, TNC = 32 * WTN;
+template <int WTM, int WTN, int NWJ = 2> struct GemmCfg {
+    // workgroup tile TMR x TNC: 2 x NWJ waves, each WTM x WTN MFMA tiles of 16x16 (NWJ = 4: eight waves, 128 x 128 from 4 x 2 tiles a wave)
+    static constexpr int NT = 128 * NWJ;                            // threads
+    static constexpr int TMR = 32 * WTM, TNC = 16 * NWJ * WTN;
     static constexpr int COLK_A = TMR + 16, COLK_B = TNC + 16;     // [16][T+16] doubles: row stride == 16 (mod 32)
     static constexpr int OPER_A = (TMR * LDS_ROWK > 16 * COLK_A) ? TMR * LDS_ROWK : 16 * COLK_A;
     static constexpr int OPER_B = (TNC * LDS_ROWK > 16 * COLK_B) ? TNC * LDS_ROWK : 16 * COLK_B;
     static constexpr int LDS_BYTES = 2 * (OPER_A + OPER_B) * 8;
-    static constexpr int EPT_A = TMR * GEMM_BK / 256, EPT_B = TNC * GEMM_BK / 256;   // doubles staged per thread (8 or 4)
+    static constexpr int EPT_A = TMR * GEMM_BK / NT, EPT_B = TNC * GEMM_BK / NT;     // doubles staged per thread (8, 4 or 2)
 };
 
 // C(TMR x TNC tile) = alpha * sum_k A[i,k] B[j,k] + beta * C on v_mfma_f64_16x16x4_f64.
@@ -41,16 +44,17 @@ __device__ unsigned long long g_gemm_tim[8 * 8192];       // per workgroup: entr
 #else
 #define GEMM_STAMP(i)
 #endif
-template <int AKM, int BKM, int WTM, int WTN>
-__global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
+template <int AKM, int BKM, int WTM, int WTN, int NWJ = 2>
+__global__ __launch_bounds__(128 * NWJ, NWJ) void k_gemm(GemmArgs g) {
     GEMM_STAMP(0);
-    using Cfg = GemmCfg<WTM, WTN>;
-    constexpr int TMR = Cfg::TMR, TNC = Cfg::TNC, COLK_A = Cfg::COLK_A, COLK_B = Cfg::COLK_B;
+    using Cfg = GemmCfg<WTM, WTN, NWJ>;
+    constexpr int TMR = Cfg::TMR, TNC = Cfg::TNC, COLK_A = Cfg::COLK_A, COLK_B = Cfg::COLK_B, NT = Cfg::NT;
     constexpr int OPER_A = Cfg::OPER_A, OPER_B = Cfg::OPER_B, EPT_A = Cfg::EPT_A, EPT_B = Cfg::EPT_B;
     constexpr int NQ_A = EPT_A / 2, NQ_B = EPT_B / 2, TPR_A = GEMM_BK / EPT_A, TPR_B = GEMM_BK / EPT_B;
+    constexpr int TPK = NT / GEMM_BK;                                     // threads per k row of a k-major operand block
     extern __shared__ __attribute__((aligned(16))) double gemm_lds[];     // [2 buffers][A operand | B operand]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave >> 1, wj = wave & 1;
+    const int wi = wave / NWJ, wj = wave % NWJ;
 
     // ---- which tile, which k range ----
     const double* Ap;
@@ -102,16 +106,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
 #endif
     // ---- global -> register staging map: EPT doubles (16-byte loads) per thread per operand ----
     // k-contiguous operand: thread -> (row = tid / TPR, EPT k's);  k-major operand: thread -> (k row = tid / 16, EPT i's)
-    const int64_t a_g = AKM ? (int64_t)(tid >> 4) * g.lda + (tid & 15) * EPT_A : (int64_t)(tid / TPR_A) * g.lda + (tid % TPR_A) * EPT_A;
-    const int64_t b_g = BKM ? (int64_t)(tid >> 4) * g.ldb + (tid & 15) * EPT_B : (int64_t)(tid / TPR_B) * g.ldb + (tid % TPR_B) * EPT_B;
-    const int a_l = AKM ? (tid >> 4) * COLK_A + (tid & 15) * EPT_A : (tid / TPR_A) * LDS_ROWK + (tid % TPR_A) * EPT_A;
-    const int b_l = BKM ? (tid >> 4) * COLK_B + (tid & 15) * EPT_B : (tid / TPR_B) * LDS_ROWK + (tid % TPR_B) * EPT_B;
+    const int64_t a_g = AKM ? (int64_t)(tid / TPK) * g.lda + (tid % TPK) * EPT_A : (int64_t)(tid / TPR_A) * g.lda + (tid % TPR_A) * EPT_A;
+    const int64_t b_g = BKM ? (int64_t)(tid / TPK) * g.ldb + (tid % TPK) * EPT_B : (int64_t)(tid / TPR_B) * g.ldb + (tid % TPR_B) * EPT_B;
+    const int a_l = AKM ? (tid / TPK) * COLK_A + (tid % TPK) * EPT_A : (tid / TPR_A) * LDS_ROWK + (tid % TPR_A) * EPT_A;
+    const int b_l = BKM ? (tid / TPK) * COLK_B + (tid % TPK) * EPT_B : (tid / TPR_B) * LDS_ROWK + (tid % TPR_B) * EPT_B;
     const int64_t a_step = AKM ? (int64_t)GEMM_BK * g.lda : GEMM_BK;
     const int64_t b_step = BKM ? (int64_t)GEMM_BK * g.ldb : GEMM_BK;
 
     // beta != 0: start the accumulators at (beta/alpha) * C so the read of C overlaps the first operand loads and the
     // epilogue is a pure store of alpha * acc.
-    const int crow = wi * (TMR / 2) + (lane >> 4), ccol = wj * (TNC / 2) + (lane & 15);
+    const int crow = wi * (TMR / 2) + (lane >> 4), ccol = wj * (TNC / NWJ) + (lane & 15);
     d4_t acc[WTM][WTN];
     if (g.beta != 0.0 && !fresh) {
         const double sc = g.beta / g.alpha;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     }
     // fragment read offsets inside an operand buffer (per m / n add 16 rows)
     const int fa = AKM ? (lane >> 4) * COLK_A + wi * (TMR / 2) + (lane & 15) : (wi * (TMR / 2) + (lane & 15)) * LDS_ROWK + (lane >> 4);
-    const int fb = BKM ? (lane >> 4) * COLK_B + wj * (TNC / 2) + (lane & 15) : (wj * (TNC / 2) + (lane & 15)) * LDS_ROWK + (lane >> 4);
+    const int fb = BKM ? (lane >> 4) * COLK_B + wj * (TNC / NWJ) + (lane & 15) : (wj * (TNC / NWJ) + (lane & 15)) * LDS_ROWK + (lane >> 4);
     constexpr int fa_m = AKM ? 16 : 16 * LDS_ROWK, fa_k = AKM ? 4 * COLK_A : 4;
     constexpr int fb_n = BKM ? 16 : 16 * LDS_ROWK, fb_k = BKM ? 4 * COLK_B : 4;
 
@@ -236,16 +240,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
 #endif
 }
 
-template <int AKM, int BKM, int WTM, int WTN>
+template <int AKM, int BKM, int WTM, int WTN, int NWJ = 2>
 static int launch_gemm_t(const GemmArgs& a, int grid, hipStream_t s) {
-    constexpr int lds_bytes = GemmCfg<WTM, WTN>::LDS_BYTES;
+    constexpr int lds_bytes = GemmCfg<WTM, WTN, NWJ>::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<AKM, BKM, WTM, WTN>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<AKM, BKM, WTM, WTN, NWJ>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm<AKM, BKM, WTM, WTN>), dim3(grid), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL((k_gemm<AKM, BKM, WTM, WTN, NWJ>), dim3(grid), dim3(128 * NWJ), lds_bytes, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -269,6 +273,20 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
             return -1;
         }
         return a.small == 1 ? launch_gemm_t<0, 0, 2, 4>(a, grid, s) : launch_gemm_t<0, 0, 2, 2>(a, grid, s);
+    }
+    // The 128 x 128 tile runs on EIGHT waves (4 x 2 MFMA tiles each, 512 threads, 128 VGPRs): two workgroups per CU as before, but four
+    // waves per SIMD instead of two to pick MFMAs from while one waits for LDS, the barrier or its C tile.  Same arithmetic in the same
+    // order (results bit-identical to the four-wave kernel); measured round 3 on one box: rank-512 lower-triangle update 57.3 -> 58.4
+    // TFLOP/s (k-contiguous), 54.7 -> 58.9 (k-major); configs[1] 13.46 -> 12.96 ms, configs[2] 555 -> 546, configs[3] 48.8 -> 47.4.
+    // MOGP_GEMM8=0: the four-wave kernel (4 x 4 MFMA tiles a wave, 224 VGPRs).
+    static const bool eight = !(std::getenv("MOGP_GEMM8") && std::atoi(std::getenv("MOGP_GEMM8")) == 0);
+    if (eight) {
+        switch (v) {
+            case 0: return launch_gemm_t<0, 0, 4, 2, 4>(a, grid, s);
+            case 1: return launch_gemm_t<0, 1, 4, 2, 4>(a, grid, s);
+            case 2: return launch_gemm_t<1, 0, 4, 2, 4>(a, grid, s);
+            default: return launch_gemm_t<1, 1, 4, 2, 4>(a, grid, s);
+        }
     }
     switch (v) {
         case 0: return launch_gemm_t<0, 0, 4, 4>(a, grid, s);
