@@ -24,10 +24,10 @@ __device__ __forceinline__ int tri_row(int b) {
     return r;
 }
 
-template <int WTM, int WTN, int NWJ = 2> struct GemmCfg {
-    // workgroup tile TMR x TNC: 2 x NWJ waves, each WTM x WTN MFMA tiles of 16x16 (NWJ = 4: eight waves, 128 x 128 from 4 x 2 tiles a wave)
-    static constexpr int NT = 128 * NWJ;                            // threads
-    static constexpr int TMR = 32 * WTM, TNC = 16 * NWJ * WTN;
+template <int WTM, int WTN, int NWJ = 2, int NWI = 2> struct GemmCfg {
+    // workgroup tile TMR x TNC: NWI x NWJ waves, each WTM x WTN MFMA tiles of 16x16 (2 x 4 waves of 4 x 2 tiles: 128 x 128 on eight waves)
+    static constexpr int NT = 64 * NWI * NWJ;                       // threads
+    static constexpr int TMR = 16 * NWI * WTM, TNC = 16 * NWJ * WTN;
     static constexpr int COLK_A = TMR + 16, COLK_B = TNC + 16;     // [16][T+16] doubles: row stride == 16 (mod 32)
     static constexpr int OPER_A = (TMR * LDS_ROWK > 16 * COLK_A) ? TMR * LDS_ROWK : 16 * COLK_A;
     static constexpr int OPER_B = (TNC * LDS_ROWK > 16 * COLK_B) ? TNC * LDS_ROWK : 16 * COLK_B;
@@ -44,10 +44,10 @@ __device__ unsigned long long g_gemm_tim[8 * 8192];       // per workgroup: entr
 #else
 #define GEMM_STAMP(i)
 #endif
-template <int AKM, int BKM, int WTM, int WTN, int NWJ = 2>
-__global__ __launch_bounds__(128 * NWJ, NWJ) void k_gemm(GemmArgs g) {
+template <int AKM, int BKM, int WTM, int WTN, int NWJ = 2, int NWI = 2>
+__global__ __launch_bounds__(64 * NWI * NWJ, NWI * NWJ / 2) void k_gemm(GemmArgs g) {
     GEMM_STAMP(0);
-    using Cfg = GemmCfg<WTM, WTN, NWJ>;
+    using Cfg = GemmCfg<WTM, WTN, NWJ, NWI>;
     constexpr int TMR = Cfg::TMR, TNC = Cfg::TNC, COLK_A = Cfg::COLK_A, COLK_B = Cfg::COLK_B, NT = Cfg::NT;
     constexpr int OPER_A = Cfg::OPER_A, OPER_B = Cfg::OPER_B, EPT_A = Cfg::EPT_A, EPT_B = Cfg::EPT_B;
     constexpr int NQ_A = EPT_A / 2, NQ_B = EPT_B / 2, TPR_A = GEMM_BK / EPT_A, TPR_B = GEMM_BK / EPT_B;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(128 * NWJ, NWJ) void k_gemm(GemmArgs g) {
 
     // beta != 0: start the accumulators at (beta/alpha) * C so the read of C overlaps the first operand loads and the
     // epilogue is a pure store of alpha * acc.
-    const int crow = wi * (TMR / 2) + (lane >> 4), ccol = wj * (TNC / NWJ) + (lane & 15);
+    const int crow = wi * (TMR / NWI) + (lane >> 4), ccol = wj * (TNC / NWJ) + (lane & 15);
     d4_t acc[WTM][WTN];
     if (g.beta != 0.0 && !fresh) {
         const double sc = g.beta / g.alpha;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(128 * NWJ, NWJ) void k_gemm(GemmArgs g) {
         for (int q = 0; q < NQ_B; ++q) rb[q] = pb[q];
     }
     // fragment read offsets inside an operand buffer (per m / n add 16 rows)
-    const int fa = AKM ? (lane >> 4) * COLK_A + wi * (TMR / 2) + (lane & 15) : (wi * (TMR / 2) + (lane & 15)) * LDS_ROWK + (lane >> 4);
+    const int fa = AKM ? (lane >> 4) * COLK_A + wi * (TMR / NWI) + (lane & 15) : (wi * (TMR / NWI) + (lane & 15)) * LDS_ROWK + (lane >> 4);
     const int fb = BKM ? (lane >> 4) * COLK_B + wj * (TNC / NWJ) + (lane & 15) : (wj * (TNC / NWJ) + (lane & 15)) * LDS_ROWK + (lane >> 4);
     constexpr int fa_m = AKM ? 16 : 16 * LDS_ROWK, fa_k = AKM ? 4 * COLK_A : 4;
     constexpr int fb_n = BKM ? 16 : 16 * LDS_ROWK, fb_k = BKM ? 4 * COLK_B : 4;
@@ -240,16 +240,16 @@ __global__ __launch_bounds__(128 * NWJ, NWJ) void k_gemm(GemmArgs g) {
 #endif
 }
 
-template <int AKM, int BKM, int WTM, int WTN, int NWJ = 2>
+template <int AKM, int BKM, int WTM, int WTN, int NWJ = 2, int NWI = 2>
 static int launch_gemm_t(const GemmArgs& a, int grid, hipStream_t s) {
-    constexpr int lds_bytes = GemmCfg<WTM, WTN, NWJ>::LDS_BYTES;
+    constexpr int lds_bytes = GemmCfg<WTM, WTN, NWJ, NWI>::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<AKM, BKM, WTM, WTN, NWJ>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<AKM, BKM, WTM, WTN, NWJ, NWI>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm<AKM, BKM, WTM, WTN, NWJ>), dim3(grid), dim3(128 * NWJ), lds_bytes, s, a);
+    hipLaunchKernelGGL((k_gemm<AKM, BKM, WTM, WTN, NWJ, NWI>), dim3(grid), dim3(64 * NWI * NWJ), lds_bytes, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -280,6 +280,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     // TFLOP/s (k-contiguous), 54.7 -> 58.9 (k-major); configs[1] 13.46 -> 12.96 ms, configs[2] 555 -> 546, configs[3] 48.8 -> 47.4.
     // MOGP_GEMM8=0: the four-wave kernel (4 x 4 MFMA tiles a wave, 224 VGPRs).
     static const bool eight = !(std::getenv("MOGP_GEMM8") && std::atoi(std::getenv("MOGP_GEMM8")) == 0);
+    // (Sixteen waves of 2 x 2 tiles -- eight per SIMD, 64 VGPRs -- spill and read LDS twice as often: 55-56 TFLOP/s, slower than either.)
     if (eight) {
         switch (v) {
             case 0: return launch_gemm_t<0, 0, 4, 2, 4>(a, grid, s);

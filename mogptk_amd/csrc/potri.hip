@@ -120,7 +120,9 @@ int inverse_step(mogp_model* m, Spd& w, const double* Wkk, int k0, int k1, const
         }
     }
     // Kinv[<=K, <=K] += W[K, <=K]^T W[K, <=K] on its own stream: the big launch runs next to the small, serial launches of the
-    // following row blocks instead of in front of them (the accumulations only order among themselves)
+    // following row blocks instead of in front of them (the accumulations only order among themselves).  (Two row blocks per launch --
+    // rank 1024, half the passes over the accumulator -- was measured SLOWER, 13.31 vs 12.93 ms: the deferred block's work is missing
+    // from what fills the chip next to the chain.)
     HIP_TRY(hipStreamWaitEvent(qacc, w_row, 0));
     GemmArgs g{};
     g.A = Wrow; g.lda = ld; g.a_kmajor = 1; g.B = Wrow; g.ldb = ld; g.b_kmajor = 1;

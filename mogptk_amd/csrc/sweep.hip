@@ -169,22 +169,31 @@ int spd_sweep(mogp_model* m, Spd& w) {
 
 // ---- sharded evaluation: assembling the authoritative panel of pivot block kb with ONE all-gather ------------------------
 // column part: tile rows i >= k0, 128 x Kd each, owner i % P; rank r's rows are first_r + idx * P
-__global__ void k_shard_pack(const double* __restrict__ A, int64_t ld, int k0, int nb, int P, int rank, int64_t Kd, double* __restrict__ send) {
+// (grid.y = 8 slabs of 16 rows per tile; 16-byte accesses along the block's columns -- Kd and ld are multiples of 128)
+__global__ __launch_bounds__(256) void k_shard_pack(const double* __restrict__ A, int64_t ld, int k0, int nb, int P, int rank, int64_t Kd, double* __restrict__ send) {
     const int first = k0 + ((rank - k0 % P) + P) % P;
     const int i = first + (int)blockIdx.x * P;
     if (i >= nb) return;
-    const double* src = A + (int64_t)i * MOGP_TILE * ld + (int64_t)k0 * MOGP_TILE;
-    double* dst = send + (int64_t)blockIdx.x * MOGP_TILE * Kd;
-    for (int64_t e = threadIdx.x; e < MOGP_TILE * Kd; e += blockDim.x) dst[e] = src[(e / Kd) * ld + (e % Kd)];
+    const int r0 = 16 * (int)blockIdx.y, kd2 = (int)(Kd >> 1);
+    const double* src = A + ((int64_t)i * MOGP_TILE + r0) * ld + (int64_t)k0 * MOGP_TILE;
+    double* dst = send + ((int64_t)blockIdx.x * MOGP_TILE + r0) * Kd;
+    for (int e = threadIdx.x; e < 16 * kd2; e += 256) {
+        const int r = e / kd2, c = 2 * (e - r * kd2);
+        *reinterpret_cast<double2*>(dst + (int64_t)r * Kd + c) = *reinterpret_cast<const double2*>(src + (int64_t)r * ld + c);
+    }
 }
-__global__ void k_shard_unpack(double* __restrict__ A, int64_t ld, int k0, int nb, int P, int64_t Kd, int64_t chunk, const double* __restrict__ recv) {
-    const int r = blockIdx.y;
+__global__ __launch_bounds__(256) void k_shard_unpack(double* __restrict__ A, int64_t ld, int k0, int nb, int P, int64_t Kd, int64_t chunk, const double* __restrict__ recv) {
+    const int r = blockIdx.z;
     const int first = k0 + ((r - k0 % P) + P) % P;
     const int i = first + (int)blockIdx.x * P;
     if (i >= nb) return;
-    double* dst = A + (int64_t)i * MOGP_TILE * ld + (int64_t)k0 * MOGP_TILE;
-    const double* src = recv + (int64_t)r * chunk + (int64_t)blockIdx.x * MOGP_TILE * Kd;
-    for (int64_t e = threadIdx.x; e < MOGP_TILE * Kd; e += blockDim.x) dst[(e / Kd) * ld + (e % Kd)] = src[e];
+    const int r0 = 16 * (int)blockIdx.y, kd2 = (int)(Kd >> 1);
+    double* dst = A + ((int64_t)i * MOGP_TILE + r0) * ld + (int64_t)k0 * MOGP_TILE;
+    const double* src = recv + (int64_t)r * chunk + ((int64_t)blockIdx.x * MOGP_TILE + r0) * Kd;
+    for (int e = threadIdx.x; e < 16 * kd2; e += 256) {
+        const int rr = e / kd2, c = 2 * (e - rr * kd2);
+        *reinterpret_cast<double2*>(dst + (int64_t)rr * ld + c) = *reinterpret_cast<const double2*>(src + (int64_t)rr * Kd + c);
+    }
 }
 
 // chunk of one rank for pivot block kb: [maxrows column tiles, 128 x Kd each][maxpiv row tiles, 128 x (k0*128) each]
@@ -209,7 +218,7 @@ int shard_pack(mogp_model* m, Spd& w, int kb, double** send, double** recv, int6
     const int P = m->sh_n;
     const ShardGeom g = shard_geometry(w, kb, P);
     RC(m->sh_send.ensure((size_t)g.chunk)); RC(m->sh_recv.ensure((size_t)g.chunk * P));
-    hipLaunchKernelGGL(k_shard_pack, dim3(g.maxrows), dim3(256), 0, m->st, w.A.p, w.Npad, g.k0, w.nb, P, m->sh_rank, g.Kd, m->sh_send.p);
+    hipLaunchKernelGGL(k_shard_pack, dim3(g.maxrows, 8), dim3(256), 0, m->st, w.A.p, w.Npad, g.k0, w.nb, P, m->sh_rank, g.Kd, m->sh_send.p);
     HIP_TRY(hipGetLastError());
     if (g.cols > 0) {
         int idx = 0;
@@ -224,7 +233,7 @@ int shard_pack(mogp_model* m, Spd& w, int kb, double** send, double** recv, int6
 int shard_unpack(mogp_model* m, Spd& w, int kb) {
     const int P = m->sh_n;
     const ShardGeom g = shard_geometry(w, kb, P);
-    hipLaunchKernelGGL(k_shard_unpack, dim3(g.maxrows, P), dim3(256), 0, m->st, w.A.p, w.Npad, g.k0, w.nb, P, g.Kd, g.chunk, m->sh_recv.p);
+    hipLaunchKernelGGL(k_shard_unpack, dim3(g.maxrows, 8, P), dim3(256), 0, m->st, w.A.p, w.Npad, g.k0, w.nb, P, g.Kd, g.chunk, m->sh_recv.p);
     HIP_TRY(hipGetLastError());
     if (g.cols > 0) {
         for (int i = g.k0; i < g.k1; ++i) {
