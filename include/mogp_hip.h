@@ -72,7 +72,9 @@ int  mogp_model_set_terms(mogp_model* m, int T, const double* table);
  * has two more moments per dimension, [ .., m5_d = sum G a_d^2 E cos, m6_d = sum G a_d E cos ], a_d = (x_a,d + x_b,d)/2 - c_d (every moment
  * array of mogp_exact_eval then has rows of that width), the kernel's diagonal is no longer constant per channel -- supply it with
  * mogp_model_set_point_diag, and pass kss_diag to mogp_exact_predict per TEST POINT (S values, caller order) instead of per channel.
- * The Titsias entry points do not take enveloped terms. */
+ * The Titsias entry points take enveloped terms the same way (any kernel under any inference, as in the reference): kff_diag per TRAINING
+ * point (N values, caller order), kss_diag per test point, moment rows of width 2 + 5 D; the derivative with respect to the inducing inputs
+ * includes the envelope's.  The Snelson and Hensman entry points still refuse them (their per-point diagonal terms are per channel here). */
 int  mogp_model_set_terms_ex(mogp_model* m, int T, int width, const double* table);
 /* K_diag(X) of the N training points in the caller's row order (reference gpr/kernel.py:483-495): enters the relative jitter
  * jitter * mean(diag) (gpr/model.py:244).  NULL: back to the per-channel constant implied by the table. */
@@ -115,7 +117,8 @@ int  mogp_exact_predict(mogp_model* m, const double* noise_var, const double* da
 /* ---- Titsias sparse variational bound (BASELINE.json configs[4]) ------------------------------------------------ */
 /* replaces Titsias.elbo (gpr/model.py:700-724) and, with MOGP_EVAL_GRAD, the autograd backward of gpr.Model.loss():
  *   Z: M x (1+D) inducing inputs (channel id in column 0), sigma: SCALAR noise scale (gpr/model.py:686-689),
- *   kff_diag[C]: the kernel's K_diag value per channel (as for mogp_exact_predict).
+ *   kff_diag[C]: the kernel's K_diag value per channel (as for mogp_exact_predict); with enveloped terms (mogp_model_set_terms_ex,
+ *   width 2 + 5 D) kff_diag[N]: K_diag per training point, and every moment row has that width.
  *   *elbo as gpr/model.py:718-723.  Gradient outputs:
  *   mom_uu: (C(C+1)/2) x T x MOGP_MOMENT_WIDTH(D) moments of dELBO/dKuu (symmetric double count, as mogp_exact_eval),
  *   mom_uf: (C*C) x T x MOGP_MOMENT_WIDTH(D) moments of dELBO/dKuf, pair index i*C + j (i: inducing channel, j: data channel),

@@ -782,6 +782,11 @@ __device__ __forceinline__ void moment_term(double* mom, const double (&g)[4][4]
                     const double j = -A * fma(V[d], uk, 6.283185307179586476925286766559 * Mv[d] * ks);
                     zr[m][d] += j;
                     zc[n][d] -= j;
+                    if (ENV) {                             // the envelope sits on the MIDPOINT: d/dx_a = d/dx_b = -1/2 L_d a_d K
+                        const double je = -0.5 * A * L.L[t][d] * (0.5 * (p[m][d] + q[n][d]) + L.e[t][d]) * kc;
+                        zr[m][d] += je;
+                        zc[n][d] += je;
+                    }
                 }
             }
         }
@@ -1006,18 +1011,17 @@ int launch_moments(const MomentArgs& a0, hipStream_t s) {
         if (!rc && a.ev1) HIP_TRY(hipEventRecord(a.ev1, s));
         return rc;
     }
-    if (env) { set_error("the dense-adjoint moment pass (Titsias) does not take terms with an envelope"); return -1; }
     if (a.gzr || a.gzc) {
         if (!a.gzp || !a.rblk || !a.cblk || a.nrb <= 0 || a.ncb <= 0) { set_error("launch_moments: the input-gradient pass needs its scratch and block tables"); return -1; }
         const size_t half = (size_t)a.nrb * a.ncb * a.D * MOGP_GT;
         HIP_TRY(hipMemsetAsync(a.gzp, 0, 2 * half * sizeof(double), s));
-        if ((rc = launch_moments_t<true, true, false>(a, s))) return rc;
+        if ((rc = env ? launch_moments_t<true, true, true>(a, s) : launch_moments_t<true, true, false>(a, s))) return rc;
         if (a.gzr) hipLaunchKernelGGL(k_gz_reduce, dim3(a.nrb), dim3(256), 0, s, a.gzp, a.ncb, a.D, a.rblk, a.gzr, a.ldgz);
         if (a.gzc) hipLaunchKernelGGL(k_gz_reduce, dim3(a.ncb), dim3(256), 0, s, a.gzp + half, a.nrb, a.D, a.cblk, a.gzc, a.ldgz);
         HIP_TRY(hipGetLastError());
         return 0;
     }
-    return launch_moments_t<true, false, false>(a, s);
+    return env ? launch_moments_t<true, false, true>(a, s) : launch_moments_t<true, false, false>(a, s);
 }
 
 // one workgroup per (lower channel pair, moment entry): 256 threads stride over that pair's tiles, then a fixed-shape

@@ -397,6 +397,34 @@ namespace mogp { double table_diag(const mogp_model* m, int c) {
 }
 }  // namespace mogp
 
+// sum over the points of `pts` of the kernel diagonal K(x, x) implied by the table: n_c table_diag(c) per channel, or -- with an envelope on
+// the input midpoint (rows of width 2 + 5 D, MOHSM) -- sum_t A_t exp(-1/2 sum_d L_d (x_d - c_d)^2) point by point
+namespace mogp { double table_diag_points(const mogp_model* m, const SortedX& pts) {
+    const int D = m->D, W = m->Wt, C = m->C;
+    double s = 0.0;
+    if (W == 2 + 3 * D) {
+        for (int c = 0; c < C; ++c) s += (double)(pts.off[c + 1] - pts.off[c]) * table_diag(m, c);
+        return s;
+    }
+    for (int c = 0; c < C; ++c) {
+        const double* tab = m->table.data() + (size_t)(c * C + c) * m->T * W;
+        for (int pos = pts.off[c]; pos < pts.off[c + 1]; ++pos)
+            for (int t = 0; t < m->T; ++t) {
+                const double* r = tab + (size_t)t * W;
+                double arg = 0.0, ph = r[1], env = 0.0;
+                for (int d = 0; d < D; ++d) {
+                    arg += r[2 + d] * r[2 + 2 * D + d] * r[2 + 2 * D + d];
+                    ph += r[2 + D + d] * r[2 + 2 * D + d];
+                    const double a = pts.xs[(size_t)d * pts.Mpad + pos] - r[2 + 4 * D + d];
+                    env += r[2 + 3 * D + d] * a * a;
+                }
+                s += r[0] * std::exp(-0.5 * (arg + env)) * std::cos(2.0 * M_PI * ph);
+            }
+    }
+    return s;
+}
+}  // namespace mogp
+
 namespace mogp { int ensure_system(mogp_model* m) {
     int rc;
     if (m->tiles.empty()) {

@@ -246,6 +246,7 @@ int use_device(mogp_ctx* c);
 int gemm_call(mogp_model* m, const GemmArgs& g, double flops, hipStream_t st = nullptr);
 int mark(mogp_model* m, int idx);
 double table_diag(const mogp_model* m, int c);
+double table_diag_points(const mogp_model* m, const SortedX& pts);      // sum of K(x, x) over the points (per point when the terms carry an envelope)
 int spd_alloc(Spd& w, int64_t Npad);
 // helpers shared by the sparse / variational models (titsias.hip)
 inline GemmArgs make_gemm(const double* A, int64_t lda, int akm, const double* B, int64_t ldb, int bkm, double* C, int64_t ldc,

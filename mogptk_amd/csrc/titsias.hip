@@ -143,10 +143,10 @@ struct TitsiasScalars { double logdet_q, yy, t1vy, t1t1, trPq, trQs, jit, ntot, 
 static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, SortedX& sz,
                          std::vector<GTile>& tuu, std::vector<int>& psuu, std::vector<GTile>& tuf, std::vector<int>& psuf,
                          TitsiasScalars& sc, int64_t* info, bool need_moment_tiles, bool sharded = false, const double* kff_diag = nullptr) {
-    const int C = m->C, D = m->D, W = 2 + 3 * D;
+    const int C = m->C, D = m->D, W = m->Wt;                   // 2 + 3 D, or 2 + 5 D: terms with an envelope on the input midpoint (MOHSM)
+    const bool env = W > 2 + 3 * D;
     const int64_t Npad = m->Npad;
     if (m->T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms must be called before an evaluation");
-    if (m->Wt != W) return fail(MOGP_EINVAL, "the Titsias path does not take terms with an envelope (MOHSM): exact inference only");
     if (!(sigma > 0.0)) return fail(MOGP_EINVAL, "sigma must be positive");
     RC(sort_inputs(Z, M, D, C, MOGP_TILE, sz));
     const int64_t Mpad = sz.Mpad;
@@ -184,14 +184,12 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     HIP_TRY(hipMemcpyAsync(m->d_info.p, &big, sizeof(big), hipMemcpyHostToDevice, m->st));
 
     // relative jitter on Kuu (reference gpr/model.py:710 -> :244)
-    double dsum = 0.0;
-    for (int c = 0; c < C; ++c) dsum += (double)(sz.off[c + 1] - sz.off[c]) * table_diag(m, c);
-    sc.jit = jitter * dsum / (double)M;
+    sc.jit = jitter * table_diag_points(m, sz) / (double)M;    // with an envelope the diagonal of Kuu follows the inducing inputs
 
     GramArgs ga{};
     ga.tiles = t.tiles_uu.p; ga.xr = t.zx.p; ga.xc = t.zx.p; ga.ldxr = ga.ldxc = Mpad; ga.nrows = ga.ncols = M;
     RC(t.ph_zz.prepare(sz.off, sz.off, C, m->T, Mpad, Mpad, m->st, ga.ph));
-    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.out = t.a.A.p; ga.ldo = Mpad;
+    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = W; ga.out = t.a.A.p; ga.ldo = Mpad;
     ga.noise = t.zero_noise.p; ga.dvar = nullptr; ga.jitter_abs = sc.jit; ga.mirror = 0;
     RC(launch_gram(ga, (int)tuu.size(), m->st));
     RC(launch_pad_identity(t.a.A.p, Mpad, M, Mpad, m->st));
@@ -219,7 +217,8 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     sc.yy = 0.0; for (int64_t i = 0; i < m->N; ++i) sc.yy += m->hy[i] * m->hy[i];
     sc.ntot = (double)m->N;
     sc.kff = 0.0;
-    if (kff_diag) for (int c = 0; c < C; ++c) sc.kff += (double)(m->sx.off[c + 1] - m->sx.off[c]) * kff_diag[c];
+    if (kff_diag && env) for (int64_t i = 0; i < m->N; ++i) sc.kff += kff_diag[i];                  // per training point
+    else if (kff_diag) for (int c = 0; c < C; ++c) sc.kff += (double)(m->sx.off[c + 1] - m->sx.off[c]) * kff_diag[c];
     if (sharded) {
         RC(comm_allreduce(m->ctx, t.q.A.p, Mpad * Mpad, m->st));
         RC(t.red.ensure((size_t)Mpad + 4));
@@ -275,7 +274,7 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
     if (!m || !Z || !kff_diag || !elbo || M <= 0) return fail(MOGP_EINVAL, "mogp_titsias_eval: bad argument");
     RC(use_device(m->ctx));
     if (info) *info = 0;
-    const int C = m->C, D = m->D, W = 2 + 3 * D, T = m->T, P = C * (C + 1) / 2;
+    const int C = m->C, D = m->D, W = m->Wt, T = m->T, P = C * (C + 1) / 2;
     const int64_t N = m->N, Npad = m->Npad;
     const bool grad = (flags & MOGP_EVAL_GRAD) != 0;
     SortedX sz;
@@ -349,7 +348,7 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
     ma.tiles = t.tiles_uf.p; ma.ntiles = (int)tuf.size(); ma.x = t.zx.p; ma.ldx = Mpad; ma.xc = m->d_x.p; ma.ldxc = Npad;
     ma.nrows = M; ma.ncols = N;
     RC(t.ph_zx.prepare(sz.off, m->sx.off, C, T, Mpad, Npad, m->st, ma.ph));
-    ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C;
+    ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C; ma.W = W;
     ma.G = t.GB.p; ma.ldg = Npad; ma.ru = beta; ma.rw = r; ma.rcoef = 1.0; ma.sym = 0;
     ma.gzr = t.gz.p; ma.gzc = nullptr; ma.ldgz = Mpad; ma.partial = t.partial_uf.p;
     RC(launch_moments(ma, m->st));
@@ -418,6 +417,7 @@ static int titsias_predict_impl(mogp_model* m, int64_t M, const double* Z, doubl
     RC(use_device(m->ctx));
     if (info) *info = 0;
     const int C = m->C, D = m->D;
+    const bool env = m->Wt > 2 + 3 * D;
     SortedX sz, ss;
     std::vector<GTile> tuu, tuf, tus;
     std::vector<int> psuu, psuf;
@@ -440,7 +440,7 @@ static int titsias_predict_impl(mogp_model* m, int64_t M, const double* Z, doubl
     GramArgs ga{};
     ga.tiles = m->d_ptiles.p; ga.xr = t.zx.p; ga.ldxr = Mpad; ga.xc = m->d_xs.p; ga.ldxc = Spad; ga.nrows = M; ga.ncols = S;
     RC(t.ph_zs.prepare(sz.off, ss.off, C, m->T, Mpad, Spad, m->st, ga.ph));
-    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.out = t.Kus.p; ga.ldo = Spad; ga.mirror = 0;
+    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = m->Wt; ga.out = t.Kus.p; ga.ldo = Spad; ga.mirror = 0;
     RC(launch_gram(ga, (int)tus.size(), m->st));
     HIP_TRY(hipMemcpyAsync(t.Aus.p, t.Kus.p, (size_t)Mpad * Spad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.Aus.p, Spad, Spad, false));                                      // a = L^-1 Kus
@@ -459,7 +459,7 @@ static int titsias_predict_impl(mogp_model* m, int64_t M, const double* Z, doubl
     for (int c = 0; c < C; ++c)
         for (int pos = ss.off[c]; pos < ss.off[c + 1]; ++pos) {
             mu[ss.perm[pos]] = hmu[pos] / s2;
-            var[ss.perm[pos]] = kss_diag[c] - hv[pos] + hv[Spad + pos];
+            var[ss.perm[pos]] = (env ? kss_diag[ss.perm[pos]] : kss_diag[c]) - hv[pos] + hv[Spad + pos];     // envelope: K_ss,diag per test point
         }
     t.pred_ss = ss; t.pred_valid = true;
     return MOGP_OK;

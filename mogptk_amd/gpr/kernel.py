@@ -222,6 +222,12 @@ class Kernel(ParameterHolder):
             gt[ch, ch, :, 2 + 4 * D:2 + 5 * D] = np.sum((A[k] * env[k])[..., None] * (Lv[k] * a[k]), axis=0)
         return gt
 
+    def _point_diag_input_grad(self, table, Xk, D):
+        """d K_diag(x_k) / d x_k,d per point: sum_t A env_t(x) (-L_d (x_d - c_d))   (N, D)"""
+        env, a, rows = self._point_env(table, Xk, D)
+        A, Lv = rows[..., 0], rows[..., 2 + 3 * D:2 + 4 * D]
+        return np.sum((A * env)[..., None] * (-Lv * a), axis=1)
+
     def __add__(self, other):
         return AddKernel(self, other)
 

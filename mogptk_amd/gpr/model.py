@@ -466,8 +466,10 @@ class Titsias(_DataParallel, Model):
         table = self.kernel._spectral_terms(D)
         h.set_terms(table)
         Zk = self.kernel._kernel_format(self.Z())
+        Xk = self._local(self.kernel._kernel_format(self.X))
+        kff = self.kernel._point_diag(table, Xk, D) if table.shape[3] > 2 + 3 * D else self.kernel._spectral_diag(D)    # envelope: per point
         try:
-            res = h.titsias_eval(Zk, self._sigma(), self.jitter, self.kernel._spectral_diag(D), grad=grad, sharded=self._data_shard() is not None)
+            res = h.titsias_eval(Zk, self._sigma(), self.jitter, kff, grad=grad, sharded=self._data_shard() is not None)
         except MogpError as e:
             if e.code in (MOGP_ENOTPD, MOGP_ENONFINITE):
                 print("ERROR:", str(e), file=sys.__stdout__)
@@ -493,16 +495,25 @@ class Titsias(_DataParallel, Model):
         zc = np.bincount(Zk[:, 0].astype(np.int64), minlength=C).astype(np.float64)
         xc = np.bincount(self.kernel._kernel_format(self.X)[:, 0].astype(np.int64), minlength=C).astype(np.float64)
         gt = _gtable_from_moments(table, res["mom_uu"], D, lower=True) + _gtable_from_moments(table, res["mom_uf"], D, lower=False)
-        for i in range(C):
-            gt[i, i, :, 0] += self.jitter * res["trGA"] * zc[i] / M          # jitter * mean(diag Kuu), gpr/model.py:244
-        self.kernel._spectral_backward(-gt)
-        # - 1/(2 s2) sum_k Kff_diag[k]  (gpr/model.py:723): K_diag is constant per channel
-        self.kernel._spectral_diag_backward(0.5 * xc / s2, D)
+        env = table.shape[3] > 2 + 3 * D
+        gz_jit = 0.0
+        if env:
+            # with an envelope (MOHSM) the diagonal follows the points: jitter * mean(diag Kuu) depends on A, L, c AND on Z itself, and
+            # sum_k Kff_diag[k] is a sum over the training points (reference gpr/model.py:244, :723 through autograd)
+            gt += (self.jitter * res["trGA"] / M) * self.kernel._point_diag_table_grad(table, Zk, D)
+            gz_jit = (self.jitter * res["trGA"] / M) * self.kernel._point_diag_input_grad(table, Zk, D)
+            self.kernel._spectral_backward(-gt + (0.5 / s2) * self.kernel._point_diag_table_grad(table, self.kernel._kernel_format(self.X), D))
+        else:
+            for i in range(C):
+                gt[i, i, :, 0] += self.jitter * res["trGA"] * zc[i] / M          # jitter * mean(diag Kuu), gpr/model.py:244
+            self.kernel._spectral_backward(-gt)
+            # - 1/(2 s2) sum_k Kff_diag[k]  (gpr/model.py:723): K_diag is constant per channel
+            self.kernel._spectral_diag_backward(0.5 * xc / s2, D)
         scale = self.likelihood.scale
         scale.accumulate_grad(np.reshape(-res["dsigma"], scale.data.shape))
         gz = np.zeros(self.Z.data.shape)
         off = 0 if self.kernel.output_dims is None else 1
-        gz[:, off:] = -res["gZ"]
+        gz[:, off:] = -(res["gZ"] + gz_jit)
         self.Z.accumulate_grad(gz)
         return config.dtype(-res["elbo"] - self.log_prior())
 
@@ -512,8 +523,11 @@ class Titsias(_DataParallel, Model):
         h = self._device_handle()
         D = self.X.shape[1] - (0 if self.kernel.output_dims is None else 1)
         h.set_terms(self.kernel._spectral_terms(D))
+        table = self.kernel._spectral_terms(D)
+        Xsk = self.kernel._kernel_format(X)
+        kss = self.kernel._point_diag(table, Xsk, D) if table.shape[3] > 2 + 3 * D else self.kernel._spectral_diag(D)
         mu, var = h.titsias_predict(self.kernel._kernel_format(self.Z()), self._sigma(), self.jitter,
-                                    self.kernel._kernel_format(X), self.kernel._spectral_diag(D), sharded=self._data_shard() is not None)
+                                    Xsk, kss, sharded=self._data_shard() is not None)
         if full:                                        # K_ss - a^T a + b^T b with the a, b this prediction left on the device (reference :758-760)
             var = h.sparse_predict_cov(X.shape[0])
         if self.mean is not None:

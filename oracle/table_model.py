@@ -154,8 +154,22 @@ def _jr_block(tab, x1, x2):
     """J_ab,d = d K_ab / d x1_a,d = sum_t A E [ -V_d u_d cos - 2 pi M_d sin ]   (n1, n2, D)"""
     D = x1.shape[1]
     A, V, M = tab[:, 0], tab[:, 2:2 + D], tab[:, 2 + D:2 + 2 * D]
-    Ec, Es, u = table_block(tab, x1, x2)
-    return np.einsum("t,tnm,tnmd,td->nmd", A, Ec, u, -V) + np.einsum("t,tnm,td->nmd", A, Es, -TWO_PI * M)
+    Ec, Es, u, a = table_block(tab, x1, x2, with_mid=True)
+    J = np.einsum("t,tnm,tnmd,td->nmd", A, Ec, u, -V) + np.einsum("t,tnm,td->nmd", A, Es, -TWO_PI * M)
+    if a is not None:             # envelope on the midpoint: d/dx1 of exp(-1/2 L a^2) = -1/2 L a
+        J = J + np.einsum("t,tnm,tnmd,td->nmd", A, Ec, a, -0.5 * tab[:, 2 + 3 * D:2 + 4 * D])
+    return J
+
+
+def _jc_block(tab, x1, x2):
+    """d K_ab / d x2_b,d (n1, n2, D): minus the stationary part of _jr_block, plus the SAME envelope part (the midpoint moves with both inputs)"""
+    D = x1.shape[1]
+    A, V, M = tab[:, 0], tab[:, 2:2 + D], tab[:, 2 + D:2 + 2 * D]
+    Ec, Es, u, a = table_block(tab, x1, x2, with_mid=True)
+    J = -(np.einsum("t,tnm,tnmd,td->nmd", A, Ec, u, -V) + np.einsum("t,tnm,td->nmd", A, Es, -TWO_PI * M))
+    if a is not None:
+        J = J + np.einsum("t,tnm,tnmd,td->nmd", A, Ec, a, -0.5 * tab[:, 2 + 3 * D:2 + 4 * D])
+    return J
 
 
 def moments_dense(table, G, X1, X2, sym):
@@ -164,21 +178,25 @@ def moments_dense(table, G, X1, X2, sym):
     C, T = table.shape[0], table.shape[2]
     D = X1.shape[1] - 1
     c1, c2 = X1[:, 0].astype(np.int64), X2[:, 0].astype(np.int64)
-    out = np.zeros(((C * (C + 1) // 2) if sym else C * C, T, 2 + 3 * D))
+    env = table.shape[3] > 2 + 3 * D
+    out = np.zeros(((C * (C + 1) // 2) if sym else C * C, T, table.shape[3]))
     for i in range(C):
         ri = np.nonzero(c1 == i)[0]
         for j in range((i + 1) if sym else C):
             rj = np.nonzero(c2 == j)[0]
             if len(ri) == 0 or len(rj) == 0:
                 continue
-            Ec, Es, u = table_block(table[i, j], X1[ri, 1:], X2[rj, 1:])
+            Ec, Es, u, amid = table_block(table[i, j], X1[ri, 1:], X2[rj, 1:], with_mid=True)
             g = G[np.ix_(ri, rj)] * (2.0 if (sym and i != j) else 1.0)
             m = out[i * (i + 1) // 2 + j] if sym else out[i * C + j]
             m[:, 0] = np.einsum("nm,tnm->t", g, Ec)
             m[:, 1] = np.einsum("nm,tnm->t", g, Es)
             m[:, 2:2 + D] = np.einsum("nm,tnm,tnmd->td", g, Ec, u * u)
             m[:, 2 + D:2 + 2 * D] = np.einsum("nm,tnm,tnmd->td", g, Ec, u)
-            m[:, 2 + 2 * D:] = np.einsum("nm,tnm,tnmd->td", g, Es, u)
+            m[:, 2 + 2 * D:2 + 3 * D] = np.einsum("nm,tnm,tnmd->td", g, Es, u)
+            if env:
+                m[:, 2 + 3 * D:2 + 4 * D] = np.einsum("nm,tnm,tnmd->td", g, Ec, amid * amid)
+                m[:, 2 + 4 * D:2 + 5 * D] = np.einsum("nm,tnm,tnmd->td", g, Ec, amid)
             if sym and i == j:          # odd-in-tau moments cancel over the full symmetric block
                 m[:, 1] = 0.0
                 m[:, 2 + D:2 + 2 * D] = 0.0
@@ -214,7 +232,9 @@ def titsias_eval(self, Z, sigma, jitter, kff_diag, grad=True, sharded=False):
     v = W @ B
     Q = red(v @ v.T)
     vy = red(v @ y)
-    yy, N, kff = red(np.array([(y.T @ y).item(), float(X.shape[0]), float(np.sum(np.asarray(kff_diag)[cx]))]))
+    env = table.shape[3] > 2 + 3 * D                       # enveloped terms: K_ff,diag per training point
+    yy, N, kff = red(np.array([(y.T @ y).item(), float(X.shape[0]),
+                               float(np.sum(np.asarray(kff_diag)) if env else np.sum(np.asarray(kff_diag)[cx]))]))
     Lq = np.linalg.cholesky(Q / s2 + np.eye(M))
     c = solve_triangular(Lq, vy, lower=True) / s2
     elbo = (-0.5 * N * np.log(TWO_PI) - np.sum(np.log(np.diagonal(Lq))) - N * np.log(sigma) - 0.5 * yy / s2
@@ -244,8 +264,13 @@ def titsias_eval(self, Z, sigma, jitter, kff_diag, grad=True, sharded=False):
             if len(rj):
                 gZ_uf[ri] += np.einsum("nm,nmd->nd", GB[np.ix_(ri, rj)], _jr_block(table[i, j], Z[ri, 1:], X[rj, 1:]))
             zj = np.nonzero(cz == j)[0]
-            if len(zj):
-                gZ_uu[ri] += 2.0 * np.einsum("nm,nmd->nd", GA[np.ix_(ri, zj)], _jr_block(table[i, j], Z[ri, 1:], Z[zj, 1:]))
+            if len(zj):             # K_uu depends on z_a through row a AND column a: sum_b GA_ab dK_ab/dz_a + sum_b GA_ba dK_ba/dz_a
+                tij = table[i, j] if i >= j else None
+                if tij is not None:
+                    Jr = _jr_block(tij, Z[ri, 1:], Z[zj, 1:])
+                else:               # block (i, j) above the diagonal is the transpose of block (j, i): K_ab = K'_ba
+                    Jr = np.transpose(_jc_block(table[j, i], Z[zj, 1:], Z[ri, 1:]), (1, 0, 2))
+                gZ_uu[ri] += 2.0 * np.einsum("nm,nmd->nd", GA[np.ix_(ri, zj)], Jr)
     return dict(elbo=elbo, jitter_abs=jit, mom_uu=mom_uu, mom_uf=mom_uf, gZ=red(gZ_uf) + gZ_uu, trGA=float(np.trace(GA)),
                 dsigma=2.0 * sigma * ds2)
 
@@ -266,7 +291,8 @@ def titsias_predict(self, Z, sigma, jitter, Xs, kss_diag, sharded=False):
     b = solve_triangular(Lq, a, lower=True)
     c = solve_triangular(Lq, red(v @ y), lower=True) / s2
     mu = b.T @ c
-    var = np.asarray(kss_diag)[Xs[:, 0].astype(np.int64)] - np.sum(a * a, axis=0) + np.sum(b * b, axis=0)
+    kd = np.asarray(kss_diag) if table.shape[3] > 2 + 3 * self.D else np.asarray(kss_diag)[Xs[:, 0].astype(np.int64)]      # enveloped terms: per test point
+    var = kd - np.sum(a * a, axis=0) + np.sum(b * b, axis=0)
     self._sparse_pred = (np.array(Xs), a, b)
     return mu, var.reshape(-1, 1)
 
@@ -340,8 +366,13 @@ def snelson_eval(self, Z, noise_var, jitter, kff_diag, grad=True, sharded=False)
             if len(rj):
                 gZ[ri] += np.einsum("nm,nmd->nd", GB[np.ix_(ri, rj)], _jr_block(table[i, j], Z[ri, 1:], X[rj, 1:]))
             zj = np.nonzero(cz == j)[0]
-            if len(zj):
-                gZ_uu[ri] += 2.0 * np.einsum("nm,nmd->nd", GA[np.ix_(ri, zj)], _jr_block(table[i, j], Z[ri, 1:], Z[zj, 1:]))
+            if len(zj):             # K_uu depends on z_a through row a AND column a: sum_b GA_ab dK_ab/dz_a + sum_b GA_ba dK_ba/dz_a
+                tij = table[i, j] if i >= j else None
+                if tij is not None:
+                    Jr = _jr_block(tij, Z[ri, 1:], Z[zj, 1:])
+                else:               # block (i, j) above the diagonal is the transpose of block (j, i): K_ab = K'_ba
+                    Jr = np.transpose(_jc_block(table[j, i], Z[zj, 1:], Z[ri, 1:]), (1, 0, 2))
+                gZ_uu[ri] += 2.0 * np.einsum("nm,nmd->nd", GA[np.ix_(ri, zj)], Jr)
     hsum = red(np.bincount(cx, weights=h, minlength=C).astype(np.float64))           # per channel: d p / d Kff_diag[c] = d p / d sigma_c^2
     return dict(lml=p, jitter_abs=jit, mom_uu=mom_uu, mom_uf=mom_uf, gZ=red(gZ) + gZ_uu, trGA=float(np.trace(GA)), hsum=hsum)
 
@@ -654,7 +685,10 @@ def _shard_finish(self):
             m[:, 1] = 0.0 if i == j else np.einsum("nm,tnm->t", g, Es)
             m[:, 2:2 + D] = np.einsum("nm,tnm,tnmd->td", g, Ec, u * u)
             m[:, 2 + D:2 + 2 * D] = 0.0 if i == j else np.einsum("nm,tnm,tnmd->td", g, Ec, u)
-            m[:, 2 + 2 * D:] = np.einsum("nm,tnm,tnmd->td", g, Es, u)
+            m[:, 2 + 2 * D:2 + 3 * D] = np.einsum("nm,tnm,tnmd->td", g, Es, u)
+            if env:
+                m[:, 2 + 3 * D:2 + 4 * D] = np.einsum("nm,tnm,tnmd->td", g, Ec, amid * amid)
+                m[:, 2 + 4 * D:2 + 5 * D] = np.einsum("nm,tnm,tnmd->td", g, Ec, amid)
     dG = np.where(mask, np.diagonal(G), 0.0)
     diagG = np.array([np.sum(dG[c == k]) for k in range(C)])
     return lml, mom, diagG

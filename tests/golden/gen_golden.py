@@ -21,6 +21,7 @@ nothing of the reference travels.  Re-run:  python tests/golden/gen_golden.py [-
   cfg2.npz      [--full] MOSM C=4 Q=3 N=8192 LML + gradient (BASELINE.json configs[1]; ~20 s, 10 GB)
   cfg4.npz      [--full] CSM C=4 Q=3 N=16384 predict_f at 64 probe rows of S=4096 (configs[3]; ~40 s, 16 GB)
   titsias.npz   small Titsias ELBO + gradients (kernel, scale, inducing points) + predict_f
+  titsias_mohsm.npz  the same with an enveloped kernel (MOHSM): any kernel under any inference
   cfg5.npz      [--full] Titsias MOSM C=4 Q=3 N=100000 M=2048 ELBO + gradient (configs[4]; ~60 s, 37 GB)
                 (reference self-consistency at cfg5, 8 vs 3 torch threads: kernel/noise gradients 4e-12..9e-12 relative,
                  inducing-point gradient 2.35e-3 relative / 2.5e-5 absolute -- that tensor is ill-conditioned)
@@ -710,6 +711,40 @@ def gen_titsias():
     print("titsias.npz written")
 
 
+def gen_titsias_mohsm():
+    """Titsias bound with an ENVELOPED kernel (MixtureKernel of MultiOutputHarmonizableSpectralKernel): the reference runs any kernel under
+    any inference (gpr/multioutput.py:340-395 under gpr/model.py:700-724).  ELBO, gradients of every parameter incl. lengthscale / center
+    and the inducing inputs (through the envelope too), predict_f."""
+    out = {}
+    cases = [(3, 2, 1, 96, [5, 4, 6], False), (2, 1, 2, 80, [4, 9], True), (1, 2, 1, 60, [9], False)]
+    out["ncases"] = np.array(len(cases))
+    for n, (C, Q, D, N, Zspec, shuffle) in enumerate(cases):
+        rng = np.random.default_rng(9500 + n)
+        X, y = small_data(N, C, D, 9600 + n, shuffle)
+        k = build_kernel("mohsm", C, Q, D, 1, rng)
+        for q in range(Q):       # K_uu carries no noise: keep the cross-channel blocks a valid covariance (shared spectrum, no delay / phase,
+            k[q].mean.assign(np.tile(rng.uniform(0.05, 0.5, (1, D)), (C, 1)))          # one lengthscale): a coregionalised harmonizable kernel
+            k[q].variance.assign(np.tile(rng.uniform(0.05, 0.5, (1, D)), (C, 1)))
+            k[q].lengthscale.assign(np.full(C, rng.uniform(0.1, 0.4)))
+            k[q].delay.assign(np.zeros((C, D)))
+            k[q].phase.assign(np.zeros(C))
+        s = float(rng.uniform(0.15, 0.4))
+        m = g.Titsias(k, T(X), T(y), Z=Zspec, Z_init="grid", variance=s ** 2, jitter=1e-6)
+        m.likelihood.scale.assign(s)
+        pre = "c%d_" % n
+        out[pre + "meta"] = np.array([C, Q, D, 1]); out[pre + "X"] = X; out[pre + "y"] = y
+        out[pre + "Zspec"] = np.atleast_1d(np.array(Zspec)); out[pre + "scale"] = np.array(s)
+        out[pre + "jitter"] = np.array(m.jitter)
+        out[pre + "elbo"] = np.array(float(m.log_marginal_likelihood()))
+        out[pre + "loss"] = np.array(float(m.loss()))
+        dump_params(pre, list(m.parameters()), out, with_grad=True)
+        Xs, _ = small_data(21, C, D, 9700 + n, shuffle)
+        mu, var = m.predict_f(T(Xs))
+        out[pre + "Xs"] = Xs; out[pre + "mu"] = mu.numpy(); out[pre + "var"] = var.numpy()
+    np.savez_compressed(os.path.join(HERE, "titsias_mohsm.npz"), **out)
+    print("titsias_mohsm.npz written")
+
+
 def gen_cfg5():
     import time
     C, Q, N, M = 4, 3, 100000, 2048
@@ -1124,7 +1159,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "lbfgs": gen_lbfgs_cfg1, "quirks": gen_quirks,
              "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2, "smlmc": gen_smlmc, "init_ls": gen_init_ls, "bnse": gen_bnse, "transformers": gen_transformers,
-             "titsias": gen_titsias, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints, "snelson": gen_snelson, "hensman": gen_hensman, "oa": gen_oa, "likelihoods": gen_likelihoods, "samples": gen_samples, "sparse_cov": gen_sparse_cov}
+             "titsias": gen_titsias, "titsias_mohsm": gen_titsias_mohsm, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints, "snelson": gen_snelson, "hensman": gen_hensman, "oa": gen_oa, "likelihoods": gen_likelihoods, "samples": gen_samples, "sparse_cov": gen_sparse_cov}
     full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:
         {**steps, **full}[a.only]()

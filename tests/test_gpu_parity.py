@@ -500,6 +500,13 @@ def test_mohsm_predict_and_wrapper_on_device():
     check_mohsm_predict_and_wrapper(tol_pred=1e-7, tol_loss=1e-9, tol_grad=1e-7, tol_trace=1e-7)
 
 
+def test_titsias_with_enveloped_terms_on_device():
+    """the sparse bound with MOHSM terms (rows of width 2 + 5 D) on the device against the reference's autograd: ELBO, every gradient incl.
+    lengthscale / center and the inducing inputs (the envelope's share of d/dZ), predict_f with K_ss,diag per test point"""
+    from test_host_logic import check_titsias_with_enveloped_terms
+    check_titsias_with_enveloped_terms(tol_loss=1e-9, tol_grad=1e-6, tol_pred=1e-7)
+
+
 def test_single_precision_switch_on_device():
     from test_host_logic import check_single_precision_switch
     check_single_precision_switch()
