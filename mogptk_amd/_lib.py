@@ -319,7 +319,7 @@ class ExactHandle:
         Z = _f64(Z)
         kff_diag = _f64(kff_diag)
         M = Z.shape[0]
-        C, T, W, D = self.C, self.T, 2 + 3 * self.D, self.D
+        C, T, W, D = self.C, self.T, self.W, self.D      # rows of the width set_terms took (2 + 3 D, or 2 + 5 D with an envelope)
         elbo, trGA, dsig, jit = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         info = ctypes.c_int64(0)
         mom_uu = np.zeros((C * (C + 1) // 2, T, W)) if grad else None
