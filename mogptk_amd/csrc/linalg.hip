@@ -254,7 +254,12 @@ static int launch_gemm_t(const GemmArgs& a, int grid, hipStream_t s) {
     return 0;
 }
 
-int launch_gemm(const GemmArgs& a, hipStream_t s) {
+int launch_gemm(const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    // MOGP_FAKE_K=d (measurement only, WRONG results): the 128 x 128-tile launches contract 1/d of their k range -- is an evaluation bound
+    // by what the GEMM streams deliver (time falls with d) or by its dependency chain (it does not)?
+    static const int fake_k = std::getenv("MOGP_FAKE_K") ? std::atoi(std::getenv("MOGP_FAKE_K")) : 0;
+    if (fake_k > 1 && !a.small && a.mode != GM_TASKS && a.K >= 512) a.K = (a.K / fake_k) / GEMM_BK * GEMM_BK;
     int grid;
     switch (a.mode) {
         case GM_LOWER: case GM_LAUUM: grid = a.mt * (a.mt + 1) / 2; break;
@@ -266,6 +271,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     const int v = (a.a_kmajor ? 2 : 0) | (a.b_kmajor ? 1 : 0);
     if (a.small) {
         const bool rect = a.mode == GM_RECT || a.mode == GM_RECT_LOWER;
+        // (eight waves on the 64-row tiles as well: no difference -- 12.97 vs 12.97 ms at configs[1], 47.4 vs 47.3 at configs[3])
         if (a.small == 1 && v == 1 && (rect || a.mode == GM_KLO_J || a.mode == GM_KHI_I)) return launch_gemm_t<0, 1, 2, 4>(a, grid, s);
         if (a.small == 1 && v == 0 && a.mode == GM_KHI_J) return launch_gemm_t<0, 0, 2, 4>(a, grid, s);
         if (v != 0 || !rect) {

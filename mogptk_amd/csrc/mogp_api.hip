@@ -553,7 +553,8 @@ static int factorize_finish(mogp_model* m, const GramArgs& ga, double* lml, int6
     std::memcpy(&hinfo, m->h_pin + nb + nzz, sizeof(hinfo));
     int rc;
     if (hinfo == MOGP_INFO_CHAIN_TIMEOUT) return MOGP_RETRY_NO_CHAIN;      // the caller repeats the evaluation on the launch-per-step chain
-    if (hinfo != big) {
+    static const bool fake = std::getenv("MOGP_FAKE_K") && std::atoi(std::getenv("MOGP_FAKE_K")) > 1;    // timing experiment: the numbers are wrong on purpose
+    if (hinfo != big && !fake) {
         if (info) *info = (int64_t)hinfo;
         // distinguish NaN / Inf in the Gram from a plain indefinite matrix (reference prints which, gpr/model.py:249-252)
         int flag = 0;

@@ -202,6 +202,11 @@ int spd_potri_fused(mogp_model* m, Spd& w) {
     //     and a FIFTH CU-masked stream slows everything on the reserved CUs (chain kernel 520-680 us instead of 245);
     //   * the inverse's streams confined to a subset of the CUs: 15.7 ms (160 CUs) ... 54 ms (48 CUs) -- the panel buffers couple the chain
     //     to the inverse.
+    //   * device-side hand-offs instead of events on the block cycle (a one-thread kernel raising a flag behind the producer, a spinning
+    //     one-wave kernel in front of the consumer): the kernel behind such a gate starts without the cache invalidation the runtime
+    //     attaches to a cross-queue wait and reads stale panel rows (wrong pivots from N = 4096 on); and with the GEMM work taken out
+    //     (MOGP_FAKE_K=8, tools/fake_k.py) a block period is 475 us = chain 245 + mini-panel 140 + 90 for three hops and two tiny launches,
+    //     so an event costs ~20 us, not the 45-55 us seen on a loaded chip -- those are slots that free in bursts.
     // What the traces say (profiles/r3_c1_timeline.txt): a block period is mini-panel (140 us) -> rest of the panel (~200) -> columns of the
     // block after next (~200) -> mini-panel, plus ~45 us per cross-stream event; the chain kernel runs next to the two tall launches, off
     // that cycle.  And the chip is busy with GEMM tiles throughout (47-58 TFLOP/s in every 500 us window): the evaluation is bound by what
