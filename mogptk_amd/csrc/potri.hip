@@ -207,6 +207,8 @@ int spd_potri_fused(mogp_model* m, Spd& w) {
     //     attaches to a cross-queue wait and reads stale panel rows (wrong pivots from N = 4096 on); and with the GEMM work taken out
     //     (MOGP_FAKE_K=8, tools/fake_k.py) a block period is 475 us = chain 245 + mini-panel 140 + 90 for three hops and two tiny launches,
     //     so an event costs ~20 us, not the 45-55 us seen on a loaded chip -- those are slots that free in bursts.
+    //   * the next block's columns and those of the block after it in ONE launch on the critical stream (high priority, one event fewer):
+    //     13.25 vs 12.99 ms -- that launch has to wait for the whole remainder of the previous panel.
     // What the traces say (profiles/r3_c1_timeline.txt): a block period is mini-panel (140 us) -> rest of the panel (~200) -> columns of the
     // block after next (~200) -> mini-panel, plus ~45 us per cross-stream event; the chain kernel runs next to the two tall launches, off
     // that cycle.  And the chip is busy with GEMM tiles throughout (47-58 TFLOP/s in every 500 us window): the evaluation is bound by what
