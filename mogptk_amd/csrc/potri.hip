@@ -209,6 +209,8 @@ int spd_potri_fused(mogp_model* m, Spd& w) {
     //     so an event costs ~20 us, not the 45-55 us seen on a loaded chip -- those are slots that free in bursts.
     //   * the next block's columns and those of the block after it in ONE launch on the critical stream (high priority, one event fewer):
     //     13.25 vs 12.99 ms -- that launch has to wait for the whole remainder of the previous panel.
+    //   * s_setprio 3 for the waves of the three tall launches on the block cycle (a 48-tile launch late in the factorisation takes 160-200 us
+    //     next to the remainders' workgroups): 13.05 vs 13.01 ms -- it is not the MFMA issue slots they wait for.
     // What the traces say (profiles/r3_c1_timeline.txt): a block period is mini-panel (140 us) -> rest of the panel (~200) -> columns of the
     // block after next (~200) -> mini-panel, plus ~45 us per cross-stream event; the chain kernel runs next to the two tall launches, off
     // that cycle.  And the chip is busy with GEMM tiles throughout (47-58 TFLOP/s in every 500 us window): the evaluation is bound by what

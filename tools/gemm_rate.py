@@ -18,13 +18,21 @@ for i, r in enumerate(rows):                      # an evaluation starts at its 
         last_gram = r[1]
 ev = rows[idx[-2]:idx[-1]] if len(idx) >= 2 else rows[idx[-1]:]
 t0 = ev[0][1]
+def tile_shape(name):
+    """k_gemm<AKM, BKM, WTM, WTN[, NWJ, NWI]> -> workgroup tile (rows, columns)"""
+    a = [int(v) for v in name[name.index("<") + 1:name.index(">")].split(",")]
+    nwj, nwi = (a[4] if len(a) > 4 else 2), (a[5] if len(a) > 5 else 2)
+    return 16 * nwi * a[2], 16 * nwj * a[3]
+
+
 W = 500.0
 nb = int((max(r[2] for r in ev) - t0) / 1e3 / W) + 1
 fl = np.zeros(nb)
 for r in ev:
     if not r[0].startswith("k_gemm"): continue
-    big = "4, 4" in r[0]
-    f = r[4] * (128 * 128 if big else (64 * 128 if "2, 4" in r[0] else 64 * 64)) * 512 * 2 * (1.0 if big else 0.4)
+    tm, tn = tile_shape(r[0])
+    big = tm == 128 and tn == 128
+    f = r[4] * tm * tn * 512 * 2 * (1.0 if big else 0.4)
     s = (r[1] - t0) / 1e3; e = (r[2] - t0) / 1e3
     for b in range(int(s // W), int(e // W) + 1):
         lo = max(s, b * W); hi = min(e, (b + 1) * W)
@@ -32,6 +40,6 @@ for r in ev:
 print("window start (us): TF  ", "  ".join("%d:%.0f" % (b * W, fl[b] / W / 1e6) for b in range(nb)))
 if "--list" in sys.argv:
     for r in ev:
-        if r[0].startswith("k_gemm") and "4, 4" in r[0]:
+        if r[0].startswith("k_gemm") and tile_shape(r[0]) == (128, 128):
             d = (r[2] - r[1]) / 1e3
             print("%8.1f %7.1f q%d grid %5d  %5.1f TF %s" % ((r[1] - t0) / 1e3, d, r[3], r[4], r[4] * 128 * 128 * 512 * 2 / d / 1e6, r[0]))
