@@ -48,9 +48,10 @@ PROBE_WORKER = textwrap.dedent('''
     import bench
     rank = int(os.environ["RANK"])
     base = int(os.environ["MASTER_PORT"]) + 20
-    out = bench.run_probes(["dummy", "hang"], base, timeout_s=25.0)
+    out = bench.run_probes(["dummy"], base, timeout_s=60.0)
+    out2 = bench.run_probes(["hang", "dummy"], base + 10, timeout_s=25.0)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps({"dummy": out["dummy"], "hang": out2["hang"], "after_hang": out2["dummy"]}))
 ''')
 
 
@@ -70,6 +71,7 @@ def test_sharded_probes_are_child_groups_with_their_own_watchdog(tmp_path):
     assert r["dummy"]["rccl_ranks"] == 2 and r["dummy"]["rank_sum_ok"] is True, r
     assert r["dummy"]["probe_wall_s"] > 0
     assert "watchdog" in r["hang"]["error"], r
+    assert "skipped" in r["after_hang"]["error"], r            # a probe behind one that hung is not started
 
 
 def test_line_objects_have_the_keys_the_driver_reads():
