@@ -240,6 +240,260 @@ __global__ __launch_bounds__(64 * NWI * NWJ, NWI * NWJ / 2) void k_gemm(GemmArgs
 #endif
 }
 
+// ---- stream-K form of the 128 x 128-tile kernel -------------------------------------------------------------------------------------
+// A launch of T equal tiles on S workgroup slots takes ceil(T / S) rounds: 2080 tiles on 512 slots pay five rounds for 4.06 rounds of work,
+// the 782-tile launches of the sparse models' substitutions two rounds for 1.53, and a launch of 16 tiles on the critical path of the
+// factorisation takes a whole tile's latency however many CUs idle.  Here the launch is S workgroups, and workgroup s takes the s-th
+// S-th of the launch's k ITERATIONS (tile by tile, k block by k block): at most one tile that started in the span before it, whole tiles,
+// and at most one tile that ends in a later span.  A tile cut that way is finished by its OWNER, the span holding its first k block:
+// the spans after it compute their k ranges first thing (nothing to wait for), leave alpha * (their sum) in a slot of a workspace
+// (write-through stores, then one agent-scope flag per span -- chain.hip's hand-off), and the owner, which reaches that tile LAST in its
+// own span, adds the slots in span order to its own sum and writes C.  Fixed order: bit-reproducible (not bit-identical to the unsplit
+// kernel: a cut tile's sum is associated differently).  No workgroup ever waits before it has produced what others wait for, and a span's
+// successors have higher span numbers inside an XCD's chunk: a launch that does not get all S slots at once still drains.
+// Supported: GM_RECT, GM_RECT_LOWER, GM_LOWER (equal k range per tile), GM_KHI_J / GM_KLO_J (k range by tile column); eight-wave tile only.
+struct SkTile { int ti, tj, kt, kbase, start; bool skip; };
+#define SK_U(x) __builtin_amdgcn_readfirstlane(x)      // launch-uniform values: keep them in scalar registers
+
+template <int TMR, int TNC>
+__device__ __forceinline__ int sk_col_kt(const GemmArgs& g, int tj) {
+    if (g.mode == GM_KHI_J) return (int)(min((int64_t)g.K, (int64_t)(tj + 1) * TNC) / GEMM_BK);
+    if (g.mode == GM_KLO_J) return (int)((g.K - (int64_t)tj * TNC) / GEMM_BK);
+    return g.K / GEMM_BK;
+}
+// the tile holding iteration `it` of the launch's flattened (tile, k block) space
+template <int TMR, int TNC>
+__device__ __forceinline__ SkTile sk_locate(const GemmArgs& g, int it, int rowcost) {
+    SkTile t;
+    t.kbase = 0; t.skip = false;
+    if (g.mode == GM_KHI_J || g.mode == GM_KLO_J) {
+        t.ti = SK_U(it / rowcost);
+        int r = it - t.ti * rowcost, tj = 0, c = sk_col_kt<TMR, TNC>(g, 0);
+        t.start = t.ti * rowcost;
+        while (r >= c) { r -= c; t.start += c; ++tj; c = sk_col_kt<TMR, TNC>(g, tj); }
+        t.tj = SK_U(tj); t.kt = SK_U(c); t.start = SK_U(t.start);
+        if (g.mode == GM_KLO_J) t.kbase = tj * TNC / GEMM_BK;
+        return t;
+    }
+    const int ktu = g.K / GEMM_BK;
+    const int b = SK_U(it / ktu);
+    t.start = b * ktu; t.kt = ktu;
+    if (g.mode == GM_LOWER) { t.ti = SK_U(tri_row(b)); t.tj = b - t.ti * (t.ti + 1) / 2; }
+    else { t.ti = SK_U(b / g.nt); t.tj = b - t.ti * g.nt; }
+    t.skip = g.mode == GM_RECT_LOWER && (t.ti + 1) * TMR <= t.tj * TNC;
+    return t;
+}
+
+template <int AKM, int BKM>
+__global__ __launch_bounds__(512, 4) void k_gemm_sk(GemmArgs g) {
+    constexpr int WTM = 4, WTN = 2, NWJ = 4, NWI = 2;
+    using Cfg = GemmCfg<WTM, WTN, NWJ, NWI>;
+    constexpr int TMR = Cfg::TMR, TNC = Cfg::TNC, COLK_A = Cfg::COLK_A, COLK_B = Cfg::COLK_B, NT = Cfg::NT;
+    constexpr int OPER_A = Cfg::OPER_A, OPER_B = Cfg::OPER_B, EPT_A = Cfg::EPT_A, EPT_B = Cfg::EPT_B;
+    constexpr int NQ_A = EPT_A / 2, NQ_B = EPT_B / 2, TPR_A = GEMM_BK / EPT_A, TPR_B = GEMM_BK / EPT_B;
+    constexpr int TPK = NT / GEMM_BK;
+    constexpr int TILE_ELEMS = TMR * TNC;
+    extern __shared__ __attribute__((aligned(16))) double gemm_lds[];
+    const int tid = threadIdx.x;
+
+    const int S = gridDim.x;
+    int sp = blockIdx.x;                                   // span number: an XCD (blockIdx % 8) takes a contiguous run of spans
+    if (S >= 64 && (S & 7) == 0) sp = (sp & 7) * (S >> 3) + (sp >> 3);
+    sp = SK_U(sp);
+    int rowcost = 0, TOT;                                  // the launcher keeps the iteration count below 2^31
+    if (g.mode == GM_KHI_J || g.mode == GM_KLO_J) {
+        for (int tj = 0; tj < g.nt; ++tj) rowcost += sk_col_kt<TMR, TNC>(g, tj);
+        TOT = g.mt * rowcost;
+    } else {
+        TOT = (g.mode == GM_LOWER ? g.mt * (g.mt + 1) / 2 : g.mt * g.nt) * (g.K / GEMM_BK);
+    }
+    const int span_q = SK_U(TOT / S), span_r = TOT - span_q * S;
+    auto span_start = [&](int s) { return SK_U(span_q * s + span_r * s / S); };       // floor(TOT s / S) without 64-bit arithmetic (span_r s < S^2)
+    int it = span_start(sp);
+    const int it1 = span_start(sp + 1);
+
+    while (it < it1) {
+        const SkTile t = sk_locate<TMR, TNC>(g, it, rowcost);
+        const int kb0 = it - t.start;
+        const int kb1 = min(t.kt, kb0 + (it1 - it));
+        it += kb1 - kb0;
+        if (t.skip) continue;
+        const bool partial = kb0 > 0;                       // the tile began in an earlier span: this one contributes a slot
+        const bool owner = !partial && kb1 < t.kt;          // the tile ends in a later span: wait for the slots, then write C
+        const int kt = kb1 - kb0;
+        const int64_t k0 = (int64_t)(t.kbase + kb0) * GEMM_BK;
+        const double* Ap = g.A + (AKM ? k0 * g.lda + (int64_t)t.ti * TMR : (int64_t)t.ti * TMR * g.lda + k0);
+        const double* Bp = g.B + (BKM ? k0 * g.ldb + (int64_t)t.tj * TNC : (int64_t)t.tj * TNC * g.ldb + k0);
+        double* Cp = g.C + (int64_t)t.ti * TMR * g.ldc + (int64_t)t.tj * TNC;
+        const bool fresh = g.beta0_from > 0 && t.ti >= g.beta0_from - 1;
+        // per-thread offsets are derived from an opaque copy of the thread id INSIDE the loop: hoisted out of it (32 64-bit C offsets among
+        // them) they would not fit next to the accumulators and spill
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+        const int ln = tl & 63, wv = tl >> 6, wi = wv / NWJ, wj = wv % NWJ;
+        const int64_t a_g = AKM ? (int64_t)(tl / TPK) * g.lda + (tl % TPK) * EPT_A : (int64_t)(tl / TPR_A) * g.lda + (tl % TPR_A) * EPT_A;
+        const int64_t b_g = BKM ? (int64_t)(tl / TPK) * g.ldb + (tl % TPK) * EPT_B : (int64_t)(tl / TPR_B) * g.ldb + (tl % TPR_B) * EPT_B;
+        const int a_l = AKM ? (tl / TPK) * COLK_A + (tl % TPK) * EPT_A : (tl / TPR_A) * LDS_ROWK + (tl % TPR_A) * EPT_A;
+        const int b_l = BKM ? (tl / TPK) * COLK_B + (tl % TPK) * EPT_B : (tl / TPR_B) * LDS_ROWK + (tl % TPR_B) * EPT_B;
+        const int64_t a_step = AKM ? (int64_t)GEMM_BK * g.lda : GEMM_BK;
+        const int64_t b_step = BKM ? (int64_t)GEMM_BK * g.ldb : GEMM_BK;
+        const int crow = wi * (TMR / NWI) + (ln >> 4), ccol = wj * (TNC / NWJ) + (ln & 15);
+        const int fa = AKM ? (ln >> 4) * COLK_A + wi * (TMR / NWI) + (ln & 15) : (wi * (TMR / NWI) + (ln & 15)) * LDS_ROWK + (ln >> 4);
+        const int fb = BKM ? (ln >> 4) * COLK_B + wj * (TNC / NWJ) + (ln & 15) : (wj * (TNC / NWJ) + (ln & 15)) * LDS_ROWK + (ln >> 4);
+        constexpr int fa_m = AKM ? 16 : 16 * LDS_ROWK, fa_k = AKM ? 4 * COLK_A : 4;
+        constexpr int fb_n = BKM ? 16 : 16 * LDS_ROWK, fb_k = BKM ? 4 * COLK_B : 4;
+
+
+        d4_t acc[WTM][WTN];
+        if (!partial && g.beta != 0.0 && !fresh) {
+            const double sc = g.beta / g.alpha;
+#pragma unroll
+            for (int m = 0; m < WTM; ++m)
+#pragma unroll
+                for (int n = 0; n < WTN; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[m][n][r] = sc * Cp[(int64_t)(crow + m * 16 + 4 * r) * g.ldc + ccol + n * 16];
+        } else {
+#pragma unroll
+            for (int m = 0; m < WTM; ++m)
+#pragma unroll
+                for (int n = 0; n < WTN; ++n) acc[m][n] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        }
+        d2_t ra[NQ_A], rb[NQ_B];
+        auto load_block = [&](int kb) {
+            const d2_t* pa = reinterpret_cast<const d2_t*>(Ap + a_g + (int64_t)kb * a_step);
+            const d2_t* pb = reinterpret_cast<const d2_t*>(Bp + b_g + (int64_t)kb * b_step);
+#pragma unroll
+            for (int q = 0; q < NQ_A; ++q) ra[q] = pa[q];
+#pragma unroll
+            for (int q = 0; q < NQ_B; ++q) rb[q] = pb[q];
+        };
+        auto write_block = [&](int buf) {
+            double* sa = gemm_lds + buf * (OPER_A + OPER_B);
+            double* sb = sa + OPER_A;
+#pragma unroll
+            for (int q = 0; q < NQ_A; ++q) *reinterpret_cast<d2_t*>(sa + a_l + 2 * q) = ra[q];
+#pragma unroll
+            for (int q = 0; q < NQ_B; ++q) *reinterpret_cast<d2_t*>(sb + b_l + 2 * q) = rb[q];
+        };
+        auto read_frag = [&](double (&av)[WTM], double (&bv)[WTN], int buf, int k4) {
+            const double* sa = gemm_lds + buf * (OPER_A + OPER_B);
+            const double* sb = sa + OPER_A;
+#pragma unroll
+            for (int m = 0; m < WTM; ++m) av[m] = sa[fa + m * fa_m + k4 * fa_k];
+#pragma unroll
+            for (int n = 0; n < WTN; ++n) bv[n] = sb[fb + n * fb_n + k4 * fb_k];
+        };
+        auto mma = [&](const double (&av)[WTM], const double (&bv)[WTN]) {
+#pragma unroll
+            for (int m = 0; m < WTM; ++m)
+#pragma unroll
+                for (int n = 0; n < WTN; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[n], acc[m][n], 0, 0, 0);
+        };
+#define GEMM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+        __syncthreads();                                   // the previous segment's last fragment reads are done
+        load_block(0);
+        write_block(0);
+        load_block(min(1, kt - 1));
+        GEMM_LDS_BARRIER();
+        {
+            double a0[WTM], b0[WTN], a1[WTM], b1[WTN];
+            read_frag(a0, b0, 0, 0);
+            for (int kb = 0; kb < kt; ++kb) {               // the pipeline of k_gemm
+                const int buf = kb & 1;
+                read_frag(a1, b1, buf, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                read_frag(a0, b0, buf, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                write_block(buf ^ 1);
+                load_block(min(kb + 2, kt - 1));
+                read_frag(a1, b1, buf, 3);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                GEMM_LDS_BARRIER();
+                read_frag(a0, b0, buf ^ 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef GEMM_LDS_BARRIER
+#pragma unroll
+        for (int m = 0; m < WTM; ++m)
+#pragma unroll
+            for (int n = 0; n < WTN; ++n) acc[m][n] *= g.alpha;
+        if (partial) {
+            // slot sp: [register][thread] -- every store a contiguous 4 KB row; write-through, drained, then ONE flag store
+            double* slot = g.sk_ws + (size_t)sp * TILE_ELEMS;
+#pragma unroll
+            for (int m = 0; m < WTM; ++m)
+#pragma unroll
+                for (int n = 0; n < WTN; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        __hip_atomic_store(slot + (size_t)((m * WTN + n) * 4 + r) * NT + tl, acc[m][n][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(g.sk_flags + sp, g.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        if (owner) {
+            const int tile_end = t.start + t.kt;
+            int last = sp + 1;
+            while (last + 1 < S && span_start(last + 1) < tile_end) ++last;      // spans sp + 1 .. last hold the rest of this tile
+            if (tid == 0) {
+                for (int q = sp + 1; q <= last; ++q) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(g.sk_flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.sk_epoch) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spins > (1u << 24)) {           // seconds: the span never ran.  Reported through the pivot word (the evaluation fails loudly)
+                            if (g.sk_info) atomicMin(g.sk_info, (unsigned long long)MOGP_INFO_CHAIN_TIMEOUT);
+                            break;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            for (int q = sp + 1; q <= last; ++q) {
+                const double* slot = g.sk_ws + (size_t)q * TILE_ELEMS;
+#pragma unroll
+                for (int m = 0; m < WTM; ++m)
+#pragma unroll
+                    for (int n = 0; n < WTN; ++n)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[m][n][r] += __hip_atomic_load(slot + (size_t)((m * WTN + n) * 4 + r) * NT + tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < WTM; ++m)
+#pragma unroll
+            for (int n = 0; n < WTN; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Cp[(int64_t)(crow + m * 16 + 4 * r) * g.ldc + ccol + n * 16] = acc[m][n][r];
+    }
+}
+
+template <int AKM, int BKM>
+static int launch_gemm_sk_t(const GemmArgs& a, hipStream_t s) {
+    constexpr int lds_bytes = GemmCfg<4, 2, 4, 2>::LDS_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_sk<AKM, BKM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gemm_sk<AKM, BKM>), dim3(a.sk_spans), dim3(512), lds_bytes, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <int AKM, int BKM, int WTM, int WTN, int NWJ = 2, int NWI = 2>
 static int launch_gemm_t(const GemmArgs& a, int grid, hipStream_t s) {
     constexpr int lds_bytes = GemmCfg<WTM, WTN, NWJ, NWI>::LDS_BYTES;
@@ -286,6 +540,15 @@ int launch_gemm(const GemmArgs& a0, hipStream_t s) {
     // TFLOP/s (k-contiguous), 54.7 -> 58.9 (k-major); configs[1] 13.46 -> 12.96 ms, configs[2] 555 -> 546, configs[3] 48.8 -> 47.4.
     // MOGP_GEMM8=0: the four-wave kernel (4 x 4 MFMA tiles a wave, 224 VGPRs).
     static const bool eight = !(std::getenv("MOGP_GEMM8") && std::atoi(std::getenv("MOGP_GEMM8")) == 0);
+    if (a.sk_spans > 0 && eight && a.ksplit <= 1 && a.row_mod <= 1 && a.sk_ws && a.sk_flags &&
+        (a.mode == GM_RECT || a.mode == GM_RECT_LOWER || a.mode == GM_LOWER || a.mode == GM_KHI_J || a.mode == GM_KLO_J)) {
+        switch (v) {
+            case 0: return launch_gemm_sk_t<0, 0>(a, s);
+            case 1: return launch_gemm_sk_t<0, 1>(a, s);
+            case 2: return launch_gemm_sk_t<1, 0>(a, s);
+            default: return launch_gemm_sk_t<1, 1>(a, s);
+        }
+    }
     // (Sixteen waves of 2 x 2 tiles -- eight per SIMD, 64 VGPRs -- spill and read LDS twice as often: 55-56 TFLOP/s, slower than either.)
     if (eight) {
         switch (v) {

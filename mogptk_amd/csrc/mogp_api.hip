@@ -170,6 +170,8 @@ int mogp_ctx_create(int device, mogp_ctx** out) {
 int mogp_ctx_destroy(mogp_ctx* ctx) {
     if (!ctx) return MOGP_OK;
     for (hipStream_t q : {ctx->st, ctx->st2, ctx->st2u, ctx->st3, ctx->st4, ctx->st5, ctx->st_priv}) if (q) { hipError_t e = hipStreamSynchronize(q); (void)e; e = hipStreamDestroy(q); (void)e; }
+    for (auto& kv : ctx->sk) { kv.second.ws.release(); kv.second.flags.release(); }
+    ctx->sk.clear();
     delete ctx;
     return MOGP_OK;
 }
@@ -220,6 +222,55 @@ namespace mogp { void build_trtri_levels(Spd& w) {
 }
 }  // namespace mogp
 
+// Stream-K form for the launches whose tile count sits badly on the workgroup slots of their stream (linalg.hip:k_gemm_sk).
+// Measured inside the schedules (round 3, tools/r3_x2.sh): the wide triangular solves of the sparse models -- 782-tile updates that have the
+// chip to themselves -- gain (configs[4] 49.5 -> 47.9 ms); the fused factorisation + inversion and the prediction LOSE (configs[1] 12.9 ->
+// 13.9 ms, configs[3] 47.2 -> 50.4): next to other launches a partly filled round is filled by them anyway, and workgroups that hold their
+// slots four tiles long delay the critical stream's launches.  So: only where the caller asks (GemmArgs::sk_hint).
+// MOGP_SK (experiments): 0 = never; bit 0 = also launches of at least half the slots whose last round would be less than MOGP_SK_FILL
+// percent full; bit 1 = also launches of fewer tiles than a quarter of the slots on the critical stream; bit 2 = every eligible launch.
+namespace mogp { static int stream_k_setup(mogp_model* m, GemmArgs& g, hipStream_t st) {
+    static const int sk_mode = std::getenv("MOGP_SK") ? std::atoi(std::getenv("MOGP_SK")) : 8;        // 8: hinted launches only
+    static const int sk_min = std::getenv("MOGP_SK_MIN") ? std::max(1, std::atoi(std::getenv("MOGP_SK_MIN"))) : 8;       // k blocks per span at least
+    static const int sk_fill = std::getenv("MOGP_SK_FILL") ? std::atoi(std::getenv("MOGP_SK_FILL")) : 60;
+    g.sk_spans = 0;
+    if (!sk_mode || m->no_chain || g.small || g.ksplit > 1 || g.row_mod > 1 || g.K % 16) return 0;
+    if (!(g.mode == GM_RECT || g.mode == GM_RECT_LOWER || g.mode == GM_LOWER || g.mode == GM_KHI_J || g.mode == GM_KLO_J)) return 0;
+    mogp_ctx* ctx = m->ctx;
+    const int ncu = ctx->ncu > 0 ? ctx->ncu : 256;
+    int cus = ncu;
+    if (ctx->st_priv) {
+        if (st == ctx->st_priv) cus = ctx->ncu_reserved;
+        else if (st == ctx->st2 || st == ctx->st3 || st == ctx->st4) cus = ncu - ctx->ncu_reserved;
+    }
+    const int slots = 2 * cus;
+    const long long T = g.mode == GM_LOWER ? (long long)g.mt * (g.mt + 1) / 2 : (long long)g.mt * g.nt;
+    long long tot;
+    if (g.mode == GM_KHI_J || g.mode == GM_KLO_J) { long long row = 0; for (int tj = 0; tj < g.nt; ++tj) row += (g.mode == GM_KHI_J ? std::min<long long>(g.K, (long long)(tj + 1) * MOGP_TILE) : g.K - (long long)tj * MOGP_TILE) / 16; tot = row * g.mt; }
+    else tot = T * (g.K / 16);
+    if (tot <= 0 || tot >= (1ll << 31) || (long long)slots * slots >= (1ll << 31)) return 0;
+    bool want = (sk_mode & 4) != 0;
+    if (((sk_mode & 1) || g.sk_hint) && 2 * T >= slots) {
+        const long long last = T % slots;                       // tiles of the last round
+        if (last != 0 && 100 * last < (long long)sk_fill * slots) want = true;
+    }
+    if ((sk_mode & 2) && st == ctx->st && 4 * T < slots) want = true;
+    if (!want) return 0;
+    const long long spans = std::min<long long>(slots, tot / sk_min);
+    if (spans < 2) return 0;
+    mogp_ctx::SkWs& w = ctx->sk[st];
+    if (w.flags.n < (size_t)slots) {
+        HIP_TRY(hipStreamSynchronize(st));
+        int rc;
+        if ((rc = w.ws.ensure((size_t)slots * MOGP_TILE * MOGP_TILE))) return rc;
+        if ((rc = w.flags.ensure((size_t)slots))) return rc;
+        HIP_TRY(hipMemsetAsync(w.flags.p, 0, (size_t)slots * sizeof(unsigned), st));      // in stream order before the launch (the streams are non-blocking)
+        w.epoch = 0;
+    }
+    g.sk_spans = (int)spans; g.sk_ws = w.ws.p; g.sk_flags = w.flags.p; g.sk_epoch = ++w.epoch; g.sk_info = m->d_info.p;
+    return 0;
+} }
+
 namespace mogp { int gemm_call(mogp_model* m, const GemmArgs& g, double flops, hipStream_t st) {
     if (!st) st = m->st;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -231,7 +282,9 @@ namespace mogp { int gemm_call(mogp_model* m, const GemmArgs& g, double flops, h
         e1 = m->gemm_ev[m->gemm_ev_used++];
         HIP_TRY(hipEventRecord(e0, st));
     }
-    int rc = launch_gemm(g, st);
+    GemmArgs gs = g;
+    { int r__ = stream_k_setup(m, gs, st); if (r__) return r__; }
+    int rc = launch_gemm(gs, st);
     if (rc) return rc;
     if (m->profiling) HIP_TRY(hipEventRecord(e1, st));
     m->gemm_launches++;
@@ -741,6 +794,7 @@ static int ctx_streams(mogp_ctx* ctx) {
         HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
         const int ncu = prop.multiProcessorCount;
         const bool masked = reserve > 0 && 16 * reserve < ncu;
+        ctx->ncu = ncu; ctx->ncu_reserved = masked ? 8 * reserve : 0;
         ctx->chain_ok = !masked || 8 * reserve >= 13;        // one 128 KB workgroup per CU: fewer reserved CUs than workgroups would never all be resident
         if (masked) {
             std::vector<uint32_t> bulk((ncu + 31) / 32, 0u), priv((ncu + 31) / 32, 0u);

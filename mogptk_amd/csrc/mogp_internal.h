@@ -156,6 +156,13 @@ struct GemmArgs {
     int ksplit; int64_t c_split;                   // ksplit > 1: the k range is cut into ksplit slices, slice s accumulates into C + s * c_split (not with GM_TASKS)
     int row_mod, row_rem, row_off, row_shift;      // row_mod > 1: only tile rows with ((ti >> row_shift) + row_off) % row_mod == row_rem
                                                    // (sharded evaluation; row_shift = 1 when the launch uses 64-row tiles: ownership is per 128 rows)
+    // stream-K form (linalg.hip:k_gemm_sk): sk_spans > 0 = launch that many workgroups, each an equal share of the launch's k iterations
+    int sk_hint;                                   // the caller asks for the stream-K form when the tile count sits badly on the slots (a launch that has its stream's CUs to itself)
+    int sk_spans;
+    double* sk_ws;                                 // sk_spans slots of 128 x 128 doubles (one workspace per stream: launches of a stream do not overlap)
+    unsigned* sk_flags;                            // one word per span, never reset: a span's flag holds the epoch of the launch that filled its slot
+    unsigned sk_epoch;                             // > 0, different from every earlier launch on this workspace
+    unsigned long long* sk_info;                   // a hand-off that times out: atomicMin(MOGP_INFO_CHAIN_TIMEOUT)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 double gemm_flops(const GemmArgs& a, const std::vector<GemmTask>* host_tasks);

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <map>
 #include <vector>
 
 namespace mogp {
@@ -88,6 +89,10 @@ struct mogp_ctx {
     hipStream_t st = nullptr, st2 = nullptr, st3 = nullptr, st4 = nullptr, st5 = nullptr, st_priv = nullptr, st2u = nullptr;
     bool streams_ready = false;
     bool chain_ok = true;               // the private stream has room for the 13 workgroups of the persistent chain kernel (chain.hip)
+    // stream-K GEMM launches (linalg.hip:k_gemm_sk): one workspace per stream (launches of one stream never overlap)
+    struct SkWs { DevBuf<double> ws; DevBuf<unsigned> flags; unsigned epoch = 0; };
+    std::map<hipStream_t, SkWs> sk;
+    int ncu = 0, ncu_reserved = 0;      // CUs of the device, and how many of them the private stream owns
 };
 
 struct TrtriLevel {

@@ -182,6 +182,7 @@ int trsm_lower(mogp_model* m, const double* L, int64_t ldl, int nb, double* B, i
             }
             g.C = Bi; g.ldc = ldb; g.alpha = -1.0; g.beta = 1.0;
             g.mode = GM_RECT; g.mt = 1; g.nt = nt; g.K = step * MOGP_TILE;
+            g.sk_hint = 1;           // nt tiles per launch (782 at N = 100000: 1.53 rounds of the chip), nothing else running: stream-K form
             RC(gemm_call(m, g, gemm_flops(g, nullptr), st));
         }
         const double* Lii = L + (int64_t)i * MOGP_TILE * (ldl + 1);
