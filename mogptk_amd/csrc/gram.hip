@@ -792,8 +792,10 @@ __device__ __forceinline__ void moment_term(double* mom, const double (&g)[4][4]
         }
 }
 
+// Two workgroups per CU wherever the registers allow it with a handful of spills (D = 1: the input-gradient variant needs 268 VGPRs
+// unconstrained, i.e. ONE wave per SIMD and nothing to hide its loads behind).
 template <int DT, bool DENSE, bool ZG, bool ENV>
-__global__ __launch_bounds__(256) void k_moments(MomentArgs a) {
+__global__ __launch_bounds__(256, (DT == 1 ? 2 : 1)) void k_moments(MomentArgs a) {
     constexpr int DM = DT > 0 ? DT : MOGP_MAXD;
     constexpr int WM = 2 + (ENV ? 5 : 3) * DM;
     constexpr int RSTRIDE = 256 + 16;                        // one moment of all threads, +1 per 16 (the slice reads hit distinct banks)
@@ -866,7 +868,7 @@ __global__ __launch_bounds__(256) void k_moments(MomentArgs a) {
     int nred = 0;                                            // reductions done so far (selects the staging buffer)
     for (int t0 = 0; t0 < a.T; t0 += MOGP_TC) {
         const int nt = min(MOGP_TC, a.T - t0);
-        __syncthreads();
+        if (t0 > 0) __syncthreads();                         // the first chunk has nothing to wait for
         stage_chunk<DM, false, (DT == 1)>(L, X, tl, tab, W, D, a.C, a.T, t0, nt, v, a.x, a.ldx, xcol, ldxc, tid);
         __syncthreads();
         for (int t = 0; t < nt; ++t) {

@@ -47,10 +47,14 @@ __global__ __launch_bounds__(THREADS) void k_trsm_leaf(const double* __restrict_
             double x[TS_SB];
 #pragma unroll
             for (int r = 0; r < TS_SB; ++r) x[r] = b[(int64_t)(sb * TS_SB + r) * ldb];
-            for (int pb = 0; pb < sb; ++pb) {                         // x -= L[sb][pb] x_pb  (solved sub-blocks, re-read)
-                double xp[TS_SB];
+            // x -= L[sb][pb] x_pb over the solved sub-blocks, re-read from the (L1 / L2 resident) right-hand side ONE SUB-BLOCK AHEAD: the 16
+            // loads of sub-block pb + 1 fly under the 256 FMAs of sub-block pb (unpipelined, each of the 120 (sb, pb) pairs of a tile paid a
+            // cache round trip: 150 us per block row at configs[4], of which ~35 are arithmetic)
+            auto fetch = [&](double (&xp)[TS_SB], int pb) {
 #pragma unroll
                 for (int c = 0; c < TS_SB; ++c) xp[c] = b[(int64_t)(pb * TS_SB + c) * ldb];
+            };
+            auto apply = [&](const double (&xp)[TS_SB], int pb) {
                 const double* Lb = Ls + (sb * TS_SB) * TS_T + pb * TS_SB;
 #pragma unroll
                 for (int r = 0; r < TS_SB; ++r)
@@ -60,6 +64,16 @@ __global__ __launch_bounds__(THREADS) void k_trsm_leaf(const double* __restrict_
                         x[r] = fma(-l[0], xp[c], x[r]);
                         x[r] = fma(-l[1], xp[c + 1], x[r]);
                     }
+            };
+            double xa[TS_SB], xb[TS_SB];
+            if (sb > 0) fetch(xa, 0);
+            for (int pb = 0; pb < sb; pb += 2) {
+                if (pb + 1 < sb) fetch(xb, pb + 1);
+                apply(xa, pb);
+                if (pb + 1 < sb) {
+                    if (pb + 2 < sb) fetch(xa, pb + 2);
+                    apply(xb, pb + 1);
+                }
             }
             const double* Ld = Ls + (sb * TS_SB) * TS_T + sb * TS_SB;    // diagonal sub-block: forward substitution
 #pragma unroll
@@ -76,10 +90,12 @@ __global__ __launch_bounds__(THREADS) void k_trsm_leaf(const double* __restrict_
             double x[TS_SB];
 #pragma unroll
             for (int r = 0; r < TS_SB; ++r) x[r] = b[(int64_t)(sb * TS_SB + r) * ldb];
-            for (int pb = TS_T / TS_SB - 1; pb > sb; --pb) {          // x -= L[pb][sb]^T x_pb
-                double xp[TS_SB];
+            // x -= L[pb][sb]^T x_pb, the solved sub-blocks re-read one ahead (see the forward form)
+            auto fetch = [&](double (&xp)[TS_SB], int pb) {
 #pragma unroll
                 for (int c = 0; c < TS_SB; ++c) xp[c] = b[(int64_t)(pb * TS_SB + c) * ldb];
+            };
+            auto apply = [&](const double (&xp)[TS_SB], int pb) {
                 const double* Lb = Ls + (pb * TS_SB) * TS_T + sb * TS_SB;
 #pragma unroll
                 for (int c = 0; c < TS_SB; ++c)
@@ -89,6 +105,17 @@ __global__ __launch_bounds__(THREADS) void k_trsm_leaf(const double* __restrict_
                         x[r] = fma(-l[0], xp[c], x[r]);
                         x[r + 1] = fma(-l[1], xp[c], x[r + 1]);
                     }
+            };
+            constexpr int LAST = TS_T / TS_SB - 1;
+            double xa[TS_SB], xb[TS_SB];
+            if (LAST > sb) fetch(xa, LAST);
+            for (int pb = LAST; pb > sb; pb -= 2) {
+                if (pb - 1 > sb) fetch(xb, pb - 1);
+                apply(xa, pb);
+                if (pb - 1 > sb) {
+                    if (pb - 2 > sb) fetch(xa, pb - 2);
+                    apply(xb, pb - 1);
+                }
             }
             const double* Ld = Ls + (sb * TS_SB) * TS_T + sb * TS_SB;    // diagonal sub-block: backward substitution with L^T
 #pragma unroll
