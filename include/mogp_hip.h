@@ -176,6 +176,12 @@ int  mogp_comm_selftest(mogp_ctx* ctx, int* ranks_seen, int* rank_sum);
  * ms[0] exchange (pack, all-gather, unpack), ms[1] the part every rank repeats (Schur block inversion and panels), ms[2] the update of the
  * next pivot block's columns (critical stream), ms[3] the rank's share of the bulk update (bulk stream, overlaps the others). */
 int  mogp_shard_stage_ms(mogp_model* m, double* ms);
+/* Fraction of the lower 128 x 128 tiles of Kj^-1 the last mogp_exact_eval(..., MOGP_EVAL_GRAD) formed: the gradient
+ * 1/2 sum_ab (alpha_a alpha_b - Kinv_ab) dK_ab/dtheta (reference gpr/model.py:291, autograd through :242-246) reads Kinv only where some term
+ * of dK/dtheta is above e^-50 of its peak, and for stationary kernels on a series much longer than their support that is a band of tiles.
+ * 1.0 = all of them (always so above 0.85, with MOGP_FULL_INVERSE=1, on the sweep schedule and sharded).  mogp_model_fetch(which = 1)
+ * completes the inverse on demand. */
+int  mogp_model_inverse_fraction(mogp_model* m, double* fraction);
 /* mogp_exact_eval(..., MOGP_EVAL_GRAD) sharded over the context's communicator: same outputs, identical on every rank. */
 int  mogp_exact_eval_sharded(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
                              double* lml, double* moments, double* diagG, double* trG, double* jitter_abs, int64_t* info);

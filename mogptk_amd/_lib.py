@@ -63,6 +63,7 @@ SIGNATURES = {
     "mogp_comm_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "mogp_comm_selftest": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "mogp_shard_stage_ms": (ctypes.c_int, [ctypes.c_void_p, c_dp]),
+    "mogp_model_inverse_fraction": (ctypes.c_int, [ctypes.c_void_p, c_dp]),
     "mogp_exact_eval_sharded": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, c_dp, c_dp, c_dp, c_dp, c_dp, c_i64p]),
     "mogp_exact_predict_sharded": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.c_int64, c_dp, c_dp, c_dp, c_i64p]),
     "mogp_shard_config": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
@@ -444,6 +445,12 @@ class ExactHandle:
         ms = np.zeros(4)
         check(lib().mogp_shard_stage_ms(self._h, _dp(ms)))
         return ms
+
+    def inverse_fraction(self):
+        """fraction of the lower tiles of Kj^-1 the last gradient evaluation formed (1.0 = all; see include/mogp_hip.h)"""
+        f = np.zeros(1)
+        check(lib().mogp_model_inverse_fraction(self._h, _dp(f)))
+        return float(f[0])
 
     def fetch(self, which):
         out = np.empty(self.N if which == 2 else (self.N, self.N))

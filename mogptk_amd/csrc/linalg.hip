@@ -63,8 +63,14 @@ __global__ __launch_bounds__(64 * NWI * NWJ, NWI * NWJ / 2) void k_gemm(GemmArgs
     int kt;
     bool fresh = false;                  // this tile row starts from zero although the launch accumulates (beta0_from)
     if (g.mode == GM_TASKS) {
-        const GemmTask t = g.tasks[blockIdx.x];
+        int bid = blockIdx.x;
+        if (g.task_chunked && gridDim.x >= 64) {            // equal-cost tasks in row-major tile order: one contiguous chunk of the list per XCD (see below)
+            const int q = gridDim.x >> 3, r = gridDim.x & 7, x = bid & 7;
+            bid = x * q + min(x, r) + (bid >> 3);
+        }
+        const GemmTask t = g.tasks[bid];
         Ap = g.A + t.a_off; Bp = g.B + t.b_off; Cp = g.C + t.c_off; kt = t.kt;
+        fresh = g.beta0_from > 0 && t.pad >= g.beta0_from;  // pad = tile row + 1 when the list carries it (0: never fresh)
     } else {
         // XCD-aware tile order: workgroup b is dispatched to XCD b % 8, each with its own L2.  Giving every XCD one contiguous
         // chunk of the (row-major) tile list keeps a panel row inside one L2 instead of all eight (measured: 2.8x the algorithmic

@@ -141,7 +141,7 @@ enum GemmMode { GM_RECT = 0,      // mt x nt tiles, k in [0, K)
 struct GemmTask {              // element offsets relative to the launch's base pointers
     int64_t a_off, b_off, c_off;
     int kt;                    // number of 16-wide k blocks
-    int pad;
+    int pad;                   // 0, or the task's tile row + 1 (GemmArgs::beta0_from applies to task lists that carry it)
 };
 
 struct GemmArgs {
@@ -151,6 +151,7 @@ struct GemmArgs {
     double alpha, beta;                            // C = alpha * A.B^T(+layout) + beta * C
     int mode, mt, nt, K;
     const GemmTask* tasks; int ntasks;
+    int task_chunked;                              // GM_TASKS: the list is equal-cost tiles in row-major order -- give each XCD a contiguous chunk of it
     int small;                                     // 0: 128x128 tiles; 1: 64x128; 2: 64x64 (mt / nt count tiles of that shape)
     int beta0_from;                                // > 0: tile rows ti >= beta0_from - 1 are written with beta = 0 (fresh rows of an accumulator: no memset)
     int ksplit; int64_t c_split;                   // ksplit > 1: the k range is cut into ksplit slices, slice s accumulates into C + s * c_split (not with GM_TASKS)

@@ -220,6 +220,14 @@ struct mogp_model {
     DevBuf<double> d_symv;
     DevBuf<double> d_x, d_y, d_table, d_noise, d_dvar, d_z, d_alpha, d_zz, d_partial, d_moments, d_diagG;
     DevBuf<GTile> d_tiles;
+    // Tiles of Kj^-1 the gradient actually reads (mogp_api.hip:kinv_plan): where every term of dK/dtheta is below e^-50 of its peak in a
+    // 64 x 64 tile the moment kernel skips the tile, so the 128 x 128 tiles of the inverse under such tiles only are never formed.
+    std::vector<GemmTask> kinv_acc_tasks, kinv_lauum_tasks;        // host lists of the current plan (tile-row-major)
+    std::vector<int> kinv_prefix;                                 // [nb + 1]: tasks with tile row < r
+    DevBuf<GemmTask> d_kinv_acc, d_kinv_lauum;
+    std::vector<double> blk_cen, blk_half;                        // [D][nblk]: centre / half span of every 64-point block (k_block_centres' numbers)
+    bool kinv_sparse = false;                                     // the inverse held by k.B lacks the tiles outside the plan
+    double kinv_fraction = 1.0;                                   // planned / all lower tiles
     DevBuf<int> d_pair_start, d_chan_off, d_flag;
     DevBuf<unsigned long long> d_info;
 

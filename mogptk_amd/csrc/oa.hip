@@ -99,6 +99,7 @@ int mogp_oa_forward(mogp_model* m, const double* q_nu, const double* q_lambda, d
     o.valid = false;
     RC(ensure_system(m));
     m->have_W = m->have_Kinv = false;
+    m->kinv_sparse = false;                    // this model reads every entry of the inverse (the exact model's gradient plan does not apply)
     m->gemm_ev_used = 0; m->gemm_launches = 0; m->gemm_flops = 0.0;
     RC(o.K.ensure((size_t)Npad * Npad));
     RC(o.vec.ensure((size_t)V_COUNT * Npad));

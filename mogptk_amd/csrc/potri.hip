@@ -129,6 +129,11 @@ int inverse_step(mogp_model* m, Spd& w, const double* Wkk, int k0, int k1, const
     g.C = w.B.p; g.ldc = ld; g.alpha = 1.0; g.beta = 1.0;
     g.mode = GM_LOWER; g.mt = g.nt = k1; g.K = (int)Kd;
     g.beta0_from = k0 + 1;                         // the row block K of the inverse is new (it held scratch): written, not accumulated -- no memset
+    if (m->kinv_sparse && &w == &m->k && Kd == 4 * MOGP_TILE && k1 < (int)m->kinv_prefix.size()) {
+        // only the tiles of the inverse the gradient reads (mogp_api.hip:kinv_plan): the planned tiles of the rows above k1, same arithmetic
+        g.mode = GM_TASKS; g.tasks = m->d_kinv_acc.p; g.ntasks = m->kinv_prefix[k1]; g.task_chunked = 1; g.mt = g.nt = 0;
+        return gemm_call(m, g, 2.0 * MOGP_TILE * MOGP_TILE * (double)Kd * g.ntasks, qacc);
+    }
     return gemm_call(m, g, gemm_flops(g, nullptr), qacc);
 }
 

@@ -445,6 +445,64 @@ def test_every_gradient_schedule_matches_reference(path):
     assert "SWEEP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+@pytest.mark.parametrize("path", ["phases", "fused"])
+def test_gradient_with_only_the_needed_tiles_of_the_inverse(path):
+    """a series much longer than the kernel's support (3000 points over [0, 900], spectral variances 0.5 .. 1.5: dK/dtheta is below e^-50
+    of its peak beyond ~15): the evaluation forms only the tiles of Kj^-1 its gradient reads (mogp_model_inverse_fraction < 0.5), and
+    moments, diagG, trG and the LML must equal -- bit for bit -- those of the same evaluation with every tile formed (MOGP_FULL_INVERSE=1),
+    which in turn match the numpy restatement; mogp_model_fetch(1) afterwards still hands back the WHOLE inverse.  Both schedules that
+    form W^T W (sweep inverts in place and has nothing to drop)."""
+    import os, subprocess, sys, tempfile, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from mogptk_amd import gpr, _lib
+        from oracle.table_model import TableDevice
+        N, C, Q = 3000, 2, 2
+        rng = np.random.default_rng(5)
+        sizes = [1400, 1600]
+        X = np.concatenate([np.stack([np.full(s, float(c)), rng.uniform(0, 900, s)], axis=1) for c, s in enumerate(sizes)])
+        X = X[np.argsort(X[:, 1])]                 # channels interleaved, each in the order of its series (the library sorts by channel, stably: a
+        y = rng.standard_normal(N)                 # tile of 64 consecutive points of a channel is then local in x -- shuffled rows have no band)
+        k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=1)
+        k.weight.assign(rng.uniform(0.5, 1.5, (C, Q))); k.mean.assign(rng.uniform(0.02, 0.4, (C, Q, 1)))
+        k.variance.assign(rng.uniform(0.5, 1.5, (C, Q, 1))); k.delay.assign(rng.normal(0, 0.3, (C, Q, 1))); k.phase.assign(rng.normal(0, 0.3, (C, Q)))
+        table = k._spectral_terms(1)
+        noise = rng.uniform(0.05, 0.2, C)
+        dev = _lib.ExactHandle(0, X, y, C)
+        dev.set_terms(table)
+        a = dev.eval(noise, 1e-8, grad=True)
+        frac = dev.inverse_fraction()
+        Kinv = dev.fetch(1)
+        out = sys.argv[1]
+        if out != "-":
+            np.savez(out, lml=a["lml"], moments=a["moments"], diagG=a["diagG"], trG=a["trG"], frac=frac)
+        else:
+            ref = TableDevice(0, X, y, C); ref.set_terms(table)
+            b = ref.eval(noise, 1e-8, grad=True)
+            assert abs(a["lml"] - b["lml"]) < 1e-10 * abs(b["lml"])
+            scale = np.max(np.abs(b["moments"]))
+            assert np.max(np.abs(a["moments"] - b["moments"])) < 1e-9 * scale
+            Kj, _ = ref._Kj(noise, 1e-8, None)
+            Ki = np.linalg.inv(Kj)
+            assert np.max(np.abs(Kinv - Ki)) < 1e-9 * np.max(np.abs(Ki))
+            f = np.load(sys.argv[2])
+            assert frac < 0.5 and float(f["frac"]) == 1.0, (frac, float(f["frac"]))
+            assert a["lml"] == float(f["lml"]) and a["trG"] == float(f["trG"])
+            assert np.array_equal(a["moments"], f["moments"]) and np.array_equal(a["diagG"], f["diagG"])
+            print("PLAN_OK", frac)
+    ''') % (root, os.path.join(root, "tests"))
+    with tempfile.TemporaryDirectory() as tmp:
+        full = os.path.join(tmp, "full.npz")
+        r1 = subprocess.run([sys.executable, "-c", code, full], capture_output=True, text=True, timeout=600,
+                            env=dict(os.environ, MOGP_GRAD_PATH=path, MOGP_FULL_INVERSE="1"))
+        assert r1.returncode == 0, r1.stdout[-1500:] + r1.stderr[-3000:]
+        r2 = subprocess.run([sys.executable, "-c", code, "-", full], capture_output=True, text=True, timeout=600,
+                            env=dict({k_: v for k_, v in os.environ.items() if k_ != "MOGP_FULL_INVERSE"}, MOGP_GRAD_PATH=path))
+        assert "PLAN_OK" in r2.stdout, r2.stdout[-1500:] + r2.stderr[-3000:]
+
+
 @pytest.mark.parametrize("ranks", [2, 4, 8])
 def test_sharded_eval_ranks_sharing_one_gpu(ranks):
     """the multi-GPU evaluation and prediction (mogp_exact_eval_sharded / mogp_exact_predict_sharded: owned Gram + moment tiles, the
