@@ -686,9 +686,6 @@ def _shard_finish(self):
             m[:, 2:2 + D] = np.einsum("nm,tnm,tnmd->td", g, Ec, u * u)
             m[:, 2 + D:2 + 2 * D] = 0.0 if i == j else np.einsum("nm,tnm,tnmd->td", g, Ec, u)
             m[:, 2 + 2 * D:2 + 3 * D] = np.einsum("nm,tnm,tnmd->td", g, Es, u)
-            if env:
-                m[:, 2 + 3 * D:2 + 4 * D] = np.einsum("nm,tnm,tnmd->td", g, Ec, amid * amid)
-                m[:, 2 + 4 * D:2 + 5 * D] = np.einsum("nm,tnm,tnmd->td", g, Ec, amid)
     dG = np.where(mask, np.diagonal(G), 0.0)
     diagG = np.array([np.sum(dG[c == k]) for k in range(C)])
     return lml, mom, diagG
