@@ -34,5 +34,8 @@ PY
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -Imogptk_amd/csrc -Iinclude tools/micro/gemm_rank.hip -o /tmp/gemm_rank 2> $O/micro_build.err
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -DGEMM_TIMING -Imogptk_amd/csrc -Iinclude tools/micro/gemm_timing.hip -o /tmp/gemm_timing 2>> $O/micro_build.err
 (timeout 100 /tmp/gemm_rank; timeout 100 /tmp/gemm_timing) > $O/gemm_micro.txt 2>&1
+timeout 100 /tmp/gemm_rank sk > $O/gemm_streamk.txt 2>&1
+timeout 100 /tmp/gemm_rank series > $O/gemm_clock_ramp.txt 2>&1
+(timeout 200 python tools/long_series.py 8192 10; timeout 200 python tools/long_series.py 8192 3; timeout 300 python tools/long_series.py 16384 10) > $O/long_series.txt 2>&1
 tail -c 1500 $O/bench_line.json; for c in cfg3 cfg4 cfg5; do python -c "
 import json; d=json.loads(open('$O/b_$c.json').read()); print('$c', round(d['ms_per_step'],2),'ms frac',round(d['roofline']['frac'],3))"; done
