@@ -131,8 +131,8 @@ int StripTiles::build(const std::vector<GTile>& tiles) {
     int rc;
     if ((rc = d_segs.ensure(std::max<size_t>(segs.size(), 1)))) return rc;
     if ((rc = d_rest.ensure(std::max<size_t>(rest.size(), 1)))) return rc;
-    if (!segs.empty()) HIP_TRY(hipMemcpy(d_segs.p, segs.data(), segs.size() * sizeof(GSeg), hipMemcpyHostToDevice));
-    if (!rest.empty()) HIP_TRY(hipMemcpy(d_rest.p, rest.data(), rest.size() * sizeof(GTile), hipMemcpyHostToDevice));
+    if (!segs.empty()) HIP_TRY(dev_upload(d_segs.p, segs.data(), segs.size() * sizeof(GSeg)));
+    if (!rest.empty()) HIP_TRY(dev_upload(d_rest.p, rest.data(), rest.size() * sizeof(GTile)));
     return 0;
 }
 
@@ -431,12 +431,12 @@ namespace mogp { int spd_alloc(Spd& w, int64_t Npad) {
     for (auto& lv : w.levels) {
         if ((rc = lv.d1.ensure(std::max<size_t>(lv.h1.size(), 1)))) return rc;
         if ((rc = lv.d2.ensure(std::max<size_t>(lv.h2.size(), 1)))) return rc;
-        HIP_TRY(hipMemcpy(lv.d1.p, lv.h1.data(), lv.h1.size() * sizeof(GemmTask), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(lv.d2.p, lv.h2.data(), lv.h2.size() * sizeof(GemmTask), hipMemcpyHostToDevice));
+        HIP_TRY(dev_upload(lv.d1.p, lv.h1.data(), lv.h1.size() * sizeof(GemmTask)));
+        HIP_TRY(dev_upload(lv.d2.p, lv.h2.data(), lv.h2.size() * sizeof(GemmTask)));
     }
     // nothing ever writes above the block diagonal of A / B; keep it finite
-    HIP_TRY(hipMemset(w.A.p, 0, (size_t)Npad * Npad * sizeof(double)));
-    HIP_TRY(hipMemset(w.B.p, 0, (size_t)Npad * Npad * sizeof(double)));
+    { int r__ = dev_fill_zero(w.A.p, (size_t)Npad * Npad * sizeof(double)); if (r__) return r__; }
+    { int r__ = dev_fill_zero(w.B.p, (size_t)Npad * Npad * sizeof(double)); if (r__) return r__; }
     return 0;
 }
 }  // namespace mogp
@@ -490,9 +490,9 @@ namespace mogp { int ensure_system(mogp_model* m) {
         build_sym_tiles(m->sx.off, m->C, m->tiles, m->pair_start);
         if ((rc = m->d_tiles.ensure(m->tiles.size()))) return rc;
         if ((rc = m->d_pair_start.ensure(m->pair_start.size()))) return rc;
-        HIP_TRY(hipMemcpy(m->d_tiles.p, m->tiles.data(), m->tiles.size() * sizeof(GTile), hipMemcpyHostToDevice));
+        HIP_TRY(dev_upload(m->d_tiles.p, m->tiles.data(), m->tiles.size() * sizeof(GTile)));
         if ((rc = m->strip.build(m->tiles))) return rc;
-        HIP_TRY(hipMemcpy(m->d_pair_start.p, m->pair_start.data(), m->pair_start.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(dev_upload(m->d_pair_start.p, m->pair_start.data(), m->pair_start.size() * sizeof(int)));
     }
     if ((rc = m->d_partial.ensure(m->tiles.size() * (size_t)std::max(m->T, 1) * (size_t)std::max(m->Wt, 1)))) return rc;
     return spd_alloc(m->k, m->Npad);
@@ -761,7 +761,7 @@ static int sweep_eval_begin(mogp_model* m, const double* noise_var, const double
         std::vector<double> dv(Npad, 0.0);
         for (int64_t pos = 0; pos < N; ++pos) { dv[pos] = data_var[m->sx.perm[pos]]; dsum += dv[pos]; }
         { int r__ = m->d_dvar.ensure(Npad); if (r__) return r__; }
-        HIP_TRY(hipMemcpy(m->d_dvar.p, dv.data(), Npad * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(dev_upload(m->d_dvar.p, dv.data(), Npad * sizeof(double)));
     }
     m->sh_jabs = jitter * dsum / (double)N;
     HIP_TRY(hipMemcpyAsync(m->d_noise.p, noise_var, C * sizeof(double), hipMemcpyHostToDevice, m->st));
@@ -942,8 +942,8 @@ int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, c
     TRY_RC(m->d_info.ensure(1));
     TRY_RC(m->d_flag.ensure(1));
     TRY_RC(m->d_chan_off.ensure(C + 1));
-    TRY_HIP(hipMemcpy(m->d_x.p, m->sx.xs.data(), (size_t)D * Npad * sizeof(double), hipMemcpyHostToDevice));
-    TRY_HIP(hipMemcpy(m->d_chan_off.p, m->sx.off.data(), (C + 1) * sizeof(int), hipMemcpyHostToDevice));
+    TRY_HIP(dev_upload(m->d_x.p, m->sx.xs.data(), (size_t)D * Npad * sizeof(double)));
+    TRY_HIP(dev_upload(m->d_chan_off.p, m->sx.off.data(), (C + 1) * sizeof(int)));
     TRY_RC(mogp_model_set_y(m, y));
 #undef TRY_RC
 #undef TRY_HIP
@@ -985,7 +985,7 @@ int mogp_model_set_y(mogp_model* m, const double* y) {
     if ((rc = use_device(m->ctx))) return rc;
     std::vector<double> ys(m->Npad, 0.0);
     for (int64_t pos = 0; pos < m->N; ++pos) ys[pos] = y[m->sx.perm[pos]];
-    HIP_TRY(hipMemcpy(m->d_y.p, ys.data(), m->Npad * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(dev_upload(m->d_y.p, ys.data(), m->Npad * sizeof(double)));
     m->hy = ys;
     return MOGP_OK;
 }
@@ -1143,7 +1143,7 @@ static int predict_core(mogp_model* m, const double* noise_var, const double* da
         std::vector<double> hw(Npad, 0.0);
         for (int64_t pos = 0; pos < m->N; ++pos) hw[pos] = mean_w[m->sx.perm[pos]];
         if ((rc = m->d_z.ensure(Npad))) return rc;
-        HIP_TRY(hipMemcpy(m->d_z.p, hw.data(), Npad * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(dev_upload(m->d_z.p, hw.data(), Npad * sizeof(double)));
         if ((rc = launch_gemv_rows(m->d_Ksf.p, Npad, Spad, Npad, m->d_z.p, m->d_mu.p, sv))) return rc;
     }
 
@@ -1280,13 +1280,13 @@ int mogp_gram_ex(mogp_ctx* ctx, int C, int D, int T, int width, const double* ta
     G_TRY(dtab.ensure((size_t)C * C * T * W));
     G_TRY(dout.ensure((size_t)R * Cc));
     G_TRY(dt.ensure(std::max<size_t>(tiles.size(), 1)));
-    G_HIP(hipMemcpy(dx1.p, s1.xs.data(), (size_t)D * s1.Mpad * sizeof(double), hipMemcpyHostToDevice));
+    G_HIP(dev_upload(dx1.p, s1.xs.data(), (size_t)D * s1.Mpad * sizeof(double)));
     if (!sym) {
         G_TRY(dx2.ensure((size_t)D * s2.Mpad));
-        G_HIP(hipMemcpy(dx2.p, s2.xs.data(), (size_t)D * s2.Mpad * sizeof(double), hipMemcpyHostToDevice));
+        G_HIP(dev_upload(dx2.p, s2.xs.data(), (size_t)D * s2.Mpad * sizeof(double)));
     }
-    G_HIP(hipMemcpy(dtab.p, table, (size_t)C * C * T * W * sizeof(double), hipMemcpyHostToDevice));
-    G_HIP(hipMemcpy(dt.p, tiles.data(), tiles.size() * sizeof(GTile), hipMemcpyHostToDevice));
+    G_HIP(dev_upload(dtab.p, table, (size_t)C * C * T * W * sizeof(double)));
+    G_HIP(dev_upload(dt.p, tiles.data(), tiles.size() * sizeof(GTile)));
     GramArgs ga{};
     ga.tiles = dt.p; ga.xr = dx1.p; ga.ldxr = s1.Mpad; ga.xc = sym ? dx1.p : dx2.p; ga.ldxc = sc.Mpad; ga.nrows = R; ga.ncols = Cc;
     G_TRY(ph.prepare(s1.off, sc.off, C, T, s1.Mpad, sc.Mpad, nullptr, ga.ph));
@@ -1338,9 +1338,9 @@ int mogp_shard_config(mogp_model* m, int rank, int nranks) {
         }
         if ((rc = m->d_tiles_own.ensure(std::max<size_t>(m->tiles_own.size(), 1)))) return rc;
         if ((rc = m->d_pair_start_own.ensure(m->pair_start_own.size()))) return rc;
-        HIP_TRY(hipMemcpy(m->d_tiles_own.p, m->tiles_own.data(), m->tiles_own.size() * sizeof(GTile), hipMemcpyHostToDevice));
+        HIP_TRY(dev_upload(m->d_tiles_own.p, m->tiles_own.data(), m->tiles_own.size() * sizeof(GTile)));
         if ((rc = m->strip_own.build(m->tiles_own))) return rc;
-        HIP_TRY(hipMemcpy(m->d_pair_start_own.p, m->pair_start_own.data(), m->pair_start_own.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(dev_upload(m->d_pair_start_own.p, m->pair_start_own.data(), m->pair_start_own.size() * sizeof(int)));
         m->own_rank = rank; m->own_n = nranks;
     }
     return MOGP_OK;
@@ -1615,6 +1615,7 @@ int mogp_comm_selftest(mogp_ctx* ctx, int* ranks_seen, int* rank_sum) {
 int mogp_dev_copy(void* dst, const void* src, int64_t bytes, int to_device) {
     if (!dst || !src || bytes < 0) return fail(MOGP_EINVAL, "mogp_dev_copy: bad argument");
     HIP_TRY(hipMemcpy(dst, src, (size_t)bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+    if (to_device) HIP_TRY(hipStreamSynchronize(nullptr));          // see dev_upload
     return MOGP_OK;
 }
 

@@ -12,6 +12,22 @@
 
 namespace mogp {
 
+// hipMemset returns before the fill has run (like cudaMemset it is asynchronous with respect to the host) and it runs on the NULL stream, which
+// the library's non-blocking streams do not wait for: a kernel launched right behind it on one of them can write the buffer BEFORE the fill does.
+// Seen as garbage in the FIRST evaluation after an allocation when eight processes shared one GPU (the fill arrived late): round 3.
+inline int dev_fill_zero(void* p, size_t bytes) {
+    HIP_TRY(hipMemset(p, 0, bytes));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return 0;
+}
+
+// a blocking upload whose data the next kernel on a non-blocking stream may read: the copy and, to be independent of when exactly the runtime
+// considers a pageable host-to-device copy finished, the NULL stream it ran on
+inline hipError_t dev_upload(void* dst, const void* src, size_t bytes) {
+    hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;

@@ -77,7 +77,7 @@ enum { V_NU = 0, V_LAM, V_MU, V_B, V_E, V_F, V_D, V_W, V_S, V_R, V_EN, V_GNU, V_
 int upload_sorted(mogp_model* m, const double* src, double* dst, double pad) {
     std::vector<double> h(m->Npad, pad);
     for (int64_t pos = 0; pos < m->N; ++pos) h[pos] = src[m->sx.perm[pos]];
-    HIP_TRY(hipMemcpy(dst, h.data(), m->Npad * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(dev_upload(dst, h.data(), m->Npad * sizeof(double)));
     return 0;
 }
 

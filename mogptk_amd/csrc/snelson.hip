@@ -111,12 +111,12 @@ int snelson_front(mogp_model* m, int64_t M, const double* Z, const double* noise
         RC(spd_alloc(t.a, Mpad)); RC(spd_alloc(t.q, Mpad));
         RC(t.zx.ensure((size_t)D * Mpad));
         RC(t.B.ensure((size_t)Mpad * Npad)); RC(t.v.ensure((size_t)Mpad * Npad));
-        HIP_TRY(hipMemset(t.v.p, 0, (size_t)Mpad * Npad * sizeof(double)));      // its padding is zero from here on (titsias.hip relies on it)
+        { int r__ = dev_fill_zero(t.v.p, (size_t)Mpad * Npad * sizeof(double)); if (r__) return r__; }      // its padding is zero from here on (titsias.hip relies on it)
         RC(t.Qs.ensure((size_t)Mpad * Mpad));
         RC(t.vec.ensure((size_t)8 * Mpad + 4 * Npad));
         RC(t.scratch.ensure((size_t)(Mpad / 256 + 2) * std::max(Npad, Mpad) + (size_t)(Mpad / 512 + 2) * Mpad));
         RC(t.zero_noise.ensure(C));
-        HIP_TRY(hipMemset(t.zero_noise.p, 0, C * sizeof(double)));
+        { int r__ = dev_fill_zero(t.zero_noise.p, C * sizeof(double)); if (r__) return r__; }
     }
     RC(t.nvec.ensure((size_t)8 * Npad + 2 * C));
     // Kuf's padding (rows >= M, columns >= N) must be zero and this path overwrites t.B with scaled copies of v: cleared per call

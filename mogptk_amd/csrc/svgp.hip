@@ -67,12 +67,12 @@ int svgp_setup(mogp_model* m, int64_t M, const double* Z, const double* q_mu, co
         RC(spd_alloc(t.a, Mpad)); RC(spd_alloc(t.q, Mpad));
         RC(t.zx.ensure((size_t)D * Mpad));
         RC(t.B.ensure((size_t)Mpad * Npad)); RC(t.v.ensure((size_t)Mpad * Npad));
-        HIP_TRY(hipMemset(t.v.p, 0, (size_t)Mpad * Npad * sizeof(double)));      // its padding is zero from here on (titsias.hip relies on it)
+        { int r__ = dev_fill_zero(t.v.p, (size_t)Mpad * Npad * sizeof(double)); if (r__) return r__; }      // its padding is zero from here on (titsias.hip relies on it)
         RC(t.Qs.ensure((size_t)Mpad * Mpad));
         RC(t.vec.ensure((size_t)8 * Mpad + 4 * Npad));
         RC(t.scratch.ensure((size_t)(Mpad / 256 + 2) * std::max(Npad, Mpad) + (size_t)(Mpad / 512 + 2) * Mpad));
         RC(t.zero_noise.ensure(C));
-        HIP_TRY(hipMemset(t.zero_noise.p, 0, C * sizeof(double)));
+        { int r__ = dev_fill_zero(t.zero_noise.p, C * sizeof(double)); if (r__) return r__; }
     }
     RC(t.R.ensure((size_t)Mpad * Mpad)); RC(t.E.ensure((size_t)Mpad * Mpad)); RC(t.GA.ensure((size_t)Mpad * Mpad));
     RC(t.GB.ensure((size_t)Mpad * Npad));
@@ -104,8 +104,8 @@ int svgp_setup(mogp_model* m, int64_t M, const double* Z, const double* q_mu, co
         hq[pos] = q_mu[src];
         for (int64_t c = 0; c <= src; ++c) hS[(size_t)pos * Mpad + c] = q_sqrt[(size_t)src * M + c];     // tril: columns <= the CALLER's row index
     }
-    HIP_TRY(hipMemcpy(t.vec.p, hq.data(), Mpad * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(t.R.p, hS.data(), (size_t)Mpad * Mpad * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(dev_upload(t.vec.p, hq.data(), Mpad * sizeof(double)));
+    HIP_TRY(dev_upload(t.R.p, hS.data(), (size_t)Mpad * Mpad * sizeof(double)));
     return 0;
 }
 

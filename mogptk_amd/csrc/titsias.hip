@@ -162,9 +162,9 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
         RC(t.vec.ensure((size_t)8 * Mpad + 4 * Npad));
         RC(t.scratch.ensure((size_t)(Mpad / 256 + 2) * std::max(Npad, Mpad) + (size_t)(Mpad / 512 + 2) * Mpad));
         RC(t.zero_noise.ensure(C));
-        HIP_TRY(hipMemset(t.zero_noise.p, 0, C * sizeof(double)));
-        HIP_TRY(hipMemset(t.B.p, 0, (size_t)Mpad * Npad * sizeof(double)));      // padding of Kuf stays zero: the Gram kernel never writes it
-        HIP_TRY(hipMemset(t.v.p, 0, (size_t)Mpad * Npad * sizeof(double)));      // ... nor that of its working copy (the solves keep zeros zero)
+        { int r__ = dev_fill_zero(t.zero_noise.p, C * sizeof(double)); if (r__) return r__; }
+        { int r__ = dev_fill_zero(t.B.p, (size_t)Mpad * Npad * sizeof(double)); if (r__) return r__; }      // padding of Kuf stays zero: the Gram kernel never writes it
+        { int r__ = dev_fill_zero(t.v.p, (size_t)Mpad * Npad * sizeof(double)); if (r__) return r__; }      // ... nor that of its working copy (the solves keep zeros zero)
     }
     m->gemm_ev_used = 0; m->gemm_launches = 0; m->gemm_flops = 0.0;
     build_sym_tiles(sz.off, C, tuu, psuu);

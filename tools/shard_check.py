@@ -150,6 +150,8 @@ errs = torch.tensor([abs(l1 - l0) / abs(l0), err, perr, abs(tl1 - tl0) / abs(tl0
 if a.backend == "nccl":
     errs = errs.cuda()
 dist.all_reduce(errs, op=dist.ReduceOp.MAX)
+per_rank = [None] * world          # every rank's own values: a rank whose ONE-GPU evaluation went wrong shows here, not in the sharded ones
+dist.all_gather_object(per_rank, [l0, l1, tl0, tl1, hl0, hl1, nl0, nl1])
 if rank == 0:
     print(json.dumps(dict(world=world, backend=a.backend, N=a.points, loss=l0, loss_sharded=l1, rel_loss=float(errs[0]), rel_grad=float(errs[1]), rel_predict=float(errs[2]),
                           transport=comm.transport, ms_single=1e3 * t_single, ms_sharded=1e3 * t_shard,
@@ -157,6 +159,7 @@ if rank == 0:
                                        rel_predict=float(errs[5]), ms_single=1e3 * tt_single, ms_sharded=1e3 * tt_shard),
                           hensman=dict(N=a.titsias_points, M=int(Mh), likelihood="StudentT", loss=hl0, rel_loss=float(errs[6]), rel_grad=float(errs[7]),
                                        ms_single=1e3 * ht_single, ms_sharded=1e3 * ht_shard),
-                          snelson=dict(loss=nl0, rel_loss=float(errs[8]), rel_grad=float(errs[9]), rel_predict=float(errs[10])))))
+                          snelson=dict(loss=nl0, rel_loss=float(errs[8]), rel_grad=float(errs[9]), rel_predict=float(errs[10])),
+                          per_rank=per_rank if any(v != per_rank[0] for v in per_rank) else "identical on every rank")))
 mogptk_amd.shutdown_distributed()
 dist.destroy_process_group()
