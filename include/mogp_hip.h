@@ -226,7 +226,10 @@ int  mogp_model_fetch(mogp_model* m, int which, double* out);
  * (Snelson.log_marginal_likelihood) + the autograd backward through it, and :543-576 (Snelson.predict_f).
  * Z: M x (1 + D) inducing inputs in kernel format (channel id first); noise_var[C] = sigma_c^2; kff_diag[C] / kss_diag[C] = K_diag per channel.
  * Gradient outputs as for mogp_titsias_eval (moments of the adjoints of Kuu and Kuf, d/dZ, tr dp/dKuu for the jitter term), and
- * hsum[C] = sum over the points of a channel of dp/dKff_nn = dp/dsigma_n^2. */
+ * hsum[C] = sum over the points of a channel of dp/dKff_nn = dp/dsigma_n^2.
+ * Term rows of width 2 + 5 D (an envelope on the input midpoint, MOHSM: reference gpr/multioutput.py:340-395 -- any kernel under any inference):
+ * the kernel diagonal follows the points, so kff_diag has N entries and kss_diag S entries (per point, caller's order) and hsum receives the
+ * N per-point values dp/dKff_nn (caller's order); the moments have 2 + 5 D entries per term.  Not on the data-parallel entry points. */
 int  mogp_snelson_eval(mogp_model* m, int64_t M, const double* Z, const double* noise_var, double jitter, const double* kff_diag, int flags,
                        double* lml, double* mom_uu, double* mom_uf, double* gZ, double* trGA, double* hsum, double* jitter_abs, int64_t* info);
 int  mogp_snelson_predict(mogp_model* m, int64_t M, const double* Z, const double* noise_var, double jitter, const double* kff_diag,

@@ -348,13 +348,16 @@ class ExactHandle:
         """Snelson (FITC) marginal likelihood (+ gradient outputs) through mogp_snelson_eval"""
         Z, noise_var, kff_diag = _f64(Z), _f64(noise_var), _f64(kff_diag)
         M = Z.shape[0]
-        C, T, W, D = self.C, self.T, 2 + 3 * self.D, self.D
+        C, T, W, D = self.C, self.T, self.W, self.D       # W = 2 + 5 D with enveloped terms: kff_diag per point in, dp/dKff per point out
+        env = W > 2 + 3 * D
+        if kff_diag.size != (self.N if env else C):
+            raise ValueError("kff_diag must have %d entries" % (self.N if env else C))
         lml, trGA, jit = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         info = ctypes.c_int64(0)
         mom_uu = np.zeros((C * (C + 1) // 2, T, W)) if grad else None
         mom_uf = np.zeros((C * C, T, W)) if grad else None
         gZ = np.zeros((M, D)) if grad else None
-        hsum = np.zeros(C) if grad else None
+        hsum = np.zeros(self.N if env else C) if grad else None
         fn = lib().mogp_snelson_eval_sharded if sharded else lib().mogp_snelson_eval
         code = fn(self._h, M, _dp(Z), _dp(noise_var), float(jitter), _dp(kff_diag), MOGP_EVAL_GRAD if grad else 0,
                   ctypes.byref(lml), _dp(mom_uu), _dp(mom_uf), _dp(gZ), ctypes.byref(trGA), _dp(hsum), ctypes.byref(jit), ctypes.byref(info))

@@ -164,6 +164,7 @@ struct TitsiasWork {
     DevBuf<double> gzp;
     // svgp.hip: what the forward pass at the training inputs leaves for the backward pass
     SortedX sv_sz; std::vector<GTile> sv_tuu, sv_tuf; std::vector<int> sv_psuu, sv_psuf; int64_t sv_M = 0; bool sv_dense = false, sv_valid = false;
+    DevBuf<double> kd_point;                            // Snelson / Hensman with enveloped terms: the kernel diagonal per training point (sorted order)
     DevBuf<double> nvec;                                // Snelson: per-point vectors (g, G, G y, sqrt G, v^T r / w, alpha, h) + per-channel inputs
     PhaseWs ph_zz, ph_zx, ph_zs;                        // phase tables: (Z, Z), (Z, X), (Z, Xs)
     void release() {
@@ -172,7 +173,7 @@ struct TitsiasWork {
         zx.release(); B.release(); v.release(); GB.release(); Qs.release(); E.release(); R.release(); T1.release(); GA.release(); Hm.release();
         vec.release(); scratch.release(); gz.release(); partial_uu.release(); partial_uf.release(); mom_uu.release(); mom_uf.release();
         zero_noise.release(); tiles_uu.release(); tiles_uf.release(); ps_uu.release(); ps_uf.release();
-        Kus.release(); Aus.release(); Bus.release(); zero_col.release(); kslices.release(); nvec.release(); red.release();
+        Kus.release(); Aus.release(); Bus.release(); zero_col.release(); kslices.release(); nvec.release(); kd_point.release(); red.release();
         blk_z.release(); blk_x.release(); gzp.release(); hblk_z.clear(); hblk_x.clear();
         for (auto& e : side_ev) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
     }

@@ -25,16 +25,17 @@ namespace {
 
 
 
-// per point (channel-sorted order): g = Kff_diag[c] - q + s2[c], G = 1/g, Gy = G y, sg = sqrt(G); zero on the padding
+// per point (channel-sorted order): g = Kff_diag[c] - q + s2[c], G = 1/g, Gy = G y, sg = sqrt(G); zero on the padding.  kd_point (terms with
+// an envelope, MOHSM): the kernel diagonal follows the points -- Kff_diag per point instead of per channel
 __global__ void k_sn_point(const double* __restrict__ q, const double* __restrict__ y, const int* __restrict__ off, int C,
-                           const double* __restrict__ kd, const double* __restrict__ s2, int64_t N, int64_t Npad,
+                           const double* __restrict__ kd, const double* __restrict__ kd_point, const double* __restrict__ s2, int64_t N, int64_t Npad,
                            double* __restrict__ g, double* __restrict__ G, double* __restrict__ Gy, double* __restrict__ sg) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= Npad) return;
     if (n >= N) { g[n] = 1.0; G[n] = 0.0; Gy[n] = 0.0; sg[n] = 0.0; return; }
     int c = 0;
     while (c + 1 < C && n >= off[c + 1]) ++c;
-    const double gv = kd[c] - q[n] + s2[c];
+    const double gv = (kd_point ? kd_point[n] : kd[c]) - q[n] + s2[c];
     g[n] = gv;
     const double Gv = 1.0 / gv;
     G[n] = Gv; Gy[n] = Gv * y[n]; sg[n] = sqrt(fabs(Gv));
@@ -96,10 +97,11 @@ struct SnScalars { double logdet_q, sumlogg, yGy, rvGy, jit, ntot; };
 int snelson_front(mogp_model* m, int64_t M, const double* Z, const double* noise_var, double jitter, const double* kff_diag, SortedX& sz,
                   std::vector<GTile>& tuu, std::vector<int>& psuu, std::vector<GTile>& tuf, std::vector<int>& psuf, SnScalars& sc,
                   int64_t* info, bool need_moment_tiles, bool sharded) {
-    const int C = m->C, D = m->D, W = 2 + 3 * D;
+    const int C = m->C, D = m->D, W = m->Wt;                   // 2 + 3 D, or 2 + 5 D: terms with an envelope on the input midpoint (MOHSM)
+    const bool env = W > 2 + 3 * D;
     const int64_t N = m->N, Npad = m->Npad;
     if (m->T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms must be called before an evaluation");
-    if (m->Wt != W) return fail(MOGP_EINVAL, "the Snelson path does not take terms with an envelope (MOHSM): exact inference only");
+    if (env && sharded) return fail(MOGP_EINVAL, "the data-parallel Snelson path does not take terms with an envelope (MOHSM)");
     for (int c = 0; c < C; ++c) if (!(noise_var[c] > 0.0)) return fail(MOGP_EINVAL, "noise variances must be positive");
     RC(sort_inputs(Z, M, D, C, MOGP_TILE, sz));
     const int64_t Mpad = sz.Mpad;
@@ -138,14 +140,12 @@ int snelson_front(mogp_model* m, int64_t M, const double* Z, const double* noise
     const unsigned long long big = std::numeric_limits<unsigned long long>::max();
     HIP_TRY(hipMemcpyAsync(m->d_info.p, &big, sizeof(big), hipMemcpyHostToDevice, m->st));
 
-    double dsum = 0.0;                                          // relative jitter on Kuu (reference gpr/model.py:524 -> :244)
-    for (int c = 0; c < C; ++c) dsum += (double)(sz.off[c + 1] - sz.off[c]) * table_diag(m, c);
-    sc.jit = jitter * dsum / (double)M;
+    sc.jit = jitter * table_diag_points(m, sz) / (double)M;      // relative jitter on Kuu (reference gpr/model.py:524 -> :244); with an envelope the diagonal follows Z
 
     GramArgs ga{};
     ga.tiles = t.tiles_uu.p; ga.xr = t.zx.p; ga.xc = t.zx.p; ga.ldxr = ga.ldxc = Mpad; ga.nrows = ga.ncols = M;
     RC(t.ph_zz.prepare(sz.off, sz.off, C, m->T, Mpad, Mpad, m->st, ga.ph));
-    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.out = t.a.A.p; ga.ldo = Mpad;
+    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = W; ga.out = t.a.A.p; ga.ldo = Mpad;
     ga.noise = t.zero_noise.p; ga.dvar = nullptr; ga.jitter_abs = sc.jit; ga.mirror = 0;
     RC(launch_gram(ga, (int)tuu.size(), m->st));
     RC(launch_pad_identity(t.a.A.p, Mpad, M, Mpad, m->st));
@@ -167,10 +167,20 @@ int snelson_front(mogp_model* m, int64_t M, const double* Z, const double* noise
     double* q = sg + Npad;                                                       // Qff_nn, then reused
     double* kd = t.nvec.p + 8 * Npad;
     double* s2 = kd + C;
-    HIP_TRY(hipMemcpyAsync(kd, kff_diag, C * sizeof(double), hipMemcpyHostToDevice, m->st));
+    double* kd_point = nullptr;                                                  // envelope: Kff_diag per training point (caller order in, sorted order here)
+    std::vector<double> hkd;
+    if (env) {
+        RC(t.kd_point.ensure((size_t)Npad));
+        hkd.assign((size_t)Npad, 0.0);
+        for (int64_t pos = 0; pos < N; ++pos) hkd[pos] = kff_diag[m->sx.perm[pos]];
+        HIP_TRY(hipMemcpyAsync(t.kd_point.p, hkd.data(), Npad * sizeof(double), hipMemcpyHostToDevice, m->st));
+        kd_point = t.kd_point.p;
+    } else {
+        HIP_TRY(hipMemcpyAsync(kd, kff_diag, C * sizeof(double), hipMemcpyHostToDevice, m->st));
+    }
     HIP_TRY(hipMemcpyAsync(s2, noise_var, C * sizeof(double), hipMemcpyHostToDevice, m->st));
     RC(launch_gemv_cols(t.v.p, Npad, Mpad, Npad, nullptr, q, t.scratch.p, m->st));
-    hipLaunchKernelGGL(k_sn_point, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, m->st, q, m->d_y.p, m->d_chan_off.p, C, kd, s2, N, Npad, g, G, Gy, sg);
+    hipLaunchKernelGGL(k_sn_point, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, m->st, q, m->d_y.p, m->d_chan_off.p, C, kd, kd_point, s2, N, Npad, g, G, Gy, sg);
     HIP_TRY(hipGetLastError());
     std::vector<double> hg(Npad);
     HIP_TRY(hipMemcpyAsync(hg.data(), g, Npad * sizeof(double), hipMemcpyDeviceToHost, m->st));
@@ -238,7 +248,8 @@ int snelson_eval_impl(mogp_model* m, int64_t M, const double* Z, const double* n
     if (!m || !Z || !noise_var || !kff_diag || !lml || M <= 0) return fail(MOGP_EINVAL, "mogp_snelson_eval: bad argument");
     RC(use_device(m->ctx));
     if (info) *info = 0;
-    const int C = m->C, D = m->D, W = 2 + 3 * D, T = m->T, P = C * (C + 1) / 2;
+    const int C = m->C, D = m->D, W = m->Wt, T = m->T, P = C * (C + 1) / 2;
+    const bool env = W > 2 + 3 * D;
     const int64_t N = m->N, Npad = m->Npad;
     const bool grad = (flags & MOGP_EVAL_GRAD) != 0;
     SortedX sz;
@@ -315,7 +326,7 @@ int snelson_eval_impl(mogp_model* m, int64_t M, const double* Z, const double* n
     ma.tiles = t.tiles_uf.p; ma.ntiles = (int)tuf.size(); ma.x = t.zx.p; ma.ldx = Mpad; ma.xc = m->d_x.p; ma.ldxc = Npad;
     ma.nrows = M; ma.ncols = N;
     RC(t.ph_zx.prepare(sz.off, m->sx.off, C, T, Mpad, Npad, m->st, ma.ph));
-    ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C;
+    ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C; ma.W = W;
     ma.G = t.GB.p; ma.ldg = Npad; ma.ru = beta; ma.rw = alpha; ma.rcoef = 0.0; ma.sym = 0;
     ma.gzr = t.gz.p; ma.gzc = nullptr; ma.ldgz = Mpad; ma.partial = t.partial_uf.p;
     gz_attach(t, ma, true);
@@ -347,6 +358,10 @@ int snelson_eval_impl(mogp_model* m, int64_t M, const double* Z, const double* n
     double tr = 0.0;
     for (int64_t i = 0; i < M; ++i) tr += hd[i] - 0.5 * hb[i] * hb[i];
     *trGA = tr;
+    if (env) {                                   // the diagonal follows the points: dp/dKff_nn per training point, caller order (N values)
+        for (int64_t pos = 0; pos < N; ++pos) hsum[m->sx.perm[pos]] = hh[pos];
+        return MOGP_OK;
+    }
     for (int c = 0; c < C; ++c) {
         double s = 0.0;
         for (int pos = m->sx.off[c]; pos < m->sx.off[c + 1]; ++pos) s += hh[pos];
@@ -402,6 +417,7 @@ int snelson_predict_impl(mogp_model* m, int64_t M, const double* Z, const double
     RC(use_device(m->ctx));
     if (info) *info = 0;
     const int C = m->C, D = m->D;
+    const bool env = m->Wt > 2 + 3 * D;
     SortedX sz, ss;
     std::vector<GTile> tuu, tuf, tus;
     std::vector<int> psuu, psuf;
@@ -422,7 +438,7 @@ int snelson_predict_impl(mogp_model* m, int64_t M, const double* Z, const double
     GramArgs ga{};
     ga.tiles = m->d_ptiles.p; ga.xr = t.zx.p; ga.ldxr = Mpad; ga.xc = m->d_xs.p; ga.ldxc = Spad; ga.nrows = M; ga.ncols = S;
     RC(t.ph_zs.prepare(sz.off, ss.off, C, m->T, Mpad, Spad, m->st, ga.ph));
-    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.out = t.Kus.p; ga.ldo = Spad; ga.mirror = 0;
+    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = m->Wt; ga.out = t.Kus.p; ga.ldo = Spad; ga.mirror = 0;
     RC(launch_gram(ga, (int)tus.size(), m->st));
     HIP_TRY(hipMemcpyAsync(t.Aus.p, t.Kus.p, (size_t)Mpad * Spad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.Aus.p, Spad, Spad, false));                                      // a = L^-1 Kus
@@ -441,7 +457,7 @@ int snelson_predict_impl(mogp_model* m, int64_t M, const double* Z, const double
     for (int c = 0; c < C; ++c)
         for (int pos = ss.off[c]; pos < ss.off[c + 1]; ++pos) {
             mu[ss.perm[pos]] = hmu[pos];
-            var[ss.perm[pos]] = kss_diag[c] - hv[pos] + hv[Spad + pos];
+            var[ss.perm[pos]] = (env ? kss_diag[ss.perm[pos]] : kss_diag[c]) - hv[pos] + hv[Spad + pos];     // envelope: K_ss,diag per test point
         }
     return MOGP_OK;
 }

@@ -207,9 +207,11 @@ class Kernel(ParameterHolder):
         env, _, rows = self._point_env(table, Xk, D)
         return np.sum(rows[..., 0] * env, axis=1)
 
-    def _point_diag_table_grad(self, table, Xk, D):
-        """d [ sum_k K_diag(x_k) ] / d table: what the relative jitter (gpr/model.py:244) contributes per unit of d/d mean(diag) * N"""
+    def _point_diag_table_grad(self, table, Xk, D, weights=None):
+        """d [ sum_k w_k K_diag(x_k) ] / d table (w = 1: what the relative jitter, gpr/model.py:244, contributes per unit of d/d mean(diag) * N)"""
         env, a, rows = self._point_env(table, Xk, D)
+        if weights is not None:
+            env = env * np.asarray(weights, dtype=np.float64).reshape(-1, 1)
         c = Xk[:, 0].astype(np.int64)
         gt = np.zeros_like(table)
         A, Lv = rows[..., 0], rows[..., 2 + 3 * D:2 + 4 * D]

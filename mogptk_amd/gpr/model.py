@@ -569,8 +569,10 @@ class Snelson(_DataParallel, Model):
         table = self.kernel._spectral_terms(D)
         h.set_terms(table)
         Zk = self.kernel._kernel_format(self.Z())
+        env = table.shape[3] > 2 + 3 * D                  # enveloped terms (MOHSM): the kernel diagonal follows the points
+        kff = self.kernel._point_diag(table, self._local(self.kernel._kernel_format(self.X)), D) if env else self.kernel._spectral_diag(D)
         try:
-            res = h.snelson_eval(Zk, self._noise_vector(), self.jitter, self.kernel._spectral_diag(D), grad=grad, sharded=self._data_shard() is not None)
+            res = h.snelson_eval(Zk, self._noise_vector(), self.jitter, kff, grad=grad, sharded=self._data_shard() is not None)
         except MogpError as e:
             if e.code in (MOGP_ENOTPD, MOGP_ENONFINITE):
                 print("ERROR:", str(e), file=sys.__stdout__)
@@ -591,11 +593,22 @@ class Snelson(_DataParallel, Model):
         M = Zk.shape[0]
         zc = np.bincount(Zk[:, 0].astype(np.int64), minlength=C).astype(np.float64)
         gt = _gtable_from_moments(table, res["mom_uu"], D, lower=True) + _gtable_from_moments(table, res["mom_uf"], D, lower=False)
-        for i in range(C):
-            gt[i, i, :, 0] += self.jitter * res["trGA"] * zc[i] / M          # jitter * mean(diag Kuu), gpr/model.py:244
-        self.kernel._spectral_backward(-gt)
-        hsum = np.asarray(res["hsum"], dtype=np.float64)                     # d p / d Kff_diag = d p / d sigma^2, summed per channel
-        self.kernel._spectral_diag_backward(-hsum, D)
+        gz_jit = 0.0
+        if table.shape[3] > 2 + 3 * D:
+            # enveloped terms: jitter * mean(diag Kuu) depends on A, L, c and on Z itself (gpr/model.py:244 through autograd); dp/dKff_nn comes
+            # back per training point and goes through the per-point diagonal K_diag(x_n) = sum_t A_t env_t(x_n)
+            Xk = self.kernel._kernel_format(self.X)
+            h_pt = np.asarray(res["hsum"], dtype=np.float64)
+            gt += (self.jitter * res["trGA"] / M) * self.kernel._point_diag_table_grad(table, Zk, D)
+            gz_jit = (self.jitter * res["trGA"] / M) * self.kernel._point_diag_input_grad(table, Zk, D)
+            self.kernel._spectral_backward(-gt - self.kernel._point_diag_table_grad(table, Xk, D, weights=h_pt))
+            hsum = np.bincount(Xk[:, 0].astype(np.int64), weights=h_pt, minlength=C).astype(np.float64)
+        else:
+            for i in range(C):
+                gt[i, i, :, 0] += self.jitter * res["trGA"] * zc[i] / M          # jitter * mean(diag Kuu), gpr/model.py:244
+            self.kernel._spectral_backward(-gt)
+            hsum = np.asarray(res["hsum"], dtype=np.float64)                     # d p / d Kff_diag = d p / d sigma^2, summed per channel
+            self.kernel._spectral_diag_backward(-hsum, D)
         scale = self.likelihood.scale
         sc = np.asarray(scale(), dtype=np.float64)
         if sc.ndim == 1 and sc.shape[0] == C and self.kernel.output_dims is not None:
@@ -605,7 +618,7 @@ class Snelson(_DataParallel, Model):
         scale.accumulate_grad(-gsc)
         gz = np.zeros(self.Z.data.shape)
         off = 0 if self.kernel.output_dims is None else 1
-        gz[:, off:] = -res["gZ"]
+        gz[:, off:] = -(res["gZ"] + gz_jit)
         self.Z.accumulate_grad(gz)
         return config.dtype(-res["lml"] - self.log_prior())
 
@@ -616,10 +629,16 @@ class Snelson(_DataParallel, Model):
         X = self._check_input(X)
         h = self._device_handle()
         D = self.X.shape[1] - (0 if self.kernel.output_dims is None else 1)
-        h.set_terms(self.kernel._spectral_terms(D))
-        kd = self.kernel._spectral_diag(D)
+        table = self.kernel._spectral_terms(D)
+        h.set_terms(table)
+        Xsk = self.kernel._kernel_format(X)
+        if table.shape[3] > 2 + 3 * D:                    # enveloped terms: K_diag per training / test point
+            kd = self.kernel._point_diag(table, self._local(self.kernel._kernel_format(self.X)), D)
+            ks = self.kernel._point_diag(table, Xsk, D)
+        else:
+            kd = ks = self.kernel._spectral_diag(D)
         mu, var = h.snelson_predict(self.kernel._kernel_format(self.Z()), self._noise_vector(), self.jitter,
-                                    self.kernel._kernel_format(X), kd, kd, sharded=self._data_shard() is not None)
+                                    Xsk, kd, ks, sharded=self._data_shard() is not None)
         if self.mean is not None:
             mu = mu + np.asarray(self.mean(X)).reshape(-1, 1)
         return mu, var

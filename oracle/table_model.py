@@ -330,7 +330,8 @@ def snelson_eval(self, Z, noise_var, jitter, kff_diag, grad=True, sharded=False)
     B = gram_from_table(table, Z, X)
     Luu = np.linalg.cholesky(A)
     v = solve_triangular(Luu, B, lower=True)
-    g = np.asarray(kff_diag)[cx] - np.sum(v * v, axis=0) + s2
+    env = table.shape[3] > 2 + 3 * D                       # enveloped terms: K_ff,diag per training point
+    g = (np.asarray(kff_diag) if env else np.asarray(kff_diag)[cx]) - np.sum(v * v, axis=0) + s2
     G = 1.0 / g
     yv = y.reshape(-1)
     Bq = red((v * G) @ v.T) + np.eye(M)
@@ -373,7 +374,7 @@ def snelson_eval(self, Z, noise_var, jitter, kff_diag, grad=True, sharded=False)
                 else:               # block (i, j) above the diagonal is the transpose of block (j, i): K_ab = K'_ba
                     Jr = np.transpose(_jc_block(table[j, i], Z[zj, 1:], Z[ri, 1:]), (1, 0, 2))
                 gZ_uu[ri] += 2.0 * np.einsum("nm,nmd->nd", GA[np.ix_(ri, zj)], Jr)
-    hsum = red(np.bincount(cx, weights=h, minlength=C).astype(np.float64))           # per channel: d p / d Kff_diag[c] = d p / d sigma_c^2
+    hsum = h if env else red(np.bincount(cx, weights=h, minlength=C).astype(np.float64))   # per channel (per point with an envelope): d p / d Kff_diag = d p / d sigma^2
     return dict(lml=p, jitter_abs=jit, mom_uu=mom_uu, mom_uf=mom_uf, gZ=red(gZ) + gZ_uu, trGA=float(np.trace(GA)), hsum=hsum)
 
 
@@ -389,14 +390,15 @@ def snelson_predict(self, Z, noise_var, jitter, Xs, kff_diag, kss_diag, sharded=
     A = Kuu + jitter * np.mean(np.diagonal(Kuu)) * np.eye(M)
     Luu = np.linalg.cholesky(A)
     v = solve_triangular(Luu, gram_from_table(table, Z, X), lower=True)
-    G = 1.0 / (np.asarray(kff_diag)[cx] - np.sum(v * v, axis=0) + s2)
+    env = table.shape[3] > 2 + 3 * self.D
+    G = 1.0 / ((np.asarray(kff_diag) if env else np.asarray(kff_diag)[cx]) - np.sum(v * v, axis=0) + s2)
     red = _all_reduce(self, sharded)
     Lq = np.linalg.cholesky(red((v * G) @ v.T) + np.eye(M))
     a = solve_triangular(Luu, gram_from_table(table, Z, Xs), lower=True)
     b = solve_triangular(Lq, a, lower=True)
     c = solve_triangular(Lq, red(v @ (G * y.reshape(-1))), lower=True)
     mu = b.T @ c
-    var = np.asarray(kss_diag)[Xs[:, 0].astype(np.int64)] - np.sum(a * a, axis=0) + np.sum(b * b, axis=0)
+    var = (np.asarray(kss_diag) if env else np.asarray(kss_diag)[Xs[:, 0].astype(np.int64)]) - np.sum(a * a, axis=0) + np.sum(b * b, axis=0)
     return mu.reshape(-1, 1), var.reshape(-1, 1)
 
 

@@ -745,6 +745,39 @@ def gen_titsias_mohsm():
     print("titsias_mohsm.npz written")
 
 
+def gen_snelson_mohsm():
+    """Snelson (FITC) with an ENVELOPED kernel (MixtureKernel of MultiOutputHarmonizableSpectralKernel; reference gpr/multioutput.py:340-395 under
+    gpr/model.py:516-576): marginal likelihood, gradients of every parameter incl. lengthscale / center, the noise scale (scalar and per channel)
+    and the inducing inputs (through the envelope and the point-dependent jitter too), predict_f."""
+    out = {}
+    cases = [(3, 2, 1, 96, [5, 4, 6], False, "vector"), (2, 1, 2, 80, [4, 9], True, "scalar"), (1, 2, 1, 60, [9], False, "scalar")]
+    out["ncases"] = np.array(len(cases))
+    for n, (C, Q, D, N, Zspec, shuffle, noise) in enumerate(cases):
+        rng = np.random.default_rng(9900 + n)
+        X, y = small_data(N, C, D, 9950 + n, shuffle)
+        k = build_kernel("mohsm", C, Q, D, 1, rng)
+        for q in range(Q):       # as in gen_titsias_mohsm: K_uu carries no noise, keep its cross-channel blocks a valid covariance
+            k[q].mean.assign(np.tile(rng.uniform(0.05, 0.5, (1, D)), (C, 1)))
+            k[q].variance.assign(np.tile(rng.uniform(0.05, 0.5, (1, D)), (C, 1)))
+            k[q].lengthscale.assign(np.full(C, rng.uniform(0.1, 0.4)))
+            k[q].delay.assign(np.zeros((C, D)))
+            k[q].phase.assign(np.zeros(C))
+        var = rng.uniform(0.02, 0.15, C) if noise == "vector" else float(rng.uniform(0.02, 0.15))
+        m = g.Snelson(k, T(X), T(y), Z=Zspec, Z_init="grid", variance=(T(var) if noise == "vector" else var), jitter=1e-6)
+        pre = "c%d_" % n
+        out[pre + "meta"] = np.array([C, Q, D, 1]); out[pre + "X"] = X; out[pre + "y"] = y
+        out[pre + "Zspec"] = np.atleast_1d(np.array(Zspec)); out[pre + "variance"] = np.asarray(var)
+        out[pre + "jitter"] = np.array(m.jitter)
+        out[pre + "lml"] = np.array(float(m.log_marginal_likelihood()))
+        out[pre + "loss"] = np.array(float(m.loss()))
+        dump_params(pre, list(m.parameters()), out, with_grad=True)
+        Xs, _ = small_data(21, C, D, 9990 + n, shuffle)
+        mu, var_p = m.predict_f(T(Xs))
+        out[pre + "Xs"] = Xs; out[pre + "mu"] = mu.numpy(); out[pre + "var"] = var_p.numpy()
+    np.savez_compressed(os.path.join(HERE, "snelson_mohsm.npz"), **out)
+    print("snelson_mohsm.npz written")
+
+
 def gen_cfg5():
     import time
     C, Q, N, M = 4, 3, 100000, 2048
@@ -1159,7 +1192,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "lbfgs": gen_lbfgs_cfg1, "quirks": gen_quirks,
              "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2, "smlmc": gen_smlmc, "init_ls": gen_init_ls, "bnse": gen_bnse, "transformers": gen_transformers,
-             "titsias": gen_titsias, "titsias_mohsm": gen_titsias_mohsm, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints, "snelson": gen_snelson, "hensman": gen_hensman, "oa": gen_oa, "likelihoods": gen_likelihoods, "samples": gen_samples, "sparse_cov": gen_sparse_cov}
+             "titsias": gen_titsias, "titsias_mohsm": gen_titsias_mohsm, "snelson_mohsm": gen_snelson_mohsm, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints, "snelson": gen_snelson, "hensman": gen_hensman, "oa": gen_oa, "likelihoods": gen_likelihoods, "samples": gen_samples, "sparse_cov": gen_sparse_cov}
     full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:
         {**steps, **full}[a.only]()

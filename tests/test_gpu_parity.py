@@ -565,6 +565,13 @@ def test_titsias_with_enveloped_terms_on_device():
     check_titsias_with_enveloped_terms(tol_loss=1e-9, tol_grad=1e-6, tol_pred=1e-7)
 
 
+def test_snelson_with_enveloped_terms_on_device():
+    """the FITC model with MOHSM terms on the device against the reference's autograd (mogp_snelson_eval with rows of width 2 + 5 D: K_ff,diag
+    per point in, dp/dK_ff,nn per point out)"""
+    from test_host_logic import check_snelson_with_enveloped_terms
+    check_snelson_with_enveloped_terms(tol_loss=1e-9, tol_grad=1e-6, tol_pred=1e-7)
+
+
 def test_single_precision_switch_on_device():
     from test_host_logic import check_single_precision_switch
     check_single_precision_switch()

@@ -426,6 +426,36 @@ def test_titsias_with_enveloped_terms_matches_reference():
     check_titsias_with_enveloped_terms()
 
 
+def check_snelson_with_enveloped_terms(tol_loss=1e-9, tol_grad=1e-8, tol_pred=1e-9):
+    """the FITC model under the same enveloped kernel (reference gpr/multioutput.py:340-395 under gpr/model.py:516-576): K_ff,diag per training
+    point inside g_n = K_ff,nn - Q_ff,nn + sigma^2 and dp/dK_ff,nn per point back through it, K_uu's relative jitter depending on Z, scalar
+    and per-channel noise -- against the reference's autograd"""
+    fx = load("snelson_mohsm.npz")
+    for n in range(int(fx["ncases"])):
+        pre = "c%d_" % n
+        C, Q, D, _ = [int(v) for v in fx[pre + "meta"]]
+        fp = fixture_params(fx, pre)
+        k = gpr.MixtureKernel(gpr.MultiOutputHarmonizableSpectralKernel(output_dims=C, input_dims=D), Q)
+        var = np.asarray(fx[pre + "variance"])
+        m = gpr.Snelson(k, fx[pre + "X"], fx[pre + "y"], Z=[int(z) for z in fx[pre + "Zspec"]], variance=(var if var.ndim else float(var)),
+                        jitter=float(fx[pre + "jitter"]))
+        assert [p._name.split(".")[-1] for p in m.parameters()] == [f["name"].split(".")[-1] for f in fp]
+        load_raw(m.parameters(), fp)
+        assert abs(float(m.log_marginal_likelihood()) - float(fx[pre + "lml"])) < tol_loss * abs(float(fx[pre + "lml"]))
+        assert abs(float(m.loss()) - float(fx[pre + "loss"])) < tol_loss * abs(float(fx[pre + "loss"]))
+        for p, f in zip(m.parameters(), fp):
+            if f["grad"] is None:
+                assert p.grad is None, p._name
+            else:
+                assert np.max(np.abs(p.grad - f["grad"])) <= tol_grad * max(1.0, np.max(np.abs(f["grad"]))), (n, p._name, p.grad, f["grad"])
+        mu, var_p = m.predict_f(fx[pre + "Xs"])
+        assert relerr(mu, fx[pre + "mu"]) < tol_pred and np.max(np.abs(var_p - fx[pre + "var"])) < tol_pred * max(1.0, np.max(np.abs(fx[pre + "var"])))
+
+
+def test_snelson_with_enveloped_terms_matches_reference():
+    check_snelson_with_enveloped_terms()
+
+
 def test_titsias_through_the_model_wrapper():
     t = np.linspace(0, 10, 40)
     ds = mogptk_amd.DataSet(t, [np.sin(t), np.cos(t)])
