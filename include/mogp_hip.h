@@ -74,7 +74,8 @@ int  mogp_model_set_terms(mogp_model* m, int T, const double* table);
  * mogp_model_set_point_diag, and pass kss_diag to mogp_exact_predict per TEST POINT (S values, caller order) instead of per channel.
  * The Titsias entry points take enveloped terms the same way (any kernel under any inference, as in the reference): kff_diag per TRAINING
  * point (N values, caller order), kss_diag per test point, moment rows of width 2 + 5 D; the derivative with respect to the inducing inputs
- * includes the envelope's.  The Snelson and Hensman entry points still refuse them (their per-point diagonal terms are per channel here). */
+ * includes the envelope's.  So do the Snelson and Hensman entry points (kff_diag / kss_diag per point; mogp_snelson_eval returns dp/dKff_nn per
+ * point); their data-parallel forms and the Opper-Archambeau entry points do not. */
 int  mogp_model_set_terms_ex(mogp_model* m, int T, int width, const double* table);
 /* K_diag(X) of the N training points in the caller's row order (reference gpr/kernel.py:483-495): enters the relative jitter
  * jitter * mean(diag) (gpr/model.py:244).  NULL: back to the per-channel constant implied by the table. */

@@ -394,7 +394,7 @@ class ExactHandle:
 
     def svgp_backward(self, e, f, sharded=False):
         e, f = _f64(np.reshape(e, -1)), _f64(np.reshape(f, -1))
-        C, T, W, D, M = self.C, self.T, 2 + 3 * self.D, self.D, self._svgp_M
+        C, T, W, D, M = self.C, self.T, self.W, self.D, self._svgp_M       # W = 2 + 5 D with enveloped terms
         mom_uu, mom_uf = np.zeros((C * (C + 1) // 2, T, W)), np.zeros((C * C, T, W))
         gZ, g_qmu, g_S = np.zeros((M, D)), np.zeros(M), np.zeros((M, M))
         trGA = ctypes.c_double()

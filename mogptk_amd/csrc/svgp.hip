@@ -49,10 +49,9 @@ __global__ void k_sv_adjoint(double* __restrict__ Gv, const double* __restrict__
 // Kuu -> L (t.a), q_mu and S = tril(q_sqrt) onto the device in the sorted order of Z (t.vec[0:Mpad], t.R with rows permuted)
 int svgp_setup(mogp_model* m, int64_t M, const double* Z, const double* q_mu, const double* q_sqrt, double jitter, SortedX& sz,
                std::vector<GTile>& tuu, std::vector<int>& psuu, double& jit, int64_t* info) {
-    const int C = m->C, D = m->D, W = 2 + 3 * D;
+    const int C = m->C, D = m->D, W = m->Wt;                   // 2 + 3 D, or 2 + 5 D: terms with an envelope on the input midpoint (MOHSM)
     const int64_t Npad = m->Npad;
     if (m->T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms must be called before an evaluation");
-    if (m->Wt != W) return fail(MOGP_EINVAL, "the Hensman path does not take terms with an envelope (MOHSM): exact inference only");
     RC(sort_inputs(Z, M, D, C, MOGP_TILE, sz));
     // The whitened parametrisation q(u) = N(L q_mu, ..) depends on the ORDER of the inducing inputs through the Cholesky factor; the device
     // factorises Kuu with the inputs grouped by channel, so that is the order they have to come in (what init_inducing_points and the
@@ -84,13 +83,11 @@ int svgp_setup(mogp_model* m, int64_t M, const double* Z, const double* q_mu, co
     HIP_TRY(hipMemcpyAsync(t.tiles_uu.p, tuu.data(), tuu.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
     const unsigned long long big = std::numeric_limits<unsigned long long>::max();
     HIP_TRY(hipMemcpyAsync(m->d_info.p, &big, sizeof(big), hipMemcpyHostToDevice, m->st));
-    double dsum = 0.0;                                          // relative jitter on Kuu (reference gpr/model.py:855 -> :244)
-    for (int c = 0; c < C; ++c) dsum += (double)(sz.off[c + 1] - sz.off[c]) * table_diag(m, c);
-    jit = jitter * dsum / (double)M;
+    jit = jitter * table_diag_points(m, sz) / (double)M;        // relative jitter on Kuu (reference gpr/model.py:855 -> :244); with an envelope the diagonal follows Z
     GramArgs ga{};
     ga.tiles = t.tiles_uu.p; ga.xr = t.zx.p; ga.xc = t.zx.p; ga.ldxr = ga.ldxc = Mpad; ga.nrows = ga.ncols = M;
     RC(t.ph_zz.prepare(sz.off, sz.off, C, m->T, Mpad, Mpad, m->st, ga.ph));
-    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.out = t.a.A.p; ga.ldo = Mpad;
+    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = W; ga.out = t.a.A.p; ga.ldo = Mpad;
     ga.noise = t.zero_noise.p; ga.dvar = nullptr; ga.jitter_abs = jit; ga.mirror = 0;
     RC(launch_gram(ga, (int)tuu.size(), m->st));
     RC(launch_pad_identity(t.a.A.p, Mpad, M, Mpad, m->st));
@@ -169,7 +166,7 @@ int mogp_svgp_forward(mogp_model* m, int64_t M, const double* Z, const double* q
         GramArgs ga{};
         ga.tiles = dt.p; ga.xr = t.zx.p; ga.ldxr = Mpad; ga.xc = xq; ga.ldxc = Qpad; ga.nrows = M; ga.ncols = Qn;
         RC((train ? t.ph_zx : t.ph_zs).prepare(sz.off, sp->off, C, m->T, Mpad, Qpad, m->st, ga.ph));
-        ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.out = Kq; ga.ldo = Qpad; ga.mirror = 0;
+        ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = m->Wt; ga.out = Kq; ga.ldo = Qpad; ga.mirror = 0;
         RC(launch_gram(ga, (int)tuf.size(), m->st));
         HIP_TRY(hipMemcpyAsync(a, Kq, (size_t)Mpad * Qpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
         RC(trsm_lower(m, t.a.A.p, Mpad, mt, a, Qpad, Qpad, false));               // a = L^-1 K(Z, .)
@@ -186,10 +183,11 @@ int mogp_svgp_forward(mogp_model* m, int64_t M, const double* Z, const double* q
     HIP_TRY(hipMemcpyAsync(hv.data(), m->d_var.p, 2 * Qpad * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
     const double* kd = train ? kff_diag : kss_diag;
+    const bool env = m->Wt > 2 + 3 * D;                          // enveloped terms: K_diag per point (caller's order) instead of per channel
     for (int c = 0; c < C; ++c)
         for (int pos = sp->off[c]; pos < sp->off[c + 1]; ++pos) {
             mu[sp->perm[pos]] = hmu[pos];
-            var[sp->perm[pos]] = (dense && train) ? hv[Qpad + pos] : kd[c] - hv[pos] + hv[Qpad + pos];
+            var[sp->perm[pos]] = (dense && train) ? hv[Qpad + pos] : (env ? kd[sp->perm[pos]] : kd[c]) - hv[pos] + hv[Qpad + pos];
         }
     if (train) {
         t.sv_sz = sz; t.sv_tuu = tuu; t.sv_psuu = psuu; t.sv_tuf = tuf; t.sv_psuf = psuf;
@@ -211,8 +209,9 @@ static int svgp_backward_impl(mogp_model* m, const double* e, const double* f, d
     if (!m->tw || !m->tw->sv_valid) return fail(MOGP_EINVAL, "mogp_svgp_backward: no forward pass at the training inputs precedes it");
     TitsiasWork& t = *m->tw;
     t.sv_valid = false;                                         // the buffers of the forward pass are consumed
-    const int C = m->C, D = m->D, W = 2 + 3 * D, T = m->T, P = C * (C + 1) / 2;
+    const int C = m->C, D = m->D, W = m->Wt, T = m->T, P = C * (C + 1) / 2;
     const int64_t N = m->N, Npad = m->Npad, Mpad = t.Mpad, M = t.sv_M;
+    if (sharded && W > 2 + 3 * D) return fail(MOGP_EINVAL, "the data-parallel Hensman path does not take terms with an envelope (MOHSM)");
     const int mt = (int)(Mpad / MOGP_TILE), nt = (int)(Npad / MOGP_TILE);
     const bool dense = t.sv_dense;
     const SortedX& sz = t.sv_sz;
@@ -272,7 +271,7 @@ static int svgp_backward_impl(mogp_model* m, const double* e, const double* f, d
 
     MomentArgs ma{};
     ma.x = t.zx.p; ma.ldx = Mpad; ma.nrows = M;
-    ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C;
+    ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C; ma.W = W;
     ma.ru = q; ma.rw = q; ma.rcoef = 0.0; ma.ldgz = Mpad;
     if (!dense) {
         // dE/dKuf = L^-T Gv, in place

@@ -778,8 +778,10 @@ class SparseHensman(_DataParallel, Model):
         table = self.kernel._spectral_terms(D)
         h.set_terms(table)
         Zk = self.kernel._kernel_format(self.Z())
+        env = table.shape[3] > 2 + 3 * D                  # enveloped terms (MOHSM): the kernel diagonal follows the points
+        kff = self.kernel._point_diag(table, self._local(self.kernel._kernel_format(self.X)), D) if env else self.kernel._spectral_diag(D)
         try:
-            res = h.svgp_forward(Zk, self.q_mu(), self.q_sqrt(), self.jitter, self.kernel._spectral_diag(D), dense=not self.is_sparse)
+            res = h.svgp_forward(Zk, self.q_mu(), self.q_sqrt(), self.jitter, kff, dense=not self.is_sparse)
         except MogpError as e:
             if e.code in (MOGP_ENOTPD, MOGP_ENONFINITE):
                 print("ERROR:", str(e), file=sys.__stdout__)
@@ -822,11 +824,21 @@ class SparseHensman(_DataParallel, Model):
         zc = np.bincount(Zk[:, 0].astype(np.int64), minlength=C).astype(np.float64)
         xc = self._local(self.kernel._kernel_format(self.X))[:, 0].astype(np.int64)
         gt = _gtable_from_moments(table, bw["mom_uu"], D, lower=True) + _gtable_from_moments(table, bw["mom_uf"], D, lower=False)
-        for i in range(C):
-            gt[i, i, :, 0] += self.jitter * bw["trGA"] * zc[i] / M          # jitter * mean(diag Kuu), gpr/model.py:244
-        self.kernel._spectral_backward(-gt)
-        if self.is_sparse:                          # var_n = K_diag[c(n)] - ... (the dense model's variance at its own inputs has no such term)
-            self.kernel._spectral_diag_backward(-self._reduce(np.bincount(xc, weights=f, minlength=C)), D)
+        gz_jit = 0.0
+        if table.shape[3] > 2 + 3 * D:
+            # enveloped terms: jitter * mean(diag Kuu) depends on A, L, c and on the inducing inputs themselves (gpr/model.py:244 through autograd),
+            # and var_n = K_diag(x_n) - ... goes back through the per-point diagonal with the likelihood's d/dvar_n as weights
+            gt += (self.jitter * bw["trGA"] / M) * self.kernel._point_diag_table_grad(table, Zk, D)
+            gz_jit = (self.jitter * bw["trGA"] / M) * self.kernel._point_diag_input_grad(table, Zk, D)
+            if self.is_sparse:
+                gt += self.kernel._point_diag_table_grad(table, self._local(self.kernel._kernel_format(self.X)), D, weights=f)
+            self.kernel._spectral_backward(-gt)
+        else:
+            for i in range(C):
+                gt[i, i, :, 0] += self.jitter * bw["trGA"] * zc[i] / M          # jitter * mean(diag Kuu), gpr/model.py:244
+            self.kernel._spectral_backward(-gt)
+            if self.is_sparse:                          # var_n = K_diag[c(n)] - ... (the dense model's variance at its own inputs has no such term)
+                self.kernel._spectral_diag_backward(-self._reduce(np.bincount(xc, weights=f, minlength=C)), D)
         for p, g in pgrads:
             p.accumulate_grad(np.reshape(-np.asarray(g, dtype=np.float64), p.data.shape))
         self.q_mu.accumulate_grad(-(np.reshape(bw["g_qmu"], q_mu.shape) - q_mu))
@@ -835,7 +847,7 @@ class SparseHensman(_DataParallel, Model):
         if self.is_sparse:
             gz = np.zeros(self.Z.data.shape)
             off = 0 if self.kernel.output_dims is None else 1
-            gz[:, off:] = -bw["gZ"]
+            gz[:, off:] = -(bw["gZ"] + gz_jit)
             self.Z.accumulate_grad(gz)
         return config.dtype(-elbo - self.log_prior())
 
@@ -844,10 +856,16 @@ class SparseHensman(_DataParallel, Model):
         X = self._check_input(X)
         h = self._device_handle()
         D = self.X.shape[1] - (0 if self.kernel.output_dims is None else 1)
-        h.set_terms(self.kernel._spectral_terms(D))
-        kd = self.kernel._spectral_diag(D)
+        table = self.kernel._spectral_terms(D)
+        h.set_terms(table)
+        Xsk = self.kernel._kernel_format(X)
+        if table.shape[3] > 2 + 3 * D:                    # enveloped terms: K_diag per training / test point
+            kd = self.kernel._point_diag(table, self._local(self.kernel._kernel_format(self.X)), D)
+            ks = self.kernel._point_diag(table, Xsk, D)
+        else:
+            kd = ks = self.kernel._spectral_diag(D)
         res = h.svgp_forward(self.kernel._kernel_format(self.Z()), self.q_mu(), self.q_sqrt(), self.jitter, kd,
-                             Xs=self.kernel._kernel_format(X), kss_diag=kd)
+                             Xs=Xsk, kss_diag=ks)
         mu = np.reshape(res["mu"], (-1, 1))
         if self.mean is not None:
             mu = mu + np.asarray(self.mean(X)).reshape(-1, 1)

@@ -418,7 +418,9 @@ def svgp_forward(self, Z, q_mu, q_sqrt, jitter, kff_diag, Xs=None, kss_diag=None
     jit = jitter * np.mean(np.diagonal(Kuu))
     Luu = np.linalg.cholesky(Kuu + jit * np.eye(M))
     Xq = self.X if Xs is None else Xs
-    kd = np.asarray(kff_diag if Xs is None else kss_diag)[Xq[:, 0].astype(np.int64)]
+    kd = np.asarray(kff_diag if Xs is None else kss_diag)
+    if self.table.shape[3] <= 2 + 3 * self.D:               # per channel; enveloped terms: already per point
+        kd = kd[Xq[:, 0].astype(np.int64)]
     S = np.tril(np.asarray(q_sqrt, dtype=np.float64))
     qm = np.asarray(q_mu, dtype=np.float64).reshape(-1)
     if dense and Xs is None:

@@ -862,6 +862,45 @@ def gen_hensman():
     print("hensman.npz written")
 
 
+def gen_hensman_mohsm():
+    """SparseHensman / Hensman (Gaussian and Student-t likelihoods) with an ENVELOPED kernel (reference gpr/multioutput.py:340-395 under
+    gpr/model.py:767-886): ELBO, gradients of every parameter (q_mu, q_sqrt, inducing inputs through the envelope and the point-dependent
+    jitter, lengthscale / center, likelihood), predict_f."""
+    out = {}
+    cases = [(3, 2, 1, 96, [5, 4, 6], "gaussian"), (2, 1, 2, 80, [4, 9], "studentt"), (2, 2, 1, 40, None, "gaussian")]
+    out["ncases"] = np.array(len(cases))
+    for n, (C, Q, D, N, Zspec, lik_name) in enumerate(cases):
+        rng = np.random.default_rng(9970 + n)
+        X, y = small_data(N, C, D, 9975 + n, False)
+        k = build_kernel("mohsm", C, Q, D, 1, rng)
+        for q in range(Q):       # as in gen_titsias_mohsm: keep K_uu's cross-channel blocks a valid covariance
+            k[q].mean.assign(np.tile(rng.uniform(0.05, 0.5, (1, D)), (C, 1)))
+            k[q].variance.assign(np.tile(rng.uniform(0.05, 0.5, (1, D)), (C, 1)))
+            k[q].lengthscale.assign(np.full(C, rng.uniform(0.1, 0.4)))
+            k[q].delay.assign(np.zeros((C, D)))
+            k[q].phase.assign(np.zeros(C))
+        lik = g.GaussianLikelihood(float(rng.uniform(0.1, 0.4))) if lik_name == "gaussian" else g.StudentTLikelihood(dof=4, scale=float(rng.uniform(0.2, 0.4)))
+        if Zspec is None:
+            m = g.Hensman(k, T(X), T(y), likelihood=lik, jitter=1e-6)
+        else:
+            m = g.SparseHensman(k, T(X), T(y), Z=Zspec, Z_init="grid", likelihood=lik, jitter=1e-6)
+        M = m.q_mu().shape[0]
+        m.q_mu.assign(rng.normal(0, 0.5, (M, 1)))
+        m.q_sqrt.assign(np.tril(rng.normal(0, 0.2, (M, M))) + np.diag(rng.uniform(0.5, 1.2, M)))
+        pre = "c%d_" % n
+        out[pre + "meta"] = np.array([C, Q, D, 1]); out[pre + "X"] = X; out[pre + "y"] = y
+        out[pre + "sparse"] = np.array(Zspec is not None); out[pre + "lik"] = np.array(lik_name)
+        out[pre + "Zspec"] = np.atleast_1d(np.array(Zspec if Zspec is not None else [0])); out[pre + "jitter"] = np.array(m.jitter)
+        out[pre + "elbo"] = np.array(float(m.log_marginal_likelihood()))
+        out[pre + "loss"] = np.array(float(m.loss()))
+        dump_params(pre, list(m.parameters()), out, with_grad=True)
+        Xs, _ = small_data(21, C, D, 9980 + n, False)
+        mu, var_p = m.predict_f(T(Xs))
+        out[pre + "Xs"] = Xs; out[pre + "mu"] = mu.numpy(); out[pre + "var"] = var_p.numpy()
+    np.savez_compressed(os.path.join(HERE, "hensman_mohsm.npz"), **out)
+    print("hensman_mohsm.npz written")
+
+
 def gen_oa():
     """small OpperArchambeau fixtures with the Gaussian likelihood (reference gpr/model.py:578-668): ELBO, gradients of every parameter
     (q_nu, q_lambda, kernel, scale), predict_f (diagonal and full); q_nu / q_lambda away from their initial values, inputs NOT grouped by channel"""
@@ -1192,7 +1231,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     steps = {"kernels": gen_kernels, "lml": gen_lml, "predict": gen_predict, "adam": gen_adam_cfg1, "lbfgs": gen_lbfgs_cfg1, "quirks": gen_quirks,
              "kernels_8f2": gen_kernels_8f2, "lml_8f2": gen_lml_8f2, "smlmc": gen_smlmc, "init_ls": gen_init_ls, "bnse": gen_bnse, "transformers": gen_transformers,
-             "titsias": gen_titsias, "titsias_mohsm": gen_titsias_mohsm, "snelson_mohsm": gen_snelson_mohsm, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints, "snelson": gen_snelson, "hensman": gen_hensman, "oa": gen_oa, "likelihoods": gen_likelihoods, "samples": gen_samples, "sparse_cov": gen_sparse_cov}
+             "titsias": gen_titsias, "titsias_mohsm": gen_titsias_mohsm, "snelson_mohsm": gen_snelson_mohsm, "hensman_mohsm": gen_hensman_mohsm, "opt_traces": gen_opt_traces, "peg": gen_peg, "mohsm": gen_mohsm, "fp32": gen_fp32, "checkpoints": gen_checkpoints, "snelson": gen_snelson, "hensman": gen_hensman, "oa": gen_oa, "likelihoods": gen_likelihoods, "samples": gen_samples, "sparse_cov": gen_sparse_cov}
     full = {"cfg2": gen_cfg2, "cfg4": gen_cfg4, "cfg5": gen_cfg5}
     if a.only:
         {**steps, **full}[a.only]()

@@ -572,6 +572,13 @@ def test_snelson_with_enveloped_terms_on_device():
     check_snelson_with_enveloped_terms(tol_loss=1e-9, tol_grad=1e-6, tol_pred=1e-7)
 
 
+def test_hensman_with_enveloped_terms_on_device():
+    """SparseHensman / Hensman with MOHSM terms on the device against the reference's autograd (mogp_svgp_forward / _backward with rows of
+    width 2 + 5 D)"""
+    from test_host_logic import check_hensman_with_enveloped_terms
+    check_hensman_with_enveloped_terms(tol_elbo=1e-9, tol_grad=1e-6, tol_pred=1e-7)
+
+
 def test_single_precision_switch_on_device():
     from test_host_logic import check_single_precision_switch
     check_single_precision_switch()

@@ -729,6 +729,42 @@ def test_hensman_matches_reference():
     check_hensman()
 
 
+def check_hensman_with_enveloped_terms(tol_elbo=1e-9, tol_grad=1e-7, tol_pred=1e-8):
+    """SparseHensman (Gaussian, Student-t) and the dense Hensman model under the enveloped MOHSM kernel (reference gpr/multioutput.py:340-395
+    under gpr/model.py:767-886): K_diag per training point inside var_n with the likelihood's d/dvar_n going back through it, K_uu's jitter
+    through the inducing inputs -- against the reference's autograd"""
+    fx = load("hensman_mohsm.npz")
+    for n in range(int(fx["ncases"])):
+        pre = "c%d_" % n
+        C, Q, D, _ = [int(v) for v in fx[pre + "meta"]]
+        fp = fixture_params(fx, pre)
+        sparse = bool(fx[pre + "sparse"])
+        k = gpr.MixtureKernel(gpr.MultiOutputHarmonizableSpectralKernel(output_dims=C, input_dims=D), Q)
+        lik = gpr.GaussianLikelihood(1.0) if str(fx[pre + "lik"]) == "gaussian" else gpr.StudentTLikelihood(dof=4, scale=1.0)
+        if sparse:
+            m = gpr.SparseHensman(k, fx[pre + "X"], fx[pre + "y"], Z=[int(z) for z in fx[pre + "Zspec"]], likelihood=lik, jitter=float(fx[pre + "jitter"]))
+        else:
+            m = gpr.Hensman(k, fx[pre + "X"], fx[pre + "y"], likelihood=lik, jitter=float(fx[pre + "jitter"]))
+        assert [p._name.split(".")[-1] for p in m.parameters()] == [f["name"].split(".")[-1] for f in fp]
+        load_raw(m.parameters(), fp)
+        elbo, ref = float(m.log_marginal_likelihood()), float(fx[pre + "elbo"])
+        assert abs(elbo - ref) < tol_elbo * max(1.0, abs(ref)), (n, elbo, ref)
+        loss, ref = float(m.loss()), float(fx[pre + "loss"])
+        assert abs(loss - ref) < tol_elbo * max(1.0, abs(ref)), (n, loss, ref)
+        for p, f in zip(m.parameters(), fp):
+            if f["grad"] is None:
+                assert p.grad is None, (n, p._name)
+            else:
+                assert p.grad is not None, (n, p._name)
+                assert np.max(np.abs(p.grad - f["grad"])) <= tol_grad * max(1.0, np.max(np.abs(f["grad"]))), (n, p._name, np.max(np.abs(p.grad - f["grad"])))
+        mu, var_p = m.predict_f(fx[pre + "Xs"])
+        assert relerr(mu, fx[pre + "mu"]) < tol_pred and np.max(np.abs(var_p - fx[pre + "var"])) < tol_pred * max(1.0, np.max(np.abs(fx[pre + "var"]))), n
+
+
+def test_hensman_with_enveloped_terms_matches_reference():
+    check_hensman_with_enveloped_terms()
+
+
 def check_oa(tol_elbo=1e-9, tol_grad=1e-7, tol_pred=1e-8):
     fx = load("oa.npz")
     for n in range(int(fx["ncases"])):
