@@ -218,6 +218,23 @@ int  mogp_set_profiling(mogp_model* m, int on);
  * *gemm_launches / *gemm_flops = their count and algorithmic flop total in the last eval. */
 int  mogp_stage_ms(mogp_model* m, double* ms, int64_t* gemm_launches, double* gemm_flops);
 
+/* The fused factorisation + inversion behind mogp_exact_eval(MOGP_EVAL_GRAD) (reference gpr/model.py:242-246 and the O(N^3) solves of its
+ * autograd backward, :291) runs as a static graph of 128 x 128 tile products inside ONE resident kernel (csrc/flow.hip).  This call returns
+ * that graph for a matrix of nb tile rows as numbers -- no device work, callable without a GPU -- so that tests can replay it on the CPU
+ * (dependencies sufficient, no deadlock, no data race, result = the inverse).  *count = rows; out (cap >= 24 * count, or NULL to ask for
+ * the count) gets 24 numbers per row:
+ *   tile task:    [queue, key, A buffer, A tile row, A tile col, B buffer, row, col, C buffer, row, col, var, k blocks of 16, ndep,
+ *                  dep counter x 4, needed value x 4, counter bumped x 2 (-1: none)]
+ *                 buffers 0 Schur matrix, 1 panels L, 2 running product Wt, 3 W = L^-1, 4 inverse; var bits 0-1: 0 = C (+)= a A B^T (both
+ *                 k-contiguous), 1 = a A B (B k-major), 2 = a A^T B (both k-major); bit 2: overwrite (beta = 0); bit 3: a = -1
+ *   chain kernel: [-1, key, block, first tile, tiles, 0.., ndep (0 / 1), dep counter, 0, 0, 0, needed value, 0, 0, 0, counter bumped, by how much] */
+int  mogp_flow_plan(int nb, int64_t* out, int64_t cap, int64_t* count);
+/* Time stamps (100 MHz device wall clock) of the last mogp_exact_eval that ran as dataflow with MOGP_FLOW_TRACE=1 in the environment:
+ * 6 numbers per tile task in the row order of mogp_flow_plan's tile tasks (the workgroup starts looking for work, has taken the task, its k loop
+ * starts, ends, the tile is stored and its counters are bumped, XCC << 16 | workgroup), then 4 per chain kernel
+ * (launched, wait over, end, 0).  *count = 0 when there is no trace.  Measurement only (tools/flow_trace.py -> profiles/). */
+int  mogp_flow_trace(mogp_model* m, int64_t* out, int64_t cap, int64_t* count);
+
 /* copy device-resident matrices of the last eval back (tests / CholeskyException payload):
  * which: 0 = W = L^-1, inverse of the lower Cholesky factor of Kj, in CHANNEL-SORTED row order (after any eval), 1 = Kj^-1 (after MOGP_EVAL_GRAD),
  *        2 = alpha (N).  Output in the caller's original row order, full N x N (symmetrised / lower-filled). */

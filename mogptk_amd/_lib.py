@@ -77,6 +77,8 @@ SIGNATURES = {
     "mogp_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "mogp_stage_ms": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i64p, c_dp]),
     "mogp_model_fetch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_dp]),
+    "mogp_flow_plan": (ctypes.c_int, [ctypes.c_int, c_i64p, ctypes.c_int64, c_i64p]),
+    "mogp_flow_trace": (ctypes.c_int, [ctypes.c_void_p, c_i64p, ctypes.c_int64, c_i64p]),
     "mogp_snelson_eval": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_double), c_dp, c_dp, c_dp, ctypes.POINTER(ctypes.c_double), c_dp,
                                          ctypes.POINTER(ctypes.c_double), c_i64p]),

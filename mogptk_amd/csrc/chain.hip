@@ -42,6 +42,11 @@ struct ChainArgs {
     double* Wk; int64_t ldw;        // W_KK (nk * 128 square; tiles above the diagonal untouched)
     unsigned* flags;                // MOGP_CHAIN_FLAGS zeroed words of this block
     unsigned* err;                  // one word per evaluation, zero at its start
+    // inside the dataflow schedule (flow.hip): wait for the diagonal block's last update, publish W_KK, count the workgroups that are through
+    unsigned* wait_flag; unsigned wait_val;
+    unsigned* done_flag;
+    int wt;                         // W_KK leaves with write-through stores (its readers are workgroups of a kernel that is already running)
+    unsigned long long* trace;
 };
 
 // ---- hand-off -------------------------------------------------------------------------------------------------------------------
@@ -105,6 +110,10 @@ __device__ __forceinline__ void ch_slab_product(const double* A, int64_t lda, co
     }
 }
 
+__device__ __forceinline__ void ch_stw(int wt, double* p, double v) {
+    if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+
 // ---- W_KK strips (the arithmetic of wkk.hip) ---------------------------------------------------------------------------------------
 __device__ __forceinline__ int ch_perm(int row) { return (row & ~15) | ((row & 3) << 2) | ((row >> 2) & 3); }
 
@@ -143,7 +152,7 @@ __device__ __forceinline__ void ch_strip_window(const ChainArgs& g, double* ctx,
             const int r = e >> 4, c = e & 15;
             const double v = Dk[r * MOGP_TILE + c0 + c];
             ctx[ch_perm(r) * CH_COLS + c] = v;
-            Wk[(int64_t)(s * MOGP_TILE + r) * g.ldw + s * MOGP_TILE + c0 + c] = v;
+            ch_stw(g.wt, Wk + (int64_t)(s * MOGP_TILE + r) * g.ldw + s * MOGP_TILE + c0 + c, v);
         }
     } else {
         d4_t o0 = (d4_t){0.0, 0.0, 0.0, 0.0}, o1 = o0;
@@ -157,8 +166,8 @@ __device__ __forceinline__ void ch_strip_window(const ChainArgs& g, double* ctx,
                 slot[ch_perm(r0) * CH_COLS + lr] = o0[r];
                 slot[ch_perm(r1) * CH_COLS + lr] = o1[r];
             }
-            Wk[(int64_t)(k * MOGP_TILE + r0) * g.ldw + s * MOGP_TILE + c0 + lr] = o0[r];
-            Wk[(int64_t)(k * MOGP_TILE + r1) * g.ldw + s * MOGP_TILE + c0 + lr] = o1[r];
+            ch_stw(g.wt, Wk + (int64_t)(k * MOGP_TILE + r0) * g.ldw + s * MOGP_TILE + c0 + lr, o0[r]);
+            ch_stw(g.wt, Wk + (int64_t)(k * MOGP_TILE + r1) * g.ldw + s * MOGP_TILE + c0 + lr, o1[r]);
         }
     }
     if (k + 1 >= g.nk) return;
@@ -182,6 +191,11 @@ __global__ __launch_bounds__(256, 1) void k_chain(ChainArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = g.nk;
+    if (g.trace && blockIdx.x == 0 && tid == 0) g.trace[0] = wall_clock64();
+    // dataflow schedule: the diagonal block is complete when the update tasks of the previous panel have all reported (their tiles were
+    // stored write-through by another kernel's workgroups: ch_wait's acquire makes them visible)
+    if (g.wait_flag) ch_wait(g.wait_flag, g.wait_val, g.err, 0x500u);
+    if (g.trace && blockIdx.x == 0 && tid == 0) g.trace[1] = wall_clock64();
     if (blockIdx.x == 0) {
         // ---- the leaves ----
         for (int k = 0; k < nk; ++k) {
@@ -269,9 +283,17 @@ __global__ __launch_bounds__(256, 1) void k_chain(ChainArgs g) {
                 const int nwork = (int)gridDim.x - 1;
                 for (int e = tid + 256 * wg; e < MOGP_TILE * MOGP_TILE; e += 256 * nwork) {
                     const int r = e >> 7, c = e & 127;
-                    g.Wk[(int64_t)(k * MOGP_TILE + r) * g.ldw + k * MOGP_TILE + c] = Dk[e];
+                    ch_stw(g.wt, g.Wk + (int64_t)(k * MOGP_TILE + r) * g.ldw + k * MOGP_TILE + c, Dk[e]);
                 }
             }
+        }
+    }
+    if (g.done_flag) {              // W_KK (and everything else this workgroup stored) has left the CU before the counter moves
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(g.done_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g.trace && blockIdx.x == 0) g.trace[2] = wall_clock64();
         }
     }
     // a timed-out wait anywhere: the results are garbage -- say so through the pivot report (a real pivot failure, being smaller, wins)
@@ -287,7 +309,7 @@ bool chain_enabled(const mogp_model* m) {
 }
 
 int launch_chain(double* A, int64_t ld, int t0, int nk, double* invd, double* logdet, unsigned long long* info, long long info_base,
-                 double* Wk, int64_t ldw, unsigned* flags, unsigned* err, hipStream_t s) {
+                 double* Wk, int64_t ldw, unsigned* flags, unsigned* err, hipStream_t s, const ChainFlow* flow) {
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES));
@@ -297,6 +319,7 @@ int launch_chain(double* A, int64_t ld, int t0, int nk, double* invd, double* lo
     ChainArgs g{};
     g.A = A; g.ld = ld; g.t0 = t0; g.nk = nk; g.invd = invd; g.logdet = logdet; g.info = info; g.info_base = info_base;
     g.Wk = Wk; g.ldw = ldw; g.flags = flags; g.err = err;
+    if (flow) { g.wait_flag = flow->wait_flag; g.wait_val = flow->wait_val; g.done_flag = flow->done_flag; g.wt = flow->write_through; g.trace = flow->trace; }
     hipLaunchKernelGGL(k_chain, dim3(nk > 1 ? CH_NWG : 2), dim3(256), CH_LDS_BYTES, s, g);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -1,0 +1,620 @@
+// flow.hip -- the fused factorisation + inversion of potri.hip as TILE DATAFLOW: one resident kernel instead of five streams of launches.
+//
+// Why (round 3's evidence): with the inverse streamed behind the Cholesky chain as rank-512 launches on five streams an
+// N = 8192 evaluation takes 13 ms although its dependency chain alone takes 7.7 ms and its GEMM work 8.5-9.3 ms at lone-launch rates: tall
+// launches on the block cycle and bulk launches steal each other's workgroup slots, and every cross-stream event waits for slots that free
+// in bursts.  Fifteen stream-level variants did not move it.  Here the SAME tile products (same operands, same k order: results identical
+// per tile) are tasks of a static graph:
+//   * k_flow: 2 workgroups per CU on the CUs the chain does not own, resident for the whole evaluation.  A workgroup looks at the HEAD of
+//     every task queue (queues in priority order: what the next chain kernel needs first, the inverse's accumulations last), takes the
+//     first head whose dependency counters are satisfied (compare-and-swap on the queue's head word), runs the 128 x 128 tile with the
+//     k loop of linalg.hip:k_gemm (eight waves, BK = 16, double-buffered LDS), stores C write-through, bumps the task's counters.
+//   * the chain kernels (chain.hip) stay the producers of L_KK / W_KK on the reserved CUs, one launch per outer block on the private
+//     stream; they now wait for "my diagonal block has all its updates" and report "W_KK is there" through the same counters.
+// Hand-off = the guide's recipe (MI355X_MICROARCH "inter-workgroup visibility"): payload with sc1 stores, every storing wave drains vmcnt,
+// ONE lane bumps an agent-scope counter; the consumer polls relaxed, ONE agent acquire after the match, barrier, plain loads.
+// A workgroup never holds a task that is not ready, so any number of resident workgroups makes progress; every queue is sorted by the
+// sequential algorithm's order (block, phase), so the globally first unfinished task is always at the head of its queue with its
+// dependencies met: no deadlock (tests/test_flow_plan_cpu.py replays the graph on numpy tiles in random orders and checks both).
+// Every wait is bounded; a time-out is reported through the pivot word like the chain kernel's and the evaluation is repeated on the
+// stream schedule.
+// Buffers (all Npad x Npad, leading dimension Npad): A = Schur data (in place), L = panels L[>K, K] at their natural position (no rotating
+// buffers: nothing is ever overwritten while it can still be read), Wt = the running product of the elementary block-column inverses,
+// Wm = W = L^-1 (final row blocks; the chain kernels write W_KK straight into its diagonal blocks), B = Kj^-1 accumulator.
+// Replaces torch.linalg.cholesky + the O(N^3) solves of its autograd backward (reference gpr/model.py:242-246, :291).
+#include "mogp_model.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace mogp {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// ---- the tile product: linalg.hip's eight-wave 128 x 128 tile (2 x 4 waves of 4 x 2 MFMA tiles), lda = ldb = ldc = ld ----------------
+#define FL_BK 16
+#define FL_ROWK 18
+#define FL_WTM 4
+#define FL_WTN 2
+#define FL_NWJ 4
+#define FL_NWI 2
+#define FL_NT 512
+#define FL_COLK (MOGP_TILE + 16)
+#define FL_OPER (MOGP_TILE * FL_ROWK)            // == 16 * FL_COLK
+#define FL_LDS_DOUBLES (2 * 2 * FL_OPER)
+#define FL_LDS_BYTES (FL_LDS_DOUBLES * 8 + 16)   // + the workgroup's pick word
+static_assert(MOGP_TILE * FL_ROWK == 16 * FL_COLK, "one LDS operand slot serves both layouts");
+
+#define FL_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// C = alpha * (sum_k A B) + (fresh ? 0 : C); alpha = +-1.  Stores are write-through (sc1): another workgroup of this launch reads them.
+template <int AKM, int BKM>
+__device__ __forceinline__ void flow_tile(const double* Ap, const double* Bp, double* Cp, const int64_t ld, const int kt, const bool fresh,
+                                          const double alpha, double* gemm_lds, unsigned long long* tr) {
+    constexpr int WTM = FL_WTM, WTN = FL_WTN, NWJ = FL_NWJ, NWI = FL_NWI, NT = FL_NT;
+    constexpr int TMR = MOGP_TILE, TNC = MOGP_TILE, COLK_A = FL_COLK, COLK_B = FL_COLK, OPER_A = FL_OPER, OPER_B = FL_OPER;
+    constexpr int EPT_A = TMR * FL_BK / NT, EPT_B = TNC * FL_BK / NT;
+    constexpr int NQ_A = EPT_A / 2, NQ_B = EPT_B / 2, TPR_A = FL_BK / EPT_A, TPR_B = FL_BK / EPT_B, TPK = NT / FL_BK;
+    // per-thread offsets from an opaque copy of the thread id (hoisted out of the task loop they would not fit next to the accumulators)
+    int tl = threadIdx.x;
+    asm volatile("" : "+v"(tl));
+    const int ln = tl & 63, wv = tl >> 6, wi = wv / NWJ, wj = wv % NWJ;
+    const int64_t a_g = AKM ? (int64_t)(tl / TPK) * ld + (tl % TPK) * EPT_A : (int64_t)(tl / TPR_A) * ld + (tl % TPR_A) * EPT_A;
+    const int64_t b_g = BKM ? (int64_t)(tl / TPK) * ld + (tl % TPK) * EPT_B : (int64_t)(tl / TPR_B) * ld + (tl % TPR_B) * EPT_B;
+    const int a_l = AKM ? (tl / TPK) * COLK_A + (tl % TPK) * EPT_A : (tl / TPR_A) * FL_ROWK + (tl % TPR_A) * EPT_A;
+    const int b_l = BKM ? (tl / TPK) * COLK_B + (tl % TPK) * EPT_B : (tl / TPR_B) * FL_ROWK + (tl % TPR_B) * EPT_B;
+    const int64_t a_step = AKM ? (int64_t)FL_BK * ld : FL_BK;
+    const int64_t b_step = BKM ? (int64_t)FL_BK * ld : FL_BK;
+    const int crow = wi * (TMR / NWI) + (ln >> 4), ccol = wj * (TNC / NWJ) + (ln & 15);
+    const int fa = AKM ? (ln >> 4) * COLK_A + wi * (TMR / NWI) + (ln & 15) : (wi * (TMR / NWI) + (ln & 15)) * FL_ROWK + (ln >> 4);
+    const int fb = BKM ? (ln >> 4) * COLK_B + wj * (TNC / NWJ) + (ln & 15) : (wj * (TNC / NWJ) + (ln & 15)) * FL_ROWK + (ln >> 4);
+    constexpr int fa_m = AKM ? 16 : 16 * FL_ROWK, fa_k = AKM ? 4 * COLK_A : 4;
+    constexpr int fb_n = BKM ? 16 : 16 * FL_ROWK, fb_k = BKM ? 4 * COLK_B : 4;
+
+    d4_t acc[WTM][WTN];
+    if (!fresh) {                                        // start from (1 / alpha) C: the epilogue is a pure store of alpha * acc (k_gemm's form)
+#pragma unroll
+        for (int m = 0; m < WTM; ++m)
+#pragma unroll
+            for (int n = 0; n < WTN; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[m][n][r] = alpha * Cp[(int64_t)(crow + m * 16 + 4 * r) * ld + ccol + n * 16];
+    } else {
+#pragma unroll
+        for (int m = 0; m < WTM; ++m)
+#pragma unroll
+            for (int n = 0; n < WTN; ++n) acc[m][n] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    }
+    d2_t ra[NQ_A], rb[NQ_B];
+    auto load_block = [&](int kb) {
+        const d2_t* pa = reinterpret_cast<const d2_t*>(Ap + a_g + (int64_t)kb * a_step);
+        const d2_t* pb = reinterpret_cast<const d2_t*>(Bp + b_g + (int64_t)kb * b_step);
+#pragma unroll
+        for (int q = 0; q < NQ_A; ++q) ra[q] = pa[q];
+#pragma unroll
+        for (int q = 0; q < NQ_B; ++q) rb[q] = pb[q];
+    };
+    auto write_block = [&](int buf) {
+        double* sa = gemm_lds + buf * (OPER_A + OPER_B);
+        double* sb = sa + OPER_A;
+#pragma unroll
+        for (int q = 0; q < NQ_A; ++q) *reinterpret_cast<d2_t*>(sa + a_l + 2 * q) = ra[q];
+#pragma unroll
+        for (int q = 0; q < NQ_B; ++q) *reinterpret_cast<d2_t*>(sb + b_l + 2 * q) = rb[q];
+    };
+    auto read_frag = [&](double (&av)[WTM], double (&bv)[WTN], int buf, int k4) {
+        const double* sa = gemm_lds + buf * (OPER_A + OPER_B);
+        const double* sb = sa + OPER_A;
+#pragma unroll
+        for (int m = 0; m < WTM; ++m) av[m] = sa[fa + m * fa_m + k4 * fa_k];
+#pragma unroll
+        for (int n = 0; n < WTN; ++n) bv[n] = sb[fb + n * fb_n + k4 * fb_k];
+    };
+    auto mma = [&](const double (&av)[WTM], const double (&bv)[WTN]) {
+#pragma unroll
+        for (int m = 0; m < WTM; ++m)
+#pragma unroll
+            for (int n = 0; n < WTN; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[n], acc[m][n], 0, 0, 0);
+    };
+    load_block(0);
+    write_block(0);
+    load_block(min(1, kt - 1));
+    FL_LDS_BARRIER();
+    if (tr) tr[2] = wall_clock64();
+    {
+        double a0[WTM], b0[WTN], a1[WTM], b1[WTN];
+        read_frag(a0, b0, 0, 0);
+        for (int kb = 0; kb < kt; ++kb) {               // the pipeline of k_gemm (linalg.hip)
+            const int buf = kb & 1;
+            read_frag(a1, b1, buf, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frag(a0, b0, buf, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            write_block(buf ^ 1);
+            load_block(min(kb + 2, kt - 1));
+            read_frag(a1, b1, buf, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            FL_LDS_BARRIER();
+            read_frag(a0, b0, buf ^ 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (tr) tr[3] = wall_clock64();
+#pragma unroll
+    for (int m = 0; m < WTM; ++m)
+#pragma unroll
+        for (int n = 0; n < WTN; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                __hip_atomic_store(Cp + (int64_t)(crow + m * 16 + 4 * r) * ld + ccol + n * 16, alpha * acc[m][n][r], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct FlowArgs {
+    double* bA; double* bL; double* bWt; double* bWm; double* bB;     // buffer ids 0 .. 4
+    int64_t ld;
+    const FlowTask* tasks;
+    const int* qmeta;                 // [2 nq]: first task, number of tasks of every queue
+    unsigned* flags;                  // dependency counters, then the queue heads, then the error word (all zero at the start of an evaluation)
+    int nq, ncas, base_heads, base_err;
+    unsigned long long* info;
+    unsigned long long* trace;        // optional: [FLOW_TRACE_W ntasks] look, claimed, k loop from, to, signalled (100 MHz wall clock), XCC << 16 | workgroup
+};
+
+#define FL_IDLE_LIMIT 60000u          // idle looks (1 .. 16 us apart) before a workgroup gives up (the chain's own waits give up after ~0.2 s)
+#define FL_LA 8                       // positions behind the head of a compare-and-swap queue whose readiness a look already knows
+
+// How a workgroup gets its next tile.  Wave 0 looks at every queue at once, one lane per candidate:
+//   * the first `ncas` queues (the few tiles the next chain kernel waits for) are taken READY ONLY: a lane per position head .. head + 7 reads
+//     that task's counters; if the head is ready, compare-and-swap head -> head + 1; a failed swap returns the new head, whose readiness the
+//     look already knows, so the retry costs one round trip, not a new look (16 tiles that become ready together are out in ~16 round trips);
+//   * every other queue is taken EAGERLY: fetch-add on its head (no contention: a look of 4 dependent round trips between two swaps of one
+//     word was the whole dispatch rate of the first version, 1 task per 6 us for 456 workgroups) and the workgroup keeps the index as its
+//     PENDING task of that queue -- one per queue -- until the counters allow it; meanwhile it runs whatever else it holds or can take.
+// Of everything ready it takes the queue with the highest priority.  No workgroup ever waits holding a slot it could use otherwise, and the
+// globally first unfinished task is either somebody's pending task with its counters met, or at the head of a queue nobody holds a
+// pending task of: progress with any number of resident workgroups.
+__global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double gemm_lds[];
+    int* pick = reinterpret_cast<int*>(gemm_lds + FL_LDS_DOUBLES);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    unsigned* heads = g.flags + g.base_heads;
+    unsigned* err = g.flags + g.base_err;
+    // wave 0's lane roles
+    const int ncl = g.ncas * FL_LA, nlanes = ncl + (g.nq - g.ncas);
+    const bool is_cas = lane < ncl, is_eager = lane >= ncl && lane < nlanes;
+    const int myq = is_cas ? lane / FL_LA : (is_eager ? g.ncas + (lane - ncl) : 0), myk = is_cas ? lane % FL_LA : 0;
+    int qbase = 0, qsize = 0;
+    if (wave == 0 && lane < nlanes) { qbase = g.qmeta[2 * myq]; qsize = g.qmeta[2 * myq + 1]; }
+    int pend = -1;                    // eager lanes: the index (inside the queue) this workgroup holds
+    bool exhausted = false;           // eager lanes: the queue has nothing left to take
+    unsigned long long cas_heads = 0; // bit q * FL_LA for every compare-and-swap queue
+    for (int q = 0; q < g.ncas; ++q) cas_heads |= 1ull << (q * FL_LA);
+    const unsigned long long eager_mask = nlanes >= 64 ? ~0ull << ncl : ((1ull << nlanes) - 1ull) & ~((1ull << ncl) - 1ull);
+    unsigned idle = 0;
+    unsigned long long t_look = 0;
+    for (;;) {
+        if (g.trace && tid == 0) t_look = wall_clock64();
+        if (wave == 0) {
+            int res = -1;
+            unsigned nap = 0;
+            for (;;) {
+                int h = 0, idx = -1;
+                if (is_cas) {
+                    h = (int)__hip_atomic_load(heads + myq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    h = __shfl(h, lane - myk, 64);                             // one head value per queue
+                    idx = h + myk < qsize ? h + myk : -1;
+                } else if (is_eager) {
+                    idx = pend;
+                }
+                bool ready = false;
+                if (idx >= 0) {
+                    const FlowTask* t = g.tasks + qbase + idx;
+                    const int nd = t->ndep;
+                    ready = true;
+                    for (int d = 0; d < 4; ++d)
+                        if (d < nd && __hip_atomic_load(g.flags + t->dep[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)t->need[d])
+                            ready = false;
+                }
+                const unsigned long long mready = __ballot(ready);
+                const unsigned long long cand = mready & (cas_heads | eager_mask);
+                if (cand) {
+                    const int wl = __ffsll((long long)cand) - 1;               // lanes are in priority order
+                    int ok = 0;
+                    if (lane == wl) {
+                        if (is_cas) {
+                            unsigned cur = (unsigned)h;
+                            for (;;) {
+                                unsigned expect = cur;
+                                if (__hip_atomic_compare_exchange_strong(heads + myq, &expect, cur + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                         __HIP_MEMORY_SCOPE_AGENT)) { ok = 1; res = qbase + (int)cur; break; }
+                                cur = expect;                                  // somebody else moved the head: is the task it now points at one this look saw ready?
+                                const unsigned off = cur - (unsigned)h;
+                                if (off >= FL_LA || !((mready >> (lane + off)) & 1ull)) break;
+                            }
+                        } else {
+                            ok = 1; res = qbase + pend;
+                            // refill the slot at once (the answer is not needed before the next look) -- except near the end of the
+                            // queue, where a task held by a busy workgroup is a task an idle one cannot take
+                            if (pend + 2 * (int)gridDim.x < qsize) {
+                                const unsigned hh = __hip_atomic_fetch_add(heads + myq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (hh < (unsigned)qsize) pend = (int)hh; else { pend = -1; exhausted = true; }
+                            } else pend = -1;
+                        }
+                    }
+                    ok = __shfl(ok, wl, 64);
+                    res = __shfl(res, wl, 64);
+                    if (ok) break;
+                    continue;                                                  // the head ran away: look again
+                }
+                // nothing this workgroup holds or may take is ready: take what can be taken eagerly
+                bool took = false;
+                if (is_eager && pend < 0 && !exhausted) {
+                    const unsigned hh = __hip_atomic_fetch_add(heads + myq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (hh < (unsigned)qsize) { pend = (int)hh; took = true; } else exhausted = true;
+                }
+                const bool open = is_cas ? (myk == 0 && h < qsize) : (is_eager && (pend >= 0 || !exhausted));
+                if (!__ballot(open)) { res = -2; break; }                      // every queue is empty and nothing is held: done
+                if (__ballot(took)) continue;
+                nap = nap < 4u ? nap + 1u : 4u;                                // back off: idle workgroups must not crowd the memory system
+                for (unsigned z = 0; z < (1u << nap); ++z) __builtin_amdgcn_s_sleep(32);
+                if ((++idle & 15u) == 0u) {
+                    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { res = -3; break; }
+                    if (idle > FL_IDLE_LIMIT) {
+                        __hip_atomic_store(err, 0x700u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        res = -3;
+                        break;
+                    }
+                }
+            }
+            if (lane == 0) {
+                pick[0] = res;
+                if (res >= 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ONE buffer_inv sc1 behind the satisfied counters
+            }
+        }
+        __syncthreads();
+        const int ti = __builtin_amdgcn_readfirstlane(pick[0]);
+        if (ti < 0) {
+            if (ti == -3 && tid == 0) atomicMin(g.info, (unsigned long long)MOGP_INFO_CHAIN_TIMEOUT);
+            break;
+        }
+        idle = 0;
+        const FlowTask* tp = g.tasks + ti;
+        const int var = tp->var, kt = tp->kt;
+        const int ab = tp->abuf, bb = tp->bbuf, cb = tp->cbuf;
+        const double* Ab = ab == 0 ? g.bA : ab == 1 ? g.bL : ab == 2 ? g.bWt : ab == 3 ? g.bWm : g.bB;
+        const double* Bb = bb == 0 ? g.bA : bb == 1 ? g.bL : bb == 2 ? g.bWt : bb == 3 ? g.bWm : g.bB;
+        double* Cb = cb == 0 ? g.bA : cb == 1 ? g.bL : cb == 2 ? g.bWt : cb == 3 ? g.bWm : g.bB;
+        const double* Ap = Ab + ((int64_t)tp->ar * g.ld + tp->ac) * MOGP_TILE;
+        const double* Bp = Bb + ((int64_t)tp->br * g.ld + tp->bc) * MOGP_TILE;
+        double* Cp = Cb + ((int64_t)tp->cr * g.ld + tp->cc) * MOGP_TILE;
+        const bool fresh = (var & 4) != 0;
+        const double alpha = (var & 8) ? -1.0 : 1.0;
+        unsigned long long* tr = (g.trace && tid == 0) ? g.trace + FLOW_TRACE_W * (size_t)ti : nullptr;
+        if (tr) { tr[0] = t_look; tr[1] = wall_clock64(); }
+        if (var & 16) __builtin_amdgcn_s_setprio(2);
+        switch (var & 3) {
+            case 0: flow_tile<0, 0>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, tr); break;
+            case 1: flow_tile<0, 1>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, tr); break;
+            default: flow_tile<1, 1>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, tr); break;
+        }
+        if (var & 16) __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its own write-through stores
+        __syncthreads();                                           // ... and the tile's last LDS reads are behind us
+        if (tid == 0) {
+            const unsigned s0 = tp->sig[0], s1 = tp->sig[1];
+            if (s0 != FLOW_NOSIG) __hip_atomic_fetch_add(g.flags + s0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s1 != FLOW_NOSIG) __hip_atomic_fetch_add(g.flags + s1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tr) {
+                tr[4] = wall_clock64();
+                tr[5] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16) | blockIdx.x;
+            }
+        }
+    }
+}
+
+// ---- the task graph (host) ------------------------------------------------------------------------------------------------------------
+// Flag words.  S[i][j]: panel updates applied to Schur tile (i, j);  R[i][c]: the same summed over row i's tiles in column block c (i outside
+// that block);  DG[c]: summed over the diagonal block c;  PN[b][i]: tiles of panel row i of block b that exist;  CH[b]: workgroups of chain
+// kernel b that have finished;  WT[i][j]: versions of running-product tile (i, j);  WC[r][j]: the same summed over the tile rows of row block
+// r;  WF[b][j]: finished tile rows of W[b, j];  KV[i][j]: accumulations into inverse tile (i, j).
+namespace {
+enum { PH_CHAIN = 0, PH_T6 = 1, PH_PANEL = 2, PH_T7 = 3, PH_T8 = 4, PH_UPDATE = 5, PH_T9 = 6 };
+enum { Q_CRIT = 0, Q_LOOK2 = 1, Q_SEMI = 2, Q_INVCRIT = 3, Q_TRAIL = 4, Q_INV = 5, Q_ACC = 6 };
+enum { BUF_A = 0, BUF_L = 1, BUF_WT = 2, BUF_WM = 3, BUF_B = 4 };
+}
+
+void flow_build(int nb, int ob, FlowPlan& p) {
+    p = FlowPlan();
+    p.nb = nb; p.ob = ob;
+    const int no = (nb + ob - 1) / ob;
+    p.nouter = no; p.nq = FLOW_NQ;
+    const uint32_t base_S = 0, base_R = base_S + (uint32_t)nb * nb, base_DG = base_R + (uint32_t)nb * no, base_PN = base_DG + no,
+                   base_CH = base_PN + (uint32_t)no * nb, base_WT = base_CH + no, base_WC = base_WT + (uint32_t)nb * nb,
+                   base_WF = base_WC + (uint32_t)no * nb, base_KV = base_WF + (uint32_t)no * nb, base_end = base_KV + (uint32_t)nb * nb;
+    p.base_heads = (int)base_end; p.base_err = p.base_heads + FLOW_NQ; p.nflags = p.base_err + 1;
+    auto S = [&](int i, int j) { return base_S + (uint32_t)i * nb + j; };
+    auto R = [&](int i, int c) { return base_R + (uint32_t)i * no + c; };
+    auto DG = [&](int c) { return base_DG + (uint32_t)c; };
+    auto PN = [&](int b, int i) { return base_PN + (uint32_t)b * nb + i; };
+    auto CH = [&](int b) { return base_CH + (uint32_t)b; };
+    auto WT = [&](int i, int j) { return base_WT + (uint32_t)i * nb + j; };
+    auto WC = [&](int r, int j) { return base_WC + (uint32_t)r * nb + j; };
+    auto WF = [&](int b, int j) { return base_WF + (uint32_t)b * nb + j; };
+    auto KV = [&](int i, int j) { return base_KV + (uint32_t)i * nb + j; };
+    auto k0 = [&](int b) { return b * ob; };
+    auto k1 = [&](int b) { return std::min(nb, (b + 1) * ob); };
+    auto nk = [&](int b) { return k1(b) - k0(b); };
+    auto blk = [&](int i) { return i / ob; };
+    auto chain_wgs = [&](int b) { return nk(b) > 1 ? 13u : 2u; };          // chain.hip: CH_NWG workgroups, 2 for a one-tile block
+
+    std::vector<FlowTask> q[FLOW_NQ];
+    auto mk = [&](int b, int phase, int var, int kt) {
+        FlowTask t{};
+        t.var = (uint8_t)var; t.kt = (uint16_t)kt; t.ndep = 0; t.sig[0] = t.sig[1] = FLOW_NOSIG; t.key = (uint32_t)(b * 8 + phase);
+        return t;
+    };
+    auto dep = [&](FlowTask& t, uint32_t idx, unsigned need) {
+        if (need == 0) return;
+        t.dep[t.ndep] = idx; t.need[t.ndep] = (uint16_t)need; ++t.ndep;
+    };
+    auto opA = [](FlowTask& t, int buf, int r, int c) { t.abuf = (uint8_t)buf; t.ar = (uint16_t)r; t.ac = (uint16_t)c; };
+    auto opB = [](FlowTask& t, int buf, int r, int c) { t.bbuf = (uint8_t)buf; t.br = (uint16_t)r; t.bc = (uint16_t)c; };
+    auto opC = [](FlowTask& t, int buf, int r, int c) { t.cbuf = (uint8_t)buf; t.cr = (uint16_t)r; t.cc = (uint16_t)c; };
+    const int KB = MOGP_TILE / FL_BK;                 // k blocks per tile
+    double tiles_k = 0.0;                             // sum over tasks of k blocks
+
+    // panel tile (b, i, c): L[i][k0 + c] = sum_{cc <= c} A[i][k0 + cc] W_bb[c][cc]^T
+    auto panel = [&](int b, int i, int c, bool prio) {
+        FlowTask t = mk(b, PH_PANEL, 0 | 4 | (prio ? 16 : 0), KB * (c + 1));
+        opA(t, BUF_A, i, k0(b)); opB(t, BUF_WM, k0(b) + c, k0(b)); opC(t, BUF_L, i, k0(b) + c);
+        dep(t, CH(b), chain_wgs(b));
+        dep(t, R(i, b), (unsigned)(nk(b) * b));
+        t.sig[0] = PN(b, i);
+        tiles_k += t.kt;
+        return t;
+    };
+    // update (b, i, j): A[i][j] -= L[i][K] L[j][K]^T
+    auto update = [&](int b, int i, int j, bool prio) {
+        FlowTask t = mk(b, PH_UPDATE, 0 | 8 | (prio ? 16 : 0), KB * nk(b));
+        opA(t, BUF_L, i, k0(b)); opB(t, BUF_L, j, k0(b)); opC(t, BUF_A, i, j);
+        dep(t, PN(b, i), (unsigned)nk(b));
+        if (j != i) dep(t, PN(b, j), (unsigned)nk(b));
+        dep(t, S(i, j), (unsigned)b);
+        t.sig[0] = S(i, j);
+        t.sig[1] = blk(i) == blk(j) ? DG(blk(j)) : R(i, blk(j));
+        tiles_k += t.kt;
+        return t;
+    };
+    // T7 (b, i, c): Wt[i][k0 + c] = -L[i][K, from tile c on] W_bb[from tile row c on, tile column c]
+    auto t7 = [&](int b, int i, int c) {
+        FlowTask t = mk(b, PH_T7, 1 | 4 | 8, KB * (nk(b) - c));
+        opA(t, BUF_L, i, k0(b) + c); opB(t, BUF_WM, k0(b) + c, k0(b) + c); opC(t, BUF_WT, i, k0(b) + c);
+        dep(t, PN(b, i), (unsigned)nk(b));
+        t.sig[0] = WT(i, k0(b) + c); t.sig[1] = WC(blk(i), k0(b) + c);
+        tiles_k += t.kt;
+        return t;
+    };
+    // T8 (b, i, j): Wt[i][j] -= L[i][K] W[K][j]      (j < k0)
+    auto t8 = [&](int b, int i, int j) {
+        FlowTask t = mk(b, PH_T8, 1 | 8, KB * nk(b));
+        opA(t, BUF_L, i, k0(b)); opB(t, BUF_WM, k0(b), j); opC(t, BUF_WT, i, j);
+        dep(t, PN(b, i), (unsigned)nk(b));
+        dep(t, WF(b, j), (unsigned)nk(b));
+        dep(t, WT(i, j), (unsigned)(b - blk(j)));
+        t.sig[0] = WT(i, j); t.sig[1] = WC(blk(i), j);
+        tiles_k += t.kt;
+        return t;
+    };
+    // T6 (b, ti, j): W[k0 + ti][j] = sum_{tt <= ti} W_bb[ti][tt] Wt[k0 + tt][j]      (j < k0)
+    auto t6 = [&](int b, int ti, int j) {
+        FlowTask t = mk(b, PH_T6, 1 | 4, KB * (ti + 1));
+        opA(t, BUF_WM, k0(b) + ti, k0(b)); opB(t, BUF_WT, k0(b), j); opC(t, BUF_WM, k0(b) + ti, j);
+        dep(t, CH(b), chain_wgs(b));
+        dep(t, WC(b, j), (unsigned)(nk(b) * (b - blk(j))));
+        t.sig[0] = WF(b, j);
+        tiles_k += t.kt;
+        return t;
+    };
+    // T9 (b, i, j): B[i][j] (+)= W[K][i]^T W[K][j]      (j <= i < k1)
+    auto t9 = [&](int b, int i, int j) {
+        FlowTask t = mk(b, PH_T9, 2 | (i >= k0(b) ? 4 : 0), KB * nk(b));
+        opA(t, BUF_WM, k0(b), i); opB(t, BUF_WM, k0(b), j); opC(t, BUF_B, i, j);
+        bool ch = false;
+        if (i >= k0(b)) { dep(t, CH(b), chain_wgs(b)); ch = true; } else dep(t, WF(b, i), (unsigned)nk(b));
+        if (j != i) { if (j >= k0(b)) { if (!ch) dep(t, CH(b), chain_wgs(b)); } else dep(t, WF(b, j), (unsigned)nk(b)); }
+        dep(t, KV(i, j), (unsigned)(b - blk(i)));
+        t.sig[0] = KV(i, j);
+        tiles_k += t.kt;
+        return t;
+    };
+
+    p.chain.resize(no);
+    for (int b = 0; b < no; ++b) {
+        const int a0 = k1(b), a1 = std::min(nb, a0 + ob), a2 = std::min(nb, a1 + ob);        // rows of block b+1: [a0, a1), of block b+2: [a1, a2)
+        FlowPlan::Chain& c = p.chain[b];
+        c.wait_idx = DG(b); c.wait_val = (uint32_t)(nk(b) * (nk(b) + 1) / 2 * b); c.done_idx = CH(b); c.expect = chain_wgs(b);
+        // Q_CRIT: what chain(b + 1) waits for
+        for (int i = a0; i < a1; ++i) for (int cc = 0; cc < nk(b); ++cc) q[Q_CRIT].push_back(panel(b, i, cc, true));
+        for (int i = a0; i < a1; ++i) for (int j = a0; j <= i; ++j) q[Q_CRIT].push_back(update(b, i, j, true));
+        // Q_LOOK2: what the critical tasks of block b + 1 wait for
+        for (int i = a1; i < a2; ++i) for (int cc = 0; cc < nk(b); ++cc) q[Q_LOOK2].push_back(panel(b, i, cc, true));
+        for (int i = a1; i < a2; ++i) for (int j = a0; j < a1; ++j) q[Q_LOOK2].push_back(update(b, i, j, true));
+        for (int i = a1; i < a2; ++i) for (int j = a1; j <= i; ++j) q[Q_LOOK2].push_back(update(b, i, j, true));
+        // Q_SEMI: the rest of the panel, of the next block's columns and of the columns of the block after it
+        for (int i = a2; i < nb; ++i) for (int cc = 0; cc < nk(b); ++cc) q[Q_SEMI].push_back(panel(b, i, cc, false));
+        for (int i = a2; i < nb; ++i) for (int j = a0; j < a2; ++j) q[Q_SEMI].push_back(update(b, i, j, false));
+        // Q_TRAIL: everything to the right
+        for (int i = a2; i < nb; ++i) for (int j = a2; j <= i; ++j) q[Q_TRAIL].push_back(update(b, i, j, false));
+        // Q_INVCRIT: the serial cycle of the inverse: final row block b -> running product of the next block's rows
+        for (int j = 0; j < k0(b); ++j) for (int ti = 0; ti < nk(b); ++ti) q[Q_INVCRIT].push_back(t6(b, ti, j));
+        for (int i = a0; i < a1; ++i) for (int cc = 0; cc < nk(b); ++cc) q[Q_INVCRIT].push_back(t7(b, i, cc));
+        for (int i = a0; i < a1; ++i) for (int j = 0; j < k0(b); ++j) q[Q_INVCRIT].push_back(t8(b, i, j));
+        // Q_INV: the running product of the rows further down
+        for (int i = a1; i < nb; ++i) for (int cc = 0; cc < nk(b); ++cc) q[Q_INV].push_back(t7(b, i, cc));
+        for (int i = a1; i < nb; ++i) for (int j = 0; j < k0(b); ++j) q[Q_INV].push_back(t8(b, i, j));
+        // Q_ACC: the inverse itself
+        for (int i = 0; i < k1(b); ++i) for (int j = 0; j <= i; ++j) q[Q_ACC].push_back(t9(b, i, j));
+    }
+    for (int qi = 0; qi < FLOW_NQ; ++qi) {
+        p.qbase[qi] = (int)p.tasks.size(); p.qsize[qi] = (int)q[qi].size();
+        p.tasks.insert(p.tasks.end(), q[qi].begin(), q[qi].end());
+    }
+    p.flops = 2.0 * MOGP_TILE * MOGP_TILE * FL_BK * tiles_k;
+}
+
+// ---- the schedule -----------------------------------------------------------------------------------------------------------------------
+// MOGP_FLOW=0: the stream schedule of potri.hip everywhere.  MOGP_FLOW_MIN=n: the smallest number of 128-row tiles that takes the dataflow
+// form (below that an evaluation is a few chain kernels long and the launches it replaces are few).
+bool flow_enabled(const mogp_model* m, const Spd& w) {
+    const char* eo = std::getenv("MOGP_FLOW");                 // read per call: tests switch it inside one process
+    const char* en = std::getenv("MOGP_FLOW_MIN");
+    const int on = eo ? std::atoi(eo) : 1, nmin = en ? std::atoi(en) : 24;
+    if (!on || m->no_flow || !chain_enabled(m) || !m->ctx->st_priv) return false;
+    if (m->kinv_sparse && &w == &m->k) return false;          // a planned (partial) inverse: the stream schedule knows how
+    return w.nb >= nmin && w.nb <= 0xfff0;
+}
+
+int spd_potri_flow(mogp_model* m, Spd& w) {
+    const int nb = w.nb, ob = 4;
+    const int64_t ld = w.Npad;
+    int rc;
+    hipStream_t crit = m->st, priv = m->st_priv, bulk = m->st2;
+    if (w.Wm.n < (size_t)ld * ld) {                      // nothing ever writes above the block diagonal of W: keep it zero
+        if ((rc = w.Wm.ensure((size_t)ld * ld))) return rc;
+        HIP_TRY(hipMemsetAsync(w.Wm.p, 0, (size_t)ld * ld * sizeof(double), crit));
+    }
+    if ((rc = w.Lm.ensure((size_t)ld * ld))) return rc;
+    if ((rc = w.Wt.ensure((size_t)ld * ld))) return rc;
+    if (w.flow.nb != nb || w.flow.ob != ob) {
+        flow_build(nb, ob, w.flow);
+        if ((rc = w.flow_tasks.ensure(w.flow.tasks.size()))) return rc;
+        if ((rc = w.flow_qmeta.ensure(2 * FLOW_NQ))) return rc;
+        if ((rc = w.flow_flags.ensure((size_t)w.flow.nflags))) return rc;
+        int qm[2 * FLOW_NQ];
+        for (int q = 0; q < FLOW_NQ; ++q) { qm[2 * q] = w.flow.qbase[q]; qm[2 * q + 1] = w.flow.qsize[q]; }
+        HIP_TRY(dev_upload(w.flow_tasks.p, w.flow.tasks.data(), w.flow.tasks.size() * sizeof(FlowTask)));
+        HIP_TRY(dev_upload(w.flow_qmeta.p, qm, sizeof(qm)));
+    }
+    const FlowPlan& p = w.flow;
+    const int nouter = p.nouter;
+    if ((rc = w.chain_flags.ensure((size_t)(nouter + 1) * MOGP_CHAIN_FLAGS))) return rc;
+    HIP_TRY(hipMemsetAsync(w.chain_flags.p, 0, (size_t)(nouter + 1) * MOGP_CHAIN_FLAGS * sizeof(unsigned), crit));
+    HIP_TRY(hipMemsetAsync(w.flow_flags.p, 0, (size_t)p.nflags * sizeof(unsigned), crit));
+    static const bool want_trace = std::getenv("MOGP_FLOW_TRACE") && std::atoi(std::getenv("MOGP_FLOW_TRACE")) != 0;
+    if (want_trace) {
+        if ((rc = w.flow_trace.ensure(FLOW_TRACE_W * p.tasks.size() + 4 * (size_t)nouter))) return rc;
+        HIP_TRY(hipMemsetAsync(w.flow_trace.p, 0, w.flow_trace.n * sizeof(unsigned long long), crit));
+    }
+    while ((int)w.inv_ev.size() < 4) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        w.inv_ev.push_back(e);
+    }
+    hipEvent_t start = w.inv_ev[0], e_flow = w.inv_ev[1], e_chain = w.inv_ev[2];
+    HIP_TRY(hipEventRecord(start, crit));                // the Gram matrix is in place, every counter is zero
+    HIP_TRY(hipStreamWaitEvent(bulk, start, 0));
+    HIP_TRY(hipStreamWaitEvent(priv, start, 0));
+
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_flow), hipFuncAttributeMaxDynamicSharedMemorySize, FL_LDS_BYTES));
+        attr_set = true;
+    }
+    static const int wg_per_cu = std::getenv("MOGP_FLOW_WGS") ? std::max(1, std::atoi(std::getenv("MOGP_FLOW_WGS"))) : 2;
+    const int cus = (m->ctx->ncu > 0 ? m->ctx->ncu : 256) - m->ctx->ncu_reserved;
+    FlowArgs g{};
+    g.bA = w.A.p; g.bL = w.Lm.p; g.bWt = w.Wt.p; g.bWm = w.Wm.p; g.bB = w.B.p; g.ld = ld;
+    g.tasks = w.flow_tasks.p; g.qmeta = w.flow_qmeta.p; g.flags = w.flow_flags.p;
+    g.nq = p.nq; g.ncas = FLOW_NCAS; g.base_heads = p.base_heads; g.base_err = p.base_err; g.info = m->d_info.p;
+    g.trace = want_trace ? w.flow_trace.p : nullptr;
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    if (m->profiling) {
+        if (m->gemm_ev_used + 2 > m->gemm_ev.size())
+            for (int i = 0; i < 64; ++i) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); m->gemm_ev.push_back(e); }
+        pe0 = m->gemm_ev[m->gemm_ev_used++]; pe1 = m->gemm_ev[m->gemm_ev_used++];
+        HIP_TRY(hipEventRecord(pe0, bulk));
+    }
+    hipLaunchKernelGGL(k_flow, dim3(wg_per_cu * cus), dim3(FL_NT), FL_LDS_BYTES, bulk, g);
+    HIP_TRY(hipGetLastError());
+    if (pe1) HIP_TRY(hipEventRecord(pe1, bulk));
+    HIP_TRY(hipEventRecord(e_flow, bulk));
+    m->gemm_launches += 1;
+    m->gemm_flops += p.flops;
+
+    unsigned* ferr = w.flow_flags.p + p.base_err;        // ONE error word for both kernels: whoever times out first stops the other
+    for (int kb = 0; kb < nouter; ++kb) {
+        const int k0 = kb * ob, k1 = std::min(k0 + ob, nb);
+        ChainFlow cf{};
+        cf.wait_flag = p.chain[kb].wait_val ? w.flow_flags.p + p.chain[kb].wait_idx : nullptr; cf.wait_val = p.chain[kb].wait_val;
+        cf.done_flag = w.flow_flags.p + p.chain[kb].done_idx; cf.write_through = 1;
+        cf.trace = want_trace ? w.flow_trace.p + FLOW_TRACE_W * p.tasks.size() + 4 * (size_t)kb : nullptr;
+        if ((rc = launch_chain(w.A.p, ld, k0, k1 - k0, w.invd.p, w.logdet.p, m->d_info.p, 0, w.Wm.p + (int64_t)k0 * MOGP_TILE * (ld + 1), ld,
+                               w.chain_flags.p + (size_t)kb * MOGP_CHAIN_FLAGS, ferr, priv, &cf))) return rc;
+    }
+    HIP_TRY(hipEventRecord(e_chain, priv));
+    HIP_TRY(hipStreamWaitEvent(crit, e_flow, 0));
+    HIP_TRY(hipStreamWaitEvent(crit, e_chain, 0));
+    w.fused_last_inv = nullptr; w.fused_last_wt = nullptr;
+    w.flow_used = true;
+    m->flow_ran = true;
+    return 0;
+}
+
+}  // namespace mogp
+
+// the time stamps of the last dataflow evaluation of the exact system (MOGP_FLOW_TRACE=1): [FLOW_TRACE_W ntasks] (see FlowArgs::trace)
+// in the order of mogp_flow_plan's task rows, then [4 nouter] chain kernel launch, wait over, end, spare
+extern "C" int mogp_flow_trace(mogp_model* m, int64_t* out, int64_t cap, int64_t* count) {
+    if (!m || !count) return fail(MOGP_EINVAL, "mogp_flow_trace: null argument");
+    int rc;
+    if ((rc = use_device(m->ctx))) return rc;
+    const Spd& w = m->k;
+    *count = 0;
+    if (!w.flow_used || !w.flow_trace.p) return MOGP_OK;
+    const int64_t n = FLOW_TRACE_W * (int64_t)w.flow.tasks.size() + 4 * (int64_t)w.flow.nouter;
+    *count = n;
+    if (!out) return MOGP_OK;
+    if (cap < n) return fail(MOGP_EINVAL, "mogp_flow_trace: the output is too small");
+    HIP_TRY(hipStreamSynchronize(m->st));
+    HIP_TRY(hipMemcpy(out, w.flow_trace.p, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return MOGP_OK;
+}
+
+// ---- the plan as numbers: tests replay it on the CPU (no device work) ----------------------------------------------------------------
+extern "C" int mogp_flow_plan(int nb, int64_t* out, int64_t cap, int64_t* count) {
+    if (nb <= 0 || nb > 4096 || !count) return fail(MOGP_EINVAL, "mogp_flow_plan: bad argument");
+    FlowPlan p;
+    flow_build(nb, 4, p);
+    const int64_t W = 24, rows = (int64_t)p.tasks.size() + p.nouter;
+    *count = rows;
+    if (!out) return MOGP_OK;
+    if (cap < rows * W) return fail(MOGP_EINVAL, "mogp_flow_plan: the output holds fewer than 24 * count numbers");
+    int64_t* o = out;
+    for (int b = 0; b < p.nouter; ++b, o += W) {          // the chain kernels: queue -1
+        std::fill(o, o + W, 0);
+        const int k0 = b * 4, k1 = std::min(nb, k0 + 4);
+        o[0] = -1; o[1] = b * 8; o[2] = b; o[3] = k0; o[4] = k1 - k0; o[13] = p.chain[b].wait_val ? 1 : 0;
+        o[14] = p.chain[b].wait_idx; o[18] = p.chain[b].wait_val; o[22] = p.chain[b].done_idx; o[23] = p.chain[b].expect;
+    }
+    for (int q = 0; q < p.nq; ++q)
+        for (int k = 0; k < p.qsize[q]; ++k, o += W) {
+            const FlowTask& t = p.tasks[p.qbase[q] + k];
+            o[0] = q; o[1] = t.key; o[2] = t.abuf; o[3] = t.ar; o[4] = t.ac; o[5] = t.bbuf; o[6] = t.br; o[7] = t.bc;
+            o[8] = t.cbuf; o[9] = t.cr; o[10] = t.cc; o[11] = t.var; o[12] = t.kt; o[13] = t.ndep;
+            for (int d = 0; d < 4; ++d) { o[14 + d] = d < t.ndep ? t.dep[d] : 0; o[18 + d] = d < t.ndep ? t.need[d] : 0; }
+            o[22] = t.sig[0] == FLOW_NOSIG ? -1 : (int64_t)t.sig[0]; o[23] = t.sig[1] == FLOW_NOSIG ? -1 : (int64_t)t.sig[1];
+        }
+    return MOGP_OK;
+}

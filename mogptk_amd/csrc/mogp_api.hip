@@ -599,6 +599,13 @@ static int factorize_finish(mogp_model* m, const GramArgs& ga, double* lml, int6
 // Nothing is wrong with the data: drain the streams and repeat the evaluation on the launch-per-step chain, which this model keeps from now on.
 #define MOGP_RETRY_NO_CHAIN 0x7e7e
 namespace mogp { int chain_fallback(mogp_model* m) {
+    if (m->flow_ran && !m->no_flow) {            // the dataflow schedule (flow.hip) was on: drop IT first, the chain kernel stays
+        m->no_flow = true; m->flow_ran = false;
+        for (hipStream_t q : {m->st, m->st2, m->st3, m->st4, m->ctx->st5, m->st_priv}) if (q) HIP_TRY(hipStreamSynchronize(q));
+        static bool said_flow = false;
+        if (!said_flow) { said_flow = true; fprintf(stderr, "mogp: the dataflow kernel timed out (GPU shared with another process?); using the stream schedule\n"); }
+        return 0;
+    }
     if (m->no_chain) return fail(MOGP_EHIP, "chain kernel: a hand-off timed out although the model is on the launch-per-step chain");
     m->no_chain = true;
     for (hipStream_t q : {m->st, m->st2, m->st3, m->st4, m->ctx->st5, m->st_priv}) if (q) HIP_TRY(hipStreamSynchronize(q));

@@ -182,8 +182,44 @@ int launch_wkk(const double* Ablk, int64_t ld, const double* invd, int nk, doubl
 // err: one zeroed word per evaluation.  A hand-off that times out is reported as MOGP_INFO_CHAIN_TIMEOUT through *info.
 #define MOGP_CHAIN_FLAGS 32
 #define MOGP_INFO_CHAIN_TIMEOUT (1ull << 62)
+// flow (optional, flow.hip): the kernel first waits until *wait_flag >= wait_val (its diagonal block has received every update from the
+// dataflow kernel), stores W_KK write-through and every workgroup bumps *done_flag when it is through.
+struct ChainFlow {
+    unsigned* wait_flag; unsigned wait_val;
+    unsigned* done_flag;
+    int write_through;
+    unsigned long long* trace;         // optional [4]: launch, after the wait, end (100 MHz wall clock), spare
+};
 int launch_chain(double* A, int64_t ld, int t0, int nk, double* invd, double* logdet, unsigned long long* info, long long info_base,
-                 double* Wk, int64_t ldw, unsigned* flags, unsigned* err, hipStream_t s);
+                 double* Wk, int64_t ldw, unsigned* flags, unsigned* err, hipStream_t s, const ChainFlow* flow = nullptr);
+
+// ---- tile dataflow form of the fused factorisation + inversion (flow.hip) --------------------------------------------------------------
+#define FLOW_NQ 7
+#define FLOW_NCAS 2                    // the first queues (by priority) are taken ready-only by compare-and-swap, the others eagerly (flow.hip:k_flow)
+#define FLOW_TRACE_W 6
+#define FLOW_NOSIG 0xffffffffu
+struct FlowTask {                      // 64 bytes; static per matrix size
+    uint16_t ar, ac, br, bc, cr, cc;   // tile coordinates (row, column) of each operand's first element in its buffer
+    uint8_t abuf, bbuf, cbuf, var;     // buffers (0 A, 1 L, 2 Wt, 3 Wm, 4 B); var: bits 0-1 operand layout (0: both k-contiguous, 1: B k-major,
+                                       // 2: both k-major), bit 2: beta = 0, bit 3: alpha = -1, bit 4: raised wave priority
+    uint16_t kt, ndep;                 // 16-wide k blocks; dependencies
+    uint32_t dep[4];                   // counter index ...
+    uint16_t need[4];                  // ... and the value it must have reached
+    uint32_t sig[2];                   // counters bumped when the tile is stored (FLOW_NOSIG: none)
+    uint32_t key;                      // position in the sequential algorithm: 8 * block + phase (every dependency has a smaller key)
+    uint32_t pad[2];
+};
+static_assert(sizeof(FlowTask) == 64, "FlowTask layout");
+struct FlowPlan {
+    int nb = 0, ob = 0, nouter = 0, nq = 0;
+    std::vector<FlowTask> tasks;       // queue after queue, queues in priority order
+    int qbase[FLOW_NQ] = {0}, qsize[FLOW_NQ] = {0};
+    int nflags = 0, base_heads = 0, base_err = 0;
+    struct Chain { uint32_t wait_idx, wait_val, done_idx, expect; };
+    std::vector<Chain> chain;          // per outer block: what the chain kernel waits for and reports
+    double flops = 0.0;
+};
+void flow_build(int nb, int ob, FlowPlan& p);
 // rows >= N of the padded matrix: identity (lower part)
 int launch_pad_identity(double* A, int64_t ld, int64_t N, int64_t Npad, hipStream_t s);
 // z = W y (W lower triangular), and partial[blk] = sum z^2 over the block's rows

@@ -133,11 +133,20 @@ struct Spd {
     DevBuf<double> Wd;                  // W_KK = L_KK^-1 of every outer block of the fused schedule (512 x 512 each, wkk.hip)
     DevBuf<double> Pb[MOGP_NPANEL];     // rotating panel buffers L[>K, K] of the fused schedule (Npad x 512 each)
     DevBuf<unsigned> chain_flags;       // hand-off words of the persistent chain kernel (chain.hip): MOGP_CHAIN_FLAGS per outer block + the error word
+    // the dataflow form (flow.hip): panels at their natural position, the running product of the block-column inverses, the task graph
+    DevBuf<double> Lm, Wt;
+    FlowPlan flow;
+    DevBuf<FlowTask> flow_tasks;
+    DevBuf<int> flow_qmeta;
+    DevBuf<unsigned> flow_flags;
+    DevBuf<unsigned long long> flow_trace;
+    bool flow_used = false;             // the last fused factorisation + inversion of this workspace ran as dataflow
     void release() {
         for (auto& lv : levels) { lv.d1.release(); lv.d2.release(); }
         for (auto e : sync_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
         for (auto e : inv_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
         inv_ev.clear(); Wm.release(); Wd.release(); chain_flags.release(); for (auto& b : Pb) b.release();
+        Lm.release(); Wt.release(); flow_tasks.release(); flow_qmeta.release(); flow_flags.release(); flow_trace.release(); flow = FlowPlan();
         levels.clear(); sync_ev.clear();
         A.release(); B.release(); invd.release(); logdet.release();
     }
@@ -265,6 +274,8 @@ struct mogp_model {
     int64_t gemm_launches = 0;
     double gemm_flops = 0.0;
     bool have_W = false, have_Kinv = false, kinv_in_A = false, w_in_Wm = false;
+    bool flow_ran = false;              // some factorisation of this model has used the dataflow schedule since the last fallback
+    bool no_flow = false;               // the dataflow kernel timed out once on this model: stream schedule from now on
     bool no_chain = false;              // the persistent chain kernel timed out once on this model (another process's chain kernel held the reserved CUs): launch-per-step chain from now on
     TitsiasWork* tw = nullptr;
     OaWork oa;
@@ -309,6 +320,8 @@ int mm_lower_splitk(mogp_model* m, TitsiasWork& t, const double* A, const double
 int ensure_system(mogp_model* m);     // the N x N system of the exact / OA paths and the tile lists over (X, X), on first use (mogp_api.hip)
 int spd_potrf(mogp_model* m, Spd& w, long long info_base = 0);
 int spd_potri_fused(mogp_model* m, Spd& w);
+bool flow_enabled(const mogp_model* m, const Spd& w);   // flow.hip
+int spd_potri_flow(mogp_model* m, Spd& w);             // flow.hip: the same result as spd_potri_fused, as tile dataflow
 int spd_potri_fused_finish(mogp_model* m, Spd& w);   // joins the inverse stream: call before reading w.B   // potri.hip: w.A (SPD, lower) -> w.Wm = L^-1, w.B = inverse (lower); w.logdet per tile
 int spd_trtri(mogp_model* m, Spd& w);
 int spd_lauum(mogp_model* m, Spd& w);

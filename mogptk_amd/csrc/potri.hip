@@ -142,6 +142,8 @@ int inverse_step(mogp_model* m, Spd& w, const double* Wkk, int k0, int k1, const
 namespace mogp {
 
 int spd_potri_fused(mogp_model* m, Spd& w) {
+    w.flow_used = false;
+    if (flow_enabled(m, w)) return spd_potri_flow(m, w);           // flow.hip: the same tile products as one resident dataflow kernel
     const int nb = w.nb;
     const int64_t ld = w.Npad;
     const int nouter = (nb + FZ_OB - 1) / FZ_OB;
