@@ -330,8 +330,11 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
 // kernel b that have finished;  WT[i][j]: versions of running-product tile (i, j);  WC[r][j]: the same summed over the tile rows of row block
 // r;  WF[b][j]: finished tile rows of W[b, j];  KV[i][j]: accumulations into inverse tile (i, j).
 namespace {
-enum { PH_CHAIN = 0, PH_T6 = 1, PH_PANEL = 2, PH_T7 = 3, PH_T8 = 4, PH_UPDATE = 5, PH_T9 = 6 };
-enum { Q_CRIT = 0, Q_LOOK2 = 1, Q_SEMI = 2, Q_INVCRIT = 3, Q_TRAIL = 4, Q_INV = 5, Q_ACC = 6 };
+// The sequential algorithm the keys follow: superstep r = [ the running product's updates INTO row block r, by source block b' < r (T7 / T8:
+// left-looking on the inverse side, so that nothing of it is due before its row block is) | chain(r) | T6(r): the final row block r of W |
+// panel(r) | update(r) (right-looking on the Schur side) | T9(r) ].  key = FLOW_KEY_STEP r + position inside the superstep.
+enum { PH_INTO = 0, PH_CHAIN = 600, PH_T6 = 601, PH_PANEL = 602, PH_UPDATE = 603, PH_T9 = 604 };
+enum { Q_CRIT = 0, Q_LOOK2 = 1, Q_INVCRIT = 2, Q_SEMI = 3, Q_FIRST_DEADLINE = 4 };
 enum { BUF_A = 0, BUF_L = 1, BUF_WT = 2, BUF_WM = 3, BUF_B = 4 };
 }
 
@@ -339,11 +342,11 @@ void flow_build(int nb, int ob, FlowPlan& p) {
     p = FlowPlan();
     p.nb = nb; p.ob = ob;
     const int no = (nb + ob - 1) / ob;
-    p.nouter = no; p.nq = FLOW_NQ;
+    p.nouter = no;
     const uint32_t base_S = 0, base_R = base_S + (uint32_t)nb * nb, base_DG = base_R + (uint32_t)nb * no, base_PN = base_DG + no,
                    base_CH = base_PN + (uint32_t)no * nb, base_WT = base_CH + no, base_WC = base_WT + (uint32_t)nb * nb,
                    base_WF = base_WC + (uint32_t)no * nb, base_KV = base_WF + (uint32_t)no * nb, base_end = base_KV + (uint32_t)nb * nb;
-    p.base_heads = (int)base_end; p.base_err = p.base_heads + FLOW_NQ; p.nflags = p.base_err + 1;
+    p.base_heads = (int)base_end; p.base_err = p.base_heads + FLOW_MAXQ; p.nflags = p.base_err + 1;
     auto S = [&](int i, int j) { return base_S + (uint32_t)i * nb + j; };
     auto R = [&](int i, int c) { return base_R + (uint32_t)i * no + c; };
     auto DG = [&](int c) { return base_DG + (uint32_t)c; };
@@ -359,10 +362,14 @@ void flow_build(int nb, int ob, FlowPlan& p) {
     auto blk = [&](int i) { return i / ob; };
     auto chain_wgs = [&](int b) { return nk(b) > 1 ? 13u : 2u; };          // chain.hip: CH_NWG workgroups, 2 for a one-tile block
 
-    std::vector<FlowTask> q[FLOW_NQ];
+    // queues 0 .. 3 as named above; then, by the superstep d that needs them (earliest deadline first): INTO[d] = the running product's updates
+    // into row block d from the source blocks <= d - 2, and TRAIL[d - 3] = the trailing update of panel d - 3 right of its two look-ahead
+    // column blocks (its first columns are block d's); last the accumulations of the inverse, which nothing waits for.
+    std::vector<FlowTask> q[4], acc;
+    std::vector<std::vector<FlowTask>> into(no), trail(no);
     auto mk = [&](int b, int phase, int var, int kt) {
         FlowTask t{};
-        t.var = (uint8_t)var; t.kt = (uint16_t)kt; t.ndep = 0; t.sig[0] = t.sig[1] = FLOW_NOSIG; t.key = (uint32_t)(b * 8 + phase);
+        t.var = (uint8_t)var; t.kt = (uint16_t)kt; t.ndep = 0; t.sig[0] = t.sig[1] = FLOW_NOSIG; t.key = (uint32_t)(b * FLOW_KEY_STEP + phase);
         return t;
     };
     auto dep = [&](FlowTask& t, uint32_t idx, unsigned need) {
@@ -399,7 +406,7 @@ void flow_build(int nb, int ob, FlowPlan& p) {
     };
     // T7 (b, i, c): Wt[i][k0 + c] = -L[i][K, from tile c on] W_bb[from tile row c on, tile column c]
     auto t7 = [&](int b, int i, int c) {
-        FlowTask t = mk(b, PH_T7, 1 | 4 | 8, KB * (nk(b) - c));
+        FlowTask t = mk(blk(i), PH_INTO + 2 * b, 1 | 4 | 8, KB * (nk(b) - c));
         opA(t, BUF_L, i, k0(b) + c); opB(t, BUF_WM, k0(b) + c, k0(b) + c); opC(t, BUF_WT, i, k0(b) + c);
         dep(t, PN(b, i), (unsigned)nk(b));
         t.sig[0] = WT(i, k0(b) + c); t.sig[1] = WC(blk(i), k0(b) + c);
@@ -408,7 +415,7 @@ void flow_build(int nb, int ob, FlowPlan& p) {
     };
     // T8 (b, i, j): Wt[i][j] -= L[i][K] W[K][j]      (j < k0)
     auto t8 = [&](int b, int i, int j) {
-        FlowTask t = mk(b, PH_T8, 1 | 8, KB * nk(b));
+        FlowTask t = mk(blk(i), PH_INTO + 2 * b + 1, 1 | 8, KB * nk(b));
         opA(t, BUF_L, i, k0(b)); opB(t, BUF_WM, k0(b), j); opC(t, BUF_WT, i, j);
         dep(t, PN(b, i), (unsigned)nk(b));
         dep(t, WF(b, j), (unsigned)nk(b));
@@ -455,21 +462,39 @@ void flow_build(int nb, int ob, FlowPlan& p) {
         // Q_SEMI: the rest of the panel, of the next block's columns and of the columns of the block after it
         for (int i = a2; i < nb; ++i) for (int cc = 0; cc < nk(b); ++cc) q[Q_SEMI].push_back(panel(b, i, cc, false));
         for (int i = a2; i < nb; ++i) for (int j = a0; j < a2; ++j) q[Q_SEMI].push_back(update(b, i, j, false));
-        // Q_TRAIL: everything to the right
-        for (int i = a2; i < nb; ++i) for (int j = a2; j <= i; ++j) q[Q_TRAIL].push_back(update(b, i, j, false));
+        // TRAIL[b]: everything to the right
+        for (int i = a2; i < nb; ++i) for (int j = a2; j <= i; ++j) trail[b].push_back(update(b, i, j, false));
         // Q_INVCRIT: the serial cycle of the inverse: final row block b -> running product of the next block's rows
         for (int j = 0; j < k0(b); ++j) for (int ti = 0; ti < nk(b); ++ti) q[Q_INVCRIT].push_back(t6(b, ti, j));
         for (int i = a0; i < a1; ++i) for (int cc = 0; cc < nk(b); ++cc) q[Q_INVCRIT].push_back(t7(b, i, cc));
         for (int i = a0; i < a1; ++i) for (int j = 0; j < k0(b); ++j) q[Q_INVCRIT].push_back(t8(b, i, j));
-        // Q_INV: the running product of the rows further down
-        for (int i = a1; i < nb; ++i) for (int cc = 0; cc < nk(b); ++cc) q[Q_INV].push_back(t7(b, i, cc));
-        for (int i = a1; i < nb; ++i) for (int j = 0; j < k0(b); ++j) q[Q_INV].push_back(t8(b, i, j));
-        // Q_ACC: the inverse itself
-        for (int i = 0; i < k1(b); ++i) for (int j = 0; j <= i; ++j) q[Q_ACC].push_back(t9(b, i, j));
+        // INTO[b]: the running product of row block b from the source blocks b' <= b - 2 (the last one, b' = b - 1, is on the serial cycle above)
+        for (int bs = 0; bs + 2 <= b; ++bs) {
+            for (int i = k0(b); i < k1(b); ++i) for (int cc = 0; cc < nk(bs); ++cc) into[b].push_back(t7(bs, i, cc));
+            for (int i = k0(b); i < k1(b); ++i) for (int j = 0; j < k0(bs); ++j) into[b].push_back(t8(bs, i, j));
+        }
+        for (int i = 0; i < k1(b); ++i) for (int j = 0; j <= i; ++j) acc.push_back(t9(b, i, j));
     }
-    for (int qi = 0; qi < FLOW_NQ; ++qi) {
-        p.qbase[qi] = (int)p.tasks.size(); p.qsize[qi] = (int)q[qi].size();
-        p.tasks.insert(p.tasks.end(), q[qi].begin(), q[qi].end());
+    std::vector<const std::vector<FlowTask>*> order = {&q[0], &q[1], &q[2], &q[3]};
+    for (int d = 2; d < no + 3; ++d) {
+        if (d < no && !into[d].empty()) order.push_back(&into[d]);
+        if (d - 3 >= 0 && d - 3 < no && !trail[d - 3].empty()) order.push_back(&trail[d - 3]);
+    }
+    order.push_back(&acc);
+    if ((int)order.size() > FLOW_MAXQ) {          // (not reached for the sizes the fused schedule serves, nb <= 80: 2 no + 2 queues) fold the farthest deadlines into one queue
+        std::vector<FlowTask> rest;
+        // merged in superstep order so that the folded queue stays sorted by key
+        std::vector<const std::vector<FlowTask>*> tail(order.begin() + (FLOW_MAXQ - 2), order.end() - 1);
+        for (auto* v : tail) rest.insert(rest.end(), v->begin(), v->end());
+        std::stable_sort(rest.begin(), rest.end(), [](const FlowTask& x, const FlowTask& y) { return x.key < y.key; });
+        p.folded = rest;
+        order.erase(order.begin() + (FLOW_MAXQ - 2), order.end() - 1);
+        order.insert(order.end() - 1, &p.folded);
+    }
+    p.nq = (int)order.size();
+    for (int qi = 0; qi < p.nq; ++qi) {
+        p.qbase[qi] = (int)p.tasks.size(); p.qsize[qi] = (int)order[qi]->size();
+        p.tasks.insert(p.tasks.end(), order[qi]->begin(), order[qi]->end());
     }
     p.flops = 2.0 * MOGP_TILE * MOGP_TILE * FL_BK * tiles_k;
 }
@@ -500,10 +525,10 @@ int spd_potri_flow(mogp_model* m, Spd& w) {
     if (w.flow.nb != nb || w.flow.ob != ob) {
         flow_build(nb, ob, w.flow);
         if ((rc = w.flow_tasks.ensure(w.flow.tasks.size()))) return rc;
-        if ((rc = w.flow_qmeta.ensure(2 * FLOW_NQ))) return rc;
+        if ((rc = w.flow_qmeta.ensure(2 * FLOW_MAXQ))) return rc;
         if ((rc = w.flow_flags.ensure((size_t)w.flow.nflags))) return rc;
-        int qm[2 * FLOW_NQ];
-        for (int q = 0; q < FLOW_NQ; ++q) { qm[2 * q] = w.flow.qbase[q]; qm[2 * q + 1] = w.flow.qsize[q]; }
+        int qm[2 * FLOW_MAXQ] = {0};
+        for (int q = 0; q < w.flow.nq; ++q) { qm[2 * q] = w.flow.qbase[q]; qm[2 * q + 1] = w.flow.qsize[q]; }
         HIP_TRY(dev_upload(w.flow_tasks.p, w.flow.tasks.data(), w.flow.tasks.size() * sizeof(FlowTask)));
         HIP_TRY(dev_upload(w.flow_qmeta.p, qm, sizeof(qm)));
     }
@@ -605,7 +630,7 @@ extern "C" int mogp_flow_plan(int nb, int64_t* out, int64_t cap, int64_t* count)
     for (int b = 0; b < p.nouter; ++b, o += W) {          // the chain kernels: queue -1
         std::fill(o, o + W, 0);
         const int k0 = b * 4, k1 = std::min(nb, k0 + 4);
-        o[0] = -1; o[1] = b * 8; o[2] = b; o[3] = k0; o[4] = k1 - k0; o[13] = p.chain[b].wait_val ? 1 : 0;
+        o[0] = -1; o[1] = (int64_t)b * FLOW_KEY_STEP + PH_CHAIN; o[2] = b; o[3] = k0; o[4] = k1 - k0; o[13] = p.chain[b].wait_val ? 1 : 0;
         o[14] = p.chain[b].wait_idx; o[18] = p.chain[b].wait_val; o[22] = p.chain[b].done_idx; o[23] = p.chain[b].expect;
     }
     for (int q = 0; q < p.nq; ++q)

@@ -194,9 +194,10 @@ int launch_chain(double* A, int64_t ld, int t0, int nk, double* invd, double* lo
                  double* Wk, int64_t ldw, unsigned* flags, unsigned* err, hipStream_t s, const ChainFlow* flow = nullptr);
 
 // ---- tile dataflow form of the fused factorisation + inversion (flow.hip) --------------------------------------------------------------
-#define FLOW_NQ 7
+#define FLOW_MAXQ 48                   // queues of a plan at most: 2 * 8 compare-and-swap lanes + one lane per other queue fit one wave
 #define FLOW_NCAS 2                    // the first queues (by priority) are taken ready-only by compare-and-swap, the others eagerly (flow.hip:k_flow)
 #define FLOW_TRACE_W 6
+#define FLOW_KEY_STEP 1024             // FlowTask::key = FLOW_KEY_STEP * superstep + position inside it
 #define FLOW_NOSIG 0xffffffffu
 struct FlowTask {                      // 64 bytes; static per matrix size
     uint16_t ar, ac, br, bc, cr, cc;   // tile coordinates (row, column) of each operand's first element in its buffer
@@ -206,14 +207,15 @@ struct FlowTask {                      // 64 bytes; static per matrix size
     uint32_t dep[4];                   // counter index ...
     uint16_t need[4];                  // ... and the value it must have reached
     uint32_t sig[2];                   // counters bumped when the tile is stored (FLOW_NOSIG: none)
-    uint32_t key;                      // position in the sequential algorithm: 8 * block + phase (every dependency has a smaller key)
+    uint32_t key;                      // position in the sequential algorithm (every dependency has a smaller key; every queue is sorted by it)
     uint32_t pad[2];
 };
 static_assert(sizeof(FlowTask) == 64, "FlowTask layout");
 struct FlowPlan {
     int nb = 0, ob = 0, nouter = 0, nq = 0;
     std::vector<FlowTask> tasks;       // queue after queue, queues in priority order
-    int qbase[FLOW_NQ] = {0}, qsize[FLOW_NQ] = {0};
+    std::vector<FlowTask> folded;      // (scratch of flow_build)
+    int qbase[FLOW_MAXQ] = {0}, qsize[FLOW_MAXQ] = {0};
     int nflags = 0, base_heads = 0, base_err = 0;
     struct Chain { uint32_t wait_idx, wait_val, done_idx, expect; };
     std::vector<Chain> chain;          // per outer block: what the chain kernel waits for and reports

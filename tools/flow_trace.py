@@ -9,7 +9,7 @@ os.environ.setdefault("MOGP_GRAD_PATH", "fused")
 import numpy as np
 from mogptk_amd import gpr, synth, _lib
 
-QN = ["crit", "look2", "semi", "invcrit", "trail", "inv", "acc"]
+QN = ["crit", "look2", "invcrit", "semi"]
 
 
 def main():
@@ -52,7 +52,16 @@ def main():
     full = tasks[:, 12] == 32
     print("full-K tiles only:  looking %.1f | prologue %.1f | k loop %.1f | epilogue %.1f"
           % ((st - look)[full].mean(), (k0 - st)[full].mean(), (k1 - k0)[full].mean(), (en - k1)[full].mean()))
-    blk = tasks[:, 1] // 8
+    blk = tasks[:, 1] // 1024
+    # queues 4 .. : INTO[d] / TRAIL[d - 3] by deadline, the last one the accumulations: fold them into three report classes
+    nq = int(tasks[:, 0].max()) + 1
+    cls = tasks[:, 0].copy()
+    rest = tasks[:, 0] >= 4
+    cls[rest & (tasks[:, 8] == 2)] = 4
+    cls[rest & (tasks[:, 8] == 0)] = 5
+    cls[tasks[:, 0] == nq - 1] = 6
+    tasks = tasks.copy(); tasks[:, 0] = cls
+    QN.extend(["into", "trail", "acc"])
     print("dataflow evaluation N=%d (nb=%d tiles, %d outer blocks): %d tile tasks, %d workgroups seen; times in us from the first chain launch"
           % (X.shape[0], nb, no, nt, len(np.unique(wg))))
     print("end of the last task %.0f us; chain kernels end %.0f us" % (en.max(), us(ch[-1, 2])))
