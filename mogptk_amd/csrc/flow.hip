@@ -167,9 +167,71 @@ struct FlowArgs {
     const int* qmeta;                 // [2 nq]: first task, number of tasks of every queue
     unsigned* flags;                  // dependency counters, then the queue heads, then the error word (all zero at the start of an evaluation)
     int nq, ncas, base_heads, base_err;
+    unsigned nap_max;                 // an idle workgroup sleeps 2^1 .. 2^nap_max microseconds between looks
+    const double* vy; double* vz; double* vzz; double* vpart;         // z = W y and alpha = W^T z as tasks (null: those tasks only count)
+    int64_t npad;
     unsigned long long* info;
     unsigned long long* trace;        // optional: [FLOW_TRACE_W ntasks] look, claimed, k loop from, to, signalled (100 MHz wall clock), XCC << 16 | workgroup
 };
+
+// ---- z = W y and alpha = W^T z inside the dataflow (they were three memory-bound launches behind the last accumulation: 0.4 ms) ----------
+// z rows: tile row i of W is final when its row block's T6 tasks are; one task = the 128 dot products of that tile row (a wave takes 16 rows,
+// four at a time, lanes along k with 16-byte loads).  zz[i] = sum of the 128 z^2 (the caller adds the tile rows up).
+__device__ __forceinline__ void flow_zrow(const FlowArgs& g, const int i, double* lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = (i + 1) * MOGP_TILE;
+    const double* Wr = g.bWm + (int64_t)(i * MOGP_TILE + wave * 16) * g.ld + 2 * lane;
+    const double* yp = g.vy + 2 * lane;
+    double zsq = 0.0;
+    for (int r4 = 0; r4 < 16; r4 += 4) {
+        const double* p0 = Wr + (int64_t)r4 * g.ld;
+        d2_t a0 = (d2_t){0.0, 0.0}, a1 = a0, a2 = a0, a3 = a0;
+#pragma unroll 2
+        for (int k = 0; k < K; k += MOGP_TILE) {
+            const d2_t yv = *reinterpret_cast<const d2_t*>(yp + k);
+            const d2_t w0 = *reinterpret_cast<const d2_t*>(p0 + k);
+            const d2_t w1 = *reinterpret_cast<const d2_t*>(p0 + g.ld + k);
+            const d2_t w2 = *reinterpret_cast<const d2_t*>(p0 + 2 * g.ld + k);
+            const d2_t w3 = *reinterpret_cast<const d2_t*>(p0 + 3 * g.ld + k);
+            a0 += w0 * yv; a1 += w1 * yv; a2 += w2 * yv; a3 += w3 * yv;
+        }
+        double s[4] = {a0[0] + a0[1], a1[0] + a1[1], a2[0] + a2[1], a3[0] + a3[1]};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s[u] += __shfl_down(s[u], off, 64);
+            if (lane == 0) {
+                __hip_atomic_store(g.vz + (int64_t)i * MOGP_TILE + wave * 16 + r4 + u, s[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                zsq += s[u] * s[u];
+            }
+        }
+    }
+    if (lane == 0) lds[wave] = zsq;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < FL_NT / 64; ++w) t += lds[w];
+        __hip_atomic_store(g.vzz + i, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// alpha, one row block at a time: part[r][col] = sum over the rows of block r of W[row][col] z[row], a thread per column, 512 columns per task
+// (the entries of W above its diagonal are zeros: no triangle logic).  alpha[col] = sum_r part[r][col] is taken by k_alpha_sum afterwards.
+__device__ __forceinline__ void flow_apart(const FlowArgs& g, const int r0, const int nrows, const int rblk, const int jg, double* lds) {
+    const int tid = threadIdx.x;
+    if (tid < nrows) lds[tid] = g.vz[r0 + tid];              // vector loads: z came from other workgroups of this launch
+    __syncthreads();
+    const int64_t col = (int64_t)jg * FL_NT + tid;
+    if (col < g.npad) {
+        const double* Wc = g.bWm + (int64_t)r0 * g.ld + col;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+        for (int r = 0; r < nrows; r += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = fma(Wc[(int64_t)(r + u) * g.ld], lds[r + u], a[u]);
+        }
+        __hip_atomic_store(g.vpart + (int64_t)rblk * g.npad + col, (a[0] + a[1]) + (a[2] + a[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 #define FL_IDLE_LIMIT 60000u          // idle looks (1 .. 16 us apart) before a workgroup gives up (the chain's own waits give up after ~0.2 s)
 #define FL_LA 8                       // positions behind the head of a compare-and-swap queue whose readiness a look already knows
@@ -202,13 +264,14 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
     unsigned long long cas_heads = 0; // bit q * FL_LA for every compare-and-swap queue
     for (int q = 0; q < g.ncas; ++q) cas_heads |= 1ull << (q * FL_LA);
     const unsigned long long eager_mask = nlanes >= 64 ? ~0ull << ncl : ((1ull << nlanes) - 1ull) & ~((1ull << ncl) - 1ull);
-    unsigned idle = 0;
+    unsigned idle = 0, naps = 0;
     unsigned long long t_look = 0;
     for (;;) {
         if (g.trace && tid == 0) t_look = wall_clock64();
         if (wave == 0) {
             int res = -1;
             unsigned nap = 0;
+            naps = 0;
             for (;;) {
                 int h = 0, idx = -1;
                 if (is_cas) {
@@ -267,8 +330,9 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                 const bool open = is_cas ? (myk == 0 && h < qsize) : (is_eager && (pend >= 0 || !exhausted));
                 if (!__ballot(open)) { res = -2; break; }                      // every queue is empty and nothing is held: done
                 if (__ballot(took)) continue;
-                nap = nap < 4u ? nap + 1u : 4u;                                // back off: idle workgroups must not crowd the memory system
+                nap = nap < g.nap_max ? nap + 1u : g.nap_max;                  // back off: idle workgroups must not crowd the memory system
                 for (unsigned z = 0; z < (1u << nap); ++z) __builtin_amdgcn_s_sleep(32);
+                ++naps;
                 if ((++idle & 15u) == 0u) {
                     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { res = -3; break; }
                     if (idle > FL_IDLE_LIMIT) {
@@ -303,6 +367,12 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
         const double alpha = (var & 8) ? -1.0 : 1.0;
         unsigned long long* tr = (g.trace && tid == 0) ? g.trace + FLOW_TRACE_W * (size_t)ti : nullptr;
         if (tr) { tr[0] = t_look; tr[1] = wall_clock64(); }
+        if (var & 32) {                                            // vector task: tile row ar (z) or row block ar .. ar + kt - 1, column group ac (alpha)
+            if (g.vy) {
+                if (var & 1) flow_apart(g, tp->ar * MOGP_TILE, kt * MOGP_TILE, tp->br, tp->ac, gemm_lds);
+                else flow_zrow(g, tp->ar, gemm_lds);
+            }
+        } else {
         if (var & 16) __builtin_amdgcn_s_setprio(2);
         switch (var & 3) {
             case 0: flow_tile<0, 0>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, tr); break;
@@ -310,6 +380,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
             default: flow_tile<1, 1>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, tr); break;
         }
         if (var & 16) __builtin_amdgcn_s_setprio(0);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its own write-through stores
         __syncthreads();                                           // ... and the tile's last LDS reads are behind us
         if (tid == 0) {
@@ -318,7 +389,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
             if (s1 != FLOW_NOSIG) __hip_atomic_fetch_add(g.flags + s1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (tr) {
                 tr[4] = wall_clock64();
-                tr[5] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16) | blockIdx.x;
+                tr[5] = ((unsigned long long)naps << 32) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16) | blockIdx.x;
             }
         }
     }
@@ -333,7 +404,7 @@ namespace {
 // The sequential algorithm the keys follow: superstep r = [ the running product's updates INTO row block r, by source block b' < r (T7 / T8:
 // left-looking on the inverse side, so that nothing of it is due before its row block is) | chain(r) | T6(r): the final row block r of W |
 // panel(r) | update(r) (right-looking on the Schur side) | T9(r) ].  key = FLOW_KEY_STEP r + position inside the superstep.
-enum { PH_INTO = 0, PH_CHAIN = 600, PH_T6 = 601, PH_PANEL = 602, PH_UPDATE = 603, PH_T9 = 604 };
+enum { PH_INTO = 0, PH_CHAIN = 600, PH_T6 = 601, PH_PANEL = 602, PH_UPDATE = 603, PH_T9 = 604, PH_ZROW = 605, PH_APART = 606 };
 enum { Q_CRIT = 0, Q_LOOK2 = 1, Q_INVCRIT = 2, Q_SEMI = 3, Q_FIRST_DEADLINE = 4 };
 enum { BUF_A = 0, BUF_L = 1, BUF_WT = 2, BUF_WM = 3, BUF_B = 4 };
 }
@@ -345,7 +416,8 @@ void flow_build(int nb, int ob, FlowPlan& p) {
     p.nouter = no;
     const uint32_t base_S = 0, base_R = base_S + (uint32_t)nb * nb, base_DG = base_R + (uint32_t)nb * no, base_PN = base_DG + no,
                    base_CH = base_PN + (uint32_t)no * nb, base_WT = base_CH + no, base_WC = base_WT + (uint32_t)nb * nb,
-                   base_WF = base_WC + (uint32_t)no * nb, base_KV = base_WF + (uint32_t)no * nb, base_end = base_KV + (uint32_t)nb * nb;
+                   base_WF = base_WC + (uint32_t)no * nb, base_KV = base_WF + (uint32_t)no * nb, base_WR = base_KV + (uint32_t)nb * nb,
+                   base_ZR = base_WR + no, base_end = base_ZR + no;
     p.base_heads = (int)base_end; p.base_err = p.base_heads + FLOW_MAXQ; p.nflags = p.base_err + 1;
     auto S = [&](int i, int j) { return base_S + (uint32_t)i * nb + j; };
     auto R = [&](int i, int c) { return base_R + (uint32_t)i * no + c; };
@@ -356,6 +428,8 @@ void flow_build(int nb, int ob, FlowPlan& p) {
     auto WC = [&](int r, int j) { return base_WC + (uint32_t)r * nb + j; };
     auto WF = [&](int b, int j) { return base_WF + (uint32_t)b * nb + j; };
     auto KV = [&](int i, int j) { return base_KV + (uint32_t)i * nb + j; };
+    auto WR = [&](int b) { return base_WR + (uint32_t)b; };          // finished T6 tasks of row block b
+    auto ZR = [&](int b) { return base_ZR + (uint32_t)b; };          // finished z tile rows of row block b
     auto k0 = [&](int b) { return b * ob; };
     auto k1 = [&](int b) { return std::min(nb, (b + 1) * ob); };
     auto nk = [&](int b) { return k1(b) - k0(b); };
@@ -365,7 +439,7 @@ void flow_build(int nb, int ob, FlowPlan& p) {
     // queues 0 .. 3 as named above; then, by the superstep d that needs them (earliest deadline first): INTO[d] = the running product's updates
     // into row block d from the source blocks <= d - 2, and TRAIL[d - 3] = the trailing update of panel d - 3 right of its two look-ahead
     // column blocks (its first columns are block d's); last the accumulations of the inverse, which nothing waits for.
-    std::vector<FlowTask> q[4], acc;
+    std::vector<FlowTask> q[4], acc, vec;
     std::vector<std::vector<FlowTask>> into(no), trail(no);
     auto mk = [&](int b, int phase, int var, int kt) {
         FlowTask t{};
@@ -430,7 +504,7 @@ void flow_build(int nb, int ob, FlowPlan& p) {
         opA(t, BUF_WM, k0(b) + ti, k0(b)); opB(t, BUF_WT, k0(b), j); opC(t, BUF_WM, k0(b) + ti, j);
         dep(t, CH(b), chain_wgs(b));
         dep(t, WC(b, j), (unsigned)(nk(b) * (b - blk(j))));
-        t.sig[0] = WF(b, j);
+        t.sig[0] = WF(b, j); t.sig[1] = WR(b);
         tiles_k += t.kt;
         return t;
     };
@@ -474,8 +548,23 @@ void flow_build(int nb, int ob, FlowPlan& p) {
             for (int i = k0(b); i < k1(b); ++i) for (int j = 0; j < k0(bs); ++j) into[b].push_back(t8(bs, i, j));
         }
         for (int i = 0; i < k1(b); ++i) for (int j = 0; j <= i; ++j) acc.push_back(t9(b, i, j));
+        // z = W y for the tile rows of row block b as soon as they are final, then this row block's share of alpha = W^T z
+        for (int i = k0(b); i < k1(b); ++i) {
+            FlowTask t = mk(b, PH_ZROW, 32, 1);
+            t.ar = (uint16_t)i;
+            dep(t, CH(b), chain_wgs(b));
+            dep(t, WR(b), (unsigned)(nk(b) * k0(b)));
+            t.sig[0] = ZR(b);
+            vec.push_back(t);
+        }
+        for (int jg = 0; jg * 4 < k1(b); ++jg) {
+            FlowTask t = mk(b, PH_APART, 32 | 1, nk(b));
+            t.ar = (uint16_t)k0(b); t.br = (uint16_t)b; t.ac = (uint16_t)jg;
+            dep(t, ZR(b), (unsigned)nk(b));
+            vec.push_back(t);
+        }
     }
-    std::vector<const std::vector<FlowTask>*> order = {&q[0], &q[1], &q[2], &q[3]};
+    std::vector<const std::vector<FlowTask>*> order = {&q[0], &q[1], &q[2], &vec, &q[3]};
     for (int d = 2; d < no + 3; ++d) {
         if (d < no && !into[d].empty()) order.push_back(&into[d]);
         if (d - 3 >= 0 && d - 3 < no && !trail[d - 3].empty()) order.push_back(&trail[d - 3]);
@@ -497,6 +586,20 @@ void flow_build(int nb, int ob, FlowPlan& p) {
         p.tasks.insert(p.tasks.end(), order[qi]->begin(), order[qi]->end());
     }
     p.flops = 2.0 * MOGP_TILE * MOGP_TILE * FL_BK * tiles_k;
+}
+
+// alpha[col] = sum over the row blocks r >= col's block of part[r][col], in that order
+__global__ void k_alpha_sum(const double* __restrict__ part, int64_t npad, int no, int ob, double* __restrict__ out) {
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= npad) return;
+    double s = 0.0;
+    for (int r = (int)(col / MOGP_TILE) / ob; r < no; ++r) s += part[(int64_t)r * npad + col];
+    out[col] = s;
+}
+int launch_flow_alpha_sum(const Spd& w, double* alpha, hipStream_t st) {
+    hipLaunchKernelGGL(k_alpha_sum, dim3((unsigned)((w.Npad + 255) / 256)), dim3(256), 0, st, w.vec_part, w.Npad, w.flow.nouter, w.flow.ob, alpha);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // ---- the schedule -----------------------------------------------------------------------------------------------------------------------
@@ -537,6 +640,7 @@ int spd_potri_flow(mogp_model* m, Spd& w) {
     if ((rc = w.chain_flags.ensure((size_t)(nouter + 1) * MOGP_CHAIN_FLAGS))) return rc;
     HIP_TRY(hipMemsetAsync(w.chain_flags.p, 0, (size_t)(nouter + 1) * MOGP_CHAIN_FLAGS * sizeof(unsigned), crit));
     HIP_TRY(hipMemsetAsync(w.flow_flags.p, 0, (size_t)p.nflags * sizeof(unsigned), crit));
+    if (w.want_vec && w.vec_zz) HIP_TRY(hipMemsetAsync(w.vec_zz, 0, (size_t)((ld + 3) / 4) * sizeof(double), crit));   // the tile rows' z^T z parts land in the first nb entries
     static const bool want_trace = std::getenv("MOGP_FLOW_TRACE") && std::atoi(std::getenv("MOGP_FLOW_TRACE")) != 0;
     if (want_trace) {
         if ((rc = w.flow_trace.ensure(FLOW_TRACE_W * p.tasks.size() + 4 * (size_t)nouter))) return rc;
@@ -564,6 +668,13 @@ int spd_potri_flow(mogp_model* m, Spd& w) {
     g.tasks = w.flow_tasks.p; g.qmeta = w.flow_qmeta.p; g.flags = w.flow_flags.p;
     g.nq = p.nq; g.ncas = FLOW_NCAS; g.base_heads = p.base_heads; g.base_err = p.base_err; g.info = m->d_info.p;
     g.trace = want_trace ? w.flow_trace.p : nullptr;
+    g.npad = ld;
+    { const char* e = std::getenv("MOGP_FLOW_NAP"); g.nap_max = e ? (unsigned)std::max(0, std::atoi(e)) : 4u; }
+    w.vec_done = false;
+    if (w.want_vec && w.vec_y && w.vec_z && w.vec_zz && w.vec_part) {       // z = W y, alpha = W^T z as tasks of the same kernel
+        g.vy = w.vec_y; g.vz = w.vec_z; g.vzz = w.vec_zz; g.vpart = w.vec_part;
+        w.vec_done = true;
+    }
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (m->profiling) {
         if (m->gemm_ev_used + 2 > m->gemm_ev.size())

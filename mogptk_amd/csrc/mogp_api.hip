@@ -664,7 +664,11 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     if ((rc = launch_pad_identity(m->k.A.p, Npad, N, Npad, m->st))) return rc;
     if ((rc = mark(m, 1))) return rc;
 
-    if ((rc = fuse_inverse ? spd_potri_fused(m, m->k) : spd_potrf(m, m->k))) return rc;
+    m->k.want_vec = fuse_inverse && !factor_only;     // the dataflow schedule (flow.hip) also forms z = W y and alpha = W^T z
+    m->k.vec_y = m->d_y.p; m->k.vec_z = m->d_z.p; m->k.vec_zz = m->d_zz.p; m->k.vec_part = m->d_alpha.p + Npad;
+    rc = fuse_inverse ? spd_potri_fused(m, m->k) : spd_potrf(m, m->k);
+    m->k.want_vec = false;
+    if (rc) return rc;
     if ((rc = mark(m, 2))) return rc;
 
     if (!fuse_inverse && !factor_only && (rc = spd_trtri(m, m->k))) return rc;
@@ -677,8 +681,12 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     } else {
         const double* Wp = fuse_inverse ? m->k.Wm.p : m->k.A.p;
         m->w_in_Wm = fuse_inverse;
-        if ((rc = launch_trmv_lower(Wp, Npad, Npad, m->d_y.p, m->d_z.p, m->d_zz.p, m->st))) return rc;
-        if ((rc = launch_trmv_lower_t(Wp, Npad, Npad, m->d_z.p, m->d_alpha.p, m->st))) return rc;
+        if (fuse_inverse && m->k.flow_used && m->k.vec_done) {
+            if ((rc = launch_flow_alpha_sum(m->k, m->d_alpha.p, m->st))) return rc;
+        } else {
+            if ((rc = launch_trmv_lower(Wp, Npad, Npad, m->d_y.p, m->d_z.p, m->d_zz.p, m->st))) return rc;
+            if ((rc = launch_trmv_lower_t(Wp, Npad, Npad, m->d_z.p, m->d_alpha.p, m->st))) return rc;
+        }
     }
     if (fuse_inverse && (rc = spd_potri_fused_finish(m, m->k))) return rc;
     if ((rc = mark(m, 4))) return rc;

@@ -141,6 +141,10 @@ struct Spd {
     DevBuf<unsigned> flow_flags;
     DevBuf<unsigned long long> flow_trace;
     bool flow_used = false;             // the last fused factorisation + inversion of this workspace ran as dataflow
+    // the caller wants z = W y and the row blocks' shares of alpha = W^T z from the same kernel: y, z [Npad], z^T z parts [(Npad + 3) / 4],
+    // shares [nouter][Npad] (device); vec_done: the last factorisation delivered them (launch_flow_alpha_sum adds the shares up)
+    bool want_vec = false, vec_done = false;
+    const double* vec_y = nullptr; double* vec_z = nullptr; double* vec_zz = nullptr; double* vec_part = nullptr;
     void release() {
         for (auto& lv : levels) { lv.d1.release(); lv.d2.release(); }
         for (auto e : sync_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
@@ -321,6 +325,7 @@ int ensure_system(mogp_model* m);     // the N x N system of the exact / OA path
 int spd_potrf(mogp_model* m, Spd& w, long long info_base = 0);
 int spd_potri_fused(mogp_model* m, Spd& w);
 bool flow_enabled(const mogp_model* m, const Spd& w);   // flow.hip
+int launch_flow_alpha_sum(const Spd& w, double* alpha, hipStream_t st);
 int spd_potri_flow(mogp_model* m, Spd& w);             // flow.hip: the same result as spd_potri_fused, as tile dataflow
 int spd_potri_fused_finish(mogp_model* m, Spd& w);   // joins the inverse stream: call before reading w.B   // potri.hip: w.A (SPD, lower) -> w.Wm = L^-1, w.B = inverse (lower); w.logdet per tile
 int spd_trtri(mogp_model* m, Spd& w);

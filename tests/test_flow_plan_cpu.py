@@ -69,8 +69,15 @@ def tile(buf, r, c, nr=1, nc=1):
 
 
 def footprint(r):
-    """(reads, write): sets of (buffer, tile row, tile col)"""
+    """(reads, write): sets of (buffer, tile row, tile col); pseudo-buffers 5 = z (per tile row), 6 = alpha shares (row block, column group)"""
     var, kt = int(r[11]), int(r[12])
+    if var & 32:
+        if var & 1:                                  # alpha share of row block br: rows ar .. ar + kt - 1, column group ac
+            cols = range(4 * int(r[4]), 4 * int(r[4]) + 4)
+            reads = {(3, int(r[3]) + k, c) for k in range(kt) for c in cols if c <= int(r[3]) + k} | {(5, int(r[3]) + k, 0) for k in range(kt)}
+            return reads, (6, int(r[6]), int(r[4]))
+        i = int(r[3])
+        return {(3, i, c) for c in range(i + 1)}, (5, i, 0)
     lay, nk = var & 3, (kt * 16 + T - 1) // T
     reads = set()
     if lay in (0, 1):
@@ -89,6 +96,16 @@ def footprint(r):
 
 def run_task(bufs, r):
     var, kt = int(r[11]), int(r[12])
+    if var & 32:
+        Wm, y, z, part = bufs[3], bufs[7], bufs[5], bufs[6]
+        if var & 1:
+            r0, nr, rb, jg = int(r[3]) * T, kt * T, int(r[6]), int(r[4])
+            c0, c1 = jg * 512, min(jg * 512 + 512, Wm.shape[1])
+            part[rb, c0:c1] = Wm[r0:r0 + nr, c0:c1].T @ z[r0:r0 + nr]
+        else:
+            i = int(r[3])
+            z[i * T:(i + 1) * T] = Wm[i * T:(i + 1) * T, :(i + 1) * T] @ y[:(i + 1) * T]
+        return
     lay, K = var & 3, kt * 16
     a, b = bufs[int(r[2])], bufs[int(r[5])]
     ar, ac, br, bc = int(r[3]) * T, int(r[4]) * T, int(r[6]) * T, int(r[7]) * T
@@ -123,7 +140,10 @@ def test_replay_with_concurrent_workgroups(nb, nwg, seed):
     G = rng.standard_normal((N, N // 2))
     K = G @ G.T / (N // 2) + 0.5 * np.eye(N)
     nan = np.full((N, N), np.nan)
-    bufs = [np.tril(K).copy(), nan.copy(), nan.copy(), np.zeros((N, N)), nan.copy()]     # A lower, L, Wt (never read before written), Wm zero, B
+    yv = rng.standard_normal(N)
+    nblk = (nb + 3) // 4
+    bufs = [np.tril(K).copy(), nan.copy(), nan.copy(), np.zeros((N, N)), nan.copy(),      # A lower, L, Wt (never read before written), Wm zero, B
+            np.full(N, np.nan), np.zeros((nblk, N)), yv]                                   # z, alpha shares per row block, y
     rows = plan(nb)
     chains, queues = split(rows)
     flags = {}
@@ -184,6 +204,8 @@ def test_replay_with_concurrent_workgroups(nb, nwg, seed):
                     chain_busy = False
                 finish(k); done += 1
             progressed = True
+        if not progressed and not chain_busy and chain_next < len(chains) and ready(chains[chain_next]):
+            start(chains[chain_next]); chain_next += 1; chain_busy = True; progressed = True       # (the coin above said "not yet")
         assert progressed, "deadlock: nothing ready, nothing running, %d of %d tasks done" % (done, total)
 
     Lref = np.linalg.cholesky(K)
@@ -193,6 +215,9 @@ def test_replay_with_concurrent_workgroups(nb, nwg, seed):
     assert np.max(np.abs(np.triu(bufs[3], 1))) == 0.0
     assert np.max(np.abs(np.tril(bufs[4]) - np.tril(Kinv))) < 1e-9 * np.max(np.abs(Kinv))
     assert abs(sum(logdet_parts) - np.log(np.diag(Lref)).sum()) < 1e-8
+    alpha = np.array([bufs[6][(c // T) // 4:, c].sum() for c in range(N)])            # k_alpha_sum: the shares of the row blocks from the column's own on
+    assert np.max(np.abs(bufs[5] - Wref @ yv)) < 1e-9 * np.max(np.abs(Wref @ yv))
+    assert np.max(np.abs(alpha - Kinv @ yv)) < 1e-8 * np.max(np.abs(Kinv @ yv))
 
 
 def happens_before(rows):

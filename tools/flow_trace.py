@@ -9,7 +9,7 @@ os.environ.setdefault("MOGP_GRAD_PATH", "fused")
 import numpy as np
 from mogptk_amd import gpr, synth, _lib
 
-QN = ["crit", "look2", "invcrit", "semi"]
+QN = ["crit", "look2", "invcrit", "vec", "semi"]
 
 
 def main():
@@ -46,9 +46,13 @@ def main():
     t00 = min(int(ch[0, 0]), int(t[:, 1][t[:, 1] > 0].min()))
     us = lambda v: (np.asarray(v, dtype=np.float64) - t00) / 100.0
     look, st, k0, k1, en, wg = us(t[:, 0]), us(t[:, 1]), us(t[:, 2]), us(t[:, 3]), us(t[:, 4]), t[:, 5] & 0xffff
+    naps = t[:, 5] >> 32
+    gem = (tasks[:, 11] & 32) == 0
+    print('looks that found nothing at first: %.1f %% of the tasks; their wait: mean %.1f us; direct looks: mean %.1f us, median %.1f us'
+          % (100.0 * (naps > 0).mean(), (st - look)[naps > 0].mean() if (naps > 0).any() else 0.0, (st - look)[naps == 0].mean(), np.median((st - look)[naps == 0])))
     dur = en - st
     print("per task (mean us): looking for work %.1f | taken -> k loop (acquire, C tile, first operands) %.1f | k loop %.1f | stores + drain + counters %.1f"
-          % ((st - look).mean(), (k0 - st).mean(), (k1 - k0).mean(), (en - k1).mean()))
+          % ((st - look).mean(), (k0 - st)[gem].mean(), (k1 - k0)[gem].mean(), (en - k1)[gem].mean()))
     full = tasks[:, 12] == 32
     print("full-K tiles only:  looking %.1f | prologue %.1f | k loop %.1f | epilogue %.1f"
           % ((st - look)[full].mean(), (k0 - st)[full].mean(), (k1 - k0)[full].mean(), (en - k1)[full].mean()))
@@ -56,10 +60,10 @@ def main():
     # queues 4 .. : INTO[d] / TRAIL[d - 3] by deadline, the last one the accumulations: fold them into three report classes
     nq = int(tasks[:, 0].max()) + 1
     cls = tasks[:, 0].copy()
-    rest = tasks[:, 0] >= 4
-    cls[rest & (tasks[:, 8] == 2)] = 4
-    cls[rest & (tasks[:, 8] == 0)] = 5
-    cls[tasks[:, 0] == nq - 1] = 6
+    rest = tasks[:, 0] >= 5
+    cls[rest & (tasks[:, 8] == 2)] = 5
+    cls[rest & (tasks[:, 8] == 0)] = 6
+    cls[tasks[:, 0] == nq - 1] = 7
     tasks = tasks.copy(); tasks[:, 0] = cls
     QN.extend(["into", "trail", "acc"])
     print("dataflow evaluation N=%d (nb=%d tiles, %d outer blocks): %d tile tasks, %d workgroups seen; times in us from the first chain launch"
