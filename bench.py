@@ -476,7 +476,8 @@ def main():
         gram_gbs = gram_bytes * nprof / (stage[_lib.ST_GRAM_KERNEL] * 1e-3) / 1e9 if stage[_lib.ST_GRAM_KERNEL] > 0 else None
         mom_gbs = gram_bytes * nprof / (stage[_lib.ST_MOMENT_KERNEL] * 1e-3) / 1e9 if stage[_lib.ST_MOMENT_KERNEL] > 0 else None
         traffic, traffic_src = None, None
-        for tf in ("r3_pmc_traffic.json", "r2_pmc_traffic.json"):     # L2<->fabric bytes per k_gemm launch from the committed rocprofv3 --pmc passes of this command
+        sched = h.schedule() if (kind == "exact" and not sharded_mode and hasattr(h, "schedule")) else None
+        for tf in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"):     # L2<->fabric bytes per k_gemm launch from the committed rocprofv3 --pmc passes of this command
             try:
                 with open(os.path.join(ROOT, "profiles", tf)) as f:
                     t = json.load(f)
@@ -507,8 +508,14 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc if not a.n else desc + " [N overridden: %d]" % N, "channels": C, "Q": Q, "N": N, "parallelism": par,
                        "inverse_tiles_formed": inv_frac,
+                       # how the factorisation + inversion was scheduled (mogp_model_schedule): a fallback to the stream schedule or to the
+                       # launch-per-step chain (a hand-off timed out: GPU shared with another process) would show here, not only as a slowdown
+                       "dataflow_kernel": None if sched is None else sched["dataflow"],
+                       "chain_kernel": None if sched is None else sched["chain_kernel"],
+                       "fell_back": None if sched is None else (sched["dataflow_fell_back"] or sched["chain_fell_back"]),
                        "step": STEP_NOTE[kind], "device": _lib.device_name(local_rank)},
-            "roofline": {"bound": "mfma", "kernel": "k_gemm (fp64 v_mfma_f64_16x16x4_f64)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": ("k_flow: the resident tile-dataflow kernel, k_gemm's k loop (fp64 v_mfma_f64_16x16x4_f64)"
+                                                     if sched and sched["dataflow"] else "k_gemm (fp64 v_mfma_f64_16x16x4_f64)"), "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "basis": "algorithmic flops of one step (SURVEY.md 8d: %.3e) / ms_per_step%s" % (algo_flops, " / ranks" if sharded_mode else ""),
                          "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src},

@@ -218,6 +218,16 @@ int  mogp_set_profiling(mogp_model* m, int on);
  * *gemm_launches / *gemm_flops = their count and algorithmic flop total in the last eval. */
 int  mogp_stage_ms(mogp_model* m, double* ms, int64_t* gemm_launches, double* gemm_flops);
 
+/* How the last mogp_exact_eval(MOGP_EVAL_GRAD) of this model was scheduled -- so that a silent degradation is visible (bench.py prints it,
+ * the GPU tests assert it).  The factorisation + inversion (reference gpr/model.py:242-246, :291) runs as ONE resident dataflow kernel fed by
+ * persistent chain kernels; if a hand-off inside them times out (their workgroups not all resident: another process on the same GPU) the
+ * evaluation is repeated on streams of launches and the model stays there.  *flags: OR of the bits below. */
+#define MOGP_SCHED_DATAFLOW            1   /* the last fused factorisation + inversion ran as tile dataflow (csrc/flow.hip) */
+#define MOGP_SCHED_CHAIN_KERNEL        2   /* the persistent chain kernel (csrc/chain.hip) is in use */
+#define MOGP_SCHED_DATAFLOW_FELL_BACK  4   /* a dataflow evaluation timed out once: stream schedule from then on */
+#define MOGP_SCHED_CHAIN_FELL_BACK     8   /* a chain kernel timed out once: launch-per-step chain from then on */
+int  mogp_model_schedule(mogp_model* m, int* flags);
+
 /* The fused factorisation + inversion behind mogp_exact_eval(MOGP_EVAL_GRAD) (reference gpr/model.py:242-246 and the O(N^3) solves of its
  * autograd backward, :291) runs as a static graph of 128 x 128 tile products inside ONE resident kernel (csrc/flow.hip).  This call returns
  * that graph for a matrix of nb tile rows as numbers -- no device work, callable without a GPU -- so that tests can replay it on the CPU

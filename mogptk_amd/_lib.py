@@ -77,6 +77,7 @@ SIGNATURES = {
     "mogp_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "mogp_stage_ms": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i64p, c_dp]),
     "mogp_model_fetch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_dp]),
+    "mogp_model_schedule": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
     "mogp_flow_plan": (ctypes.c_int, [ctypes.c_int, c_i64p, ctypes.c_int64, c_i64p]),
     "mogp_flow_trace": (ctypes.c_int, [ctypes.c_void_p, c_i64p, ctypes.c_int64, c_i64p]),
     "mogp_snelson_eval": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.c_int,
@@ -450,6 +451,12 @@ class ExactHandle:
         ms = np.zeros(4)
         check(lib().mogp_shard_stage_ms(self._h, _dp(ms)))
         return ms
+
+    def schedule(self):
+        """-> dict(dataflow, chain_kernel, dataflow_fell_back, chain_fell_back): how the last gradient evaluation was scheduled (mogp_model_schedule)"""
+        f = ctypes.c_int(0)
+        check(lib().mogp_model_schedule(self._h, ctypes.byref(f)))
+        return dict(dataflow=bool(f.value & 1), chain_kernel=bool(f.value & 2), dataflow_fell_back=bool(f.value & 4), chain_fell_back=bool(f.value & 8))
 
     def inverse_fraction(self):
         """fraction of the lower tiles of Kj^-1 the last gradient evaluation formed (1.0 = all; see include/mogp_hip.h)"""

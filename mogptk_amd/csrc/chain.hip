@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256, 1) void k_chain(ChainArgs g) {
             if (g.trace && blockIdx.x == 0) g.trace[2] = wall_clock64();
         }
     }
-    // a timed-out wait anywhere: the results are garbage -- say so through the pivot report (a real pivot failure, being smaller, wins)
+    // a timed-out wait anywhere: the results are garbage -- say so through the pivot report (the time-out value is below every pivot index: it wins)
     if (tid == 0 && __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
         atomicMin(g.info, (unsigned long long)MOGP_INFO_CHAIN_TIMEOUT);
 }

@@ -1599,6 +1599,13 @@ int mogp_model_inverse_fraction(mogp_model* m, double* fraction) {
     return MOGP_OK;
 }
 
+int mogp_model_schedule(mogp_model* m, int* flags) {
+    if (!m || !flags) return fail(MOGP_EINVAL, "mogp_model_schedule: null argument");
+    *flags = (m->k.flow_used ? MOGP_SCHED_DATAFLOW : 0) | (chain_enabled(m) ? MOGP_SCHED_CHAIN_KERNEL : 0) |
+             (m->no_flow ? MOGP_SCHED_DATAFLOW_FELL_BACK : 0) | (m->no_chain ? MOGP_SCHED_CHAIN_FELL_BACK : 0);
+    return MOGP_OK;
+}
+
 int mogp_shard_stage_ms(mogp_model* m, double* ms) {
     if (!m || !ms) return fail(MOGP_EINVAL, "mogp_shard_stage_ms: bad argument");
     for (int i = 0; i < 4; ++i) ms[i] = m->sh_ms[i];

@@ -181,7 +181,9 @@ int launch_wkk(const double* Ablk, int64_t ld, const double* invd, int nk, doubl
 // and updates inside the block and W_KK = L_KK^-1 (-> Wk, as launch_wkk leaves it).  flags: MOGP_CHAIN_FLAGS zeroed words of this block;
 // err: one zeroed word per evaluation.  A hand-off that times out is reported as MOGP_INFO_CHAIN_TIMEOUT through *info.
 #define MOGP_CHAIN_FLAGS 32
-#define MOGP_INFO_CHAIN_TIMEOUT (1ull << 62)
+// 0: below every pivot index (they are 1-based), so that atomicMin lets a time-out WIN over the non-positive pivots the garbage behind it
+// produces (round 4: with several processes on one GPU a timed-out dataflow evaluation was reported as "not positive definite" instead of repeated)
+#define MOGP_INFO_CHAIN_TIMEOUT 0ull
 // flow (optional, flow.hip): the kernel first waits until *wait_flag >= wait_val (its diagonal block has received every update from the
 // dataflow kernel), stores W_KK write-through and every workgroup bumps *done_flag when it is through.
 struct ChainFlow {

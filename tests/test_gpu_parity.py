@@ -408,11 +408,12 @@ def test_cfg5_titsias_golden():
         assert np.array_equal(p.grad, g), p._name
 
 
-@pytest.mark.parametrize("path", ["sweep", "phases", "fused"])
+@pytest.mark.parametrize("path", ["sweep", "phases", "fused", "fused-streams"])
 def test_every_gradient_schedule_matches_reference(path):
-    """the three schedules of the gradient evaluation (MOGP_GRAD_PATH: single-sweep inversion; POTRF -> TRTRI -> LAUUM, the default
-    above 80 tile rows; inverse streamed behind the Cholesky chain, the default below) against the same golden vectors, each in a
-    fresh process because the schedule is chosen once per process"""
+    """the schedules of the gradient evaluation (MOGP_GRAD_PATH: single-sweep inversion; POTRF -> TRTRI -> LAUUM, the default
+    above 80 tile rows; inverse fused with the Cholesky chain, the default below -- as tile dataflow (forced on for every size here) and,
+    "fused-streams", as streams of launches) against the same golden vectors, each in a fresh process because the schedule is chosen
+    once per process"""
     import os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent('''
@@ -441,7 +442,7 @@ def test_every_gradient_schedule_matches_reference(path):
         print("SWEEP_OK")
     ''') % (root, os.path.join(root, "tests"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, MOGP_GRAD_PATH=path))
+                         env=dict(os.environ, MOGP_GRAD_PATH=path.split("-")[0], MOGP_FLOW="0" if path == "fused-streams" else "1", MOGP_FLOW_MIN="2"))
     assert "SWEEP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
@@ -496,7 +497,8 @@ def test_gradient_with_only_the_needed_tiles_of_the_inverse(path):
     with tempfile.TemporaryDirectory() as tmp:
         full = os.path.join(tmp, "full.npz")
         r1 = subprocess.run([sys.executable, "-c", code, full], capture_output=True, text=True, timeout=600,
-                            env=dict(os.environ, MOGP_GRAD_PATH=path, MOGP_FULL_INVERSE="1"))
+                            env=dict(os.environ, MOGP_GRAD_PATH=path, MOGP_FULL_INVERSE="1", MOGP_FLOW="0"))     # the same schedule for both runs: a
+        # planned (partial) inverse takes the stream form of the fused schedule, and the dataflow form adds z^T z in a different order
         assert r1.returncode == 0, r1.stdout[-1500:] + r1.stderr[-3000:]
         r2 = subprocess.run([sys.executable, "-c", code, "-", full], capture_output=True, text=True, timeout=600,
                             env=dict({k_: v for k_, v in os.environ.items() if k_ != "MOGP_FULL_INVERSE"}, MOGP_GRAD_PATH=path))
@@ -848,3 +850,95 @@ np.savez(sys.argv[1], **out)
     for key in res[0].files:
         a, b = res[0][key], res[1][key]
         assert np.max(np.abs(a - b)) <= 1e-9 * max(1.0, np.max(np.abs(a))), (key, float(np.max(np.abs(a - b))))      # measured: <= 2e-11 (atomics)
+
+
+def test_dataflow_schedule_ran_and_equals_the_stream_schedule():
+    """BASELINE.json configs[1] in ONE process: the default gradient evaluation runs as tile dataflow (csrc/flow.hip) on the persistent chain
+    kernels -- asserted through mogp_model_schedule, so that a silent fallback cannot pass -- and gives the SAME W = L^-1 and Kj^-1, bit for bit,
+    as the stream schedule of the same tile products (MOGP_FLOW is read per evaluation); loss and gradient agree to rounding (the dataflow
+    kernel adds z^T z per tile row)."""
+    import os
+    C, Q, N = 4, 3, 8192
+    old = {k: os.environ.get(k) for k in ("MOGP_FLOW", "MOGP_FLOW_MIN")}
+    try:
+        os.environ.pop("MOGP_FLOW", None); os.environ.pop("MOGP_FLOW_MIN", None)
+        m = _synth_mosm(N, C, Q)
+        l1 = float(m.loss())
+        g1 = [p.grad.copy() for p in m.parameters()]
+        hd = m._handle
+        s = hd.schedule()
+        assert s["dataflow"] and s["chain_kernel"] and not s["dataflow_fell_back"] and not s["chain_fell_back"], s
+        W1, K1 = hd.fetch(0), hd.fetch(1)
+        assert float(m.loss()) == l1                                   # bitwise repeatable although the tiles run in a different order every time
+        for g, p in zip(g1, m.parameters()):
+            assert np.array_equal(g, p.grad)
+        os.environ["MOGP_FLOW"] = "0"
+        l0 = float(m.loss())
+        s0 = hd.schedule()
+        assert not s0["dataflow"] and s0["chain_kernel"], s0
+        W0, K0 = hd.fetch(0), hd.fetch(1)
+        assert np.array_equal(W0, W1) and np.array_equal(K0, K1)
+        assert abs(l0 - l1) <= 1e-13 * abs(l0)
+        for g, p in zip(g1, m.parameters()):
+            assert np.max(np.abs(g - p.grad)) <= 1e-11 * max(1.0, np.max(np.abs(g)))
+        # a size whose last outer block is partial (14 tile rows: blocks of 4, 4, 4, 2), dataflow forced on
+        os.environ["MOGP_FLOW"] = "1"; os.environ["MOGP_FLOW_MIN"] = "2"
+        m2 = _synth_mosm(1700, 2, 2)
+        la = float(m2.loss()); Wa = m2._handle.fetch(0)
+        assert m2._handle.schedule()["dataflow"]
+        os.environ["MOGP_FLOW"] = "0"
+        lb = float(m2.loss()); Wb = m2._handle.fetch(0)
+        assert not m2._handle.schedule()["dataflow"]
+        assert np.array_equal(Wa, Wb) and abs(la - lb) <= 1e-13 * abs(la)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_first_evaluation_after_allocation_in_concurrent_processes(tmp_path):
+    """Eight fresh processes share the GPU, each allocates its workspaces and evaluates ONCE (exact model with the dataflow schedule, sparse bound):
+    every result is finite and equal to the single-process value.  Two hazards live here: the zero fills behind a first allocation used to race
+    with the first Gram kernel on a shared GPU (round 3: garbage in the first ELBO of 15-30 % of such runs), and the resident kernels of
+    several processes compete for the same reserved CUs -- a hand-off that times out must end in the stream schedule with the same numbers."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "first.py"
+    script.write_text('''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from mogptk_amd import gpr, synth, _lib
+C, Q, N, M = 3, 2, 3072, 384
+X, y = synth.make_data(N, C)
+h = synth.mosm_hypers(C, Q)
+k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
+for name in ("weight", "mean", "variance", "delay", "phase"):
+    getattr(k, name).assign(h[name])
+dev = _lib.ExactHandle(0, X, y, C); dev.set_terms(k._spectral_terms(1))
+a = dev.eval(h["scale"] ** 2, 1e-8)
+rng = np.random.default_rng(2)
+Z = np.concatenate([np.stack([np.full(M // C, float(c)), np.sort(rng.uniform(0, 100, M // C))], axis=1) for c in range(C)])
+dev2 = _lib.ExactHandle(0, X, y, C); dev2.set_terms(k._spectral_terms(1))
+b = dev2.titsias_eval(Z, 0.3, 1e-6, k._spectral_diag(1))
+s = dev.schedule()
+np.savez(sys.argv[1], lml=a["lml"], mom=a["moments"], elbo=b["elbo"], gz=b["gZ"], fell=int(s["dataflow_fell_back"]) + 2 * int(s["chain_fell_back"]))
+''' % root)
+    def launch(i):
+        return subprocess.Popen([sys.executable, str(script), str(tmp_path / ("o%d.npz" % i))], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    p = launch(0)
+    out, err = p.communicate(timeout=600)
+    assert p.returncode == 0, out[-1000:] + err[-2000:]
+    ref = np.load(tmp_path / "o0.npz")
+    assert int(ref["fell"]) == 0                                          # alone on the GPU nothing falls back
+    procs = [launch(i) for i in range(1, 9)]
+    for i, p in enumerate(procs, 1):
+        out, err = p.communicate(timeout=900)
+        assert p.returncode == 0, out[-1000:] + err[-2000:]
+        r = np.load(tmp_path / ("o%d.npz" % i))
+        assert np.isfinite(r["lml"]) and np.isfinite(r["elbo"])
+        assert abs(float(r["lml"]) - float(ref["lml"])) <= 1e-12 * abs(float(ref["lml"])), (i, float(r["lml"]), float(ref["lml"]), int(r["fell"]))
+        assert np.max(np.abs(r["mom"] - ref["mom"])) <= 1e-9 * np.max(np.abs(ref["mom"]))
+        assert float(r["elbo"]) == float(ref["elbo"]) and np.array_equal(r["gz"], ref["gz"])

@@ -41,6 +41,8 @@ def main():
     l.mogp_flow_plan(nb, rows.ctypes.data_as(_lib.c_i64p), rows.size, ctypes.byref(pc))
     tasks = rows[rows[:, 0] >= 0]
     nt, no = len(tasks), int((rows[:, 0] < 0).sum())
+    if os.environ.get("FLOW_TRACE_SAVE"):
+        np.savez_compressed(os.environ["FLOW_TRACE_SAVE"], trace=tr, rows=rows)
     t = tr[:6 * nt].reshape(nt, 6)
     ch = tr[6 * nt:6 * nt + 4 * no].reshape(no, 4)
     t00 = min(int(ch[0, 0]), int(t[:, 1][t[:, 1] > 0].min()))
