@@ -324,6 +324,7 @@ class ExactHandle:
         kff_diag = _f64(kff_diag)
         M = Z.shape[0]
         C, T, W, D = self.C, self.T, self.W, self.D      # rows of the width set_terms took (2 + 3 D, or 2 + 5 D with an envelope)
+        self._check_diag("kff_diag", kff_diag, self.N)
         elbo, trGA, dsig, jit = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         info = ctypes.c_int64(0)
         mom_uu = np.zeros((C * (C + 1) // 2, T, W)) if grad else None
@@ -340,12 +341,21 @@ class ExactHandle:
     def titsias_predict(self, Z, sigma, jitter, Xs, kss_diag, sharded=False):
         Z, Xs, kss_diag = _f64(Z), _f64(Xs), _f64(kss_diag)
         S = Xs.shape[0]
+        self._check_diag("kss_diag", kss_diag, S)
         mu, var = np.empty(S), np.empty(S)
         info = ctypes.c_int64(0)
         fn = lib().mogp_titsias_predict_sharded if sharded else lib().mogp_titsias_predict
         code = fn(self._h, Z.shape[0], _dp(Z), float(sigma), float(jitter), _dp(kss_diag), S, _dp(Xs), _dp(mu), _dp(var), ctypes.byref(info))
         check(code, info.value)
         return mu.reshape(-1, 1), var.reshape(-1, 1)
+
+    def _check_diag(self, name, diag, npoints):
+        """K_diag arrays of the sparse / variational entry points: one value per CHANNEL, or -- with enveloped terms (rows of width 2 + 5 D),
+        whose diagonal follows the points -- one per point; the C side indexes them accordingly, so the length is checked here"""
+        want = npoints if self.W > 2 + 3 * self.D else self.C
+        if diag is None or diag.size != want:
+            raise ValueError("%s must have %d entries (%s), got %s" % (name, want, "per point: the terms carry an envelope" if want != self.C else "per channel",
+                                                                       None if diag is None else diag.size))
 
     def snelson_eval(self, Z, noise_var, jitter, kff_diag, grad=True, sharded=False):
         """Snelson (FITC) marginal likelihood (+ gradient outputs) through mogp_snelson_eval"""
@@ -370,6 +380,8 @@ class ExactHandle:
     def snelson_predict(self, Z, noise_var, jitter, Xs, kff_diag, kss_diag, sharded=False):
         Z, Xs, noise_var, kff_diag, kss_diag = _f64(Z), _f64(Xs), _f64(noise_var), _f64(kff_diag), _f64(kss_diag)
         S = Xs.shape[0]
+        self._check_diag("kff_diag", kff_diag, self.N)
+        self._check_diag("kss_diag", kss_diag, S)
         mu, var = np.empty(S), np.empty(S)
         info = ctypes.c_int64(0)
         fn = lib().mogp_snelson_predict_sharded if sharded else lib().mogp_snelson_predict
@@ -386,6 +398,10 @@ class ExactHandle:
         Xs = None if Xs is None else _f64(Xs)
         kss = None if kss_diag is None else _f64(kss_diag)
         n = self.N if Xs is None else S
+        if Xs is None:
+            self._check_diag("kff_diag", kff_diag, self.N)
+        else:
+            self._check_diag("kss_diag", kss, S)
         mu, var = np.empty(n), np.empty(n)
         jit = ctypes.c_double()
         info = ctypes.c_int64(0)

@@ -56,20 +56,28 @@ def _num(v):
     return np.array(v, dtype=np.float64)
 
 
-# What a checkpoint written by the reference's Model.save() needs besides its own classes: torch's tensor / storage rebuilders, the containers
-# torch.nn.Module state uses, numpy's array rebuilders and a few builtins.  Nothing else is resolved: a crafted "checkpoint" naming os.system
-# (the reference's plain pickle.load would run it) raises instead.
-_ALLOWED_MODULE_PREFIXES = ("torch._utils", "torch.nn.modules.", "torch.nn.parameter", "torch._tensor", "torch.storage", "torch.serialization",
-                            "numpy.core.multiarray", "numpy._core.multiarray", "numpy.core.numeric", "numpy._core.numeric")
-_ALLOWED_NAMES = {
+# What a checkpoint written by the reference's Model.save() needs besides its own classes: torch's tensor / parameter rebuilders, the container
+# torch.nn.Module state uses, numpy's array rebuilders and a few builtins -- EXACT (module, name) pairs, nothing resolved by prefix and no dotted
+# names (pickle protocol 4 resolves "a.b" attribute by attribute: with whole modules allowed, GLOBAL('torch.serialization', 'os.getcwd') or
+# torch._utils._import_dotted_name reached anything importable).  A crafted "checkpoint" naming os.system -- which the reference's plain
+# pickle.load would run -- raises instead.
+_ALLOWED = {
+    "torch._utils": {"_rebuild_tensor_v2", "_rebuild_tensor", "_rebuild_parameter", "_rebuild_parameter_with_state"},
+    "torch._tensor": {"_rebuild_from_type_v2"},
+    "torch.nn.modules.container": {"ModuleList"},
+    "torch.nn.parameter": {"Parameter"},
     "torch": {"FloatStorage", "DoubleStorage", "LongStorage", "IntStorage", "BoolStorage", "HalfStorage", "ByteStorage", "Size", "device", "dtype",
               "float32", "float64", "int64", "int32", "bool", "Tensor", "UntypedStorage"},
     "numpy": {"dtype", "ndarray", "float64", "float32", "int64", "int32", "bool_"},
+    "numpy.core.multiarray": {"_reconstruct", "scalar"},
+    "numpy._core.multiarray": {"_reconstruct", "scalar"},
+    "numpy.core.numeric": {"_frombuffer"},
+    "numpy._core.numeric": {"_frombuffer"},
     "collections": {"OrderedDict"},
     "builtins": {"set", "frozenset", "slice", "complex", "list", "dict", "tuple", "bytearray", "range", "object", "int", "float", "bool", "str", "bytes"},
     "copyreg": {"_reconstructor"},
-    "functools": {"partial"},
-    "_operator": {"mul", "add", "sub", "truediv", "neg", "pow"},     # what peg transforms are made of                  # harmless by itself: whatever it wraps is resolved through this same list
+    "functools": {"partial"},                                        # peg transforms: partial(operator.mul, c) -- whatever it wraps is resolved through this same list
+    "_operator": {"mul", "add", "sub", "truediv", "neg", "pow"},
     "datetime": {"datetime", "timedelta", "date"},
     "pandas._libs.tslibs.timestamps": {"_unpickle_timestamp", "Timestamp"},
 }
@@ -83,17 +91,43 @@ def _load_storage_bytes(b):
     return torch.load(io.BytesIO(b), weights_only=True)
 
 
+def _refuse(module, name, what):
+    raise pickle.UnpicklingError("%s names %s.%s, which a mogptk checkpoint has no use for: refused" % (what, module, name))
+
+
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if module == "mogptk.gpr.parameter" and name == "Parameter._rebuild":
             return _RefParameter
         if module == "mogptk" or module.startswith("mogptk."):
-            return type(name.split(".")[-1], (_Bag,), {"_mod": module, "_cls": name.split(".")[-1]})
+            return type(name.split(".")[-1], (_Bag,), {"_mod": module, "_cls": name.split(".")[-1]})        # a state bag: nothing of the reference is imported or run
         if module == "torch.storage" and name == "_load_from_bytes":
             return _load_storage_bytes
-        if name in _ALLOWED_NAMES.get(module, ()) or any(module == p.rstrip(".") or module.startswith(p) for p in _ALLOWED_MODULE_PREFIXES):
+        if "." not in name and name in _ALLOWED.get(module, ()):
             return super().find_class(module, name)
-        raise pickle.UnpicklingError("reference checkpoint names %s.%s, which a mogptk checkpoint has no use for: refused" % (module, name))
+        _refuse(module, name, "reference checkpoint")
+
+
+class _NativeUnpickler(pickle.Unpickler):
+    """this package's own checkpoints (Model.save pickles the model): classes and functions DEFINED in mogptk_amd, numpy's array rebuilders and
+    the same small set of builtins -- an object merely reachable through one of the package's modules (an imported os, subprocess, pickle ...)
+    is not resolved"""
+
+    def find_class(self, module, name):
+        if "." in name:
+            _refuse(module, name, "checkpoint")
+        if module == "mogptk_amd" or module.startswith("mogptk_amd."):
+            obj = super().find_class(module, name)
+            if (isinstance(obj, type) or callable(obj)) and str(getattr(obj, "__module__", "")).startswith("mogptk_amd"):
+                return obj
+            _refuse(module, name, "checkpoint")
+        if not module.startswith("torch") and name in _ALLOWED.get(module, ()):
+            return super().find_class(module, name)
+        _refuse(module, name, "checkpoint")
+
+
+def load_native_model(raw):
+    return _NativeUnpickler(io.BytesIO(raw)).load()
 
 
 def is_reference_checkpoint(raw):

@@ -310,11 +310,8 @@ bool chain_enabled(const mogp_model* m) {
 
 int launch_chain(double* A, int64_t ld, int t0, int nk, double* invd, double* logdet, unsigned long long* info, long long info_base,
                  double* Wk, int64_t ldw, unsigned* flags, unsigned* err, hipStream_t s, const ChainFlow* flow) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0ull};                 // one bit per device
+    { int r__ = set_max_dynamic_lds(reinterpret_cast<const void*>(k_chain), CH_LDS_BYTES, attr_done); if (r__) return r__; }
     if (nk < 1 || nk > 4) { set_error("launch_chain: a block has 1 .. 4 tiles"); return -1; }
     ChainArgs g{};
     g.A = A; g.ld = ld; g.t0 = t0; g.nk = nk; g.invd = invd; g.logdet = logdet; g.info = info; g.info_base = info_base;

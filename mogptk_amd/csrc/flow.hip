@@ -656,11 +656,8 @@ int spd_potri_flow(mogp_model* m, Spd& w) {
     HIP_TRY(hipStreamWaitEvent(bulk, start, 0));
     HIP_TRY(hipStreamWaitEvent(priv, start, 0));
 
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_flow), hipFuncAttributeMaxDynamicSharedMemorySize, FL_LDS_BYTES));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0ull};                 // one bit per device
+    { int r__ = set_max_dynamic_lds(reinterpret_cast<const void*>(k_flow), FL_LDS_BYTES, attr_done); if (r__) return r__; }
     static const int wg_per_cu = std::getenv("MOGP_FLOW_WGS") ? std::max(1, std::atoi(std::getenv("MOGP_FLOW_WGS"))) : 2;
     const int cus = (m->ctx->ncu > 0 ? m->ctx->ncu : 256) - m->ctx->ncu_reserved;
     FlowArgs g{};

@@ -26,11 +26,8 @@ __global__ __launch_bounds__(256) void k_leaf128(double* A, int64_t ld, int t, d
 
 int launch_potrf_trtri_tile(double* A, int64_t ld, int t, double* invd, double* logdet, unsigned long long* info, hipStream_t s,
                             long long info_base, int store_L) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_leaf128), hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS_BYTES));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0ull};                 // one bit per device
+    { int r__ = set_max_dynamic_lds(reinterpret_cast<const void*>(k_leaf128), LF_LDS_BYTES, attr_done); if (r__) return r__; }
     hipLaunchKernelGGL(k_leaf128, dim3(1), dim3(256), LF_LDS_BYTES, s, A, ld, t, invd, logdet, info, info_base, store_L);
     HIP_TRY(hipGetLastError());
     return 0;

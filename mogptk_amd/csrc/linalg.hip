@@ -490,11 +490,8 @@ __global__ __launch_bounds__(512, 4) void k_gemm_sk(GemmArgs g) {
 template <int AKM, int BKM>
 static int launch_gemm_sk_t(const GemmArgs& a, hipStream_t s) {
     constexpr int lds_bytes = GemmCfg<4, 2, 4, 2>::LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_sk<AKM, BKM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0ull};                 // one bit per device
+    { int r__ = set_max_dynamic_lds(reinterpret_cast<const void*>(k_gemm_sk<AKM, BKM>), lds_bytes, attr_done); if (r__) return r__; }
     hipLaunchKernelGGL((k_gemm_sk<AKM, BKM>), dim3(a.sk_spans), dim3(512), lds_bytes, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -503,12 +500,8 @@ static int launch_gemm_sk_t(const GemmArgs& a, hipStream_t s) {
 template <int AKM, int BKM, int WTM, int WTN, int NWJ = 2, int NWI = 2>
 static int launch_gemm_t(const GemmArgs& a, int grid, hipStream_t s) {
     constexpr int lds_bytes = GemmCfg<WTM, WTN, NWJ, NWI>::LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<AKM, BKM, WTM, WTN, NWJ, NWI>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0ull};                 // one bit per device
+    { int r__ = set_max_dynamic_lds(reinterpret_cast<const void*>(k_gemm<AKM, BKM, WTM, WTN, NWJ, NWI>), lds_bytes, attr_done); if (r__) return r__; }
     hipLaunchKernelGGL((k_gemm<AKM, BKM, WTM, WTN, NWJ, NWI>), dim3(grid), dim3(64 * NWI * NWJ), lds_bytes, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -844,6 +837,17 @@ __global__ void k_sum_slices(const double* __restrict__ slices, int64_t n, int k
 }
 int launch_sum_slices(const double* slices, int64_t n, int ks, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slices, n, ks, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// between two factorisations of one evaluation: the pivot word back to "no failure" -- unless it holds a time-out, which must survive until the
+// host looks (a stream-K hand-off of a triangular solve that timed out used to be overwritten here: ADVICE round 3)
+__global__ void k_info_rearm(unsigned long long* info) {
+    if (*info != MOGP_INFO_CHAIN_TIMEOUT) *info = ~0ull;
+}
+int launch_info_rearm(unsigned long long* info, hipStream_t s) {
+    hipLaunchKernelGGL(k_info_rearm, dim3(1), dim3(1), 0, s, info);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -20,6 +21,18 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
         hipError_t e__ = (x);                                             \
         if (e__ != hipSuccess) return mogp::hip_fail(e__, #x, __FILE__, __LINE__); \
     } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: set it once per (kernel, device) -- a process may hold contexts on
+// several GPUs, and host threads may evaluate on them at the same time (a function-local `static bool` covered neither: ADVICE round 3)
+inline int set_max_dynamic_lds(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
 
 // ---- Gram / moment tiles ---------------------------------------------------------------------------
 // One descriptor per 64x64 tile of one channel-pair block (never straddles a channel boundary).
@@ -252,6 +265,8 @@ int launch_get_diag(const double* A, int64_t ld, int64_t n, double* out, hipStre
 int launch_axpby(int64_t n, double a, const double* x, double b, const double* y, double* out, hipStream_t s);
 // out[i] = sum over ks slices of n doubles each (split-K partial results, summed in slice order)
 int launch_sum_slices(const double* slices, int64_t n, int ks, double* out, hipStream_t s);
+// the pivot word <- "no failure", unless it holds a time-out (MOGP_INFO_CHAIN_TIMEOUT)
+int launch_info_rearm(unsigned long long* info, hipStream_t s);
 // non-finite scan of the lower triangle: flag[0] |= 1 if NaN seen, |= 2 if Inf seen
 int launch_nonfinite_scan(const double* A, int64_t ld, int64_t n, int* flag, hipStream_t s);
 

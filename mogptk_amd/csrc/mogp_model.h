@@ -311,6 +311,9 @@ int side_join(mogp_model* m, TitsiasWork& t, hipStream_t side);
 int gz_prepare(mogp_model* m, TitsiasWork& t, const std::vector<int>& offz, int D);
 void gz_attach(const TitsiasWork& t, MomentArgs& ma, bool zx);
 int spd_check_info(mogp_model* m, const char* which, int64_t* info);
+// after the LAST stream sync of a sparse / variational evaluation: did a hand-off between workgroups (stream-K GEMM of a wide triangular solve,
+// chain kernel) time out anywhere?  Then the numbers are not valid: the model drops those forms and the call fails, loudly (titsias.hip)
+int sparse_timeout_check(mogp_model* m);
 bool chain_enabled(const mogp_model* m);   // chain.hip
 int chain_fallback(mogp_model* m);     // mogp_api.hip: after MOGP_INFO_CHAIN_TIMEOUT -- drain, switch the model to the launch-per-step chain; the caller repeats the evaluation
 // w.A (SPD, lower tiles) -> w.B = its inverse (lower tiles, full diagonal tiles) and *W = L^-1 (lower; in w.A, or in w.Wm on the fused path),

@@ -217,7 +217,7 @@ int snelson_front(mogp_model* m, int64_t M, const double* Z, const double* noise
     if (sharded) RC(comm_allreduce(m->ctx, t.q.A.p, Mpad * Mpad, m->st));
     RC(launch_add_diag(t.q.A.p, Mpad, Mpad, 1.0, m->st));
     HIP_TRY(hipMemcpyAsync(t.Qs.p, t.q.A.p, (size_t)Mpad * Mpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
-    HIP_TRY(hipMemcpyAsync(m->d_info.p, &big, sizeof(big), hipMemcpyHostToDevice, m->st));
+    RC(launch_info_rearm(m->d_info.p, m->st));              // (not a plain overwrite: a time-out of the wide solve above must reach the host)
     RC(spd_invert(m, t.q, "v G v^T + I", info, &t.Wq));                         // t.Wq = Lq^-1, t.q.B = Pq (lower)
     RC(launch_symmetrize(t.q.B.p, Mpad, Mpad, m->st));
     RC(launch_symmetrize(t.Qs.p, Mpad, Mpad, m->st));
@@ -262,7 +262,7 @@ int snelson_eval_impl(mogp_model* m, int64_t M, const double* Z, const double* n
     const int mt = (int)(Mpad / MOGP_TILE), nt = (int)(Npad / MOGP_TILE);
     *lml = -0.5 * sc.ntot * std::log(2.0 * M_PI) - sc.logdet_q - 0.5 * sc.sumlogg - 0.5 * sc.yGy + 0.5 * sc.rvGy;
     if (jitter_abs) *jitter_abs = sc.jit;
-    if (!grad) return MOGP_OK;
+    if (!grad) return sparse_timeout_check(m);
     if (!mom_uu || !mom_uf || !gZ || !trGA || !hsum) return fail(MOGP_EINVAL, "mogp_snelson_eval: gradient outputs are null");
 
     RC(t.GB.ensure((size_t)Mpad * Npad)); RC(t.E.ensure((size_t)Mpad * Mpad)); RC(t.R.ensure((size_t)Mpad * Mpad));
@@ -353,6 +353,7 @@ int snelson_eval_impl(mogp_model* m, int64_t M, const double* Z, const double* n
     HIP_TRY(hipMemcpyAsync(hd.data(), dga, Mpad * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(hh.data(), h, Npad * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
+    RC(sparse_timeout_check(m));
     for (int64_t pos = 0; pos < M; ++pos)
         for (int d = 0; d < D; ++d) gZ[sz.perm[pos] * D + d] = hgz[(size_t)d * Mpad + pos];
     double tr = 0.0;
@@ -454,6 +455,7 @@ int snelson_predict_impl(mogp_model* m, int64_t M, const double* Z, const double
     HIP_TRY(hipMemcpyAsync(hmu.data(), m->d_mu.p, Spad * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(hv.data(), m->d_var.p, 2 * Spad * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
+    RC(sparse_timeout_check(m));
     for (int c = 0; c < C; ++c)
         for (int pos = ss.off[c]; pos < ss.off[c + 1]; ++pos) {
             mu[ss.perm[pos]] = hmu[pos];

@@ -182,6 +182,7 @@ int mogp_svgp_forward(mogp_model* m, int64_t M, const double* Z, const double* q
     HIP_TRY(hipMemcpyAsync(hmu.data(), m->d_mu.p, Qpad * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(hv.data(), m->d_var.p, 2 * Qpad * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
+    RC(sparse_timeout_check(m));
     const double* kd = train ? kff_diag : kss_diag;
     const bool env = m->Wt > 2 + 3 * D;                          // enveloped terms: K_diag per point (caller's order) instead of per channel
     for (int c = 0; c < C; ++c)
@@ -307,6 +308,7 @@ static int svgp_backward_impl(mogp_model* m, const double* e, const double* f, d
     HIP_TRY(hipMemcpyAsync(hd.data(), dga, Mpad * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(hS.data(), t.q.A.p, hS.size() * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
+    RC(sparse_timeout_check(m));
     double tr = 0.0;
     for (int64_t pos = 0; pos < M; ++pos) {
         const int64_t dst = sz.perm[pos];

@@ -93,14 +93,27 @@ int spd_check_info(mogp_model* m, const char* which, int64_t* info) {
     unsigned long long hinfo = 0;
     HIP_TRY(hipMemcpyAsync(&hinfo, m->d_info.p, sizeof(hinfo), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
-    if (hinfo == MOGP_INFO_CHAIN_TIMEOUT)
-        return fail(MOGP_EHIP, "chain kernel: a hand-off between its workgroups timed out (chain.hip; MOGP_CHAIN=0 selects the launch-per-step form)");
+    if (hinfo == MOGP_INFO_CHAIN_TIMEOUT) {
+        m->no_chain = true;                                  // gates the chain kernel AND the stream-K launches (mogp_api.hip:stream_k_setup)
+        return fail(MOGP_EHIP, "a hand-off between workgroups timed out (chain kernel, chain.hip, or a stream-K GEMM, linalg.hip:k_gemm_sk: the GPU is "
+                               "shared with another process?).  The model has switched both forms off, as MOGP_CHAIN=0 and MOGP_SK=0 do: repeat the call");
+    }
     if (hinfo != std::numeric_limits<unsigned long long>::max()) {
         if (info) *info = (int64_t)hinfo;
         return fail(MOGP_ENOTPD, std::string("linalg.cholesky: ") + which + " is not positive-definite (the leading minor of order " +
                                  std::to_string(hinfo) + " is not positive-definite).");
     }
     return 0;
+}
+
+int sparse_timeout_check(mogp_model* m) {
+    unsigned long long hinfo = 1;
+    HIP_TRY(hipMemcpy(&hinfo, m->d_info.p, sizeof(hinfo), hipMemcpyDeviceToHost));     // the caller has just synchronised the stream
+    if (hinfo != MOGP_INFO_CHAIN_TIMEOUT) return 0;
+    m->no_chain = true;
+    return fail(MOGP_EHIP, "a hand-off between workgroups timed out during this evaluation (stream-K GEMM of a triangular solve, linalg.hip:k_gemm_sk, "
+                           "or the chain kernel: the GPU is shared with another process?): its result is not valid.  The model has switched both forms "
+                           "off, as MOGP_SK=0 and MOGP_CHAIN=0 do: repeat the call");
 }
 
 // mt (mt + 1) / 2 = 136 tiles at configs[4] would leave half the chip idle over K = N: K is cut into ks slices, each slice into a block of
@@ -234,7 +247,7 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     }
     RC(launch_add_diag(t.q.A.p, Mpad, Mpad, 1.0, m->st));
     HIP_TRY(hipMemcpyAsync(t.Qs.p, t.q.A.p, (size_t)Mpad * Mpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
-    HIP_TRY(hipMemcpyAsync(m->d_info.p, &big, sizeof(big), hipMemcpyHostToDevice, m->st));
+    RC(launch_info_rearm(m->d_info.p, m->st));              // (not a plain overwrite: a time-out of the wide solve above must reach the host)
     RC(spd_invert(m, t.q, "Q/sigma^2 + I", info, &t.Wq));                       // t.Wq = Lq^-1, t.q.B = Pq (lower)
     RC(launch_symmetrize(t.q.B.p, Mpad, Mpad, m->st));
     double* t1 = t.vec.p + Mpad;
@@ -291,7 +304,7 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
     *elbo = -0.5 * Ntot * std::log(2.0 * M_PI) - sc.logdet_q - Ntot * std::log(sigma) - 0.5 * sc.yy / s2
             + 0.5 * sc.t1vy / (s2 * s2) - 0.5 * (kff - trQ) / s2;
     if (jitter_abs) *jitter_abs = sc.jit;
-    if (!grad) return MOGP_OK;
+    if (!grad) return sparse_timeout_check(m);
     if (!mom_uu || !mom_uf || !gZ || !trGA || !dsigma) return fail(MOGP_EINVAL, "mogp_titsias_eval: gradient outputs are null");
 
     // d ELBO / d s2, then d sigma  (tr(Pq Q) = s2 (M - tr Pq);  vy^T Pq Q Pq vy = s2 (t1.vy - t1.t1))
@@ -373,6 +386,7 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
     HIP_TRY(hipMemcpyAsync(hb.data(), beta, Mpad * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(hd.data(), dga, Mpad * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
+    RC(sparse_timeout_check(m));
     for (int64_t pos = 0; pos < M; ++pos)
         for (int d = 0; d < D; ++d) gZ[sz.perm[pos] * D + d] = hgz[(size_t)d * Mpad + pos];
     double tr = 0.0;
@@ -456,6 +470,7 @@ static int titsias_predict_impl(mogp_model* m, int64_t M, const double* Z, doubl
     HIP_TRY(hipMemcpyAsync(hmu.data(), m->d_mu.p, Spad * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(hv.data(), m->d_var.p, 2 * Spad * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
+    RC(sparse_timeout_check(m));
     for (int c = 0; c < C; ++c)
         for (int pos = ss.off[c]; pos < ss.off[c + 1]; ++pos) {
             mu[ss.perm[pos]] = hmu[pos] / s2;

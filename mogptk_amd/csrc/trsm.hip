@@ -132,11 +132,8 @@ __global__ __launch_bounds__(THREADS) void k_trsm_leaf(const double* __restrict_
 
 template <bool TRANS, int THREADS>
 static int launch_leaf_t(const double* Lt, int64_t ldl, double* B, int64_t ldb, int64_t ncols, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_leaf<TRANS, THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_BYTES));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0ull};                 // one bit per device
+    { int r__ = set_max_dynamic_lds(reinterpret_cast<const void*>(k_trsm_leaf<TRANS, THREADS>), TS_LDS_BYTES, attr_done); if (r__) return r__; }
     hipLaunchKernelGGL((k_trsm_leaf<TRANS, THREADS>), dim3((unsigned)((ncols + THREADS - 1) / THREADS)), dim3(THREADS), TS_LDS_BYTES, s, Lt, ldl, B, ldb, ncols);
     HIP_TRY(hipGetLastError());
     return 0;

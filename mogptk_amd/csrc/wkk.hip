@@ -95,11 +95,8 @@ __global__ __launch_bounds__(256) void k_wkk(const double* __restrict__ Ablk, in
 // Ablk: origin of the diagonal block in the matrix (leading dimension ld), holding L_KK's tiles below the diagonal; invd: the nk tile
 // inverses; Wk: nk*128 square, leading dimension ldw, tiles above the diagonal untouched (zero from allocation)
 int launch_wkk(const double* Ablk, int64_t ld, const double* invd, int nk, double* Wk, int64_t ldw, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wkk), hipFuncAttributeMaxDynamicSharedMemorySize, WK_LDS_BYTES));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0ull};                 // one bit per device
+    { int r__ = set_max_dynamic_lds(reinterpret_cast<const void*>(k_wkk), WK_LDS_BYTES, attr_done); if (r__) return r__; }
     hipLaunchKernelGGL(k_wkk, dim3(MOGP_TILE / WK_COLS, nk), dim3(256), WK_LDS_BYTES, s, Ablk, ld, invd, nk, Wk, ldw);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -570,6 +570,9 @@ class Snelson(_DataParallel, Model):
         h.set_terms(table)
         Zk = self.kernel._kernel_format(self.Z())
         env = table.shape[3] > 2 + 3 * D                  # enveloped terms (MOHSM): the kernel diagonal follows the points
+        if env and self._data_shard() is not None:
+            raise NotImplementedError("Snelson with an enveloped kernel (MOHSM) is single-process only: its per-point diagonal gradient is not reduced "
+                                      "over the ranks of the data-parallel form")
         kff = self.kernel._point_diag(table, self._local(self.kernel._kernel_format(self.X)), D) if env else self.kernel._spectral_diag(D)
         try:
             res = h.snelson_eval(Zk, self._noise_vector(), self.jitter, kff, grad=grad, sharded=self._data_shard() is not None)
@@ -779,6 +782,9 @@ class SparseHensman(_DataParallel, Model):
         h.set_terms(table)
         Zk = self.kernel._kernel_format(self.Z())
         env = table.shape[3] > 2 + 3 * D                  # enveloped terms (MOHSM): the kernel diagonal follows the points
+        if env and self._data_shard() is not None:
+            raise NotImplementedError("SparseHensman with an enveloped kernel (MOHSM) is single-process only: the per-point diagonal gradient is not "
+                                      "reduced over the ranks of the data-parallel form")
         kff = self.kernel._point_diag(table, self._local(self.kernel._kernel_format(self.X)), D) if env else self.kernel._spectral_diag(D)
         try:
             res = h.svgp_forward(Zk, self.q_mu(), self.q_sqrt(), self.jitter, kff, dense=not self.is_sparse)

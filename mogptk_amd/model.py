@@ -31,7 +31,7 @@ def LoadModel(filename):
     from . import compat
     if compat.is_reference_checkpoint(raw):
         return compat.load_reference_model(raw)
-    return pickle.loads(raw)
+    return compat.load_native_model(raw)          # restricted unpickler: classes defined in this package, numpy arrays, a few builtins
 
 
 class Exact:

@@ -951,3 +951,43 @@ def test_reference_checkpoint_loader_refuses_names_a_checkpoint_has_no_use_for(t
     import io
     with pytest.raises(pickle.UnpicklingError):
         compat._Unpickler(io.BytesIO(raw)).load()
+
+
+def test_checkpoint_loaders_refuse_dotted_names_and_module_prefix_tricks(tmp_path):
+    """round 3's allow list matched whole modules by prefix, and pickle protocol 4 resolves dotted names attribute by attribute: both
+    GLOBAL('torch.serialization', 'os.getcwd') and torch._utils._import_dotted_name('os.getcwd') + REDUCE got through.  Now only exact
+    (module, name) pairs resolve -- for the reference's checkpoints and for this package's own -- and a native checkpoint still round-trips."""
+    import io, pickle, pickletools
+    from mogptk_amd import compat
+
+    def stack_global(module, name, args=b")"):
+        # protocol 4: module, name as short unicode strings, STACK_GLOBAL, empty tuple (or `args`), REDUCE, STOP
+        def u(s):
+            b = s.encode()
+            return b"\x8c" + bytes([len(b)]) + b
+        return b"\x80\x04" + u(module) + u(name) + b"\x93" + args + b"R."
+
+    payloads = [
+        stack_global("torch.serialization", "os.getcwd"),
+        stack_global("torch._utils", "_import_dotted_name", b"\x8c\x09os.getcwd\x85"),
+        stack_global("torch.nn.modules.module", "Module"),
+        stack_global("mogptk_amd.model", "os.getcwd"),
+        stack_global("mogptk_amd.model", "pickle"),                 # reachable through the package, not defined in it
+        stack_global("builtins", "eval", b"\x8c\x031+1\x85"),
+    ]
+    for raw in payloads:
+        pickletools.dis(raw, out=io.StringIO())                      # well-formed pickles
+        for cls in (compat._Unpickler, compat._NativeUnpickler):
+            with pytest.raises(pickle.UnpicklingError):
+                cls(io.BytesIO(raw)).load()
+    # a model of this package still saves and loads through the restricted loader
+    import mogptk_amd
+    rng = np.random.default_rng(0)
+    x = np.sort(rng.uniform(0, 10, 40))
+    ds = mogptk_amd.DataSet(mogptk_amd.Data(x, np.sin(x)), mogptk_amd.Data(x, np.cos(x)))
+    m = mogptk_amd.MOSM(ds, Q=2)
+    path = str(tmp_path / "native")
+    m.save(path)
+    m2 = mogptk_amd.LoadModel(path)
+    for a, b in zip(m.gpr.parameters(), m2.gpr.parameters()):
+        assert np.array_equal(a.data, b.data)
