@@ -564,7 +564,7 @@ void flow_build(int nb, int ob, FlowPlan& p) {
             vec.push_back(t);
         }
     }
-    std::vector<const std::vector<FlowTask>*> order = {&q[0], &q[1], &q[2], &vec, &q[3]};
+    std::vector<const std::vector<FlowTask>*> order = {&q[0], &q[1], &q[3], &q[2], &vec};     // crit, look2, semi (the Schur side feeds the chain), then the inverse's cycle, z / alpha
     for (int d = 2; d < no + 3; ++d) {
         if (d < no && !into[d].empty()) order.push_back(&into[d]);
         if (d - 3 >= 0 && d - 3 < no && !trail[d - 3].empty()) order.push_back(&trail[d - 3]);

@@ -720,34 +720,24 @@ class Model:
         return X, Mu, Lower, Upper
 
     def sample(self, X=None, n=None, prior=False, transformed=False):
-        """Samples of y at X (reference mogptk/model.py:692-734; the posterior's full covariance comes from the device).  Mirrors the reference
-        as written: `prior` is accepted and not used, and with n given the samples come as (n, data_points) while the channels are cut along
-        the FIRST axis -- n=None is the form that works for every shape there, and here."""
-        if X is None:
-            X = self.dataset.get_prediction_data()
-        else:
-            X = self.dataset._format_X(X)
-        x = self._to_kernel_format(X)
-        samples = self.gpr.sample_y(Z=x, n=n)
-        i = 0
-        Samples = []
-        for j in range(self.dataset.get_output_dims()):
-            N = X[j].shape[0]
+        """Draws of y at X (the behaviour of reference mogptk/model.py:692-734; the posterior's full covariance comes from the device).  As in
+        the reference `prior` is accepted and unused, and the stacked draws are cut into channels along their FIRST axis whatever n is."""
+        X = self.dataset.get_prediction_data() if X is None else self.dataset._format_X(X)
+        draws = np.asarray(self.gpr.sample_y(Z=self._to_kernel_format(X), n=n))
+        edges = np.cumsum([0] + [Xj.shape[0] for Xj in X])              # rows of each channel inside the stacked prediction inputs
+        per_channel = []
+        for j, Xj in enumerate(X):
+            block = draws[edges[j]:edges[j + 1]]
+            undo = None if transformed else self.dataset[j].Y_transformer.backward
             if n is None:
-                sample = np.squeeze(samples[i:i + N])
-                if not transformed:
-                    sample = self.dataset[j].Y_transformer.backward(sample, X[j])
-                Samples.append(sample)
-            else:
-                sample = samples[i:i + N, :]
-                for k in range(n):
-                    if not transformed:
-                        sample[:, k] = self.dataset[j].Y_transformer.backward(sample[:, k], X[j])
-                Samples.append(sample)
-            i += N
-        if self.dataset.get_output_dims() == 1:
-            return Samples[0]
-        return Samples
+                block = np.squeeze(block)
+                if undo is not None:
+                    block = undo(block, Xj)
+            elif undo is not None:
+                for k in range(n):                                       # one draw per column
+                    block[:, k] = undo(block[:, k], Xj)
+            per_channel.append(block)
+        return per_channel[0] if len(per_channel) == 1 else per_channel
 
     def K(self, X1, X2=None):
         """reference mogptk/model.py:666-700"""

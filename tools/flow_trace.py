@@ -9,7 +9,7 @@ os.environ.setdefault("MOGP_GRAD_PATH", "fused")
 import numpy as np
 from mogptk_amd import gpr, synth, _lib
 
-QN = ["crit", "look2", "invcrit", "vec", "semi"]
+QN = ["crit", "look2", "semi", "invcrit", "vec"]
 
 
 def main():
