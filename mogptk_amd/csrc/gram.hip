@@ -794,8 +794,10 @@ __device__ __forceinline__ void moment_term(double* mom, const double (&g)[4][4]
 
 // Two workgroups per CU wherever the registers allow it with a handful of spills (D = 1: the input-gradient variant needs 268 VGPRs
 // unconstrained, i.e. ONE wave per SIMD and nothing to hide its loads behind).
-template <int DT, bool DENSE, bool ZG, bool ENV, int OCC = (DT == 1 ? 2 : 1)>
-__global__ __launch_bounds__(256, OCC) void k_moments(MomentArgs a) {
+// (round 4: cutting the registers to three or four waves per SIMD -- __launch_bounds__(256, 3 / 4) -- costs 81 / 92 spilled VGPRs; the pressure is
+// the tile's adjoint block (g: 32 VGPRs), the staged factors and the staging prefetch, not the Horner chains)
+template <int DT, bool DENSE, bool ZG, bool ENV>
+__global__ __launch_bounds__(256, (DT == 1 ? 2 : 1)) void k_moments(MomentArgs a) {
     constexpr int DM = DT > 0 ? DT : MOGP_MAXD;
     constexpr int WM = 2 + (ENV ? 5 : 3) * DM;
     constexpr int RSTRIDE = 256 + 16;                        // one moment of all threads, +1 per 16 (the slice reads hit distinct banks)
@@ -989,13 +991,7 @@ __global__ __launch_bounds__(256) void k_gz_reduce(const double* __restrict__ gz
 template <bool DENSE, bool ZG, bool ENV>
 static int launch_moments_t(const MomentArgs& a, hipStream_t s) {
     switch (a.D) {
-        case 1: {
-            static const int occ = std::getenv("MOGP_MOM_OCC") ? std::atoi(std::getenv("MOGP_MOM_OCC")) : 2;      // experiment: waves per SIMD the registers are cut to
-            if (!DENSE && !ZG && !ENV && occ == 3) hipLaunchKernelGGL((k_moments<1, DENSE, ZG, ENV, 3>), dim3(a.ntiles), dim3(256), 0, s, a);
-            else if (!DENSE && !ZG && !ENV && occ == 4) hipLaunchKernelGGL((k_moments<1, DENSE, ZG, ENV, 4>), dim3(a.ntiles), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((k_moments<1, DENSE, ZG, ENV>), dim3(a.ntiles), dim3(256), 0, s, a);
-            break;
-        }
+        case 1: hipLaunchKernelGGL((k_moments<1, DENSE, ZG, ENV>), dim3(a.ntiles), dim3(256), 0, s, a); break;
         case 2: hipLaunchKernelGGL((k_moments<2, DENSE, ZG, ENV>), dim3(a.ntiles), dim3(256), 0, s, a); break;
         case 3: hipLaunchKernelGGL((k_moments<3, DENSE, ZG, ENV>), dim3(a.ntiles), dim3(256), 0, s, a); break;
         default: hipLaunchKernelGGL((k_moments<0, DENSE, ZG, ENV>), dim3(a.ntiles), dim3(256), 0, s, a); break;
