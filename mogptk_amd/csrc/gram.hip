@@ -691,7 +691,7 @@ int launch_gram(const GramArgs& a0, int ntiles, hipStream_t s) {
     if (a.W <= 0) a.W = 2 + 3 * a.D;
     static const int dbg = []() { const char* e = std::getenv("MOGP_GRAM_DBG"); return e ? std::atoi(e) : 0; }();
     a.dbg = dbg;
-    int rc = launch_phase_tables(a.ph, a.xr, a.ldxr, a.nrows, a.xc, a.ldxc, a.ncols, a.table, a.T, a.D, a.C, a.W, s);
+    int rc = a.phases_ready ? 0 : launch_phase_tables(a.ph, a.xr, a.ldxr, a.nrows, a.xc, a.ldxc, a.ncols, a.table, a.T, a.D, a.C, a.W, s);
     if (rc) return rc;
     static const int ncu = []() { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256; return pr.multiProcessorCount; }();
     const int grid = std::min(ntiles, 2 * ncu);              // persistent: two workgroups per CU (__launch_bounds__(256, 2))

@@ -492,6 +492,15 @@ namespace mogp { int ensure_system(mogp_model* m) {
         if ((rc = m->d_pair_start.ensure(m->pair_start.size()))) return rc;
         HIP_TRY(dev_upload(m->d_tiles.p, m->tiles.data(), m->tiles.size() * sizeof(GTile)));
         if ((rc = m->strip.build(m->tiles))) return rc;
+        for (const GTile& t : m->tiles) (t.c0 < 4 * MOGP_TILE ? m->tiles_head : m->tiles_tail).push_back(t);
+        if (!m->tiles_head.empty() && !m->tiles_tail.empty()) {
+            if ((rc = m->d_tiles_head.ensure(m->tiles_head.size()))) return rc;
+            if ((rc = m->d_tiles_tail.ensure(m->tiles_tail.size()))) return rc;
+            HIP_TRY(dev_upload(m->d_tiles_head.p, m->tiles_head.data(), m->tiles_head.size() * sizeof(GTile)));
+            HIP_TRY(dev_upload(m->d_tiles_tail.p, m->tiles_tail.data(), m->tiles_tail.size() * sizeof(GTile)));
+            if ((rc = m->strip_head.build(m->tiles_head))) return rc;
+            if ((rc = m->strip_tail.build(m->tiles_tail))) return rc;
+        }
         HIP_TRY(dev_upload(m->d_pair_start.p, m->pair_start.data(), m->pair_start.size() * sizeof(int)));
     }
     if ((rc = m->d_partial.ensure(m->tiles.size() * (size_t)std::max(m->T, 1) * (size_t)std::max(m->Wt, 1)))) return rc;
@@ -659,9 +668,26 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     ga.jitter_abs = jabs; ga.mirror = 0;
     ga.ev0 = prof_event(m, 7); ga.ev1 = prof_event(m, 8);
     m->strip.attach(ga);
-    if ((rc = launch_gram(ga, (int)m->tiles.size(), m->st))) return rc;
+    // Dataflow schedule: the first chain kernel and the first panel read the first 512 columns only, so the Gram matrix is built in two
+    // launches -- those columns on this stream, the rest on the bulk stream in front of the dataflow kernel, i.e. UNDERNEATH the first chain
+    // kernel (whose 240 us every workgroup of the dataflow kernel used to sit out after the whole Gram build).  MOGP_GRAM_SPLIT=0: one launch.
+    static const bool split_on = !(std::getenv("MOGP_GRAM_SPLIT") && std::atoi(std::getenv("MOGP_GRAM_SPLIT")) == 0);
+    const bool split = split_on && fuse_inverse && !factor_only && flow_enabled(m, m->k) && !m->tiles_head.empty() && !m->tiles_tail.empty() && m->st2;
+    if (split) {
+        GramArgs gh = ga, gt = ga;
+        gh.tiles = m->d_tiles_head.p; m->strip_head.attach(gh); gh.ev1 = nullptr;
+        gt.tiles = m->d_tiles_tail.p; m->strip_tail.attach(gt); gt.ev0 = nullptr; gt.phases_ready = 1;
+        if ((rc = launch_gram(gh, (int)m->tiles_head.size(), m->st))) return rc;
+        if ((rc = launch_pad_identity(m->k.A.p, Npad, N, Npad, m->st))) return rc;
+        if (!m->gram_ev) HIP_TRY(hipEventCreateWithFlags(&m->gram_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(m->gram_ev, m->st));
+        HIP_TRY(hipStreamWaitEvent(m->st2, m->gram_ev, 0));
+        if ((rc = launch_gram(gt, (int)m->tiles_tail.size(), m->st2))) return rc;       // spd_potri_flow enqueues the dataflow kernel behind it
+    } else {
+        if ((rc = launch_gram(ga, (int)m->tiles.size(), m->st))) return rc;
+        if ((rc = launch_pad_identity(m->k.A.p, Npad, N, Npad, m->st))) return rc;
+    }
     ga.ev0 = ga.ev1 = nullptr;
-    if ((rc = launch_pad_identity(m->k.A.p, Npad, N, Npad, m->st))) return rc;
     if ((rc = mark(m, 1))) return rc;
 
     m->k.want_vec = fuse_inverse && !factor_only;     // the dataflow schedule (flow.hip) also forms z = W y and alpha = W^T z
@@ -984,6 +1010,8 @@ int mogp_model_destroy(mogp_model* m) {
     m->d_x.release(); m->d_y.release(); m->d_table.release();
     m->d_noise.release(); m->d_dvar.release(); m->d_z.release(); m->d_alpha.release(); m->d_zz.release();
     m->d_partial.release(); m->d_moments.release(); m->d_diagG.release(); m->d_tiles.release(); m->d_pair_start.release(); m->strip.release(); m->strip_own.release();
+    m->d_tiles_head.release(); m->d_tiles_tail.release(); m->strip_head.release(); m->strip_tail.release();
+    if (m->gram_ev) { hipError_t r = hipEventDestroy(m->gram_ev); (void)r; m->gram_ev = nullptr; }
     m->d_chan_off.release(); m->d_flag.release(); m->d_info.release();
     m->d_xs.release(); m->d_Ksf.release(); m->d_Vt.release(); m->d_mu.release(); m->d_var.release(); m->d_kdiag.release();
     m->d_Kss.release(); m->d_ptiles.release();

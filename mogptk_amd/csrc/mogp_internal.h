@@ -82,6 +82,7 @@ struct GramArgs {
     const GTile* rest; int nrest;     // ... and everything else (diagonal, ragged and odd-aligned tiles) for the general kernel
     int dbg;               // measurement only (MOGP_GRAM_DBG): 1 = no stores, 2 = no terms (stores only)
     int tab_lds;           // set by the launcher: the term table is copied to LDS
+    int phases_ready;      // the phase workspace already holds this table's phases and block centres (an earlier launch of the same evaluation)
 };
 
 struct MomentArgs {

@@ -237,6 +237,12 @@ struct mogp_model {
     bool factor_only = false;           // the last factorisation stopped at L (prediction): no W, no alpha
     hipEvent_t pred_ev[2] = {nullptr, nullptr};      // fork / join of the prediction's side stream
     StripTiles strip, strip_own;        // the same tile lists (all / owned) split for the Gram strip kernel
+    // the Gram build in two launches for the dataflow schedule: the tiles that start in the first 512 columns (all the first chain kernel and the
+    // first panel read) and the rest, which is then built on the bulk stream UNDERNEATH the first chain kernel
+    std::vector<GTile> tiles_head, tiles_tail;
+    DevBuf<GTile> d_tiles_head, d_tiles_tail;
+    StripTiles strip_head, strip_tail;
+    hipEvent_t gram_ev = nullptr;
     DevBuf<int> d_pair_start_own;
     int own_rank = -1, own_n = 0;       // (rank, nranks) the owned lists were built for
     DevBuf<double> sh_send, sh_recv;
