@@ -696,6 +696,13 @@ int spd_potri_flow(mogp_model* m, Spd& w) {
         if ((rc = launch_chain(w.A.p, ld, k0, k1 - k0, w.invd.p, w.logdet.p, m->d_info.p, 0, w.Wm.p + (int64_t)k0 * MOGP_TILE * (ld + 1), ld,
                                w.chain_flags.p + (size_t)kb * MOGP_CHAIN_FLAGS, ferr, priv, &cf))) return rc;
     }
+    // behind the last chain kernel the reserved CUs have nothing left to do while a quarter of the tile work is still queued: a second, small
+    // instance of the dataflow kernel on the private stream takes tasks from the same queues until they are empty (MOGP_FLOW_TAIL=0: off)
+    static const bool tail_on = !(std::getenv("MOGP_FLOW_TAIL") && std::atoi(std::getenv("MOGP_FLOW_TAIL")) == 0);
+    if (tail_on && m->ctx->ncu_reserved > 0) {
+        hipLaunchKernelGGL(k_flow, dim3(wg_per_cu * m->ctx->ncu_reserved), dim3(FL_NT), FL_LDS_BYTES, priv, g);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(e_chain, priv));
     HIP_TRY(hipStreamWaitEvent(crit, e_flow, 0));
     HIP_TRY(hipStreamWaitEvent(crit, e_chain, 0));
