@@ -604,11 +604,12 @@ int launch_flow_alpha_sum(const Spd& w, double* alpha, hipStream_t st) {
 
 // ---- the schedule -----------------------------------------------------------------------------------------------------------------------
 // MOGP_FLOW=0: the stream schedule of potri.hip everywhere.  MOGP_FLOW_MIN=n: the smallest number of 128-row tiles that takes the dataflow
-// form (below that an evaluation is a few chain kernels long and the launches it replaces are few).
+// form (below that an evaluation is bound by its chain of a few kernels, and the 128 x 128 tiles the dataflow kernel uses for the two
+// products between chain kernels take longer than the 64-row tiles of the stream schedule on the reserved CUs).
 bool flow_enabled(const mogp_model* m, const Spd& w) {
     const char* eo = std::getenv("MOGP_FLOW");                 // read per call: tests switch it inside one process
     const char* en = std::getenv("MOGP_FLOW_MIN");
-    const int on = eo ? std::atoi(eo) : 1, nmin = en ? std::atoi(en) : 24;
+    const int on = eo ? std::atoi(eo) : 1, nmin = en ? std::atoi(en) : 44;        // measured: 40 tile rows 6.04 vs 5.68 ms (streams win), 48: 7.03 vs 7.45, 56: 8.56 vs 9.55, 64: 11.0 vs 12.7
     if (!on || m->no_flow || !chain_enabled(m) || !m->ctx->st_priv) return false;
     if (m->kinv_sparse && &w == &m->k) return false;          // a planned (partial) inverse: the stream schedule knows how
     return w.nb >= nmin && w.nb <= 0xfff0;
