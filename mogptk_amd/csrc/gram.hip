@@ -951,6 +951,180 @@ __global__ __launch_bounds__(256, (DT == 1 ? 2 : 1)) void k_moments(MomentArgs a
     }
 }
 
+// ---- exact mode, D = 1, no envelope: the persistent, software-pipelined form (round 4) -------------------------------------------------------
+// k_moments above is one workgroup per tile: descriptor -> inputs and adjoint entries -> staging are three DEPENDENT memory round trips (12 of
+// the 16 us a tile takes), two tiles in flight per CU, the VALUs busy half the time.  Here one 512-thread workgroup per CU walks over tiles
+// blockIdx.x, + gridDim.x, ...: everything tile i + 1 needs from memory (its 64 x 64 block of Kj^-1: 8 entries per thread, alpha, inputs, phase
+// factors; the descriptor came one tile earlier still) is REQUESTED BEFORE tile i's arithmetic and lands under it -- in registers: with one
+// workgroup per CU a wave may use 256 VGPRs, which the one-tile-per-workgroup form could not afford.  A thread owns 2 x 4 entries, accumulates
+// the five moments of every term over the whole tile in registers, and the workgroup reduces them ONCE per tile (wave butterflies, then eight
+// partial sums through LDS in wave order: fixed order, bit-reproducible) instead of once per term.  Same arithmetic per entry as moment_term.
+template <int N>
+__device__ __forceinline__ void mx_term(double (&mom)[5], const double (&g)[2][4], const double (&p)[2], const double (&q)[4], double V, double s,
+                                        const double (&cu)[2], const double (&su)[2], const double (&cw)[4], const double (&sw)[4]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const double vp = V * p[m];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const double u = (p[m] - q[n]) + s;
+            double e;
+            if (N > 0) e = exp_taylor<N>(vp * q[n]);
+            else e = exp(-0.5 * (V * u) * u);
+            const double ge = g[m][n] * e;
+            const double kc = ge * fma(cu[m], cw[n], su[m] * sw[n]);
+            const double ks = ge * fma(su[m], cw[n], -cu[m] * sw[n]);
+            mom[0] += kc;
+            mom[1] += ks;
+            const double uk = u * kc;
+            mom[2] = fma(u, uk, mom[2]);
+            mom[3] += uk;
+            mom[4] = fma(u, ks, mom[4]);
+        }
+    }
+}
+
+#define MX_T 8                                             // terms at most (registers: 5 moments per term)
+struct MxFetch {                                           // what a thread requests for a tile one iteration ahead
+    double kv[2][4], ar[2], ac[4], xr[2], xc[4];
+    StageItem<1> it[2];
+    double cr, hr, cc, hc;
+};
+
+template <int TT>
+__global__ __launch_bounds__(512, 2) void k_moments_x(MomentArgs a) {
+    const int T = a.T, W = a.W, tid = threadIdx.x;
+    const int cg = tid & 15, rg = tid >> 4;                  // rows 2 rg, 2 rg + 1; columns 4 cg .. 4 cg + 3
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int st_which = wave & 1, st_tb = wave >> 1, st_pnt = lane;      // staging: wave -> (rows | columns) of the terms wave / 2 and wave / 2 + 4
+    __shared__ TileLds<1> Lb[2];
+    constexpr int MXS = 512 + 32;                          // one moment of all threads, +1 per 16 (the slice reads hit distinct banks)
+    __shared__ double s_red[TT * 5 * MXS];
+    const PhaseView v = phase_view(a.ph.ws, a.C, T, 1, a.ldx, a.ldx);
+    const int stride = gridDim.x;
+    int tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+
+    auto fetch = [&](MxFetch& F, const GTile& tl) {
+        F.cr = v.rcen[tl.r0]; F.hr = v.rhalf[tl.r0]; F.cc = v.ccen[tl.c0]; F.hc = v.chalf[tl.c0];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int64_t r = tl.r0 + min(2 * rg + m, tl.nr - 1);
+            F.ar[m] = a.alpha[r];
+            F.xr[m] = a.x[r];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int64_t c = tl.c0 + min(4 * cg + n, tl.nc - 1);
+                const int64_t hi = r > c ? r : c, lo = r > c ? c : r;      // the lower triangle holds the matrix
+                F.kv[m][n] = a.kinv[hi * a.ld + lo];
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int64_t c = tl.c0 + min(4 * cg + n, tl.nc - 1);
+            F.ac[n] = a.alpha[c];
+            F.xc[n] = a.x[c];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (st_tb + 4 * k < T) stage_item_load<1>(F.it[k], st_which, st_tb + 4 * k, st_pnt, tl, 1, a.C, T, 0, v, a.x, a.ldx, a.x, a.ldx);
+    };
+
+    GTile tl = a.tiles[tile];
+    GTile tl1 = a.tiles[min(tile + stride, a.ntiles - 1)];
+    MxFetch F;
+    fetch(F, tl);
+    int buf = 0;
+    while (true) {
+        TileLds<1>& L = Lb[buf];
+        const GTile cur = tl;
+        const double* tab = a.table + (size_t)cur.pair * T * W;
+        double* outp = a.partial + (size_t)tile * T * W;
+        // ---- this tile out of the registers its requests landed in ----
+        TileCtx<1> X;
+        X.cr[0] = F.cr; X.hr[0] = F.hr; X.cc[0] = F.cc; X.hc[0] = F.hc;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (st_tb + 4 * k < T) stage_item_compute<1, false>(L, F.it[k], X, tab, W, st_which, st_tb + 4 * k, st_pnt, 1, 0);
+        double g[2][4], p[2], q[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) q[n] = F.xc[n] - F.cc;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            p[m] = F.xr[m] - F.cr;
+            const int lr = 2 * rg + m;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int lc = 4 * cg + n;
+                double w = 0.0;
+                if (lr < cur.nr && lc < cur.nc) {
+                    w = 2.0;
+                    if (cur.flags & GT_DIAG) w = lr > lc ? 2.0 : (lr == lc ? 1.0 : 0.0);
+                }
+                g[m][n] = w * 0.5 * (F.ar[m] * F.ac[n] - a.kinv_sign * F.kv[m][n]);
+            }
+        }
+        // ---- the next tile's requests go out now, under this tile's arithmetic ----
+        const int nxt = tile + stride;
+        const bool more = nxt < a.ntiles;
+        if (more) {
+            tl = tl1;
+            tl1 = a.tiles[min(nxt + stride, a.ntiles - 1)];
+            fetch(F, tl);
+        }
+        // LDS-only barrier: __syncthreads() would also wait for the requests just issued -- the whole point is that they stay in flight
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the staged factors of this tile are in L
+        double mom[TT][5];
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int w = 0; w < 5; ++w) mom[t][w] = 0.0;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            if (t >= T) break;
+            const int deg = __builtin_amdgcn_readfirstlane(L.deg[t]);
+            if (deg == GT_SKIP) continue;
+            const double V = L.V[t][0], sft = L.s[t][0];
+            double cu[2], su[2], cw[4], sw[4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) { cu[m] = L.cu[t][2 * rg + m]; su[m] = L.su[t][2 * rg + m]; }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) { cw[n] = L.cw[t][4 * cg + n]; sw[n] = L.sw[t][4 * cg + n]; }
+            switch (deg) {
+                case 4: mx_term<4>(mom[t], g, p, q, V, sft, cu, su, cw, sw); break;
+                case 6: mx_term<6>(mom[t], g, p, q, V, sft, cu, su, cw, sw); break;
+                case 8: mx_term<8>(mom[t], g, p, q, V, sft, cu, su, cw, sw); break;
+                case 11: mx_term<11>(mom[t], g, p, q, V, sft, cu, su, cw, sw); break;
+                case 14: mx_term<14>(mom[t], g, p, q, V, sft, cu, su, cw, sw); break;
+                default: mx_term<0>(mom[t], g, p, q, V, sft, cu, su, cw, sw); break;
+            }
+        }
+        // ---- one reduction per tile through LDS, fixed order: thread (w, i) adds the values of threads 16 i .. 16 i + 15 of moment w, a
+        // 5-step butterfly over i finishes (32 slices)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            if (t >= T) break;
+#pragma unroll
+            for (int w = 0; w < 5; ++w) s_red[(t * 5 + w) * MXS + tid + (tid >> 4)] = mom[t][w];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int e = tid; e < T * 5 * 32; e += 512) {
+            const int w = e >> 5, i = e & 31;
+            const double* src = s_red + w * MXS + i * 17;
+            double x = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x += src[k];
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+            if (i == 0) outp[w] = x;                         // (a skipped term left zeros)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // s_red is read: the next tile may write it
+        if (!more) break;
+        tile = nxt;
+        buf ^= 1;                                            // the other staging buffer: its last readers passed the barrier above
+    }
+}
+
 // out[d][first + pnt] += sum over the `nminor` slots of block b (slot layout [block][minor][d][64]), in slot order: four interleaved partial
 // sums per point, combined as (s0 + s1) + (s2 + s3).  Slots no tile wrote are zero (the scratch is cleared per launch).
 __global__ __launch_bounds__(256) void k_gz_reduce(const double* __restrict__ gzp, int nminor, int D, const int* __restrict__ blk,
@@ -1011,6 +1185,14 @@ int launch_moments(const MomentArgs& a0, hipStream_t s) {
     if (rc) return rc;
     if (a.G == nullptr) {
         if (a.ev0) HIP_TRY(hipEventRecord(a.ev0, s));
+        // D = 1 without an envelope, every row this rank's own: the persistent pipelined kernel (MOGP_MOM_X=0: the tile-per-workgroup one)
+        static const bool mx_on = !(std::getenv("MOGP_MOM_X") && std::atoi(std::getenv("MOGP_MOM_X")) == 0);
+        if (mx_on && !env && a.D == 1 && a.W == 5 && a.T <= 4 && a.row_mod <= 1 && a.xc == nullptr) {
+            static const int ncu = []() { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256; return pr.multiProcessorCount; }();
+            hipLaunchKernelGGL(k_moments_x<4>, dim3(std::min(a.ntiles, ncu)), dim3(512), 0, s, a);      // (the reduction staging of eight terms does not fit in LDS)
+            HIP_TRY(hipGetLastError());
+            rc = 0;
+        } else
         rc = env ? launch_moments_t<false, false, true>(a, s) : launch_moments_t<false, false, false>(a, s);
         if (!rc && a.ev1) HIP_TRY(hipEventRecord(a.ev1, s));
         return rc;
