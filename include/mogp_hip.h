@@ -237,7 +237,11 @@ int  mogp_model_schedule(mogp_model* m, int* flags);
  *                  dep counter x 4, needed value x 4, counter bumped x 2 (-1: none)]
  *                 buffers 0 Schur matrix, 1 panels L, 2 running product Wt, 3 W = L^-1, 4 inverse; var bits 0-1: 0 = C (+)= a A B^T (both
  *                 k-contiguous), 1 = a A B (B k-major), 2 = a A^T B (both k-major); bit 2: overwrite (beta = 0); bit 3: a = -1
- *   chain kernel: [-1, key, block, first tile, tiles, 0.., ndep (0 / 1), dep counter, 0, 0, 0, needed value, 0, 0, 0, counter bumped, by how much] */
+ *   launches of the private stream, in stream order (one at a time), three per outer block:
+ *     chain kernel          [-1, key, block, first tile k0, tiles nk, 0 .., counter bumped, by how much]                 (columns 22, 23)
+ *     mini-panel            [-2, key, block, k0, nk, first row tile k1, row tiles na, .., ndep, dep counter x 4, needed value x 4,
+ *                            first counter bumped (one per row tile, consecutive), by how much each]   L[k1.., K] = A[k1.., K] W_KK^T
+ *     next-diagonal update  [-3, key, block, k0, nk, k1, na, .., ndep, dep counter, .., needed value, .., -1, 0]          A[k1.., k1..] -= P P^T */
 int  mogp_flow_plan(int nb, int64_t* out, int64_t cap, int64_t* count);
 /* Time stamps (100 MHz device wall clock) of the last mogp_exact_eval that ran as dataflow with MOGP_FLOW_TRACE=1 in the environment:
  * 6 numbers per tile task in the row order of mogp_flow_plan's tile tasks (the workgroup starts looking for work, has taken the task, its k loop

@@ -168,6 +168,8 @@ struct FlowArgs {
     unsigned* flags;                  // dependency counters, then the queue heads, then the error word (all zero at the start of an evaluation)
     int nq, ncas, base_heads, base_err;
     unsigned nap_max;                 // an idle workgroup sleeps 2^1 .. 2^nap_max microseconds between looks
+    int claim_one;                    // nothing ready: take from ONE queue per look (the highest priority with a free slot) instead of from all
+    int refill;                       // a taken eager slot is refilled at once (0: only when the workgroup finds nothing ready)
     const double* vy; double* vz; double* vzz; double* vpart;         // z = W y and alpha = W^T z as tasks (null: those tasks only count)
     int64_t npad;
     unsigned long long* info;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                             ok = 1; res = qbase + pend;
                             // refill the slot at once (the answer is not needed before the next look) -- except near the end of the
                             // queue, where a task held by a busy workgroup is a task an idle one cannot take
-                            if (pend + 2 * (int)gridDim.x < qsize) {
+                            if (g.refill && pend + 2 * (int)gridDim.x < qsize) {
                                 const unsigned hh = __hip_atomic_fetch_add(heads + myq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 if (hh < (unsigned)qsize) pend = (int)hh; else { pend = -1; exhausted = true; }
                             } else pend = -1;
@@ -323,7 +325,12 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                 }
                 // nothing this workgroup holds or may take is ready: take what can be taken eagerly
                 bool took = false;
-                if (is_eager && pend < 0 && !exhausted) {
+                bool want = is_eager && pend < 0 && !exhausted;
+                if (g.claim_one) {                                             // one queue per look, the highest priority first: a workgroup then holds at
+                    const unsigned long long mw = __ballot(want);              // most one READY task it is not running (held ready tasks are tasks idle
+                    want = want && mw && lane == __ffsll((long long)mw) - 1;   // workgroups cannot take)
+                }
+                if (want) {
                     const unsigned hh = __hip_atomic_fetch_add(heads + myq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (hh < (unsigned)qsize) { pend = (int)hh; took = true; } else exhausted = true;
                 }
@@ -405,7 +412,7 @@ namespace {
 // left-looking on the inverse side, so that nothing of it is due before its row block is) | chain(r) | T6(r): the final row block r of W |
 // panel(r) | update(r) (right-looking on the Schur side) | T9(r) ].  key = FLOW_KEY_STEP r + position inside the superstep.
 enum { PH_INTO = 0, PH_CHAIN = 600, PH_T6 = 601, PH_PANEL = 602, PH_UPDATE = 603, PH_T9 = 604, PH_ZROW = 605, PH_APART = 606 };
-enum { Q_CRIT = 0, Q_LOOK2 = 1, Q_INVCRIT = 2, Q_SEMI = 3, Q_FIRST_DEADLINE = 4 };
+enum { Q_LOOK2 = 0, Q_INVCRIT = 1, Q_SEMI = 2 };
 enum { BUF_A = 0, BUF_L = 1, BUF_WT = 2, BUF_WM = 3, BUF_B = 4 };
 }
 
@@ -439,7 +446,7 @@ void flow_build(int nb, int ob, FlowPlan& p) {
     // queues 0 .. 3 as named above; then, by the superstep d that needs them (earliest deadline first): INTO[d] = the running product's updates
     // into row block d from the source blocks <= d - 2, and TRAIL[d - 3] = the trailing update of panel d - 3 right of its two look-ahead
     // column blocks (its first columns are block d's); last the accumulations of the inverse, which nothing waits for.
-    std::vector<FlowTask> q[4], acc, vec;
+    std::vector<FlowTask> q[3], acc, vec;
     std::vector<std::vector<FlowTask>> into(no), trail(no);
     auto mk = [&](int b, int phase, int var, int kt) {
         FlowTask t{};
@@ -456,6 +463,12 @@ void flow_build(int nb, int ob, FlowPlan& p) {
     const int KB = MOGP_TILE / FL_BK;                 // k blocks per tile
     double tiles_k = 0.0;                             // sum over tasks of k blocks
 
+    // The two products a chain kernel waits for -- the panel rows of block b + 1 ("mini-panel") and the last update of its diagonal block -- are NOT
+    // tasks: they run as launches on the private stream between the chain kernels, on 64-row tiles on the reserved CUs as in potri.hip (as
+    // 128 x 128 tasks next to the bulk work they took 230 us per block against 140 us there, and the chain phase is where workgroups wait).
+    // The mini-panel is 64 x 128 tiles: PN(b, i) of its rows counts two tiles per column tile.
+    auto crit_row = [&](int b, int i) { return i >= k1(b) && i < std::min(nb, k1(b) + ob); };
+    auto pn_need = [&](int b, int i) { return (unsigned)((crit_row(b, i) ? 2 : 1) * nk(b)); };
     // panel tile (b, i, c): L[i][k0 + c] = sum_{cc <= c} A[i][k0 + cc] W_bb[c][cc]^T
     auto panel = [&](int b, int i, int c, bool prio) {
         FlowTask t = mk(b, PH_PANEL, 0 | 4 | (prio ? 16 : 0), KB * (c + 1));
@@ -470,8 +483,8 @@ void flow_build(int nb, int ob, FlowPlan& p) {
     auto update = [&](int b, int i, int j, bool prio) {
         FlowTask t = mk(b, PH_UPDATE, 0 | 8 | (prio ? 16 : 0), KB * nk(b));
         opA(t, BUF_L, i, k0(b)); opB(t, BUF_L, j, k0(b)); opC(t, BUF_A, i, j);
-        dep(t, PN(b, i), (unsigned)nk(b));
-        if (j != i) dep(t, PN(b, j), (unsigned)nk(b));
+        dep(t, PN(b, i), pn_need(b, i));
+        if (j != i) dep(t, PN(b, j), pn_need(b, j));
         dep(t, S(i, j), (unsigned)b);
         t.sig[0] = S(i, j);
         t.sig[1] = blk(i) == blk(j) ? DG(blk(j)) : R(i, blk(j));
@@ -482,7 +495,7 @@ void flow_build(int nb, int ob, FlowPlan& p) {
     auto t7 = [&](int b, int i, int c) {
         FlowTask t = mk(blk(i), PH_INTO + 2 * b, 1 | 4 | 8, KB * (nk(b) - c));
         opA(t, BUF_L, i, k0(b) + c); opB(t, BUF_WM, k0(b) + c, k0(b) + c); opC(t, BUF_WT, i, k0(b) + c);
-        dep(t, PN(b, i), (unsigned)nk(b));
+        dep(t, PN(b, i), pn_need(b, i));
         t.sig[0] = WT(i, k0(b) + c); t.sig[1] = WC(blk(i), k0(b) + c);
         tiles_k += t.kt;
         return t;
@@ -491,7 +504,7 @@ void flow_build(int nb, int ob, FlowPlan& p) {
     auto t8 = [&](int b, int i, int j) {
         FlowTask t = mk(blk(i), PH_INTO + 2 * b + 1, 1 | 8, KB * nk(b));
         opA(t, BUF_L, i, k0(b)); opB(t, BUF_WM, k0(b), j); opC(t, BUF_WT, i, j);
-        dep(t, PN(b, i), (unsigned)nk(b));
+        dep(t, PN(b, i), pn_need(b, i));
         dep(t, WF(b, j), (unsigned)nk(b));
         dep(t, WT(i, j), (unsigned)(b - blk(j)));
         t.sig[0] = WT(i, j); t.sig[1] = WC(blk(i), j);
@@ -525,10 +538,14 @@ void flow_build(int nb, int ob, FlowPlan& p) {
     for (int b = 0; b < no; ++b) {
         const int a0 = k1(b), a1 = std::min(nb, a0 + ob), a2 = std::min(nb, a1 + ob);        // rows of block b+1: [a0, a1), of block b+2: [a1, a2)
         FlowPlan::Chain& c = p.chain[b];
-        c.wait_idx = DG(b); c.wait_val = (uint32_t)(nk(b) * (nk(b) + 1) / 2 * b); c.done_idx = CH(b); c.expect = chain_wgs(b);
-        // Q_CRIT: what chain(b + 1) waits for
-        for (int i = a0; i < a1; ++i) for (int cc = 0; cc < nk(b); ++cc) q[Q_CRIT].push_back(panel(b, i, cc, true));
-        for (int i = a0; i < a1; ++i) for (int j = a0; j <= i; ++j) q[Q_CRIT].push_back(update(b, i, j, true));
+        c = FlowPlan::Chain{};
+        c.done_idx = CH(b); c.expect = chain_wgs(b);
+        // the mini-panel reads A[rows of block b + 1][columns of block b]: every update of those tiles (from the panels before b) must be in
+        c.t1_nwait = 0;
+        for (int i = a0; i < a1 && b > 0; ++i) { c.t1_widx[c.t1_nwait] = R(i, b); c.t1_wval[c.t1_nwait] = (uint32_t)(nk(b) * b); ++c.t1_nwait; }
+        c.t1_sig_base = PN(b, a0); c.t1_sig_per_row = 2u * (uint32_t)nk(b);
+        // the next-diagonal update is the LAST update of block b + 1's diagonal block: the b earlier ones (dataflow tasks) first
+        if (a1 > a0) { const int n1 = a1 - a0; c.t2_widx = DG(b + 1); c.t2_wval = (uint32_t)(n1 * (n1 + 1) / 2 * b); }
         // Q_LOOK2: what the critical tasks of block b + 1 wait for
         for (int i = a1; i < a2; ++i) for (int cc = 0; cc < nk(b); ++cc) q[Q_LOOK2].push_back(panel(b, i, cc, true));
         for (int i = a1; i < a2; ++i) for (int j = a0; j < a1; ++j) q[Q_LOOK2].push_back(update(b, i, j, true));
@@ -564,7 +581,7 @@ void flow_build(int nb, int ob, FlowPlan& p) {
             vec.push_back(t);
         }
     }
-    std::vector<const std::vector<FlowTask>*> order = {&q[0], &q[1], &q[3], &q[2], &vec};     // crit, look2, semi (the Schur side feeds the chain), then the inverse's cycle, z / alpha
+    std::vector<const std::vector<FlowTask>*> order = {&q[Q_LOOK2], &q[Q_SEMI], &q[Q_INVCRIT], &vec};      // look-ahead, the rest of the Schur side next to the chain, then the inverse's cycle, z / alpha
     for (int d = 2; d < no + 3; ++d) {
         if (d < no && !into[d].empty()) order.push_back(&into[d]);
         if (d - 3 >= 0 && d - 3 < no && !trail[d - 3].empty()) order.push_back(&trail[d - 3]);
@@ -604,12 +621,13 @@ int launch_flow_alpha_sum(const Spd& w, double* alpha, hipStream_t st) {
 
 // ---- the schedule -----------------------------------------------------------------------------------------------------------------------
 // MOGP_FLOW=0: the stream schedule of potri.hip everywhere.  MOGP_FLOW_MIN=n: the smallest number of 128-row tiles that takes the dataflow
-// form (below that an evaluation is bound by its chain of a few kernels, and the 128 x 128 tiles the dataflow kernel uses for the two
-// products between chain kernels take longer than the 64-row tiles of the stream schedule on the reserved CUs).
+// form.  With the two products between chain kernels as launches on the private stream (64-row tiles on the reserved CUs, as in the stream
+// schedule) the dataflow form is the faster one at every size measured: 900 points 1.07 vs 1.11 ms, 1700: 1.73 vs 1.92, 4097: 4.02 vs 4.37,
+// 8192: 10.5 vs 12.8.
 bool flow_enabled(const mogp_model* m, const Spd& w) {
     const char* eo = std::getenv("MOGP_FLOW");                 // read per call: tests switch it inside one process
     const char* en = std::getenv("MOGP_FLOW_MIN");
-    const int on = eo ? std::atoi(eo) : 1, nmin = en ? std::atoi(en) : 44;        // measured: 40 tile rows 6.04 vs 5.68 ms (streams win), 48: 7.03 vs 7.45, 56: 8.56 vs 9.55, 64: 11.0 vs 12.7
+    const int on = eo ? std::atoi(eo) : 1, nmin = en ? std::atoi(en) : 8;          // (two outer blocks: below that there is nothing to overlap)
     if (!on || m->no_flow || !chain_enabled(m) || !m->ctx->st_priv) return false;
     if (m->kinv_sparse && &w == &m->k) return false;          // a planned (partial) inverse: the stream schedule knows how
     return w.nb >= nmin && w.nb <= 0xfff0;
@@ -667,6 +685,8 @@ int spd_potri_flow(mogp_model* m, Spd& w) {
     g.nq = p.nq; g.ncas = FLOW_NCAS; g.base_heads = p.base_heads; g.base_err = p.base_err; g.info = m->d_info.p;
     g.trace = want_trace ? w.flow_trace.p : nullptr;
     g.npad = ld;
+    { const char* e = std::getenv("MOGP_FLOW_REFILL"); g.refill = e ? std::atoi(e) : 0; }
+    { const char* e = std::getenv("MOGP_FLOW_CLAIM1"); g.claim_one = e ? std::atoi(e) : 0; }
     { const char* e = std::getenv("MOGP_FLOW_NAP"); g.nap_max = e ? (unsigned)std::max(0, std::atoi(e)) : 4u; }
     w.vec_done = false;
     if (w.want_vec && w.vec_y && w.vec_z && w.vec_zz && w.vec_part) {       // z = W y, alpha = W^T z as tasks of the same kernel
@@ -689,13 +709,34 @@ int spd_potri_flow(mogp_model* m, Spd& w) {
 
     unsigned* ferr = w.flow_flags.p + p.base_err;        // ONE error word for both kernels: whoever times out first stops the other
     for (int kb = 0; kb < nouter; ++kb) {
-        const int k0 = kb * ob, k1 = std::min(k0 + ob, nb);
+        const int k0 = kb * ob, k1 = std::min(k0 + ob, nb), nk = k1 - k0, na = std::min(ob, nb - k1);
+        const FlowPlan::Chain& pc = p.chain[kb];
         ChainFlow cf{};
-        cf.wait_flag = p.chain[kb].wait_val ? w.flow_flags.p + p.chain[kb].wait_idx : nullptr; cf.wait_val = p.chain[kb].wait_val;
-        cf.done_flag = w.flow_flags.p + p.chain[kb].done_idx; cf.write_through = 1;
+        cf.done_flag = w.flow_flags.p + pc.done_idx; cf.write_through = 1;       // (its diagonal block is complete in stream order: the update below)
         cf.trace = want_trace ? w.flow_trace.p + FLOW_TRACE_W * p.tasks.size() + 4 * (size_t)kb : nullptr;
-        if ((rc = launch_chain(w.A.p, ld, k0, k1 - k0, w.invd.p, w.logdet.p, m->d_info.p, 0, w.Wm.p + (int64_t)k0 * MOGP_TILE * (ld + 1), ld,
+        if ((rc = launch_chain(w.A.p, ld, k0, nk, w.invd.p, w.logdet.p, m->d_info.p, 0, w.Wm.p + (int64_t)k0 * MOGP_TILE * (ld + 1), ld,
                                w.chain_flags.p + (size_t)kb * MOGP_CHAIN_FLAGS, ferr, priv, &cf))) return rc;
+        if (na <= 0) continue;
+        // mini-panel  L[rows of block kb + 1][K] = A[rows][K] W_KK^T  on 64 x 128 tiles: waits for those rows' last updates from the dataflow
+        // kernel, leaves with write-through stores and reports per row (the look-ahead tasks and the inverse's cycle read it)
+        GemmArgs t1{};
+        t1.A = w.A.p + (int64_t)k1 * MOGP_TILE * ld + (int64_t)k0 * MOGP_TILE; t1.lda = ld; t1.a_kmajor = 0;
+        t1.B = w.Wm.p + (int64_t)k0 * MOGP_TILE * (ld + 1); t1.ldb = ld; t1.b_kmajor = 0;
+        t1.C = w.Lm.p + (int64_t)k1 * MOGP_TILE * ld + (int64_t)k0 * MOGP_TILE; t1.ldc = ld; t1.alpha = 1.0; t1.beta = 0.0;
+        t1.mode = GM_KHI_J; t1.small = 1; t1.mt = 2 * na; t1.nt = nk; t1.K = nk * MOGP_TILE;
+        t1.fl_flags = w.flow_flags.p; t1.fl_nwait = pc.t1_nwait;
+        for (int k = 0; k < pc.t1_nwait; ++k) { t1.fl_widx[k] = pc.t1_widx[k]; t1.fl_wval[k] = pc.t1_wval[k]; }
+        t1.fl_wt = 1; t1.fl_sig = 1; t1.fl_sig_base = pc.t1_sig_base; t1.fl_sig_shift = 1; t1.fl_err = ferr; t1.sk_info = m->d_info.p;
+        if ((rc = launch_gemm(t1, priv))) return rc;
+        // next-diagonal update  D_{K+1,K+1} -= P P^T  on 64 x 64 tiles: the block's last update -- the earlier ones are dataflow tasks
+        GemmArgs t2{};
+        t2.A = t1.C; t2.lda = ld; t2.a_kmajor = 0; t2.B = t1.C; t2.ldb = ld; t2.b_kmajor = 0;
+        t2.C = w.A.p + (int64_t)k1 * MOGP_TILE * (ld + 1); t2.ldc = ld; t2.alpha = -1.0; t2.beta = 1.0;
+        t2.mode = GM_RECT_LOWER; t2.small = 2; t2.mt = 2 * na; t2.nt = 2 * na; t2.K = nk * MOGP_TILE;
+        t2.fl_flags = w.flow_flags.p; t2.fl_nwait = pc.t2_wval ? 1 : 0; t2.fl_widx[0] = pc.t2_widx; t2.fl_wval[0] = pc.t2_wval;
+        t2.fl_err = ferr; t2.sk_info = m->d_info.p;
+        if ((rc = launch_gemm(t2, priv))) return rc;
+        m->gemm_flops += gemm_flops(t1, nullptr) + gemm_flops(t2, nullptr);
     }
     // behind the last chain kernel the reserved CUs have nothing left to do while a quarter of the tile work is still queued: a second, small
     // instance of the dataflow kernel on the private stream takes tasks from the same queues until they are empty (MOGP_FLOW_TAIL=0: off)
@@ -738,16 +779,29 @@ extern "C" int mogp_flow_plan(int nb, int64_t* out, int64_t cap, int64_t* count)
     if (nb <= 0 || nb > 4096 || !count) return fail(MOGP_EINVAL, "mogp_flow_plan: bad argument");
     FlowPlan p;
     flow_build(nb, 4, p);
-    const int64_t W = 24, rows = (int64_t)p.tasks.size() + p.nouter;
+    int nlaunch = 0;
+    for (int b = 0; b < p.nouter; ++b) nlaunch += (std::min(nb, b * 4 + 4) < nb) ? 3 : 1;
+    const int64_t W = 24, rows = (int64_t)p.tasks.size() + nlaunch;
     *count = rows;
     if (!out) return MOGP_OK;
     if (cap < rows * W) return fail(MOGP_EINVAL, "mogp_flow_plan: the output holds fewer than 24 * count numbers");
     int64_t* o = out;
-    for (int b = 0; b < p.nouter; ++b, o += W) {          // the chain kernels: queue -1
+    for (int b = 0; b < p.nouter; ++b) {                  // the private stream, in its order: chain kernel (-1), mini-panel (-2), next-diagonal update (-3)
+        const int k0 = b * 4, k1 = std::min(nb, k0 + 4), na = std::min(4, nb - k1);
+        const FlowPlan::Chain& c = p.chain[b];
         std::fill(o, o + W, 0);
-        const int k0 = b * 4, k1 = std::min(nb, k0 + 4);
-        o[0] = -1; o[1] = (int64_t)b * FLOW_KEY_STEP + PH_CHAIN; o[2] = b; o[3] = k0; o[4] = k1 - k0; o[13] = p.chain[b].wait_val ? 1 : 0;
-        o[14] = p.chain[b].wait_idx; o[18] = p.chain[b].wait_val; o[22] = p.chain[b].done_idx; o[23] = p.chain[b].expect;
+        o[0] = -1; o[1] = (int64_t)b * FLOW_KEY_STEP + PH_CHAIN; o[2] = b; o[3] = k0; o[4] = k1 - k0; o[22] = c.done_idx; o[23] = c.expect;
+        o += W;
+        if (na <= 0) continue;
+        std::fill(o, o + W, 0);
+        o[0] = -2; o[1] = (int64_t)b * FLOW_KEY_STEP + PH_PANEL; o[2] = b; o[3] = k0; o[4] = k1 - k0; o[5] = k1; o[6] = na; o[13] = c.t1_nwait;
+        for (int d = 0; d < c.t1_nwait; ++d) { o[14 + d] = c.t1_widx[d]; o[18 + d] = c.t1_wval[d]; }
+        o[22] = c.t1_sig_base; o[23] = c.t1_sig_per_row;
+        o += W;
+        std::fill(o, o + W, 0);
+        o[0] = -3; o[1] = (int64_t)b * FLOW_KEY_STEP + PH_UPDATE; o[2] = b; o[3] = k0; o[4] = k1 - k0; o[5] = k1; o[6] = na; o[13] = c.t2_wval ? 1 : 0;
+        o[14] = c.t2_widx; o[18] = c.t2_wval; o[22] = -1;
+        o += W;
     }
     for (int q = 0; q < p.nq; ++q)
         for (int k = 0; k < p.qsize[q]; ++k, o += W) {

@@ -44,9 +44,25 @@ __device__ unsigned long long g_gemm_tim[8 * 8192];       // per workgroup: entr
 #else
 #define GEMM_STAMP(i)
 #endif
-template <int AKM, int BKM, int WTM, int WTN, int NWJ = 2, int NWI = 2>
+template <int AKM, int BKM, int WTM, int WTN, int NWJ = 2, int NWI = 2, bool FLOWH = false>
 __global__ __launch_bounds__(64 * NWI * NWJ, NWI * NWJ / 2) void k_gemm(GemmArgs g) {
     GEMM_STAMP(0);
+    if (FLOWH && g.fl_nwait > 0) {      // inside the dataflow schedule: the operands come from workgroups of a kernel that is still running
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < g.fl_nwait; ++k) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(g.fl_flags + g.fl_widx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.fl_wval[k]) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if ((++spins & 127u) == 0u) {
+                        if (__hip_atomic_load(g.fl_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                        if (spins > 400000u) { __hip_atomic_store(g.fl_err, 0x800u + (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
     using Cfg = GemmCfg<WTM, WTN, NWJ, NWI>;
     constexpr int TMR = Cfg::TMR, TNC = Cfg::TNC, COLK_A = Cfg::COLK_A, COLK_B = Cfg::COLK_B, NT = Cfg::NT;
     constexpr int OPER_A = Cfg::OPER_A, OPER_B = Cfg::OPER_B, EPT_A = Cfg::EPT_A, EPT_B = Cfg::EPT_B;
@@ -237,8 +253,20 @@ __global__ __launch_bounds__(64 * NWI * NWJ, NWI * NWJ / 2) void k_gemm(GemmArgs
 #pragma unroll
         for (int n = 0; n < WTN; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                Cp[(int64_t)(crow + m * 16 + 4 * r) * g.ldc + ccol + n * 16] = g.alpha * acc[m][n][r];
+            for (int r = 0; r < 4; ++r) {
+                double* cp = Cp + (int64_t)(crow + m * 16 + 4 * r) * g.ldc + ccol + n * 16;
+                if (FLOWH && g.fl_wt) __hip_atomic_store(cp, g.alpha * acc[m][n][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *cp = g.alpha * acc[m][n][r];
+            }
+    if (FLOWH && g.fl_sig) {                // the tile has left the CU (write-through stores, drained by every wave) before its counter moves
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int trow = (int)((Cp - g.C) / ((int64_t)TMR * g.ldc));
+            __hip_atomic_fetch_add(g.fl_flags + g.fl_sig_base + (unsigned)(trow >> g.fl_sig_shift), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_load(g.fl_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u && g.sk_info) atomicMin(g.sk_info, (unsigned long long)MOGP_INFO_CHAIN_TIMEOUT);
+        }
+    }
 #ifdef GEMM_TIMING
     __builtin_amdgcn_s_waitcnt(0);          // the stores are acknowledged
     GEMM_STAMP(3);
@@ -497,12 +525,12 @@ static int launch_gemm_sk_t(const GemmArgs& a, hipStream_t s) {
     return 0;
 }
 
-template <int AKM, int BKM, int WTM, int WTN, int NWJ = 2, int NWI = 2>
+template <int AKM, int BKM, int WTM, int WTN, int NWJ = 2, int NWI = 2, bool FLOWH = false>
 static int launch_gemm_t(const GemmArgs& a, int grid, hipStream_t s) {
     constexpr int lds_bytes = GemmCfg<WTM, WTN, NWJ, NWI>::LDS_BYTES;
     static std::atomic<unsigned long long> attr_done{0ull};                 // one bit per device
-    { int r__ = set_max_dynamic_lds(reinterpret_cast<const void*>(k_gemm<AKM, BKM, WTM, WTN, NWJ, NWI>), lds_bytes, attr_done); if (r__) return r__; }
-    hipLaunchKernelGGL((k_gemm<AKM, BKM, WTM, WTN, NWJ, NWI>), dim3(grid), dim3(64 * NWI * NWJ), lds_bytes, s, a);
+    { int r__ = set_max_dynamic_lds(reinterpret_cast<const void*>(k_gemm<AKM, BKM, WTM, WTN, NWJ, NWI, FLOWH>), lds_bytes, attr_done); if (r__) return r__; }
+    hipLaunchKernelGGL((k_gemm<AKM, BKM, WTM, WTN, NWJ, NWI, FLOWH>), dim3(grid), dim3(64 * NWI * NWJ), lds_bytes, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -526,6 +554,12 @@ int launch_gemm(const GemmArgs& a0, hipStream_t s) {
         const bool rect = a.mode == GM_RECT || a.mode == GM_RECT_LOWER;
         // (eight waves on the 64-row tiles as well: no difference -- 12.97 vs 12.97 ms at configs[1], 47.4 vs 47.3 at configs[3])
         if (a.small == 1 && v == 1 && (rect || a.mode == GM_KLO_J || a.mode == GM_KHI_I)) return launch_gemm_t<0, 1, 2, 4>(a, grid, s);
+        if (a.fl_flags) {               // the two products between chain kernels of the dataflow schedule (flow.hip): same tiles, hand-off hooks compiled in
+            if (a.small == 1 && v == 0 && a.mode == GM_KHI_J) return launch_gemm_t<0, 0, 2, 4, 2, 2, true>(a, grid, s);
+            if (a.small == 2 && v == 0 && a.mode == GM_RECT_LOWER) return launch_gemm_t<0, 0, 2, 2, 2, 2, true>(a, grid, s);
+            set_error("launch_gemm: the dataflow hooks exist for the mini-panel and the next-diagonal update only");
+            return -1;
+        }
         if (a.small == 1 && v == 0 && a.mode == GM_KHI_J) return launch_gemm_t<0, 0, 2, 4>(a, grid, s);
         if (v != 0 || !rect) {
             set_error("launch_gemm: small-tile variants are built for A k-contiguous and rectangular grids only");

@@ -178,6 +178,12 @@ struct GemmArgs {
     unsigned* sk_flags;                            // one word per span, never reset: a span's flag holds the epoch of the launch that filled its slot
     unsigned sk_epoch;                             // > 0, different from every earlier launch on this workspace
     unsigned long long* sk_info;                   // a hand-off that times out: atomicMin(MOGP_INFO_CHAIN_TIMEOUT)
+    // a launch of the small-tile variants INSIDE the dataflow schedule (flow.hip: the two products between chain kernels run as launches on the
+    // private stream, their operands and results shared with the resident dataflow kernel through its counters): every workgroup first waits
+    // until fl_flags[fl_widx[k]] >= fl_wval[k] for k < fl_nwait (then ONE agent acquire), stores C write-through when fl_wt, and when fl_sig
+    // bumps fl_flags[fl_sig_base + (tile row >> fl_sig_shift)] once its tile has left the CU.  fl_err: the schedule's error word.
+    unsigned* fl_flags; int fl_nwait; unsigned fl_widx[4]; unsigned fl_wval[4];
+    int fl_wt, fl_sig; unsigned fl_sig_base; int fl_sig_shift; unsigned* fl_err;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 double gemm_flops(const GemmArgs& a, const std::vector<GemmTask>* host_tasks);
@@ -211,7 +217,7 @@ int launch_chain(double* A, int64_t ld, int t0, int nk, double* invd, double* lo
 
 // ---- tile dataflow form of the fused factorisation + inversion (flow.hip) --------------------------------------------------------------
 #define FLOW_MAXQ 48                   // queues of a plan at most: 2 * 8 compare-and-swap lanes + one lane per other queue fit one wave
-#define FLOW_NCAS 2                    // the first queues (by priority) are taken ready-only by compare-and-swap, the others eagerly (flow.hip:k_flow)
+#define FLOW_NCAS 1                    // the first queues (by priority) are taken ready-only by compare-and-swap, the others eagerly (flow.hip:k_flow)
 #define FLOW_TRACE_W 6
 #define FLOW_KEY_STEP 1024             // FlowTask::key = FLOW_KEY_STEP * superstep + position inside it
 #define FLOW_NOSIG 0xffffffffu
@@ -233,8 +239,10 @@ struct FlowPlan {
     std::vector<FlowTask> folded;      // (scratch of flow_build)
     int qbase[FLOW_MAXQ] = {0}, qsize[FLOW_MAXQ] = {0};
     int nflags = 0, base_heads = 0, base_err = 0;
-    struct Chain { uint32_t wait_idx, wait_val, done_idx, expect; };
-    std::vector<Chain> chain;          // per outer block: what the chain kernel waits for and reports
+    // per outer block, the private stream's three launches: the chain kernel (reports done_idx += expect workgroups), the mini-panel (rows of
+    // the next block: waits for t1_nwait counters, bumps t1_sig_base + row by 2 nk in all) and the next-diagonal update (waits for one counter)
+    struct Chain { uint32_t done_idx, expect; int t1_nwait; uint32_t t1_widx[4], t1_wval[4], t1_sig_base, t1_sig_per_row; uint32_t t2_widx, t2_wval; };
+    std::vector<Chain> chain;
     double flops = 0.0;
 };
 void flow_build(int nb, int ob, FlowPlan& p);

@@ -25,7 +25,7 @@ def plan(nb):
 
 
 def split(rows):
-    chains = [r for r in rows if r[0] == -1]
+    chains = [r for r in rows if r[0] < 0]                  # the private stream's launches, in stream order
     nq = int(rows[:, 0].max()) + 1
     queues = [[r for r in rows if r[0] == q] for q in range(nq)]
     return chains, queues
@@ -36,8 +36,12 @@ def deps_of(r):
 
 
 def signals_of(r):
-    if r[0] == -1:
+    if r[0] == -1:                                           # chain kernel: its workgroups count themselves off
         return [(int(r[22]), int(r[23]))]
+    if r[0] == -2:                                           # mini-panel: 2 nk tiles per panel row of the next block
+        return [(int(r[22]) + i, int(r[23])) for i in range(int(r[6]))]
+    if r[0] == -3:
+        return []
     return [(int(r[22 + s]), 1) for s in range(2) if r[22 + s] >= 0]
 
 
@@ -123,6 +127,31 @@ def run_task(bufs, r):
         c += alpha * prod
 
 
+def priv_footprint(r):
+    """(reads, writes) of a launch of the private stream"""
+    k0, nk = int(r[3]), int(r[4])
+    diag = {(k0 + i, k0 + j) for i in range(nk) for j in range(i + 1)}
+    if r[0] == -1:
+        return {(0, i, j) for i, j in diag}, {(3, i, j) for i, j in diag} | {(0, i, j) for i, j in diag}
+    k1, na = int(r[5]), int(r[6])
+    panel = {(1, k1 + i, k0 + c) for i in range(na) for c in range(nk)}
+    if r[0] == -2:
+        return {(0, k1 + i, k0 + c) for i in range(na) for c in range(nk)} | {(3, i, j) for i, j in diag}, panel
+    nxt = {(0, k1 + i, k1 + j) for i in range(na) for j in range(i + 1)}
+    return panel | nxt, nxt
+
+
+def run_priv(bufs, r):
+    """mini-panel L[rows of the next block][K] = A[rows][K] W_KK^T, or the next diagonal block's last update"""
+    k0, nk, k1, na = int(r[3]), int(r[4]), int(r[5]), int(r[6])
+    A, Lm, Wm = bufs[0], bufs[1], bufs[3]
+    if r[0] == -2:
+        tile(Lm, k1, k0, na, nk)[...] = tile(A, k1, k0, na, nk) @ np.tril(tile(Wm, k0, k0, nk, nk)).T
+    else:
+        P = tile(Lm, k1, k0, na, nk)
+        tile(A, k1, k1, na, na)[...] -= P @ P.T
+
+
 def run_chain(bufs, r):
     k0, nk = int(r[3]), int(r[4])
     A, Wm = bufs[0], bufs[3]
@@ -156,12 +185,10 @@ def test_replay_with_concurrent_workgroups(nb, nwg, seed):
         return all(flags.get(i, 0) >= n for i, n in deps_of(r))
 
     def start(r):
-        reads, wr = (set(), None) if r[0] == -1 else footprint(r)
-        if r[0] == -1:
-            k0, nk = int(r[3]), int(r[4])
-            reads = {(0, k0 + i, k0 + j) for i in range(nk) for j in range(i + 1)}
-            wr_set = {(3, k0 + i, k0 + j) for i in range(nk) for j in range(i + 1)}
+        if r[0] < 0:
+            reads, wr_set = priv_footprint(r)
         else:
+            reads, wr = footprint(r)
             wr_set = {wr}
         for _, oreads, owr in running:           # nobody in flight writes what this one touches, nobody reads what this one writes
             assert not (owr & (reads | wr_set)), ("write in flight", r)
@@ -173,6 +200,8 @@ def test_replay_with_concurrent_workgroups(nb, nwg, seed):
         if r[0] == -1:
             L = run_chain(bufs, r)
             logdet_parts.append(np.log(np.diag(L)).sum())
+        elif r[0] < 0:
+            run_priv(bufs, r)
         else:
             run_task(bufs, r)
         for idx, inc in signals_of(r):
@@ -187,7 +216,7 @@ def test_replay_with_concurrent_workgroups(nb, nwg, seed):
         if not chain_busy and chain_next < len(chains) and ready(chains[chain_next]) and rng.random() < 0.7:
             start(chains[chain_next]); chain_next += 1; chain_busy = True; progressed = True
         # free workgroups take the first ready head, by priority
-        nflow = sum(1 for r, _, _ in running if r[0] != -1)
+        nflow = sum(1 for r, _, _ in running if r[0] >= 0)
         while nflow < nwg:
             took = False
             for q, tasks in enumerate(queues):
@@ -200,7 +229,7 @@ def test_replay_with_concurrent_workgroups(nb, nwg, seed):
             nfin = int(rng.integers(1, max(2, len(running) // 2 + 1)))
             for _ in range(min(nfin, len(running))):
                 k = int(rng.integers(0, len(running)))
-                if running[k][0][0] == -1:
+                if running[k][0][0] < 0:
                     chain_busy = False
                 finish(k); done += 1
             progressed = True
@@ -244,7 +273,7 @@ def happens_before(rows):
                 a |= anc[p] | (1 << p)
                 got += inc
             assert got >= need
-        if r[0] == -1:
+        if r[0] < 0:                                         # the private stream runs its launches one after the other
             if prev_chain is not None:
                 a |= anc[prev_chain] | (1 << prev_chain)
             prev_chain = k
@@ -258,10 +287,8 @@ def test_every_conflicting_pair_of_tasks_is_ordered_by_the_counters(nb):
     anc = happens_before(rows)
     touch = {}
     for k, r in enumerate(rows):
-        if r[0] == -1:
-            k0, nk = int(r[3]), int(r[4])
-            reads = {(0, k0 + i, k0 + j) for i in range(nk) for j in range(i + 1)}
-            writes = {(3, k0 + i, k0 + j) for i in range(nk) for j in range(i + 1)} | reads      # the factor replaces the block
+        if r[0] < 0:
+            reads, writes = priv_footprint(r)
         else:
             reads, wr = footprint(r)
             writes = {wr}

@@ -9,7 +9,7 @@ os.environ.setdefault("MOGP_GRAD_PATH", "fused")
 import numpy as np
 from mogptk_amd import gpr, synth, _lib
 
-QN = ["crit", "look2", "semi", "invcrit", "vec"]
+QN = ["look2", "semi", "invcrit", "vec"]
 
 
 def main():
@@ -40,7 +40,7 @@ def main():
     rows = np.zeros((pc.value, 24), dtype=np.int64)
     l.mogp_flow_plan(nb, rows.ctypes.data_as(_lib.c_i64p), rows.size, ctypes.byref(pc))
     tasks = rows[rows[:, 0] >= 0]
-    nt, no = len(tasks), int((rows[:, 0] < 0).sum())
+    nt, no = len(tasks), int((rows[:, 0] == -1).sum())
     if os.environ.get("FLOW_TRACE_SAVE"):
         np.savez_compressed(os.environ["FLOW_TRACE_SAVE"], trace=tr, rows=rows)
     t = tr[:6 * nt].reshape(nt, 6)
@@ -62,10 +62,10 @@ def main():
     # queues 4 .. : INTO[d] / TRAIL[d - 3] by deadline, the last one the accumulations: fold them into three report classes
     nq = int(tasks[:, 0].max()) + 1
     cls = tasks[:, 0].copy()
-    rest = tasks[:, 0] >= 5
-    cls[rest & (tasks[:, 8] == 2)] = 5
-    cls[rest & (tasks[:, 8] == 0)] = 6
-    cls[tasks[:, 0] == nq - 1] = 7
+    rest = tasks[:, 0] >= 4
+    cls[rest & (tasks[:, 8] == 2)] = 4
+    cls[rest & (tasks[:, 8] == 0)] = 5
+    cls[tasks[:, 0] == nq - 1] = 6
     tasks = tasks.copy(); tasks[:, 0] = cls
     QN.extend(["into", "trail", "acc"])
     print("dataflow evaluation N=%d (nb=%d tiles, %d outer blocks): %d tile tasks, %d workgroups seen; times in us from the first chain launch"
