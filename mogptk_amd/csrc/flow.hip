@@ -168,6 +168,7 @@ struct FlowArgs {
     unsigned* flags;                  // dependency counters, then the queue heads, then the error word (all zero at the start of an evaluation)
     int nq, ncas, base_heads, base_err;
     unsigned nap_max;                 // an idle workgroup sleeps 2^1 .. 2^nap_max microseconds between looks
+    int nhi;                          // queues below this index always hold a task per workgroup (claimed at the next look after one was taken)
     int claim_one;                    // nothing ready: take from ONE queue per look (the highest priority with a free slot) instead of from all
     int refill;                       // a taken eager slot is refilled at once (0: only when the workgroup finds nothing ready)
     const double* vy; double* vz; double* vzz; double* vpart;         // z = W y and alpha = W^T z as tasks (null: those tasks only count)
@@ -276,10 +277,17 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
             naps = 0;
             for (;;) {
                 int h = 0, idx = -1;
+                // the few queues right behind the critical one are LOOKED AT by every workgroup at every look (their head's readiness, like the
+                // compare-and-swap queue's) but taken by fetch-add only when the head is ready: taken only by idle workgroups (like the bulk queues)
+                // they starved, kept filled per workgroup their ready tasks sat in busy workgroups' slots
+                const bool peek = is_eager && myq < g.nhi && pend < 0 && !exhausted;
                 if (is_cas) {
                     h = (int)__hip_atomic_load(heads + myq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     h = __shfl(h, lane - myk, 64);                             // one head value per queue
                     idx = h + myk < qsize ? h + myk : -1;
+                } else if (peek) {
+                    h = (int)__hip_atomic_load(heads + myq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (h >= qsize) exhausted = true; else idx = h;
                 } else if (is_eager) {
                     idx = pend;
                 }
@@ -308,6 +316,11 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                                 const unsigned off = cur - (unsigned)h;
                                 if (off >= FL_LA || !((mready >> (lane + off)) & 1ull)) break;
                             }
+                        } else if (peek) {                                      // the head looked ready: take a ticket; if others were faster the ticket is a
+                            const unsigned hh = __hip_atomic_fetch_add(heads + myq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // later task: hold it
+                            if (hh == (unsigned)h) { ok = 1; res = qbase + h; }
+                            else if (hh < (unsigned)qsize) pend = (int)hh;
+                            else exhausted = true;
                         } else {
                             ok = 1; res = qbase + pend;
                             // refill the slot at once (the answer is not needed before the next look) -- except near the end of the
@@ -325,7 +338,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                 }
                 // nothing this workgroup holds or may take is ready: take what can be taken eagerly
                 bool took = false;
-                bool want = is_eager && pend < 0 && !exhausted;
+                bool want = is_eager && myq >= g.nhi && pend < 0 && !exhausted;      // (the looked-at queues are taken ready-only, above)
                 if (g.claim_one) {                                             // one queue per look, the highest priority first: a workgroup then holds at
                     const unsigned long long mw = __ballot(want);              // most one READY task it is not running (held ready tasks are tasks idle
                     want = want && mw && lane == __ffsll((long long)mw) - 1;   // workgroups cannot take)
@@ -687,6 +700,7 @@ int spd_potri_flow(mogp_model* m, Spd& w) {
     g.npad = ld;
     { const char* e = std::getenv("MOGP_FLOW_REFILL"); g.refill = e ? std::atoi(e) : 0; }
     { const char* e = std::getenv("MOGP_FLOW_CLAIM1"); g.claim_one = e ? std::atoi(e) : 0; }
+    { const char* e = std::getenv("MOGP_FLOW_NHI"); g.nhi = e ? std::atoi(e) : 0; }            // measured 3 / 4 (semi, the inverse cycle, z and alpha looked at by everybody): 10.74-10.79 vs 10.52-10.65 ms
     { const char* e = std::getenv("MOGP_FLOW_NAP"); g.nap_max = e ? (unsigned)std::max(0, std::atoi(e)) : 4u; }
     w.vec_done = false;
     if (w.want_vec && w.vec_y && w.vec_z && w.vec_zz && w.vec_part) {       // z = W y, alpha = W^T z as tasks of the same kernel
@@ -728,6 +742,8 @@ int spd_potri_flow(mogp_model* m, Spd& w) {
         for (int k = 0; k < pc.t1_nwait; ++k) { t1.fl_widx[k] = pc.t1_widx[k]; t1.fl_wval[k] = pc.t1_wval[k]; }
         t1.fl_wt = 1; t1.fl_sig = 1; t1.fl_sig_base = pc.t1_sig_base; t1.fl_sig_shift = 1; t1.fl_err = ferr; t1.sk_info = m->d_info.p;
         if ((rc = launch_gemm(t1, priv))) return rc;
+        // (the first launch of this stream that touches A beyond its first 512 columns: the rest of the Gram matrix may still be on its way)
+        if (kb == 0 && w.tail_ready) HIP_TRY(hipStreamWaitEvent(priv, w.tail_ready, 0));
         // next-diagonal update  D_{K+1,K+1} -= P P^T  on 64 x 64 tiles: the block's last update -- the earlier ones are dataflow tasks
         GemmArgs t2{};
         t2.A = t1.C; t2.lda = ld; t2.a_kmajor = 0; t2.B = t1.C; t2.ldb = ld; t2.b_kmajor = 0;

@@ -683,6 +683,11 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
         HIP_TRY(hipEventRecord(m->gram_ev, m->st));
         HIP_TRY(hipStreamWaitEvent(m->st2, m->gram_ev, 0));
         if ((rc = launch_gram(gt, (int)m->tiles_tail.size(), m->st2))) return rc;       // spd_potri_flow enqueues the dataflow kernel behind it
+        // ... and makes the private stream wait for this event before the first launch that reads beyond the first 512 columns (round 4: with
+        // four processes on one GPU the next-diagonal update of block 0 ran BEFORE this launch had written its block: "not positive definite")
+        if (!m->gram_tail_ev) HIP_TRY(hipEventCreateWithFlags(&m->gram_tail_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(m->gram_tail_ev, m->st2));
+        m->k.tail_ready = m->gram_tail_ev;
     } else {
         if ((rc = launch_gram(ga, (int)m->tiles.size(), m->st))) return rc;
         if ((rc = launch_pad_identity(m->k.A.p, Npad, N, Npad, m->st))) return rc;
@@ -693,7 +698,7 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     m->k.want_vec = fuse_inverse && !factor_only;     // the dataflow schedule (flow.hip) also forms z = W y and alpha = W^T z
     m->k.vec_y = m->d_y.p; m->k.vec_z = m->d_z.p; m->k.vec_zz = m->d_zz.p; m->k.vec_part = m->d_alpha.p + Npad;
     rc = fuse_inverse ? spd_potri_fused(m, m->k) : spd_potrf(m, m->k);
-    m->k.want_vec = false;
+    m->k.want_vec = false; m->k.tail_ready = nullptr;
     if (rc) return rc;
     if ((rc = mark(m, 2))) return rc;
 
@@ -1012,6 +1017,7 @@ int mogp_model_destroy(mogp_model* m) {
     m->d_partial.release(); m->d_moments.release(); m->d_diagG.release(); m->d_tiles.release(); m->d_pair_start.release(); m->strip.release(); m->strip_own.release();
     m->d_tiles_head.release(); m->d_tiles_tail.release(); m->strip_head.release(); m->strip_tail.release();
     if (m->gram_ev) { hipError_t r = hipEventDestroy(m->gram_ev); (void)r; m->gram_ev = nullptr; }
+    if (m->gram_tail_ev) { hipError_t r = hipEventDestroy(m->gram_tail_ev); (void)r; m->gram_tail_ev = nullptr; }
     m->d_chan_off.release(); m->d_flag.release(); m->d_info.release();
     m->d_xs.release(); m->d_Ksf.release(); m->d_Vt.release(); m->d_mu.release(); m->d_var.release(); m->d_kdiag.release();
     m->d_Kss.release(); m->d_ptiles.release();

@@ -140,6 +140,8 @@ struct Spd {
     DevBuf<int> flow_qmeta;
     DevBuf<unsigned> flow_flags;
     DevBuf<unsigned long long> flow_trace;
+    hipEvent_t tail_ready = nullptr;    // set by the caller for ONE factorisation: everything of A right of the first 512 columns is in place after this event
+                                        // (the Gram build in two launches: the second one runs on the bulk stream underneath the first chain kernel)
     bool flow_used = false;             // the last fused factorisation + inversion of this workspace ran as dataflow
     // the caller wants z = W y and the row blocks' shares of alpha = W^T z from the same kernel: y, z [Npad], z^T z parts [(Npad + 3) / 4],
     // shares [nouter][Npad] (device); vec_done: the last factorisation delivered them (launch_flow_alpha_sum adds the shares up)
@@ -242,7 +244,7 @@ struct mogp_model {
     std::vector<GTile> tiles_head, tiles_tail;
     DevBuf<GTile> d_tiles_head, d_tiles_tail;
     StripTiles strip_head, strip_tail;
-    hipEvent_t gram_ev = nullptr;
+    hipEvent_t gram_ev = nullptr, gram_tail_ev = nullptr;
     DevBuf<int> d_pair_start_own;
     int own_rank = -1, own_n = 0;       // (rank, nranks) the owned lists were built for
     DevBuf<double> sh_send, sh_recv;
