@@ -475,7 +475,7 @@ def main():
         # the two HBM-bound passes: algorithmic bytes over the duration of the tile kernel alone (HIP events around that one launch)
         gram_gbs = gram_bytes * nprof / (stage[_lib.ST_GRAM_KERNEL] * 1e-3) / 1e9 if stage[_lib.ST_GRAM_KERNEL] > 0 else None
         mom_gbs = gram_bytes * nprof / (stage[_lib.ST_MOMENT_KERNEL] * 1e-3) / 1e9 if stage[_lib.ST_MOMENT_KERNEL] > 0 else None
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_eval = None, None, None
         sched = h.schedule() if (kind == "exact" and not sharded_mode and hasattr(h, "schedule")) else None
         for tf in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"):     # L2<->fabric bytes per k_gemm launch from the committed rocprofv3 --pmc passes of this command
             try:
@@ -483,6 +483,7 @@ def main():
                     t = json.load(f)
                 if a.config == "cfg2" and not sharded_mode:
                     traffic, traffic_src = t["bytes_per_launch"], "profiles/%s: %s" % (tf, t["source"])
+                    traffic_eval = t.get("fetch_bytes_per_eval", 0.0) + t.get("write_bytes_per_eval", 0.0)
                 break
             except Exception:
                 continue
@@ -520,6 +521,14 @@ def main():
                          "basis": "algorithmic flops of one step (SURVEY.md 8d: %.3e) / ms_per_step%s" % (algo_flops, " / ranks" if sharded_mode else ""),
                          "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src},
         }
+        if sched and sched["dataflow"] and traffic is not None:
+            # The dataflow kernel cannot be measured by rocprofv3 --pmc: counter collection serialises dispatches, and k_flow and the chain
+            # kernels that feed it have to run concurrently (under --pmc the evaluation times out and falls back to the stream schedule).
+            # What the committed counter passes measure is the stream schedule's launches of the SAME tile products (MOGP_FLOW=0).
+            out["roofline"]["traffic"] = None
+            out["roofline"]["traffic_note"] = ("null: rocprofv3 --pmc serialises dispatches, which the co-operating dataflow / chain kernels cannot run under; "
+                                               "traffic_stream_schedule is the same tile products as launches (MOGP_FLOW=0)")
+            out["roofline"]["traffic_stream_schedule"] = {"bytes_per_eval": traffic_eval, "bytes_per_launch": traffic, "source": traffic_src}
         if rccl is not None:
             out["config"]["rccl_ranks"] = rccl[0]
         if kind == "exact" and not sharded_mode and acc["nprof"] > 0:

@@ -10,7 +10,10 @@ if os.path.isdir(src):
 agg = collections.defaultdict(lambda: [0, 0, 10 ** 18, 0])
 for r in csv.DictReader(open(src)):
     d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    a = agg[r["Kernel_Name"]]
+    name = r["Kernel_Name"]
+    if "k_flow" in name and "Grid_Size_X" in r:      # two instances per evaluation (bulk CUs / the private stream's after the last chain kernel): keep them apart
+        name += " [grid %s]" % r["Grid_Size_X"]
+    a = agg[name]
     a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
 tot = sum(a[1] for a in agg.values())
 rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
