@@ -23,5 +23,7 @@ print("loss rel err %.2e" % (abs(loss - float(fx["loss"])) / abs(float(fx["loss"
 g1 = [p.grad.copy() for p in m.parameters()]
 for p, f in zip(m.parameters(), fp):
     print("%-60s rel err %.3e" % (p._name, np.max(np.abs(p.grad - f["grad"])) / np.max(np.abs(f["grad"]))))
+import hashlib
+print("checksum", hashlib.sha1(b"".join(np.ascontiguousarray(g).tobytes() for g in g1) + np.float64(loss).tobytes()).hexdigest())
 loss2 = float(m.loss())
 print("bitwise repeat:", loss2 == loss and all(np.array_equal(p.grad, g) for p, g in zip(m.parameters(), g1)))
