@@ -8,10 +8,11 @@
 // diagonal tiles are NOT enough (their own condition number is ~1e10): the substitution has to go down to single rows.
 //
 // Blocked left-looking form over 128-row blocks:  B_i -= L[i, <i] X[<i]  on the fp64 MFMA GEMM (k_gemm, K growing with i), then
-// X_i = L_ii^-1 B_i in k_trsm_leaf: one COLUMN of the right-hand side per thread (no cross-thread dependency at all), the 128 x 128 tile of
-// L in LDS (every read is a wave-wide broadcast), forward / backward substitution in 16-row sub-blocks: the current 16 unknowns in
-// registers, the already solved sub-blocks re-read from the (L1 / L2 resident) right-hand side.  2 * 8256 flops per column and block row:
-// 1.3e10 flops for the 2048 x 100 000 solve of configs[4] next to 4.2e11 in the GEMMs.
+// X_i = L_ii^-1 B_i by a leaf kernel: substitution in 16-row sub-blocks through the 128 x 128 tile of L.  Round 3's leaf (k_trsm_leaf: one COLUMN of the
+// right-hand side per thread, the tile in LDS, every read a wave-wide broadcast) was bound by that broadcast -- 8 bytes per lane and FMA through LDS.
+// Round 4 (k_trsm_leaf_r): the products with the solved sub-blocks on v_mfma_f64_16x16x4_f64, the solved rows kept in registers, the vector ALU only for
+// the 16 x 16 diagonal blocks: 114 -> 80 us per block row at configs[4], the same bits.  2 * 8256 flops per column and block row: 1.3e10 flops for the
+// 2048 x 100 000 solve of configs[4] next to 4.2e11 in the GEMMs.
 #include "mogp_model.h"
 
 using namespace mogp;
@@ -467,6 +468,155 @@ __global__ __launch_bounds__(256, 2) void k_trsm_leaf_m(const double* __restrict
     }
 }
 
+// (round 4, second step) k_trsm_leaf_m still takes 125 us: every sub-block is a chain of global round trips -- its rows in, the solved rows of all earlier
+// sub-blocks in again as MFMA operands (448 loads per lane and block row), the result out, and the next sub-block cannot request its operands before
+// those stores have landed.  Here a wave keeps what it has solved IN REGISTERS: the accumulator layout of v_mfma_f64_16x16x4_f64 (lane (n, j), register v:
+// row j + 4 v, column n) is also its B-operand layout (lane (n, k): row 4 ks + k), so a solved 16 x 64 block, turned from one column per lane back into
+// that layout through the wave's LDS slab, IS the operand of every later sub-block.  The first TR_KEEP solved sub-blocks stay in registers for the whole
+// tile (16 doubles a lane each), the one solved last comes straight from the slab, and only what lies between is read back from memory (3 block reads a
+// block row instead of 28), requested a whole step ahead.  L comes out of LDS: the 28 off-diagonal 16 x 16 blocks as A operands (one double a lane and k
+// step, padded rows), the diagonal blocks and reciprocal pivots for the substitution.  512 threads = 512 columns per workgroup, two waves per SIMD (one
+// wave's substitution under the other's MFMAs), 144 KB of LDS: 196 workgroups at configs[4], a single round of the chip.
+// (First version: everything solved kept in registers, ~330 of them, one wave per SIMD, 256-column workgroups: 391 workgroups on 256 CUs = two rounds of
+// 46 us; before that, with the tile copied to LDS by a loop with a `continue`, 122 us: the 64 loads of a thread went out one at a time.)
+#define TR_BLK (TS_SB * 17)
+#define TR_WAVES 8
+#define TR_LDS_BYTES ((28 * TR_BLK + 8 * TS_SB * TS_SB + TS_T + TR_WAVES * TM_SLAB) * 8)
+template <bool TRANS, int TR_KEEP>
+__global__ __launch_bounds__(64 * TR_WAVES) void k_trsm_leaf_r(const double* __restrict__ Lt, int64_t ldl, double* __restrict__ B, int64_t ldb, int64_t ncols) {
+    extern __shared__ __attribute__((aligned(16))) double tr_lds[];
+    double* La = tr_lds;                                  // [28][16][17]: block (R, C), R > C, at R (R - 1) / 2 + C; forward: [m][k] = L[16 R + m][16 C + k]; transposed: [m][k] = L[16 R + k][16 C + m]
+    double* dg = La + 28 * TR_BLK;                        // [8][16][16] diagonal blocks
+    double* inv = dg + 8 * TS_SB * TS_SB;                 // [128]
+    double* slabs = inv + TS_T;                           // [waves][16][65]
+    constexpr int NT = 64 * TR_WAVES;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    {   // the tile into LDS: all of a thread's loads in flight at once (thread = column c of the tile, rows r0, r0 + NT / 128, ...)
+        constexpr int RS = NT / TS_T, NI = TS_T / RS;
+        const int c = tid & 127, C = c >> 4, r0 = tid >> 7;
+        double v[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int r = r0 + RS * i;
+            v[i] = (r >> 4) >= C ? Lt[(int64_t)r * ldl + c] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int r = r0 + RS * i, R = r >> 4;
+            if (R == C) dg[(R * TS_SB + (r & 15)) * TS_SB + (c & 15)] = v[i];
+            else if (R > C) La[(R * (R - 1) / 2 + C) * TR_BLK + (TRANS ? (c & 15) * 17 + (r & 15) : (r & 15) * 17 + (c & 15))] = v[i];
+        }
+    }
+    if (tid < TS_T) inv[tid] = 1.0 / Lt[(int64_t)tid * ldl + tid];
+    __syncthreads();
+    const int64_t col0 = (int64_t)blockIdx.x * NT + wv * 64;
+    if (col0 >= ncols) return;                                 // ncols is a multiple of 128: whole waves only
+    const int ln = lane & 15, lk = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(B + col0, 0, (int)0xffffffffu, 0x00020000);
+    typedef decltype(__builtin_amdgcn_raw_buffer_load_b64(rb, 0, 0, 0)) raw64_t;
+    typedef double d4_t __attribute__((ext_vector_type(4)));
+    const unsigned ldb8 = (unsigned)(ldb * 8);                                    // the caller guarantees 128 ldb 8 < 2^32
+    const unsigned vB = (unsigned)lk * ldb8 + (unsigned)ln * 8u;               // row lk, column ln of the wave's 64 columns
+    const unsigned vC = (unsigned)lane * 8u;                                     // column `lane`
+    double* sl = slabs + wv * TM_SLAB;
+    const double* Aln = La + ln * 17 + lk;                                        // this lane's element of a block's k step 0
+    constexpr int NSB = TS_T / TS_SB;
+    auto load_rows = [&](d4_t (&d)[4], int sb) {              // sub-block sb in the accumulator = operand layout
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                d[g][v] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rb, vB + 128 * g, (unsigned)(sb * TS_SB + 4 * v) * ldb8, 0));
+    };
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto sbq = [](int q) { return TRANS ? NSB - 1 - q : q; };   // the q-th sub-block in solving order
+    d4_t keep[TR_KEEP][4];                                      // the first TR_KEEP solved sub-blocks
+    d4_t last[4];                                               // the one solved in the previous step
+    d4_t acc[4], accn[4];
+    load_rows(acc, sbq(0));
+#pragma unroll
+    for (int step = 0; step < NSB; ++step) {
+        const int sb = sbq(step);
+        d4_t back[NSB > TR_KEEP + 1 ? NSB - TR_KEEP - 1 : 1][4];          // solved sub-blocks TR_KEEP .. step - 2, read back (stored at least a step ago)
+#pragma unroll
+        for (int q = TR_KEEP; q < step - 1; ++q) load_rows(back[q - TR_KEEP], sbq(q));
+        if (step + 1 < NSB) load_rows(accn, sbq(step + 1));
+#pragma unroll
+        for (int q = 0; q < step; ++q) {                       // the solved sub-blocks in k_trsm_leaf's order
+            const int p = sbq(q);
+            const int R = TRANS ? p : sb, C = TRANS ? sb : p;
+            const double* Ab = Aln + (R * (R - 1) / 2 + C) * TR_BLK;
+            const d4_t (&bq)[4] = q < TR_KEEP ? keep[q < TR_KEEP ? q : 0] : (q == step - 1 ? last : back[q >= TR_KEEP ? q - TR_KEEP : 0]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double a = -Ab[4 * ks];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[g][ks], acc[g], 0, 0, 0);
+            }
+        }
+        // accumulator layout -> one column per lane
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sl[(lk + 4 * v) * 65 + 16 * g + ln] = acc[g][v];
+        wave_sync();
+        double x[TS_SB];
+#pragma unroll
+        for (int r = 0; r < TS_SB; ++r) x[r] = sl[r * 65 + lane];
+        const double* Ld = dg + sb * TS_SB * TS_SB;
+        if (!TRANS) {
+#pragma unroll
+            for (int c = 0; c < TS_SB; ++c) {
+                x[c] *= inv[sb * TS_SB + c];
+#pragma unroll
+                for (int r = c + 1; r < TS_SB; ++r) x[r] = fma(-Ld[r * TS_SB + c], x[c], x[r]);
+            }
+        } else {
+#pragma unroll
+            for (int c = TS_SB - 1; c >= 0; --c) {
+                x[c] *= inv[sb * TS_SB + c];
+#pragma unroll
+                for (int r = 0; r < c; ++r) x[r] = fma(-Ld[c * TS_SB + r], x[c], x[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < TS_SB; ++r)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(raw64_t, x[r]), rb, vC, (unsigned)(sb * TS_SB + r) * ldb8, 0);
+        if (step + 1 < NSB) {
+            // the solved block back into the accumulator = operand layout, for the sub-blocks still to come
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < TS_SB; ++r) sl[r * 65 + lane] = x[r];
+            wave_sync();
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) last[g][v] = sl[(lk + 4 * v) * 65 + 16 * g + ln];
+            if (step < TR_KEEP) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) keep[step < TR_KEEP ? step : 0][g] = last[g];
+            }
+            wave_sync();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = accn[g];
+        }
+    }
+}
+
+template <bool TRANS, int KEEP>
+static int launch_leaf_r(const double* Lt, int64_t ldl, double* B, int64_t ldb, int64_t ncols, hipStream_t s) {
+    static std::atomic<unsigned long long> attr_done{0ull};                 // one bit per device
+    { int r__ = set_max_dynamic_lds(reinterpret_cast<const void*>(k_trsm_leaf_r<TRANS, KEEP>), TR_LDS_BYTES, attr_done); if (r__) return r__; }
+    constexpr int NT = 64 * TR_WAVES;
+    hipLaunchKernelGGL((k_trsm_leaf_r<TRANS, KEEP>), dim3((unsigned)((ncols + NT - 1) / NT)), dim3(NT), TR_LDS_BYTES, s, Lt, ldl, B, ldb, ncols);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <bool TRANS>
 static int launch_leaf_m(const double* Lt, int64_t ldl, double* B, int64_t ldb, int64_t ncols, hipStream_t s) {
     hipLaunchKernelGGL((k_trsm_leaf_m<TRANS>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, Lt, ldl, B, ldb, ncols);
@@ -492,8 +642,13 @@ static int launch_leaf_s(const double* Lt, int64_t ldl, double* B, int64_t ldb, 
 }
 template <bool TRANS>
 static int launch_leaf(const double* Lt, int64_t ldl, double* B, int64_t ldb, int64_t ncols, hipStream_t s) {
-    static const int form = []() { const char* e = std::getenv("MOGP_TRSM_LEAF"); return e ? atoi(e) : 5; }();      // 0: the LDS-tile kernel of round 3
+    // MOGP_TRSM_LEAF: 0 the LDS-tile kernel of round 3; 1-4 L through the scalar path; 5 / 6 matrix cores, solved rows re-read from memory (wide / all
+    // right-hand sides); 7 / 8 matrix cores, solved rows kept in registers (wide / all); 9 / 10 the same with three kept sub-blocks.  Every form gives
+    // the same bits (tools/r4_leaf.sh: the checksum of a configs[4] gradient); 8 is the fastest (configs[4]: 48.3 -> 46.3 ms on one box).
+    static const int form = []() { const char* e = std::getenv("MOGP_TRSM_LEAF"); return e ? atoi(e) : 8; }();
     if (form >= 5 && ldb * 8 * TS_T < (int64_t)1 << 32) {     // matrix-core form for wide right-hand sides (6: for the narrow ones as well)
+        if (form >= 9) { if (ncols >= 65536 || form == 10) return launch_leaf_r<TRANS, 3>(Lt, ldl, B, ldb, ncols, s); return launch_leaf_t<TRANS, 64>(Lt, ldl, B, ldb, ncols, s); }
+        if (form >= 7) { if (ncols >= 65536 || form == 8) return launch_leaf_r<TRANS, 4>(Lt, ldl, B, ldb, ncols, s); return launch_leaf_t<TRANS, 64>(Lt, ldl, B, ldb, ncols, s); }
         if (ncols >= 65536 || form == 6) return launch_leaf_m<TRANS>(Lt, ldl, B, ldb, ncols, s);
         return launch_leaf_t<TRANS, 64>(Lt, ldl, B, ldb, ncols, s);
     }
