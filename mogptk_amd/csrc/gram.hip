@@ -662,9 +662,15 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* _
         if (!((a.dbg & 1) && acc[0][0] != 12345.678)) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                double* o = a.out + (int64_t)(sg.r0 + rg * 4 + m) * a.ldo + c0 + cg * 4;
+                const int64_t at = (int64_t)(sg.r0 + rg * 4 + m) * a.ldo + c0 + cg * 4;
+                double* o = a.out + at;
                 *reinterpret_cast<d2_t*>(o) = (d2_t){acc[m][0], acc[m][1]};
                 *reinterpret_cast<d2_t*>(o + 2) = (d2_t){acc[m][2], acc[m][3]};
+                if (a.out2) {                              // the sparse models' working copy of K_uf (same leading dimension)
+                    double* o2 = a.out2 + at;
+                    *reinterpret_cast<d2_t*>(o2) = (d2_t){acc[m][0], acc[m][1]};
+                    *reinterpret_cast<d2_t*>(o2 + 2) = (d2_t){acc[m][2], acc[m][3]};
+                }
             }
         }
         __syncthreads();                                   // the next tile's columns are in LDS; this tile's factors are consumed
@@ -700,7 +706,7 @@ int launch_gram(const GramArgs& a0, int ntiles, hipStream_t s) {
     const size_t dyn = a.tab_lds ? tab_bytes : 0;
     if (a.ev0) HIP_TRY(hipEventRecord(a.ev0, s));
     static const bool strip_on = !(std::getenv("MOGP_GRAM_STRIP") && std::atoi(std::getenv("MOGP_GRAM_STRIP")) == 0);
-    if (strip_on && a.segs && a.nsegs > 0 && a.D == 1 && a.W == 5 && a.T <= GS_TC_MAX && !a.mirror && !a.out2 && (a.ldo & 1) == 0) {
+    if (strip_on && a.segs && a.nsegs > 0 && a.D == 1 && a.W == 5 && a.T <= GS_TC_MAX && !a.mirror && (a.ldo & 1) == 0) {
         if (a.T <= 4) hipLaunchKernelGGL(k_gram_strip<4>, dim3(a.nsegs), dim3(256), 0, s, a, a.segs);
         else hipLaunchKernelGGL(k_gram_strip<8>, dim3(a.nsegs), dim3(256), 0, s, a, a.segs);
         if (a.nrest > 0) {

@@ -92,17 +92,26 @@ __global__ __launch_bounds__(64 * NWI * NWJ, NWI * NWJ / 2) void k_gemm(GemmArgs
         // chunk of the (row-major) tile list keeps a panel row inside one L2 instead of all eight (measured: 2.8x the algorithmic
         // HBM traffic without it).  Only for the modes whose tiles all cost the same (equal chunks = equal work).
         int bid = blockIdx.x, grid = gridDim.x, ks = 0;
+        bool placed = false;
         if (g.ksplit > 1) {            // split K: slice ks of the k range, accumulated into its own copy of C (c_split apart); the caller adds them
             grid /= g.ksplit;
-            ks = bid / grid;
-            bid -= ks * grid;
+            if (g.ksplit_xcd) {        // slices x, x + 8, ... on XCD x, one after the other: every workgroup resident on an XCD reads the same k window
+                const int x = bid & 7, local = bid >> 3, sl = local / grid;      // (slice-major numbering put ~4 slices on every XCD at once: 4 k windows
+                ks = x + 8 * sl;                                                   // x 12 row panels per k step against a 4 MB L2 -- 12.4 GB fetched for 1.6 GB of v)
+                bid = local - sl * grid;
+                placed = true;
+            } else {
+                ks = bid / grid;
+                bid -= ks * grid;
+            }
         }
-        if (g.mode == GM_RECT || g.mode == GM_RECT_LOWER || g.mode == GM_LOWER || g.mode == GM_KLO_J || g.mode == GM_KHI_J) {
+        if (!placed && (g.mode == GM_RECT || g.mode == GM_RECT_LOWER || g.mode == GM_LOWER || g.mode == GM_KLO_J || g.mode == GM_KHI_J)) {
             const int q = grid >> 3, r = grid & 7, x = bid & 7;
             if (grid >= 64) bid = x * q + min(x, r) + (bid >> 3);
         }
         int ti, tj;
         if (g.mode == GM_LOWER || g.mode == GM_LAUUM) { ti = tri_row(bid); tj = bid - ti * (ti + 1) / 2; }
+        else if (g.col_major) { tj = bid / g.mt; ti = bid - tj * g.mt; }
         else { ti = bid / g.nt; tj = bid - ti * g.nt; }
         if (g.mode == GM_RECT_LOWER && (ti + 1) * TMR <= tj * TNC) return;        // tile entirely above the diagonal
         fresh = g.beta0_from > 0 && ti >= g.beta0_from - 1;
@@ -879,6 +888,17 @@ int launch_sum_slices(const double* slices, int64_t n, int ks, double* out, hipS
 // host looks (a stream-K hand-off of a triangular solve that timed out used to be overwritten here: ADVICE round 3)
 __global__ void k_info_rearm(unsigned long long* info) {
     if (*info != MOGP_INFO_CHAIN_TIMEOUT) *info = ~0ull;
+}
+// the same, keeping what the first factorisation reported in info[1]: the host then looks at both words ONCE, at the synchronisation it needs anyway,
+// instead of stopping the device behind every factorisation (two host round trips of ~250 us per evaluation of the sparse bound)
+__global__ void k_info_stash(unsigned long long* info) {
+    info[1] = info[0];
+    if (info[0] != MOGP_INFO_CHAIN_TIMEOUT) info[0] = ~0ull;
+}
+int launch_info_stash(unsigned long long* info, hipStream_t s) {
+    hipLaunchKernelGGL(k_info_stash, dim3(1), dim3(1), 0, s, info);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 int launch_info_rearm(unsigned long long* info, hipStream_t s) {
     hipLaunchKernelGGL(k_info_rearm, dim3(1), dim3(1), 0, s, info);

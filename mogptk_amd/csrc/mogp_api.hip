@@ -985,7 +985,7 @@ int mogp_model_create(mogp_ctx* ctx, int64_t N, int D, int C, const double* X, c
     TRY_RC(m->d_alpha.ensure((size_t)(1 + nchunks) * Npad));
     TRY_RC(m->d_zz.ensure((Npad + 3) / 4));
     TRY_RC(m->d_diagG.ensure(C));
-    TRY_RC(m->d_info.ensure(1));
+    TRY_RC(m->d_info.ensure(2));                      // [1]: the first factorisation's report of a sparse evaluation (launch_info_stash)
     TRY_RC(m->d_flag.ensure(1));
     TRY_RC(m->d_chan_off.ensure(C + 1));
     TRY_HIP(dev_upload(m->d_x.p, m->sx.xs.data(), (size_t)D * Npad * sizeof(double)));

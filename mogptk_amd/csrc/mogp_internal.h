@@ -169,6 +169,8 @@ struct GemmArgs {
     int small;                                     // 0: 128x128 tiles; 1: 64x128; 2: 64x64 (mt / nt count tiles of that shape)
     int beta0_from;                                // > 0: tile rows ti >= beta0_from - 1 are written with beta = 0 (fresh rows of an accumulator: no memset)
     int ksplit; int64_t c_split;                   // ksplit > 1: the k range is cut into ksplit slices, slice s accumulates into C + s * c_split (not with GM_TASKS)
+    int ksplit_xcd;                                // ksplit a multiple of 8: slice s runs on XCD s mod 8 only (workgroup b -> XCD b mod 8): the 64 workgroups an XCD holds share ONE k window
+    int col_major;                                 // GM_RECT: tiles numbered down the columns (the concurrent workgroups of an XCD share B's column panels; A must be cache-resident)
     int row_mod, row_rem, row_off, row_shift;      // row_mod > 1: only tile rows with ((ti >> row_shift) + row_off) % row_mod == row_rem
                                                    // (sharded evaluation; row_shift = 1 when the launch uses 64-row tiles: ownership is per 128 rows)
     // stream-K form (linalg.hip:k_gemm_sk): sk_spans > 0 = launch that many workgroups, each an equal share of the launch's k iterations
@@ -276,6 +278,7 @@ int launch_axpby(int64_t n, double a, const double* x, double b, const double* y
 int launch_sum_slices(const double* slices, int64_t n, int ks, double* out, hipStream_t s);
 // the pivot word <- "no failure", unless it holds a time-out (MOGP_INFO_CHAIN_TIMEOUT)
 int launch_info_rearm(unsigned long long* info, hipStream_t s);
+int launch_info_stash(unsigned long long* info, hipStream_t s);      // info[1] <- info[0], then re-arm info[0]
 // non-finite scan of the lower triangle: flag[0] |= 1 if NaN seen, |= 2 if Inf seen
 int launch_nonfinite_scan(const double* A, int64_t ld, int64_t n, int* flag, hipStream_t s);
 

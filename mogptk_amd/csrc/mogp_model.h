@@ -158,6 +158,17 @@ struct Spd {
     }
 };
 
+// a tile list split into runs of full interior tiles (strip kernel) and the rest; see split_strip_tiles
+struct StripTiles {
+    std::vector<mogp::GSeg> segs;
+    std::vector<mogp::GTile> rest;
+    mogp::DevBuf<mogp::GSeg> d_segs;
+    mogp::DevBuf<mogp::GTile> d_rest;
+    int build(const std::vector<mogp::GTile>& tiles);      // host split + upload
+    void attach(mogp::GramArgs& ga) const { ga.segs = d_segs.p; ga.nsegs = (int)segs.size(); ga.rest = d_rest.p; ga.nrest = (int)rest.size(); }
+    void release() { d_segs.release(); d_rest.release(); }
+};
+
 // workspaces of the Titsias sparse bound (config 5): two M x M SPD systems and three M x N panels
 struct TitsiasWork {
     int64_t Mpad = 0;
@@ -166,6 +177,8 @@ struct TitsiasWork {
     DevBuf<double> vec, scratch, gz, partial_uu, partial_uf, mom_uu, mom_uf, zero_noise;
     DevBuf<GTile> tiles_uu, tiles_uf;
     DevBuf<int> ps_uu, ps_uf;
+    StripTiles strip_uf;                                // (Z, X) tiles as strip-kernel runs + the rest (titsias_front)
+    std::vector<int> tile_key;                          // channel offsets of Z and X the device copies of the four lists above were made for
     DevBuf<double> Kus, Aus, Bus;                       // prediction panels (Mpad x Spad)
     DevBuf<double> zero_col;                            // Mpad zeros
     DevBuf<double> kslices;                             // split-K partial sums of the Qs SYRK (ks x Mpad x Mpad)
@@ -187,29 +200,18 @@ struct TitsiasWork {
         a.release(); q.release();
         zx.release(); B.release(); v.release(); GB.release(); Qs.release(); E.release(); R.release(); T1.release(); GA.release(); Hm.release();
         vec.release(); scratch.release(); gz.release(); partial_uu.release(); partial_uf.release(); mom_uu.release(); mom_uf.release();
-        zero_noise.release(); tiles_uu.release(); tiles_uf.release(); ps_uu.release(); ps_uf.release();
+        zero_noise.release(); tiles_uu.release(); tiles_uf.release(); ps_uu.release(); ps_uf.release(); strip_uf.release(); tile_key.clear();
         Kus.release(); Aus.release(); Bus.release(); zero_col.release(); kslices.release(); nvec.release(); kd_point.release(); red.release();
         blk_z.release(); blk_x.release(); gzp.release(); hblk_z.clear(); hblk_x.clear();
         for (auto& e : side_ev) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
     }
 };
 
-// a tile list split into runs of full interior tiles (strip kernel) and the rest; see split_strip_tiles
 // workspaces of the Opper-Archambeau model (oa.hip): K itself, two N x N temporaries, the per-point vectors
 struct OaWork {
     mogp::DevBuf<double> K, Sc, Y, vec;
     bool valid = false;                 // a forward pass left its state for the backward call
     void release() { K.release(); Sc.release(); Y.release(); vec.release(); valid = false; }
-};
-
-struct StripTiles {
-    std::vector<mogp::GSeg> segs;
-    std::vector<mogp::GTile> rest;
-    mogp::DevBuf<mogp::GSeg> d_segs;
-    mogp::DevBuf<mogp::GTile> d_rest;
-    int build(const std::vector<mogp::GTile>& tiles);      // host split + upload
-    void attach(mogp::GramArgs& ga) const { ga.segs = d_segs.p; ga.nsegs = (int)segs.size(); ga.rest = d_rest.p; ga.nrest = (int)rest.size(); }
-    void release() { d_segs.release(); d_rest.release(); }
 };
 
 struct mogp_model {
@@ -319,6 +321,7 @@ int side_join(mogp_model* m, TitsiasWork& t, hipStream_t side);
 int gz_prepare(mogp_model* m, TitsiasWork& t, const std::vector<int>& offz, int D);
 void gz_attach(const TitsiasWork& t, MomentArgs& ma, bool zx);
 int spd_check_info(mogp_model* m, const char* which, int64_t* info);
+int spd_info_verdict(mogp_model* m, const char* which, unsigned long long hinfo, int64_t* info);   // what spd_check_info concludes from the word
 // after the LAST stream sync of a sparse / variational evaluation: did a hand-off between workgroups (stream-K GEMM of a wide triangular solve,
 // chain kernel) time out anywhere?  Then the numbers are not valid: the model drops those forms and the call fails, loudly (titsias.hip)
 int sparse_timeout_check(mogp_model* m);
@@ -328,7 +331,7 @@ int chain_fallback(mogp_model* m);     // mogp_api.hip: after MOGP_INFO_CHAIN_TI
 // w.logdet per tile: POTRF, TRTRI, LAUUM.  MOGP_SPARSE_FUSED=1 takes the fused factorisation + inversion schedule of the exact path
 // (potri.hip) instead -- measured SLOWER for the 16-tile-row systems of configs[4] (52.0 vs 49.9 ms per evaluation: four outer blocks give
 // its streams nothing to overlap), kept as a switch.  A failed factorisation is reported through `info` / MOGP_ENOTPD naming `which`.
-int spd_invert(mogp_model* m, Spd& w, const char* which, int64_t* info, const double** W);   // the pivot report of the last factorisation -> MOGP_ENOTPD naming `which`
+int spd_invert(mogp_model* m, Spd& w, const char* which, int64_t* info, const double** W, bool defer_check = false);   // the pivot report of the last factorisation -> MOGP_ENOTPD naming `which`
 // out (Mpad x Mpad, lower tiles) = alpha A B^T over K (leading dimension ldk), K cut into slices so that the launch fills the chip
 int mm_lower_splitk(mogp_model* m, TitsiasWork& t, const double* A, const double* B, double* out, int mt, int64_t Mpad, int64_t ldk, int64_t K,
                     double alpha = 1.0);

@@ -126,6 +126,7 @@ int snelson_front(mogp_model* m, int64_t M, const double* Z, const double* noise
     m->gemm_ev_used = 0; m->gemm_launches = 0; m->gemm_flops = 0.0;
     build_sym_tiles(sz.off, C, tuu, psuu);
     build_rect_tiles(sz.off, m->sx.off, C, tuf, &psuf);
+    t.tile_key.clear();                                     // (the Titsias path keeps its lists in these buffers between evaluations)
     RC(t.tiles_uu.ensure(tuu.size())); RC(t.tiles_uf.ensure(tuf.size()));
     HIP_TRY(hipMemcpyAsync(t.zx.p, sz.xs.data(), (size_t)D * Mpad * sizeof(double), hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(t.tiles_uu.p, tuu.data(), tuu.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));

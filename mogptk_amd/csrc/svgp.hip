@@ -160,6 +160,7 @@ int mogp_svgp_forward(mogp_model* m, int64_t M, const double* Z, const double* q
         build_rect_tiles(sz.off, sp->off, C, tuf, &psuf);
         DevBuf<GTile>& dt = train ? t.tiles_uf : m->d_ptiles;
         RC(dt.ensure(tuf.size()));
+        t.tile_key.clear();
         HIP_TRY(hipMemcpyAsync(dt.p, tuf.data(), tuf.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
         double* Kq = train ? t.B.p : t.Kus.p;
         HIP_TRY(hipMemsetAsync(Kq, 0, (size_t)Mpad * Qpad * sizeof(double), m->st));

@@ -48,17 +48,18 @@ int side_join(mogp_model* m, TitsiasWork& t, hipStream_t side) {
     return 0;
 }
 
-int spd_invert(mogp_model* m, Spd& w, const char* which, int64_t* info, const double** W) {
+// defer_check: the caller reads the pivot word itself at its next synchronisation (a failed factorisation then runs on with garbage: bounded, harmless)
+int spd_invert(mogp_model* m, Spd& w, const char* which, int64_t* info, const double** W, bool defer_check) {
     static const bool fused = std::getenv("MOGP_SPARSE_FUSED") && std::atoi(std::getenv("MOGP_SPARSE_FUSED")) != 0;
     if (fused && w.nb <= 80) {
         RC(spd_potri_fused(m, w));
         RC(spd_potri_fused_finish(m, w));
-        RC(spd_check_info(m, which, info));
+        if (!defer_check) RC(spd_check_info(m, which, info));
         *W = w.Wm.p;
         return 0;
     }
     RC(spd_potrf(m, w));
-    RC(spd_check_info(m, which, info));
+    if (!defer_check) RC(spd_check_info(m, which, info));
     RC(spd_trtri(m, w));                                                        // w.A = L^-1
     RC(spd_lauum(m, w));                                                        // w.B = inverse (lower)
     *W = w.A.p;
@@ -93,6 +94,10 @@ int spd_check_info(mogp_model* m, const char* which, int64_t* info) {
     unsigned long long hinfo = 0;
     HIP_TRY(hipMemcpyAsync(&hinfo, m->d_info.p, sizeof(hinfo), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
+    return spd_info_verdict(m, which, hinfo, info);
+}
+
+int spd_info_verdict(mogp_model* m, const char* which, unsigned long long hinfo, int64_t* info) {
     if (hinfo == MOGP_INFO_CHAIN_TIMEOUT) {
         m->no_chain = true;                                  // gates the chain kernel AND the stream-K launches (mogp_api.hip:stream_k_setup)
         return fail(MOGP_EHIP, "a hand-off between workgroups timed out (chain kernel, chain.hip, or a stream-K GEMM, linalg.hip:k_gemm_sk: the GPU is "
@@ -124,6 +129,7 @@ int mm_lower_splitk(mogp_model* m, TitsiasWork& t, const double* A, const double
     GemmArgs g = make_gemm(A, ldk, 0, B, ldk, 0, out, Mpad, alpha, GM_LOWER, mt, mt, K);
     const int tiles_q = mt * (mt + 1) / 2;
     int ks = 1;
+    static const int ks_env = []() { const char* e = std::getenv("MOGP_SYRK_KS"); return e ? atoi(e) : 0; }();      // > 0: that many slices, slice-major; < 0: |.| slices, one XCD each
     if (tiles_q < 512 && K >= 4096) {
         double best = 1e30;
         for (int c = 1; c <= 16; ++c) {
@@ -131,6 +137,11 @@ int mm_lower_splitk(mogp_model* m, TitsiasWork& t, const double* A, const double
             const double cost = std::ceil((double)tiles_q * c / 512.0) / c;
             if (cost < best - 1e-12) { best = cost; ks = c; }
         }
+        // (round 4: eight or sixteen slices, each on ONE XCD -- k_gemm: ksplit_xcd, the workgroups that share an L2 then share a k window as well --
+        // measured no faster than fifteen slice-major ones, 45.4 vs 45.3 ms at configs[4], although those fetch 12.4 GB for 1.6 GB of v: the product is
+        // not bound by that traffic; kept as a switch)
+        if (ks_env > 0) ks = ks_env;
+        if (ks_env < 0) { ks = -ks_env; g.ksplit_xcd = (ks % 8 == 0); }
     }
     if (ks > 1) {
         if (t.kslices.n < (size_t)ks * Mpad * Mpad) {         // the upper tiles are never written: keep them finite
@@ -182,14 +193,24 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     m->gemm_ev_used = 0; m->gemm_launches = 0; m->gemm_flops = 0.0;
     build_sym_tiles(sz.off, C, tuu, psuu);
     build_rect_tiles(sz.off, m->sx.off, C, tuf, &psuf);
-    RC(t.tiles_uu.ensure(tuu.size())); RC(t.tiles_uf.ensure(tuf.size()));
     HIP_TRY(hipMemcpyAsync(t.zx.p, sz.xs.data(), (size_t)D * Mpad * sizeof(double), hipMemcpyHostToDevice, m->st));
-    HIP_TRY(hipMemcpyAsync(t.tiles_uu.p, tuu.data(), tuu.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
-    HIP_TRY(hipMemcpyAsync(t.tiles_uf.p, tuf.data(), tuf.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
-    if (need_moment_tiles) {
+    // the tile lists depend on the channel offsets of Z and X only: uploaded when those change, not per evaluation (1.2 MB of pageable copies at
+    // configs[4]); the (Z, X) list also as strip-kernel runs
+    std::vector<int> key(sz.off);
+    key.insert(key.end(), m->sx.off.begin(), m->sx.off.end());
+    if (key != t.tile_key) {
+        t.tile_key.clear();
+        HIP_TRY(hipStreamSynchronize(m->st));                   // a previous evaluation's kernels may still read the lists (first call / a new Z layout only)
+        RC(t.tiles_uu.ensure(tuu.size())); RC(t.tiles_uf.ensure(tuf.size()));
+        HIP_TRY(dev_upload(t.tiles_uu.p, tuu.data(), tuu.size() * sizeof(GTile)));
+        HIP_TRY(dev_upload(t.tiles_uf.p, tuf.data(), tuf.size() * sizeof(GTile)));
+        RC(t.strip_uf.build(tuf));
         RC(t.ps_uu.ensure(psuu.size())); RC(t.ps_uf.ensure(psuf.size()));
-        HIP_TRY(hipMemcpyAsync(t.ps_uu.p, psuu.data(), psuu.size() * sizeof(int), hipMemcpyHostToDevice, m->st));
-        HIP_TRY(hipMemcpyAsync(t.ps_uf.p, psuf.data(), psuf.size() * sizeof(int), hipMemcpyHostToDevice, m->st));
+        HIP_TRY(dev_upload(t.ps_uu.p, psuu.data(), psuu.size() * sizeof(int)));
+        HIP_TRY(dev_upload(t.ps_uf.p, psuf.data(), psuf.size() * sizeof(int)));
+        t.tile_key = key;
+    }
+    if (need_moment_tiles) {
         RC(t.partial_uu.ensure(tuu.size() * (size_t)m->T * W)); RC(t.partial_uf.ensure(tuf.size() * (size_t)m->T * W));
         RC(t.mom_uu.ensure((size_t)(C * (C + 1) / 2) * m->T * W)); RC(t.mom_uf.ensure((size_t)C * C * m->T * W));
     }
@@ -211,12 +232,12 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     RC(side_fork(m, t, &side));
     ga.tiles = t.tiles_uf.p; ga.xc = m->d_x.p; ga.ldxc = Npad; ga.ncols = m->N; ga.out = t.B.p; ga.ldo = Npad; ga.noise = nullptr; ga.jitter_abs = 0.0;
     ga.out2 = t.v.p;                                                            // the copy the solve below works in, written by the same kernel
+    t.strip_uf.attach(ga);                                                      // full interior tiles in runs of four on the strip kernel
     RC(t.ph_zx.prepare(sz.off, m->sx.off, C, m->T, Mpad, Npad, side, ga.ph));
     RC(launch_gram(ga, (int)tuf.size(), side));
 
     t.a.keep_L = true;                                                          // the solves below need L itself, diagonal tiles included
-    RC(spd_potrf(m, t.a));
-    RC(spd_check_info(m, "Kuu", info));
+    RC(spd_potrf(m, t.a));                                                      // its pivot report is read with the scalars at the end of this function
     const double s2 = sigma * sigma;
     RC(side_join(m, t, side));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.v.p, Npad, Npad, false));              // v = L^-1 B   (reference gpr/model.py:711)
@@ -247,8 +268,8 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     }
     RC(launch_add_diag(t.q.A.p, Mpad, Mpad, 1.0, m->st));
     HIP_TRY(hipMemcpyAsync(t.Qs.p, t.q.A.p, (size_t)Mpad * Mpad * sizeof(double), hipMemcpyDeviceToDevice, m->st));
-    RC(launch_info_rearm(m->d_info.p, m->st));              // (not a plain overwrite: a time-out of the wide solve above must reach the host)
-    RC(spd_invert(m, t.q, "Q/sigma^2 + I", info, &t.Wq));                       // t.Wq = Lq^-1, t.q.B = Pq (lower)
+    RC(launch_info_stash(m->d_info.p, m->st));              // Kuu's report (and a time-out of the wide solve above) -> info[1]; info[0] armed for Qs
+    RC(spd_invert(m, t.q, "Q/sigma^2 + I", info, &t.Wq, true));                 // t.Wq = Lq^-1, t.q.B = Pq (lower)
     RC(launch_symmetrize(t.q.B.p, Mpad, Mpad, m->st));
     double* t1 = t.vec.p + Mpad;
     double* dg = t.vec.p + 2 * Mpad;                                            // diag Pq, diag Qs
@@ -271,7 +292,11 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     std::vector<double> hv((size_t)4 * Mpad), hl(nbq);
     HIP_TRY(hipMemcpyAsync(hv.data(), t.vec.p, (size_t)4 * Mpad * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(hl.data(), t.q.logdet.p, nbq * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    unsigned long long hinfo[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(hinfo, m->d_info.p, sizeof(hinfo), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
+    RC(spd_info_verdict(m, "Kuu", hinfo[1], info));                             // the one synchronisation of the forward part: both factorisations' reports
+    RC(spd_info_verdict(m, "Q/sigma^2 + I", hinfo[0], info));
     sc.logdet_q = 0.0; for (double x : hl) sc.logdet_q += x;
     sc.t1vy = sc.t1t1 = sc.trPq = sc.trQs = 0.0;
     for (int64_t i = 0; i < M; ++i) {
@@ -331,6 +356,10 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
     // The large product is ENQUEUED before the side chain's ~70 launches, so that a slow host does not hold it back.
     RC(launch_combine(t.R.p, t.q.B.p, nullptr, Mpad, Mpad, 1.0, 1.0, 0.0, m->st));           // R = I - Pq
     GemmArgs g = make_gemm(t.R.p, Mpad, 0, t.v.p, Npad, 1, t.GB.p, Npad, 1.0 / s2, GM_RECT, mt, nt, Mpad);
+    // tiles down the columns: the 64 workgroups an XCD holds are then 64 / mt column blocks of v against all of R (M x M: cache-resident), and v comes
+    // in from memory once -- row by row it came in mt times (27 GB fetched at configs[4] for a 1.6 GB panel)
+    static const bool rv_cols = !(std::getenv("MOGP_RV_COLS") && atoi(std::getenv("MOGP_RV_COLS")) == 0);
+    g.col_major = rv_cols ? 1 : 0;
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
     RC(launch_combine(t.E.p, t.q.B.p, t.Qs.p, Mpad, Mpad, 2.0, 1.0, 1.0, side));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.E.p, Mpad, Mpad, true, side));
