@@ -179,6 +179,7 @@ struct TitsiasWork {
     DevBuf<int> ps_uu, ps_uf;
     StripTiles strip_uf;                                // (Z, X) tiles as strip-kernel runs + the rest (titsias_front)
     std::vector<int> tile_key;                          // channel offsets of Z and X the device copies of the four lists above were made for
+    size_t n_tuu = 0, n_tuf = 0;                        // their lengths (the host lists themselves are built only when the key changes)
     DevBuf<double> Kus, Aus, Bus;                       // prediction panels (Mpad x Spad)
     DevBuf<double> zero_col;                            // Mpad zeros
     DevBuf<double> kslices;                             // split-K partial sums of the Qs SYRK (ks x Mpad x Mpad)

@@ -191,15 +191,15 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
         { int r__ = dev_fill_zero(t.v.p, (size_t)Mpad * Npad * sizeof(double)); if (r__) return r__; }      // ... nor that of its working copy (the solves keep zeros zero)
     }
     m->gemm_ev_used = 0; m->gemm_launches = 0; m->gemm_flops = 0.0;
-    build_sym_tiles(sz.off, C, tuu, psuu);
-    build_rect_tiles(sz.off, m->sx.off, C, tuf, &psuf);
     HIP_TRY(hipMemcpyAsync(t.zx.p, sz.xs.data(), (size_t)D * Mpad * sizeof(double), hipMemcpyHostToDevice, m->st));
-    // the tile lists depend on the channel offsets of Z and X only: uploaded when those change, not per evaluation (1.2 MB of pageable copies at
-    // configs[4]); the (Z, X) list also as strip-kernel runs
+    // the tile lists depend on the channel offsets of Z and X only: built and uploaded when those change, not per evaluation (50 000 tiles and 1.2 MB
+    // of pageable copies at configs[4], all of it in front of the evaluation's first kernel); the (Z, X) list also as strip-kernel runs
     std::vector<int> key(sz.off);
     key.insert(key.end(), m->sx.off.begin(), m->sx.off.end());
     if (key != t.tile_key) {
         t.tile_key.clear();
+        build_sym_tiles(sz.off, C, tuu, psuu);
+        build_rect_tiles(sz.off, m->sx.off, C, tuf, &psuf);
         HIP_TRY(hipStreamSynchronize(m->st));                   // a previous evaluation's kernels may still read the lists (first call / a new Z layout only)
         RC(t.tiles_uu.ensure(tuu.size())); RC(t.tiles_uf.ensure(tuf.size()));
         HIP_TRY(dev_upload(t.tiles_uu.p, tuu.data(), tuu.size() * sizeof(GTile)));
@@ -208,10 +208,11 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
         RC(t.ps_uu.ensure(psuu.size())); RC(t.ps_uf.ensure(psuf.size()));
         HIP_TRY(dev_upload(t.ps_uu.p, psuu.data(), psuu.size() * sizeof(int)));
         HIP_TRY(dev_upload(t.ps_uf.p, psuf.data(), psuf.size() * sizeof(int)));
+        t.n_tuu = tuu.size(); t.n_tuf = tuf.size();
         t.tile_key = key;
     }
     if (need_moment_tiles) {
-        RC(t.partial_uu.ensure(tuu.size() * (size_t)m->T * W)); RC(t.partial_uf.ensure(tuf.size() * (size_t)m->T * W));
+        RC(t.partial_uu.ensure(t.n_tuu * (size_t)m->T * W)); RC(t.partial_uf.ensure(t.n_tuf * (size_t)m->T * W));
         RC(t.mom_uu.ensure((size_t)(C * (C + 1) / 2) * m->T * W)); RC(t.mom_uf.ensure((size_t)C * C * m->T * W));
     }
     const unsigned long long big = std::numeric_limits<unsigned long long>::max();
@@ -225,7 +226,7 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     RC(t.ph_zz.prepare(sz.off, sz.off, C, m->T, Mpad, Mpad, m->st, ga.ph));
     ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = W; ga.out = t.a.A.p; ga.ldo = Mpad;
     ga.noise = t.zero_noise.p; ga.dvar = nullptr; ga.jitter_abs = sc.jit; ga.mirror = 0;
-    RC(launch_gram(ga, (int)tuu.size(), m->st));
+    RC(launch_gram(ga, (int)t.n_tuu, m->st));
     RC(launch_pad_identity(t.a.A.p, Mpad, M, Mpad, m->st));
     // Kuf and its working copy on the side stream, underneath the (chain-bound) factorisation of Kuu
     hipStream_t side;
@@ -234,7 +235,7 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     ga.out2 = t.v.p;                                                            // the copy the solve below works in, written by the same kernel
     t.strip_uf.attach(ga);                                                      // full interior tiles in runs of four on the strip kernel
     RC(t.ph_zx.prepare(sz.off, m->sx.off, C, m->T, Mpad, Npad, side, ga.ph));
-    RC(launch_gram(ga, (int)tuf.size(), side));
+    RC(launch_gram(ga, (int)t.n_tuf, side));
 
     t.a.keep_L = true;                                                          // the solves below need L itself, diagonal tiles included
     RC(spd_potrf(m, t.a));                                                      // its pivot report is read with the scalars at the end of this function
@@ -387,7 +388,7 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
 
     MomentArgs ma{};
     gz_attach(t, ma, true);
-    ma.tiles = t.tiles_uf.p; ma.ntiles = (int)tuf.size(); ma.x = t.zx.p; ma.ldx = Mpad; ma.xc = m->d_x.p; ma.ldxc = Npad;
+    ma.tiles = t.tiles_uf.p; ma.ntiles = (int)t.n_tuf; ma.x = t.zx.p; ma.ldx = Mpad; ma.xc = m->d_x.p; ma.ldxc = Npad;
     ma.nrows = M; ma.ncols = N;
     RC(t.ph_zx.prepare(sz.off, m->sx.off, C, T, Mpad, Npad, m->st, ma.ph));
     ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C; ma.W = W;
@@ -400,7 +401,7 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
         RC(comm_allreduce(m->ctx, t.gz.p, (int64_t)D * Mpad, m->st));
     }
     RC(side_join(m, t, side));
-    ma.tiles = t.tiles_uu.p; ma.ntiles = (int)tuu.size(); ma.xc = nullptr; ma.ldxc = 0; ma.ncols = M;
+    ma.tiles = t.tiles_uu.p; ma.ntiles = (int)t.n_tuu; ma.xc = nullptr; ma.ldxc = 0; ma.ncols = M;
     RC(t.ph_zz.prepare(sz.off, sz.off, C, T, Mpad, Mpad, m->st, ma.ph));
     ma.G = t.GA.p; ma.ldg = Mpad; ma.ru = beta; ma.rw = beta; ma.rcoef = -0.5 / (s2 * s2); ma.sym = 1;
     ma.gzr = t.gz.p; ma.gzc = t.gz.p; ma.partial = t.partial_uu.p;

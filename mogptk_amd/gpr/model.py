@@ -493,7 +493,11 @@ class Titsias(_DataParallel, Model):
         s2 = self._sigma() ** 2
         M = Zk.shape[0]
         zc = np.bincount(Zk[:, 0].astype(np.int64), minlength=C).astype(np.float64)
-        xc = np.bincount(self.kernel._kernel_format(self.X)[:, 0].astype(np.int64), minlength=C).astype(np.float64)
+        xc = self.__dict__.get("_xc_cache")                    # training points per channel: X does not change under a model (O(N) per evaluation otherwise)
+        if xc is None or xc[0] is not self.X or xc[1].shape[0] != C:
+            xc = (self.X, np.bincount(self.kernel._kernel_format(self.X)[:, 0].astype(np.int64), minlength=C).astype(np.float64))
+            self.__dict__["_xc_cache"] = xc
+        xc = xc[1]
         gt = _gtable_from_moments(table, res["mom_uu"], D, lower=True) + _gtable_from_moments(table, res["mom_uf"], D, lower=False)
         env = table.shape[3] > 2 + 3 * D
         gz_jit = 0.0
