@@ -23,6 +23,7 @@
 // Wm = W = L^-1 (final row blocks; the chain kernels write W_KK straight into its diagonal blocks), B = Kj^-1 accumulator.
 // Replaces torch.linalg.cholesky + the O(N^3) solves of its autograd backward (reference gpr/model.py:242-246, :291).
 #include "mogp_model.h"
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -740,6 +741,8 @@ int spd_potri_flow(mogp_model* m, Spd& w) {
         t1.mode = GM_KHI_J; t1.small = 1; t1.mt = 2 * na; t1.nt = nk; t1.K = nk * MOGP_TILE;
         t1.fl_flags = w.flow_flags.p; t1.fl_nwait = pc.t1_nwait;
         for (int k = 0; k < pc.t1_nwait; ++k) { t1.fl_widx[k] = pc.t1_widx[k]; t1.fl_wval[k] = pc.t1_wval[k]; }
+        static const unsigned hook_spins = std::getenv("MOGP_FLOW_HOOK_SPINS") ? (unsigned)std::atoll(std::getenv("MOGP_FLOW_HOOK_SPINS")) : 0u;
+        t1.fl_spins = hook_spins;
         t1.fl_wt = 1; t1.fl_sig = 1; t1.fl_sig_base = pc.t1_sig_base; t1.fl_sig_shift = 1; t1.fl_err = ferr; t1.sk_info = m->d_info.p;
         if ((rc = launch_gemm(t1, priv))) return rc;
         // (the first launch of this stream that touches A beyond its first 512 columns: the rest of the Gram matrix may still be on its way)
@@ -750,7 +753,7 @@ int spd_potri_flow(mogp_model* m, Spd& w) {
         t2.C = w.A.p + (int64_t)k1 * MOGP_TILE * (ld + 1); t2.ldc = ld; t2.alpha = -1.0; t2.beta = 1.0;
         t2.mode = GM_RECT_LOWER; t2.small = 2; t2.mt = 2 * na; t2.nt = 2 * na; t2.K = nk * MOGP_TILE;
         t2.fl_flags = w.flow_flags.p; t2.fl_nwait = pc.t2_wval ? 1 : 0; t2.fl_widx[0] = pc.t2_widx; t2.fl_wval[0] = pc.t2_wval;
-        t2.fl_err = ferr; t2.sk_info = m->d_info.p;
+        t2.fl_err = ferr; t2.sk_info = m->d_info.p; t2.fl_spins = hook_spins;
         if ((rc = launch_gemm(t2, priv))) return rc;
         m->gemm_flops += gemm_flops(t1, nullptr) + gemm_flops(t2, nullptr);
     }
@@ -767,6 +770,8 @@ int spd_potri_flow(mogp_model* m, Spd& w) {
     w.fused_last_inv = nullptr; w.fused_last_wt = nullptr;
     w.flow_used = true;
     m->flow_ran = true;
+    { const char* e = std::getenv("MOGP_FLOW_DEBUG");
+      if (e && std::atoi(e) == 2 && &w == &m->k) { usleep(60000); fprintf(stderr, "mogp: dataflow state 60 ms after the evaluation was enqueued\n"); flow_debug_dump(m); } }
     return 0;
 }
 

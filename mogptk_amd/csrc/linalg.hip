@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64 * NWI * NWJ, NWI * NWJ / 2) void k_gemm(GemmArgs
                     __builtin_amdgcn_s_sleep(2);
                     if ((++spins & 127u) == 0u) {
                         if (__hip_atomic_load(g.fl_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                        if (spins > 400000u) { __hip_atomic_store(g.fl_err, 0x800u + (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        if (spins > (g.fl_spins ? g.fl_spins : 400000u)) { __hip_atomic_store(g.fl_err, 0x800u + (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                     }
                 }
             }

@@ -9,6 +9,9 @@
 #include <cstdlib>
 #include <limits>
 #include <numeric>
+#include <unistd.h>
+#include <map>
+#include <set>
 
 namespace mogp {
 
@@ -163,6 +166,20 @@ int mogp_ctx_create(int device, mogp_ctx** out) {
     mogp_ctx* c = new mogp_ctx();
     c->device = device;
     c->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    {   // One device-to-host copy of more than 16 KB into pinned memory NOW.  The first such copy of a process sets something up inside the runtime, and when
+        // that happened while the dataflow kernel and its chain kernels were running (the z^T z parts of a model with more than 8192 points: 18 KB), they
+        // stalled until their waits gave up: every first evaluation above N = 8192 fell back to the stream schedule (tools/r4_first.py; 16 KB pieces do not
+        // trigger it, a sleep in front of the copy avoids it).  Found in round 4 when the dataflow default went to 96 tile rows.
+        void* dsrc = nullptr; void* hdst = nullptr;
+        const size_t nbytes = 256 * 1024;
+        if (hipMalloc(&dsrc, nbytes) == hipSuccess && hipHostMalloc(&hdst, nbytes, hipHostMallocDefault) == hipSuccess) {
+            hipError_t e = hipMemsetAsync(dsrc, 0, nbytes, c->st); (void)e;
+            e = hipMemcpyAsync(hdst, dsrc, nbytes, hipMemcpyDeviceToHost, c->st); (void)e;
+            e = hipStreamSynchronize(c->st); (void)e;
+        }
+        if (hdst) { hipError_t e = hipHostFree(hdst); (void)e; }
+        if (dsrc) { hipError_t e = hipFree(dsrc); (void)e; }
+    }
     *out = c;
     return MOGP_OK;
 }
@@ -603,6 +620,62 @@ static int pin_ensure(mogp_model* m, size_t n) {
 
 static int factorize_finish(mogp_model* m, const GramArgs& ga, double* lml, int64_t* info);
 
+// MOGP_FLOW_DEBUG: where every queue of the dataflow schedule stands, what its next tasks wait for, the private stream's waits; with MOGP_FLOW_TRACE=1
+// also the tasks finished per 5 ms.  (1: after a time-out; 2: 60 ms after the evaluation was enqueued, while whatever is stuck is still stuck)
+namespace mogp { void flow_debug_dump(mogp_model* m) {
+    if (!m->k.flow_flags.p) return;
+    const FlowPlan& p = m->k.flow;
+    std::vector<unsigned> fl((size_t)p.nflags);
+    hipError_t e = hipMemcpy(fl.data(), m->k.flow_flags.p, fl.size() * sizeof(unsigned), hipMemcpyDeviceToHost); (void)e;
+    std::vector<unsigned long long> tr;
+    if (m->k.flow_trace.p && m->k.flow_trace.n >= FLOW_TRACE_W * p.tasks.size()) {
+        tr.resize(FLOW_TRACE_W * p.tasks.size());
+        e = hipMemcpy(tr.data(), m->k.flow_trace.p, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost); (void)e;
+    }
+    fprintf(stderr, "  error word 0x%x\n", fl[p.base_err]);
+    for (int q = 0; q < p.nq; ++q) {
+        const unsigned h = fl[p.base_heads + q];
+        const unsigned claimed = std::min<unsigned>(h, (unsigned)p.qsize[q]);
+        unsigned done = 0, shown = 0;
+        fprintf(stderr, "  queue %2d: head %u of %d", q, h, p.qsize[q]);
+        for (unsigned hh = 0; hh < (unsigned)p.qsize[q]; ++hh) {
+            const size_t ti = (size_t)p.qbase[q] + hh;
+            const FlowTask& t = p.tasks[ti];
+            const bool fin = !tr.empty() && tr[FLOW_TRACE_W * ti + 4] != 0;
+            if (fin) { ++done; continue; }
+            if (tr.empty() && hh + 4 < claimed) continue;              // without the trace: the last claimed ones and the head
+            if (hh > claimed || shown >= 6) continue;
+            ++shown;
+            fprintf(stderr, "\n      %s task %u key %u C(buf %d %d,%d) A(buf %d %d,%d) B(buf %d %d,%d) kt %d var %d:", hh < claimed ? "CLAIMED" : "head   ", hh, t.key,
+                    t.cbuf, t.cr, t.cc, t.abuf, t.ar, t.ac, t.bbuf, t.br, t.bc, t.kt, t.var);
+            for (int d = 0; d < t.ndep; ++d) fprintf(stderr, " flag[%u]=%u/%u", t.dep[d], fl[t.dep[d]], (unsigned)t.need[d]);
+            if (!tr.empty()) fprintf(stderr, "  (taken by wg %llu: %s)", tr[FLOW_TRACE_W * ti + 5] & 0xffff, tr[FLOW_TRACE_W * ti + 1] ? "running" : "not started");
+        }
+        if (!tr.empty()) fprintf(stderr, "\n      finished %u", done);
+        fprintf(stderr, "\n");
+    }
+    if (!tr.empty()) {                                                      // tasks finished and workgroups seen per 5 ms
+        unsigned long long t0 = ~0ull;
+        for (size_t i = 0; i < p.tasks.size(); ++i) if (tr[FLOW_TRACE_W * i + 1] && tr[FLOW_TRACE_W * i + 1] < t0) t0 = tr[FLOW_TRACE_W * i + 1];
+        std::map<long, std::pair<int, std::set<unsigned>>> win;
+        for (size_t i = 0; i < p.tasks.size(); ++i) {
+            const unsigned long long en = tr[FLOW_TRACE_W * i + 4];
+            if (!en) continue;
+            auto& w = win[(long)((en - t0) / 500000ull)];
+            ++w.first; w.second.insert((unsigned)(tr[FLOW_TRACE_W * i + 5] & 0xffff));
+        }
+        for (auto& kv : win) fprintf(stderr, "  %4ld ms: %6d tasks done by %3zu workgroups\n", kv.first * 5, kv.second.first, kv.second.second.size());
+    }
+    for (size_t b = 0; b < p.chain.size(); ++b) {
+        const FlowPlan::Chain& c = p.chain[b];
+        fprintf(stderr, "  chain %zu done flag[%u]=%u/%u; mini-panel waits", b, c.done_idx, fl[c.done_idx], c.expect);
+        for (int k = 0; k < c.t1_nwait; ++k) fprintf(stderr, " flag[%u]=%u/%u", c.t1_widx[k], fl[c.t1_widx[k]], c.t1_wval[k]);
+        fprintf(stderr, "; signals from %u:", c.t1_sig_base);
+        for (int k = 0; k < 4; ++k) fprintf(stderr, " %u", fl[c.t1_sig_base + k]);
+        fprintf(stderr, " (of %u); next-diagonal update waits flag[%u]=%u/%u\n", c.t1_sig_per_row, c.t2_widx, fl[c.t2_widx], c.t2_wval);
+    }
+} }
+
 // A hand-off inside the persistent chain kernel (chain.hip) timed out: its 13 workgroups were not all resident -- another process sharing the
 // GPU holds part of the reserved CUs with its own chain kernel (two such kernels can each hold some of the 16 CUs and wait for the rest).
 // Nothing is wrong with the data: drain the streams and repeat the evaluation on the launch-per-step chain, which this model keeps from now on.
@@ -612,7 +685,13 @@ namespace mogp { int chain_fallback(mogp_model* m) {
         m->no_flow = true; m->flow_ran = false;
         for (hipStream_t q : {m->st, m->st2, m->st3, m->st4, m->ctx->st5, m->st_priv}) if (q) HIP_TRY(hipStreamSynchronize(q));
         static bool said_flow = false;
-        if (!said_flow) { said_flow = true; fprintf(stderr, "mogp: the dataflow kernel timed out (GPU shared with another process?); using the stream schedule\n"); }
+        if (!said_flow) {
+            said_flow = true;
+            unsigned code = 0;                       // which wait gave up: 0x700 an idle workgroup of the dataflow kernel, 0x800 + k a hook of a private-stream launch, else a chain kernel's
+            if (m->k.flow_flags.p && m->k.flow.base_err > 0) { hipError_t e = hipMemcpy(&code, m->k.flow_flags.p + m->k.flow.base_err, sizeof(code), hipMemcpyDeviceToHost); (void)e; }
+            fprintf(stderr, "mogp: the dataflow kernel timed out (wait 0x%x; GPU shared with another process?); using the stream schedule\n", code);
+            if (std::getenv("MOGP_FLOW_DEBUG")) flow_debug_dump(m);
+        }
         return 0;
     }
     if (m->no_chain) return fail(MOGP_EHIP, "chain kernel: a hand-off timed out although the model is on the launch-per-step chain");
@@ -695,6 +774,9 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     ga.ev0 = ga.ev1 = nullptr;
     if ((rc = mark(m, 1))) return rc;
 
+    // every allocation of this evaluation BEFORE the co-operating kernels are enqueued
+    if ((rc = pin_ensure(m, (size_t)m->nb + (size_t)((Npad + 3) / 4) + 1 + (size_t)(C * (C + 1) / 2) * m->T * m->Wt + C))) return rc;
+    m->k.flow_used = false;                           // (mogp_model_schedule reports the LAST evaluation: set again by spd_potri_flow)
     m->k.want_vec = fuse_inverse && !factor_only;     // the dataflow schedule (flow.hip) also forms z = W y and alpha = W^T z
     m->k.vec_y = m->d_y.p; m->k.vec_z = m->d_z.p; m->k.vec_zz = m->d_zz.p; m->k.vec_part = m->d_alpha.p + Npad;
     rc = fuse_inverse ? spd_potri_fused(m, m->k) : spd_potrf(m, m->k);
@@ -727,7 +809,9 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     const int nb = m->nb;
     if ((rc = pin_ensure(m, (size_t)nb + nzz + 1 + (size_t)(C * (C + 1) / 2) * m->T * m->Wt + C))) return rc;
     HIP_TRY(hipMemcpyAsync(m->h_pin, m->k.logdet.p, nb * sizeof(double), hipMemcpyDeviceToHost, m->st));
-    HIP_TRY(hipMemcpyAsync(m->h_pin + nb, m->d_zz.p, nzz * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    static const int zz_piece = []() { const char* e = std::getenv("MOGP_D2H_CHUNK"); const int v = e ? std::atoi(e) : 2048; return v > 0 ? v : (1 << 30); }();
+    for (int o = 0; o < nzz; o += zz_piece)               // in pieces of 16 KB: see mogp_ctx_create on larger device-to-host copies next to running co-operating kernels
+        HIP_TRY(hipMemcpyAsync(m->h_pin + nb + o, m->d_zz.p + o, std::min(zz_piece, nzz - o) * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(m->h_pin + nb + nzz, m->d_info.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, m->st));
     if (ga_out) *ga_out = ga;
     if (defer) return 0;
@@ -1081,18 +1165,22 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     if (info) *info = 0;
     // Gradient evaluation, three schedules of the same arithmetic (MOGP_GRAD_PATH = fused | phases | sweep overrides the choice):
     //   fused   potri.hip: the inverse streamed behind the Cholesky chain.  Wins while the serial chain dominates: 15.1 vs 15.9 ms at
-    //           N = 8192, 20.1 vs 21.1 ms at N = 9216, even at N = 10240 -- the default up to 80 tile rows.
+    //           N = 8192, 20.1 vs 21.1 ms at N = 9216, even at N = 10240 -- the default up to 80 tile rows (112 as dataflow, below).
     //   phases  POTRF, TRTRI, LAUUM one after the other: fewer, larger GEMM launches.  Wins once the evaluation is flop-bound
     //           (38.8 vs 41.8 ms at N = 12288, 80.6 vs 90.1 ms at N = 16384, 569 vs 657 ms at N = 32768) -- the default above.
     //   sweep   sweep.hip: single-sweep blocked inversion; slower on one GPU (47 evals/s at N = 8192) but with one panel
     //           exchange per pivot block, which is what the sharded multi-GPU evaluation (mogp_shard_*) is built on.
     static const std::string grad_path = []() { const char* e = std::getenv("MOGP_GRAD_PATH"); return std::string(e ? e : ""); }();
     const bool sweep = grad_path == "sweep" && (flags & MOGP_EVAL_GRAD);
-    const bool fused = !sweep && (flags & MOGP_EVAL_GRAD) && (grad_path == "fused" || (grad_path != "phases" && m->nb <= 80));
     const bool grad = (flags & MOGP_EVAL_GRAD) != 0;
     GramArgs ga{};
     if ((rc = ensure_system(m))) return rc;
     if ((rc = kinv_plan(m, grad && !sweep))) return rc;
+    // round 4: as tile dataflow (flow.hip) the fused schedule also beats the phases at 81 .. 112 tile rows (configs[1]'s kernel, tools/r4_sizes.sh:
+    // 19.3 vs 22.4 ms at N = 10240, 32.5 vs 35.9 at 12288, 41.0 vs 43.8 at 13312, 50.7 vs 53.0 at 14336; 76.6 vs 75.8 the other way at 16384); where
+    // the dataflow kernel is not available (switched off, fallen back, a planned inverse) the stream form keeps its 80
+    const int fused_max = flow_enabled(m, m->k) ? 112 : 80;
+    const bool fused = !sweep && grad && (grad_path == "fused" || (grad_path != "phases" && m->nb <= fused_max));
     if (sweep) {
         if ((rc = eval_sweep(m, noise_var, data_var, jitter, lml, jitter_abs, info))) {
             if (rc != MOGP_RETRY_NO_CHAIN) return rc;

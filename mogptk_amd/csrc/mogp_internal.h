@@ -185,7 +185,7 @@ struct GemmArgs {
     // until fl_flags[fl_widx[k]] >= fl_wval[k] for k < fl_nwait (then ONE agent acquire), stores C write-through when fl_wt, and when fl_sig
     // bumps fl_flags[fl_sig_base + (tile row >> fl_sig_shift)] once its tile has left the CU.  fl_err: the schedule's error word.
     unsigned* fl_flags; int fl_nwait; unsigned fl_widx[4]; unsigned fl_wval[4];
-    int fl_wt, fl_sig; unsigned fl_sig_base; int fl_sig_shift; unsigned* fl_err;
+    int fl_wt, fl_sig; unsigned fl_sig_base; int fl_sig_shift; unsigned* fl_err; unsigned fl_spins;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 double gemm_flops(const GemmArgs& a, const std::vector<GemmTask>* host_tasks);

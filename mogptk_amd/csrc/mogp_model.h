@@ -341,7 +341,9 @@ int spd_potrf(mogp_model* m, Spd& w, long long info_base = 0);
 int spd_potri_fused(mogp_model* m, Spd& w);
 bool flow_enabled(const mogp_model* m, const Spd& w);   // flow.hip
 int launch_flow_alpha_sum(const Spd& w, double* alpha, hipStream_t st);
-int spd_potri_flow(mogp_model* m, Spd& w);             // flow.hip: the same result as spd_potri_fused, as tile dataflow
+int spd_potri_flow(mogp_model* m, Spd& w);
+void flow_debug_dump(mogp_model* m);                 // MOGP_FLOW_DEBUG (mogp_api.hip)
+void flow_debug_dump(mogp_model* m);                 // MOGP_FLOW_DEBUG (mogp_api.hip)             // flow.hip: the same result as spd_potri_fused, as tile dataflow
 int spd_potri_fused_finish(mogp_model* m, Spd& w);   // joins the inverse stream: call before reading w.B   // potri.hip: w.A (SPD, lower) -> w.Wm = L^-1, w.B = inverse (lower); w.logdet per tile
 int spd_trtri(mogp_model* m, Spd& w);
 int spd_lauum(mogp_model* m, Spd& w);

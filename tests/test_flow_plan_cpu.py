@@ -45,7 +45,7 @@ def signals_of(r):
     return [(int(r[22 + s]), 1) for s in range(2) if r[22 + s] >= 0]
 
 
-@pytest.mark.parametrize("nb", [3, 4, 5, 9, 12, 14])
+@pytest.mark.parametrize("nb", [3, 4, 5, 9, 12, 14, 96, 112])   # 96, 112: more deadline queues than the kernel has -- the farthest are folded into one
 def test_keys_give_a_topological_order_and_queues_follow_it(nb):
     rows = plan(nb)
     chains, queues = split(rows)

@@ -890,6 +890,19 @@ def test_dataflow_schedule_ran_and_equals_the_stream_schedule():
         lb = float(m2.loss()); Wb = m2._handle.fetch(0)
         assert not m2._handle.schedule()["dataflow"]
         assert np.array_equal(Wa, Wb) and abs(la - lb) <= 1e-13 * abs(la)
+        # 112 tile rows, the largest size the dataflow schedule is the default for: more deadline queues than the kernel has (the farthest are folded)
+        os.environ.pop("MOGP_FLOW", None); os.environ.pop("MOGP_FLOW_MIN", None)
+        m3 = _synth_mosm(14336, 4, 3)                                  # configs[1]'s kernel: its support is the whole series, every tile of the inverse is formed
+        lc = float(m3.loss()); Wc = m3._handle.fetch(0)
+        s3 = m3._handle.schedule()
+        assert s3["dataflow"] and not s3["dataflow_fell_back"], s3
+        g3 = [p.grad.copy() for p in m3.parameters()]
+        os.environ["MOGP_FLOW"] = "0"                                  # above 80 tile rows that means POTRF / TRTRI / LAUUM: other summation orders
+        ld = float(m3.loss()); Wd = m3._handle.fetch(0)
+        assert not m3._handle.schedule()["dataflow"]
+        assert np.max(np.abs(Wc - Wd)) <= 1e-9 * np.max(np.abs(Wd)) and abs(lc - ld) <= 1e-11 * abs(lc)
+        for g, p in zip(g3, m3.parameters()):
+            assert np.max(np.abs(g - p.grad)) <= 1e-8 * max(1.0, np.max(np.abs(g)))
     finally:
         for k, v in old.items():
             if v is None:

@@ -14,5 +14,6 @@ for n in [int(v) for v in os.environ.get("SIZES", "256,512,1024,1536,2048,2560,3
     for _ in range(60): m.gpr.loss()                 # short runs on an idle GPU are bimodal (clock ramp): warm up well
     t0 = time.perf_counter()
     for _ in range(150): m.gpr.loss()
-    out.append("%d:%.2f" % (3 * n, 1e3 * (time.perf_counter() - t0) / 150))
+    sch = m.gpr._handle.schedule()
+    out.append("%d:%.2f%s" % (3 * n, 1e3 * (time.perf_counter() - t0) / 150, ("[flow]" if sch["dataflow"] else "") + ("" if m.gpr._handle.inverse_fraction() >= 0.999 else "[inv %.2f]" % m.gpr._handle.inverse_fraction())))
 print(os.environ.get("MOGP_GRAD_PATH", "default"), " ".join(out))
