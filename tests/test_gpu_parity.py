@@ -958,6 +958,39 @@ np.savez(sys.argv[1], lml=a["lml"], mom=a["moments"], elbo=b["elbo"], gz=b["gZ"]
         assert float(r["elbo"]) == float(ref["elbo"]) and np.array_equal(r["gz"], ref["gz"])
 
 
+def test_first_evaluation_of_a_fresh_process_above_8192_points_runs_as_dataflow(tmp_path):
+    """A fresh process, a model with more than 8192 points, ONE evaluation: it must run as tile dataflow and must not have fallen back.  Until round 4
+    every such first evaluation timed out and the model stayed on the stream schedule for good (17.2 instead of 14.5 ms at N = 9216): the z^T z parts
+    of N > 8192 points are more than 16 KB, and the process's first device-to-host copy of that size, enqueued while the co-operating kernels ran,
+    stalled them (mogp_ctx_create now makes such a copy first).  Every other test and the benchmark sit at N <= 8192 or evaluate a smaller model first."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "fresh.py"
+    script.write_text('''
+import sys, json
+sys.path.insert(0, %r)
+from mogptk_amd import gpr, synth
+C, Q, N = 4, 3, 9216
+X, y = synth.make_data(N, C)
+h = synth.mosm_hypers(C, Q)
+k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
+for name in ("weight", "mean", "variance", "delay", "phase"):
+    getattr(k, name).assign(h[name])
+m = gpr.Exact(k, X, y, variance=h["scale"] ** 2)
+m.likelihood.scale.assign(h["scale"])
+l1 = float(m.loss())
+s = m._handle.schedule()
+l2 = float(m.loss())
+print(json.dumps(dict(s, same=bool(l1 == l2))))
+''' % root)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MOGP_")}
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-2000:]
+    import json
+    s = json.loads(p.stdout.strip().splitlines()[-1])
+    assert s["dataflow"] and s["chain_kernel"] and not s["dataflow_fell_back"] and not s["chain_fell_back"] and s["same"], (s, p.stderr[-500:])
+
+
 def test_titsias_inducing_gradient_against_extended_precision_truth():
     """dELBO/dZ at the conditioning of BASELINE.json configs[4] (M = 2048 grid inducing points 0.2 apart, cond K_uu ~ 1e11) against the 80-bit
     evaluation of the same function (tests/golden/gen_titsias_truth.py, N = 20 000: Gram matrices, Cholesky, solves, adjoints and kernel derivative
