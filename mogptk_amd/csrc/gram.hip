@@ -510,9 +510,14 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a, int ntiles) {
 template <int TC>
 struct StripLds {
     static constexpr int RAW = 1 + 2 * TC, PF = (RAW * MOGP_GT + 255) / 256;      // PF: prefetch registers per thread
+    // column-side arrays in two planes: a thread's four columns 4 cg .. 4 cg + 3 are two 16-byte reads, and with the points in order lane cg's reads sat
+    // 32 bytes apart -- every fourth lane on the same banks (SQ_LDS_BANK_CONFLICT: 54 % of the kernel's LDS cycles).  Columns 4 cg, 4 cg + 1 at
+    // [2 cg], columns 4 cg + 2, 4 cg + 3 at [CP + 2 cg]: each read is 16 contiguous lanes x 16 bytes.
+    static constexpr int CP = 36, CL = 72;
+    __device__ static __forceinline__ int cs(int pnt) { return ((pnt & 2) ? CP : 0) + ((pnt >> 2) << 1) + (pnt & 1); }
     double rowraw[RAW][MOGP_GT];
-    double colraw[2][RAW][MOGP_GT];
-    double cu[TC][MOGP_GT], su[TC][MOGP_GT], cw[TC][MOGP_GT], sw[TC][MOGP_GT];
+    double colraw[2][RAW][CL];
+    double cu[TC][MOGP_GT], su[TC][MOGP_GT], cw[TC][CL], sw[TC][CL];
     double tab[TC][3];                            // A, V, Delta of the pair's terms
     double V[TC], s[TC];
     int deg[TC];
@@ -587,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* _
 #pragma unroll
         for (int k5 = 0; k5 < GS_PF; ++k5) {
             const int e = tid + 256 * k5;
-            if (e < nraw) L.colraw[b][slot(e >> 6)][e & 63] = pf[k5];
+            if (e < nraw) L.colraw[b][slot(e >> 6)][StripLds<TC>::cs(e & 63)] = pf[k5];
         }
     };
     col_fetch(sg.c0);
@@ -615,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* _
             if (pnt == 0 && which == 0) { L.deg[t] = deg; L.V[t] = V; L.s[t] = s; }
             if (deg == GT_SKIP) continue;
             double f = 1.0;
-            if (a.dbg & 4) { L.cu[t][pnt] = 1.0; L.su[t][pnt] = 0.5; L.cw[t][pnt] = 0.25; L.sw[t][pnt] = 2.0; continue; }
+            if (a.dbg & 4) { L.cu[t][pnt] = 1.0; L.su[t][pnt] = 0.5; L.cw[t][StripLds<TC>::cs(pnt)] = 0.25; L.sw[t][StripLds<TC>::cs(pnt)] = 2.0; continue; }
             if (which == 0) {
                 if (deg != GT_GENERAL) {
                     const double pp = L.rowraw[0][pnt] - cr;
@@ -625,16 +630,16 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* _
                 L.cu[t][pnt] = f * L.rowraw[1 + t][pnt]; L.su[t][pnt] = f * L.rowraw[1 + GS_TC + t][pnt];
             } else {
                 if (deg != GT_GENERAL) {
-                    const double qq = L.colraw[b][0][pnt] - cc;
+                    const double qq = L.colraw[b][0][StripLds<TC>::cs(pnt)] - cc;
                     f = fast_exp(-0.5 * (V * (qq * qq - 2.0 * qq * s)));
                 }
-                L.cw[t][pnt] = f * L.colraw[b][1 + t][pnt]; L.sw[t][pnt] = f * L.colraw[b][1 + GS_TC + t][pnt];
+                { const int cp = StripLds<TC>::cs(pnt); L.cw[t][cp] = f * L.colraw[b][1 + t][cp]; L.sw[t][cp] = f * L.colraw[b][1 + GS_TC + t][cp]; }
             }
         }
         __syncthreads();
         double q[4], acc[4][4];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) q[n] = L.colraw[b][0][cg * 4 + n] - cc;
+        for (int n = 0; n < 4; ++n) q[n] = L.colraw[b][0][StripLds<TC>::cs(cg * 4 + n)] - cc;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -647,7 +652,7 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* _
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 cu[m] = L.cu[t][rg * 4 + m]; su[m] = L.su[t][rg * 4 + m];
-                cw[m] = L.cw[t][cg * 4 + m]; sw[m] = L.sw[t][cg * 4 + m];
+                cw[m] = L.cw[t][StripLds<TC>::cs(cg * 4 + m)]; sw[m] = L.sw[t][StripLds<TC>::cs(cg * 4 + m)];
             }
             switch (deg) {
                 case 4: strip_term<4>(acc, p, q, V, s, cu, su, cw, sw); break;
