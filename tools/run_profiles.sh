@@ -11,7 +11,8 @@ for c in cfg3 cfg4 cfg5; do timeout 300 python bench.py --config $c --no-cpu-bas
 (timeout 150 python tools/flow_trace.py 8192) > $O/cfg2_timeline.txt 2>&1
 cd /tmp
 for c in cfg2 cfg3 cfg4 cfg5; do
-  timeout -k 5 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-configs --no-shard-probe > $O/kt_$c.log 2>&1
+  st=5; wu=2; if [ $c = cfg2 ]; then st=20; wu=5; fi      # the headline as the driver runs it: the average then is the steady state's, not the warm-up's
+  timeout -k 5 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --config $c --steps $st --warmup $wu --no-cpu-baseline --no-configs --no-shard-probe > $O/kt_$c.log 2>&1
 done
 for cnt in FETCH_SIZE WRITE_SIZE; do
   MOGP_FLOW=0 timeout -k 5 300 rocprofv3 --pmc $cnt --kernel-trace --output-format csv -d $O/pmc_$cnt -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-shard-probe > $O/pmc_$cnt.log 2>&1
