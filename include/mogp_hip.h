@@ -243,6 +243,9 @@ int  mogp_model_schedule(mogp_model* m, int* flags);
  *                            first counter bumped (one per row tile, consecutive), by how much each]   L[k1.., K] = A[k1.., K] W_KK^T
  *     next-diagonal update  [-3, key, block, k0, nk, k1, na, .., ndep, dep counter, .., needed value, .., -1, 0]          A[k1.., k1..] -= P P^T */
 int  mogp_flow_plan(int nb, int64_t* out, int64_t cap, int64_t* count);
+/* The same for the prediction's schedule: factorisation + forward substitution X L^T = T of rhs_nt tile rows of right-hand sides (no inverse);
+ * the right-hand sides T are buffer 2, the solution X buffer 4 in the task rows (reference seam: Exact.predict_f, gpr/model.py:455-483). */
+int  mogp_flow_plan_rhs(int nb, int rhs_nt, int64_t* out, int64_t cap, int64_t* count);
 /* Time stamps (100 MHz device wall clock) of the last mogp_exact_eval that ran as dataflow with MOGP_FLOW_TRACE=1 in the environment:
  * 6 numbers per tile task in the row order of mogp_flow_plan's tile tasks (the workgroup starts looking for work, has taken the task, its k loop
  * starts, ends, the tile is stored and its counters are bumped, XCC << 16 | workgroup), then 4 per chain kernel

@@ -79,6 +79,7 @@ SIGNATURES = {
     "mogp_model_fetch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_dp]),
     "mogp_model_schedule": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
     "mogp_flow_plan": (ctypes.c_int, [ctypes.c_int, c_i64p, ctypes.c_int64, c_i64p]),
+    "mogp_flow_plan_rhs": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_i64p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     "mogp_flow_trace": (ctypes.c_int, [ctypes.c_void_p, c_i64p, ctypes.c_int64, c_i64p]),
     "mogp_snelson_eval": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_double), c_dp, c_dp, c_dp, ctypes.POINTER(ctypes.c_double), c_dp,

@@ -425,20 +425,21 @@ namespace {
 // The sequential algorithm the keys follow: superstep r = [ the running product's updates INTO row block r, by source block b' < r (T7 / T8:
 // left-looking on the inverse side, so that nothing of it is due before its row block is) | chain(r) | T6(r): the final row block r of W |
 // panel(r) | update(r) (right-looking on the Schur side) | T9(r) ].  key = FLOW_KEY_STEP r + position inside the superstep.
-enum { PH_INTO = 0, PH_CHAIN = 600, PH_T6 = 601, PH_PANEL = 602, PH_UPDATE = 603, PH_T9 = 604, PH_ZROW = 605, PH_APART = 606 };
+enum { PH_INTO = 0, PH_CHAIN = 600, PH_T6 = 601, PH_PANEL = 602, PH_UPDATE = 603, PH_T9 = 604, PH_ZROW = 605, PH_APART = 606, PH_XS = 607, PH_TU = 608 };
 enum { Q_LOOK2 = 0, Q_INVCRIT = 1, Q_SEMI = 2 };
 enum { BUF_A = 0, BUF_L = 1, BUF_WT = 2, BUF_WM = 3, BUF_B = 4 };
 }
 
-void flow_build(int nb, int ob, FlowPlan& p) {
+void flow_build(int nb, int ob, FlowPlan& p, int rhs_nt) {
     p = FlowPlan();
-    p.nb = nb; p.ob = ob;
+    p.nb = nb; p.ob = ob; p.rhs_nt = rhs_nt;
     const int no = (nb + ob - 1) / ob;
     p.nouter = no;
     const uint32_t base_S = 0, base_R = base_S + (uint32_t)nb * nb, base_DG = base_R + (uint32_t)nb * no, base_PN = base_DG + no,
                    base_CH = base_PN + (uint32_t)no * nb, base_WT = base_CH + no, base_WC = base_WT + (uint32_t)nb * nb,
                    base_WF = base_WC + (uint32_t)no * nb, base_KV = base_WF + (uint32_t)no * nb, base_WR = base_KV + (uint32_t)nb * nb,
-                   base_ZR = base_WR + no, base_end = base_ZR + no;
+                   base_ZR = base_WR + no, base_TS = base_ZR + no, base_TR = base_TS + (uint32_t)rhs_nt * nb, base_XN = base_TR + (uint32_t)rhs_nt * no,
+                   base_end = base_XN + (uint32_t)no * rhs_nt;
     p.base_heads = (int)base_end; p.base_err = p.base_heads + FLOW_MAXQ; p.nflags = p.base_err + 1;
     auto S = [&](int i, int j) { return base_S + (uint32_t)i * nb + j; };
     auto R = [&](int i, int c) { return base_R + (uint32_t)i * no + c; };
@@ -451,6 +452,9 @@ void flow_build(int nb, int ob, FlowPlan& p) {
     auto KV = [&](int i, int j) { return base_KV + (uint32_t)i * nb + j; };
     auto WR = [&](int b) { return base_WR + (uint32_t)b; };          // finished T6 tasks of row block b
     auto ZR = [&](int b) { return base_ZR + (uint32_t)b; };          // finished z tile rows of row block b
+    auto TS = [&](int i, int j) { return base_TS + (uint32_t)i * nb + j; };       // right-hand sides: updates applied to tile (i, j) of T
+    auto TR = [&](int i, int c) { return base_TR + (uint32_t)i * no + c; };       // ... summed over row i's tiles in column block c
+    auto XN = [&](int b, int i) { return base_XN + (uint32_t)b * rhs_nt + i; };   // solved tiles X[i][block b] that exist
     auto k0 = [&](int b) { return b * ob; };
     auto k1 = [&](int b) { return std::min(nb, (b + 1) * ob); };
     auto nk = [&](int b) { return k1(b) - k0(b); };
@@ -548,6 +552,33 @@ void flow_build(int nb, int ob, FlowPlan& p) {
         return t;
     };
 
+    // ---- right-hand sides (rhs_nt > 0: the prediction's X L^T = T, rows = tile rows of test points, no inverse).  T lives where the running product
+    // does otherwise (BUF_WT), X where the inverse does (BUF_B): same leading dimension, the kernel needs no change.
+    // XS (b, i, c): X[i][k0 + c] = sum_{cc <= c} T[i][k0 + cc] W_bb[c][cc]^T        -- the panel's product on a row of right-hand sides
+    auto xs = [&](int b, int i, int c) {
+        FlowTask t = mk(b, PH_XS, 0 | 4, KB * (c + 1));
+        opA(t, BUF_WT, i, k0(b)); opB(t, BUF_WM, k0(b) + c, k0(b)); opC(t, BUF_B, i, k0(b) + c);
+        dep(t, CH(b), chain_wgs(b));
+        dep(t, TR(i, b), (unsigned)(nk(b) * b));
+        t.sig[0] = XN(b, i);
+        tiles_k += t.kt;
+        return t;
+    };
+    // TU (b, i, j): T[i][j] -= X[i][K] L[j][K]^T      (j >= k1), keyed by its SOURCE block (right-looking): everything a solved block can update is ready at
+    // once and fills the chip.  (Keyed by the column block that needs the tile -- deadline first, in ONE backlog queue -- only the head of the queue
+    // was ever eligible and two thirds of the workgroups idled: configs[3] 62.3 instead of 45.6 ms.)
+    auto tu = [&](int b, int i, int j) {
+        FlowTask t = mk(b, PH_TU, 0 | 8, KB * nk(b));
+        opA(t, BUF_B, i, k0(b)); opB(t, BUF_L, j, k0(b)); opC(t, BUF_WT, i, j);
+        dep(t, XN(b, i), (unsigned)nk(b));
+        dep(t, PN(b, j), pn_need(b, j));
+        dep(t, TS(i, j), (unsigned)b);
+        t.sig[0] = TS(i, j); t.sig[1] = TR(i, blk(j));
+        tiles_k += t.kt;
+        return t;
+    };
+    std::vector<FlowTask> rrest;       // (the updates into the next 3 / 6 / 12 column blocks in a queue of their own ahead of the rest: 45.6 / 45.6 / 45.9 vs 45.6 ms, dropped)
+
     p.chain.resize(no);
     for (int b = 0; b < no; ++b) {
         const int a0 = k1(b), a1 = std::min(nb, a0 + ob), a2 = std::min(nb, a1 + ob);        // rows of block b+1: [a0, a1), of block b+2: [a1, a2)
@@ -569,6 +600,13 @@ void flow_build(int nb, int ob, FlowPlan& p) {
         for (int i = a2; i < nb; ++i) for (int j = a0; j < a2; ++j) q[Q_SEMI].push_back(update(b, i, j, false));
         // TRAIL[b]: everything to the right
         for (int i = a2; i < nb; ++i) for (int j = a2; j <= i; ++j) trail[b].push_back(update(b, i, j, false));
+        if (rhs_nt > 0) {
+            // the substitution's own cycle (solved block b -> the next block's columns of T) in the inverse cycle's place; the rest is backlog
+            for (int i = 0; i < rhs_nt; ++i) for (int cc = 0; cc < nk(b); ++cc) q[Q_INVCRIT].push_back(xs(b, i, cc));
+            for (int i = 0; i < rhs_nt; ++i) for (int j = a0; j < a1; ++j) q[Q_INVCRIT].push_back(tu(b, i, j));
+            for (int i = 0; i < rhs_nt; ++i) for (int j = a1; j < nb; ++j) rrest.push_back(tu(b, i, j));
+            continue;
+        }
         // Q_INVCRIT: the serial cycle of the inverse: final row block b -> running product of the next block's rows
         for (int j = 0; j < k0(b); ++j) for (int ti = 0; ti < nk(b); ++ti) q[Q_INVCRIT].push_back(t6(b, ti, j));
         for (int i = a0; i < a1; ++i) for (int cc = 0; cc < nk(b); ++cc) q[Q_INVCRIT].push_back(t7(b, i, cc));
@@ -600,7 +638,8 @@ void flow_build(int nb, int ob, FlowPlan& p) {
         if (d < no && !into[d].empty()) order.push_back(&into[d]);
         if (d - 3 >= 0 && d - 3 < no && !trail[d - 3].empty()) order.push_back(&trail[d - 3]);
     }
-    order.push_back(&acc);
+    order.push_back(rhs_nt > 0 ? &rrest : &acc);
+    for (size_t k = order.size(); k-- > 1;) if (order[k]->empty()) order.erase(order.begin() + (long)k);      // (the first queue keeps its place: it is the compare-and-swap one)
     if ((int)order.size() > FLOW_MAXQ) {          // (not reached for the sizes the fused schedule serves, nb <= 80: 2 no + 2 queues) fold the farthest deadlines into one queue
         std::vector<FlowTask> rest;
         // merged in superstep order so that the folded queue stays sorted by key
@@ -647,7 +686,7 @@ bool flow_enabled(const mogp_model* m, const Spd& w) {
     return w.nb >= nmin && w.nb <= 0xfff0;
 }
 
-int spd_potri_flow(mogp_model* m, Spd& w) {
+int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     const int nb = w.nb, ob = 4;
     const int64_t ld = w.Npad;
     int rc;
@@ -657,23 +696,30 @@ int spd_potri_flow(mogp_model* m, Spd& w) {
         HIP_TRY(hipMemsetAsync(w.Wm.p, 0, (size_t)ld * ld * sizeof(double), crit));
     }
     if ((rc = w.Lm.ensure((size_t)ld * ld))) return rc;
-    if ((rc = w.Wt.ensure((size_t)ld * ld))) return rc;
-    if (w.flow.nb != nb || w.flow.ob != ob) {
-        flow_build(nb, ob, w.flow);
-        if ((rc = w.flow_tasks.ensure(w.flow.tasks.size()))) return rc;
-        if ((rc = w.flow_qmeta.ensure(2 * FLOW_MAXQ))) return rc;
-        if ((rc = w.flow_flags.ensure((size_t)w.flow.nflags))) return rc;
+    if (!rhs && (rc = w.Wt.ensure((size_t)ld * ld))) return rc;
+    // two plans per system: the gradient's (factorisation + inversion) and the prediction's (factorisation + substitution of right-hand sides)
+    FlowPlan& plan = rhs ? w.flow_rhs : w.flow;
+    DevBuf<FlowTask>& d_tasks = rhs ? w.flow_tasks_rhs : w.flow_tasks;
+    DevBuf<int>& d_qmeta = rhs ? w.flow_qmeta_rhs : w.flow_qmeta;
+    const int rhs_nt = rhs ? rhs->nt : 0;
+    if (plan.nb != nb || plan.ob != ob || plan.rhs_nt != rhs_nt) {
+        flow_build(nb, ob, plan, rhs_nt);
+        if ((rc = d_tasks.ensure(plan.tasks.size()))) return rc;
+        if ((rc = d_qmeta.ensure(2 * FLOW_MAXQ))) return rc;
         int qm[2 * FLOW_MAXQ] = {0};
-        for (int q = 0; q < w.flow.nq; ++q) { qm[2 * q] = w.flow.qbase[q]; qm[2 * q + 1] = w.flow.qsize[q]; }
-        HIP_TRY(dev_upload(w.flow_tasks.p, w.flow.tasks.data(), w.flow.tasks.size() * sizeof(FlowTask)));
-        HIP_TRY(dev_upload(w.flow_qmeta.p, qm, sizeof(qm)));
+        for (int q = 0; q < plan.nq; ++q) { qm[2 * q] = plan.qbase[q]; qm[2 * q + 1] = plan.qsize[q]; }
+        HIP_TRY(hipStreamSynchronize(crit));               // (a previous run may still read the old copy)
+        HIP_TRY(dev_upload(d_tasks.p, plan.tasks.data(), plan.tasks.size() * sizeof(FlowTask)));
+        HIP_TRY(dev_upload(d_qmeta.p, qm, sizeof(qm)));
     }
-    const FlowPlan& p = w.flow;
+    if ((rc = w.flow_flags.ensure((size_t)plan.nflags))) return rc;
+    w.flow_cur = &plan;
+    const FlowPlan& p = plan;
     const int nouter = p.nouter;
     if ((rc = w.chain_flags.ensure((size_t)(nouter + 1) * MOGP_CHAIN_FLAGS))) return rc;
     HIP_TRY(hipMemsetAsync(w.chain_flags.p, 0, (size_t)(nouter + 1) * MOGP_CHAIN_FLAGS * sizeof(unsigned), crit));
     HIP_TRY(hipMemsetAsync(w.flow_flags.p, 0, (size_t)p.nflags * sizeof(unsigned), crit));
-    if (w.want_vec && w.vec_zz) HIP_TRY(hipMemsetAsync(w.vec_zz, 0, (size_t)((ld + 3) / 4) * sizeof(double), crit));   // the tile rows' z^T z parts land in the first nb entries
+    if (!rhs && w.want_vec && w.vec_zz) HIP_TRY(hipMemsetAsync(w.vec_zz, 0, (size_t)((ld + 3) / 4) * sizeof(double), crit));   // the tile rows' z^T z parts land in the first nb entries
     static const bool want_trace = std::getenv("MOGP_FLOW_TRACE") && std::atoi(std::getenv("MOGP_FLOW_TRACE")) != 0;
     if (want_trace) {
         if ((rc = w.flow_trace.ensure(FLOW_TRACE_W * p.tasks.size() + 4 * (size_t)nouter))) return rc;
@@ -694,8 +740,8 @@ int spd_potri_flow(mogp_model* m, Spd& w) {
     static const int wg_per_cu = std::getenv("MOGP_FLOW_WGS") ? std::max(1, std::atoi(std::getenv("MOGP_FLOW_WGS"))) : 2;
     const int cus = (m->ctx->ncu > 0 ? m->ctx->ncu : 256) - m->ctx->ncu_reserved;
     FlowArgs g{};
-    g.bA = w.A.p; g.bL = w.Lm.p; g.bWt = w.Wt.p; g.bWm = w.Wm.p; g.bB = w.B.p; g.ld = ld;
-    g.tasks = w.flow_tasks.p; g.qmeta = w.flow_qmeta.p; g.flags = w.flow_flags.p;
+    g.bA = w.A.p; g.bL = w.Lm.p; g.bWt = rhs ? rhs->T : w.Wt.p; g.bWm = w.Wm.p; g.bB = rhs ? rhs->X : w.B.p; g.ld = ld;       // (right-hand sides: T where the running product is, X where the inverse is)
+    g.tasks = d_tasks.p; g.qmeta = d_qmeta.p; g.flags = w.flow_flags.p;
     g.nq = p.nq; g.ncas = FLOW_NCAS; g.base_heads = p.base_heads; g.base_err = p.base_err; g.info = m->d_info.p;
     g.trace = want_trace ? w.flow_trace.p : nullptr;
     g.npad = ld;
@@ -704,7 +750,7 @@ int spd_potri_flow(mogp_model* m, Spd& w) {
     { const char* e = std::getenv("MOGP_FLOW_NHI"); g.nhi = e ? std::atoi(e) : 0; }            // measured 3 / 4 (semi, the inverse cycle, z and alpha looked at by everybody): 10.74-10.79 vs 10.52-10.65 ms
     { const char* e = std::getenv("MOGP_FLOW_NAP"); g.nap_max = e ? (unsigned)std::max(0, std::atoi(e)) : 4u; }
     w.vec_done = false;
-    if (w.want_vec && w.vec_y && w.vec_z && w.vec_zz && w.vec_part) {       // z = W y, alpha = W^T z as tasks of the same kernel
+    if (!rhs && w.want_vec && w.vec_y && w.vec_z && w.vec_zz && w.vec_part) {       // z = W y, alpha = W^T z as tasks of the same kernel
         g.vy = w.vec_y; g.vz = w.vec_z; g.vzz = w.vec_zz; g.vpart = w.vec_part;
         w.vec_done = true;
     }
@@ -715,6 +761,7 @@ int spd_potri_flow(mogp_model* m, Spd& w) {
         pe0 = m->gemm_ev[m->gemm_ev_used++]; pe1 = m->gemm_ev[m->gemm_ev_used++];
         HIP_TRY(hipEventRecord(pe0, bulk));
     }
+    if (rhs && rhs->ready) HIP_TRY(hipStreamWaitEvent(bulk, rhs->ready, 0));          // the right-hand sides are in place (the chain kernels need not wait for them)
     hipLaunchKernelGGL(k_flow, dim3(wg_per_cu * cus), dim3(FL_NT), FL_LDS_BYTES, bulk, g);
     HIP_TRY(hipGetLastError());
     if (pe1) HIP_TRY(hipEventRecord(pe1, bulk));
@@ -761,6 +808,7 @@ int spd_potri_flow(mogp_model* m, Spd& w) {
     // instance of the dataflow kernel on the private stream takes tasks from the same queues until they are empty (MOGP_FLOW_TAIL=0: off)
     static const bool tail_on = !(std::getenv("MOGP_FLOW_TAIL") && std::atoi(std::getenv("MOGP_FLOW_TAIL")) == 0);
     if (tail_on && m->ctx->ncu_reserved > 0) {
+        if (rhs && rhs->ready) HIP_TRY(hipStreamWaitEvent(priv, rhs->ready, 0));
         hipLaunchKernelGGL(k_flow, dim3(wg_per_cu * m->ctx->ncu_reserved), dim3(FL_NT), FL_LDS_BYTES, priv, g);
         HIP_TRY(hipGetLastError());
     }
@@ -785,8 +833,8 @@ extern "C" int mogp_flow_trace(mogp_model* m, int64_t* out, int64_t cap, int64_t
     if ((rc = use_device(m->ctx))) return rc;
     const Spd& w = m->k;
     *count = 0;
-    if (!w.flow_used || !w.flow_trace.p) return MOGP_OK;
-    const int64_t n = FLOW_TRACE_W * (int64_t)w.flow.tasks.size() + 4 * (int64_t)w.flow.nouter;
+    if (!w.flow_used || !w.flow_trace.p || !w.flow_cur) return MOGP_OK;
+    const int64_t n = FLOW_TRACE_W * (int64_t)w.flow_cur->tasks.size() + 4 * (int64_t)w.flow_cur->nouter;
     *count = n;
     if (!out) return MOGP_OK;
     if (cap < n) return fail(MOGP_EINVAL, "mogp_flow_trace: the output is too small");
@@ -796,10 +844,13 @@ extern "C" int mogp_flow_trace(mogp_model* m, int64_t* out, int64_t cap, int64_t
 }
 
 // ---- the plan as numbers: tests replay it on the CPU (no device work) ----------------------------------------------------------------
-extern "C" int mogp_flow_plan(int nb, int64_t* out, int64_t cap, int64_t* count) {
-    if (nb <= 0 || nb > 4096 || !count) return fail(MOGP_EINVAL, "mogp_flow_plan: bad argument");
+extern "C" int mogp_flow_plan_rhs(int nb, int rhs_nt, int64_t* out, int64_t cap, int64_t* count);
+extern "C" int mogp_flow_plan(int nb, int64_t* out, int64_t cap, int64_t* count) { return mogp_flow_plan_rhs(nb, 0, out, cap, count); }
+// rhs_nt > 0: the plan of factorisation + forward substitution of rhs_nt tile rows of right-hand sides (the prediction; T in buffer 2, X in buffer 4)
+extern "C" int mogp_flow_plan_rhs(int nb, int rhs_nt, int64_t* out, int64_t cap, int64_t* count) {
+    if (nb <= 0 || nb > 4096 || rhs_nt < 0 || rhs_nt > 4096 || !count) return fail(MOGP_EINVAL, "mogp_flow_plan: bad argument");
     FlowPlan p;
-    flow_build(nb, 4, p);
+    flow_build(nb, 4, p, rhs_nt);
     int nlaunch = 0;
     for (int b = 0; b < p.nouter; ++b) nlaunch += (std::min(nb, b * 4 + 4) < nb) ? 3 : 1;
     const int64_t W = 24, rows = (int64_t)p.tasks.size() + nlaunch;

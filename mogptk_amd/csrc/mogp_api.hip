@@ -623,8 +623,8 @@ static int factorize_finish(mogp_model* m, const GramArgs& ga, double* lml, int6
 // MOGP_FLOW_DEBUG: where every queue of the dataflow schedule stands, what its next tasks wait for, the private stream's waits; with MOGP_FLOW_TRACE=1
 // also the tasks finished per 5 ms.  (1: after a time-out; 2: 60 ms after the evaluation was enqueued, while whatever is stuck is still stuck)
 namespace mogp { void flow_debug_dump(mogp_model* m) {
-    if (!m->k.flow_flags.p) return;
-    const FlowPlan& p = m->k.flow;
+    if (!m->k.flow_flags.p || !m->k.flow_cur) return;
+    const FlowPlan& p = *m->k.flow_cur;
     std::vector<unsigned> fl((size_t)p.nflags);
     hipError_t e = hipMemcpy(fl.data(), m->k.flow_flags.p, fl.size() * sizeof(unsigned), hipMemcpyDeviceToHost); (void)e;
     std::vector<unsigned long long> tr;
@@ -688,7 +688,7 @@ namespace mogp { int chain_fallback(mogp_model* m) {
         if (!said_flow) {
             said_flow = true;
             unsigned code = 0;                       // which wait gave up: 0x700 an idle workgroup of the dataflow kernel, 0x800 + k a hook of a private-stream launch, else a chain kernel's
-            if (m->k.flow_flags.p && m->k.flow.base_err > 0) { hipError_t e = hipMemcpy(&code, m->k.flow_flags.p + m->k.flow.base_err, sizeof(code), hipMemcpyDeviceToHost); (void)e; }
+            if (m->k.flow_flags.p && m->k.flow_cur && m->k.flow_cur->base_err > 0) { hipError_t e = hipMemcpy(&code, m->k.flow_flags.p + m->k.flow_cur->base_err, sizeof(code), hipMemcpyDeviceToHost); (void)e; }
             fprintf(stderr, "mogp: the dataflow kernel timed out (wait 0x%x; GPU shared with another process?); using the stream schedule\n", code);
             if (std::getenv("MOGP_FLOW_DEBUG")) flow_debug_dump(m);
         }
@@ -751,6 +751,7 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     // launches -- those columns on this stream, the rest on the bulk stream in front of the dataflow kernel, i.e. UNDERNEATH the first chain
     // kernel (whose 240 us every workgroup of the dataflow kernel used to sit out after the whole Gram build).  MOGP_GRAM_SPLIT=0: one launch.
     static const bool split_on = !(std::getenv("MOGP_GRAM_SPLIT") && std::atoi(std::getenv("MOGP_GRAM_SPLIT")) == 0);
+    // (the prediction's dataflow schedule gains nothing from the split: 45.55 vs 45.59 ms at configs[3], it is throughput-bound)
     const bool split = split_on && fuse_inverse && !factor_only && flow_enabled(m, m->k) && !m->tiles_head.empty() && !m->tiles_tail.empty() && m->st2;
     if (split) {
         GramArgs gh = ga, gt = ga;
@@ -779,7 +780,8 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     m->k.flow_used = false;                           // (mogp_model_schedule reports the LAST evaluation: set again by spd_potri_flow)
     m->k.want_vec = fuse_inverse && !factor_only;     // the dataflow schedule (flow.hip) also forms z = W y and alpha = W^T z
     m->k.vec_y = m->d_y.p; m->k.vec_z = m->d_z.p; m->k.vec_zz = m->d_zz.p; m->k.vec_part = m->d_alpha.p + Npad;
-    rc = fuse_inverse ? spd_potri_fused(m, m->k) : spd_potrf(m, m->k);
+    if (factor_only && !fuse_inverse && m->rhs_job && flow_enabled(m, m->k)) rc = spd_potri_flow(m, m->k, m->rhs_job);      // the prediction: factor + substitute as dataflow
+    else rc = fuse_inverse ? spd_potri_fused(m, m->k) : spd_potrf(m, m->k);
     m->k.want_vec = false; m->k.tail_ready = nullptr;
     if (rc) return rc;
     if ((rc = mark(m, 2))) return rc;
@@ -1284,13 +1286,34 @@ static int predict_core(mogp_model* m, const double* noise_var, const double* da
         if ((rc = launch_gemv_rows(m->d_Ksf.p, Npad, Spad, Npad, m->d_z.p, m->d_mu.p, sv))) return rc;
     }
 
+    // Round 4: factorisation AND substitution as ONE tile-dataflow schedule (flow.hip, the prediction's plan: panels, Schur updates, the solved block
+    // X[:, K] = T[:, K] W_KK^T and the updates T[:, > K] -= X[:, K] L[> K, K]^T as tasks of the resident kernel, the chain kernels as producers) where the
+    // dataflow kernel is available: the two sets of rank-512 launches on their streams got in each other's way like those of round 3's gradient schedule.
+    // MOGP_FLOW_PREDICT=0: the stream form below.
+    // From 48 tile rows on (CSM, S = N / 4, tools/r4_predict_sizes.py: N = 4096 3.9 vs 3.5 ms -- below, the chain sets the pace and the launch-per-step
+    // chain of the stream form is the shorter one -- 8192 8.6 vs 9.5, 12288 21.1 vs 22.8, 16384 45.6 vs 47.8, 20480 86.3 vs 90.3).
+    if ((rc = ensure_system(m))) return rc;                                                 // (flow_enabled looks at the system's tile count: a model's first call may be a prediction)
+    const char* fpe = std::getenv("MOGP_FLOW_PREDICT");                                     // "0": never; "lo:hi": the range of tile rows (read per call: tests)
+    int fp_lo = 48, fp_hi = 160;
+    if (fpe && std::strchr(fpe, ':')) { fp_lo = std::atoi(fpe); fp_hi = std::atoi(std::strchr(fpe, ':') + 1); }
+    else if (fpe) fp_hi = std::atoi(fpe);
+    const bool as_flow = fp_hi > 0 && nb >= fp_lo && nb <= fp_hi && Srow / MOGP_TILE <= 4096 && flow_enabled(m, m->k) && !m->kinv_sparse;
+    FlowRhs job{m->d_Ksf.p, m->d_Vt.p, (int)(Srow / MOGP_TILE), nullptr};
+    if (as_flow) {
+        HIP_TRY(hipEventRecord(m->pred_ev[1], sv));           // K_sf (and y^T in its last tile row) are in place
+        job.ready = m->pred_ev[1];
+        m->rhs_job = &job;
+    }
     // the factorisation: enqueued on the model's streams, not waited for
     GramArgs gaK{};
-    if ((rc = factorize(m, noise_var, data_var, jitter, nullptr, nullptr, info, false, true, &gaK, true))) return rc;
+    rc = factorize(m, noise_var, data_var, jitter, nullptr, nullptr, info, false, true, &gaK, true);
+    m->rhs_job = nullptr;
+    if (rc) return rc;
+    const bool flowed = as_flow && m->k.flow_used;
 
     // X L^T = [K_sf ; y^T]  by block columns of 512 (right-looking):  X[:, K] = T[:, K] W_KK^T,  T[:, > K] -= X[:, K] L[> K, K]^T.
     // W_KK = L_KK^-1 of the 512 x 512 diagonal blocks comes from the tile inverses the factorisation leaves behind (wkk.hip).
-    {
+    if (!flowed) {
         constexpr int OB = 4, KD = OB * MOGP_TILE;
         const int nouter = (nb + OB - 1) / OB, mt = (int)(Srow / MOGP_TILE);
         Spd& w = m->k;
@@ -1336,7 +1359,11 @@ static int predict_core(mogp_model* m, const double* noise_var, const double* da
         std::vector<double> hv(Spad);
         HIP_TRY(hipMemcpyAsync(hv.data(), m->d_var.p, Spad * sizeof(double), hipMemcpyDeviceToHost, m->st));
         HIP_TRY(hipStreamSynchronize(m->st));
-        if ((rc = factorize_finish(m, gaK, nullptr, info))) return rc;                  // the pivot report of the factorisation
+        if ((rc = factorize_finish(m, gaK, nullptr, info))) {                           // the pivot report of the factorisation
+            if (rc != MOGP_RETRY_NO_CHAIN) return rc;
+            if ((rc = chain_fallback(m))) return rc;                                     // a hand-off of the dataflow schedule timed out: again, on streams
+            return predict_core(m, noise_var, data_var, jitter, kss_diag, S, Xs, full, mu, var, info, mean_w);
+        }
         for (int64_t pos = 0; pos < S; ++pos) { mu[ss.perm[pos]] = hmu[pos]; var[ss.perm[pos]] = hv[pos]; }
         return MOGP_OK;
     }
@@ -1359,7 +1386,11 @@ static int predict_core(mogp_model* m, const double* noise_var, const double* da
     std::vector<double> hc((size_t)Spad * Spad);
     HIP_TRY(hipMemcpyAsync(hc.data(), m->d_Kss.p, hc.size() * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipStreamSynchronize(m->st));
-    if ((rc = factorize_finish(m, gaK, nullptr, info))) return rc;
+    if ((rc = factorize_finish(m, gaK, nullptr, info))) {
+        if (rc != MOGP_RETRY_NO_CHAIN) return rc;
+        if ((rc = chain_fallback(m))) return rc;
+        return predict_core(m, noise_var, data_var, jitter, kss_diag, S, Xs, full, mu, var, info, mean_w);
+    }
     for (int64_t a = 0; a < S; ++a) {
         mu[ss.perm[a]] = hmu[a];
         for (int64_t b = 0; b < S; ++b) var[ss.perm[a] * S + ss.perm[b]] = hc[(size_t)a * Spad + b];

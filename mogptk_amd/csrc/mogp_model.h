@@ -138,6 +138,10 @@ struct Spd {
     FlowPlan flow;
     DevBuf<FlowTask> flow_tasks;
     DevBuf<int> flow_qmeta;
+    FlowPlan flow_rhs;                                  // the prediction's plan (factorisation + forward substitution of right-hand sides) and its device copy
+    DevBuf<FlowTask> flow_tasks_rhs;
+    DevBuf<int> flow_qmeta_rhs;
+    const FlowPlan* flow_cur = nullptr;                 // the plan of the last dataflow run (debug dump, trace)
     DevBuf<unsigned> flow_flags;
     DevBuf<unsigned long long> flow_trace;
     hipEvent_t tail_ready = nullptr;    // set by the caller for ONE factorisation: everything of A right of the first 512 columns is in place after this event
@@ -153,6 +157,7 @@ struct Spd {
         for (auto e : inv_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
         inv_ev.clear(); Wm.release(); Wd.release(); chain_flags.release(); for (auto& b : Pb) b.release();
         Lm.release(); Wt.release(); flow_tasks.release(); flow_qmeta.release(); flow_flags.release(); flow_trace.release(); flow = FlowPlan();
+        flow_tasks_rhs.release(); flow_qmeta_rhs.release(); flow_rhs = FlowPlan(); flow_cur = nullptr;
         levels.clear(); sync_ev.clear();
         A.release(); B.release(); invd.release(); logdet.release();
     }
@@ -215,6 +220,8 @@ struct OaWork {
     void release() { K.release(); Sc.release(); Y.release(); vec.release(); valid = false; }
 };
 
+// right-hand sides of the prediction's dataflow schedule: X L^T = T, `nt` tile rows (row-major, the leading dimension of the N x N matrices), `ready`: T is in place
+struct FlowRhs { double* T; double* X; int nt; hipEvent_t ready; };
 struct mogp_model {
     mogp_ctx* ctx = nullptr;
     int64_t N = 0, Npad = 0;
@@ -290,6 +297,7 @@ struct mogp_model {
     double gemm_flops = 0.0;
     bool have_W = false, have_Kinv = false, kinv_in_A = false, w_in_Wm = false;
     bool flow_ran = false;              // some factorisation of this model has used the dataflow schedule since the last fallback
+    const FlowRhs* rhs_job = nullptr;   // set by the prediction around its factorize() call: solve these right-hand sides inside the dataflow schedule
     bool no_flow = false;               // the dataflow kernel timed out once on this model: stream schedule from now on
     bool no_chain = false;              // the persistent chain kernel timed out once on this model (another process's chain kernel held the reserved CUs): launch-per-step chain from now on
     TitsiasWork* tw = nullptr;
@@ -341,8 +349,7 @@ int spd_potrf(mogp_model* m, Spd& w, long long info_base = 0);
 int spd_potri_fused(mogp_model* m, Spd& w);
 bool flow_enabled(const mogp_model* m, const Spd& w);   // flow.hip
 int launch_flow_alpha_sum(const Spd& w, double* alpha, hipStream_t st);
-int spd_potri_flow(mogp_model* m, Spd& w);
-void flow_debug_dump(mogp_model* m);                 // MOGP_FLOW_DEBUG (mogp_api.hip)
+int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs = nullptr);
 void flow_debug_dump(mogp_model* m);                 // MOGP_FLOW_DEBUG (mogp_api.hip)             // flow.hip: the same result as spd_potri_fused, as tile dataflow
 int spd_potri_fused_finish(mogp_model* m, Spd& w);   // joins the inverse stream: call before reading w.B   // potri.hip: w.A (SPD, lower) -> w.Wm = L^-1, w.B = inverse (lower); w.logdet per tile
 int spd_trtri(mogp_model* m, Spd& w);

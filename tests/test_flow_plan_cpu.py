@@ -15,12 +15,13 @@ T = 128
 W = 24
 
 
-def plan(nb):
+def plan(nb, rhs=0):
+    """rhs > 0: the prediction's plan -- factorisation + forward substitution of rhs tile rows of right-hand sides (T in buffer 2, X in buffer 4)"""
     l = _lib.lib()
     cnt = ctypes.c_int64(0)
-    assert l.mogp_flow_plan(nb, None, 0, ctypes.byref(cnt)) == 0
+    assert l.mogp_flow_plan_rhs(nb, rhs, None, 0, ctypes.byref(cnt)) == 0
     out = np.zeros((cnt.value, W), dtype=np.int64)
-    assert l.mogp_flow_plan(nb, out.ctypes.data_as(_lib.c_i64p), out.size, ctypes.byref(cnt)) == 0
+    assert l.mogp_flow_plan_rhs(nb, rhs, out.ctypes.data_as(_lib.c_i64p), out.size, ctypes.byref(cnt)) == 0
     return out
 
 
@@ -45,9 +46,10 @@ def signals_of(r):
     return [(int(r[22 + s]), 1) for s in range(2) if r[22 + s] >= 0]
 
 
-@pytest.mark.parametrize("nb", [3, 4, 5, 9, 12, 14, 96, 112])   # 96, 112: more deadline queues than the kernel has -- the farthest are folded into one
-def test_keys_give_a_topological_order_and_queues_follow_it(nb):
-    rows = plan(nb)
+@pytest.mark.parametrize("nb,rhs", [(3, 0), (4, 0), (5, 0), (9, 0), (12, 0), (14, 0), (96, 0), (112, 0),      # 96, 112: more deadline queues than the kernel has -- the farthest are folded into one
+                                    (3, 1), (5, 2), (9, 3), (14, 5), (128, 33)])                                   # with right-hand sides (128, 33: BASELINE.json configs[3])
+def test_keys_give_a_topological_order_and_queues_follow_it(nb, rhs):
+    rows = plan(nb, rhs)
     chains, queues = split(rows)
     for q in queues:
         keys = [int(r[1]) for r in q]
@@ -61,7 +63,7 @@ def test_keys_give_a_topological_order_and_queues_follow_it(nb):
             j += 1
         for k in order[i:j]:
             for idx, need in deps_of(rows[k]):
-                assert flags.get(idx, 0) >= need, (nb, rows[k])
+                assert flags.get(idx, 0) >= need, (nb, rhs, rows[k])
         for k in order[i:j]:
             for idx, inc in signals_of(rows[k]):
                 flags[idx] = flags.get(idx, 0) + inc
@@ -162,18 +164,9 @@ def run_chain(bufs, r):
     return L
 
 
-@pytest.mark.parametrize("nb,nwg,seed", [(5, 7, 0), (9, 40, 1), (12, 96, 2), (14, 1, 3), (10, 480, 4)])
-def test_replay_with_concurrent_workgroups(nb, nwg, seed):
-    rng = np.random.default_rng(seed)
-    N = nb * T
-    G = rng.standard_normal((N, N // 2))
-    K = G @ G.T / (N // 2) + 0.5 * np.eye(N)
-    nan = np.full((N, N), np.nan)
-    yv = rng.standard_normal(N)
-    nblk = (nb + 3) // 4
-    bufs = [np.tril(K).copy(), nan.copy(), nan.copy(), np.zeros((N, N)), nan.copy(),      # A lower, L, Wt (never read before written), Wm zero, B
-            np.full(N, np.nan), np.zeros((nblk, N)), yv]                                   # z, alpha shares per row block, y
-    rows = plan(nb)
+def replay(rows, bufs, nwg, rng):
+    """the device's rule with nwg concurrent workgroups finishing in random order; asserts that nothing in flight is written or overwritten; returns
+    the chain kernels' log-determinant parts"""
     chains, queues = split(rows)
     flags = {}
     heads = [0] * len(queues)
@@ -236,7 +229,25 @@ def test_replay_with_concurrent_workgroups(nb, nwg, seed):
         if not progressed and not chain_busy and chain_next < len(chains) and ready(chains[chain_next]):
             start(chains[chain_next]); chain_next += 1; chain_busy = True; progressed = True       # (the coin above said "not yet")
         assert progressed, "deadlock: nothing ready, nothing running, %d of %d tasks done" % (done, total)
+    return logdet_parts
 
+
+def spd(N, rng):
+    G = rng.standard_normal((N, N // 2))
+    return G @ G.T / (N // 2) + 0.5 * np.eye(N)
+
+
+@pytest.mark.parametrize("nb,nwg,seed", [(5, 7, 0), (9, 40, 1), (12, 96, 2), (14, 1, 3), (10, 480, 4)])
+def test_replay_with_concurrent_workgroups(nb, nwg, seed):
+    rng = np.random.default_rng(seed)
+    N = nb * T
+    K = spd(N, rng)
+    nan = np.full((N, N), np.nan)
+    yv = rng.standard_normal(N)
+    nblk = (nb + 3) // 4
+    bufs = [np.tril(K).copy(), nan.copy(), nan.copy(), np.zeros((N, N)), nan.copy(),      # A lower, L, Wt (never read before written), Wm zero, B
+            np.full(N, np.nan), np.zeros((nblk, N)), yv]                                   # z, alpha shares per row block, y
+    logdet_parts = replay(plan(nb), bufs, nwg, rng)
     Lref = np.linalg.cholesky(K)
     Wref = np.linalg.inv(Lref)
     Kinv = np.linalg.inv(K)
@@ -247,6 +258,30 @@ def test_replay_with_concurrent_workgroups(nb, nwg, seed):
     alpha = np.array([bufs[6][(c // T) // 4:, c].sum() for c in range(N)])            # k_alpha_sum: the shares of the row blocks from the column's own on
     assert np.max(np.abs(bufs[5] - Wref @ yv)) < 1e-9 * np.max(np.abs(Wref @ yv))
     assert np.max(np.abs(alpha - Kinv @ yv)) < 1e-8 * np.max(np.abs(Kinv @ yv))
+
+
+@pytest.mark.parametrize("nb,rhs,nwg,seed", [(5, 2, 7, 0), (9, 3, 40, 1), (12, 5, 96, 2), (14, 2, 1, 3), (10, 4, 480, 4), (3, 1, 16, 5)])
+def test_replay_of_the_prediction_plan(nb, rhs, nwg, seed):
+    """factorisation + forward substitution X L^T = T of rhs tile rows of right-hand sides: the same rule, the same hazard checks; X = T L^-T comes out"""
+    rng = np.random.default_rng(100 + seed)
+    N = nb * T
+    K = spd(N, rng)
+    T0 = rng.standard_normal((rhs * T, N))
+    nan = np.full((N, N), np.nan)
+    Tb = nan.copy(); Tb[:rhs * T] = T0
+    bufs = [np.tril(K).copy(), nan.copy(), Tb, np.zeros((N, N)), nan.copy(), np.full(N, np.nan), np.zeros(((nb + 3) // 4, N)), np.zeros(N)]
+    rows = plan(nb, rhs)
+    assert not any(int(r[11]) & 32 for r in rows if r[0] >= 0)                       # no vector tasks, and nothing of the inverse:
+    assert not any(r[0] >= 0 and int(r[8]) == 4 and int(r[2]) == 3 and int(r[5]) == 3 for r in rows)      # no W^T W accumulations
+    logdet_parts = replay(rows, bufs, nwg, rng)
+    Lref = np.linalg.cholesky(K)
+    Xref = np.linalg.solve(Lref, T0.T).T
+    assert np.max(np.abs(bufs[4][:rhs * T] - Xref)) < 1e-9 * np.max(np.abs(Xref))
+    for b in range((nb + 3) // 4):                                                  # the panels L[below block b][block b], where the substitution read them
+        k0, k1 = 4 * b, min(nb, 4 * b + 4)
+        if k1 < nb:
+            assert np.max(np.abs(bufs[1][k1 * T:, k0 * T:k1 * T] - Lref[k1 * T:, k0 * T:k1 * T])) < 1e-9 * np.max(np.abs(Lref))
+    assert abs(sum(logdet_parts) - np.log(np.diag(Lref)).sum()) < 1e-8
 
 
 def happens_before(rows):
@@ -281,9 +316,9 @@ def happens_before(rows):
     return anc
 
 
-@pytest.mark.parametrize("nb", [6, 13, 22])
-def test_every_conflicting_pair_of_tasks_is_ordered_by_the_counters(nb):
-    rows = plan(nb)
+@pytest.mark.parametrize("nb,rhs", [(6, 0), (13, 0), (22, 0), (6, 2), (13, 4), (22, 3)])
+def test_every_conflicting_pair_of_tasks_is_ordered_by_the_counters(nb, rhs):
+    rows = plan(nb, rhs)
     anc = happens_before(rows)
     touch = {}
     for k, r in enumerate(rows):

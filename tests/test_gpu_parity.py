@@ -958,6 +958,46 @@ np.savez(sys.argv[1], lml=a["lml"], mom=a["moments"], elbo=b["elbo"], gz=b["gZ"]
         assert float(r["elbo"]) == float(ref["elbo"]) and np.array_equal(r["gz"], ref["gz"])
 
 
+def test_prediction_as_dataflow_equals_the_stream_form():
+    """predict_f with the factorisation AND the forward substitution as one tile-dataflow schedule (csrc/flow.hip, the prediction's plan) against the
+    stream form of the same tile products, in one process (MOGP_FLOW_PREDICT is read per call), at a size below the default threshold too; the
+    schedule is asserted through mogp_model_schedule.  BASELINE.json configs[3] itself is pinned on the reference's golden by test_cfg4_predict_golden."""
+    import os
+    old = os.environ.get("MOGP_FLOW_PREDICT")
+    try:
+        for N, S, C, Q in ((6400, 1500, 4, 3), (2304, 700, 3, 2)):              # 50 and 18 tile rows; S not a multiple of 128
+            X, y = synth.make_data(N, C)
+            h = synth.csm_hypers(C, Q)
+            k = gpr.MixtureKernel(gpr.CrossSpectralKernel(output_dims=C, input_dims=1, Rq=1), Q)
+            for q in range(Q):
+                k[q].amplitude.assign(h["amplitude"][q]); k[q].mean.assign(h["mean"][q])
+                k[q].variance.assign(h["variance"][q]); k[q].shift.assign(h["shift"][q])
+            m = gpr.Exact(k, X, y, variance=h["scale"] ** 2)
+            m.likelihood.scale.assign(h["scale"])
+            Xs = synth.test_inputs(S, C)
+            os.environ["MOGP_FLOW_PREDICT"] = "8:200"
+            mu1, var1 = m.predict_f(Xs)
+            s1 = m._handle.schedule()
+            assert s1["dataflow"] and not s1["dataflow_fell_back"], s1
+            mu1b, var1b = m.predict_f(Xs)
+            assert np.array_equal(mu1, mu1b) and np.array_equal(var1, var1b)     # the tiles run in a different order every time: same bits
+            os.environ["MOGP_FLOW_PREDICT"] = "0"
+            mu0, var0 = m.predict_f(Xs)
+            assert not m._handle.schedule()["dataflow"]
+            assert np.max(np.abs(mu1 - mu0)) <= 1e-9 * max(1.0, np.max(np.abs(mu0)))
+            assert np.max(np.abs(var1 - var0)) <= 1e-9 * max(1.0, np.max(np.abs(var0)))
+            cov1 = m.predict_f(Xs[:300], full=True)[1] if N < 3000 else None      # the full-covariance branch reads the same X
+            if cov1 is not None:
+                os.environ["MOGP_FLOW_PREDICT"] = "8:200"
+                cov2 = m.predict_f(Xs[:300], full=True)[1]
+                assert np.max(np.abs(cov1 - cov2)) <= 1e-9 * np.max(np.abs(cov1))
+    finally:
+        if old is None:
+            os.environ.pop("MOGP_FLOW_PREDICT", None)
+        else:
+            os.environ["MOGP_FLOW_PREDICT"] = old
+
+
 def test_first_evaluation_of_a_fresh_process_above_8192_points_runs_as_dataflow(tmp_path):
     """A fresh process, a model with more than 8192 points, ONE evaluation: it must run as tile dataflow and must not have fallen back.  Until round 4
     every such first evaluation timed out and the model stayed on the stream schedule for good (17.2 instead of 14.5 ms at N = 9216): the z^T z parts
