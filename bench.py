@@ -226,6 +226,10 @@ def extra_configs(device, names=("cfg3", "cfg4", "cfg5"), steps=None):
             out[cfg] = config_entry(cfg, ms, k, flops)
             h = getattr(m, "_handle", None)
             if h is not None:
+                if kind in ("exact", "predict") and hasattr(h, "schedule"):        # which schedule the last call ran on (mogp_model_schedule): a fallback shows
+                    sc = h.schedule()
+                    out[cfg]["dataflow_kernel"] = sc["dataflow"]
+                    out[cfg]["fell_back"] = sc["dataflow_fell_back"] or sc["chain_fell_back"]
                 h.close()
             del m, run_step, step
         except Exception as e:          # a report, never a reason to lose the headline
@@ -476,7 +480,7 @@ def main():
         gram_gbs = gram_bytes * nprof / (stage[_lib.ST_GRAM_KERNEL] * 1e-3) / 1e9 if stage[_lib.ST_GRAM_KERNEL] > 0 else None
         mom_gbs = gram_bytes * nprof / (stage[_lib.ST_MOMENT_KERNEL] * 1e-3) / 1e9 if stage[_lib.ST_MOMENT_KERNEL] > 0 else None
         traffic, traffic_src, traffic_eval = None, None, None
-        sched = h.schedule() if (kind == "exact" and not sharded_mode and hasattr(h, "schedule")) else None
+        sched = h.schedule() if (kind in ("exact", "predict") and not sharded_mode and hasattr(h, "schedule")) else None
         for tf in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"):     # L2<->fabric bytes per k_gemm launch from the committed rocprofv3 --pmc passes of this command
             try:
                 with open(os.path.join(ROOT, "profiles", tf)) as f:
