@@ -9,6 +9,7 @@ T=${1:-prof}; O=$GRAFT_REPO_ROOT/gpurun_out/$T; mkdir -p $O
 timeout 900 python bench.py > $O/bench_line.json 2> $O/bench_line.err
 for c in cfg3 cfg4 cfg5; do timeout 300 python bench.py --config $c --no-cpu-baseline --no-configs --no-shard-probe 2> $O/b_$c.err | tail -1 > $O/b_$c.json; done
 (timeout 150 python tools/flow_trace.py 8192) > $O/cfg2_timeline.txt 2>&1
+(timeout 150 python tools/flow_trace_predict.py) > $O/cfg4_timeline.txt 2>&1
 cd /tmp
 for c in cfg2 cfg3 cfg4 cfg5; do
   st=5; wu=2; if [ $c = cfg2 ]; then st=20; wu=5; fi      # the headline as the driver runs it: the average then is the steady state's, not the warm-up's
