@@ -111,8 +111,9 @@ def build_model(cfg, device, n_override=None):
     s = float(np.mean(h["scale"]))
     m = gpr.Titsias(k, X, y, Z=[M // C] * C, variance=s ** 2)
     m.likelihood.scale.assign(s)
-    # forward: v = L^-1 Kuf (M^2 N) + Q = v v^T (M^2 N); backward: (I - Pq) v (2 M^2 N) + L^-T (.) (M^2 N); the M^3 terms are 1 %
-    return m, (lambda: m.loss()), 5.0 * float(M) ** 2 * N + 4.0 * float(M) ** 3
+    # forward: v = L^-1 Kuf (M^2 N) + Q = v v^T (M^2 N); backward: (L^-T (I - Pq)) v (2 M^2 N); the M^3 terms are 1 %.  (Until round 4 the backward
+    # part was (I - Pq) v followed by an M x N solve with L^T, and this count was 5 M^2 N: the solve is gone from the algorithm, so it is gone from here.)
+    return m, (lambda: m.loss()), 4.0 * float(M) ** 2 * N + 5.0 * float(M) ** 3
 
 
 def training_step(m, run_step, kind):

@@ -356,6 +356,13 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
     // and t1 travels through the blocked solve in the first of them (a vector solve of its own is 2 nb dependent, almost empty launches).
     // The large product is ENQUEUED before the side chain's ~70 launches, so that a slow host does not hold it back.
     RC(launch_combine(t.R.p, t.q.B.p, nullptr, Mpad, Mpad, 1.0, 1.0, 0.0, m->st));           // R = I - Pq
+    // Round 4: GB = (L^-T R) v / s2 -- the M x M solve FIRST (16 block rows of a 2048-column right-hand side), then ONE M x M x N product, instead of
+    // the product followed by the M x N solve (8.6 of configs[4]'s 45 ms).  This is not the explicit-inverse product that cost round 1 its dELBO/dZ:
+    // L^-T R comes from a backward-stable substitution, v is the accurately solved L^-1 B, and the product is the LAST step before the contraction
+    // with the kernel derivatives -- no solve behind it amplifies its rounding.  Against the 80-bit truth dELBO/dZ is 2.17e-3 of the tensor off
+    // (M x N solve: 2.37e-3, the reference's fp64: 2.40e-3); kernel gradients 9.6e-9 (9.2e-9).  MOGP_TITSIAS_GB=0: the M x N solve.
+    static const bool gb_first = !(std::getenv("MOGP_TITSIAS_GB") && atoi(std::getenv("MOGP_TITSIAS_GB")) == 0);
+    if (gb_first) RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.R.p, Mpad, Mpad, true));
     GemmArgs g = make_gemm(t.R.p, Mpad, 0, t.v.p, Npad, 1, t.GB.p, Npad, 1.0 / s2, GM_RECT, mt, nt, Mpad);
     // tiles down the columns: the 64 workgroups an XCD holds are then 64 / mt column blocks of v against all of R (M x M: cache-resident), and v comes
     // in from memory once -- row by row it came in mt times (27 GB fetched at configs[4] for a 1.6 GB panel)
@@ -368,9 +375,9 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.GA.p, Mpad, Mpad, true, side));
     RC(launch_sym_lower_avg(t.GA.p, Mpad, Mpad, 0.5, side));
     RC(launch_get_diag(t.GA.p, Mpad, Mpad, dga, side));
-    const bool ride = Npad > N;
+    const bool ride = Npad > N && !gb_first;
     if (ride) RC(launch_copy2d(t.GB.p + N, Npad, t1, 1, Mpad, 1, 1.0, m->st));
-    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.GB.p, Npad, Npad, true));
+    if (!gb_first) RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.GB.p, Npad, Npad, true));
     if (ride) {
         RC(launch_copy2d(beta, 1, t.GB.p + N, Npad, Mpad, 1, 1.0, m->st));
         RC(launch_copy2d(t.GB.p + N, Npad, t.zero_col.p, 1, Mpad, 1, 1.0, m->st));          // the padding column is zero again
