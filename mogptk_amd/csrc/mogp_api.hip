@@ -171,10 +171,10 @@ int mogp_ctx_create(int device, mogp_ctx** out) {
         // stalled until their waits gave up: every first evaluation above N = 8192 fell back to the stream schedule (tools/r4_first.py; 16 KB pieces do not
         // trigger it, a sleep in front of the copy avoids it).  Found in round 4 when the dataflow default went to 96 tile rows.
         void* dsrc = nullptr; void* hdst = nullptr;
-        const size_t nbytes = 256 * 1024;
+        const size_t nbytes = 32u << 20;                     // and at three sizes: the runtime picks its copy path by size (the prediction brings back 33 KB, a fetch 512 MB)
         if (hipMalloc(&dsrc, nbytes) == hipSuccess && hipHostMalloc(&hdst, nbytes, hipHostMallocDefault) == hipSuccess) {
             hipError_t e = hipMemsetAsync(dsrc, 0, nbytes, c->st); (void)e;
-            e = hipMemcpyAsync(hdst, dsrc, nbytes, hipMemcpyDeviceToHost, c->st); (void)e;
+            for (size_t nb : {(size_t)64 << 10, (size_t)2 << 20, nbytes}) { e = hipMemcpyAsync(hdst, dsrc, nb, hipMemcpyDeviceToHost, c->st); (void)e; }
             e = hipStreamSynchronize(c->st); (void)e;
         }
         if (hdst) { hipError_t e = hipHostFree(hdst); (void)e; }
