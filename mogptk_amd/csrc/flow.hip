@@ -640,7 +640,7 @@ void flow_build(int nb, int ob, FlowPlan& p, int rhs_nt) {
     }
     order.push_back(rhs_nt > 0 ? &rrest : &acc);
     for (size_t k = order.size(); k-- > 1;) if (order[k]->empty()) order.erase(order.begin() + (long)k);      // (the first queue keeps its place: it is the compare-and-swap one)
-    if ((int)order.size() > FLOW_MAXQ) {          // (not reached for the sizes the fused schedule serves, nb <= 80: 2 no + 2 queues) fold the farthest deadlines into one queue
+    if ((int)order.size() > FLOW_MAXQ) {          // more deadline queues than the kernel has lanes for (above 85 tile rows): fold the farthest deadlines into one queue
         std::vector<FlowTask> rest;
         // merged in superstep order so that the folded queue stays sorted by key
         std::vector<const std::vector<FlowTask>*> tail(order.begin() + (FLOW_MAXQ - 2), order.end() - 1);
