@@ -129,7 +129,7 @@ int mogp_oa_forward(mogp_model* m, const double* q_nu, const double* q_lambda, d
     // B = Lambda K Lambda + I -> B^-1 (m->k.B: lower tiles, then mirrored), log det from the factorisation
     hipLaunchKernelGGL(k_oa_scale, dim3((unsigned)Npad), dim3(256), 0, m->st, o.K.p, m->k.A.p, Npad, lam);
     HIP_TRY(hipGetLastError());
-    if (m->nb <= 80) {                                            // the same choice of schedule as mogp_exact_eval
+    if (m->nb <= (flow_enabled(m, m->k) ? 112 : 80)) {             // the same choice of schedule as mogp_exact_eval (112 tile rows as dataflow, 80 as streams)
         RC(spd_potri_fused(m, m->k));
         RC(spd_potri_fused_finish(m, m->k));
     } else {
