@@ -976,9 +976,14 @@ def test_prediction_as_dataflow_equals_the_stream_form():
             m.likelihood.scale.assign(h["scale"])
             Xs = synth.test_inputs(S, C)
             os.environ["MOGP_FLOW_PREDICT"] = "8:200"
+            l_before = float(m.loss())                                         # a gradient evaluation (its own dataflow plan) before and after:
+            g_before = [p.grad.copy() for p in m.parameters()]                 # the two plans share the handle's counters and buffers
             mu1, var1 = m.predict_f(Xs)
             s1 = m._handle.schedule()
             assert s1["dataflow"] and not s1["dataflow_fell_back"], s1
+            assert float(m.loss()) == l_before
+            for g, p in zip(g_before, m.parameters()):
+                assert np.array_equal(g, p.grad)
             mu1b, var1b = m.predict_f(Xs)
             assert np.array_equal(mu1, mu1b) and np.array_equal(var1, var1b)     # the tiles run in a different order every time: same bits
             os.environ["MOGP_FLOW_PREDICT"] = "0"
