@@ -510,9 +510,16 @@ class Titsias(_DataParallel, Model):
         else:
             for i in range(C):
                 gt[i, i, :, 0] += self.jitter * res["trGA"] * zc[i] / M          # jitter * mean(diag Kuu), gpr/model.py:244
-            self.kernel._spectral_backward(-gt)
-            # - 1/(2 s2) sum_k Kff_diag[k]  (gpr/model.py:723): K_diag is constant per channel
-            self.kernel._spectral_diag_backward(0.5 * xc / s2, D)
+            # - 1/(2 s2) sum_k Kff_diag[k]  (gpr/model.py:723): K_diag is constant per channel.  Where K_diag[c] is the sum of the diagonal amplitudes
+            # (the kernels that keep Kernel._spectral_diag_backward) that is a table gradient too: ONE pass through the parameter algebra instead of two
+            from .kernel import Kernel
+            if type(self.kernel)._spectral_diag_backward is Kernel._spectral_diag_backward:
+                for i in range(C):
+                    gt[i, i, :, 0] -= 0.5 * xc[i] / s2
+                self.kernel._spectral_backward(-gt)
+            else:
+                self.kernel._spectral_backward(-gt)
+                self.kernel._spectral_diag_backward(0.5 * xc / s2, D)
         scale = self.likelihood.scale
         scale.accumulate_grad(np.reshape(-res["dsigma"], scale.data.shape))
         gz = np.zeros(self.Z.data.shape)
