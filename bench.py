@@ -18,7 +18,11 @@ The default line (cfg2) also carries, outside its timed region:
   roofline / gram_hbm / moments_hbm / stages_ms_per_eval from HIP events inside the timed region
 `--config cfgN` makes that configuration the timed step instead (same JSON shape).
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU):
+N > 1: one rank per GPU.  Under a launcher (torch.distributed.run: WORLD_SIZE / RANK / LOCAL_RANK / MASTER_* in the environment) this process is one
+rank; as a PLAIN process (`python bench.py --gpus N`, WORLD_SIZE unset) it starts the N ranks itself (self_launch: rank r on GPU r, rendezvous on
+127.0.0.1) and exits non-zero with a one-line reason when the node shows fewer than N GPUs -- it never prints a 1-GPU line for an N-GPU request.
+The N > 1 line carries `sharded_cfg3` at top level (ONE N = 32768 evaluation split over the ranks: ms_one_gpu, ms_sharded, speedup, rccl_ranks,
+rel_loss / rel_grad) next to the replicas `value`.
   replicas (default)  `value` = aggregate evals/s of N independent replicas of the workload (one 13 ms evaluation does not pay for an
                       exchange per pivot block; N GPUs are best used as N evaluations: restarts, models); scaling "weak".  BEFORE the timed
                       region every rank runs the `sharded` probes -- the north_star's split of ONE evaluation over the GPUs
@@ -161,11 +165,11 @@ def cpu_baseline(N, C, Q, budget_s=240.0):
             n *= 2
             t = one(n)
     if n == N:
-        return dict(value=1.0 / t, unit="evals/s", cores=cores, kind="port", extrapolated=False, seconds=t,
+        return dict(value=1.0 / t, unit="evals/s", cores=cores, torch_threads=cores, kind="port", extrapolated=False, seconds=t,
                     sample="1 LML+grad eval of the same workload (MOSM C=%d Q=%d N=%d), torch-CPU fp64 port of the "
                            "reference op sequence, timed directly: %.1f s" % (C, Q, N, t))
     scale = (N / n) ** 3
-    return dict(value=1.0 / (t * scale), unit="evals/s", cores=cores, kind="port", extrapolated=True, seconds=t * scale,
+    return dict(value=1.0 / (t * scale), unit="evals/s", cores=cores, torch_threads=cores, kind="port", extrapolated=True, seconds=t * scale,
                 sample="1 eval at N=%d took %.1f s; a direct evaluation at N=%d was predicted to exceed %.0f s on this host; "
                        "extrapolated by N^3 (x%.0f)" % (n, t, N, budget_s, scale))
 
@@ -364,6 +368,129 @@ def run_probes(names, base_port, timeout_s, reps=None):
     return out
 
 
+def device_count():
+    """GPUs this process can see, from the library the benchmark measures (mogp_device_count = hipGetDeviceCount)"""
+    from mogptk_amd import _lib
+    return int(_lib.lib().mogp_device_count())
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv, selftest=False):
+    """`python bench.py --gpus N` as a PLAIN process (no torch.distributed.run around it, WORLD_SIZE unset): start the N ranks here -- one
+    process per GPU, rank r pinned to GPU r, rendezvous on 127.0.0.1 and a free port of its own -- and wait for them.  Rank 0 prints the line on
+    the inherited stdout.  Fewer than N visible GPUs is an error with a one-line reason (exit code 2), never a silent 1-GPU run that reports
+    n_gpus 1; a rank that dies takes the others with it and its exit code becomes this process's."""
+    import signal
+    if not selftest:
+        try:
+            have = device_count()
+        except Exception as e:
+            print("bench.py: --gpus %d: cannot count the GPUs (%r)" % (n, e), file=sys.stderr)
+            return 2
+        if have < n:
+            print("bench.py: --gpus %d asked for, but this node shows %d GPU%s (hipGetDeviceCount); not starting" % (n, have, "" if have == 1 else "s"),
+                  file=sys.stderr)
+            return 2
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MOGP_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # RCCL across processes needs dmabuf IPC on these hosts
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, start_new_session=True))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            time.sleep(0.05)
+            for p in list(live):
+                c = p.poll()
+                if c is None:
+                    continue
+                live.remove(p)
+                if c != 0 and rc == 0:
+                    rc = c if c > 0 else 1
+                    print("bench.py: rank %d of the self-launched job exited with code %d; stopping the other ranks" % (procs.index(p), c), file=sys.stderr)
+                    for q in live:
+                        try:
+                            os.killpg(q.pid, signal.SIGTERM)
+                        except Exception:
+                            pass
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except Exception:
+                    pass
+    return rc
+
+
+def cpu_identity():
+    """CPU model string and the thread counts behind `cpu_baseline.cores` (core count and CPU model printed)"""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except Exception:
+        pass
+    out = {"cpu_model": model, "logical_cpus": os.cpu_count()}
+    try:
+        out["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    return out
+
+
+def sharded_headline(sharded, world):
+    """the north_star's multi-GPU number, first-class on the N > 1 line: ONE configs[2] evaluation (MOSM C=8 Q=5 N=32768) split over the ranks by
+    mogp_exact_eval_sharded against the same evaluation on one GPU of the same job (`value` beside it is N independent replicas of configs[1])"""
+    r = dict((sharded or {}).get("cfg3") or {})
+    keys = ("ms_one_gpu", "ms_sharded", "speedup", "evals_per_s_sharded", "rccl_ranks", "rank_sum_ok", "transport", "rel_loss", "rel_grad",
+            "exchange_ms", "serial_ms", "next_cols_ms", "bulk_ms", "error")
+    out = {"workload": CONFIGS["cfg3"][5], "ranks": world, "scaling": "strong"}
+    out.update({k: r[k] for k in keys if k in r})
+    if "speedup" in r:
+        out["target"] = "north_star: >= 3.5x at 8 GPUs"
+    return out
+
+
+def selftest_main(a, rank, world):
+    """the orchestration of an N > 1 run without a GPU or a native call (tests/test_bench_dist_cpu.py): gloo ranks, the probe mechanism with its
+    `dummy` probe (one all-reduce of (1, rank + 1) in a child process group), the timed region around a sleeping step, the line's top level"""
+    dist = None
+    sharded = None
+    if world > 1:
+        base_port = int(os.environ.get("MASTER_PORT", "29655")) + 20
+        sharded = run_probes(["dummy"], base_port, a.probe_timeout)
+        sharded["ranks"] = world
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    steps = a.steps if a.steps is not None else 5
+    warmup = a.warmup if a.warmup is not None else 1
+    dt = timed_region(lambda i: time.sleep(0.002), steps, warmup, dist)
+    if rank == 0:
+        out = {"metric": "selftest (no GPU work)", "value": aggregate_value(world, steps, dt), "unit": "steps/s", "n_gpus": world, "steps": steps,
+               "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic", "config": {"workload": "selftest", "parallelism": "replicas x%d" % world,
+                                                               "self_launched": os.environ.get("MOGP_BENCH_SELF_LAUNCHED") == "1"}}
+        if sharded is not None:
+            out["sharded"] = sharded
+            out["rccl_ranks"] = (sharded.get("dummy") or {}).get("rccl_ranks")
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -373,6 +500,7 @@ def main():
     ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"])
     ap.add_argument("--n", type=int, default=None, help="override the configuration's N (development)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustained", type=int, default=200, help="steps of the longer sample taken behind the timed region of the headline configuration (0: none)")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (cfg3 / cfg4 / cfg5 on this GPU)")
     ap.add_argument("--shard-probe", action="store_true", help="also run the sharded probes at --gpus 1 (1-rank RCCL group)")
     ap.add_argument("--no-shard-probe", action="store_true")
@@ -380,10 +508,16 @@ def main():
     ap.add_argument("--probe-timeout", type=float, default=180.0, help="watchdog of EACH sharded probe in seconds")
     ap.add_argument("--probe-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--probe-reps", type=int, default=3, help=argparse.SUPPRESS)
+    ap.add_argument("--selftest", action="store_true", help=argparse.SUPPRESS)     # the launch / probe / timing orchestration on CPU ranks (gloo, a dummy step): tests/test_bench_dist_cpu.py
     a = ap.parse_args()
     if a.probe_child:
         probe_child(a.probe_child, a.probe_reps)
         return
+    if a.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # a plain `python bench.py --gpus N`: nobody started the ranks, so this process does (and fails loudly if the node has fewer GPUs)
+        sys.exit(self_launch(a.gpus, sys.argv[1:], selftest=a.selftest))
     kind, C, Q, N, extra, desc = CONFIGS[a.config]
     if a.n:
         N = a.n
@@ -394,6 +528,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d rank%s (WORLD_SIZE); the line reports n_gpus = %d" % (a.gpus, world, "" if world == 1 else "s", world),
+              file=sys.stderr)
+    if a.selftest:
+        selftest_main(a, rank, world)
+        return
+    if world > 1:
+        have = device_count()
+        if local_rank >= have:
+            print("bench.py: rank %d is pinned to GPU %d but this node shows %d GPU%s" % (rank, local_rank, have, "" if have == 1 else "s"), file=sys.stderr)
+            sys.exit(2)
     sharded_mode = a.mode == "sharded"       # exact / predict: one evaluation's tiles over the ranks; titsias: its data points over the ranks
 
     # ---- the sharded probes FIRST (N > 1, replicas mode): nothing of this process is on the GPU yet, every probe is a group of child
@@ -456,6 +601,13 @@ def main():
     dt = timed_region(step, steps, warmup, dist, sync, "cuda" if dist is not None else "cpu")
     gemm_flops, gemm_launches, nprof = acc["flops"], acc["launches"], max(acc["nprof"], 1)
     h.set_profiling(False)
+    # a longer sample of the same step right behind the timed region (the chip's clocks take tens of ms of load to settle, and K = 20 steps of
+    # configs[1] are 0.2 s): reported beside `value`, never instead of it
+    sustained = None
+    if a.sustained > 0 and not big and not sharded_mode:
+        dts = timed_region(lambda i: train_step(), a.sustained, 0, dist, sync, "cuda" if dist is not None else "cpu")
+        sustained = {"steps": a.sustained, "ms_per_step": 1e3 * dts / a.sustained, "value": aggregate_value(world, a.sustained, dts),
+                     "note": "the same step, %d more times behind the timed region" % a.sustained}
     if sharded_mode:
         mogptk_amd.use_single_device()
 
@@ -554,8 +706,11 @@ def main():
                                "bytes_per_launch": gram_bytes}
             out["moments_hbm"] = {"bound": "hbm", "achieved": mom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mom_gbs / HBM_PEAK_GBS if mom_gbs else None,
                                   "bytes_per_launch": gram_bytes}
+        if sustained is not None:
+            out["sustained"] = sustained
         if sharded is not None:
             out["sharded"] = sharded
+            out["sharded_cfg3"] = sharded_headline(sharded, world)
 
     # ---- the other configurations on this GPU, then the CPU baseline: outside the timed region, rank 0 at N = 1 only -----------------------
     if rank == 0 and world == 1 and not sharded_mode and a.config == "cfg2" and not a.n:
@@ -565,6 +720,7 @@ def main():
         if not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, C, Q)
+                out["cpu_baseline"].update(cpu_identity())
             except Exception as e:      # the baseline is a report, never a reason to lose the GPU measurement
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
     elif rank == 0 and world == 1 and not a.no_cpu_baseline and not sharded_mode:

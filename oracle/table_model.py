@@ -701,3 +701,83 @@ for _n, _f in (("shard_begin", _shard_begin), ("shard_pack", _shard_pack), ("sha
     setattr(TableDevice, _n, _f)
 TableDevice.mem_get = lambda self, buf, count: np.array(buf[:count], dtype=np.float64)
 TableDevice.mem_put = lambda self, buf, arr: buf.__setitem__(slice(0, len(arr)), arr)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The exact evaluation at sizes where TableDevice.eval's handful of dense N x N temporaries do not fit (BASELINE.json
+# configs[2], N = 32768: 8.6 GB each).  Same formulas, ONE N x N array: the Gram goes into it block row by block row, LAPACK
+# factors it in place (dpotrf), turns the factor into Kj^-1 in place (dpotri), and the moments are taken from row chunks of
+# G = 1/2 (alpha alpha^T - Kj^-1) that are never held as a matrix.  Rows must be channel-contiguous (what the wrappers pass,
+# reference model.py:594-598).  Pinned on TableDevice.eval itself at small N (tests/test_oracle_golden.py) and on the
+# reference's own forward LML at N = 32768 (tests/golden/gen_cfg3.py).
+# ----------------------------------------------------------------------------------------------------------------
+class TableDeviceLean(TableDevice):
+    chunk = 256
+
+    def eval(self, noise_var, jitter, grad=True, data_var=None):
+        from scipy.linalg import lapack
+        N, C, D, T = self.N, self.C, self.D, self.T
+        c = self.X[:, 0].astype(np.int64)
+        if np.any(np.diff(c) < 0):
+            raise ValueError("TableDeviceLean needs channel-contiguous rows")
+        lo = np.searchsorted(c, np.arange(C), side="left")
+        hi = np.searchsorted(c, np.arange(C), side="right")
+        x = self.X[:, 1:]
+        K = np.empty((N, N))
+        for i in range(C):
+            for j in range(i + 1):
+                if hi[i] == lo[i] or hi[j] == lo[j]:
+                    continue
+                tab = self.table[i, j]
+                for r0 in range(lo[i], hi[i], self.chunk):
+                    r1 = min(r0 + self.chunk, hi[i])
+                    Ec, _, _ = table_block(tab, x[r0:r1], x[lo[j]:hi[j]])
+                    K[r0:r1, lo[j]:hi[j]] = np.einsum("t,tnm->nm", tab[:, 0], Ec)
+        idx = np.arange(N)
+        d = K[idx, idx] + np.asarray(noise_var)[c] + (0.0 if data_var is None else np.asarray(data_var))
+        jit = jitter * np.mean(d)
+        K[idx, idx] = d + jit
+        # K is C-ordered with its lower triangle filled: K.T is the Fortran-ordered matrix with its UPPER triangle filled
+        U, info = lapack.dpotrf(K.T, lower=0, clean=0, overwrite_a=1)
+        if info != 0:
+            raise np.linalg.LinAlgError("dpotrf info=%d" % info)
+        assert np.shares_memory(U, K)
+        logdet_half = float(np.sum(np.log(K[idx, idx])))
+        alpha, info = lapack.dpotrs(U, self.y, lower=0)
+        lml = -0.5 * N * np.log(TWO_PI) - logdet_half - 0.5 * (self.y.T @ alpha).item()
+        if not grad:
+            return dict(lml=lml, moments=None, diagG=None, trG=0.0, jitter_abs=jit)
+        Ui, info = lapack.dpotri(U, lower=0, overwrite_c=1)              # lower triangle of K (C order) now holds Kj^-1
+        if info != 0:
+            raise np.linalg.LinAlgError("dpotri info=%d" % info)
+        assert np.shares_memory(Ui, K)
+        for i in range(C):                                               # the diagonal channel blocks are read as full symmetric blocks
+            B = K[lo[i]:hi[i], lo[i]:hi[i]]
+            B[:] = np.tril(B) + np.tril(B, -1).T
+        a = alpha[:, 0]
+        W = self.table.shape[3]
+        if W > 2 + 3 * D:
+            raise ValueError("TableDeviceLean: plain (2 + 3 D) term rows only")
+        mom = np.zeros((C * (C + 1) // 2, T, W))
+        for i in range(C):
+            for j in range(i + 1):
+                if hi[i] == lo[i] or hi[j] == lo[j]:
+                    continue
+                tab = self.table[i, j]
+                m = mom[i * (i + 1) // 2 + j]
+                for r0 in range(lo[i], hi[i], self.chunk):
+                    r1 = min(r0 + self.chunk, hi[i])
+                    Ec, Es, u = table_block(tab, x[r0:r1], x[lo[j]:hi[j]])
+                    g = (0.5 if i == j else 1.0) * (np.outer(a[r0:r1], a[lo[j]:hi[j]]) - K[r0:r1, lo[j]:hi[j]])
+                    gc = g[None] * Ec
+                    gs = g[None] * Es
+                    m[:, 0] += gc.sum(axis=(1, 2))
+                    m[:, 1] += gs.sum(axis=(1, 2))
+                    gcu = gc[..., None] * u
+                    m[:, 2:2 + D] += (gcu * u).sum(axis=(1, 2))
+                    m[:, 2 + D:2 + 2 * D] += gcu.sum(axis=(1, 2))
+                    m[:, 2 + 2 * D:2 + 3 * D] += (gs[..., None] * u).sum(axis=(1, 2))
+        dG = 0.5 * (a * a - K[idx, idx])
+        diagG = np.array([np.sum(dG[lo[k]:hi[k]]) for k in range(C)])
+        self._last = None
+        return dict(lml=lml, moments=mom, diagG=diagG, trG=float(np.sum(dG)), jitter_abs=jit)

@@ -85,3 +85,41 @@ def test_line_objects_have_the_keys_the_driver_reads():
     assert set(bench.PROBES) >= {"cfg3", "cfg2", "cfg5"} and bench.PROBES[0] == "cfg3"       # the cfg3 probe runs first
     b = bench.cpu_baseline(256, 2, 2)              # tiny: timed directly at its own N
     assert b["extrapolated"] is False and b["kind"] == "port" and b["value"] > 0 and "N=256" in b["sample"]
+
+
+def test_plain_process_launches_its_own_ranks():
+    """`python bench.py --gpus 2` as a PLAIN process (WORLD_SIZE unset: how the driver starts the 1-GPU line) must not run on one device and
+    print n_gpus 1: it starts the two ranks itself.  --selftest keeps the GPU out of it (gloo ranks, a sleeping step, the `dummy` probe)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                        # ONE line, from rank 0
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["config"]["self_launched"] is True
+    assert r["rccl_ranks"] == 2 and r["sharded"]["dummy"]["rank_sum_ok"] is True      # the probe's child group spanned both ranks
+    assert abs(r["value"] - 2 * 3 / (r["ms_per_step"] * 3e-3)) < 1e-6 * r["value"]
+
+
+def test_more_gpus_than_the_node_has_is_an_error_with_a_reason():
+    """--gpus 8 on a box with fewer GPUs (none here): exit code 2 and one line on stderr saying why -- not a 1-GPU line"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 2
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    msg = [l for l in out.stderr.splitlines() if l.startswith("bench.py:")]
+    assert len(msg) == 1 and "--gpus 8" in msg[0] and "GPU" in msg[0], out.stderr
+
+
+def test_sharded_headline_is_top_level():
+    sys.path.insert(0, ROOT)
+    import bench
+    sh = {"cfg3": {"ms_one_gpu": 540.0, "ms_sharded": 120.0, "speedup": 4.5, "rccl_ranks": 8, "rel_loss": 1e-13, "rel_grad": 1e-9, "probe_wall_s": 30.0},
+          "ranks": 8}
+    top = bench.sharded_headline(sh, 8)
+    assert top["speedup"] == 4.5 and top["rccl_ranks"] == 8 and top["ranks"] == 8 and "N=32768" in top["workload"] and top["scaling"] == "strong"
+    assert bench.sharded_headline({"cfg3": {"error": "watchdog"}}, 8)["error"] == "watchdog"
+    ident = bench.cpu_identity()
+    assert "cpu_model" in ident and ident["logical_cpus"] >= 1
