@@ -91,8 +91,8 @@ def _load_storage_bytes(b):
     return torch.load(io.BytesIO(b), weights_only=True)
 
 
-def _refuse(module, name, what):
-    raise pickle.UnpicklingError("%s names %s.%s, which a mogptk checkpoint has no use for: refused" % (what, module, name))
+def _refuse(module, name, what, hint=""):
+    raise pickle.UnpicklingError("%s names %s.%s, which a mogptk checkpoint has no use for: refused%s" % (what, module, name, hint))
 
 
 class _Unpickler(pickle.Unpickler):
@@ -108,26 +108,51 @@ class _Unpickler(pickle.Unpickler):
         _refuse(module, name, "reference checkpoint")
 
 
+# functions of this package a checkpoint of this package may name (everything else it names here must be a CLASS defined in the package: a
+# class is only instantiated, a function would be CALLED with arguments the file chooses)
+_NATIVE_FUNCTIONS = {("mogptk_amd.gpr.likelihood", "_link_by_name")}
+
+
+def _in_package(module):
+    return module == "mogptk_amd" or module.startswith("mogptk_amd.")
+
+
 class _NativeUnpickler(pickle.Unpickler):
-    """this package's own checkpoints (Model.save pickles the model): classes and functions DEFINED in mogptk_amd, numpy's array rebuilders and
-    the same small set of builtins -- an object merely reachable through one of the package's modules (an imported os, subprocess, pickle ...)
-    is not resolved"""
+    """this package's own checkpoints (Model.save pickles the model): classes DEFINED in mogptk_amd, the few of its functions listed above,
+    numpy's array rebuilders and the same small set of builtins -- an object merely reachable through one of the package's modules (an imported
+    os, subprocess, pickle ...) is not resolved.  A model that carries user code (a mean function, a Kernel / Likelihood / transformer
+    subclass of the caller's) names that code's module: `allow=[...]` admits exactly those objects, `LoadModel(..., trusted=True)` is the
+    reference's plain pickle.load."""
+
+    def __init__(self, f, allow=()):
+        super().__init__(f)
+        self._extra = {}
+        for obj in allow or ():
+            mod, qual = getattr(obj, "__module__", None), getattr(obj, "__qualname__", getattr(obj, "__name__", None))
+            if mod is None or qual is None:
+                raise TypeError("allow= takes classes and functions (objects with __module__ and __qualname__), got %r" % (obj,))
+            self._extra[(mod, qual)] = obj
 
     def find_class(self, module, name):
+        if (module, name) in self._extra:                      # the caller vouched for this object (nested classes come as dotted names)
+            return self._extra[(module, name)]
+        hint = "; pass it to LoadModel(filename, allow=[...]) if it is yours, or LoadModel(filename, trusted=True) for a file you trust"
         if "." in name:
-            _refuse(module, name, "checkpoint")
-        if module == "mogptk_amd" or module.startswith("mogptk_amd."):
+            _refuse(module, name, "checkpoint", hint)
+        if _in_package(module):
             obj = super().find_class(module, name)
-            if (isinstance(obj, type) or callable(obj)) and str(getattr(obj, "__module__", "")).startswith("mogptk_amd"):
+            if _in_package(str(getattr(obj, "__module__", ""))) and (isinstance(obj, type) or (module, name) in _NATIVE_FUNCTIONS):
                 return obj
-            _refuse(module, name, "checkpoint")
+            _refuse(module, name, "checkpoint", hint)
         if not module.startswith("torch") and name in _ALLOWED.get(module, ()):
             return super().find_class(module, name)
-        _refuse(module, name, "checkpoint")
+        _refuse(module, name, "checkpoint", hint)
 
 
-def load_native_model(raw):
-    return _NativeUnpickler(io.BytesIO(raw)).load()
+def load_native_model(raw, allow=(), trusted=False):
+    if trusted:
+        return pickle.loads(raw)
+    return _NativeUnpickler(io.BytesIO(raw), allow).load()
 
 
 def is_reference_checkpoint(raw):

@@ -23,6 +23,14 @@
 #include <vector>
 #include <cstdlib>
 
+// measurement switches of the tile kernels (no stores / no terms / constant staging: tools/r4_gram_lds.sh) exist only in a build with
+// -DMOGP_GRAM_DEBUG; in the product kernels the conditions are the constant 0 and the branches are gone
+#ifdef MOGP_GRAM_DEBUG
+#define GRAM_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define GRAM_DBG(a, bit) 0
+#endif
+
 namespace mogp {
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a, int ntiles) {
             }
             for (int t = 0; t < nt; ++t) {
                 const int deg = L.deg[t];
-                if (deg == GT_SKIP || (a.dbg & 2)) continue;
+                if (deg == GT_SKIP || GRAM_DBG(a, 2)) continue;
                 double cu[4], su[4], cw[4], sw[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a, int ntiles) {
             }
         }
         if (a.T > MOGP_TC) __syncthreads();                // the in-place chunks above must be consumed before this buffer is restaged
-        if (!((a.dbg & 1) && acc[0][0] != 12345.678)) gram_store(a, cur, acc, rg, cg);
+        if (!(GRAM_DBG(a, 1) && acc[0][0] != 12345.678)) gram_store(a, cur, acc, rg, cg);
         if (!more) break;
         tile = nxt;
         buf ^= 1;
@@ -620,7 +628,7 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* _
             if (pnt == 0 && which == 0) { L.deg[t] = deg; L.V[t] = V; L.s[t] = s; }
             if (deg == GT_SKIP) continue;
             double f = 1.0;
-            if (a.dbg & 4) { L.cu[t][pnt] = 1.0; L.su[t][pnt] = 0.5; L.cw[t][StripLds<TC>::cs(pnt)] = 0.25; L.sw[t][StripLds<TC>::cs(pnt)] = 2.0; continue; }
+            if (GRAM_DBG(a, 4)) { L.cu[t][pnt] = 1.0; L.su[t][pnt] = 0.5; L.cw[t][StripLds<TC>::cs(pnt)] = 0.25; L.sw[t][StripLds<TC>::cs(pnt)] = 2.0; continue; }
             if (which == 0) {
                 if (deg != GT_GENERAL) {
                     const double pp = L.rowraw[0][pnt] - cr;
@@ -646,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* _
             for (int n = 0; n < 4; ++n) acc[m][n] = 0.0;
         for (int t = 0; t < T; ++t) {
             const int deg = __builtin_amdgcn_readfirstlane(L.deg[t]);
-            if (deg == GT_SKIP || (a.dbg & 2)) continue;
+            if (deg == GT_SKIP || GRAM_DBG(a, 2)) continue;
             const double V = L.V[t], s = L.s[t];
             double cu[4], su[4], cw[4], sw[4];
 #pragma unroll
@@ -664,7 +672,7 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* _
             }
         }
         if (u + 1 < sg.n) { col_commit(b ^ 1); cc = cc_n; hc = hc_n; }
-        if (!((a.dbg & 1) && acc[0][0] != 12345.678)) {
+        if (!(GRAM_DBG(a, 1) && acc[0][0] != 12345.678)) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int64_t at = (int64_t)(sg.r0 + rg * 4 + m) * a.ldo + c0 + cg * 4;
@@ -700,8 +708,12 @@ int launch_gram(const GramArgs& a0, int ntiles, hipStream_t s) {
     if (ntiles <= 0) return 0;
     GramArgs a = a0;
     if (a.W <= 0) a.W = 2 + 3 * a.D;
+#ifdef MOGP_GRAM_DEBUG
     static const int dbg = []() { const char* e = std::getenv("MOGP_GRAM_DBG"); return e ? std::atoi(e) : 0; }();
     a.dbg = dbg;
+#else
+    a.dbg = 0;
+#endif
     int rc = a.phases_ready ? 0 : launch_phase_tables(a.ph, a.xr, a.ldxr, a.nrows, a.xc, a.ldxc, a.ncols, a.table, a.T, a.D, a.C, a.W, s);
     if (rc) return rc;
     static const int ncu = []() { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256; return pr.multiProcessorCount; }();

@@ -170,15 +170,22 @@ int mogp_ctx_create(int device, mogp_ctx** out) {
         // that happened while the dataflow kernel and its chain kernels were running (the z^T z parts of a model with more than 8192 points: 18 KB), they
         // stalled until their waits gave up: every first evaluation above N = 8192 fell back to the stream schedule (tools/r4_first.py; 16 KB pieces do not
         // trigger it, a sleep in front of the copy avoids it).  Found in round 4 when the dataflow default went to 96 tile rows.
-        void* dsrc = nullptr; void* hdst = nullptr;
-        const size_t nbytes = 32u << 20;                     // and at three sizes: the runtime picks its copy path by size (the prediction brings back 33 KB, a fetch 512 MB)
-        if (hipMalloc(&dsrc, nbytes) == hipSuccess && hipHostMalloc(&hdst, nbytes, hipHostMallocDefault) == hipSuccess) {
-            hipError_t e = hipMemsetAsync(dsrc, 0, nbytes, c->st); (void)e;
-            for (size_t nb : {(size_t)64 << 10, (size_t)2 << 20, nbytes}) { e = hipMemcpyAsync(hdst, dsrc, nb, hipMemcpyDeviceToHost, c->st); (void)e; }
-            e = hipStreamSynchronize(c->st); (void)e;
+        // ON THIS CONTEXT'S DEVICE (whatever the calling thread's current device is -- if the set-up is per device, GPUs 1 .. n need it as well), on
+        // that device's null stream (the context's own streams are created with its first model), and the caller's current device is restored.
+        int prev = -1;
+        hipError_t e = hipGetDevice(&prev); (void)e;
+        if (hipSetDevice(device) == hipSuccess) {
+            void* dsrc = nullptr; void* hdst = nullptr;
+            const size_t nbytes = 32u << 20;                     // and at three sizes: the runtime picks its copy path by size (the prediction brings back 33 KB, a fetch 512 MB)
+            if (hipMalloc(&dsrc, nbytes) == hipSuccess && hipHostMalloc(&hdst, nbytes, hipHostMallocDefault) == hipSuccess) {
+                e = hipMemsetAsync(dsrc, 0, nbytes, nullptr); (void)e;
+                for (size_t nb : {(size_t)64 << 10, (size_t)2 << 20, nbytes}) { e = hipMemcpyAsync(hdst, dsrc, nb, hipMemcpyDeviceToHost, nullptr); (void)e; }
+                e = hipStreamSynchronize(nullptr); (void)e;
+            }
+            if (hdst) { e = hipHostFree(hdst); (void)e; }
+            if (dsrc) { e = hipFree(dsrc); (void)e; }
+            if (prev >= 0 && prev != device) { e = hipSetDevice(prev); (void)e; }
         }
-        if (hdst) { hipError_t e = hipHostFree(hdst); (void)e; }
-        if (dsrc) { hipError_t e = hipFree(dsrc); (void)e; }
     }
     *out = c;
     return MOGP_OK;
@@ -778,6 +785,7 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     // every allocation of this evaluation BEFORE the co-operating kernels are enqueued
     if ((rc = pin_ensure(m, (size_t)m->nb + (size_t)((Npad + 3) / 4) + 1 + (size_t)(C * (C + 1) / 2) * m->T * m->Wt + C))) return rc;
     m->k.flow_used = false;                           // (mogp_model_schedule reports the LAST evaluation: set again by spd_potri_flow)
+    m->flow_ran = false;                              // ... and chain_fallback decides from THIS evaluation which schedule to drop, not from an earlier one
     m->k.want_vec = fuse_inverse && !factor_only;     // the dataflow schedule (flow.hip) also forms z = W y and alpha = W^T z
     m->k.vec_y = m->d_y.p; m->k.vec_z = m->d_z.p; m->k.vec_zz = m->d_zz.p; m->k.vec_part = m->d_alpha.p + Npad;
     if (factor_only && !fuse_inverse && m->rhs_job && flow_enabled(m, m->k)) rc = spd_potri_flow(m, m->k, m->rhs_job);      // the prediction: factor + substitute as dataflow

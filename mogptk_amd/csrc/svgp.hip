@@ -79,6 +79,7 @@ int svgp_setup(mogp_model* m, int64_t M, const double* Z, const double* q_mu, co
     m->gemm_ev_used = 0; m->gemm_launches = 0; m->gemm_flops = 0.0;
     build_sym_tiles(sz.off, C, tuu, psuu);
     RC(t.tiles_uu.ensure(tuu.size()));
+    t.tile_key.clear();                                     // the (Z, Z) list is rewritten here: a Titsias evaluation on this handle must not trust its cached lists
     HIP_TRY(hipMemcpyAsync(t.zx.p, sz.xs.data(), (size_t)D * Mpad * sizeof(double), hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(t.tiles_uu.p, tuu.data(), tuu.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
     const unsigned long long big = std::numeric_limits<unsigned long long>::max();

@@ -110,30 +110,25 @@ class Kernel(ParameterHolder):
         return X1, X2
 
     def _check_kernels(self, kernels, length=None):
-        """reference gpr/kernel.py:82-110"""
+        """Normalise what a combinator was given -- one kernel, several, or one list (reference gpr/kernel.py:82-110, same messages) -- into a
+        list of `length` kernels that agree on input and output dimensions; a single kernel is cloned up to `length`."""
         if isinstance(kernels, tuple):
-            if len(kernels) == 1 and isinstance(kernels[0], list):
-                kernels = kernels[0]
-            else:
-                kernels = list(kernels)
-        elif not isinstance(kernels, list):
-            kernels = [kernels]
-        if len(kernels) == 0:
+            items = list(kernels[0]) if (len(kernels) == 1 and isinstance(kernels[0], list)) else list(kernels)
+        else:
+            items = kernels if isinstance(kernels, list) else [kernels]
+        if not items:
             raise ValueError("must pass at least one kernel")
-        elif length is not None and len(kernels) != length:
-            if len(kernels) != 1:
+        if length is not None and len(items) != length:
+            if len(items) > 1:
                 raise ValueError("must pass %d kernels" % length)
-            for i in range(length - len(kernels)):
-                kernels.append(kernels[0].clone())
-        for kernel in kernels:
-            if not issubclass(type(kernel), Kernel):
-                raise ValueError("must pass kernels")
-        if any(kernel.input_dims != kernels[0].input_dims for kernel in kernels[1:]):
+            items = items + [items[0].clone() for _ in range(length - 1)]
+        if not all(isinstance(k, Kernel) for k in items):
+            raise ValueError("must pass kernels")
+        if len({k.input_dims for k in items}) > 1:
             raise ValueError("kernels must have same input dimensions")
-        output_dims = [kernel.output_dims for kernel in kernels if kernel.output_dims is not None]
-        if any(output_dim != output_dims[0] for output_dim in output_dims[1:]):
+        if len({k.output_dims for k in items if k.output_dims is not None}) > 1:
             raise ValueError("multi-output kernels must have same output dimensions")
-        return kernels
+        return items
 
     def clone(self):
         return copy.deepcopy(self)

@@ -219,16 +219,16 @@ class Parameter:
 
     @staticmethod
     def to_transform(lower, upper):
-        """reference parameter.py:220-230"""
-        if lower is not None and upper is not None:
+        """the transform the bounds call for (reference parameter.py:220-230): both -> sigmoid between them, one -> softplus away from it (beta
+        0.1 above a lower bound, -0.1 below an upper one), none -> the raw value is the value"""
+        bounded = (lower is not None, upper is not None)
+        if bounded == (False, False):
+            return None
+        if bounded == (True, True):
             if np.any(upper < lower):
                 raise ValueError("lower limit %s must be lower than upper limit %s" % (lower, upper))
             return Sigmoid(lower=lower, upper=upper)
-        elif lower is not None:
-            return Softplus(lower=lower)
-        elif upper is not None:
-            return Softplus(lower=upper, beta=-0.1)
-        return None
+        return Softplus(lower=lower) if bounded[0] else Softplus(lower=upper, beta=-0.1)
 
     def _fit_shape(self, arr, value, what):
         if arr.ndim != 0:
@@ -293,14 +293,13 @@ class Parameter:
         self.pegged_transform = None
 
     def peg(self, other, transform=None):
-        """reference parameter.py:321-335"""
+        """follow `other` (optionally through `transform`) instead of being trained: reference parameter.py:321-335, same refusals.  Chains of
+        pegged parameters are not allowed, so a gradient has exactly one hop to make (gpr/model.py: accumulate_grad through the peg)."""
         if not isinstance(other, Parameter):
             raise ValueError("parameter must be pegged to other parameter object")
-        elif other.pegged:
+        if other.pegged:
             raise ValueError("cannot peg parameter to another pegged parameter")
-        self.pegged_parameter = other
-        self.pegged_transform = transform
-        self.train = False
+        self.pegged_parameter, self.pegged_transform, self.train = other, transform, False
 
     def log_prior(self):
         """reference parameter.py:337-346.  Priors are out of the hot-path scope (all None in the configs)."""

@@ -22,16 +22,21 @@ from .util import (mean_absolute_error, mean_absolute_percentage_error, symmetri
 logger = logging.getLogger("mogptk")
 
 
-def LoadModel(filename):
+def LoadModel(filename, allow=None, trusted=False):
     """reference mogptk/model.py:62-74.  Reads this package's own checkpoints and -- through mogptk_amd.compat, without the reference
-    installed -- files written by the reference's `Model.save()`."""
+    installed -- files written by the reference's `Model.save()`.
+
+    The reference unpickles whatever the file names.  Here a checkpoint of this package may name classes defined in this package, numpy arrays
+    and a few builtins; a model saved with the caller's own code in it -- a mean function, a Kernel / Likelihood / transformer subclass -- needs
+    `allow=[MyMean, ...]` (exactly those objects are admitted as well), or `trusted=True` (plain pickle.load, the reference's behaviour: only
+    for files you wrote).  The refusal message of a blocked load says which name was blocked."""
     filename += ".npy"
     with open(filename, "rb") as r:
         raw = r.read()
     from . import compat
     if compat.is_reference_checkpoint(raw):
         return compat.load_reference_model(raw)
-    return compat.load_native_model(raw)          # restricted unpickler: classes defined in this package, numpy arrays, a few builtins
+    return compat.load_native_model(raw, allow=allow or (), trusted=trusted)
 
 
 class Exact:
@@ -45,21 +50,17 @@ class Exact:
     """
 
     def __init__(self, variance=None, data_variance=None, jitter=1e-8):
-        self.variance = variance
-        self.data_variance = data_variance
-        self.jitter = jitter
+        self.variance, self.data_variance, self.jitter = variance, data_variance, jitter
 
     def _build(self, kernel, x, y, y_err=None, mean=None):
-        variance = self.variance
-        if variance is None:
-            if kernel.output_dims is not None:
-                variance = [1.0] * kernel.output_dims
-            else:
-                variance = 1.0
-        data_variance = self.data_variance
-        if data_variance is None and y_err is not None:
-            data_variance = y_err ** 2
-        return gpr.Exact(kernel, x, y, variance=variance, data_variance=data_variance, jitter=self.jitter, mean=mean)
+        """the gpr model this choice of inference stands for.  Defaults as the reference's: unit noise variance -- one per channel under a
+        multi-output kernel --, and the data's own error bars as fixed per-point variances when none were given"""
+        channels = kernel.output_dims
+        noise = self.variance if self.variance is not None else (1.0 if channels is None else [1.0] * channels)
+        fixed = self.data_variance
+        if fixed is None and y_err is not None:
+            fixed = np.square(y_err)
+        return gpr.Exact(kernel, x, y, variance=noise, data_variance=fixed, jitter=self.jitter, mean=mean)
 
 
 class Titsias:
@@ -686,38 +687,23 @@ class Model:
         reference mogptk/model.py:608-664.  Returns (X, mu, lower, upper) as lists per channel, or bare arrays
         for a single channel.
         """
-        if X is None:
-            X = self.dataset.get_prediction_data()
-        else:
-            X = self.dataset._format_X(X)
-        x = self._to_kernel_format(X)
-
-        if isinstance(ci, float):
-            ci = (1.0 - ci) / 2.0
-            ci = [ci, 1.0 - ci]
+        X = self.dataset.get_prediction_data() if X is None else self.dataset._format_X(X)
+        if isinstance(ci, float):                       # a coverage -> the two quantile limits around the median
+            ci = [0.5 - 0.5 * ci, 0.5 + 0.5 * ci]
         if ci is not None:
             ci = [max(0.0, ci[0]), min(1.0, ci[1])]
+        stacked = self.gpr.predict_y(self._to_kernel_format(X), ci, sigma=sigma, n=n)        # (mean, lower, upper), channels stacked in order
 
-        mu, lower, upper = self.gpr.predict_y(x, ci, sigma=sigma, n=n)
-
-        i = 0
-        Mu, Lower, Upper = [], [], []
-        for j in range(self.dataset.get_output_dims()):
-            N = X[j].shape[0]
-            Mu.append(np.squeeze(mu[i:i + N]))
-            Lower.append(np.squeeze(lower[i:i + N]))
-            Upper.append(np.squeeze(upper[i:i + N]))
-            i += N
-
-        if not transformed:
-            for j in range(self.dataset.get_output_dims()):
-                Mu[j] = self.dataset[j].Y_transformer.backward(Mu[j], X[j])
-                Lower[j] = self.dataset[j].Y_transformer.backward(Lower[j], X[j])
-                Upper[j] = self.dataset[j].Y_transformer.backward(Upper[j], X[j])
-
+        edges = np.cumsum([0] + [Xj.shape[0] for Xj in X])
+        per_channel = []                                 # [channel] -> [mean, lower, upper]
+        for j, Xj in enumerate(X):
+            undo = None if transformed else self.dataset[j].Y_transformer.backward
+            parts = [np.squeeze(v[edges[j]:edges[j + 1]]) for v in stacked]
+            per_channel.append(parts if undo is None else [undo(v, Xj) for v in parts])
         if len(self.dataset) == 1:
-            return X[0], Mu[0], Lower[0], Upper[0]
-        return X, Mu, Lower, Upper
+            return (X[0],) + tuple(per_channel[0])
+        mu, lower, upper = ([c[k] for c in per_channel] for k in range(3))
+        return X, mu, lower, upper
 
     def sample(self, X=None, n=None, prior=False, transformed=False):
         """Draws of y at X (the behaviour of reference mogptk/model.py:692-734; the posterior's full covariance comes from the device).  As in

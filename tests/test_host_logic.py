@@ -991,3 +991,49 @@ def test_checkpoint_loaders_refuse_dotted_names_and_module_prefix_tricks(tmp_pat
     m2 = mogptk_amd.LoadModel(path)
     for a, b in zip(m.gpr.parameters(), m2.gpr.parameters()):
         assert np.array_equal(a.data, b.data)
+
+
+class _UserMean:
+    """a caller's own mean function: lives in the test module, not in the package"""
+
+    def __init__(self, slope):
+        self.slope = slope
+
+    def __call__(self, X):
+        return self.slope * np.asarray(X)[:, -1]
+
+
+class _Outer:
+    class NestedMean(_UserMean):
+        pass
+
+
+def test_checkpoint_with_user_code_needs_an_opt_in(tmp_path):
+    """a model saved with the caller's own mean function names the caller's module.  The restricted loader refuses it with a
+    message that names the opt-in; LoadModel(allow=[...]) admits exactly that class (nested classes too), trusted=True is plain pickle.load;
+    a package merely NAMED like this one ('mogptk_amd_x') is not this one."""
+    import io
+    import pickle
+    import mogptk_amd
+    from mogptk_amd import compat
+    rng = np.random.default_rng(1)
+    x = np.sort(rng.uniform(0, 10, 30))
+    for mean in (_UserMean(0.3), _Outer.NestedMean(0.3)):
+        m = mogptk_amd.SM(mogptk_amd.Data(x, np.sin(x) + 0.3 * x), Q=1, mean=mean)
+        path = str(tmp_path / "user_mean")
+        m.save(path)
+        with pytest.raises(pickle.UnpicklingError) as e:
+            mogptk_amd.LoadModel(path)
+        assert "allow=" in str(e.value) and "trusted=True" in str(e.value) and type(mean).__name__ in str(e.value)
+        for kw in (dict(allow=[type(mean)]), dict(trusted=True)):
+            m2 = mogptk_amd.LoadModel(path, **kw)
+            assert type(m2.gpr.mean) is type(mean) and m2.gpr.mean.slope == 0.3
+            for a, b in zip(m.gpr.parameters(), m2.gpr.parameters()):
+                assert np.array_equal(a.data, b.data)
+    with pytest.raises(pickle.UnpicklingError):                     # allow= admits the named object only
+        mogptk_amd.LoadModel(path, allow=[_UserMean])
+    assert not compat._in_package("mogptk_amd_x") and compat._in_package("mogptk_amd.gpr.kernel") and compat._in_package("mogptk_amd")
+    # a function of the package that is not on the short list is not callable from a checkpoint
+    raw = pickle.dumps(compat.is_reference_checkpoint)
+    with pytest.raises(pickle.UnpicklingError):
+        compat._NativeUnpickler(io.BytesIO(raw)).load()
