@@ -715,7 +715,6 @@ class TableDeviceLean(TableDevice):
     chunk = 256
 
     def eval(self, noise_var, jitter, grad=True, data_var=None):
-        from scipy.linalg import lapack
         N, C, D, T = self.N, self.C, self.D, self.T
         c = self.X[:, 0].astype(np.int64)
         if np.any(np.diff(c) < 0):
@@ -737,20 +736,44 @@ class TableDeviceLean(TableDevice):
         d = K[idx, idx] + np.asarray(noise_var)[c] + (0.0 if data_var is None else np.asarray(data_var))
         jit = jitter * np.mean(d)
         K[idx, idx] = d + jit
-        # K is C-ordered with its lower triangle filled: K.T is the Fortran-ordered matrix with its UPPER triangle filled
-        U, info = lapack.dpotrf(K.T, lower=0, clean=0, overwrite_a=1)
-        if info != 0:
-            raise np.linalg.LinAlgError("dpotrf info=%d" % info)
-        assert np.shares_memory(U, K)
-        logdet_half = float(np.sum(np.log(K[idx, idx])))
-        alpha, info = lapack.dpotrs(U, self.y, lower=0)
-        lml = -0.5 * N * np.log(TWO_PI) - logdet_half - 0.5 * (self.y.T @ alpha).item()
-        if not grad:
-            return dict(lml=lml, moments=None, diagG=None, trG=0.0, jitter_abs=jit)
-        Ui, info = lapack.dpotri(U, lower=0, overwrite_c=1)              # lower triangle of K (C order) now holds Kj^-1
-        if info != 0:
-            raise np.linalg.LinAlgError("dpotri info=%d" % info)
-        assert np.shares_memory(Ui, K)
+        # LAPACK through torch's CPU build (MKL: what the reference itself factors with, gpr/model.py:246) when torch is there, scipy's otherwise.
+        # (scipy 1.15's bundled OpenBLAS 0.3.28 returns dpotrf info = 16545 for THIS matrix at N = 32768 -- a positive definite matrix that MKL, the
+        # device and OpenBLAS itself at N = 4096 factor without complaint; a random diagonally dominant matrix of the same size passes.)
+        try:
+            import torch
+        except ImportError:
+            torch = None
+        if torch is not None:
+            Kt = torch.from_numpy(K)
+            L, info = torch.linalg.cholesky_ex(Kt)                       # reads the lower triangle only
+            if int(info) != 0:
+                raise np.linalg.LinAlgError("cholesky info=%d" % int(info))
+            del Kt
+            logdet_half = float(torch.log(torch.diagonal(L)).sum())
+            alpha = torch.cholesky_solve(torch.from_numpy(self.y), L).numpy()
+            lml = -0.5 * N * np.log(TWO_PI) - logdet_half - 0.5 * (self.y.T @ alpha).item()
+            if not grad:
+                return dict(lml=lml, moments=None, diagG=None, trG=0.0, jitter_abs=jit)
+            K = None
+            Ki = torch.cholesky_inverse(L)                               # full symmetric Kj^-1
+            del L
+            K = Ki.numpy()
+        else:
+            from scipy.linalg import lapack
+            # K is C-ordered with its lower triangle filled: K.T is the Fortran-ordered matrix with its UPPER triangle filled
+            U, info = lapack.dpotrf(K.T, lower=0, clean=0, overwrite_a=1)
+            if info != 0:
+                raise np.linalg.LinAlgError("dpotrf info=%d" % info)
+            assert np.shares_memory(U, K)
+            logdet_half = float(np.sum(np.log(K[idx, idx])))
+            alpha, info = lapack.dpotrs(U, self.y, lower=0)
+            lml = -0.5 * N * np.log(TWO_PI) - logdet_half - 0.5 * (self.y.T @ alpha).item()
+            if not grad:
+                return dict(lml=lml, moments=None, diagG=None, trG=0.0, jitter_abs=jit)
+            Ui, info = lapack.dpotri(U, lower=0, overwrite_c=1)              # lower triangle of K (C order) now holds Kj^-1
+            if info != 0:
+                raise np.linalg.LinAlgError("dpotri info=%d" % info)
+            assert np.shares_memory(Ui, K)
         for i in range(C):                                               # the diagonal channel blocks are read as full symmetric blocks
             B = K[lo[i]:hi[i], lo[i]:hi[i]]
             B[:] = np.tril(B) + np.tril(B, -1).T

@@ -107,6 +107,21 @@ def main():
     gaps = np.concatenate(gaps)
     print("\ngap between consecutive tasks of a workgroup: median %.1f us, mean %.1f us, p95 %.1f us, sum / workgroup %.2f ms"
           % (np.median(gaps), gaps.mean(), np.percentile(gaps, 95), gaps.sum() / nwg / 1e3))
+    # the number that does not depend on where the time stamps of a task begin and end (round 5's kernel signals a tile from inside the NEXT
+    # task's prologue, so "claimed .. signalled" intervals of one workgroup overlap): the time a workgroup spends BETWEEN two k loops
+    kgaps, direct = [], []
+    for g in np.unique(wg):
+        s = (wg == g) & gem
+        o = np.argsort(k0[s])
+        d = k0[s][o][1:] - k1[s][o][:-1]
+        kgaps.append(d)
+        direct.append(d[naps[s][o][1:] == 0])
+    kgaps, direct = np.concatenate(kgaps), np.concatenate(direct)
+    print("between two k loops of a workgroup (stores, look, descriptor, C tile, first operands): median %.1f us, mean %.1f us, p95 %.1f us; "
+          "when the look found something at once (%.1f %% of the tasks): median %.1f us, mean %.1f us"
+          % (np.median(kgaps), kgaps.mean(), np.percentile(kgaps, 95), 100.0 * len(direct) / max(len(kgaps), 1), np.median(direct), direct.mean()))
+    kin = np.clip(k1 - k0, 0.0, None)[gem].sum()
+    print("workgroup slots inside a k loop: %.3f of %d slots x %.0f us" % (kin / (nwg * T), nwg, T))
     return 0
 
 
