@@ -228,6 +228,16 @@ int  mogp_stage_ms(mogp_model* m, double* ms, int64_t* gemm_launches, double* ge
 #define MOGP_SCHED_CHAIN_FELL_BACK     8   /* a chain kernel timed out once: launch-per-step chain from then on */
 int  mogp_model_schedule(mogp_model* m, int* flags);
 
+/* Measurement mode for the dataflow kernel (no counterpart in the reference: it has no kernels to profile).  A counter-collecting profiler
+ * (rocprofv3 --pmc) serialises dispatches, and the dataflow kernel normally CO-OPERATES with the chain kernels that factor the diagonal blocks,
+ * so under such a profiler an evaluation falls back to streams of launches and the kernel that does the N^3 work is never counted.  With
+ * on = 1, the following mogp_exact_eval(MOGP_EVAL_GRAD) calls of this model launch the dataflow kernel ALONE on a replay plan: the chain
+ * kernels' counters are preset, their results (the W_KK = L_KK^-1 blocks) are the ones the last completed evaluation left in place, and the two
+ * products the private stream normally runs are ordinary tile tasks.  Same Gram, same tile products, same inverse (mogp_model_fetch(which = 1)
+ * returns the same Kj^-1 -- tools/flow_replay.py checks it); the log-determinant part of the returned LML is NOT recomputed, so the value is
+ * the previous evaluation's: use the mode for measurement only.  Requires a completed gradient evaluation on this model.  on = 0: back to normal. */
+int  mogp_model_flow_replay(mogp_model* m, int on);
+
 /* The fused factorisation + inversion behind mogp_exact_eval(MOGP_EVAL_GRAD) (reference gpr/model.py:242-246 and the O(N^3) solves of its
  * autograd backward, :291) runs as a static graph of 128 x 128 tile products inside ONE resident kernel (csrc/flow.hip).  This call returns
  * that graph for a matrix of nb tile rows as numbers -- no device work, callable without a GPU -- so that tests can replay it on the CPU

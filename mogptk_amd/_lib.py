@@ -78,6 +78,7 @@ SIGNATURES = {
     "mogp_stage_ms": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_i64p, c_dp]),
     "mogp_model_fetch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_dp]),
     "mogp_model_schedule": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
+    "mogp_model_flow_replay": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "mogp_flow_plan": (ctypes.c_int, [ctypes.c_int, c_i64p, ctypes.c_int64, c_i64p]),
     "mogp_flow_plan_rhs": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_i64p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     "mogp_flow_trace": (ctypes.c_int, [ctypes.c_void_p, c_i64p, ctypes.c_int64, c_i64p]),
@@ -474,6 +475,10 @@ class ExactHandle:
         f = ctypes.c_int(0)
         check(lib().mogp_model_schedule(self._h, ctypes.byref(f)))
         return dict(dataflow=bool(f.value & 1), chain_kernel=bool(f.value & 2), dataflow_fell_back=bool(f.value & 4), chain_fell_back=bool(f.value & 8))
+
+    def flow_replay(self, on):
+        """measurement mode (mogp_model_flow_replay): the next gradient evaluations run the dataflow kernel alone on the replay plan"""
+        check(lib().mogp_model_flow_replay(self._h, 1 if on else 0))
 
     def inverse_fraction(self):
         """fraction of the lower tiles of Kj^-1 the last gradient evaluation formed (1.0 = all; see include/mogp_hip.h)"""

@@ -172,6 +172,7 @@ struct FlowArgs {
     int nhi;                          // queues below this index always hold a task per workgroup (claimed at the next look after one was taken)
     int claim_one;                    // nothing ready: take from ONE queue per look (the highest priority with a free slot) instead of from all
     int refill;                       // a taken eager slot is refilled at once (0: only when the workgroup finds nothing ready)
+    int refill_from;                  // k_flow2: a task taken from a fetch-add queue with at least this index is replaced at once (claim + descriptor under the tile's prologue)
     const double* vy; double* vz; double* vzz; double* vpart;         // z = W y and alpha = W^T z as tasks (null: those tasks only count)
     int64_t npad;
     unsigned long long* info;
@@ -436,9 +437,14 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
 // vmcnt(0) through the builtin, not inline asm: the compiler's wait-count pass reads it and knows nothing is in flight behind it (an asm wait is
 // invisible to it -- it then keeps "pending" stores on its books across the loop's back edges and answers with vmcnt(0) at the next merge)
 #define FL_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)        // gfx9 encoding: vmcnt = 0, expcnt = 7, lgkmcnt = 15 (not waited for)
-#define FL2_LDS_BYTES (FL_LDS_DOUBLES * 8 + 16 + 64 * FL2_SLOT_INTS * 4)
+#define FL2_LDS_BYTES (FL_LDS_DOUBLES * 8 + 16 + FL2_SLOT_INTS * 4 + 64 * FL2_SLOT_INTS * 4)     // tile operands, pick word, current descriptor, 64 slots
 static_assert(sizeof(FlowTask) == FL2_SLOT_INTS * 4, "a slot holds one descriptor");
 static_assert(2 * FL2_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+
+// byte address inside the workgroup's LDS of a pointer into a __shared__ array (what M0 takes for an LDS-DMA load)
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
+}
 
 struct FlowOwed {                      // what a workgroup still owes for the tile whose stores are draining
     unsigned s0, s1;                   // its counters (FLOW_NOSIG: none)
@@ -452,10 +458,10 @@ __device__ __forceinline__ void flow_pay(const FlowArgs& g, FlowOwed& o) {      
 
 // flow_tile without its epilogue: the accumulators stay in registers (the caller stores them: flow_store), and the PREVIOUS tile's counters are
 // bumped here, behind the first LDS barrier -- every wave has waited for vmcnt(0) (its own stores of that tile included) to fill the first block
-template <int AKM, int BKM>
+template <int AKM, int BKM, typename Hook>
 __device__ __forceinline__ void flow_compute(const double* Ap, const double* Bp, const double* Cp, const int64_t ld, const int kt, const bool fresh,
                                              const double alpha, double* gemm_lds, d4_t (&acc)[FL_WTM][FL_WTN], const FlowArgs& g, FlowOwed& owed,
-                                             unsigned long long* tr) {
+                                             unsigned long long* tr, Hook&& after_first_wait) {
     constexpr int WTM = FL_WTM, WTN = FL_WTN, NWJ = FL_NWJ, NWI = FL_NWI, NT = FL_NT;
     constexpr int TMR = MOGP_TILE, TNC = MOGP_TILE, COLK_A = FL_COLK, COLK_B = FL_COLK, OPER_A = FL_OPER, OPER_B = FL_OPER;
     constexpr int EPT_A = TMR * FL_BK / NT, EPT_B = TNC * FL_BK / NT;
@@ -522,6 +528,7 @@ __device__ __forceinline__ void flow_compute(const double* Ap, const double* Bp,
     };
     load_block(0);
     FL_VMCNT0();     // the first block is here -- and so is everything this wave had in flight: the previous tile's stores
+    after_first_wait();                                  // (the replacement claim issued at the top of the task is back as well: its descriptor's copy starts here)
     write_block(0);
     load_block(min(1, kt - 1));
     FL_LDS_BARRIER();
@@ -585,8 +592,9 @@ static_assert(FL2_STORES_PER_LANE == 32, "flow_requests_wait counts the stores b
 
 __global__ __launch_bounds__(FL_NT, 4) void k_flow2(FlowArgs g) {
     extern __shared__ __attribute__((aligned(16))) double gemm_lds[];
-    int* pick = reinterpret_cast<int*>(gemm_lds + FL_LDS_DOUBLES);     // [0] the task (or -2 done, -3 error, -4 "nothing at hand: drain and signal first"), [1] the lane whose slot holds its descriptor
-    int* slots = pick + 4;                                             // [64][16]: wave 0's lanes, one descriptor each
+    int* pick = reinterpret_cast<int*>(gemm_lds + FL_LDS_DOUBLES);     // [0] the task (or -2 done, -3 error, -4 "nothing at hand: drain and signal first"), [1] the lane that held it
+    int* cur = pick + 4;                                               // [16]: the descriptor of the task about to run (copied out of its lane's slot, which may be refilled at once)
+    int* slots = cur + FL2_SLOT_INTS;                                  // [64][16]: wave 0's lanes, one descriptor each
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     unsigned* heads = g.flags + g.base_heads;
@@ -706,6 +714,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow2(FlowArgs g) {
                     }
                 }
             }
+            if (res >= 0 && lane < FL2_SLOT_INTS) cur[lane] = slots[FL2_SLOT_INTS * src + lane];
             if (lane == 0) {
                 pick[0] = res; pick[1] = src;
                 if (res >= 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ONE buffer_inv sc1 behind the satisfied counters (nothing of this wave's is in flight here)
@@ -720,7 +729,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow2(FlowArgs g) {
         // ================= a chain of tasks: each one's stores drain under the next one's first loads =====================================
         for (;;) {
             idle = 0;
-            const int* sd = slots + FL2_SLOT_INTS * __builtin_amdgcn_readfirstlane(pick[1]);
+            const int* sd = cur;
             const unsigned w0 = (unsigned)__builtin_amdgcn_readfirstlane(sd[0]), w1 = (unsigned)__builtin_amdgcn_readfirstlane(sd[1]),
                            w2 = (unsigned)__builtin_amdgcn_readfirstlane(sd[2]), w3 = (unsigned)__builtin_amdgcn_readfirstlane(sd[3]),
                            w4 = (unsigned)__builtin_amdgcn_readfirstlane(sd[4]);
@@ -754,12 +763,34 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow2(FlowArgs g) {
                 owed.s0 = sg0; owed.s1 = sg1; owed.tr = tr;
                 break;                                                 // -> drain, pay, the long way
             }
+            // ---- a replacement for the task just taken (fetch-add queues from refill_from on: the backlog, where the next task is ready long
+            // before anybody gets to it): claimed NOW, its descriptor copied into the lane's slot by an LDS-DMA load issued behind the tile's first
+            // wait -- both round trips ride under the prologue's own.  At the end of this tile wave 0 then HOLDS a task whose counters it can ask for
+            // in front of the stores; without it the short look found nothing (what a workgroup keeps holding are the tasks that are NOT ready)
+            // and every task went the long way: 21 us between two k loops against round 4's 20.
+            const int srcl = __builtin_amdgcn_readfirstlane(pick[1]);
+            int hh = -1;
+            const bool refill = wave == 0 && lane == srcl && is_eager && myq >= g.refill_from && !exhausted && pend < 0 &&
+                                (ti - qbase) + 2 * (int)gridDim.x < qsize;          // (near the end of a queue a task held by a busy workgroup is a task an idle one cannot take)
+            if (refill) hh = (int)__hip_atomic_fetch_add(heads + myq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            auto after_first_wait = [&]() {
+                if (wave != 0) return;
+                if (refill) { if (hh < qsize) pend = hh; else { exhausted = true; hh = -1; } }
+                const int hs = __shfl(hh, srcl, 64), qb = __shfl(qbase, srcl, 64);
+                if (hs >= 0 && lane < 4) {                          // 4 lanes x 16 bytes: LDS destination = M0 + lane * 16 (wave-uniform base), source per lane
+                    const char* gsrc = reinterpret_cast<const char*>(g.tasks + qb + hs) + 16 * lane;
+                    const unsigned ldst = lds_address(slots + FL2_SLOT_INTS * srcl);
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
+                }
+            };
             d4_t acc[FL_WTM][FL_WTN];
             if (var & 16) __builtin_amdgcn_s_setprio(2);
             switch (var & 3) {
-                case 0: flow_compute<0, 0>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, acc, g, owed, tr); break;
-                case 1: flow_compute<0, 1>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, acc, g, owed, tr); break;
-                default: flow_compute<1, 1>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, acc, g, owed, tr); break;
+                case 0: flow_compute<0, 0>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, acc, g, owed, tr, after_first_wait); break;
+                case 1: flow_compute<0, 1>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, acc, g, owed, tr, after_first_wait); break;
+                default: flow_compute<1, 1>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, acc, g, owed, tr, after_first_wait); break;
             }
             if (var & 16) __builtin_amdgcn_s_setprio(0);
             owed.s0 = sg0; owed.s1 = sg1; owed.tr = tr;
@@ -804,6 +835,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow2(FlowArgs g) {
                 if (!mlost && cand) {
                     if (!take(__ffsll((long long)cand) - 1, h, mready, res, src)) res = -4;
                 }
+                if (res >= 0 && lane < FL2_SLOT_INTS) cur[lane] = slots[FL2_SLOT_INTS * src + lane];
                 if (lane == 0) {
                     pick[0] = res; pick[1] = src;
                     // the agent acquire behind the satisfied counters WITHOUT the s_waitcnt vmcnt(0) the fence builtin puts in front of it: the
@@ -838,9 +870,9 @@ enum { Q_LOOK2 = 0, Q_INVCRIT = 1, Q_SEMI = 2 };
 enum { BUF_A = 0, BUF_L = 1, BUF_WT = 2, BUF_WM = 3, BUF_B = 4 };
 }
 
-void flow_build(int nb, int ob, FlowPlan& p, int rhs_nt) {
+void flow_build(int nb, int ob, FlowPlan& p, int rhs_nt, bool replay) {
     p = FlowPlan();
-    p.nb = nb; p.ob = ob; p.rhs_nt = rhs_nt;
+    p.nb = nb; p.ob = ob; p.rhs_nt = rhs_nt; p.replay = replay;
     const int no = (nb + ob - 1) / ob;
     p.nouter = no;
     const uint32_t base_S = 0, base_R = base_S + (uint32_t)nb * nb, base_DG = base_R + (uint32_t)nb * no, base_PN = base_DG + no,
@@ -893,7 +925,10 @@ void flow_build(int nb, int ob, FlowPlan& p, int rhs_nt) {
     // tasks: they run as launches on the private stream between the chain kernels, on 64-row tiles on the reserved CUs as in potri.hip (as
     // 128 x 128 tasks next to the bulk work they took 230 us per block against 140 us there, and the chain phase is where workgroups wait).
     // The mini-panel is 64 x 128 tiles: PN(b, i) of its rows counts two tiles per column tile.
-    auto crit_row = [&](int b, int i) { return i >= k1(b) && i < std::min(nb, k1(b) + ob); };
+    // replay (mogp_model_flow_replay, a measurement mode): those two products ARE tasks -- 128 x 128 like everything else --, at the head of the
+    // critical queue, and the host presets the chain kernels' counters: with W_KK left in place by an earlier evaluation the dataflow kernel then
+    // runs the whole evaluation ALONE, which is what a serialising profiler (rocprofv3 --pmc) needs to count its traffic.
+    auto crit_row = [&](int b, int i) { return !replay && i >= k1(b) && i < std::min(nb, k1(b) + ob); };
     auto pn_need = [&](int b, int i) { return (unsigned)((crit_row(b, i) ? 2 : 1) * nk(b)); };
     // panel tile (b, i, c): L[i][k0 + c] = sum_{cc <= c} A[i][k0 + cc] W_bb[c][cc]^T
     auto panel = [&](int b, int i, int c, bool prio) {
@@ -1003,6 +1038,10 @@ void flow_build(int nb, int ob, FlowPlan& p, int rhs_nt) {
         c.t1_sig_base = PN(b, a0); c.t1_sig_per_row = 2u * (uint32_t)nk(b);
         // the next-diagonal update is the LAST update of block b + 1's diagonal block: the b earlier ones (dataflow tasks) first
         if (a1 > a0) { const int n1 = a1 - a0; c.t2_widx = DG(b + 1); c.t2_wval = (uint32_t)(n1 * (n1 + 1) / 2 * b); }
+        if (replay) {
+            for (int i = a0; i < a1; ++i) for (int cc = 0; cc < nk(b); ++cc) q[Q_LOOK2].push_back(panel(b, i, cc, true));
+            for (int i = a0; i < a1; ++i) for (int j = a0; j <= i; ++j) q[Q_LOOK2].push_back(update(b, i, j, true));
+        }
         // Q_LOOK2: what the critical tasks of block b + 1 wait for
         for (int i = a1; i < a2; ++i) for (int cc = 0; cc < nk(b); ++cc) q[Q_LOOK2].push_back(panel(b, i, cc, true));
         for (int i = a1; i < a2; ++i) for (int j = a0; j < a1; ++j) q[Q_LOOK2].push_back(update(b, i, j, true));
@@ -1110,12 +1149,13 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     if ((rc = w.Lm.ensure((size_t)ld * ld))) return rc;
     if (!rhs && (rc = w.Wt.ensure((size_t)ld * ld))) return rc;
     // two plans per system: the gradient's (factorisation + inversion) and the prediction's (factorisation + substitution of right-hand sides)
-    FlowPlan& plan = rhs ? w.flow_rhs : w.flow;
-    DevBuf<FlowTask>& d_tasks = rhs ? w.flow_tasks_rhs : w.flow_tasks;
-    DevBuf<int>& d_qmeta = rhs ? w.flow_qmeta_rhs : w.flow_qmeta;
+    const bool replay = m->replay_flow && !rhs && &w == &m->k;        // measurement mode: the dataflow kernel alone on the replay plan
+    FlowPlan& plan = rhs ? w.flow_rhs : replay ? w.flow_replay : w.flow;
+    DevBuf<FlowTask>& d_tasks = rhs ? w.flow_tasks_rhs : replay ? w.flow_tasks_replay : w.flow_tasks;
+    DevBuf<int>& d_qmeta = rhs ? w.flow_qmeta_rhs : replay ? w.flow_qmeta_replay : w.flow_qmeta;
     const int rhs_nt = rhs ? rhs->nt : 0;
     if (plan.nb != nb || plan.ob != ob || plan.rhs_nt != rhs_nt) {
-        flow_build(nb, ob, plan, rhs_nt);
+        flow_build(nb, ob, plan, rhs_nt, replay);
         if ((rc = d_tasks.ensure(plan.tasks.size()))) return rc;
         if ((rc = d_qmeta.ensure(2 * FLOW_MAXQ))) return rc;
         int qm[2 * FLOW_MAXQ] = {0};
@@ -1131,6 +1171,12 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     if ((rc = w.chain_flags.ensure((size_t)(nouter + 1) * MOGP_CHAIN_FLAGS))) return rc;
     HIP_TRY(hipMemsetAsync(w.chain_flags.p, 0, (size_t)(nouter + 1) * MOGP_CHAIN_FLAGS * sizeof(unsigned), crit));
     HIP_TRY(hipMemsetAsync(w.flow_flags.p, 0, (size_t)p.nflags * sizeof(unsigned), crit));
+    if (replay) {                                        // every chain kernel "has finished": W_KK is what the last evaluation left in Wm's diagonal blocks
+        std::vector<unsigned> preset((size_t)p.nflags, 0u);
+        for (const FlowPlan::Chain& c : p.chain) preset[c.done_idx] = c.expect;
+        HIP_TRY(hipMemcpyAsync(w.flow_flags.p, preset.data(), preset.size() * sizeof(unsigned), hipMemcpyHostToDevice, crit));
+        HIP_TRY(hipStreamSynchronize(crit));
+    }
     if (!rhs && w.want_vec && w.vec_zz) HIP_TRY(hipMemsetAsync(w.vec_zz, 0, (size_t)((ld + 3) / 4) * sizeof(double), crit));   // the tile rows' z^T z parts land in the first nb entries
     static const bool want_trace = std::getenv("MOGP_FLOW_TRACE") && std::atoi(std::getenv("MOGP_FLOW_TRACE")) != 0;
     if (want_trace) {
@@ -1162,6 +1208,7 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     g.npad = ld;
     { const char* e = std::getenv("MOGP_FLOW_REFILL"); g.refill = e ? std::atoi(e) : 0; }
     { const char* e = std::getenv("MOGP_FLOW_CLAIM1"); g.claim_one = e ? std::atoi(e) : 0; }
+    { const char* e = std::getenv("MOGP_FLOW_REFILL_FROM"); g.refill_from = e ? std::atoi(e) : 4; }          // k_flow2: queues 0 .. 3 (look-ahead, semi-critical, the inverse's cycle, vectors) are never held ahead; 99: no queue is
     { const char* e = std::getenv("MOGP_FLOW_NHI"); g.nhi = e ? std::atoi(e) : 0; }            // measured 3 / 4 (semi, the inverse cycle, z and alpha looked at by everybody): 10.74-10.79 vs 10.52-10.65 ms
     { const char* e = std::getenv("MOGP_FLOW_NAP"); g.nap_max = e ? (unsigned)std::max(0, std::atoi(e)) : 4u; }
     w.vec_done = false;
@@ -1186,7 +1233,7 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     m->gemm_flops += p.flops;
 
     unsigned* ferr = w.flow_flags.p + p.base_err;        // ONE error word for both kernels: whoever times out first stops the other
-    for (int kb = 0; kb < nouter; ++kb) {
+    for (int kb = 0; kb < nouter && !replay; ++kb) {
         const int k0 = kb * ob, k1 = std::min(k0 + ob, nb), nk = k1 - k0, na = std::min(ob, nb - k1);
         const FlowPlan::Chain& pc = p.chain[kb];
         ChainFlow cf{};
@@ -1223,7 +1270,7 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     // behind the last chain kernel the reserved CUs have nothing left to do while a quarter of the tile work is still queued: a second, small
     // instance of the dataflow kernel on the private stream takes tasks from the same queues until they are empty (MOGP_FLOW_TAIL=0: off)
     static const bool tail_on = !(std::getenv("MOGP_FLOW_TAIL") && std::atoi(std::getenv("MOGP_FLOW_TAIL")) == 0);
-    if (tail_on && m->ctx->ncu_reserved > 0) {
+    if (tail_on && m->ctx->ncu_reserved > 0 && !replay) {
         if (rhs && rhs->ready) HIP_TRY(hipStreamWaitEvent(priv, rhs->ready, 0));
         if (pipe) hipLaunchKernelGGL(k_flow2, dim3(wg_per_cu * m->ctx->ncu_reserved), dim3(FL_NT), FL2_LDS_BYTES, priv, g);
         else hipLaunchKernelGGL(k_flow, dim3(wg_per_cu * m->ctx->ncu_reserved), dim3(FL_NT), FL_LDS_BYTES, priv, g);

@@ -1767,6 +1767,13 @@ int mogp_model_schedule(mogp_model* m, int* flags) {
     return MOGP_OK;
 }
 
+int mogp_model_flow_replay(mogp_model* m, int on) {
+    if (!m) return fail(MOGP_EINVAL, "mogp_model_flow_replay: null model");
+    if (on && !(m->k.Wm.p && m->have_Kinv)) return fail(MOGP_EINVAL, "mogp_model_flow_replay: needs a completed gradient evaluation on this model first (its W_KK blocks are the replay's input)");
+    m->replay_flow = on != 0;
+    return MOGP_OK;
+}
+
 int mogp_shard_stage_ms(mogp_model* m, double* ms) {
     if (!m || !ms) return fail(MOGP_EINVAL, "mogp_shard_stage_ms: bad argument");
     for (int i = 0; i < 4; ++i) ms[i] = m->sh_ms[i];

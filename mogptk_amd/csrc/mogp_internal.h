@@ -237,6 +237,7 @@ struct FlowTask {                      // 64 bytes; static per matrix size
 static_assert(sizeof(FlowTask) == 64, "FlowTask layout");
 struct FlowPlan {
     int nb = 0, ob = 0, nouter = 0, nq = 0, rhs_nt = 0;
+    bool replay = false;               // the measurement plan (flow.hip: flow_build): the private stream's products are tasks too, the chain kernels' counters preset
     std::vector<FlowTask> tasks;       // queue after queue, queues in priority order
     std::vector<FlowTask> folded;      // (scratch of flow_build)
     int qbase[FLOW_MAXQ] = {0}, qsize[FLOW_MAXQ] = {0};
@@ -248,7 +249,7 @@ struct FlowPlan {
     double flops = 0.0;
 };
 // rhs_nt > 0: factorisation + forward substitution of rhs_nt tile rows of right-hand sides X L^T = T (the prediction) instead of the inverse
-void flow_build(int nb, int ob, FlowPlan& p, int rhs_nt = 0);
+void flow_build(int nb, int ob, FlowPlan& p, int rhs_nt = 0, bool replay = false);
 // rows >= N of the padded matrix: identity (lower part)
 int launch_pad_identity(double* A, int64_t ld, int64_t N, int64_t Npad, hipStream_t s);
 // z = W y (W lower triangular), and partial[blk] = sum z^2 over the block's rows

@@ -138,6 +138,9 @@ struct Spd {
     FlowPlan flow;
     DevBuf<FlowTask> flow_tasks;
     DevBuf<int> flow_qmeta;
+    FlowPlan flow_replay;                               // the measurement plan of mogp_model_flow_replay and its device copy
+    DevBuf<FlowTask> flow_tasks_replay;
+    DevBuf<int> flow_qmeta_replay;
     FlowPlan flow_rhs;                                  // the prediction's plan (factorisation + forward substitution of right-hand sides) and its device copy
     DevBuf<FlowTask> flow_tasks_rhs;
     DevBuf<int> flow_qmeta_rhs;
@@ -158,6 +161,7 @@ struct Spd {
         inv_ev.clear(); Wm.release(); Wd.release(); chain_flags.release(); for (auto& b : Pb) b.release();
         Lm.release(); Wt.release(); flow_tasks.release(); flow_qmeta.release(); flow_flags.release(); flow_trace.release(); flow = FlowPlan();
         flow_tasks_rhs.release(); flow_qmeta_rhs.release(); flow_rhs = FlowPlan(); flow_cur = nullptr;
+        flow_tasks_replay.release(); flow_qmeta_replay.release(); flow_replay = FlowPlan();
         levels.clear(); sync_ev.clear();
         A.release(); B.release(); invd.release(); logdet.release();
     }
@@ -298,6 +302,7 @@ struct mogp_model {
     bool have_W = false, have_Kinv = false, kinv_in_A = false, w_in_Wm = false;
     bool flow_ran = false;              // some factorisation of this model has used the dataflow schedule since the last fallback
     const FlowRhs* rhs_job = nullptr;   // set by the prediction around its factorize() call: solve these right-hand sides inside the dataflow schedule
+    bool replay_flow = false;           // mogp_model_flow_replay: the next gradient evaluations run the dataflow kernel ALONE on the measurement plan (no chain kernels)
     bool no_flow = false;               // the dataflow kernel timed out once on this model: stream schedule from now on
     bool no_chain = false;              // the persistent chain kernel timed out once on this model (another process's chain kernel held the reserved CUs): launch-per-step chain from now on
     TitsiasWork* tw = nullptr;
