@@ -28,15 +28,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 TMP = os.environ.get("CFG3_TMP", "/tmp/cfg3_parts")
 C, Q, N = 8, 5, 32768
-FD_SEED, FD_EPS = 3, 1e-4
-
-
-def direction(shapes):
-    """the unit direction tests/test_gpu_parity.py::test_cfg3_size_gradient_is_the_derivative_of_the_lml walks along"""
-    rng = np.random.default_rng(FD_SEED)
-    d = [rng.standard_normal(s) for s in shapes]
-    nrm = np.sqrt(sum(float(np.sum(v * v)) for v in d))
-    return [v / nrm for v in d]
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import cfg3_direction as direction, CFG3_FD_SEED as FD_SEED, CFG3_FD_EPS as FD_EPS     # noqa: E402  (shared with the GPU test)
 
 
 def peak_gb():

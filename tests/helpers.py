@@ -130,3 +130,15 @@ def product_exact(fx, prefix=""):
 def relerr(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+CFG3_FD_SEED, CFG3_FD_EPS = 3, 1e-4
+
+
+def cfg3_direction(shapes):
+    """the unit direction in raw-parameter space along which tests/golden/gen_cfg3.py takes the reference's central difference of its LML at
+    BASELINE.json configs[2] (and tests/test_gpu_parity.py::test_cfg3_size_gradient_is_the_derivative_of_the_lml the device's)"""
+    rng = np.random.default_rng(CFG3_FD_SEED)
+    d = [rng.standard_normal(s) for s in shapes]
+    nrm = np.sqrt(sum(float(np.sum(v * v)) for v in d))
+    return [v / nrm for v in d]
