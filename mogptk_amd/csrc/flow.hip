@@ -172,6 +172,7 @@ struct FlowArgs {
     int nhi;                          // queues below this index always hold a task per workgroup (claimed at the next look after one was taken)
     int claim_one;                    // nothing ready: take from ONE queue per look (the highest priority with a free slot) instead of from all
     int refill;                       // a taken eager slot is refilled at once (0: only when the workgroup finds nothing ready)
+    int fast;                         // k_flow2: 0 = no short look behind the stores (every task the long way: the slot-cached descriptors alone)
     int refill_from;                  // k_flow2: a task taken from a fetch-add queue with at least this index is replaced at once (claim + descriptor under the tile's prologue)
     const double* vy; double* vz; double* vzz; double* vpart;         // z = W y and alpha = W^T z as tasks (null: those tasks only count)
     int64_t npad;
@@ -794,6 +795,10 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow2(FlowArgs g) {
             }
             if (var & 16) __builtin_amdgcn_s_setprio(0);
             owed.s0 = sg0; owed.s1 = sg1; owed.tr = tr;
+            if (!g.fast) {                                             // (measurement switch: the long way after every tile)
+                flow_store(Cp, g.ld, alpha, acc);
+                break;
+            }
             // ---- wave 0 asks for the counters of what it holds NOW, in front of the stores (loads and stores retire in order through vmcnt: the
             // answers are back long before the stores have drained).  Branch-free, executed by every wave (lanes with nothing to ask read the
             // error word), and in inline asm together with the stores: see flow_store.
@@ -1208,7 +1213,8 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     g.npad = ld;
     { const char* e = std::getenv("MOGP_FLOW_REFILL"); g.refill = e ? std::atoi(e) : 0; }
     { const char* e = std::getenv("MOGP_FLOW_CLAIM1"); g.claim_one = e ? std::atoi(e) : 0; }
-    { const char* e = std::getenv("MOGP_FLOW_REFILL_FROM"); g.refill_from = e ? std::atoi(e) : 4; }          // k_flow2: queues 0 .. 3 (look-ahead, semi-critical, the inverse's cycle, vectors) are never held ahead; 99: no queue is
+    { const char* e = std::getenv("MOGP_FLOW_REFILL_FROM"); g.refill_from = e ? std::atoi(e) : 4; }
+    { const char* e = std::getenv("MOGP_FLOW_FAST"); g.fast = e ? std::atoi(e) : 1; }          // k_flow2: queues 0 .. 3 (look-ahead, semi-critical, the inverse's cycle, vectors) are never held ahead; 99: no queue is
     { const char* e = std::getenv("MOGP_FLOW_NHI"); g.nhi = e ? std::atoi(e) : 0; }            // measured 3 / 4 (semi, the inverse cycle, z and alpha looked at by everybody): 10.74-10.79 vs 10.52-10.65 ms
     { const char* e = std::getenv("MOGP_FLOW_NAP"); g.nap_max = e ? (unsigned)std::max(0, std::atoi(e)) : 4u; }
     w.vec_done = false;
