@@ -153,7 +153,11 @@ class Model(ParameterHolder):
 
     def log_prior(self):
         """reference gpr/model.py:268-277"""
-        return sum(p.log_prior() for p in self.parameters())
+        total = 0.0
+        for p in self._parameter_list():
+            if p.prior is not None:
+                total = total + p.log_prior()
+        return total
 
     def forward(self, x=None):
         """reference gpr/model.py:124-125"""

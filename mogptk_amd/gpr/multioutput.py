@@ -12,7 +12,7 @@ import ctypes
 import numpy as np
 
 from .config import config
-from .parameter import Parameter
+from .parameter import Parameter, _STRUCTURE_EPOCH
 from .kernel import Kernel, MultiOutputKernel, term_width, cached_terms
 
 PI = np.pi
@@ -317,6 +317,7 @@ class UncoupledMultiOutputSpectralKernel(MultiOutputSpectralKernel):
         del self.__dict__["weight"]
         self.__dict__["_order"].remove("weight")
         self.__dict__["_order"].insert(0, "weight")
+        _STRUCTURE_EPOCH[0] += 1
         self.weight = Parameter(np.tril(np.ones((output_dims, output_dims))))
         self.weight.num_parameters = int((output_dims * output_dims + output_dims) / 2)
 

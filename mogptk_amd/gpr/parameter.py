@@ -308,6 +308,9 @@ class Parameter:
         raise NotImplementedError("parameter priors are not on the HIP path")
 
 
+_STRUCTURE_EPOCH = [0]
+
+
 class ParameterHolder:
     """Minimal stand-in for torch.nn.Module's parameter registry: attributes that are Parameters (or
     holders, or lists of holders) are enumerated in registration order, like Module.parameters()."""
@@ -329,7 +332,17 @@ class ParameterHolder:
                 order = self.__dict__.setdefault("_order", [])
                 if name not in order:
                     order.append(name)
+                _STRUCTURE_EPOCH[0] += 1            # some holder's registry changed: every cached parameter list is stale
         object.__setattr__(self, name, val)
+
+    def _parameter_list(self):
+        """`list(self.parameters())`, kept until a registry changes anywhere: the training loop asks for it several times per evaluation
+        (zero_grad, log_prior, the optimiser), and the recursive walk was 15 % of the host's share of a configs[1] step"""
+        c = self.__dict__.get("_plist")
+        if c is None or c[0] != _STRUCTURE_EPOCH[0]:
+            c = (_STRUCTURE_EPOCH[0], list(self.parameters()))
+            self.__dict__["_plist"] = c
+        return c[1]
 
     def parameters(self):
         """All Parameters in torch.nn.Module.parameters() order: the holder's own Parameters first (registration
@@ -353,5 +366,5 @@ class ParameterHolder:
                         yield p
 
     def zero_grad(self, set_to_none=True):
-        for p in self.parameters():
+        for p in self._parameter_list():
             p.grad = None if set_to_none else np.zeros_like(p.data)

@@ -52,6 +52,8 @@ def main():
         os.environ["MOGP_FLOW"] = "0"
     loss2 = float(m.loss())
     print("normal evaluation again: loss %.10f (same: %s)" % (loss2, loss2 == loss0))
+    hd.close()                      # before the interpreter tears the library down (under rocprofv3 an implicit teardown at exit crashed in the tool's hooks)
+    m._handle = None
     return 0
 
 
