@@ -299,15 +299,40 @@ def probe_child(name, reps):
                rccl_ranks=seen, rank_sum_ok=(rsum == world * (world + 1) // 2), transport=comm.transport,
                rel_loss=abs(l1 - l0) / abs(l0),
                rel_grad=max(float(np.max(np.abs(b - c)) / np.max(np.abs(c))) for b, c in zip(g1, g0)))
+    if name == "cfg3" and world > 1:
+        # the A/B the exchange was built with switches for (mogp_api.hip:sharded_inverse): the whole panel in ONE message on the critical stream
+        # (rounds 1-4) and the pivot block inverted ONCE, by its owner, with an all-reduce of the factor -- against the default timed above
+        # (two messages, the large one on a communication stream; every rank repeats the 512 x 512 inversion).  Read per evaluation.
+        variants = {}
+        for vname, env in (("one_message", {"MOGP_SHARD_SPLIT": "0"}), ("factor_once", {"MOGP_SHARD_FACTOR_ONCE": "1"})):
+            old_env = {k_: os.environ.get(k_) for k_ in env}
+            os.environ.update(env)
+            try:
+                lv = float(m.loss())
+                dist.barrier(); sync(); t = time.perf_counter()
+                for _ in range(reps):
+                    m.loss()
+                sync(); dist.barrier()
+                variants[vname] = {"ms_sharded": 1e3 * (time.perf_counter() - t) / reps, "rel_loss": abs(lv - l0) / abs(l0)}
+            except Exception as e:
+                variants[vname] = {"error": repr(e)}
+            finally:
+                for k_, v_ in old_env.items():
+                    if v_ is None:
+                        os.environ.pop(k_, None)
+                    else:
+                        os.environ[k_] = v_
+        res["variants"] = variants
     h = getattr(m, "_handle", None)
     if name in ("cfg3", "cfg2") and h is not None:         # where one sharded evaluation spends its time (HIP events, summed over the pivot blocks)
         h.set_profiling(True)
         m.loss()
-        ex, ser, nxt, blk = [float(v) for v in h.shard_stage_ms()]
+        ex, ser, nxt, blk, exc, stall = [float(v) for v in h.shard_stage_ms()]
         h.set_profiling(False)
-        res.update(exchange_ms=ex, serial_ms=ser, next_cols_ms=nxt, bulk_ms=blk,
-                   split_note="critical stream: exchange (pack, all-gather, unpack) + serial (Schur block inversion and panels, repeated on every "
-                              "rank) + next_cols; the rank's share of the bulk update runs on the bulk stream underneath")
+        res.update(exchange_ms=ex, serial_ms=ser, next_cols_ms=nxt, bulk_ms=blk, exchange_comm_stream_ms=exc, wait_for_comm_stream_ms=stall,
+                   split_note="critical stream: exchange (the pivot block's own rows) + serial (Schur block inversion and panels, repeated on every "
+                              "rank) + next_cols; underneath, the rank's share of the bulk update on the bulk stream and the rest of the panel "
+                              "(exchange_comm_stream) on the communication stream -- wait_for_comm_stream is what the critical stream still waited for it")
     if name.startswith("cfg5"):
         res["N"] = 100000 * (world if name == "cfg5_weak" else 1)
     mogptk_amd.use_single_device()
@@ -456,7 +481,7 @@ def sharded_headline(sharded, world):
     mogp_exact_eval_sharded against the same evaluation on one GPU of the same job (`value` beside it is N independent replicas of configs[1])"""
     r = dict((sharded or {}).get("cfg3") or {})
     keys = ("ms_one_gpu", "ms_sharded", "speedup", "evals_per_s_sharded", "rccl_ranks", "rank_sum_ok", "transport", "rel_loss", "rel_grad",
-            "exchange_ms", "serial_ms", "next_cols_ms", "bulk_ms", "error")
+            "exchange_ms", "serial_ms", "next_cols_ms", "bulk_ms", "exchange_comm_stream_ms", "wait_for_comm_stream_ms", "variants", "error")
     out = {"workload": CONFIGS["cfg3"][5], "ranks": world, "scaling": "strong"}
     out.update({k: r[k] for k in keys if k in r})
     if "speedup" in r:

@@ -173,9 +173,11 @@ int  mogp_comm_info(mogp_ctx* ctx, int* kind, int* rank, int* nranks);
  * without a communicator reports (1, 1).  What bench.py prints as `rccl_ranks` (there is no reference counterpart: the reference has no
  * multi-GPU path). */
 int  mogp_comm_selftest(mogp_ctx* ctx, int* ranks_seen, int* rank_sum);
-/* HIP-event times (ms, summed over the pivot blocks) of the last mogp_exact_eval_sharded on this model with profiling on (mogp_set_profiling):
- * ms[0] exchange (pack, all-gather, unpack), ms[1] the part every rank repeats (Schur block inversion and panels), ms[2] the update of the
- * next pivot block's columns (critical stream), ms[3] the rank's share of the bulk update (bulk stream, overlaps the others). */
+/* HIP-event times (ms, summed over the pivot blocks) of the last mogp_exact_eval_sharded on this model with profiling on (mogp_set_profiling), SIX numbers:
+ * ms[0] exchange on the critical stream (pack, all-gather, unpack -- with the split exchange of round 5 only the pivot block's own rows: 2 MB),
+ * ms[1] the part every rank repeats (Schur block inversion and panels), ms[2] the update of the next pivot block's columns (critical stream),
+ * ms[3] the rank's share of the bulk update (bulk stream, overlaps the others), ms[4] the rest of the panel on the communication stream (all-gather
+ * + unpack, underneath the inversion), ms[5] how long the critical stream then still waited for it (0 when MOGP_SHARD_SPLIT=0). */
 int  mogp_shard_stage_ms(mogp_model* m, double* ms);
 /* Fraction of the lower 128 x 128 tiles of Kj^-1 the last mogp_exact_eval(..., MOGP_EVAL_GRAD) formed: the gradient
  * 1/2 sum_ab (alpha_a alpha_b - Kinv_ab) dK_ab/dtheta (reference gpr/model.py:291, autograd through :242-246) reads Kinv only where some term

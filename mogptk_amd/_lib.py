@@ -465,8 +465,9 @@ class ExactHandle:
         return ms, n.value, fl.value
 
     def shard_stage_ms(self):
-        """(exchange, serial, next_cols, bulk) ms of the last profiled sharded evaluation"""
-        ms = np.zeros(4)
+        """(exchange on the critical stream, serial, next_cols, bulk, exchange on the communication stream, the critical stream's wait for it) ms of the
+        last profiled sharded evaluation"""
+        ms = np.zeros(6)
         check(lib().mogp_shard_stage_ms(self._h, _dp(ms)))
         return ms
 

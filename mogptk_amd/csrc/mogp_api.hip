@@ -1103,7 +1103,8 @@ int mogp_model_destroy(mogp_model* m) {
     for (int b = 0; b < 2; ++b) { m->swU[b].release(); m->swUr[b].release(); }
     for (auto e : m->sw_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
     for (auto e : m->sh_prof) { hipError_t r = hipEventDestroy(e); (void)r; }
-    m->d_symv.release(); m->sh_send.release(); m->sh_recv.release();
+    m->d_symv.release(); m->sh_send.release(); m->sh_recv.release(); m->sh_send1.release(); m->sh_recv1.release(); m->sh_fact.release();
+    for (auto e : m->sh_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
     if (m->tw) { m->tw->release(); delete m->tw; m->tw = nullptr; }
     m->oa.release();
     m->d_x.release(); m->d_y.release(); m->d_table.release();
@@ -1591,20 +1592,49 @@ static int sharded_inverse(mogp_model* m, const double* noise_var, const double*
     if (jitter_abs) *jitter_abs = m->sh_jabs;
     const int nblocks = sweep_nblocks(m->k);
     m->sh_prof_blocks = 0;
+    // Round 5: the exchange of a pivot block in TWO messages.  The serial part (Schur block inversion, 0.3 ms, repeated on every rank) needs the pivot
+    // block's own tile rows only: 4 tiles of 128 x 512, 2 MB.  The rest of the panel -- the column part below the block and the row part left of it,
+    // up to 134 MB at configs[2] -- is needed by the panel products behind it.  So: small message on the critical stream, large message on a
+    // communication stream of its own (the context's third stream, idle in this schedule) UNDERNEATH the serial part; the critical stream waits
+    // for it only where the panels start.  Both are collectives of the same communicator issued in the same order on every rank.
+    // MOGP_SHARD_SPLIT=0: one message on the critical stream, as in rounds 1-4.
+    { const char* e = std::getenv("MOGP_SHARD_SPLIT"); m->sh_split = c.n > 1 && m->st3 && !(e && std::atoi(e) == 0); }
+    { const char* e = std::getenv("MOGP_SHARD_FACTOR_ONCE"); m->sh_factor_once = c.n > 1 && e && std::atoi(e) != 0; }
+    const int PEV = 10;                                  // timing events per pivot block
     if (m->profiling) {
-        while ((int)m->sh_prof.size() < 6 * nblocks) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); m->sh_prof.push_back(e); }
+        while ((int)m->sh_prof.size() < PEV * nblocks) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); m->sh_prof.push_back(e); }
         m->sh_prof_blocks = nblocks;
     }
+    while ((int)m->sh_ev.size() < 2 * nblocks) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m->sh_ev.push_back(e); }
+    hipStream_t qc = m->st3;
     for (int kb = 0; kb < nblocks; ++kb) {
-        double *send = nullptr, *recv = nullptr;
         int64_t count = 0;
-        hipEvent_t* pe = m->profiling ? m->sh_prof.data() + 6 * kb : nullptr;
+        hipEvent_t* pe = m->profiling ? m->sh_prof.data() + PEV * kb : nullptr;
         if (pe) HIP_TRY(hipEventRecord(pe[0], m->st));
-        if ((rc = shard_pack(m, m->k, kb, &send, &recv, &count))) return rc;
-        if ((rc = comm_allgather(m->ctx, send, recv, count, m->st))) return rc;       // stream ordered: no host round trip with RCCL
-        if ((rc = shard_unpack(m, m->k, kb))) return rc;
+        if (!m->sh_split) {
+            double *send = nullptr, *recv = nullptr;
+            if ((rc = shard_pack(m, m->k, kb, &send, &recv, &count))) return rc;
+            if ((rc = comm_allgather(m->ctx, send, recv, count, m->st))) return rc;       // stream ordered: no host round trip with RCCL
+            if ((rc = shard_unpack(m, m->k, kb))) return rc;
+            if (pe) HIP_TRY(hipEventRecord(pe[1], m->st));
+            if ((rc = sweep_block(m, m->k, kb, pe ? pe + 2 : nullptr))) return rc;
+            continue;
+        }
+        hipEvent_t packed = m->sh_ev[2 * kb], rest_in = m->sh_ev[2 * kb + 1];
+        int64_t count2 = 0;
+        if ((rc = shard_pack_part(m, m->k, kb, 1, m->sh_send1, m->sh_recv1, &count, m->st))) return rc;
+        if ((rc = shard_pack_part(m, m->k, kb, 2, m->sh_send, m->sh_recv, &count2, m->st))) return rc;     // (both read what the previous block's next-columns update left: this stream)
+        HIP_TRY(hipEventRecord(packed, m->st));
+        if ((rc = comm_allgather(m->ctx, m->sh_send1.p, m->sh_recv1.p, count, m->st))) return rc;
+        if ((rc = shard_unpack_part(m, m->k, kb, 1, m->sh_recv1, m->st))) return rc;
         if (pe) HIP_TRY(hipEventRecord(pe[1], m->st));
-        if ((rc = sweep_block(m, m->k, kb, pe ? pe + 2 : nullptr))) return rc;
+        HIP_TRY(hipStreamWaitEvent(qc, packed, 0));
+        if (pe) HIP_TRY(hipEventRecord(pe[6], qc));
+        if ((rc = comm_allgather(m->ctx, m->sh_send.p, m->sh_recv.p, count2, qc))) return rc;
+        if ((rc = shard_unpack_part(m, m->k, kb, 2, m->sh_recv, qc))) return rc;            // other ranks' rows only: nothing this rank's streams touch
+        if (pe) HIP_TRY(hipEventRecord(pe[7], qc));
+        HIP_TRY(hipEventRecord(rest_in, qc));
+        if ((rc = sweep_block(m, m->k, kb, pe ? pe + 2 : nullptr, rest_in, pe ? pe + 8 : nullptr))) return rc;
     }
     if ((rc = sweep_finish(m, m->k))) return rc;
     if ((rc = sweep_eval_alpha(m))) return rc;                                         // owned-row partial sums of alpha
@@ -1628,13 +1658,19 @@ int mogp_exact_eval_sharded(mogp_model* m, const double* noise_var, const double
     if ((rc = sweep_eval_scalars(m, lml, info))) return sharded_rc(m, rc);             // syncs the stream
     if (m->sh_prof_blocks > 0) {
         for (hipStream_t q : {m->st2, m->st2u}) if (q) HIP_TRY(hipStreamSynchronize(q));
-        double acc4[4] = {0, 0, 0, 0};
+        if (m->st3) HIP_TRY(hipStreamSynchronize(m->st3));
+        double acc6[6] = {0, 0, 0, 0, 0, 0};
         for (int kb = 0; kb < m->sh_prof_blocks; ++kb) {
-            hipEvent_t* pe = m->sh_prof.data() + 6 * kb;
-            const int a_[4] = {0, 1, 2, 4}, b_[4] = {1, 2, 3, 5};       // exchange | serial part (inversion + panels) | next-block columns | bulk
-            for (int i = 0; i < 4; ++i) { float t = 0.f; if (hipEventElapsedTime(&t, pe[a_[i]], pe[b_[i]]) == hipSuccess) acc4[i] += t; }
+            hipEvent_t* pe = m->sh_prof.data() + 10 * kb;
+            // exchange on the critical stream | serial part (inversion + panels) | next-block columns | bulk | exchange on the communication stream | the critical stream's wait for it
+            const int a_[6] = {0, 1, 2, 4, 6, 8}, b_[6] = {1, 2, 3, 5, 7, 9};
+            for (int i = 0; i < 6; ++i) {
+                if (i >= 4 && !m->sh_split) continue;
+                float t = 0.f;
+                if (hipEventElapsedTime(&t, pe[a_[i]], pe[b_[i]]) == hipSuccess) acc6[i] += t;
+            }
         }
-        for (int i = 0; i < 4; ++i) m->sh_ms[i] = acc4[i];
+        for (int i = 0; i < 6; ++i) m->sh_ms[i] = acc6[i];
     }
     double tr = 0.0;
     for (int c = 0; c < C; ++c) tr += diagG[c];
@@ -1776,7 +1812,7 @@ int mogp_model_flow_replay(mogp_model* m, int on) {
 
 int mogp_shard_stage_ms(mogp_model* m, double* ms) {
     if (!m || !ms) return fail(MOGP_EINVAL, "mogp_shard_stage_ms: bad argument");
-    for (int i = 0; i < 4; ++i) ms[i] = m->sh_ms[i];
+    for (int i = 0; i < 6; ++i) ms[i] = m->sh_ms[i];
     return MOGP_OK;
 }
 

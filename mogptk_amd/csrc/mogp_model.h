@@ -262,8 +262,13 @@ struct mogp_model {
     DevBuf<int> d_pair_start_own;
     int own_rank = -1, own_n = 0;       // (rank, nranks) the owned lists were built for
     DevBuf<double> sh_send, sh_recv;
+    DevBuf<double> sh_send1, sh_recv1;  // the pivot block's own rows (the first, small message of a split exchange)
+    DevBuf<double> sh_fact;             // factor-once: [P | log-det parts | pivot report]
+    bool sh_factor_once = false;        // MOGP_SHARD_FACTOR_ONCE, read per sharded evaluation
+    bool sh_split = false;              // the exchange in two messages, the large one on the communication stream (MOGP_SHARD_SPLIT=0: one message)
+    std::vector<hipEvent_t> sh_ev;      // split exchange: per pivot block [packed, rest of the panel in place]
     std::vector<hipEvent_t> sh_prof;    // profiling (mogp_set_profiling) of a sharded evaluation: 6 timing events per pivot block
-    double sh_ms[4] = {0, 0, 0, 0};     // ... summed over the blocks: exchange, serial part, next-block columns, bulk update (mogp_shard_stage_ms)
+    double sh_ms[6] = {0, 0, 0, 0, 0, 0};   // ... summed over the blocks: exchange on the critical stream, serial part, next-block columns, bulk update, exchange on the communication stream, the critical stream's wait for it (mogp_shard_stage_ms)
     int sh_prof_blocks = 0;
     double sh_jabs = 0.0;
     bool sh_dvar = false;
@@ -362,7 +367,7 @@ int spd_lauum(mogp_model* m, Spd& w);
 int spd_sweep(mogp_model* m, Spd& w);
 int sweep_prepare(mogp_model* m, Spd& w);
 int sweep_nblocks(const Spd& w);
-int sweep_block(mogp_model* m, Spd& w, int kb, hipEvent_t* prof = nullptr);   // prof (4 timing events or null): panels ready / next-block columns done (critical stream), bulk start / end
+int sweep_block(mogp_model* m, Spd& w, int kb, hipEvent_t* prof = nullptr, hipEvent_t panel_ready = nullptr, hipEvent_t* stall = nullptr);   // prof (4 timing events or null): panels ready / next-block columns done (critical stream), bulk start / end
 int sweep_finish(mogp_model* m, Spd& w);
 // B (nb*128 rows x ncols, leading dimension ldb, ncols a multiple of 128) <- L^-1 B  (trans: L^-T B) by blocked substitution, in place;
 // L lower triangular nb*128 square with leading dimension ldl, diagonal tiles included (Spd::keep_L).  trsm.hip
@@ -373,5 +378,8 @@ int comm_allgather(mogp_ctx* ctx, const double* send, double* recv, int64_t coun
 int comm_allreduce(mogp_ctx* ctx, double* buf, int64_t count, hipStream_t st);                        // sum, in place
 int shard_pack(mogp_model* m, Spd& w, int kb, double** send, double** recv, int64_t* count);
 int shard_unpack(mogp_model* m, Spd& w, int kb);
+int shard_pack_part(mogp_model* m, Spd& w, int kb, int part, DevBuf<double>& sendb, DevBuf<double>& recvb, int64_t* count, hipStream_t st);
+int shard_unpack_part(mogp_model* m, Spd& w, int kb, int part, DevBuf<double>& recvb, hipStream_t st);
+int shard_factor_bcast(mogp_model* m, Spd& w, Spd& s, int k0, int nk, bool mine, hipStream_t st);
 // w.A (SPD, lower) -> -inverse (lower); w.logdet per tile; failure through m->d_info
 }  // namespace mogp

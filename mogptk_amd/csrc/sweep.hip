@@ -52,7 +52,7 @@ int sweep_nblocks(const Spd& w) { return (w.nb + SW_OB - 1) / SW_OB; }
 
 // one pivot block.  With m->sh_n > 1 (sharded evaluation) the chain (P, panels) is repeated by every rank from the assembled
 // authoritative panel and the rank-Kd update touches only the tile rows this rank owns (row i is owned by rank i % sh_n).
-int sweep_block(mogp_model* m, Spd& w, int kb, hipEvent_t* prof) {
+int sweep_block(mogp_model* m, Spd& w, int kb, hipEvent_t* prof, hipEvent_t panel_ready, hipEvent_t* stall) {
     const int nb = w.nb;
     const int64_t ld = w.Npad;
     const int rm = m->sh_n > 1 ? m->sh_n : 0, rr = m->sh_rank;
@@ -73,14 +73,24 @@ int sweep_block(mogp_model* m, Spd& w, int kb, hipEvent_t* prof) {
     // CUs with 128 KB of LDS free: they find them on the reserved CUs as long as the bulk stream is masked off those (q2 == st2) and the
     // ranks do not share a GPU (external communicator = the test suite's ranks on one device: two such kernels would starve each other).
     const bool chain = chain_enabled(m) && q2 == m->st2 && m->st_priv && m->ctx->comm.kind != MOGP_COMM_EXTERNAL;
-    if (chain) {
+    // MOGP_SHARD_FACTOR_ONCE=1 (an A/B switch): only the rank that owns the pivot block's first tile row inverts the Schur block; the others
+    // contribute zeros to an all-reduce of [P | log-det parts | pivot report] -- "all-gather of panel factors" in BASELINE.json's wording.
+    // Same bits (x + 0), one more collective on the critical stream per block; the default repeats the 0.3 ms inversion on every rank instead.
+    const bool once = rm > 0 && m->sh_factor_once;
+    const bool mine = !once || (k0 % rm) == rr;
+    if (chain && kb == 0) {                              // (also on the ranks that, factoring once, run their first chain kernel at a later block)
+        const int nouter = (nb + SW_OB - 1) / SW_OB;
+        RC(w.chain_flags.ensure((size_t)(nouter + 1) * MOGP_CHAIN_FLAGS));
+        HIP_TRY(hipMemsetAsync(w.chain_flags.p, 0, (size_t)(nouter + 1) * MOGP_CHAIN_FLAGS * sizeof(unsigned), q1));
+    }
+    if (!mine) {
+        HIP_TRY(hipMemsetAsync(s.B.p, 0, (size_t)Kd * Kd * sizeof(double), q1));
+    } else if (chain) {
         const int nouter = (nb + SW_OB - 1) / SW_OB;
         if (s.Wm.n < (size_t)Kd * Kd) {
             RC(s.Wm.ensure((size_t)Kd * Kd));
             HIP_TRY(hipMemsetAsync(s.Wm.p, 0, (size_t)Kd * Kd * sizeof(double), q1));     // the tiles above the diagonal are never written
         }
-        RC(w.chain_flags.ensure((size_t)(nouter + 1) * MOGP_CHAIN_FLAGS));
-        if (kb == 0) HIP_TRY(hipMemsetAsync(w.chain_flags.p, 0, (size_t)(nouter + 1) * MOGP_CHAIN_FLAGS * sizeof(unsigned), q1));
         RC(launch_chain(A, ld, k0, nk, w.invd.p, w.logdet.p, m->d_info.p, 0, s.Wm.p, Kd, w.chain_flags.p + (size_t)kb * MOGP_CHAIN_FLAGS,
                         w.chain_flags.p + (size_t)nouter * MOGP_CHAIN_FLAGS, q1));
         GemmArgs g{};
@@ -95,8 +105,12 @@ int sweep_block(mogp_model* m, Spd& w, int kb, hipEvent_t* prof) {
         RC(spd_trtri(m, s));
         RC(spd_lauum(m, s));
     }
-    RC(launch_symmetrize(s.B.p, Kd, Kd, q1));
+    if (mine) RC(launch_symmetrize(s.B.p, Kd, Kd, q1));
+    if (once) RC(shard_factor_bcast(m, w, s, k0, nk, mine, q1));
     const double* P = s.B.p;
+    if (stall) HIP_TRY(hipEventRecord(stall[0], q1));
+    if (panel_ready) HIP_TRY(hipStreamWaitEvent(q1, panel_ready, 0));        // the rest of the panel (other ranks' rows) arrives on the communication stream
+    if (stall) HIP_TRY(hipEventRecord(stall[1], q1));
     // ---- old panels out, new panels X = U P in place, diagonal block = -P
     double* Uc = m->swU[kb & 1].p;                                                     // [below*128][Kd]
     double* Ur = m->swUr[kb & 1].p;                                                    // [Kd][ld] (first k0*128 columns used)
@@ -170,10 +184,11 @@ int spd_sweep(mogp_model* m, Spd& w) {
 // ---- sharded evaluation: assembling the authoritative panel of pivot block kb with ONE all-gather ------------------------
 // column part: tile rows i >= k0, 128 x Kd each, owner i % P; rank r's rows are first_r + idx * P
 // (grid.y = 8 slabs of 16 rows per tile; 16-byte accesses along the block's columns -- Kd and ld are multiples of 128)
-__global__ __launch_bounds__(256) void k_shard_pack(const double* __restrict__ A, int64_t ld, int k0, int nb, int P, int rank, int64_t Kd, double* __restrict__ send) {
-    const int first = k0 + ((rank - k0 % P) + P) % P;
+__global__ __launch_bounds__(256) void k_shard_pack(const double* __restrict__ A, int64_t ld, int k0, int row_lo, int row_hi, int P, int rank, int64_t Kd,
+                                                    double* __restrict__ send) {
+    const int first = row_lo + ((rank - row_lo % P) + P) % P;
     const int i = first + (int)blockIdx.x * P;
-    if (i >= nb) return;
+    if (i >= row_hi) return;
     const int r0 = 16 * (int)blockIdx.y, kd2 = (int)(Kd >> 1);
     const double* src = A + ((int64_t)i * MOGP_TILE + r0) * ld + (int64_t)k0 * MOGP_TILE;
     double* dst = send + ((int64_t)blockIdx.x * MOGP_TILE + r0) * Kd;
@@ -182,11 +197,12 @@ __global__ __launch_bounds__(256) void k_shard_pack(const double* __restrict__ A
         *reinterpret_cast<double2*>(dst + (int64_t)r * Kd + c) = *reinterpret_cast<const double2*>(src + (int64_t)r * ld + c);
     }
 }
-__global__ __launch_bounds__(256) void k_shard_unpack(double* __restrict__ A, int64_t ld, int k0, int nb, int P, int64_t Kd, int64_t chunk, const double* __restrict__ recv) {
+__global__ __launch_bounds__(256) void k_shard_unpack(double* __restrict__ A, int64_t ld, int k0, int row_lo, int row_hi, int P, int64_t Kd, int64_t chunk,
+                                                      const double* __restrict__ recv) {
     const int r = blockIdx.z;
-    const int first = k0 + ((r - k0 % P) + P) % P;
+    const int first = row_lo + ((r - row_lo % P) + P) % P;
     const int i = first + (int)blockIdx.x * P;
-    if (i >= nb) return;
+    if (i >= row_hi) return;
     const int r0 = 16 * (int)blockIdx.y, kd2 = (int)(Kd >> 1);
     double* dst = A + ((int64_t)i * MOGP_TILE + r0) * ld + (int64_t)k0 * MOGP_TILE;
     const double* src = recv + (int64_t)r * chunk + ((int64_t)blockIdx.x * MOGP_TILE + r0) * Kd;
@@ -194,6 +210,22 @@ __global__ __launch_bounds__(256) void k_shard_unpack(double* __restrict__ A, in
         const int rr = e / kd2, c = 2 * (e - rr * kd2);
         *reinterpret_cast<double2*>(dst + (int64_t)rr * ld + c) = *reinterpret_cast<const double2*>(src + (int64_t)rr * Kd + c);
     }
+}
+
+// factor-once: [P (Kd x Kd) | nk log-det parts | pivot report as a double (0: none, else index + 1)] in one buffer, so that ONE all-reduce carries
+// the owner's result to everybody (the other ranks hold zeros)
+__global__ void k_factor_pack(double* __restrict__ buf, int64_t kd2, const double* __restrict__ logdet, int nk, const unsigned long long* __restrict__ info, int mine) {
+    const int t = threadIdx.x;
+    if (t < nk) buf[kd2 + t] = mine ? logdet[t] : 0.0;
+    if (t == 0) {
+        const unsigned long long v = *info;
+        buf[kd2 + nk] = (mine && v != ~0ull) ? (double)(v + 1ull) : 0.0;
+    }
+}
+__global__ void k_factor_unpack(const double* __restrict__ buf, int64_t kd2, double* __restrict__ logdet, int nk, unsigned long long* __restrict__ info) {
+    const int t = threadIdx.x;
+    if (t < nk) logdet[t] = buf[kd2 + t];
+    if (t == 0 && buf[kd2 + nk] > 0.0) atomicMin(info, (unsigned long long)(buf[kd2 + nk] - 1.0));
 }
 
 // chunk of one rank for pivot block kb: [maxrows column tiles, 128 x Kd each][maxpiv row tiles, 128 x (k0*128) each]
@@ -214,34 +246,80 @@ static ShardGeom shard_geometry(const Spd& w, int kb, int P) {
 }
 static inline int first_owned(int k0, int P, int r) { return k0 + ((r - k0 % P) + P) % P; }
 
-int shard_pack(mogp_model* m, Spd& w, int kb, double** send, double** recv, int64_t* count) {
+// part: 0 = the whole panel in one message (the stage API and MOGP_SHARD_SPLIT=0), 1 = the pivot block's own tile rows (all the serial part
+// needs: 2 MB), 2 = the rest (the column part below the block + the row part left of it: up to 134 MB at configs[2], needed by the panels only)
+static void part_rows(const ShardGeom& g, int nb, int part, int& lo, int& hi) {
+    lo = part == 2 ? g.k1 : g.k0;
+    hi = part == 1 ? g.k1 : nb;
+}
+static int64_t part_chunk(const ShardGeom& g, int nb, int P, int part, int& maxrows, int64_t& rowoff) {
+    int lo, hi;
+    part_rows(g, nb, part, lo, hi);
+    maxrows = (hi - lo + P - 1) / P;
+    rowoff = (int64_t)maxrows * MOGP_TILE * g.Kd;
+    return rowoff + (part == 1 ? 0 : (int64_t)g.maxpiv * MOGP_TILE * g.cols);
+}
+
+int shard_pack_part(mogp_model* m, Spd& w, int kb, int part, DevBuf<double>& sendb, DevBuf<double>& recvb, int64_t* count, hipStream_t st) {
     const int P = m->sh_n;
     const ShardGeom g = shard_geometry(w, kb, P);
-    RC(m->sh_send.ensure((size_t)g.chunk)); RC(m->sh_recv.ensure((size_t)g.chunk * P));
-    hipLaunchKernelGGL(k_shard_pack, dim3(g.maxrows, 8), dim3(256), 0, m->st, w.A.p, w.Npad, g.k0, w.nb, P, m->sh_rank, g.Kd, m->sh_send.p);
-    HIP_TRY(hipGetLastError());
-    if (g.cols > 0) {
+    int maxrows, lo, hi; int64_t rowoff;
+    const int64_t chunk = part_chunk(g, w.nb, P, part, maxrows, rowoff);
+    part_rows(g, w.nb, part, lo, hi);
+    RC(sendb.ensure((size_t)std::max<int64_t>(chunk, 1))); RC(recvb.ensure((size_t)std::max<int64_t>(chunk, 1) * P));
+    *count = chunk;
+    if (maxrows > 0) {
+        hipLaunchKernelGGL(k_shard_pack, dim3(maxrows, 8), dim3(256), 0, st, w.A.p, w.Npad, g.k0, lo, hi, P, m->sh_rank, g.Kd, sendb.p);
+        HIP_TRY(hipGetLastError());
+    }
+    if (part != 1 && g.cols > 0) {
         int idx = 0;
         for (int i = first_owned(g.k0, P, m->sh_rank); i < g.k1; i += P, ++idx)
-            RC(launch_copy2d(m->sh_send.p + g.rowoff + (int64_t)idx * MOGP_TILE * g.cols, g.cols, w.A.p + (int64_t)i * MOGP_TILE * w.Npad, w.Npad,
-                             MOGP_TILE, g.cols, 1.0, m->st));
+            RC(launch_copy2d(sendb.p + rowoff + (int64_t)idx * MOGP_TILE * g.cols, g.cols, w.A.p + (int64_t)i * MOGP_TILE * w.Npad, w.Npad,
+                             MOGP_TILE, g.cols, 1.0, st));
     }
-    *send = m->sh_send.p; *recv = m->sh_recv.p; *count = g.chunk;
     return 0;
 }
 
-int shard_unpack(mogp_model* m, Spd& w, int kb) {
+int shard_unpack_part(mogp_model* m, Spd& w, int kb, int part, DevBuf<double>& recvb, hipStream_t st) {
     const int P = m->sh_n;
     const ShardGeom g = shard_geometry(w, kb, P);
-    hipLaunchKernelGGL(k_shard_unpack, dim3(g.maxrows, 8, P), dim3(256), 0, m->st, w.A.p, w.Npad, g.k0, w.nb, P, g.Kd, g.chunk, m->sh_recv.p);
-    HIP_TRY(hipGetLastError());
-    if (g.cols > 0) {
+    int maxrows, lo, hi; int64_t rowoff;
+    const int64_t chunk = part_chunk(g, w.nb, P, part, maxrows, rowoff);
+    part_rows(g, w.nb, part, lo, hi);
+    if (maxrows > 0) {
+        hipLaunchKernelGGL(k_shard_unpack, dim3(maxrows, 8, P), dim3(256), 0, st, w.A.p, w.Npad, g.k0, lo, hi, P, g.Kd, chunk, recvb.p);
+        HIP_TRY(hipGetLastError());
+    }
+    if (part != 1 && g.cols > 0) {
         for (int i = g.k0; i < g.k1; ++i) {
             const int r = i % P, idx = (i - first_owned(g.k0, P, r)) / P;
-            RC(launch_copy2d(w.A.p + (int64_t)i * MOGP_TILE * w.Npad, w.Npad, m->sh_recv.p + (int64_t)r * g.chunk + g.rowoff + (int64_t)idx * MOGP_TILE * g.cols,
-                             g.cols, MOGP_TILE, g.cols, 1.0, m->st));
+            RC(launch_copy2d(w.A.p + (int64_t)i * MOGP_TILE * w.Npad, w.Npad, recvb.p + (int64_t)r * chunk + rowoff + (int64_t)idx * MOGP_TILE * g.cols,
+                             g.cols, MOGP_TILE, g.cols, 1.0, st));
         }
     }
+    return 0;
+}
+
+int shard_pack(mogp_model* m, Spd& w, int kb, double** send, double** recv, int64_t* count) {
+    RC(shard_pack_part(m, w, kb, 0, m->sh_send, m->sh_recv, count, m->st));
+    *send = m->sh_send.p; *recv = m->sh_recv.p;
+    return 0;
+}
+
+int shard_unpack(mogp_model* m, Spd& w, int kb) { return shard_unpack_part(m, w, kb, 0, m->sh_recv, m->st); }
+
+// factor-once (sweep_block): the owner's P, log-det parts and pivot report to every rank by ONE all-reduce (everybody else adds zeros)
+int shard_factor_bcast(mogp_model* m, Spd& w, Spd& s, int k0, int nk, bool mine, hipStream_t st) {
+    const int64_t kd2 = (int64_t)nk * MOGP_TILE * nk * MOGP_TILE;
+    RC(m->sh_fact.ensure((size_t)kd2 + nk + 1));
+    HIP_TRY(hipMemcpyAsync(m->sh_fact.p, s.B.p, (size_t)kd2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_factor_pack, dim3(1), dim3(64), 0, st, m->sh_fact.p, kd2, w.logdet.p + k0, nk, m->d_info.p, mine ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    RC(comm_allreduce(m->ctx, m->sh_fact.p, kd2 + nk + 1, st));
+    HIP_TRY(hipMemcpyAsync(s.B.p, m->sh_fact.p, (size_t)kd2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_factor_unpack, dim3(1), dim3(64), 0, st, m->sh_fact.p, kd2, w.logdet.p + k0, nk, m->d_info.p);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

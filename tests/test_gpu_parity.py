@@ -555,6 +555,26 @@ def test_sharded_eval_ranks_sharing_one_gpu(ranks):
     assert r["snelson"]["rel_loss"] < 1e-10 and r["snelson"]["rel_grad"] < 1e-6 and r["snelson"]["rel_predict"] < 1e-7, r["snelson"]
 
 
+@pytest.mark.parametrize("variant", ["one_message", "factor_once", "factor_once_one_message"])
+def test_sharded_eval_exchange_variants(variant):
+    """the switches of the sharded evaluation's exchange (round 5), four ranks sharing this GPU: MOGP_SHARD_SPLIT=0 (the whole panel of a pivot block in one
+    all-gather on the critical stream, rounds 1-4; the default sends the pivot block's own rows first and the rest on a communication stream underneath the
+    inversion) and MOGP_SHARD_FACTOR_ONCE=1 (the owner of the pivot block inverts it, an all-reduce carries the factor to the others) -- same results"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    if "one_message" in variant:
+        env["MOGP_SHARD_SPLIT"] = "0"
+    if "factor_once" in variant:
+        env["MOGP_SHARD_FACTOR_ONCE"] = "1"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+                          "--master-port", "29652", os.path.join(root, "tools", "shard_check.py"), "--points", "3000", "--backend", "gloo", "--exact-only"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["world"] == 4 and r["rel_loss"] < 1e-10 and r["rel_grad"] < 1e-7 and r["rel_predict"] < 1e-7, r
+
+
 def test_rccl_communicator_single_rank():
     """the library's own RCCL communicator (dlopen'ed librccl, unique id, ncclAllGather / ncclAllReduce on the library's streams) on a
     1-rank group: the sharded evaluation and prediction through it equal the one-GPU ones.  More ranks need more GPUs."""

@@ -19,6 +19,7 @@ ap.add_argument("--backend", default="gloo")
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--titsias-points", type=int, default=6000)
 ap.add_argument("--inducing", type=int, default=96, help="inducing points per channel of the Titsias check")
+ap.add_argument("--exact-only", action="store_true", help="the exact model's evaluation and prediction only (the exchange-variant tests)")
 a = ap.parse_args()
 
 import torch
@@ -69,6 +70,19 @@ mu0, var0 = m.predict_f(Xs)
 perr = max(float(np.max(np.abs(mu1 - mu0)) / np.max(np.abs(mu0))), float(np.max(np.abs(var1 - var0)) / np.max(np.abs(var0))))
 
 err = max(float(np.max(np.abs(b - c)) / np.max(np.abs(c))) for b, c in zip(g1, g0))
+
+if a.exact_only:
+    errs = torch.tensor([abs(l1 - l0) / abs(l0), err, perr], dtype=torch.float64)
+    if a.backend == "nccl":
+        errs = errs.cuda()
+    dist.all_reduce(errs, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps(dict(world=world, backend=a.backend, N=a.points, loss=l0, loss_sharded=l1, rel_loss=float(errs[0]), rel_grad=float(errs[1]),
+                              rel_predict=float(errs[2]), transport=comm.transport, ms_single=1e3 * t_single, ms_sharded=1e3 * t_shard,
+                              split=os.environ.get("MOGP_SHARD_SPLIT", "1"), factor_once=os.environ.get("MOGP_SHARD_FACTOR_ONCE", "0"))))
+    mogptk_amd.shutdown_distributed()
+    dist.destroy_process_group()
+    sys.exit(0)
 
 # the sparse (Titsias) bound DATA-PARALLEL: every rank holds every world-th training point, the sums over points are all-reduced inside the
 # library (mogp_titsias_eval_sharded / _predict_sharded); bound, every gradient and the prediction against the one-GPU evaluation
