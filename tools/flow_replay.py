@@ -7,6 +7,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
+import torch          # noqa: F401  (as bench.py does: with torch's copy of the HIP runtime in the process the profiler's exit hooks behave)
 from mogptk_amd import gpr, synth, _lib
 
 
@@ -54,6 +55,9 @@ def main():
     print("normal evaluation again: loss %.10f (same: %s)" % (loss2, loss2 == loss0))
     hd.close()                      # before the interpreter tears the library down (under rocprofv3 an implicit teardown at exit crashed in the tool's hooks)
     m._handle = None
+    for dev, ctx in list(_lib._ctx.items()):
+        _lib.lib().mogp_ctx_destroy(ctx)
+        del _lib._ctx[dev]
     return 0
 
 
