@@ -703,14 +703,32 @@ def main():
                          "basis": "algorithmic flops of one step (SURVEY.md 8d: %.3e) / ms_per_step%s" % (algo_flops, " / ranks" if sharded_mode else ""),
                          "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src},
         }
-        if sched and sched["dataflow"] and traffic is not None:
-            # The dataflow kernel cannot be measured by rocprofv3 --pmc: counter collection serialises dispatches, and k_flow and the chain
-            # kernels that feed it have to run concurrently (under --pmc the evaluation times out and falls back to the stream schedule).
-            # What the committed counter passes measure is the stream schedule's launches of the SAME tile products (MOGP_FLOW=0).
-            out["roofline"]["traffic"] = None
-            out["roofline"]["traffic_note"] = ("null: rocprofv3 --pmc serialises dispatches, which the co-operating dataflow / chain kernels cannot run under; "
-                                               "traffic_stream_schedule is the same tile products as launches (MOGP_FLOW=0)")
-            out["roofline"]["traffic_stream_schedule"] = {"bytes_per_eval": traffic_eval, "bytes_per_launch": traffic, "source": traffic_src}
+        if sched and sched["dataflow"] and a.config == "cfg2" and not sharded_mode:
+            # rocprofv3 --pmc serialises dispatches, and the dataflow kernel normally co-operates with the chain kernels (under --pmc an evaluation
+            # falls back to the stream schedule).  Its traffic is therefore counted with the kernel running ALONE on the replay plan
+            # (mogp_model_flow_replay: chain counters preset, same tile products, same Kj^-1 bit for bit -- tools/flow_replay.py, tools/pmc_flow.py);
+            # the stream schedule's launches of the same products stay beside it.
+            stream = {"bytes_per_eval": traffic_eval, "bytes_per_launch": traffic, "source": traffic_src} if traffic is not None else None
+            flow_t = None
+            for tf in ("r5_pmc_traffic.json",):
+                try:
+                    with open(os.path.join(ROOT, "profiles", tf)) as f:
+                        flow_t = json.load(f)
+                    flow_t["file"] = tf
+                    break
+                except Exception:
+                    continue
+            if flow_t is not None and flow_t.get("kernel", "").startswith("k_flow"):
+                out["roofline"]["traffic"] = flow_t["bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/%s: %s" % (flow_t["file"], flow_t["source"])
+                out["roofline"]["traffic_fetch"] = flow_t["fetch_bytes_per_launch"]
+                out["roofline"]["traffic_write"] = flow_t["write_bytes_per_launch"]
+                out["roofline"]["traffic_over_algorithmic"] = flow_t["bytes_per_launch"] / (8.0 * N * N * (N / 512.0))
+            else:
+                out["roofline"]["traffic"] = None
+                out["roofline"]["traffic_note"] = "null: no counter pass of the dataflow kernel (profiles/r5_pmc_traffic.json) in this tree"
+            if stream is not None:
+                out["roofline"]["traffic_stream_schedule"] = stream
         if rccl is not None:
             out["config"]["rccl_ranks"] = rccl[0]
         if kind == "exact" and not sharded_mode and acc["nprof"] > 0:

@@ -170,7 +170,6 @@ struct FlowArgs {
     int nq, ncas, base_heads, base_err;
     unsigned nap_max;                 // an idle workgroup sleeps 2^1 .. 2^nap_max microseconds between looks
     int nhi;                          // queues below this index always hold a task per workgroup (claimed at the next look after one was taken)
-    int xcd_heads;                    // fetch-add queues: one head per XCD over interleaved positions (0: one head per queue, round 4)
     int claim_one;                    // nothing ready: take from ONE queue per look (the highest priority with a free slot) instead of from all
     int refill;                       // a taken eager slot is refilled at once (0: only when the workgroup finds nothing ready)
     const double* vy; double* vz; double* vzz; double* vpart;         // z = W y and alpha = W^T z as tasks (null: those tasks only count)
@@ -240,7 +239,6 @@ __device__ __forceinline__ void flow_apart(const FlowArgs& g, const int r0, cons
 
 #define FL_IDLE_LIMIT 60000u          // idle looks (1 .. 16 us apart) before a workgroup gives up (the chain's own waits give up after ~0.2 s)
 #define FL_LA 8                       // positions behind the head of a compare-and-swap queue whose readiness a look already knows
-#define FL_XS FLOW_XCDS               // sub-queues of a fetch-add queue: sub-queue x holds the queue's positions x, x + 8, x + 16, ... and is XCD x's first choice
 
 // How a workgroup gets its next tile.  Wave 0 looks at every queue at once, one lane per candidate:
 //   * the first `ncas` queues (the few tiles the next chain kernel waits for) are taken READY ONLY: a lane per position head .. head + 7 reads
@@ -267,27 +265,6 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
     if (wave == 0 && lane < nlanes) { qbase = g.qmeta[2 * myq]; qsize = g.qmeta[2 * myq + 1]; }
     int pend = -1;                    // eager lanes: the index (inside the queue) this workgroup holds
     bool exhausted = false;           // eager lanes: the queue has nothing left to take
-    // Round 5, XCD-aware claims.  The rocprofv3 counters of the kernel alone (profiles/r5_pmc_flow.txt) showed 34.8 GB fetched per evaluation for 8.6 GB of
-    // algorithmic traffic: consecutive tasks of a queue share an operand panel (a row of the sweep shares A, a column shares B), but a fetch-add on ONE
-    // head deals them to workgroups all over the chip, and every XCD's L2 fetches every panel.  Now a fetch-add queue has one head PER XCD: XCD x takes
-    // the queue's positions x, x + 8, ..., and flow_build orders every run of equal keys so that those positions hold the tasks whose B panel falls
-    // into class x -- a panel is fetched by ONE XCD's L2 instead of eight.  A workgroup whose own sub-queue is empty takes from the next one (the
-    // tail stays balanced); a queue is exhausted when all eight are.
-    int xs = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (FL_XS - 1));        // HW_REG_XCC_ID: the XCD this workgroup runs on
-    unsigned dead = g.xcd_heads ? 0u : ((1u << FL_XS) - 2u);                       // sub-queues found empty (one head per queue: only sub-queue 0 exists)
-    if (!g.xcd_heads) xs = 0;
-    const int xstep = g.xcd_heads ? FL_XS : 1;
-    // one ticket from my queue: -> its position inside the queue, or -1 (then `exhausted` is set)
-    auto ticket = [&]() {
-        for (;;) {
-            const unsigned hh = __hip_atomic_fetch_add(heads + FL_XS * myq + xs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long pos = (unsigned long long)hh * xstep + xs;
-            if (pos < (unsigned long long)qsize) return (int)pos;
-            dead |= 1u << xs;
-            if (dead == (1u << FL_XS) - 1u) { exhausted = true; return -1; }
-            do { xs = (xs + 1) & (FL_XS - 1); } while (dead & (1u << xs));
-        }
-    };
     unsigned long long cas_heads = 0; // bit q * FL_LA for every compare-and-swap queue
     for (int q = 0; q < g.ncas; ++q) cas_heads |= 1ull << (q * FL_LA);
     const unsigned long long eager_mask = nlanes >= 64 ? ~0ull << ncl : ((1ull << nlanes) - 1ull) & ~((1ull << ncl) - 1ull);
@@ -306,11 +283,11 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                 // they starved, kept filled per workgroup their ready tasks sat in busy workgroups' slots
                 const bool peek = is_eager && myq < g.nhi && pend < 0 && !exhausted;
                 if (is_cas) {
-                    h = (int)__hip_atomic_load(heads + FL_XS * myq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    h = (int)__hip_atomic_load(heads + myq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     h = __shfl(h, lane - myk, 64);                             // one head value per queue
                     idx = h + myk < qsize ? h + myk : -1;
                 } else if (peek) {
-                    h = (int)__hip_atomic_load(heads + FL_XS * myq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (nhi > 0 is a measurement switch of the one-head form)
+                    h = (int)__hip_atomic_load(heads + myq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (h >= qsize) exhausted = true; else idx = h;
                 } else if (is_eager) {
                     idx = pend;
@@ -334,14 +311,14 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                             unsigned cur = (unsigned)h;
                             for (;;) {
                                 unsigned expect = cur;
-                                if (__hip_atomic_compare_exchange_strong(heads + FL_XS * myq, &expect, cur + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                if (__hip_atomic_compare_exchange_strong(heads + myq, &expect, cur + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                                          __HIP_MEMORY_SCOPE_AGENT)) { ok = 1; res = qbase + (int)cur; break; }
                                 cur = expect;                                  // somebody else moved the head: is the task it now points at one this look saw ready?
                                 const unsigned off = cur - (unsigned)h;
                                 if (off >= FL_LA || !((mready >> (lane + off)) & 1ull)) break;
                             }
                         } else if (peek) {                                      // the head looked ready: take a ticket; if others were faster the ticket is a
-                            const unsigned hh = __hip_atomic_fetch_add(heads + FL_XS * myq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // later task: hold it
+                            const unsigned hh = __hip_atomic_fetch_add(heads + myq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // later task: hold it
                             if (hh == (unsigned)h) { ok = 1; res = qbase + h; }
                             else if (hh < (unsigned)qsize) pend = (int)hh;
                             else exhausted = true;
@@ -349,8 +326,10 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                             ok = 1; res = qbase + pend;
                             // refill the slot at once (the answer is not needed before the next look) -- except near the end of the
                             // queue, where a task held by a busy workgroup is a task an idle one cannot take
-                            if (g.refill && pend + 2 * (int)gridDim.x < qsize) pend = ticket();
-                            else pend = -1;
+                            if (g.refill && pend + 2 * (int)gridDim.x < qsize) {
+                                const unsigned hh = __hip_atomic_fetch_add(heads + myq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (hh < (unsigned)qsize) pend = (int)hh; else { pend = -1; exhausted = true; }
+                            } else pend = -1;
                         }
                     }
                     ok = __shfl(ok, wl, 64);
@@ -366,8 +345,8 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                     want = want && mw && lane == __ffsll((long long)mw) - 1;   // workgroups cannot take)
                 }
                 if (want) {
-                    pend = ticket();
-                    took = pend >= 0;
+                    const unsigned hh = __hip_atomic_fetch_add(heads + myq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (hh < (unsigned)qsize) { pend = (int)hh; took = true; } else exhausted = true;
                 }
                 const bool open = is_cas ? (myk == 0 && h < qsize) : (is_eager && (pend >= 0 || !exhausted));
                 if (!__ballot(open)) { res = -2; break; }                      // every queue is empty and nothing is held: done
@@ -462,7 +441,7 @@ void flow_build(int nb, int ob, FlowPlan& p, int rhs_nt, bool replay) {
                    base_WF = base_WC + (uint32_t)no * nb, base_KV = base_WF + (uint32_t)no * nb, base_WR = base_KV + (uint32_t)nb * nb,
                    base_ZR = base_WR + no, base_TS = base_ZR + no, base_TR = base_TS + (uint32_t)rhs_nt * nb, base_XN = base_TR + (uint32_t)rhs_nt * no,
                    base_end = base_XN + (uint32_t)no * rhs_nt;
-    p.base_heads = (int)base_end; p.base_err = p.base_heads + FLOW_XCDS * FLOW_MAXQ; p.nflags = p.base_err + 1;       // FLOW_XCDS head words per queue
+    p.base_heads = (int)base_end; p.base_err = p.base_heads + FLOW_MAXQ; p.nflags = p.base_err + 1;
     auto S = [&](int i, int j) { return base_S + (uint32_t)i * nb + j; };
     auto R = [&](int i, int c) { return base_R + (uint32_t)i * no + c; };
     auto DG = [&](int c) { return base_DG + (uint32_t)c; };
@@ -684,42 +663,9 @@ void flow_build(int nb, int ob, FlowPlan& p, int rhs_nt, bool replay) {
         order.insert(order.end() - 1, &p.folded);
     }
     p.nq = (int)order.size();
-    // XCD locality (k_flow: one head per XCD): inside every run of equal keys of a fetch-add queue -- tasks of one phase of one block, free to run in any
-    // order -- the tasks are dealt out so that queue position x, x + 8, ... (XCD x's share) holds the tasks whose B operand panel is of class x
-    // (tile row + tile column mod 8: for an update sweep the column j of C, for the inverse's products the column of W): the 57 workgroups of an XCD
-    // then share a handful of B panels and walk down the rows together.  Order inside a class is the run's own (row-major) order.
-    static const bool xcd_order = !(std::getenv("MOGP_FLOW_XCD") && std::atoi(std::getenv("MOGP_FLOW_XCD")) == 0);
-    auto interleave = [&](std::vector<FlowTask>& v) {
-        std::vector<FlowTask> out;
-        out.reserve(v.size());
-        size_t r0 = 0;
-        while (r0 < v.size()) {
-            size_t r1 = r0;
-            while (r1 < v.size() && v[r1].key == v[r0].key) ++r1;
-            std::vector<size_t> cls[FLOW_XCDS];
-            size_t nxt[FLOW_XCDS] = {0};
-            for (size_t k = r0; k < r1; ++k) cls[(v[k].br + v[k].bc) % FLOW_XCDS].push_back(k);
-            for (size_t k = r0; k < r1; ++k) {
-                int x = (int)(out.size() % FLOW_XCDS);
-                if (nxt[x] >= cls[x].size()) {                       // this class is used up: the fullest of the others
-                    size_t best = 0; int bx = -1;
-                    for (int c = 0; c < FLOW_XCDS; ++c) { const size_t left = cls[c].size() - nxt[c]; if (left > best) { best = left; bx = c; } }
-                    x = bx;
-                }
-                out.push_back(v[cls[x][nxt[x]++]]);
-            }
-            r0 = r1;
-        }
-        v.swap(out);
-    };
-    p.xcd_order = xcd_order;
     for (int qi = 0; qi < p.nq; ++qi) {
         p.qbase[qi] = (int)p.tasks.size(); p.qsize[qi] = (int)order[qi]->size();
-        if (xcd_order && qi >= FLOW_NCAS && !order[qi]->empty() && !((*order[qi])[0].var & 32)) {
-            std::vector<FlowTask> v(*order[qi]);
-            interleave(v);
-            p.tasks.insert(p.tasks.end(), v.begin(), v.end());
-        } else p.tasks.insert(p.tasks.end(), order[qi]->begin(), order[qi]->end());
+        p.tasks.insert(p.tasks.end(), order[qi]->begin(), order[qi]->end());
     }
     p.flops = 2.0 * MOGP_TILE * MOGP_TILE * FL_BK * tiles_k;
 }
@@ -821,7 +767,6 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     g.npad = ld;
     { const char* e = std::getenv("MOGP_FLOW_REFILL"); g.refill = e ? std::atoi(e) : 0; }
     { const char* e = std::getenv("MOGP_FLOW_CLAIM1"); g.claim_one = e ? std::atoi(e) : 0; }
-    g.xcd_heads = p.xcd_order ? 1 : 0;                   // (MOGP_FLOW_XCD=0, read when a plan is built: one head per queue and the run's own order, as in round 4)
     { const char* e = std::getenv("MOGP_FLOW_NHI"); g.nhi = e ? std::atoi(e) : 0; }            // measured 3 / 4 (semi, the inverse cycle, z and alpha looked at by everybody): 10.74-10.79 vs 10.52-10.65 ms
     { const char* e = std::getenv("MOGP_FLOW_NAP"); g.nap_max = e ? (unsigned)std::max(0, std::atoi(e)) : 4u; }
     w.vec_done = false;

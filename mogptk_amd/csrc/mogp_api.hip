@@ -641,8 +641,7 @@ namespace mogp { void flow_debug_dump(mogp_model* m) {
     }
     fprintf(stderr, "  error word 0x%x\n", fl[p.base_err]);
     for (int q = 0; q < p.nq; ++q) {
-        unsigned h = fl[p.base_heads + FLOW_XCDS * q];                      // tickets drawn: with one head per XCD the sum over the sub-queues (their positions interleave)
-        if (p.xcd_order && q >= FLOW_NCAS) for (int x = 1; x < FLOW_XCDS; ++x) h += fl[p.base_heads + FLOW_XCDS * q + x];
+        const unsigned h = fl[p.base_heads + q];
         const unsigned claimed = std::min<unsigned>(h, (unsigned)p.qsize[q]);
         unsigned done = 0, shown = 0;
         fprintf(stderr, "  queue %2d: head %u of %d", q, h, p.qsize[q]);

@@ -219,7 +219,6 @@ int launch_chain(double* A, int64_t ld, int t0, int nk, double* invd, double* lo
 
 // ---- tile dataflow form of the fused factorisation + inversion (flow.hip) --------------------------------------------------------------
 #define FLOW_MAXQ 48                   // queues of a plan at most: 2 * 8 compare-and-swap lanes + one lane per other queue fit one wave
-#define FLOW_XCDS 8                    // head words per queue: one per XCD (flow.hip: XCD-aware claims)
 #define FLOW_NCAS 1                    // the first queues (by priority) are taken ready-only by compare-and-swap, the others eagerly (flow.hip:k_flow)
 #define FLOW_TRACE_W 6
 #define FLOW_KEY_STEP 1024             // FlowTask::key = FLOW_KEY_STEP * superstep + position inside it
@@ -238,7 +237,6 @@ struct FlowTask {                      // 64 bytes; static per matrix size
 static_assert(sizeof(FlowTask) == 64, "FlowTask layout");
 struct FlowPlan {
     int nb = 0, ob = 0, nouter = 0, nq = 0, rhs_nt = 0;
-    bool xcd_order = false;            // the fetch-add queues are interleaved for one head per XCD (flow_build)
     bool replay = false;               // the measurement plan (flow.hip: flow_build): the private stream's products are tasks too, the chain kernels' counters preset
     std::vector<FlowTask> tasks;       // queue after queue, queues in priority order
     std::vector<FlowTask> folded;      // (scratch of flow_build)
