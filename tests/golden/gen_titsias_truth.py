@@ -8,7 +8,8 @@ expl / cosl, Cholesky, triangular solves, adjoints, the kernel's derivative; eps
 at N reduced to 20 000 points (same grid, same spacing, same K_uu), and runs the reference itself (torch fp64) on the same inputs.
 Output: tests/golden/titsias_dz_truth.npz = {meta, scale, Z, gz_truth, gz_ref, elbo_truth, loss_ref, ref_err}.  The device test asserts that
 its dELBO/dZ is no further from the truth than the reference's.
-usage (build container, reference importable; ~35 min on one core):  python tests/golden/gen_titsias_truth.py [N=20000] [M=2048]"""
+usage (build container, reference importable; ~35 min on one core):  python tests/golden/gen_titsias_truth.py [N=20000] [M=2048]
+round 5, the truth AT configs[4] (column chunks over 8 processes):  python tests/golden/gen_titsias_truth.py 100000 2048 --workers 8 --out titsias_dz_truth_cfg5.npz"""
 import os
 import sys
 import time
@@ -138,9 +139,124 @@ def truth(table, Z, X, y, sigma, jitter):
     return float(elbo), gz.astype(np.float64)
 
 
+# ---- the same evaluation in column chunks over worker processes (round 5: the truth AT configs[4], N = 100 000) --------------------------------
+# numpy.longdouble products do not go through BLAS and run on one core: at N = 100 000 the seven M x M x N products of truth() would take ~3 h.  Every
+# M x N quantity is a function of its own columns only (v = L^-1 Kuf, Pq v, the adjoint of Kuf) and enters the rest through sums over columns
+# (v v^T, v y, the row sums of the adjoint times the kernel derivative), so the columns are dealt to worker processes in chunks: pass 1 returns the
+# sums, the M x M algebra runs in the parent, pass 2 the share of dELBO/dZ.  Same formulas, same extended precision as truth().
+_W = {}
+
+
+def _w_init(table, Z, X, y, L):
+    _W.update(table=table, Z=Z, X=X, y=y, L=L)
+    C = table.shape[0]
+    cz, cx = Z[:, 0].astype(np.int64), X[:, 0].astype(np.int64)
+    _W["rz"] = [np.nonzero(cz == c)[0] for c in range(C)]
+    _W["cx"] = cx
+
+
+def _kuf(cols, want_j=False):
+    table, Z, X, rz, cx = _W["table"], _W["Z"], _W["X"], _W["rz"], _W["cx"]
+    C = table.shape[0]
+    z, x = Z[:, 1].astype(LD), X[cols, 1].astype(LD)
+    B = np.zeros((z.size, x.size), dtype=LD)
+    J = np.zeros_like(B) if want_j else None
+    for j in range(C):
+        cj = np.nonzero(cx[cols] == j)[0]
+        if cj.size == 0:
+            continue
+        for i in range(C):
+            Kb, Jb = kblock(table[i, j], z[rz[i]], x[cj], want_j)
+            B[np.ix_(rz[i], cj)] = Kb
+            if want_j:
+                J[np.ix_(rz[i], cj)] = Jb
+    return B, J
+
+
+def _pass1(cols):
+    B, _ = _kuf(cols)
+    v = trsm_ld(_W["L"], B)
+    yv = _W["y"][cols].astype(LD).reshape(-1, 1)
+    return v @ v.T, v @ yv, (yv.T @ yv)[0, 0]
+
+
+def _pass2(args):
+    cols, Lq, beta, s2 = args
+    B, J = _kuf(cols, True)
+    v = trsm_ld(_W["L"], B)
+    yv = _W["y"][cols].astype(LD).reshape(-1, 1)
+    r = yv / s2 ** 2 - (B.T @ beta) / s2 ** 3
+    Pv = trsm_ld(Lq, trsm_ld(Lq, v), True)
+    GB = trsm_ld(_W["L"], (v - Pv) / s2, True) + beta @ r.T
+    return np.sum(GB * J, axis=1)
+
+
+def truth_chunked(table, Z, X, y, sigma, jitter, workers, chunk=3125):
+    import multiprocessing as mp
+    t0 = time.time()
+    C = table.shape[0]
+    cz = Z[:, 0].astype(np.int64)
+    z = Z[:, 1].astype(LD)
+    M, N = z.size, X.shape[0]
+    rz = [np.nonzero(cz == c)[0] for c in range(C)]
+    Kuu = np.zeros((M, M), dtype=LD)
+    for i in range(C):
+        for j in range(i + 1):
+            Kb, _ = kblock(table[i, j], z[rz[i]], z[rz[j]])
+            Kuu[np.ix_(rz[i], rz[j])] = Kb
+            if j < i:
+                Kuu[np.ix_(rz[j], rz[i])] = Kb.T
+    s2 = LD(sigma) * LD(sigma)
+    I = np.eye(M, dtype=LD)
+    A = Kuu + LD(jitter) * np.mean(np.diagonal(Kuu)) * I
+    L = chol_ld(A)
+    print("  Kuu factored %.0f s" % (time.time() - t0), flush=True)
+    chunks = [np.arange(c0, min(c0 + chunk, N)) for c0 in range(0, N, chunk)]
+    with mp.get_context("fork").Pool(workers, initializer=_w_init, initargs=(table, Z, X, y, L)) as pool:
+        Qm, vy, yy = np.zeros((M, M), dtype=LD), np.zeros((M, 1), dtype=LD), LD(0)
+        for q, w, t in pool.imap(_pass1, chunks):                 # (in chunk order: the sums are reproducible)
+            Qm += q; vy += w; yy += t
+        print("  pass 1 (v v^T, v y) %.0f s" % (time.time() - t0), flush=True)
+        Qs = Qm / s2 + I
+        Lq = chol_ld(Qs)
+        t1 = trsm_ld(Lq, trsm_ld(Lq, vy), True)                  # Pq v y
+        beta = trsm_ld(L, t1, True)
+        Pq = trsm_ld(Lq, trsm_ld(Lq, I), True)
+        Em = 2 * I - Pq - Qs
+        T1 = trsm_ld(L, Em, True)
+        GA = trsm_ld(L, T1.T, True).T / 2 - (beta @ beta.T) / (2 * s2 ** 2)
+        GA = (GA + GA.T) / 2
+        print("  M x M algebra %.0f s" % (time.time() - t0), flush=True)
+        gz = np.zeros(M, dtype=LD)
+        for part in pool.imap(_pass2, [(c, Lq, beta, s2) for c in chunks]):
+            gz += part
+        print("  pass 2 (adjoint of Kuf) %.0f s" % (time.time() - t0), flush=True)
+    cx = X[:, 0].astype(np.int64)
+    kff = sum(int(np.sum(cx == c)) * kblock(table[c, c], np.zeros(1, dtype=LD), np.zeros(1, dtype=LD))[0][0, 0] for c in range(C))
+    logdet_q = 2 * np.sum(np.log(np.diagonal(Lq)))
+    elbo = (-LD(N) / 2 * np.log(TWO_PI) - logdet_q / 2 - LD(N) * np.log(LD(sigma)) - yy / (2 * s2)
+            + (t1.T @ vy)[0, 0] / (2 * s2 ** 2) - (kff - np.trace(Qm)) / (2 * s2))
+    for i in range(C):
+        for j in range(C):
+            if i >= j:
+                _, Ju = kblock(table[i, j], z[rz[i]], z[rz[j]], True)
+            else:
+                _, Jt = kblock(table[j, i], z[rz[j]], z[rz[i]], True)
+                Ju = -Jt.T
+            gz[rz[i]] += 2 * np.sum(GA[np.ix_(rz[i], rz[j])] * Ju, axis=1)
+    print("  done %.0f s" % (time.time() - t0), flush=True)
+    return float(elbo), gz.astype(np.float64)
+
+
 def main():
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-    M = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("N", nargs="?", type=int, default=20000)
+    ap.add_argument("M", nargs="?", type=int, default=2048)
+    ap.add_argument("--workers", type=int, default=0, help="> 0: the column-chunked evaluation on this many processes (the N = 100 000 fixture: 8)")
+    ap.add_argument("--out", default="titsias_dz_truth.npz")
+    a = ap.parse_args()
+    N, M = a.N, a.M
     C, Q = 4, 3
     from mogptk_amd import synth, gpr as agpr
     X, y = synth.make_data(N, C)
@@ -173,6 +289,9 @@ def main():
         out["p%d_cons" % n] = p().detach().numpy().copy()
         out["p%d_grad" % n] = np.array(np.nan) if p.grad is None else p.grad.detach().numpy().copy()
     out["names"] = np.array([p._name for p in params])
+    del m, k
+    import gc
+    gc.collect()
     # this package's model with the reference's RAW parameter values: its term table, inducing inputs and noise scale are the fp64 numbers the
     # device receives (host algebra pinned on the reference elsewhere) -- the function whose exact derivative is taken below
     ka = agpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
@@ -180,18 +299,21 @@ def main():
         getattr(ka, name).assign(h[name])
     ma = agpr.Titsias(ka, X, y, Z=[M // C] * C, variance=s ** 2)
     ma.likelihood.scale.assign(s)
-    for pa, pr in zip(ma.parameters(), params):
-        assert pa.data.shape == tuple(pr.data.shape), (pa._name, pr._name)
-        pa.data = pr.data.detach().numpy().copy()
+    for pa, n in zip(ma.parameters(), range(len(params))):
+        assert pa.data.shape == tuple(out["p%d_raw" % n].shape), pa._name
+        pa.data = out["p%d_raw" % n].copy()
     table = np.asarray(ka._spectral_terms(1), dtype=np.float64)
     Z = np.asarray(ma.kernel._kernel_format(ma.Z()), dtype=np.float64)
     sigma = float(np.asarray(ma.likelihood.scale()).reshape(-1)[0])
-    elbo, gz = truth(table, Z, X, y, sigma, jitter)
+    if a.workers > 0:
+        elbo, gz = truth_chunked(table, Z, X, y, sigma, jitter, a.workers)
+    else:
+        elbo, gz = truth(table, Z, X, y, sigma, jitter)
     ref_err = float(np.max(np.abs(gz_ref - gz)) / np.max(np.abs(gz)))
     print("extended precision: elbo %.10f (reference %.10f), |dELBO/dZ|max %.3e; the reference's fp64 run is %.3e of the tensor away"
           % (elbo, -loss, np.abs(gz).max(), ref_err))
     out.update(scale=np.array(s), Z=Z, gz_truth=gz, elbo_truth=np.array(elbo), ref_err=np.array(ref_err))
-    np.savez_compressed(os.path.join(HERE, "titsias_dz_truth.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, a.out), **out)
 
 
 if __name__ == "__main__":
