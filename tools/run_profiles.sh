@@ -15,6 +15,13 @@ for c in cfg2 cfg3 cfg4 cfg5; do
   st=5; wu=2; if [ $c = cfg2 ]; then st=20; wu=5; fi      # the headline as the driver runs it: the average then is the steady state's, not the warm-up's
   timeout -k 5 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --config $c --steps $st --warmup $wu --no-cpu-baseline --no-configs --no-shard-probe > $O/kt_$c.log 2>&1
 done
+# the dataflow kernel itself: ALONE on the replay plan (mogp_model_flow_replay; tools/flow_replay.py checks that it forms the same Kj^-1 bit for bit)
+for cnt in FETCH_SIZE WRITE_SIZE; do
+  FLOW_REPLAY_SERIAL=1 timeout -k 5 400 rocprofv3 --pmc $cnt --kernel-trace --output-format csv -d $O/pmcflow_$cnt -o p -- python $GRAFT_REPO_ROOT/tools/flow_replay.py 8192 3 > $O/pmcflow_$cnt.log 2>&1
+done
+(cd $GRAFT_REPO_ROOT; python tools/pmc_flow.py "$(find $O/pmcflow_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $O/pmcflow_WRITE_SIZE -name '*counter_collection.csv' | head -1)" 8192 $O/pmc_flow_traffic.json > $O/pmc_flow.txt 2>&1)
+(cd $GRAFT_REPO_ROOT; timeout 200 python tools/flow_replay.py 8192 5) > $O/flow_replay.txt 2>&1
+rm -rf $O/pmcflow_FETCH_SIZE $O/pmcflow_WRITE_SIZE
 for cnt in FETCH_SIZE WRITE_SIZE; do
   MOGP_FLOW=0 timeout -k 5 300 rocprofv3 --pmc $cnt --kernel-trace --output-format csv -d $O/pmc_$cnt -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-shard-probe > $O/pmc_$cnt.log 2>&1
 done
