@@ -672,7 +672,27 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* _
             }
         }
         if (u + 1 < sg.n) { col_commit(b ^ 1); cc = cc_n; hc = hc_n; }
-        if (!(GRAM_DBG(a, 1) && acc[0][0] != 12345.678)) {
+        if (sg.diag && u + 1 == sg.n) {
+            // the run's last tile sits on the matrix diagonal: the general kernel's epilogue for such a tile (gram_store) -- lower part only,
+            // noise + jitter (+ per-point variance) on the diagonal entries
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int lr = rg * 4 + m;
+                const int64_t r = sg.r0 + lr;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int lc = cg * 4 + n;
+                    if (lc > lr) continue;
+                    double val = acc[m][n];
+                    if (a.noise != nullptr && lc == lr) {
+                        val += a.noise[ci] + a.jitter_abs;
+                        if (a.dvar != nullptr) val += a.dvar[r];
+                    }
+                    a.out[r * a.ldo + c0 + lc] = val;
+                    if (a.out2) a.out2[r * a.ldo + c0 + lc] = val;
+                }
+            }
+        } else if (!(GRAM_DBG(a, 1) && acc[0][0] != 12345.678)) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int64_t at = (int64_t)(sg.r0 + rg * 4 + m) * a.ldo + c0 + cg * 4;
@@ -694,13 +714,17 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* _
 void split_strip_tiles(const std::vector<GTile>& tiles, int maxrun, std::vector<GSeg>& segs, std::vector<GTile>& rest) {
     segs.clear(); rest.clear();
     for (const GTile& t : tiles) {
-        const bool fast = t.nr == MOGP_GT && t.nc == MOGP_GT && !(t.flags & GT_DIAG) && (t.c0 & 1) == 0;
+        // round 5: a full-size tile ON the diagonal rides at the end of its row block's run (the strip kernel's store handles it: lower part only,
+        // noise + jitter on the diagonal) instead of going to the general kernel in a launch of its own -- 128 tiles, 17 us at the head of every
+        // configs[1] evaluation.  (The strip kernel never mirrors: launch_gram takes it only when a.mirror is 0.)
+        const bool fast = t.nr == MOGP_GT && t.nc == MOGP_GT && (t.c0 & 1) == 0;
         if (!fast) { rest.push_back(t); continue; }
+        const int dg = (t.flags & GT_DIAG) ? 1 : 0;
         if (!segs.empty()) {
             GSeg& g = segs.back();
-            if (g.pair == t.pair && g.r0 == t.r0 && g.c0 + g.n * MOGP_GT == t.c0 && g.n < maxrun) { ++g.n; continue; }
+            if (!g.diag && g.pair == t.pair && g.r0 == t.r0 && g.c0 + g.n * MOGP_GT == t.c0 && g.n < maxrun) { ++g.n; g.diag = dg; continue; }
         }
-        segs.push_back(GSeg{t.r0, t.c0, 1, t.pair});
+        segs.push_back(GSeg{t.r0, t.c0, 1, t.pair, dg, {0, 0, 0}});
     }
 }
 

@@ -333,8 +333,12 @@ static hipEvent_t prof_event(mogp_model* m, int idx) {
 
 // Cholesky of w.A (lower) in place; w.invd gets the inverses of the diagonal 128-tiles, w.logdet the per-tile sums of
 // log L_kk; a non-positive pivot is reported through m->d_info (atomicMin of the 1-based index).
-namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base) {
+namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base, hipStream_t chain_q) {
     int rc;
+    // chain_q (round 5): the stream of the serial chain -- leaf, panel, in-block update, next-block columns.  The sparse bound factors K_uu while a
+    // Gram kernel fills every other CU (K_uf, on the side stream): on the model's unmasked stream the chain's one-workgroup kernels then land on CUs they
+    // share with Gram waves (leaf 156 instead of 42 us, 3.7 ms for a 2048 x 2048 factorisation); on the CU-masked private stream they own the reserved CUs.
+    hipStream_t cq = chain_q ? chain_q : m->st;
     // Bulk stream: the one masked to everything but the reserved CUs while the serial chain matters -- the chain's small kernels (this
     // stream, all CUs) then find idle CUs instead of sharing one with GEMM waves: 15.9 vs 21.1 ms per evaluation at N = 8192, 74 vs 82 ms
     // for the N = 16384 prediction.  Once the work is flop-bound the 6 % of CUs matter more (sweep at N = 32768: 597 vs 638 ms): all CUs.
@@ -358,7 +362,7 @@ namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base) {
     for (int kb = 0; kb < nouter; ++kb) {
         const int k0 = kb * MOGP_OUTER, k1 = std::min(k0 + MOGP_OUTER, nb);
         for (int k = k0; k < k1; ++k) {
-            if ((rc = launch_potrf_trtri_tile(w.A.p, w.Npad, k, w.invd.p, w.logdet.p, m->d_info.p, m->st, info_base, w.keep_L ? 1 : 0))) return rc;
+            if ((rc = launch_potrf_trtri_tile(w.A.p, w.Npad, k, w.invd.p, w.logdet.p, m->d_info.p, cq, info_base, w.keep_L ? 1 : 0))) return rc;
             const int rem = nb - k - 1;
             if (rem <= 0) break;
             double* panel = w.A.p + (int64_t)(k + 1) * MOGP_TILE * w.Npad + (int64_t)k * MOGP_TILE;
@@ -367,18 +371,18 @@ namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base) {
             g.B = w.invd.p + (int64_t)k * MOGP_TILE * MOGP_TILE; g.ldb = MOGP_TILE; g.b_kmajor = 0;
             g.C = panel; g.ldc = w.Npad; g.alpha = 1.0; g.beta = 0.0;
             g.mode = GM_RECT; g.small = 1; g.mt = 2 * rem; g.nt = 1; g.K = MOGP_TILE;      // 64x128 tiles: in place
-            if ((rc = gemm_call(m, g, gemm_flops(g, nullptr)))) return rc;
+            if ((rc = gemm_call(m, g, gemm_flops(g, nullptr), cq))) return rc;
             const int inner = k1 - k - 1;            // columns k+1 .. k1-1 of this outer block
             if (inner > 0) {
                 GemmArgs u{};
                 u.A = panel; u.lda = w.Npad; u.a_kmajor = 0; u.B = panel; u.ldb = w.Npad; u.b_kmajor = 0;
                 u.C = w.A.p + (int64_t)(k + 1) * MOGP_TILE * (w.Npad + 1); u.ldc = w.Npad; u.alpha = -1.0; u.beta = 1.0;
                 u.mode = GM_RECT_LOWER; u.small = 2; u.mt = 2 * rem; u.nt = 2 * inner; u.K = MOGP_TILE;
-                if ((rc = gemm_call(m, u, gemm_flops(u, nullptr)))) return rc;
+                if ((rc = gemm_call(m, u, gemm_flops(u, nullptr), cq))) return rc;
             }
         }
         const int rem = nb - k1;
-        HIP_TRY(hipEventRecord(w.sync_ev[2 * kb], m->st));                       // chain(kb) done
+        HIP_TRY(hipEventRecord(w.sync_ev[2 * kb], cq));                       // chain(kb) done
         if (rem <= 0) break;
         double* blockp = w.A.p + (int64_t)k1 * MOGP_TILE * w.Npad + (int64_t)k0 * MOGP_TILE;
         const int K = (k1 - k0) * MOGP_TILE;
@@ -392,17 +396,17 @@ namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base) {
             u.mode = GM_LOWER; u.mt = rem - na; u.nt = rem - na; u.K = K;
             if ((rc = gemm_call(m, u, gemm_flops(u, nullptr), bulk_q))) return rc;
         }
-        if (last_bulk >= 0) HIP_TRY(hipStreamWaitEvent(m->st, w.sync_ev[2 * last_bulk + 1], 0));   // A(kb) after B(kb-1)
+        if (last_bulk >= 0) HIP_TRY(hipStreamWaitEvent(cq, w.sync_ev[2 * last_bulk + 1], 0));   // A(kb) after B(kb-1)
         if (rem > na) { HIP_TRY(hipEventRecord(w.sync_ev[2 * kb + 1], bulk_q)); last_bulk = kb; }
         {
             GemmArgs u{};                                                         // A(kb): columns k1 .. k1+na-1, rows >= column
             u.A = blockp; u.lda = w.Npad; u.a_kmajor = 0; u.B = blockp; u.ldb = w.Npad; u.b_kmajor = 0;
             u.C = w.A.p + (int64_t)k1 * MOGP_TILE * (w.Npad + 1); u.ldc = w.Npad; u.alpha = -1.0; u.beta = 1.0;
             u.mode = GM_RECT_LOWER; u.mt = rem; u.nt = na; u.K = K;
-            if ((rc = gemm_call(m, u, gemm_flops(u, nullptr)))) return rc;
+            if ((rc = gemm_call(m, u, gemm_flops(u, nullptr), cq))) return rc;
         }
     }
-    if (last_bulk >= 0) HIP_TRY(hipStreamWaitEvent(m->st, w.sync_ev[2 * last_bulk + 1], 0));
+    if (last_bulk >= 0) HIP_TRY(hipStreamWaitEvent(cq, w.sync_ev[2 * last_bulk + 1], 0));
     return 0;
 }
 }  // namespace mogp

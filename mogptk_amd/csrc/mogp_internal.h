@@ -44,7 +44,7 @@ struct GTile {
     int rb, cb;      // index of the tile's 64-point row / column block among all row / column blocks (channel by channel): the slot of its
 };                   // per-point input gradients in the fixed-order reduction (k_gz_reduce)
 // a run of n consecutive FULL interior tiles of one row block: columns c0, c0 + 64, ... (the strip kernel of gram.hip)
-struct GSeg { int r0, c0, n, pair; };
+struct GSeg { int r0, c0, n, pair; int diag, pad[3]; };      // a run of n consecutive full 64 x 64 tiles of one row block; diag: the LAST one sits on the matrix diagonal
 enum { GT_MIRROR = 1,     // also write the transpose to (c, r)   (off-diagonal tile of the symmetric Gram)
        GT_DIAG = 2 };     // tile sits on the matrix diagonal (r0 == c0)
 
