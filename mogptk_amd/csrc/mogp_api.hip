@@ -333,12 +333,9 @@ static hipEvent_t prof_event(mogp_model* m, int idx) {
 
 // Cholesky of w.A (lower) in place; w.invd gets the inverses of the diagonal 128-tiles, w.logdet the per-tile sums of
 // log L_kk; a non-positive pivot is reported through m->d_info (atomicMin of the 1-based index).
-namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base, hipStream_t chain_q) {
+namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base) {
     int rc;
-    // chain_q (round 5): the stream of the serial chain -- leaf, panel, in-block update, next-block columns.  The sparse bound factors K_uu while a
-    // Gram kernel fills every other CU (K_uf, on the side stream): on the model's unmasked stream the chain's one-workgroup kernels then land on CUs they
-    // share with Gram waves (leaf 156 instead of 42 us, 3.7 ms for a 2048 x 2048 factorisation); on the CU-masked private stream they own the reserved CUs.
-    hipStream_t cq = chain_q ? chain_q : m->st;
+    hipStream_t cq = m->st;
     // Bulk stream: the one masked to everything but the reserved CUs while the serial chain matters -- the chain's small kernels (this
     // stream, all CUs) then find idle CUs instead of sharing one with GEMM waves: 15.9 vs 21.1 ms per evaluation at N = 8192, 74 vs 82 ms
     // for the N = 16384 prediction.  Once the work is flop-bound the 6 % of CUs matter more (sweep at N = 32768: 597 vs 638 ms): all CUs.

@@ -197,7 +197,6 @@ struct TitsiasWork {
     SortedX pred_ss;                                    // the test inputs of the last sparse prediction (a = L^-1 Kus in Aus, b in Bus): what
     bool pred_valid = false;                            // mogp_sparse_predict_cov needs for the full covariance K_ss - a^T a + b^T b
     hipEvent_t side_ev[2] = {nullptr, nullptr};         // fork / join of the M x M adjoint chain on a side stream (side_fork / side_join)
-    hipEvent_t priv_ev[2] = {nullptr, nullptr};         // fork / join of K_uu's factorisation chain on the private stream (spd_potrf_private)
     DevBuf<int> blk_z, blk_x;                           // [first point, count] of the 64-point blocks of Z and of X (tile_blocks): the slots of
     std::vector<int> hblk_z, hblk_x;                    // the fixed-order reduction of d/dZ (gz_prepare / gz_attach)
     DevBuf<double> gzp;
@@ -215,7 +214,6 @@ struct TitsiasWork {
         Kus.release(); Aus.release(); Bus.release(); zero_col.release(); kslices.release(); nvec.release(); kd_point.release(); red.release();
         blk_z.release(); blk_x.release(); gzp.release(); hblk_z.clear(); hblk_x.clear();
         for (auto& e : side_ev) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
-        for (auto& e : priv_ev) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
     }
 };
 
@@ -357,8 +355,7 @@ int spd_invert(mogp_model* m, Spd& w, const char* which, int64_t* info, const do
 int mm_lower_splitk(mogp_model* m, TitsiasWork& t, const double* A, const double* B, double* out, int mt, int64_t Mpad, int64_t ldk, int64_t K,
                     double alpha = 1.0);
 int ensure_system(mogp_model* m);     // the N x N system of the exact / OA paths and the tile lists over (X, X), on first use (mogp_api.hip)
-int spd_potrf(mogp_model* m, Spd& w, long long info_base = 0, hipStream_t chain_q = nullptr);
-int spd_potrf_private(mogp_model* m, Spd& w);      // titsias.hip: the same with the chain on the CU-masked private stream (a Gram kernel is filling the other CUs)
+int spd_potrf(mogp_model* m, Spd& w, long long info_base = 0);
 int spd_potri_fused(mogp_model* m, Spd& w);
 bool flow_enabled(const mogp_model* m, const Spd& w);   // flow.hip
 int launch_flow_alpha_sum(const Spd& w, double* alpha, hipStream_t st);

@@ -48,22 +48,6 @@ int side_join(mogp_model* m, TitsiasWork& t, hipStream_t side) {
     return 0;
 }
 
-// K_uu's factorisation while a Gram kernel (K_uf, on the side stream) fills the other CUs: the serial chain on the private, CU-masked stream, where its
-// one-workgroup kernels own the reserved CUs instead of sharing a CU with Gram waves; same kernels, same arithmetic, same bits.  MOGP_POTRF_PRIVATE=0:
-// on the model's stream as in rounds 1-4.
-int spd_potrf_private(mogp_model* m, Spd& w) {
-    static const bool on = !(std::getenv("MOGP_POTRF_PRIVATE") && std::atoi(std::getenv("MOGP_POTRF_PRIVATE")) == 0);
-    TitsiasWork& t = *m->tw;
-    if (!on || !m->st_priv || m->ctx->ncu_reserved <= 0) return spd_potrf(m, w);
-    for (auto& e : t.priv_ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(t.priv_ev[0], m->st));
-    HIP_TRY(hipStreamWaitEvent(m->st_priv, t.priv_ev[0], 0));
-    RC(spd_potrf(m, w, 0, m->st_priv));
-    HIP_TRY(hipEventRecord(t.priv_ev[1], m->st_priv));
-    HIP_TRY(hipStreamWaitEvent(m->st, t.priv_ev[1], 0));
-    return 0;
-}
-
 // defer_check: the caller reads the pivot word itself at its next synchronisation (a failed factorisation then runs on with garbage: bounded, harmless)
 int spd_invert(mogp_model* m, Spd& w, const char* which, int64_t* info, const double** W, bool defer_check) {
     static const bool fused = std::getenv("MOGP_SPARSE_FUSED") && std::atoi(std::getenv("MOGP_SPARSE_FUSED")) != 0;
@@ -254,7 +238,10 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     RC(launch_gram(ga, (int)t.n_tuf, side));
 
     t.a.keep_L = true;                                                          // the solves below need L itself, diagonal tiles included
-    RC(spd_potrf_private(m, t.a));                                              // its pivot report is read with the scalars at the end of this function
+    // (round 5, measured and dropped: the chain of this factorisation on the CU-masked private stream, so that its one-workgroup kernels do not share
+    // a CU with the K_uf Gram waves -- configs[4] 39.7-39.9 vs 39.3-39.5 ms, bit-identical: the panel and next-column products of the chain are
+    // slower on 16 CUs than the leaves gain)
+    RC(spd_potrf(m, t.a));                                                      // its pivot report is read with the scalars at the end of this function
     const double s2 = sigma * sigma;
     RC(side_join(m, t, side));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.v.p, Npad, Npad, false));              // v = L^-1 B   (reference gpr/model.py:711)
