@@ -1048,9 +1048,15 @@ __global__ __launch_bounds__(512, 2) void k_moments_x(MomentArgs a) {
     constexpr int MXS = 512 + 32;                          // one moment of all threads, +1 per 16 (the slice reads hit distinct banks)
     __shared__ double s_red[TT * 5 * MXS];
     const PhaseView v = phase_view(a.ph.ws, a.C, T, 1, a.ldx, a.ldx);
-    const int stride = gridDim.x;
-    int tile = blockIdx.x;
-    if (tile >= a.ntiles) return;
+    // round 5: a workgroup walks a CONTIGUOUS chunk of the tile list and keeps the moments in registers from tile to tile for as long as the
+    // channel pair stays the same (the tiles of a pair are contiguous in the list: a chunk crosses a pair boundary once or twice); the LDS
+    // reduction and its two barriers then happen once per run instead of once per tile, and the slots of the run's other tiles receive zeros
+    // (k_moment_reduce adds the slots of a pair in fixed order, as before).  The counters had the kernel's waves parked at s_waitcnt / s_barrier
+    // 41 % of their cycles (SQ_WAIT_ANY; profiles/r5_pmc_tile_kernels.txt), the vector ALUs busy half the time.
+    const int per = (a.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    int tile = blockIdx.x * per;
+    const int tend = min(tile + per, a.ntiles);
+    if (tile >= tend) return;
 
     auto fetch = [&](MxFetch& F, const GTile& tl) {
         F.cr = v.rcen[tl.r0]; F.hr = v.rhalf[tl.r0]; F.cc = v.ccen[tl.c0]; F.hc = v.chalf[tl.c0];
@@ -1078,10 +1084,15 @@ __global__ __launch_bounds__(512, 2) void k_moments_x(MomentArgs a) {
     };
 
     GTile tl = a.tiles[tile];
-    GTile tl1 = a.tiles[min(tile + stride, a.ntiles - 1)];
+    GTile tl1 = a.tiles[min(tile + 1, tend - 1)];
     MxFetch F;
     fetch(F, tl);
     int buf = 0;
+    double mom[TT][5];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int w = 0; w < 5; ++w) mom[t][w] = 0.0;
     while (true) {
         TileLds<1>& L = Lb[buf];
         const GTile cur = tl;
@@ -1112,20 +1123,16 @@ __global__ __launch_bounds__(512, 2) void k_moments_x(MomentArgs a) {
             }
         }
         // ---- the next tile's requests go out now, under this tile's arithmetic ----
-        const int nxt = tile + stride;
-        const bool more = nxt < a.ntiles;
+        const int nxt = tile + 1;
+        const bool more = nxt < tend;
         if (more) {
             tl = tl1;
-            tl1 = a.tiles[min(nxt + stride, a.ntiles - 1)];
+            tl1 = a.tiles[min(nxt + 1, tend - 1)];
             fetch(F, tl);
         }
+        const bool flush = !more || tl.pair != cur.pair;      // the run of this channel pair ends with this tile
         // LDS-only barrier: __syncthreads() would also wait for the requests just issued -- the whole point is that they stay in flight
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the staged factors of this tile are in L
-        double mom[TT][5];
-#pragma unroll
-        for (int t = 0; t < TT; ++t)
-#pragma unroll
-            for (int w = 0; w < 5; ++w) mom[t][w] = 0.0;
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             if (t >= T) break;
@@ -1146,26 +1153,30 @@ __global__ __launch_bounds__(512, 2) void k_moments_x(MomentArgs a) {
                 default: mx_term<0>(mom[t], g, p, q, V, sft, cu, su, cw, sw); break;
             }
         }
-        // ---- one reduction per tile through LDS, fixed order: thread (w, i) adds the values of threads 16 i .. 16 i + 15 of moment w, a
-        // 5-step butterfly over i finishes (32 slices)
+        if (!flush) {
+            if (tid < T * 5) outp[tid] = 0.0;                 // this tile's moments ride on in registers: its slot adds nothing
+        } else {
+            // ---- one reduction per RUN through LDS, fixed order: thread (w, i) adds the values of threads 16 i .. 16 i + 15 of moment w, a
+            // 5-step butterfly over i finishes (32 slices)
 #pragma unroll
-        for (int t = 0; t < TT; ++t) {
-            if (t >= T) break;
+            for (int t = 0; t < TT; ++t) {
+                if (t >= T) break;
 #pragma unroll
-            for (int w = 0; w < 5; ++w) s_red[(t * 5 + w) * MXS + tid + (tid >> 4)] = mom[t][w];
+                for (int w = 0; w < 5; ++w) { s_red[(t * 5 + w) * MXS + tid + (tid >> 4)] = mom[t][w]; mom[t][w] = 0.0; }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            for (int e = tid; e < T * 5 * 32; e += 512) {
+                const int w = e >> 5, i = e & 31;
+                const double* src = s_red + w * MXS + i * 17;
+                double x = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) x += src[k];
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+                if (i == 0) outp[w] = x;                     // (a skipped term left zeros)
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // s_red is read: the next run may write it
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        for (int e = tid; e < T * 5 * 32; e += 512) {
-            const int w = e >> 5, i = e & 31;
-            const double* src = s_red + w * MXS + i * 17;
-            double x = 0.0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) x += src[k];
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-            if (i == 0) outp[w] = x;                         // (a skipped term left zeros)
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // s_red is read: the next tile may write it
         if (!more) break;
         tile = nxt;
         buf ^= 1;                                            // the other staging buffer: its last readers passed the barrier above
@@ -1236,7 +1247,10 @@ int launch_moments(const MomentArgs& a0, hipStream_t s) {
         static const bool mx_on = !(std::getenv("MOGP_MOM_X") && std::atoi(std::getenv("MOGP_MOM_X")) == 0);
         if (mx_on && !env && a.D == 1 && a.W == 5 && a.T <= 4 && a.row_mod <= 1 && a.xc == nullptr) {
             static const int ncu = []() { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256; return pr.multiProcessorCount; }();
-            hipLaunchKernelGGL(k_moments_x<4>, dim3(std::min(a.ntiles, ncu)), dim3(512), 0, s, a);      // (the reduction staging of eight terms does not fit in LDS)
+            // (the reduction staging of eight terms does not fit in LDS; three terms -- every BASELINE config of the exact model -- get an instantiation of their
+            // own: the moments now live in registers across tiles, and five fewer accumulators keep the kernel clear of spills)
+            if (a.T <= 3) hipLaunchKernelGGL(k_moments_x<3>, dim3(std::min(a.ntiles, ncu)), dim3(512), 0, s, a);
+            else hipLaunchKernelGGL(k_moments_x<4>, dim3(std::min(a.ntiles, ncu)), dim3(512), 0, s, a);
             HIP_TRY(hipGetLastError());
             rc = 0;
         } else
