@@ -257,8 +257,11 @@ def probe_child(name, reps):
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
         t = torch.tensor([1.0, rank + 1.0], dtype=torch.float64)
         dist.all_reduce(t)
-        if name == "hang" and rank == world - 1:
-            time.sleep(3600)
+        if name == "hang":
+            if rank == 0:                         # a finished stage's line must survive the watchdog
+                print(json.dumps({"rccl_ranks": int(t[0].item()), "stage": "before the hang"}), flush=True)
+            if rank == world - 1:
+                time.sleep(3600)
         dist.barrier()
         if rank == 0:
             print(json.dumps({"rccl_ranks": int(t[0].item()), "rank_sum_ok": int(t[1].item()) == world * (world + 1) // 2}), flush=True)
@@ -281,6 +284,14 @@ def probe_child(name, reps):
     def sync():
         torch.cuda.synchronize()
 
+    def emit(d):
+        """rank 0: one JSON line per finished stage -- a later stage that hangs is killed by the parent's watchdog, which keeps the last line"""
+        if rank == 0:
+            sys.stdout.flush()
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+            print(json.dumps(d), flush=True)
+
     mogptk_amd.use_single_device()
     l0 = float(m.loss()); g0 = [p.grad.copy() for p in m.parameters()]
     sync(); t = time.perf_counter()
@@ -290,39 +301,52 @@ def probe_child(name, reps):
     comm = mogptk_amd.use_distributed()
     comm.force = True
     seen, rsum = _lib.comm_selftest(local_rank)            # one all-reduce issued by the library over ITS communicator
-    l1 = float(m.loss()); g1 = [p.grad.copy() for p in m.parameters()]
-    dist.barrier(); sync(); t = time.perf_counter()
-    for _ in range(reps):
-        m.loss()
-    sync(); dist.barrier(); t_shard = (time.perf_counter() - t) / reps
-    res = dict(ms_one_gpu=1e3 * t_single, ms_sharded=1e3 * t_shard, speedup=t_single / t_shard, evals_per_s_sharded=1.0 / t_shard,
-               rccl_ranks=seen, rank_sum_ok=(rsum == world * (world + 1) // 2), transport=comm.transport,
-               rel_loss=abs(l1 - l0) / abs(l0),
-               rel_grad=max(float(np.max(np.abs(b - c)) / np.max(np.abs(c))) for b, c in zip(g1, g0)))
+    res = dict(ms_one_gpu=1e3 * t_single, rccl_ranks=seen, rank_sum_ok=(rsum == world * (world + 1) // 2), transport=comm.transport, stage="communicator up")
+    emit(res)
+
+    def timed_sharded(env):
+        """one sharded evaluation for the parity numbers, then `reps` timed ones, under the given switches (read per evaluation by the library)"""
+        old_env = {k_: os.environ.get(k_) for k_ in env}
+        os.environ.update(env)
+        try:
+            lv = float(m.loss()); gv = [p.grad.copy() for p in m.parameters()]
+            dist.barrier(); sync(); t0 = time.perf_counter()
+            for _ in range(reps):
+                m.loss()
+            sync(); dist.barrier()
+            ts = (time.perf_counter() - t0) / reps
+            return {"ms_sharded": 1e3 * ts, "rel_loss": abs(lv - l0) / abs(l0),
+                    "rel_grad": max(float(np.max(np.abs(b - c)) / np.max(np.abs(c))) for b, c in zip(gv, g0))}
+        finally:
+            for k_, v_ in old_env.items():
+                if v_ is None:
+                    os.environ.pop(k_, None)
+                else:
+                    os.environ[k_] = v_
+
     if name == "cfg3" and world > 1:
-        # the A/B the exchange was built with switches for (mogp_api.hip:sharded_inverse): the whole panel in ONE message on the critical stream
-        # (rounds 1-4) and the pivot block inverted ONCE, by its owner, with an all-reduce of the factor -- against the default timed above
-        # (two messages, the large one on a communication stream; every rank repeats the 512 x 512 inversion).  Read per evaluation.
+        # Three forms of the exchange (mogp_api.hip:sharded_inverse), the most conservative FIRST, a line after each: the whole panel of a pivot
+        # block in ONE message on the critical stream (rounds 1-4); the default -- two messages, the large one on a communication stream underneath the
+        # block's inversion; and the pivot block inverted ONCE, by its owner, with an all-reduce of the factor.  The headline numbers are the default's
+        # (the one-message form's if the default did not finish).
         variants = {}
-        for vname, env in (("one_message", {"MOGP_SHARD_SPLIT": "0"}), ("factor_once", {"MOGP_SHARD_FACTOR_ONCE": "1"})):
-            old_env = {k_: os.environ.get(k_) for k_ in env}
-            os.environ.update(env)
+        for vname, env in (("one_message", {"MOGP_SHARD_SPLIT": "0"}), ("split", {}), ("factor_once", {"MOGP_SHARD_FACTOR_ONCE": "1"})):
             try:
-                lv = float(m.loss())
-                dist.barrier(); sync(); t = time.perf_counter()
-                for _ in range(reps):
-                    m.loss()
-                sync(); dist.barrier()
-                variants[vname] = {"ms_sharded": 1e3 * (time.perf_counter() - t) / reps, "rel_loss": abs(lv - l0) / abs(l0)}
+                variants[vname] = timed_sharded(env)
             except Exception as e:
                 variants[vname] = {"error": repr(e)}
-            finally:
-                for k_, v_ in old_env.items():
-                    if v_ is None:
-                        os.environ.pop(k_, None)
-                    else:
-                        os.environ[k_] = v_
-        res["variants"] = variants
+            best = variants.get("split") if "ms_sharded" in variants.get("split", {}) else variants.get("one_message", {})
+            if "ms_sharded" in best:
+                res.update(ms_sharded=best["ms_sharded"], speedup=1e3 * t_single / best["ms_sharded"], evals_per_s_sharded=1e3 / best["ms_sharded"],
+                           rel_loss=best["rel_loss"], rel_grad=best["rel_grad"], headline_variant="split" if best is variants.get("split") else "one_message")
+            res["variants"] = variants
+            res["stage"] = "variant %s done" % vname
+            emit(res)
+    else:
+        v = timed_sharded({})
+        res.update(ms_sharded=v["ms_sharded"], speedup=1e3 * t_single / v["ms_sharded"], evals_per_s_sharded=1e3 / v["ms_sharded"], rel_loss=v["rel_loss"],
+                   rel_grad=v["rel_grad"], stage="timed")
+        emit(res)
     h = getattr(m, "_handle", None)
     if name in ("cfg3", "cfg2") and h is not None:         # where one sharded evaluation spends its time (HIP events, summed over the pivot blocks)
         h.set_profiling(True)
@@ -335,13 +359,10 @@ def probe_child(name, reps):
                               "(exchange_comm_stream) on the communication stream -- wait_for_comm_stream is what the critical stream still waited for it")
     if name.startswith("cfg5"):
         res["N"] = 100000 * (world if name == "cfg5_weak" else 1)
+    res["stage"] = "complete"
+    emit(res)
     mogptk_amd.use_single_device()
     mogptk_amd.shutdown_distributed()
-    if rank == 0:
-        sys.stdout.flush()
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-        print(json.dumps(res), flush=True)
     dist.destroy_process_group()
 
 
@@ -364,11 +385,21 @@ def run_probe(name, port, timeout_s, reps):
             os.killpg(p.pid, signal.SIGKILL)
         except Exception:
             p.kill()
+        so = ""
         try:
-            p.communicate(timeout=10)
+            so, _ = p.communicate(timeout=10)
         except Exception:
             pass
-        return {"error": "the probe did not finish within %.0f s (watchdog); its processes were killed" % timeout_s}
+        lines = [l for l in (so or "").splitlines() if l.startswith("{")]
+        r = {}
+        if lines:                                   # what the child had finished before it hung: every stage prints a line
+            try:
+                r = json.loads(lines[-1])
+            except Exception:
+                r = {}
+        r["error"] = "the probe did not finish within %.0f s (watchdog); its processes were killed%s" % (
+            timeout_s, (" -- the numbers are those of the stages it had finished (last: %s)" % r.get("stage")) if r else "")
+        return r
     took = time.perf_counter() - t0
     if p.returncode != 0:
         return {"error": "probe exited with code %d: %s" % (p.returncode, (se or "")[-400:])}
@@ -481,7 +512,7 @@ def sharded_headline(sharded, world):
     mogp_exact_eval_sharded against the same evaluation on one GPU of the same job (`value` beside it is N independent replicas of configs[1])"""
     r = dict((sharded or {}).get("cfg3") or {})
     keys = ("ms_one_gpu", "ms_sharded", "speedup", "evals_per_s_sharded", "rccl_ranks", "rank_sum_ok", "transport", "rel_loss", "rel_grad",
-            "exchange_ms", "serial_ms", "next_cols_ms", "bulk_ms", "exchange_comm_stream_ms", "wait_for_comm_stream_ms", "variants", "error")
+            "exchange_ms", "serial_ms", "next_cols_ms", "bulk_ms", "exchange_comm_stream_ms", "wait_for_comm_stream_ms", "variants", "headline_variant", "stage", "error")
     out = {"workload": CONFIGS["cfg3"][5], "ranks": world, "scaling": "strong"}
     out.update({k: r[k] for k in keys if k in r})
     if "speedup" in r:

@@ -71,6 +71,7 @@ def test_sharded_probes_are_child_groups_with_their_own_watchdog(tmp_path):
     assert r["dummy"]["rccl_ranks"] == 2 and r["dummy"]["rank_sum_ok"] is True, r
     assert r["dummy"]["probe_wall_s"] > 0
     assert "watchdog" in r["hang"]["error"], r
+    assert r["hang"].get("rccl_ranks") == 2 and r["hang"].get("stage") == "before the hang", r      # what the child had finished is kept
     assert "skipped" in r["after_hang"]["error"], r            # a probe behind one that hung is not started
 
 
