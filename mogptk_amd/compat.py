@@ -375,3 +375,215 @@ def load_reference_model(source):
     if not isinstance(top, _Bag) or "gpr" not in top.state() or "dataset" not in top.state():
         raise ValueError("not a model checkpoint of the reference")
     return _convert_model(top)
+
+
+# ======================================================================================================================================
+# Writing a checkpoint the REFERENCE reads (`mogptk.LoadModel`, reference mogptk/model.py:62-74), without the reference installed.
+#
+# The file must name the reference's classes (`mogptk.models.mosm.MOSM`, `mogptk.gpr.model.Exact`, ...) and carry the attribute dictionaries
+# their methods expect after `pickle.load` (no __init__ runs on that side: everything an __init__ would have set has to be in the state --
+# the dense identity `eye`, the quadrature nodes of the likelihood, torch.nn.Module's registries).  A small pickler writes the global
+# references and object states directly, so nothing is registered in sys.modules and no class of the reference is needed here; tensors are
+# written by torch itself.  Scope: Exact and Titsias inference with a Gaussian likelihood and no mean function, the kernels of the six model
+# wrappers (and sums / products of them), the Y transformers.  Anything else raises NotImplementedError naming the object.
+# ======================================================================================================================================
+class _Global:
+    """a name in a module of the reference; pickled as a global reference"""
+
+    def __init__(self, module, qualname):
+        self.module, self.qualname = module, qualname
+
+    def __call__(self, *a, **k):                 # save_reduce wants a callable
+        raise TypeError("placeholder for %s.%s" % (self.module, self.qualname))
+
+
+class _Obj:
+    """an instance of a class of the reference (or of torch) with the given attribute dictionary"""
+
+    def __init__(self, cls, state):
+        self.cls, self.state = cls, state
+
+
+class _Par:
+    """a `mogptk.gpr.parameter.Parameter`: rebuilt on the reference's side by Parameter._rebuild (gpr/parameter.py:157-177)"""
+
+    def __init__(self, args):
+        self.args = args
+
+
+class _RefPickler(pickle._Pickler):
+    dispatch = dict(pickle._Pickler.dispatch)
+
+    def _save_global_name(self, g):
+        self.save(g.module)
+        self.save(g.qualname)
+        self.write(pickle.STACK_GLOBAL)
+        self.memoize(g)
+
+    def _save_obj(self, o):
+        self.save(o.cls)
+        self.save(())
+        self.write(pickle.NEWOBJ)
+        self.memoize(o)
+        self.save(o.state)
+        self.write(pickle.BUILD)
+
+    def _save_par(self, p):
+        self.save_reduce(_PARAMETER_REBUILD, p.args, obj=p)
+
+    dispatch[_Global] = _save_global_name
+    dispatch[_Obj] = _save_obj
+    dispatch[_Par] = _save_par
+
+
+_PARAMETER_REBUILD = _Global("mogptk.gpr.parameter", "Parameter._rebuild")
+_REF_KERNEL_MODULE = {
+    "AddKernel": "kernel", "MulKernel": "kernel", "MixtureKernel": "kernel",
+    "SpectralKernel": "singleoutput", "SpectralMixtureKernel": "singleoutput", "SquaredExponentialKernel": "singleoutput",
+    "IndependentMultiOutputKernel": "multioutput", "MultiOutputSpectralMixtureKernel": "multioutput", "CrossSpectralKernel": "multioutput",
+    "LinearModelOfCoregionalizationKernel": "multioutput", "GaussianConvolutionProcessKernel": "multioutput",
+    "MultiOutputHarmonizableSpectralKernel": "multioutput", "MultiOutputSpectralKernel": "multioutput",
+    "UncoupledMultiOutputSpectralKernel": "multioutput",
+}
+_REF_WRAPPER_MODULE = {"MOSM": "models.mosm", "SM": "models.sm", "CSM": "models.csm", "SM_LMC": "models.sm_lmc", "CONV": "models.conv",
+                       "MOHSM": "models.mohsm", "Model": "model"}
+_REF_TRANSFORMER_STATE = {"TransformDetrend": ("degree", "dim", "coef"), "TransformStandard": ("mean", "std"),
+                          "TransformNormalize": ("ymin", "ymax"), "TransformLog": ("shift", "mean"), "TransformLinear": ("bias", "slope")}
+
+
+def _module_state(own, parameters=(), modules=(), first=None):
+    """attribute dictionary of a torch.nn.Module in the order the reference's constructors leave it: what they set before
+    torch.nn.Module.__init__ (`first`), the registries that __init__ creates (taken from a fresh Module of the installed torch; a reader with
+    a newer torch adds the ones it misses in Module.__setstate__), then the class's own attributes"""
+    import torch
+    st = dict(first or {})
+    st.update(torch.nn.Module().__dict__)
+    st["_parameters"].update(parameters)
+    st["_modules"].update(modules)
+    st.update(own)
+    return st
+
+
+class _Exporter:
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.pars = {}                                           # id(our Parameter) -> its _Par (one object per parameter: pegging keeps identity)
+
+    def tensor(self, a):
+        return self.torch.tensor(np.array(a, dtype=np.float64), dtype=self.torch.float64)
+
+    def bound(self, b):
+        return None if b is None else self.tensor(b)
+
+    def parameter(self, p):
+        got = self.pars.get(id(p))
+        if got is not None:
+            return got
+        if p.prior is not None:
+            raise NotImplementedError("parameter %s carries a prior; priors are not written" % p._name)
+        out = _Par(None)
+        self.pars[id(p)] = out
+        peg = None if p.pegged_parameter is None else self.parameter(p.pegged_parameter)
+        from collections import OrderedDict
+        out.args = (self.torch._utils._rebuild_parameter, (self.tensor(p.data), True, OrderedDict()), p._name, self.bound(p.lower),
+                    self.bound(p.upper), None, bool(p.train), peg, p.pegged_transform, int(p.num_parameters))
+        return out
+
+    def own_parameters(self, holder):
+        return [(n, self.parameter(holder.__dict__[n])) for n in holder.__dict__.get("_order", []) if isinstance(holder.__dict__[n], _gpr.Parameter)]
+
+    def module_list(self, items):
+        return _Obj(_Global("torch.nn.modules.container", "ModuleList"), _module_state({}, modules=[(str(i), m) for i, m in enumerate(items)]))
+
+    def kernel(self, k):
+        name = type(k).__name__
+        where = _REF_KERNEL_MODULE.get(name)
+        if where is None or type(k) is not getattr(_gpr, name, None):
+            raise NotImplementedError("the checkpoint writer does not cover the kernel %s" % name)
+        own = {"input_dims": None if name == "IndependentMultiOutputKernel" else k.input_dims, "_active_dims": None, "output_dims": k.output_dims}
+        if "twopi" in k.__dict__:
+            own["twopi"] = np.float64(k.twopi)
+        mods = []
+        if isinstance(k.__dict__.get("kernels"), (list, tuple)):
+            mods.append(("kernels", self.module_list([self.kernel(s) for s in k.kernels])))
+        return _Obj(_Global("mogptk.gpr." + where, name), _module_state(own, self.own_parameters(k), mods))
+
+    def likelihood(self, lik):
+        if type(lik) is not _gpr.GaussianLikelihood:
+            raise NotImplementedError("the checkpoint writer covers the Gaussian likelihood only, not %s" % type(lik).__name__)
+        q = lik.quadrature                                       # reference gpr/likelihood.py:65-81, :90: the nodes every Likelihood object carries
+        quad = _Obj(_Global("mogptk.gpr.likelihood", "GaussHermiteQuadrature"),
+                    {"t": self.tensor(q.t).reshape(-1, 1), "w": self.tensor(q.w).reshape(-1, 1), "deg": int(q.deg)})
+        return _Obj(_Global("mogptk.gpr.likelihood", "GaussianLikelihood"),
+                    _module_state({"quadrature": quad, "output_dims": lik.output_dims}, self.own_parameters(lik)))
+
+    def inference(self, g):
+        name = type(g).__name__
+        if type(g) not in (_gpr.Exact, _gpr.Titsias):
+            raise NotImplementedError("the checkpoint writer covers Exact and Titsias inference, not %s" % name)
+        if g.mean is not None:
+            raise NotImplementedError("mean functions are not written")
+        X = np.asarray(g.X, dtype=np.float64)
+        own, first = {}, {}
+        if name == "Exact":
+            dv = g.data_variance
+            first["data_variance"] = None if dv is None else self.tensor(dv)
+        own.update({"X": self.tensor(X), "y": self.tensor(np.reshape(g.y, (-1, 1))), "mean": None, "jitter": float(g.jitter),
+                    "input_dims": int(X.shape[1]), "_compiled_forward": None})
+        pars = []
+        if name == "Titsias":
+            own["eye"] = self.torch.eye(g.Z.data.shape[0], dtype=self.torch.float64)
+            pars.append(("Z", self.parameter(g.Z)))
+        else:
+            own["eye"] = self.torch.eye(X.shape[0], dtype=self.torch.float64)
+        own["log_marginal_likelihood_constant"] = np.float64(0.5 * X.shape[0] * np.log(2.0 * np.pi))
+        return _Obj(_Global("mogptk.gpr.model", name),
+                    _module_state(own, pars, [("kernel", self.kernel(g.kernel)), ("likelihood", self.likelihood(g.likelihood))], first))
+
+    def transformer(self, t):
+        name = type(t).__name__
+        keys = _REF_TRANSFORMER_STATE.get(name)
+        if keys is None or type(t) is not getattr(_transformer, name, None):
+            raise NotImplementedError("the checkpoint writer does not cover the transformer %s" % name)
+        return _Obj(_Global("mogptk.transformer", name), {k: getattr(t, k) for k in keys})
+
+    def data(self, d):
+        D = d.X.shape[1]
+        st = {"X": np.array(d.X, dtype=np.float64), "Y": np.array(d.Y, dtype=np.float64),
+              "Y_err": None if d.Y_err is None else np.array(d.Y_err, dtype=np.float64),
+              "X_pred": None if d.X_pred is None or d.X_pred is d.X else np.array(d.X_pred, dtype=np.float64),
+              "mask": np.array(d.mask, dtype=bool), "F": getattr(d, "F", None),
+              "X_dtypes": list(getattr(d, "X_dtypes", [np.dtype("float64")] * D)),
+              "Y_transformer": _Obj(_Global("mogptk.transformer", "Transformer"),
+                                    {"transformers": [self.transformer(t) for t in d.Y_transformer.transformers]}),
+              "removed_ranges": getattr(d, "removed_ranges", [[] for _ in range(D)]),
+              "X_labels": list(getattr(d, "X_labels", ["X"] * D)), "name": d.name, "Y_label": getattr(d, "Y_label", "Y")}
+        return _Obj(_Global("mogptk.data", "Data"), st)
+
+    def model(self, m):
+        name = type(m).__name__
+        where = _REF_WRAPPER_MODULE.get(name)
+        from . import model as _model, wrappers as _wrappers
+        if where is None or type(m) is not (getattr(_wrappers, name, None) or _model.Model):
+            raise NotImplementedError("the checkpoint writer does not cover the model class %s" % name)
+        st = {"name": m.name, "dataset": _Obj(_Global("mogptk.dataset", "DataSet"), {"channels": [self.data(c) for c in m.dataset.channels]}),
+              "is_multioutput": m.gpr.kernel.output_dims is not None, "gpr": self.inference(m.gpr), "iters": int(m.iters),
+              "times": np.array(m.times, dtype=np.float64), "losses": np.array(m.losses, dtype=np.float64),
+              "errors": np.array(m.errors, dtype=np.float64)}
+        for key in ("Q", "Rq", "P"):
+            if key in m.__dict__:
+                st[key] = m.__dict__[key]
+        return _Obj(_Global("mogptk." + where, name), st)
+
+
+def dump_reference_model(model):
+    """bytes of a checkpoint of `model` that the reference's `mogptk.LoadModel` reads (see the block comment above for the scope)"""
+    try:
+        ex = _Exporter()
+    except ImportError as e:
+        raise ImportError("a reference checkpoint stores torch tensors: torch must be importable to write one") from e
+    top = ex.model(model)
+    buf = io.BytesIO()
+    _RefPickler(buf, protocol=4).dump(top)
+    return buf.getvalue()

@@ -553,15 +553,24 @@ class Model:
     def num_training_points(self):
         return sum(len(channel.get_train_data()[1]) for channel in self.dataset)
 
-    def save(self, filename):
-        """reference mogptk/model.py:320-336 (pickles the whole model; device handles are dropped and rebuilt lazily)"""
+    def save(self, filename, reference=False):
+        """reference mogptk/model.py:320-336 (pickles the whole model; device handles are dropped and rebuilt lazily).
+
+        reference=True writes the file in the REFERENCE's format instead -- `mogptk.LoadModel` of the reference reads it (and so does
+        LoadModel here): Exact / Titsias models of the six wrappers, see mogptk_amd.compat.dump_reference_model for the scope."""
         filename += ".npy"
+        if reference:
+            from . import compat
+            raw = compat.dump_reference_model(self)           # before the old file goes: a model outside the writer's scope leaves it alone
         try:
             os.remove(filename)
         except OSError:
             pass
         with open(filename, "wb") as w:
-            pickle.dump(self, w)
+            if reference:
+                w.write(raw)
+            else:
+                pickle.dump(self, w)
 
     def log_marginal_likelihood(self):
         """reference mogptk/model.py:338-348"""

@@ -4,6 +4,7 @@ semantics of the product package, with the device replaced by the numpy table mo
 The native library is NOT exercised here (see tests/test_gpu_parity.py for that); results are compared with the
 reference's own outputs in tests/golden/.
 """
+import os
 import pickle
 import numpy as np
 import pytest
@@ -638,10 +639,128 @@ def check_reference_checkpoints(tmp_path, tol_value=1e-12, tol_loss=1e-8, tol_gr
             ref = fx[tag + key]
             fin = np.isfinite(ref)                               # (the log of a zero Poisson count is -inf on both sides)
             assert np.array_equal(cat(got)[~fin], ref[~fin]) and np.max(np.abs(cat(got)[fin] - ref[fin])) <= tol_pred * max(1.0, np.max(np.abs(ref[fin]))), (tag, key)
-        # and back out through this package's own save / load
+        # and back out through this package's own save / load, and through a file in the reference's format
         m.save(str(tmp_path / ("own_%s" % tag)))
         m2 = mogptk_amd.LoadModel(str(tmp_path / ("own_%s" % tag)))
         assert abs(m2.loss() - loss) <= 1e-12 * max(1.0, abs(loss))
+        if tag in WRITER_TAGS:
+            m.save(str(tmp_path / ("back_%s" % tag)), reference=True)
+            m3 = mogptk_amd.LoadModel(str(tmp_path / ("back_%s" % tag)))
+            assert type(m3) is type(m) and abs(m3.loss() - loss) <= 1e-12 * max(1.0, abs(loss))
+
+
+WRITER_TAGS = ("mosm", "sm", "csm", "smlmc", "conv", "titsias")
+
+
+def _checkpoint_tree(o, pars):
+    """a pickled model of the reference, read into state bags, as nested plain data: class names, attribute dictionaries IN ORDER, tensors as
+    arrays, each parameter once (pegging refers to it by number)"""
+    import torch
+    from mogptk_amd import compat
+    if isinstance(o, compat._Bag):
+        return ("obj", o._mod, o._cls, [(k, _checkpoint_tree(v, pars)) for k, v in o.state().items() if k != "compiled_forward"])
+    if isinstance(o, compat._RefParameter):
+        if id(o) in pars:
+            return ("parameter", pars[id(o)])
+        pars[id(o)] = len(pars)
+        return ("parameter", pars[id(o)], o.name, o.data, o.lower, o.upper, o.train, o.num_parameters, o.prior,
+                _checkpoint_tree(o.pegged_parameter, pars), repr(o.pegged_transform))
+    if isinstance(o, torch.nn.ModuleList):
+        return ("obj", "torch.nn.modules.container", "ModuleList", [(k, _checkpoint_tree(v, pars)) for k, v in o.__dict__.items()])
+    if isinstance(o, torch.Tensor):
+        return ("tensor", str(o.dtype), o.detach().numpy())
+    if isinstance(o, dict):
+        return (type(o).__name__, [(k, _checkpoint_tree(v, pars)) for k, v in o.items()])
+    if isinstance(o, (list, tuple)):
+        return (type(o).__name__, [_checkpoint_tree(v, pars) for v in o])
+    return (type(o).__name__, o)
+
+
+def _tree_differences(a, b, path, out):
+    if type(a) is not type(b):
+        out.append((path, type(a).__name__, type(b).__name__))
+    elif isinstance(a, (tuple, list)):
+        if len(a) != len(b):
+            out.append((path, "length", len(a), len(b)))
+        for i, (x, y) in enumerate(zip(a, b)):
+            _tree_differences(x, y, "%s/%s" % (path, x[0] if isinstance(x, tuple) and x and isinstance(x[0], str) else i), out)
+    elif isinstance(a, np.ndarray):
+        if a.shape != b.shape or a.dtype != b.dtype or not np.array_equal(a, b, equal_nan=True):
+            out.append((path, "array", a.shape, b.shape, a.dtype, b.dtype))
+    elif a != b:
+        out.append((path, a, b))
+
+
+def test_written_checkpoints_are_what_the_reference_writes():
+    """SURVEY 8f-4, the other direction.  A model read from a file of the reference and written back in the reference's format
+    (compat.dump_reference_model, no reference installed) has the same object tree as the reference's own file: the same classes under the
+    same module names, the same attributes in the same order, the same tensors (data, the dense identity, the quadrature nodes) and arrays,
+    masks, fitted transformers, bounds, train flags, pegging and history -- bit for bit."""
+    pytest.importorskip("torch")
+    import io
+    from mogptk_amd import compat
+    fx = load("checkpoints.npz")
+    for tag in WRITER_TAGS:
+        raw = fx[tag + "_file"].tobytes()
+        written = compat.dump_reference_model(compat.load_reference_model(raw))
+        assert compat.is_reference_checkpoint(written)
+        theirs = _checkpoint_tree(compat._Unpickler(io.BytesIO(raw)).load(), {})
+        ours = _checkpoint_tree(compat._Unpickler(io.BytesIO(written)).load(), {})
+        out = []
+        _tree_differences(theirs, ours, tag, out)
+        assert not out, out[:5]
+
+
+def test_the_writer_says_what_it_does_not_cover(tmp_path):
+    pytest.importorskip("torch")
+    fx = load("checkpoints.npz")
+    from mogptk_amd import compat
+    m = compat.load_reference_model(fx["snelson_file"].tobytes())
+    (tmp_path / "keep.npy").write_bytes(b"previous file")
+    with pytest.raises(NotImplementedError, match="Snelson"):
+        m.save(str(tmp_path / "keep"), reference=True)
+    assert (tmp_path / "keep.npy").read_bytes() == b"previous file"
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/mogptk"), reason="needs the reference itself (build container only)")
+def test_the_reference_reads_written_checkpoints(tmp_path):
+    """the reference's own LoadModel (mogptk/model.py:62-74), in a process of its own, reads the files this package writes and computes the
+    loss and the predictions recorded for its own files in checkpoints.npz"""
+    pytest.importorskip("torch")
+    import subprocess
+    import sys
+    from mogptk_amd import compat
+    fx = load("checkpoints.npz")
+    for tag in WRITER_TAGS:
+        (tmp_path / ("w_%s.npy" % tag)).write_bytes(compat.dump_reference_model(compat.load_reference_model(fx[tag + "_file"].tobytes())))
+    script = """
+import sys, types, json
+ip, disp = types.ModuleType("IPython"), types.ModuleType("IPython.display")
+disp.display = lambda *a, **k: None; disp.HTML = lambda s: s; ip.display = disp
+sys.modules["IPython"] = ip; sys.modules["IPython.display"] = disp
+sys.path.insert(0, "/root/reference")
+import numpy as np, mogptk
+out = {}
+for tag in sys.argv[2:]:
+    m = mogptk.LoadModel(sys.argv[1] + "/w_" + tag)
+    loss = float(m.loss())
+    X, mu, lower, upper = m.predict(transformed=False)
+    m.train(method="Adam", lr=0.01, iters=2, verbose=False)          # and it trains on
+    out[tag] = {"cls": type(m).__module__ + "." + type(m).__name__, "loss": loss, "mu": np.concatenate([np.asarray(v).reshape(-1) for v in mu]).tolist(),
+                "upper": np.concatenate([np.asarray(v).reshape(-1) for v in upper]).tolist(), "iters": int(m.iters)}
+print("RESULT " + json.dumps(out))
+"""
+    r = subprocess.run([sys.executable, "-c", script, str(tmp_path)] + list(WRITER_TAGS), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    got = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    for tag in WRITER_TAGS:
+        g = got[tag]
+        assert g["cls"].startswith("mogptk.models.")
+        assert abs(g["loss"] - float(fx[tag + "_loss"])) <= 1e-12 * max(1.0, abs(float(fx[tag + "_loss"]))), tag
+        assert np.max(np.abs(np.array(g["mu"]) - fx[tag + "_mu"])) <= 1e-10 * max(1.0, np.max(np.abs(fx[tag + "_mu"]))), tag
+        assert np.max(np.abs(np.array(g["upper"]) - fx[tag + "_upper"])) <= 1e-10 * max(1.0, np.max(np.abs(fx[tag + "_upper"]))), tag
+        assert g["iters"] == int(fx[tag + "_history"][0]) + 2
 
 
 def test_reference_checkpoints_load_without_the_reference(tmp_path):
