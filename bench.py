@@ -324,13 +324,15 @@ def probe_child(name, reps):
                 else:
                     os.environ[k_] = v_
 
-    if name == "cfg3" and world > 1:
+    if name == "cfg3":
         # Three forms of the exchange (mogp_api.hip:sharded_inverse), the most conservative FIRST, a line after each: the whole panel of a pivot
         # block in ONE message on the critical stream (rounds 1-4); the default -- two messages, the large one on a communication stream underneath the
         # block's inversion; and the pivot block inverted ONCE, by its owner, with an all-reduce of the factor.  The headline numbers are the default's
         # (the one-message form's if the default did not finish).
         variants = {}
         for vname, env in (("one_message", {"MOGP_SHARD_SPLIT": "0"}), ("split", {}), ("factor_once", {"MOGP_SHARD_FACTOR_ONCE": "1"})):
+            if vname == "factor_once" and world == 1:
+                continue                                 # (one rank owns every pivot block: nothing to compare)
             try:
                 variants[vname] = timed_sharded(env)
             except Exception as e:

@@ -1598,8 +1598,9 @@ static int sharded_inverse(mogp_model* m, const double* noise_var, const double*
     // up to 134 MB at configs[2] -- is needed by the panel products behind it.  So: small message on the critical stream, large message on a
     // communication stream of its own (the context's third stream, idle in this schedule) UNDERNEATH the serial part; the critical stream waits
     // for it only where the panels start.  Both are collectives of the same communicator issued in the same order on every rank.
-    // MOGP_SHARD_SPLIT=0: one message on the critical stream, as in rounds 1-4.
-    { const char* e = std::getenv("MOGP_SHARD_SPLIT"); m->sh_split = c.n > 1 && m->st3 && !(e && std::atoi(e) == 0); }
+    // MOGP_SHARD_SPLIT=0: one message on the critical stream, as in rounds 1-4.  (A group of ONE rank runs the same schedule -- its messages are
+    // copies -- so that the one-rank time measures what the schedule costs a rank, not a schedule of its own.)
+    { const char* e = std::getenv("MOGP_SHARD_SPLIT"); m->sh_split = m->st3 && !(e && std::atoi(e) == 0); }
     { const char* e = std::getenv("MOGP_SHARD_FACTOR_ONCE"); m->sh_factor_once = c.n > 1 && e && std::atoi(e) != 0; }
     const int PEV = 10;                                  // timing events per pivot block
     if (m->profiling) {

@@ -197,9 +197,11 @@ __global__ __launch_bounds__(256) void k_shard_pack(const double* __restrict__ A
         *reinterpret_cast<double2*>(dst + (int64_t)r * Kd + c) = *reinterpret_cast<const double2*>(src + (int64_t)r * ld + c);
     }
 }
+// (the rows of rank `own` are skipped: they are where they were packed from)
 __global__ __launch_bounds__(256) void k_shard_unpack(double* __restrict__ A, int64_t ld, int k0, int row_lo, int row_hi, int P, int64_t Kd, int64_t chunk,
-                                                      const double* __restrict__ recv) {
+                                                      const double* __restrict__ recv, int own) {
     const int r = blockIdx.z;
+    if (r == own) return;
     const int first = row_lo + ((r - row_lo % P) + P) % P;
     const int i = first + (int)blockIdx.x * P;
     if (i >= row_hi) return;
@@ -288,12 +290,13 @@ int shard_unpack_part(mogp_model* m, Spd& w, int kb, int part, DevBuf<double>& r
     const int64_t chunk = part_chunk(g, w.nb, P, part, maxrows, rowoff);
     part_rows(g, w.nb, part, lo, hi);
     if (maxrows > 0) {
-        hipLaunchKernelGGL(k_shard_unpack, dim3(maxrows, 8, P), dim3(256), 0, st, w.A.p, w.Npad, g.k0, lo, hi, P, g.Kd, chunk, recvb.p);
+        if (P > 1) hipLaunchKernelGGL(k_shard_unpack, dim3(maxrows, 8, P), dim3(256), 0, st, w.A.p, w.Npad, g.k0, lo, hi, P, g.Kd, chunk, recvb.p, m->sh_rank);
         HIP_TRY(hipGetLastError());
     }
     if (part != 1 && g.cols > 0) {
         for (int i = g.k0; i < g.k1; ++i) {
             const int r = i % P, idx = (i - first_owned(g.k0, P, r)) / P;
+            if (r == m->sh_rank) continue;                    // this rank's own rows never left
             RC(launch_copy2d(w.A.p + (int64_t)i * MOGP_TILE * w.Npad, w.Npad, recvb.p + (int64_t)r * chunk + rowoff + (int64_t)idx * MOGP_TILE * g.cols,
                              g.cols, MOGP_TILE, g.cols, 1.0, st));
         }

@@ -8,8 +8,8 @@ pass under torch.no_grad() fits (K, the dense eye it keeps, the noise product, t
               inputs of mogptk_amd/synth.py, its raw parameter values, wall time and peak memory;
   fd_ref      the reference's own central difference of that LML along ONE seeded raw-space direction (two more forward runs):
               a derivative of the reference that no code of this repository took part in;
-  lml_oracle, p*_grad   the numpy oracle (oracle/table_model.py:TableDeviceLean: the Gram from the term table, LAPACK dpotrf /
-              dpotri in place, moments of G = 1/2 (alpha alpha^T - Kj^-1), then the host chain rule) -- all 208 raw gradients.
+  lml_oracle, p*_grad   the numpy oracle (oracle/table_model.py:TableDeviceLean: the Gram from the term table, LAPACK potrf / potri in place
+              through torch (MKL: the OpenBLAS build scipy bundles stops with info = 16545 on this matrix), moments of G = 1/2 (alpha alpha^T - Kj^-1), then the host chain rule) -- all 208 raw gradients.
               lml_oracle must agree with lml_ref (asserted here to 1e-11) and the gradient's projection on the direction with fd_ref.
 
 Stages run as separate processes so that each one's memory is gone before the next starts:

@@ -255,6 +255,9 @@ def main():
     ap.add_argument("M", nargs="?", type=int, default=2048)
     ap.add_argument("--workers", type=int, default=0, help="> 0: the column-chunked evaluation on this many processes (the N = 100 000 fixture: 8)")
     ap.add_argument("--out", default="titsias_dz_truth.npz")
+    ap.add_argument("--add-ref-run", type=int, default=0, metavar="THREADS",
+                    help="add one more fp64 run of the reference, on this many torch threads, to an existing fixture (gz_ref_alt, ref_alt_threads, "
+                         "ref_alt_err): how far from the truth the reference lands depends on its own summation order")
     a = ap.parse_args()
     N, M = a.N, a.M
     C, Q = 4, 3
@@ -270,6 +273,26 @@ def main():
     sys.path.insert(0, "/root/reference")
     import torch
     import mogptk
+    if a.add_ref_run > 0:
+        out = dict(np.load(os.path.join(HERE, a.out)))
+        assert [int(v) for v in out["meta"]] == [C, Q, 1, 1, N, M], "the fixture was made for another size"
+        torch.set_num_threads(a.add_ref_run)
+        g = mogptk.gpr
+        T = lambda v: torch.tensor(np.asarray(v), dtype=torch.float64)
+        k = g.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=1)
+        k.weight.assign(h["weight"]); k.mean.assign(h["mean"]); k.variance.assign(h["variance"]); k.delay.assign(h["delay"]); k.phase.assign(h["phase"])
+        m = g.Titsias(k, T(X), T(y), Z=[M // C] * C, Z_init="grid", variance=s ** 2, jitter=jitter)
+        m.likelihood.scale.assign(s)
+        t0 = time.time()
+        loss = float(m.loss())
+        gz = -m.Z.grad.detach().numpy()[:, 1].copy()
+        truth = out["gz_truth"]
+        err = float(np.max(np.abs(gz - truth)) / np.max(np.abs(truth)))
+        print("reference on %d threads: loss %.10f in %.0f s; %.3e of the tensor from the truth (the fixture's first run: %.3e), %.3e from that run"
+              % (a.add_ref_run, loss, time.time() - t0, err, float(out["ref_err"]), float(np.max(np.abs(gz - out["gz_ref"])) / np.max(np.abs(truth)))))
+        out.update(gz_ref_alt=gz, ref_alt_threads=np.array(a.add_ref_run), ref_alt_err=np.array(err), loss_ref_alt=np.array(loss))
+        np.savez_compressed(os.path.join(HERE, a.out), **out)
+        return
     g = mogptk.gpr
     T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
     k = g.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C, input_dims=1)
