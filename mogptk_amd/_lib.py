@@ -3,9 +3,11 @@ ctypes binding of libmogp_hip.so (include/mogp_hip.h).  This is the only place t
 native library.  There is NO fallback: if the library is missing, or no gfx950 device is visible when a
 compute entry point is called, the call fails loudly.
 """
+import atexit
 import ctypes
 import os
 import threading
+import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -21,6 +23,7 @@ ST_GRAM, ST_POTRF, ST_TRTRI, ST_LAUUM, ST_SOLVE, ST_MOMENTS, ST_TOTAL, ST_GEMM_K
 _lib = None
 _lock = threading.RLock()
 _ctx = {}
+_live = weakref.WeakSet()             # open ExactHandles (shutdown() closes them before their contexts go)
 
 c_dp = ctypes.POINTER(ctypes.c_double)
 c_i64p = ctypes.POINTER(ctypes.c_int64)
@@ -183,6 +186,28 @@ def gram(device, C, D, table, X1, X2=None):
     return out
 
 
+def shutdown():
+    """Release every model and context of this process while the HIP runtime is still up.  Registered with atexit: left to the interpreter's
+    own teardown, the handles' destructors ran after the runtime's (harmless on its own, a crash inside rocprofv3's exit hooks under the
+    profiler).  Calling it earlier is allowed; the next use of the library makes a new context."""
+    with _lock:
+        for h in list(_live):
+            try:
+                h.close()
+            except Exception:
+                pass
+        if _lib is not None:
+            for c in list(_ctx.values()):
+                try:
+                    _lib.mogp_ctx_destroy(c)
+                except Exception:
+                    pass
+        _ctx.clear()
+
+
+atexit.register(shutdown)
+
+
 class ExactHandle:
     """Owner of one mogp_model (device workspaces for a fixed training set)."""
 
@@ -197,6 +222,7 @@ class ExactHandle:
         self._h = ctypes.c_void_p()             # stays null if creation fails: close() / __del__ then have nothing to destroy
         check(lib().mogp_model_create(context(device), self.N, self.D, C, _dp(X), _dp(y), ctypes.byref(h)))
         self._h = h
+        _live.add(self)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value is not None:

@@ -53,11 +53,8 @@ def main():
         os.environ["MOGP_FLOW"] = "0"
     loss2 = float(m.loss())
     print("normal evaluation again: loss %.10f (same: %s)" % (loss2, loss2 == loss0))
-    hd.close()                      # before the interpreter tears the library down (under rocprofv3 an implicit teardown at exit crashed in the tool's hooks)
     m._handle = None
-    for dev, ctx in list(_lib._ctx.items()):
-        _lib.lib().mogp_ctx_destroy(ctx)
-        del _lib._ctx[dev]
+    _lib.shutdown()                 # models and contexts go while the runtime is up (also registered with atexit: under rocprofv3 an implicit teardown crashed in the tool's exit hooks)
     return 0
 
 
