@@ -128,6 +128,12 @@ int  mogp_exact_predict(mogp_model* m, const double* noise_var, const double* da
 int  mogp_titsias_eval(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kff_diag, int flags,
                        double* elbo, double* mom_uu, double* mom_uf, double* gZ, double* trGA, double* dsigma,
                        double* jitter_abs, int64_t* info);
+/* what the last mogp_titsias_eval with MOGP_EVAL_GRAD left on the device, in the device's CHANNEL-SORTED order of Z's and X's rows (identical to
+ * the caller's when both came sorted by channel), padding removed (M: the rows of that call's Z) -- numerics diagnostics (tools/titsias_stage_errors.py), no reference seam:
+ *   which 0: dELBO/dKuu_jittered (M x M; its lower triangle is what the moment pass reads), 1: dELBO/dKuf WITHOUT its rank-one part (M x N),
+ *         2: beta (M), 3: r (N)  [the rank-one part is beta r^T], 4: v = L^-1 Kuf (M x N), 5: L, the lower Cholesky factor of Kuu + jitter (M x M),
+ *         6: Qs = v v^T / sigma^2 + I (M x M, symmetric), 7: its inverse Pq (M x M, symmetric), 8: t1 = Pq v y (M). */
+int  mogp_titsias_fetch(mogp_model* m, int which, int64_t M, double* out);
 /* replaces Titsias.predict_f (gpr/model.py:730-765), diagonal variance: mu[S], var[S]. */
 int  mogp_titsias_predict(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kss_diag,
                           int64_t S, const double* Xs, double* mu, double* var, int64_t* info);

@@ -53,6 +53,7 @@ SIGNATURES = {
                                           ctypes.c_int, c_dp, c_dp, c_i64p]),
     "mogp_titsias_eval": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, ctypes.c_double, ctypes.c_double, c_dp, ctypes.c_int,
                                          c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_i64p]),
+    "mogp_titsias_fetch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, c_dp]),
     "mogp_titsias_predict": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, ctypes.c_double, ctypes.c_double, c_dp,
                                             ctypes.c_int64, c_dp, c_dp, c_dp, c_i64p]),
     "mogp_titsias_eval_sharded": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, c_dp, ctypes.c_double, ctypes.c_double, c_dp, ctypes.c_int,
@@ -344,6 +345,14 @@ class ExactHandle:
     def mem_put(self, ptr, arr):
         arr = np.ascontiguousarray(arr, dtype=np.float64)
         check(lib().mogp_dev_copy(ctypes.c_void_p(ptr), arr.ctypes.data_as(ctypes.c_void_p), 8 * arr.size, 1))
+
+    def titsias_fetch(self, which, M):
+        """intermediates of the last Titsias gradient evaluation in the device's channel-sorted order (mogp_titsias_fetch): 0 dELBO/dKuu (M x M),
+        1 dELBO/dKuf without its rank-one part (M x N), 2 beta (M), 3 r (N), 4 v = L^-1 Kuf (M x N), 5 L (M x M), 6 Qs, 7 Pq = Qs^-1, 8 t1 = Pq v y"""
+        shape = {0: (M, M), 1: (M, self.N), 2: (M,), 3: (self.N,), 4: (M, self.N), 5: (M, M), 6: (M, M), 7: (M, M), 8: (M,)}[which]
+        out = np.empty(shape)
+        check(lib().mogp_titsias_fetch(self._h, int(which), int(M), _dp(out)))
+        return out
 
     def titsias_eval(self, Z, sigma, jitter, kff_diag, grad=True, sharded=False):
         """Titsias bound (+ gradient outputs) through mogp_titsias_eval, or -- this handle holding one shard of the data -- through

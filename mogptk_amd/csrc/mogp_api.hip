@@ -368,7 +368,26 @@ namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base) {
             g.B = w.invd.p + (int64_t)k * MOGP_TILE * MOGP_TILE; g.ldb = MOGP_TILE; g.b_kmajor = 0;
             g.C = panel; g.ldc = w.Npad; g.alpha = 1.0; g.beta = 0.0;
             g.mode = GM_RECT; g.small = 1; g.mt = 2 * rem; g.nt = 1; g.K = MOGP_TILE;      // 64x128 tiles: in place
+            if (w.refine_panels) {            // keep the panel as it came: the residual below is taken against it
+                if ((rc = w.pscr.ensure((size_t)w.Npad * MOGP_TILE))) return rc;
+                if ((rc = launch_copy2d(w.pscr.p, MOGP_TILE, panel, w.Npad, (int64_t)rem * MOGP_TILE, MOGP_TILE, 1.0, cq))) return rc;
+            }
             if ((rc = gemm_call(m, g, gemm_flops(g, nullptr), cq))) return rc;
+            if (w.refine_panels) {
+                // (round 5) P = A0 W^T is only as good as the explicit tile inverse: with L_kk of condition 4e4 (a 128-point stretch of the inducing
+                // grid of configs[4]) the leaf's W has |I - L W| = 3e-11 and the factor a backward error |L L^T - A| / |A| = 1.3e-11 -- four orders
+                // above LAPACK's, 5 % of the smallest eigenvalue of K_uu + jitter, and the reason dELBO/dZ sat twice as far from the 80-bit truth
+                // as the reference (tools/titsias_stage_errors.py, tools/titsias_chol_residual.py).  One step of iterative refinement against
+                // the factor itself, P += (A0 - P L_kk^T) W^T, brings the residual to 6e-16.  Two more small GEMMs per tile column; asked for by
+                // the sparse models' K_uu only (Spd::refine_panels; needs keep_L: the diagonal tile of A holds L_kk).
+                GemmArgs r1 = g;
+                r1.A = panel; r1.lda = w.Npad; r1.B = w.A.p + (int64_t)k * MOGP_TILE * (w.Npad + 1); r1.ldb = w.Npad;
+                r1.C = w.pscr.p; r1.ldc = MOGP_TILE; r1.alpha = -1.0; r1.beta = 1.0;
+                if ((rc = gemm_call(m, r1, gemm_flops(r1, nullptr), cq))) return rc;
+                GemmArgs r2 = g;
+                r2.A = w.pscr.p; r2.lda = MOGP_TILE; r2.C = panel; r2.ldc = w.Npad; r2.alpha = 1.0; r2.beta = 1.0;
+                if ((rc = gemm_call(m, r2, gemm_flops(r2, nullptr), cq))) return rc;
+            }
             const int inner = k1 - k - 1;            // columns k+1 .. k1-1 of this outer block
             if (inner > 0) {
                 GemmArgs u{};

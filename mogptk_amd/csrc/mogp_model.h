@@ -124,6 +124,8 @@ struct Spd {
     int64_t Npad = 0;
     int nb = 0;
     bool keep_L = false;                // spd_potrf also stores the diagonal tiles of L (the triangular-solve path needs the factor itself)
+    bool refine_panels = false;         // spd_potrf refines every panel once against L_kk itself (ill-conditioned K_uu of the sparse models; needs keep_L)
+    DevBuf<double> pscr;                // its scratch: one panel (Npad x 128)
     DevBuf<double> A, B, invd, logdet;
     DevBuf<double> Wm;                  // W = L^-1 when the inverse is streamed behind the factorisation (spd_potrf fuse_inverse)
     std::vector<TrtriLevel> levels;
@@ -163,7 +165,7 @@ struct Spd {
         flow_tasks_rhs.release(); flow_qmeta_rhs.release(); flow_rhs = FlowPlan(); flow_cur = nullptr;
         flow_tasks_replay.release(); flow_qmeta_replay.release(); flow_replay = FlowPlan();
         levels.clear(); sync_ev.clear();
-        A.release(); B.release(); invd.release(); logdet.release();
+        A.release(); B.release(); invd.release(); logdet.release(); pscr.release();
     }
 };
 

@@ -155,6 +155,7 @@ int snelson_front(mogp_model* m, int64_t M, const double* Z, const double* noise
     RC(launch_gram(ga, (int)tuf.size(), m->st));
 
     t.a.keep_L = true;
+    t.a.refine_panels = !(std::getenv("MOGP_REFINE_PANELS") && std::atoi(std::getenv("MOGP_REFINE_PANELS")) == 0);   // K_uu + jitter is ill-conditioned: mogp_api.hip:spd_potrf
     RC(spd_potrf(m, t.a));
     RC(spd_check_info(m, "Kuu", info));
     HIP_TRY(hipMemcpyAsync(t.v.p, t.B.p, (size_t)Mpad * Npad * sizeof(double), hipMemcpyDeviceToDevice, m->st));

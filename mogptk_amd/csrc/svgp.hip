@@ -93,6 +93,7 @@ int svgp_setup(mogp_model* m, int64_t M, const double* Z, const double* q_mu, co
     RC(launch_gram(ga, (int)tuu.size(), m->st));
     RC(launch_pad_identity(t.a.A.p, Mpad, M, Mpad, m->st));
     t.a.keep_L = true;
+    t.a.refine_panels = !(std::getenv("MOGP_REFINE_PANELS") && std::atoi(std::getenv("MOGP_REFINE_PANELS")) == 0);   // K_uu + jitter is ill-conditioned: mogp_api.hip:spd_potrf
     RC(spd_potrf(m, t.a));
     RC(spd_check_info(m, "Kuu", info));
     // q_mu and S in the device's order of the inducing points: row pos of the device = row sz.perm[pos] of the caller

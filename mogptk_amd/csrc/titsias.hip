@@ -238,6 +238,7 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     RC(launch_gram(ga, (int)t.n_tuf, side));
 
     t.a.keep_L = true;                                                          // the solves below need L itself, diagonal tiles included
+    t.a.refine_panels = !(std::getenv("MOGP_REFINE_PANELS") && std::atoi(std::getenv("MOGP_REFINE_PANELS")) == 0);   // K_uu + jitter is ill-conditioned: mogp_api.hip:spd_potrf
     // (round 5, measured and dropped: the chain of this factorisation on the CU-masked private stream, so that its one-workgroup kernels do not share
     // a CU with the K_uf Gram waves -- configs[4] 39.7-39.9 vs 39.3-39.5 ms, bit-identical: the panel and next-column products of the chain are
     // slower on 16 CUs than the leaves gain)
@@ -445,6 +446,30 @@ int mogp_titsias_eval(mogp_model* m, int64_t M, const double* Z, double sigma, d
                       double* elbo, double* mom_uu, double* mom_uf, double* gZ, double* trGA, double* dsigma,
                       double* jitter_abs, int64_t* info) {
     return titsias_eval_impl(m, M, Z, sigma, jitter, kff_diag, flags, elbo, mom_uu, mom_uf, gZ, trGA, dsigma, jitter_abs, info, false);
+}
+
+int mogp_titsias_fetch(mogp_model* m, int which, int64_t M, double* out) {
+    if (!m || !out || which < 0 || which > 8 || M <= 0) return fail(MOGP_EINVAL, "mogp_titsias_fetch: bad argument");
+    if (!m->tw || m->tw->Mpad <= 0 || m->tw->GA.n == 0) return fail(MOGP_EINVAL, "mogp_titsias_fetch: no gradient evaluation of the Titsias bound on this handle yet");
+    RC(use_device(m->ctx));
+    TitsiasWork& t = *m->tw;
+    const int64_t Mpad = t.Mpad, Npad = m->Npad, N = m->N;
+    if (M > Mpad) return fail(MOGP_EINVAL, "mogp_titsias_fetch: M is larger than the last evaluation's");
+    HIP_TRY(hipStreamSynchronize(m->st));
+    const double* src = nullptr; int64_t rows = 0, cols = 0, ld = 0;
+    switch (which) {
+        case 0: src = t.GA.p; rows = M; cols = M; ld = Mpad; break;
+        case 1: src = t.GB.p; rows = M; cols = N; ld = Npad; break;
+        case 2: src = t.vec.p + 4 * Mpad; rows = 1; cols = M; ld = Mpad; break;
+        case 3: src = t.vec.p + 8 * Mpad + Npad; rows = 1; cols = N; ld = Npad; break;
+        case 4: src = t.v.p; rows = M; cols = N; ld = Npad; break;
+        case 5: src = t.a.A.p; rows = M; cols = M; ld = Mpad; break;
+        case 6: src = t.Qs.p; rows = M; cols = M; ld = Mpad; break;
+        case 7: src = t.q.B.p; rows = M; cols = M; ld = Mpad; break;
+        default: src = t.vec.p + Mpad; rows = 1; cols = M; ld = Mpad; break;
+    }
+    HIP_TRY(hipMemcpy2D(out, (size_t)cols * sizeof(double), src, (size_t)ld * sizeof(double), (size_t)cols * sizeof(double), (size_t)rows, hipMemcpyDeviceToHost));
+    return MOGP_OK;
 }
 
 int mogp_titsias_eval_sharded(mogp_model* m, int64_t M, const double* Z, double sigma, double jitter, const double* kff_diag, int flags,

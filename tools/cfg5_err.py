@@ -23,6 +23,18 @@ print("loss rel err %.2e" % (abs(loss - float(fx["loss"])) / abs(float(fx["loss"
 g1 = [p.grad.copy() for p in m.parameters()]
 for p, f in zip(m.parameters(), fp):
     print("%-60s rel err %.3e" % (p._name, np.max(np.abs(p.grad - f["grad"])) / np.max(np.abs(f["grad"]))))
+try:
+    tr = load("titsias_dz_truth_cfg5.npz")
+    zp = [p for p in m.parameters() if p._name.endswith("induction_points")][0]
+    gz, truth = -zp.grad[:, 1], tr["gz_truth"]
+    for nm, g in (("device", gz), ("reference, 8 threads", tr["gz_ref"]), ("reference, 3 threads", tr["gz_ref_alt"])):
+        print("dELBO/dZ against the 80-bit truth, %-22s max-norm %.3e  2-norm %.3e  1 - cos %.2e" % (nm, np.max(np.abs(g - truth)) / np.max(np.abs(truth)),
+              np.linalg.norm(g - truth) / np.linalg.norm(truth), 1.0 - np.dot(g, truth) / np.linalg.norm(g) / np.linalg.norm(truth)))
+    d = gz - truth
+    blk = np.abs(d).reshape(C, -1)
+    print("  device error by channel (max): " + ", ".join("%.2e" % v for v in blk.max(axis=1) / np.max(np.abs(truth))))
+except FileNotFoundError:
+    pass
 import hashlib
 print("checksum", hashlib.sha1(b"".join(np.ascontiguousarray(g).tobytes() for g in g1) + np.float64(loss).tobytes()).hexdigest())
 loss2 = float(m.loss())

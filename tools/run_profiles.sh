@@ -13,7 +13,7 @@ for c in cfg3 cfg4 cfg5; do timeout 300 python bench.py --config $c --no-cpu-bas
 cd /tmp
 for c in cfg2 cfg3 cfg4 cfg5; do
   st=5; wu=2; if [ $c = cfg2 ]; then st=20; wu=5; fi      # the headline as the driver runs it: the average then is the steady state's, not the warm-up's
-  timeout -k 5 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --config $c --steps $st --warmup $wu --no-cpu-baseline --no-configs --no-shard-probe > $O/kt_$c.log 2>&1
+  timeout -k 5 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --config $c --steps $st --warmup $wu --sustained 0 --no-cpu-baseline --no-configs --no-shard-probe > $O/kt_$c.log 2>&1
 done
 # the dataflow kernel itself: ALONE on the replay plan (mogp_model_flow_replay; tools/flow_replay.py checks that it forms the same Kj^-1 bit for bit)
 for cnt in FETCH_SIZE WRITE_SIZE; do
@@ -23,10 +23,10 @@ done
 (cd $GRAFT_REPO_ROOT; timeout 200 python tools/flow_replay.py 8192 5) > $O/flow_replay.txt 2>&1
 rm -rf $O/pmcflow_FETCH_SIZE $O/pmcflow_WRITE_SIZE
 for cnt in FETCH_SIZE WRITE_SIZE; do
-  MOGP_FLOW=0 timeout -k 5 300 rocprofv3 --pmc $cnt --kernel-trace --output-format csv -d $O/pmc_$cnt -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-shard-probe > $O/pmc_$cnt.log 2>&1
+  MOGP_FLOW=0 timeout -k 5 300 rocprofv3 --pmc $cnt --kernel-trace --output-format csv -d $O/pmc_$cnt -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --sustained 0 --no-cpu-baseline --no-configs --no-shard-probe > $O/pmc_$cnt.log 2>&1
 done
-MOGP_FLOW=0 timeout -k 5 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc_valu -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-shard-probe > $O/pmc_valu.log 2>&1
-MOGP_FLOW=0 timeout -k 5 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-shard-probe > $O/pmc_mfma.log 2>&1
+MOGP_FLOW=0 timeout -k 5 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc_valu -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --sustained 0 --no-cpu-baseline --no-configs --no-shard-probe > $O/pmc_valu.log 2>&1
+MOGP_FLOW=0 timeout -k 5 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --sustained 0 --no-cpu-baseline --no-configs --no-shard-probe > $O/pmc_mfma.log 2>&1
 cd $GRAFT_REPO_ROOT
 for c in cfg2 cfg3 cfg4 cfg5; do python tools/ktrace.py $O/kt_$c --csv $O/${c}_kernel_stats.csv > /dev/null 2>&1; done
 python tools/eval_timeline.py $O/kt_cfg5 60 > $O/cfg5_timeline.txt 2>&1

@@ -113,15 +113,27 @@ def grads(L, mode, dt=np.float64):
         Lqi = sol(Lq, I); Pqe = Lqi.T @ Lqi                   # explicit inverse of the inner system
         Pqs = sol(Lq, sol(Lq, I), True)                       # the same by solves
         which = mode[1:] or "tge"                             # which uses take the explicit one: t(1), g(B), e (E)
+        if "n" in which:                                      # the explicit inverse after one Newton-Schulz step Pq <- Pq + Pq (I - Qs Pq) (two M^3 products)
+            Pqe = Pqe + Pqe @ (I - Qs @ Pqe)
+            Pqe = 0.5 * (Pqe + Pqe.T)
         if "r" in which:                                      # explicit inverse + one step of iterative refinement
             t1 = Pqe @ vy
             t1 = t1 + Pqe @ (vy - Qs @ t1)
         else:
             t1 = Pqe @ vy if "t" in which else sol(Lq, sol(Lq, vy), True)
         beta = sol(L, t1, True)
+        if "x" in which:                                      # beta = L^-T t1 by an 80-bit substitution, rounded once (is it this vector's forward error?)
+            beta = trsm_ld(L, t1, True).astype(dt)
+        if "y" in which:                                      # ... and t1 itself from an 80-bit solve of the inner system
+            Lq_ld = chol_ld(Qs)
+            t1 = trsm_ld(Lq_ld, trsm_ld(Lq_ld, vy), True).astype(dt)
+            beta = trsm_ld(L, t1, True).astype(dt)
         r = yd / s2 ** 2 - (Bd.T @ beta) / s2 ** 3
-        Pv = Pqe @ v if "g" in which else sol(Lq, sol(Lq, v), True)
-        GB = sol(L, (v - Pv) / s2, True) + beta @ r.T
+        if "b" in which:                                      # round 4's order: the M x M solve first, then ONE M x M x N product
+            GB = sol(L, (I - Pqe) / s2, True) @ v + beta @ r.T
+        else:
+            Pv = Pqe @ v if "g" in which else sol(Lq, sol(Lq, v), True)
+            GB = sol(L, (v - Pv) / s2, True) + beta @ r.T
         Pq = Pqe if "e" in which else Pqs
         Em = 2.0 * I - Pq - Qs
         T1 = sol(L, Em, True)
