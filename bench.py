@@ -692,7 +692,7 @@ def main():
         mom_gbs = gram_bytes * nprof / (stage[_lib.ST_MOMENT_KERNEL] * 1e-3) / 1e9 if stage[_lib.ST_MOMENT_KERNEL] > 0 else None
         traffic, traffic_src, traffic_eval = None, None, None
         sched = h.schedule() if (kind in ("exact", "predict") and not sharded_mode and hasattr(h, "schedule")) else None
-        for tf in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"):     # L2<->fabric bytes per k_gemm launch from the committed rocprofv3 --pmc passes of this command
+        for tf in ("r5_pmc_traffic_stream_schedule.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"):     # L2<->fabric bytes per k_gemm launch from the committed rocprofv3 --pmc passes of this command
             try:
                 with open(os.path.join(ROOT, "profiles", tf)) as f:
                     t = json.load(f)

@@ -406,9 +406,12 @@ def test_cfg5_titsias_golden():
         assert np.max(np.abs(p.data - f["raw"])) < 1e-12 * max(1.0, np.max(np.abs(f["raw"]))), p._name
         p.data = np.array(f["raw"])
     loss = float(m.loss())
-    assert abs(loss - float(fx["loss"])) < 1e-7 * abs(float(fx["loss"])), (loss, float(fx["loss"]))
+    print("ELBO against the reference's: %.2e relative" % (abs(loss - float(fx["loss"])) / abs(float(fx["loss"]))))
+    assert abs(loss - float(fx["loss"])) < 1e-11 * abs(float(fx["loss"])), (loss, float(fx["loss"]))       # measured 1.3e-13 (2.9e-10 before the refined panels)
     for p, f in zip(m.parameters(), fp):
         err = np.max(np.abs(p.grad - f["grad"])) / np.max(np.abs(f["grad"]))
+        if not p._name.endswith("induction_points"):
+            print("    %-50s %.2e" % (p._name, err))
         if p._name.endswith("induction_points"):
             # dELBO/dZ is O(1e-2) here, the residue of O(1e4) terms cancelling through a K_uu with condition number ~1e11 (512 grid points
             # per channel, 0.2 apart): the reference's OWN value moves by 2.35e-3 of this tensor when only its thread count changes
@@ -1115,11 +1118,12 @@ def test_titsias_inducing_gradient_against_extended_precision_truth(fixture):
     assert abs(err_ref - float(fx["ref_err"])) < 1e-12
     if "gz_ref_alt" in fx:
         # configs[4] itself: where the reference lands depends on its summation order -- 1.442e-3 of the tensor from the truth on 8 torch
-        # threads, 1.928e-3 on 3 (the two runs 2.35e-3 apart); the device, the same bits on every run, 2.598e-3
+        # threads, 1.928e-3 on 3 (the two runs 2.35e-3 apart); the device, the same bits on every run, 2.188e-3 (2.598e-3 before the panels of
+        # the K_uu factorisation were refined: DESIGN 4b)
         err_alt = float(np.max(np.abs(fx["gz_ref_alt"] - truth)) / scale)
         print("    the reference again on %d threads: %.3e" % (int(fx["ref_alt_threads"]), err_alt))
-        assert err_dev <= 1.5 * max(err_ref, err_alt), (err_dev, err_ref, err_alt)
-        assert err_dev <= 2.0 * min(err_ref, err_alt), (err_dev, err_ref, err_alt)
+        assert err_dev <= 1.25 * max(err_ref, err_alt), (err_dev, err_ref, err_alt)
+        assert err_dev <= 1.75 * min(err_ref, err_alt), (err_dev, err_ref, err_alt)
     else:
         assert err_dev <= 1.1 * err_ref, (err_dev, err_ref)      # N = 20 000, measured: 2.365e-3 against the reference's 2.399e-3 (bit-reproducible)
     assert np.dot(gz, truth) / (np.linalg.norm(gz) * np.linalg.norm(truth)) > 0.99999
