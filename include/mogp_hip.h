@@ -191,6 +191,11 @@ int  mogp_shard_stage_ms(mogp_model* m, double* ms);
  * 1.0 = all of them (always so above 0.85, with MOGP_FULL_INVERSE=1, on the sweep schedule and sharded).  mogp_model_fetch(which = 1)
  * completes the inverse on demand. */
 int  mogp_model_inverse_fraction(mogp_model* m, double* fraction);
+/* Smallest and largest diagonal entry of the Cholesky factor of Kj from the last mogp_exact_eval / mogp_exact_predict (0, 0 when that call was a
+ * sweep or sharded evaluation): (lmax / lmin)^2 is a cheap lower estimate of cond(Kj).  The exact path forms its panels with explicit block
+ * inverses and stays within the reference's tolerances (LML 1e-9, gradients 1e-5) up to cond(Kj) ~ 1e6 - 1e7; the host side
+ * (mogptk_amd.gpr.Exact) warns beyond.  No reference seam: torch.linalg.cholesky (gpr/model.py:246) is backward stable and says nothing. */
+int  mogp_model_pivot_range(mogp_model* m, double* lmin, double* lmax);
 /* mogp_exact_eval(..., MOGP_EVAL_GRAD) sharded over the context's communicator: same outputs, identical on every rank. */
 int  mogp_exact_eval_sharded(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
                              double* lml, double* moments, double* diagG, double* trG, double* jitter_abs, int64_t* info);

@@ -68,6 +68,7 @@ SIGNATURES = {
     "mogp_comm_selftest": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "mogp_shard_stage_ms": (ctypes.c_int, [ctypes.c_void_p, c_dp]),
     "mogp_model_inverse_fraction": (ctypes.c_int, [ctypes.c_void_p, c_dp]),
+    "mogp_model_pivot_range": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp]),
     "mogp_exact_eval_sharded": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, c_dp, c_dp, c_dp, c_dp, c_dp, c_i64p]),
     "mogp_exact_predict_sharded": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.c_int64, c_dp, c_dp, c_dp, c_i64p]),
     "mogp_shard_config": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
@@ -515,6 +516,12 @@ class ExactHandle:
     def flow_replay(self, on):
         """measurement mode (mogp_model_flow_replay): the next gradient evaluations run the dataflow kernel alone on the replay plan"""
         check(lib().mogp_model_flow_replay(self._h, 1 if on else 0))
+
+    def condition_estimate(self):
+        """(largest / smallest diagonal entry of L)^2 of the last factorisation: a lower estimate of cond(Kj); nan when it was not reported"""
+        lo, hi = np.zeros(1), np.zeros(1)
+        check(lib().mogp_model_pivot_range(self._h, _dp(lo), _dp(hi)))
+        return float((hi[0] / lo[0]) ** 2) if lo[0] > 0.0 else float("nan")
 
     def inverse_fraction(self):
         """fraction of the lower tiles of Kj^-1 the last gradient evaluation formed (1.0 = all; see include/mogp_hip.h)"""

@@ -916,6 +916,30 @@ __global__ void k_nonfinite_scan(const double* __restrict__ A, int64_t ld, int64
     }
     if (f) atomicOr(flag, f);
 }
+// smallest and largest diagonal entry of the Cholesky factor, read off the tile inverses (diag W_kk = 1 / diag L_kk): out[0] = min, out[1] = max over the
+// first n rows (the padding rows carry ones).  One workgroup; the factorisation's cheap condition signal (mogp_model_pivot_range).
+__global__ __launch_bounds__(256) void k_pivot_range(const double* __restrict__ invd, int64_t n, double* __restrict__ out) {
+    __shared__ double smin[256], smax[256];
+    double lo = 1e300, hi = 0.0;
+    for (int64_t r = threadIdx.x; r < n; r += 256) {
+        const double w = fabs(invd[(r >> 7) * (int64_t)(MOGP_TILE * MOGP_TILE) + (r & 127) * (MOGP_TILE + 1)]);
+        const double l = w > 0.0 ? 1.0 / w : 1e300;
+        lo = fmin(lo, l); hi = fmax(hi, l);
+    }
+    smin[threadIdx.x] = lo; smax[threadIdx.x] = hi;
+    __syncthreads();
+    for (int s_ = 128; s_ > 0; s_ >>= 1) {
+        if ((int)threadIdx.x < s_) { smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + s_]); smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + s_]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = smin[0]; out[1] = smax[0]; }
+}
+int launch_pivot_range(const double* invd, int64_t n, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_pivot_range, dim3(1), dim3(256), 0, s, invd, n, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_nonfinite_scan(const double* A, int64_t ld, int64_t n, int* flag, hipStream_t s) {
     hipLaunchKernelGGL(k_nonfinite_scan, dim3((unsigned)n), dim3(256), 0, s, A, ld, n, flag);
     HIP_TRY(hipGetLastError());

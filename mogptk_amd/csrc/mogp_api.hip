@@ -837,7 +837,13 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     // scalars back: [nb log-det parts][nzz z^T z parts][pivot report] through the pinned block
     const int nzz = (int)((Npad + 3) / 4);
     const int nb = m->nb;
-    if ((rc = pin_ensure(m, (size_t)nb + nzz + 1 + (size_t)(C * (C + 1) / 2) * m->T * m->Wt + C))) return rc;
+    const size_t pin_n = (size_t)nb + nzz + 1 + (size_t)(C * (C + 1) / 2) * m->T * m->Wt + C;
+    if ((rc = pin_ensure(m, pin_n + 2))) return rc;
+    // the factor's smallest and largest diagonal entry ride back with the scalars (two doubles behind everything else in the block)
+    if ((rc = m->d_pivots.ensure(2))) return rc;
+    if ((rc = launch_pivot_range(m->k.invd.p, N, m->d_pivots.p, m->st))) return rc;
+    HIP_TRY(hipMemcpyAsync(m->h_pin + pin_n, m->d_pivots.p, 2 * sizeof(double), hipMemcpyDeviceToHost, m->st));
+    m->pin_pivots = pin_n;
     HIP_TRY(hipMemcpyAsync(m->h_pin, m->k.logdet.p, nb * sizeof(double), hipMemcpyDeviceToHost, m->st));
     static const int zz_piece = []() { const char* e = std::getenv("MOGP_D2H_CHUNK"); const int v = e ? std::atoi(e) : 2048; return v > 0 ? v : (1 << 30); }();
     for (int o = 0; o < nzz; o += zz_piece)               // in pieces of 16 KB: see mogp_ctx_create on larger device-to-host copies next to running co-operating kernels
@@ -872,6 +878,7 @@ static int factorize_finish(mogp_model* m, const GramArgs& ga, double* lml, int6
         return fail(MOGP_ENOTPD, "linalg.cholesky: The factorization could not be completed because the input is not "
                                  "positive-definite (the leading minor of order " + std::to_string(hinfo) + " is not positive-definite).");
     }
+    m->pivot_min = m->h_pin[m->pin_pivots]; m->pivot_max = m->h_pin[m->pin_pivots + 1];
     double logdet = 0.0, zz = 0.0;
     for (int i = 0; i < nb; ++i) logdet += m->h_pin[i];
     for (int i = 0; i < nzz; ++i) zz += m->h_pin[nb + i];
@@ -1213,6 +1220,7 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     const int fused_max = flow_enabled(m, m->k) ? 112 : 80;
     const bool fused = !sweep && grad && (grad_path == "fused" || (grad_path != "phases" && m->nb <= fused_max));
     if (sweep) {
+        m->pivot_min = m->pivot_max = 0.0;                     // (the sweep reports no pivot range)
         if ((rc = eval_sweep(m, noise_var, data_var, jitter, lml, jitter_abs, info))) {
             if (rc != MOGP_RETRY_NO_CHAIN) return rc;
             if ((rc = chain_fallback(m))) return rc;
@@ -1669,6 +1677,7 @@ int mogp_exact_eval_sharded(mogp_model* m, const double* noise_var, const double
     if ((rc = use_device(m->ctx))) return rc;
     if (info) *info = 0;
     const int C = m->C, W = m->Wt, T = m->T, P = C * (C + 1) / 2;
+    m->pivot_min = m->pivot_max = 0.0;
     if ((rc = sharded_inverse(m, noise_var, data_var, jitter, jitter_abs))) return rc;
     if ((rc = mark(m, 5))) return rc;
     if ((rc = moment_pass_device(m, m->k.A.p, -1.0))) return rc;                       // owned rows only
@@ -1808,6 +1817,12 @@ int mogp_exact_predict_sharded(mogp_model* m, const double* noise_var, const dou
     HIP_TRY(hipStreamSynchronize(m->st));
     for (int64_t pos = 0; pos < S; ++pos) { mu[ss.perm[pos]] = hmu[pos]; var[ss.perm[pos]] = hv[pos]; }
     m->have_Kinv = false; m->have_W = false;
+    return MOGP_OK;
+}
+
+int mogp_model_pivot_range(mogp_model* m, double* lmin, double* lmax) {
+    if (!m || !lmin || !lmax) return fail(MOGP_EINVAL, "mogp_model_pivot_range: bad argument");
+    *lmin = m->pivot_min; *lmax = m->pivot_max;
     return MOGP_OK;
 }
 

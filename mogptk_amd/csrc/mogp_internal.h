@@ -283,5 +283,6 @@ int launch_info_rearm(unsigned long long* info, hipStream_t s);
 int launch_info_stash(unsigned long long* info, hipStream_t s);      // info[1] <- info[0], then re-arm info[0]
 // non-finite scan of the lower triangle: flag[0] |= 1 if NaN seen, |= 2 if Inf seen
 int launch_nonfinite_scan(const double* A, int64_t ld, int64_t n, int* flag, hipStream_t s);
+int launch_pivot_range(const double* invd, int64_t n, double* out, hipStream_t s);
 
 }  // namespace mogp

@@ -288,6 +288,9 @@ struct mogp_model {
     bool kinv_sparse = false;                                     // the inverse held by k.B lacks the tiles outside the plan
     double kinv_fraction = 1.0;                                   // planned / all lower tiles
     DevBuf<int> d_pair_start, d_chan_off, d_flag;
+    DevBuf<double> d_pivots;            // [min, max] diagonal entry of the last factorisation's L (k_pivot_range)
+    size_t pin_pivots = 0;              // where in the pinned block they come back
+    double pivot_min = 0.0, pivot_max = 0.0;      // the same on the host, 0 when the last evaluation did not report them (sweep / sharded)
     DevBuf<unsigned long long> d_info;
 
     // prediction workspaces

@@ -1152,3 +1152,24 @@ def test_exact_path_conditioning_envelope():
     assert abs(ld - lt) <= 1e-9 * abs(lt), (ld, lt)
     for a, b in zip(out["device"][1], out["twin"][1]):
         assert np.max(np.abs(a - b)) <= 1e-5 * np.max(np.abs(b))
+    # ... and beyond it the model says so: the factor's own diagonal gives a lower estimate of the condition number
+    import warnings
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
+    for name in ("weight", "mean", "variance", "delay", "phase"):
+        getattr(k, name).assign(h[name])
+    m = gpr.Exact(k, X, y, variance=1e-6)
+    m.likelihood.scale.assign(1e-3)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m.loss(); m.loss()
+    est = m._handle.condition_estimate()
+    assert 1e5 < est < 7.4e7, est                    # cond(Kj) = 7.4e7 (numpy); the estimate is a lower bound (measured 8.8e5)
+    assert len([x for x in w if "ill-conditioned" in str(x.message)]) == 1        # once per model
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        k2 = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
+        for name in ("weight", "mean", "variance", "delay", "phase"):
+            getattr(k2, name).assign(h[name])
+        m2 = gpr.Exact(k2, X, y, variance=h["scale"] ** 2)
+        m2.loss()
+    assert not [x for x in w if "ill-conditioned" in str(x.message)] and m2._handle.condition_estimate() < 1e4
