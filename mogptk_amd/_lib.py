@@ -69,6 +69,7 @@ SIGNATURES = {
     "mogp_shard_stage_ms": (ctypes.c_int, [ctypes.c_void_p, c_dp]),
     "mogp_model_inverse_fraction": (ctypes.c_int, [ctypes.c_void_p, c_dp]),
     "mogp_model_pivot_range": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp]),
+    "mogp_model_set_accurate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "mogp_exact_eval_sharded": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, c_dp, c_dp, c_dp, c_dp, c_dp, c_i64p]),
     "mogp_exact_predict_sharded": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.c_int64, c_dp, c_dp, c_dp, c_i64p]),
     "mogp_shard_config": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
@@ -516,6 +517,10 @@ class ExactHandle:
     def flow_replay(self, on):
         """measurement mode (mogp_model_flow_replay): the next gradient evaluations run the dataflow kernel alone on the replay plan"""
         check(lib().mogp_model_flow_replay(self._h, 1 if on else 0))
+
+    def set_accurate(self, on):
+        """gradient evaluations in the backward-stable form (mogp_model_set_accurate): slower, for ill-conditioned Kj"""
+        check(lib().mogp_model_set_accurate(self._h, 1 if on else 0))
 
     def condition_estimate(self):
         """(largest / smallest diagonal entry of L)^2 of the last factorisation: a lower estimate of cond(Kj); nan when it was not reported"""

@@ -808,6 +808,35 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     m->flow_ran = false;                              // ... and chain_fallback decides from THIS evaluation which schedule to drop, not from an earlier one
     m->k.want_vec = fuse_inverse && !factor_only;     // the dataflow schedule (flow.hip) also forms z = W y and alpha = W^T z
     m->k.vec_y = m->d_y.p; m->k.vec_z = m->d_z.p; m->k.vec_zz = m->d_zz.p; m->k.vec_part = m->d_alpha.p + Npad;
+    const bool accurate = m->accurate && !fuse_inverse && !factor_only;
+    m->accurate_ran = accurate;
+    if (accurate) {
+        // (round 5) The backward-stable form, for matrices outside the envelope of the schedules below: the launch-per-step Cholesky with
+        // every panel refined against L_kk (Spd::refine_panels), then Kj^-1 = L^-T (L^-1 I) by two blocked SUBSTITUTIONS (trsm.hip) instead of
+        // products with explicit block inverses, z and alpha by the same substitution on a 128-column block.  2 1/3 N^3 flop at the solves' rate
+        // instead of N^3 at the products', behind a launch-per-step factorisation: 95 ms against 10 at N = 8192.  mogp_model_set_accurate; the host side switches to it when the pivot range says so.
+        m->k.keep_L = true; m->k.refine_panels = true;
+        m->k.want_vec = false;
+        rc = spd_potrf(m, m->k);
+        m->k.keep_L = false; m->k.refine_panels = false;
+        m->k.tail_ready = nullptr;
+        if (rc) return rc;
+        if ((rc = mark(m, 2))) return rc;
+        HIP_TRY(hipMemsetAsync(m->k.B.p, 0, (size_t)Npad * Npad * sizeof(double), m->st));
+        if ((rc = launch_add_diag(m->k.B.p, Npad, Npad, 1.0, m->st))) return rc;
+        if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->k.B.p, Npad, Npad, false))) return rc;
+        if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->k.B.p, Npad, Npad, true))) return rc;
+        if ((rc = mark(m, 3))) return rc;
+        if ((rc = m->acc_rhs.ensure((size_t)Npad * MOGP_TILE))) return rc;
+        HIP_TRY(hipMemsetAsync(m->acc_rhs.p, 0, (size_t)Npad * MOGP_TILE * sizeof(double), m->st));
+        if ((rc = launch_copy2d(m->acc_rhs.p, MOGP_TILE, m->d_y.p, 1, Npad, 1, 1.0, m->st))) return rc;
+        if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->acc_rhs.p, MOGP_TILE, MOGP_TILE, false))) return rc;
+        if ((rc = launch_copy2d(m->d_z.p, 1, m->acc_rhs.p, MOGP_TILE, Npad, 1, 1.0, m->st))) return rc;
+        HIP_TRY(hipMemsetAsync(m->d_zz.p, 0, (size_t)((Npad + 3) / 4) * sizeof(double), m->st));
+        if ((rc = launch_gemv_rows(m->d_z.p, Npad, 1, Npad, m->d_z.p, m->d_zz.p, m->st))) return rc;       // z^T z into the first part
+        if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->acc_rhs.p, MOGP_TILE, MOGP_TILE, true))) return rc;
+        if ((rc = launch_copy2d(m->d_alpha.p, 1, m->acc_rhs.p, MOGP_TILE, Npad, 1, 1.0, m->st))) return rc;
+    } else {
     if (factor_only && !fuse_inverse && m->rhs_job && flow_enabled(m, m->k)) rc = spd_potri_flow(m, m->k, m->rhs_job);      // the prediction: factor + substitute as dataflow
     else rc = fuse_inverse ? spd_potri_fused(m, m->k) : spd_potrf(m, m->k);
     m->k.want_vec = false; m->k.tail_ready = nullptr;
@@ -816,12 +845,13 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
 
     if (!fuse_inverse && !factor_only && (rc = spd_trtri(m, m->k))) return rc;
     if ((rc = mark(m, 3))) return rc;
+    }
 
     // ---- z = W y, alpha = W^T z   (factor_only: the caller solves with L itself; the LML is not formed)
     const int nzz_clear = (int)((Npad + 3) / 4);
     if (factor_only) {
         HIP_TRY(hipMemsetAsync(m->d_zz.p, 0, nzz_clear * sizeof(double), m->st));
-    } else {
+    } else if (!accurate) {
         const double* Wp = fuse_inverse ? m->k.Wm.p : m->k.A.p;
         m->w_in_Wm = fuse_inverse;
         if (fuse_inverse && m->k.flow_used && m->k.vec_done) {
@@ -883,7 +913,7 @@ static int factorize_finish(mogp_model* m, const GramArgs& ga, double* lml, int6
     for (int i = 0; i < nb; ++i) logdet += m->h_pin[i];
     for (int i = 0; i < nzz; ++i) zz += m->h_pin[nb + i];
     if (lml) *lml = -0.5 * (double)N * std::log(2.0 * M_PI) - logdet - 0.5 * zz;
-    m->have_W = !m->factor_only;
+    m->have_W = !m->factor_only && !m->accurate_ran;     // (the accurate form keeps L, not W = L^-1)
     return 0;
 }
 
@@ -1140,7 +1170,7 @@ int mogp_model_destroy(mogp_model* m) {
     m->d_tiles_head.release(); m->d_tiles_tail.release(); m->strip_head.release(); m->strip_tail.release();
     if (m->gram_ev) { hipError_t r = hipEventDestroy(m->gram_ev); (void)r; m->gram_ev = nullptr; }
     if (m->gram_tail_ev) { hipError_t r = hipEventDestroy(m->gram_tail_ev); (void)r; m->gram_tail_ev = nullptr; }
-    m->d_chan_off.release(); m->d_flag.release(); m->d_info.release();
+    m->d_chan_off.release(); m->d_flag.release(); m->d_info.release(); m->d_pivots.release(); m->acc_rhs.release();
     m->d_xs.release(); m->d_Ksf.release(); m->d_Vt.release(); m->d_mu.release(); m->d_var.release(); m->d_kdiag.release();
     m->d_Kss.release(); m->d_ptiles.release();
     m->ph_xx.release(); m->ph_sx.release(); m->ph_ss.release();
@@ -1213,12 +1243,12 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     const bool grad = (flags & MOGP_EVAL_GRAD) != 0;
     GramArgs ga{};
     if ((rc = ensure_system(m))) return rc;
-    if ((rc = kinv_plan(m, grad && !sweep))) return rc;
+    if ((rc = kinv_plan(m, grad && !sweep && !m->accurate))) return rc;
     // round 4: as tile dataflow (flow.hip) the fused schedule also beats the phases at 81 .. 112 tile rows (configs[1]'s kernel, tools/r4_sizes.sh:
     // 19.3 vs 22.4 ms at N = 10240, 32.5 vs 35.9 at 12288, 41.0 vs 43.8 at 13312, 50.7 vs 53.0 at 14336; 76.6 vs 75.8 the other way at 16384); where
     // the dataflow kernel is not available (switched off, fallen back, a planned inverse) the stream form keeps its 80
     const int fused_max = flow_enabled(m, m->k) ? 112 : 80;
-    const bool fused = !sweep && grad && (grad_path == "fused" || (grad_path != "phases" && m->nb <= fused_max));
+    const bool fused = !sweep && grad && !m->accurate && (grad_path == "fused" || (grad_path != "phases" && m->nb <= fused_max));
     if (sweep) {
         m->pivot_min = m->pivot_max = 0.0;                     // (the sweep reports no pivot range)
         if ((rc = eval_sweep(m, noise_var, data_var, jitter, lml, jitter_abs, info))) {
@@ -1238,7 +1268,7 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     const int C = m->C, W = m->Wt, T = m->T, P = C * (C + 1) / 2;
 
     // K^-1: the sweep left -Kj^-1 in k.A; the POTRF path needs W^T W (lower tiles, full diagonal tiles) in k.B
-    if (!sweep && !fused && (rc = spd_lauum(m, m->k))) return rc;
+    if (!sweep && !fused && !m->accurate_ran && (rc = spd_lauum(m, m->k))) return rc;          // (the accurate form left Kj^-1 itself in k.B)
     const double* kinv = sweep ? m->k.A.p : m->k.B.p;
     const double ksign = sweep ? -1.0 : 1.0;
     if ((rc = mark(m, 5))) return rc;
@@ -1817,6 +1847,12 @@ int mogp_exact_predict_sharded(mogp_model* m, const double* noise_var, const dou
     HIP_TRY(hipStreamSynchronize(m->st));
     for (int64_t pos = 0; pos < S; ++pos) { mu[ss.perm[pos]] = hmu[pos]; var[ss.perm[pos]] = hv[pos]; }
     m->have_Kinv = false; m->have_W = false;
+    return MOGP_OK;
+}
+
+int mogp_model_set_accurate(mogp_model* m, int on) {
+    if (!m) return fail(MOGP_EINVAL, "mogp_model_set_accurate: model is null");
+    m->accurate = on != 0;
     return MOGP_OK;
 }
 

@@ -289,6 +289,8 @@ struct mogp_model {
     double kinv_fraction = 1.0;                                   // planned / all lower tiles
     DevBuf<int> d_pair_start, d_chan_off, d_flag;
     DevBuf<double> d_pivots;            // [min, max] diagonal entry of the last factorisation's L (k_pivot_range)
+    bool accurate = false, accurate_ran = false;      // mogp_model_set_accurate: gradient evaluations by refined panels + substitutions (factorize); the last one did
+    DevBuf<double> acc_rhs;             // its 128-column right-hand-side block (y -> z -> alpha)
     size_t pin_pivots = 0;              // where in the pinned block they come back
     double pivot_min = 0.0, pivot_max = 0.0;      // the same on the host, 0 when the last evaluation did not report them (sweep / sharded)
     DevBuf<unsigned long long> d_info;

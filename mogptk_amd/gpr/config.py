@@ -15,6 +15,7 @@ class Config:
     device = 0
     positive_minimum = 1e-8
     comm = None          # mogptk_amd.dist.Comm when exact evaluations are sharded over several GPUs
+    accurate_fallback = True      # gpr.Exact repeats a gradient evaluation in the backward-stable form when the factor's diagonal says K + noise is ill-conditioned
 
 
 config = Config()

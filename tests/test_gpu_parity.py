@@ -1152,24 +1152,42 @@ def test_exact_path_conditioning_envelope():
     assert abs(ld - lt) <= 1e-9 * abs(lt), (ld, lt)
     for a, b in zip(out["device"][1], out["twin"][1]):
         assert np.max(np.abs(a - b)) <= 1e-5 * np.max(np.abs(b))
-    # ... and beyond it the model says so: the factor's own diagonal gives a lower estimate of the condition number
+    # ... and beyond it the model says so and switches to the backward-stable form: the factor's own diagonal gives a lower estimate of the condition number
     import warnings
-    k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
-    for name in ("weight", "mean", "variance", "delay", "phase"):
-        getattr(k, name).assign(h[name])
-    m = gpr.Exact(k, X, y, variance=1e-6)
-    m.likelihood.scale.assign(1e-3)
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        m.loss(); m.loss()
-    est = m._handle.condition_estimate()
-    assert 1e5 < est < 7.4e7, est                    # cond(Kj) = 7.4e7 (numpy); the estimate is a lower bound (measured 8.8e5)
-    assert len([x for x in w if "ill-conditioned" in str(x.message)]) == 1        # once per model
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        k2 = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
+
+    def model(sigma):
+        k = gpr.MultiOutputSpectralMixtureKernel(Q=Q, output_dims=C)
         for name in ("weight", "mean", "variance", "delay", "phase"):
-            getattr(k2, name).assign(h[name])
-        m2 = gpr.Exact(k2, X, y, variance=h["scale"] ** 2)
+            getattr(k, name).assign(h[name])
+        m = gpr.Exact(k, X, y, variance=sigma ** 2)
+        m.likelihood.scale.assign(sigma)
+        return m
+
+    for sigma, tol_l, tol_g in ((1e-3, 2e-9, 1e-5), (1e-4, 1e-7, 1e-3)):      # cond(Kj) 7.4e7 and 4e9: the fast schedules are 3.7e-7 / 2e-4 and 4.6e-3 / 0.15 off
+        mt = model(sigma)
+        mt._handle = TableDevice(0, mt.kernel._kernel_format(mt.X), mt.y, C)
+        lt, gt = float(mt.loss()), [p.grad.copy() for p in mt.parameters()]
+        m = model(sigma)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            ld = float(m.loss())
+            ld2 = float(m.loss())
+        assert len([x for x in w if "ill-conditioned" in str(x.message)]) == 1        # once per model
+        assert m._accurate and ld == ld2
+        est = m._handle.condition_estimate()
+        assert 1e5 < est, est                            # a lower bound of cond(Kj) (8.8e5 where it is 7.4e7)
+        el = abs(ld - lt) / abs(lt)
+        eg = max(float(np.max(np.abs(p.grad - b)) / np.max(np.abs(b))) for p, b in zip(m.parameters(), gt))
+        print("sigma %.0e: backward-stable form against the LAPACK twin: LML %.2e, worst gradient tensor %.2e (estimate %.1e)" % (sigma, el, eg, est))
+        assert el <= tol_l and eg <= tol_g, (sigma, el, eg)
+    # a well-conditioned model is left alone, and a model whose noise comes back up returns to the fast form
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m2 = model(0.2)
         m2.loss()
-    assert not [x for x in w if "ill-conditioned" in str(x.message)] and m2._handle.condition_estimate() < 1e4
+    assert not [x for x in w if "ill-conditioned" in str(x.message)] and m2._handle.condition_estimate() < 1e4 and not getattr(m2, "_accurate", False)
+    m.likelihood.scale.assign(0.2)
+    m.loss()
+    assert not m._accurate
+    l_fast = float(m.loss())
+    assert abs(l_fast - float(m2.loss())) <= 1e-12 * abs(l_fast)
