@@ -918,24 +918,34 @@ __global__ void k_nonfinite_scan(const double* __restrict__ A, int64_t ld, int64
 }
 // smallest and largest diagonal entry of the Cholesky factor, read off the tile inverses (diag W_kk = 1 / diag L_kk): out[0] = min, out[1] = max over the
 // first n rows (the padding rows carry ones).  One workgroup; the factorisation's cheap condition signal (mogp_model_pivot_range).
-__global__ __launch_bounds__(256) void k_pivot_range(const double* __restrict__ invd, int64_t n, double* __restrict__ out) {
-    __shared__ double smin[256], smax[256];
+__global__ __launch_bounds__(1024) void k_pivot_range(const double* __restrict__ invd, int64_t n, double* __restrict__ out) {
+    __shared__ double smin[16], smax[16];
     double lo = 1e300, hi = 0.0;
-    for (int64_t r = threadIdx.x; r < n; r += 256) {
-        const double w = fabs(invd[(r >> 7) * (int64_t)(MOGP_TILE * MOGP_TILE) + (r & 127) * (MOGP_TILE + 1)]);
-        const double l = w > 0.0 ? 1.0 / w : 1e300;
-        lo = fmin(lo, l); hi = fmax(hi, l);
+    for (int64_t r0 = threadIdx.x; r0 < n; r0 += 8 * 1024) {            // eight independent loads in flight per thread
+        double w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t r = r0 + (int64_t)u * 1024;
+            w[u] = r < n ? fabs(invd[(r >> 7) * (int64_t)(MOGP_TILE * MOGP_TILE) + (r & 127) * (MOGP_TILE + 1)]) : -1.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (w[u] < 0.0) continue;
+            const double l = w[u] > 0.0 ? 1.0 / w[u] : 1e300;
+            lo = fmin(lo, l); hi = fmax(hi, l);
+        }
     }
-    smin[threadIdx.x] = lo; smax[threadIdx.x] = hi;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { lo = fmin(lo, __shfl_xor(lo, off, 64)); hi = fmax(hi, __shfl_xor(hi, off, 64)); }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
     __syncthreads();
-    for (int s_ = 128; s_ > 0; s_ >>= 1) {
-        if ((int)threadIdx.x < s_) { smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + s_]); smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + s_]); }
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) { lo = fmin(lo, smin[i]); hi = fmax(hi, smax[i]); }
+        out[0] = lo; out[1] = hi;
     }
-    if (threadIdx.x == 0) { out[0] = smin[0]; out[1] = smax[0]; }
 }
 int launch_pivot_range(const double* invd, int64_t n, double* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_pivot_range, dim3(1), dim3(256), 0, s, invd, n, out);
+    hipLaunchKernelGGL(k_pivot_range, dim3(1), dim3(1024), 0, s, invd, n, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }
