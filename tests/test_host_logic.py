@@ -1156,3 +1156,70 @@ def test_checkpoint_with_user_code_needs_an_opt_in(tmp_path):
     raw = pickle.dumps(compat.is_reference_checkpoint)
     with pytest.raises(pickle.UnpicklingError):
         compat._NativeUnpickler(io.BytesIO(raw)).load()
+
+
+# ---- the host side of the exact path's conditioning check (no device: a handle that only reports an estimate) ------------------------
+def test_ill_conditioned_models_warn_once_and_switch_to_the_backward_stable_form():
+    import warnings
+    from oracle.table_model import TableDevice
+
+    class Reporting(TableDevice):
+        """the numpy twin plus the two entry points of the device handle the check uses; the estimate is dialled by the test"""
+        estimate = 1.0
+
+        def __init__(self, *a):
+            super().__init__(*a)
+            self.accurate, self.evals = False, []
+
+        def condition_estimate(self):
+            return type(self).estimate
+
+        def set_accurate(self, on):
+            self.accurate = bool(on)
+
+        def eval(self, *a, **k):
+            self.evals.append(self.accurate)
+            return super().eval(*a, **k)
+
+    rng = np.random.default_rng(3)
+    x = np.sort(rng.uniform(0, 10, 40))
+    X = np.c_[np.repeat([0, 1], 20), np.r_[x[:20], x[20:]]]
+    y = np.sin(X[:, 1]) + 0.1 * rng.standard_normal(40)
+    k = gpr.MultiOutputSpectralMixtureKernel(Q=1, output_dims=2)
+    old = L.ExactHandle
+    L.ExactHandle = Reporting
+    try:
+        m = gpr.Exact(k, X, y, variance=0.04)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            Reporting.estimate = 5e3
+            l0 = m.loss()
+            assert not w and m._handle.evals == [False] and not getattr(m, "_accurate", False)
+            Reporting.estimate = 3e6                       # the factor's diagonal says: ill-conditioned
+            l1 = m.loss()
+            assert len(w) == 1 and issubclass(w[0].category, RuntimeWarning) and "ill-conditioned" in str(w[0].message)
+            assert m._accurate and m._handle.evals == [False, False, True]            # the evaluation was repeated in the other form
+            m.loss()
+            assert len(w) == 1 and m._handle.evals[-1] is True and len(m._handle.evals) == 4      # stays there, says it once
+            m.log_marginal_likelihood()                   # (the LML alone does not take part)
+            Reporting.estimate = 5e4                       # better, but not by the factor of ten that switches back
+            m.loss()
+            assert m._accurate
+            Reporting.estimate = 5e3
+            m.loss()
+            assert not m._accurate and m._handle.accurate is False
+            n = len(m._handle.evals)
+            m.loss()
+            assert m._handle.evals[n:] == [False]
+        assert l0 == l1                                    # (the twin computes the same thing either way)
+        # the switch that only warns
+        gpr.config.accurate_fallback = False
+        m2 = gpr.Exact(gpr.MultiOutputSpectralMixtureKernel(Q=1, output_dims=2), X, y, variance=0.04)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            Reporting.estimate = 3e6
+            m2.loss(); m2.loss()
+        assert len(w) == 1 and not getattr(m2, "_accurate", False) and m2._handle.evals == [False, False]
+    finally:
+        gpr.config.accurate_fallback = True
+        L.ExactHandle = old
