@@ -310,7 +310,7 @@ class Exact(Model):
             return None
         accurate = getattr(self, "_accurate", False)
         if not accurate and est > self.CONDITION_WARN:
-            fallback = getattr(config, "accurate_fallback", True) and hasattr(h, "set_accurate")
+            fallback = redo is not None and getattr(config, "accurate_fallback", True) and hasattr(h, "set_accurate")      # (redo None: the prediction, which has the fast form only)
             if not getattr(self, "_cond_warned", False):
                 self._cond_warned = True
                 import warnings
@@ -378,6 +378,8 @@ class Exact(Model):
         try:
             mu, var = h.predict(self._noise_var(), self.jitter, kss, Xk, full=full,
                                 data_var=self.data_variance)
+            if not getattr(self, "_accurate", False):
+                self._check_conditioning(h, None)              # warns (once per model); there is no backward-stable form of the prediction
         except MogpError as e:
             if e.code in (MOGP_ENOTPD, MOGP_ENONFINITE):
                 print("ERROR:", str(e), file=sys.__stdout__)
