@@ -1364,7 +1364,9 @@ static int predict_core(mogp_model* m, const double* noise_var, const double* da
     int fp_lo = 48, fp_hi = 160;
     if (fpe && std::strchr(fpe, ':')) { fp_lo = std::atoi(fpe); fp_hi = std::atoi(std::strchr(fpe, ':') + 1); }
     else if (fpe) fp_hi = std::atoi(fpe);
-    const bool as_flow = fp_hi > 0 && nb >= fp_lo && nb <= fp_hi && Srow / MOGP_TILE <= 4096 && flow_enabled(m, m->k) && !m->kinv_sparse;
+    // mogp_model_set_accurate: the stream form with every panel of the factorisation and every solved block column refined once against L itself
+    const bool acc = m->accurate;
+    const bool as_flow = !acc && fp_hi > 0 && nb >= fp_lo && nb <= fp_hi && Srow / MOGP_TILE <= 4096 && flow_enabled(m, m->k) && !m->kinv_sparse;
     FlowRhs job{m->d_Ksf.p, m->d_Vt.p, (int)(Srow / MOGP_TILE), nullptr};
     if (as_flow) {
         HIP_TRY(hipEventRecord(m->pred_ev[1], sv));           // K_sf (and y^T in its last tile row) are in place
@@ -1373,7 +1375,9 @@ static int predict_core(mogp_model* m, const double* noise_var, const double* da
     }
     // the factorisation: enqueued on the model's streams, not waited for
     GramArgs gaK{};
+    if (acc) { m->k.keep_L = true; m->k.refine_panels = true; }
     rc = factorize(m, noise_var, data_var, jitter, nullptr, nullptr, info, false, true, &gaK, true);
+    if (acc) { m->k.keep_L = false; m->k.refine_panels = false; }
     m->rhs_job = nullptr;
     if (rc) return rc;
     const bool flowed = as_flow && m->k.flow_used;
@@ -1404,6 +1408,14 @@ static int predict_core(mogp_model* m, const double* noise_var, const double* da
             g.C = m->d_Vt.p + c0; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
             g.mode = GM_KHI_J; g.small = 1; g.mt = 2 * mt; g.nt = nk; g.K = nk * MOGP_TILE;        // 64 x 128 tiles: twice the workgroups of a launch that fills a quarter of the chip
             if ((rc = gemm_call(m, g, gemm_flops(g, nullptr), sv))) return rc;
+            if (acc) {                 // X += (T - X L_KK^T) W_KK^T: the product with the explicit W_KK is only a first approximation of the solve (spd_potrf does the same to its panels)
+                GemmArgs r1 = g;
+                r1.A = m->d_Vt.p + c0; r1.B = w.A.p + c0 * (Npad + 1); r1.ldb = Npad; r1.C = m->d_Ksf.p + c0; r1.alpha = -1.0; r1.beta = 1.0;
+                if ((rc = gemm_call(m, r1, gemm_flops(r1, nullptr), sv))) return rc;
+                GemmArgs r2 = g;
+                r2.A = m->d_Ksf.p + c0; r2.C = m->d_Vt.p + c0; r2.alpha = 1.0; r2.beta = 1.0;
+                if ((rc = gemm_call(m, r2, gemm_flops(r2, nullptr), sv))) return rc;
+            }
             if (rem > 0) {
                 GemmArgs u{};
                 u.A = m->d_Vt.p + c0; u.lda = Npad; u.a_kmajor = 0;

@@ -310,7 +310,7 @@ class Exact(Model):
             return None
         accurate = getattr(self, "_accurate", False)
         if not accurate and est > self.CONDITION_WARN:
-            fallback = redo is not None and getattr(config, "accurate_fallback", True) and hasattr(h, "set_accurate")      # (redo None: the prediction, which has the fast form only)
+            fallback = getattr(config, "accurate_fallback", True) and hasattr(h, "set_accurate")
             if not getattr(self, "_cond_warned", False):
                 self._cond_warned = True
                 import warnings
@@ -376,10 +376,11 @@ class Exact(Model):
         Xk = self.kernel._kernel_format(X)
         kss = self.kernel._point_diag(table, Xk, D) if table.shape[3] > 2 + 3 * D else self.kernel._spectral_diag(D)
         try:
-            mu, var = h.predict(self._noise_var(), self.jitter, kss, Xk, full=full,
-                                data_var=self.data_variance)
-            if not getattr(self, "_accurate", False):
-                self._check_conditioning(h, None)              # warns (once per model); there is no backward-stable form of the prediction
+            run = lambda: h.predict(self._noise_var(), self.jitter, kss, Xk, full=full, data_var=self.data_variance)
+            mu, var = run()
+            again = self._check_conditioning(h, run)           # an ill-conditioned system: said once, predicted again in the refined form
+            if again is not None:
+                mu, var = again
         except MogpError as e:
             if e.code in (MOGP_ENOTPD, MOGP_ENONFINITE):
                 print("ERROR:", str(e), file=sys.__stdout__)

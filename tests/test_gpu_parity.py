@@ -1180,6 +1180,27 @@ def test_exact_path_conditioning_envelope():
         eg = max(float(np.max(np.abs(p.grad - b)) / np.max(np.abs(b))) for p, b in zip(m.parameters(), gt))
         print("sigma %.0e: backward-stable form against the LAPACK twin: LML %.2e, worst gradient tensor %.2e (estimate %.1e)" % (sigma, el, eg, est))
         assert el <= tol_l and eg <= tol_g, (sigma, el, eg)
+    # the prediction of an ill-conditioned model: fast form first, then -- the warning, once -- the refined one (panels and solved block columns refined against L)
+    Xs = synth.test_inputs(256, C)
+    mt = model(1e-3)
+    mt._handle = TableDevice(0, mt.kernel._kernel_format(mt.X), mt.y, C)
+    mu_t, var_t = mt.predict_f(Xs)
+    gpr.config.accurate_fallback = False
+    try:
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter("always")
+            mu_f, var_f = model(1e-3).predict_f(Xs)
+    finally:
+        gpr.config.accurate_fallback = True
+    mp = model(1e-3)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        mu_a, var_a = mp.predict_f(Xs)
+    assert len([x for x in w if "ill-conditioned" in str(x.message)]) == 1 and mp._accurate
+    e = lambda a, b: float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+    print("prediction at sigma 1e-3 against the LAPACK twin: mean fast %.2e refined %.2e; variance fast %.2e refined %.2e" % (e(mu_f, mu_t), e(mu_a, mu_t), e(var_f, var_t), e(var_a, var_t)))
+    assert e(mu_a, mu_t) <= 1e-6 and e(var_a, var_t) <= 1e-6
+    assert e(mu_a, mu_t) <= e(mu_f, mu_t) and e(var_a, var_t) <= e(var_f, var_t)
     # a well-conditioned model is left alone, and a model whose noise comes back up returns to the fast form
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
