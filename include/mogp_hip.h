@@ -197,7 +197,7 @@ int  mogp_model_inverse_fraction(mogp_model* m, double* fraction);
  * (mogptk_amd.gpr.Exact) warns beyond.  No reference seam: torch.linalg.cholesky (gpr/model.py:246) is backward stable and says nothing. */
 int  mogp_model_pivot_range(mogp_model* m, double* lmin, double* lmax);
 /* on != 0: mogp_exact_eval evaluates in its backward-stable form -- launch-per-step Cholesky with refined panels, Kj^-1 = L^-T (L^-1 I) and
- * alpha by blocked substitution instead of products with explicit block inverses -- several times slower (95 ms against 10 at N = 8192), and within the reference's
+ * alpha by blocked substitution instead of products with explicit block inverses -- about four times slower (43 ms against 10 at N = 8192), and within the reference's
  * tolerances where the default schedules are not (cond(Kj) >~ 1e7).  gpr.Exact switches it on when the pivot range says so.
  * mogp_exact_predict follows: refined panels, and every solved block column of the forward substitution refined once against L_KK.
  * Not for the sweep / sharded evaluation.  No reference seam (the reference's LAPACK calls are this form already). */

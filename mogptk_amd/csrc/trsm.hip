@@ -344,14 +344,17 @@ int launch_sym_lower_avg(double* A, int64_t ld, int64_t n, double scale, hipStre
     return 0;
 }
 
-int trsm_lower(mogp_model* m, const double* L, int64_t ldl, int nb, double* B, int64_t ldb, int64_t ncols, bool trans, hipStream_t st) {
+// tri (square right-hand side): the solution is wanted -- forward: IS, the right-hand side being lower triangular -- in its lower block triangle only:
+// right-looking, block row i solved in and its update applied to the first i + 1 column tiles (L^-1 I and the lower half of L^-T (L^-1 I): half the
+// products of the full solves; the accurate form of the exact evaluation, mogp_api.hip:factorize)
+int trsm_lower(mogp_model* m, const double* L, int64_t ldl, int nb, double* B, int64_t ldb, int64_t ncols, bool trans, hipStream_t st, bool tri) {
     if (!st) st = m->st;
     if (ncols % MOGP_TILE) return fail(MOGP_EINVAL, "trsm_lower: the number of right-hand sides must be a multiple of 128");
     const int nt = (int)(ncols / MOGP_TILE);
     // Wide right-hand sides (N columns): left-looking -- block row i is updated once, by one GEMM with K = 128 i, and B is swept once.
     // Narrow ones (M x M): right-looking -- every solved block updates all remaining block rows at once (K = 128, but (nb - i) nt
     // workgroups per launch instead of nt; the matrix stays in the Infinity Cache).
-    const bool right = nt <= 32;
+    const bool right = tri || nt <= 32;        // (tri: a square system -- one tile row per launch would use (i + 1) of the chip's 256 CUs: 75 ms for the two solves at N = 8192, 2/3 of the accurate evaluation)
     for (int step = 0; step < nb; ++step) {
         const int i = trans ? nb - 1 - step : step;
         double* Bi = B + (int64_t)i * MOGP_TILE * ldb;
@@ -370,7 +373,9 @@ int trsm_lower(mogp_model* m, const double* L, int64_t ldl, int nb, double* B, i
             RC(gemm_call(m, g, gemm_flops(g, nullptr), st));
         }
         const double* Lii = L + (int64_t)i * MOGP_TILE * (ldl + 1);
-        RC(trans ? launch_leaf<true>(Lii, ldl, Bi, ldb, ncols, st) : launch_leaf<false>(Lii, ldl, Bi, ldb, ncols, st));
+        const int ntu = tri ? std::min(nt, i + 1) : nt;        // tri: block row i lives in its first i + 1 column tiles (forward: the rest is zero; transposed: the rest is the upper triangle nobody reads)
+        const int64_t lc = (int64_t)ntu * MOGP_TILE;
+        RC(trans ? launch_leaf<true>(Lii, ldl, Bi, ldb, lc, st) : launch_leaf<false>(Lii, ldl, Bi, ldb, lc, st));
         const int rest = nb - 1 - step;
         if (right && rest > 0) {
             GemmArgs g{};
@@ -383,7 +388,7 @@ int trsm_lower(mogp_model* m, const double* L, int64_t ldl, int nb, double* B, i
             }
             g.B = Bi; g.ldb = ldb; g.b_kmajor = 1;
             g.ldc = ldb; g.alpha = -1.0; g.beta = 1.0;
-            g.mode = GM_RECT; g.mt = rest; g.nt = nt; g.K = MOGP_TILE;
+            g.mode = GM_RECT; g.mt = rest; g.nt = ntu; g.K = MOGP_TILE;
             RC(gemm_call(m, g, gemm_flops(g, nullptr), st));
         }
     }
