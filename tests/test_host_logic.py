@@ -1212,6 +1212,20 @@ def test_ill_conditioned_models_warn_once_and_switch_to_the_backward_stable_form
             m.loss()
             assert m._handle.evals[n:] == [False]
         assert l0 == l1                                    # (the twin computes the same thing either way)
+        # predict_f takes part in the same way: an ill-conditioned system found by a prediction is said once and predicted again in the refined form
+        m3 = gpr.Exact(gpr.MultiOutputSpectralMixtureKernel(Q=1, output_dims=2), X, y, variance=0.04)
+        calls = []
+        orig = Reporting.predict
+        Reporting.predict = lambda self, *a, **k: (calls.append(self.accurate), orig(self, *a, **k))[1]
+        try:
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                Reporting.estimate = 3e6
+                mu1, _ = m3.predict_f(X[:5])
+                mu2, _ = m3.predict_f(X[:5])
+            assert len(w) == 1 and m3._accurate and calls == [False, True, True] and np.array_equal(mu1, mu2)
+        finally:
+            Reporting.predict = orig
         # the switch that only warns
         gpr.config.accurate_fallback = False
         m2 = gpr.Exact(gpr.MultiOutputSpectralMixtureKernel(Q=1, output_dims=2), X, y, variance=0.04)
