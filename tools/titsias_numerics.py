@@ -23,7 +23,7 @@ for name in ("weight", "mean", "variance", "delay", "phase"):
 table = k._spectral_terms(1)
 from mogptk_amd.gpr.model import init_inducing_points
 Z = init_inducing_points([M // C] * C, X, "grid", C)
-sigma, jitter = 0.25, 1e-8
+sigma, jitter = float(__import__('os').environ.get('TITSIAS_SIGMA', '0.25')), 1e-8
 s2 = sigma * sigma
 y = y.reshape(-1, 1)
 Kuu = gram_from_table(table, Z)
@@ -170,7 +170,7 @@ def gz_from(GA, GB):
 
 import os
 t0 = time.time()
-cache = "/tmp/titsias_truth_%d.npz" % N
+cache = "/tmp/titsias_truth_%d_%g.npz" % (N, sigma)
 if os.path.exists(cache):
     f = np.load(cache); gZt, GAt, GBt = f["gZ"], f["GA"], f["GB"]
 else:
@@ -184,10 +184,10 @@ Ll = np.linalg.cholesky(A)
 Ld = chol_device(A)
 print("Cholesky residuals |LL^T - A|/|A|: lapack %.2e, device-style %.2e" % (np.abs(Ll @ Ll.T - A).max() / np.abs(A).max(), np.abs(Ld @ Ld.T - A).max() / np.abs(A).max()))
 for lname, L in (("lapack chol", Ll), ("device chol", Ld)):
-    for mode in (("S", "H", "Hge", "Hrge") if lname == "device chol" else ()):
+    for mode in (("S", "H", "Hge", "Hrge", "Hrgeb") if lname == "device chol" else ("S",)):
         GA, GB = grads(L, mode)
         gZ = gz_from(GA, GB)
         e = np.abs(gZ - gZt).max() / np.abs(gZt).max()
         cos = float(gZ[:, 0] @ gZt[:, 0] / np.linalg.norm(gZ) / np.linalg.norm(gZt))
-        print("%-12s %s: gZ rel err %.3e  cos %.6f   GA rel err %.2e  GB rel err %.2e" % (lname, {"E": "explicit W", "S": "solves   ", "H": "solves L, explicit Lq", "Ht": "explicit Pq in t1 only", "Hg": "explicit Pq in GB only", "He": "explicit Pq in E only", "Hge": "explicit Pq in GB and E, t1 by solves", "Hrge": "explicit Pq everywhere, t1 refined once"}[mode], e, cos,
+        print("%-12s %s: gZ rel err %.3e  cos %.6f   GA rel err %.2e  GB rel err %.2e" % (lname, {"E": "explicit W", "S": "solves   ", "H": "solves L, explicit Lq", "Ht": "explicit Pq in t1 only", "Hg": "explicit Pq in GB only", "He": "explicit Pq in E only", "Hge": "explicit Pq in GB and E, t1 by solves", "Hrge": "explicit Pq everywhere, t1 refined once", "Hrgeb": "the same, M x M solve before the M x N product (titsias.hip)"}[mode], e, cos,
               float(np.abs(GA - GAt).max() / np.abs(GAt).max()), float(np.abs(GB - GBt).max() / np.abs(GBt).max())))
