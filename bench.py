@@ -729,6 +729,7 @@ def main():
                        "dataflow_kernel": None if sched is None else sched["dataflow"],
                        "chain_kernel": None if sched is None else sched["chain_kernel"],
                        "fell_back": None if sched is None else (sched["dataflow_fell_back"] or sched["chain_fell_back"]),
+                       "dataflow_timeouts": None if sched is None else sched.get("dataflow_timeouts"),
                        "step": STEP_NOTE[kind], "device": _lib.device_name(local_rank)},
             "roofline": {"bound": "mfma", "kernel": ("k_flow: the resident tile-dataflow kernel, k_gemm's k loop (fp64 v_mfma_f64_16x16x4_f64)"
                                                      if sched and sched["dataflow"] else "k_gemm (fp64 v_mfma_f64_16x16x4_f64)"), "achieved": achieved,

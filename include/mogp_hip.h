@@ -240,10 +240,12 @@ int  mogp_stage_ms(mogp_model* m, double* ms, int64_t* gemm_launches, double* ge
 /* How the last mogp_exact_eval(MOGP_EVAL_GRAD) of this model was scheduled -- so that a silent degradation is visible (bench.py prints it,
  * the GPU tests assert it).  The factorisation + inversion (reference gpr/model.py:242-246, :291) runs as ONE resident dataflow kernel fed by
  * persistent chain kernels; if a hand-off inside them times out (their workgroups not all resident: another process on the same GPU) the
- * evaluation is repeated on streams of launches and the model stays there.  *flags: OR of the bits below. */
+ * evaluation is repeated on streams of launches and the model stays there for a while (below).  *flags: OR of the bits below. */
 #define MOGP_SCHED_DATAFLOW            1   /* the last fused factorisation + inversion ran as tile dataflow (csrc/flow.hip) */
 #define MOGP_SCHED_CHAIN_KERNEL        2   /* the persistent chain kernel (csrc/chain.hip) is in use */
-#define MOGP_SCHED_DATAFLOW_FELL_BACK  4   /* a dataflow evaluation timed out once: stream schedule from then on */
+#define MOGP_SCHED_DATAFLOW_FELL_BACK  4   /* a dataflow evaluation timed out and the model is on the stream schedule at the moment: for 64 evaluations after the first
+                                            * time-out, four times as many after each further one (up to 16384), then the dataflow kernel gets another try */
+#define MOGP_SCHED_TIMEOUTS_SHIFT      8   /* bits 8 .. 23: how many dataflow evaluations of this model have timed out so far */
 #define MOGP_SCHED_CHAIN_FELL_BACK     8   /* a chain kernel timed out once: launch-per-step chain from then on */
 int  mogp_model_schedule(mogp_model* m, int* flags);
 

@@ -509,10 +509,11 @@ class ExactHandle:
         return ms
 
     def schedule(self):
-        """-> dict(dataflow, chain_kernel, dataflow_fell_back, chain_fell_back): how the last gradient evaluation was scheduled (mogp_model_schedule)"""
+        """-> dict(dataflow, chain_kernel, dataflow_fell_back, chain_fell_back, dataflow_timeouts): how the last gradient evaluation was scheduled (mogp_model_schedule)"""
         f = ctypes.c_int(0)
         check(lib().mogp_model_schedule(self._h, ctypes.byref(f)))
-        return dict(dataflow=bool(f.value & 1), chain_kernel=bool(f.value & 2), dataflow_fell_back=bool(f.value & 4), chain_fell_back=bool(f.value & 8))
+        return dict(dataflow=bool(f.value & 1), chain_kernel=bool(f.value & 2), dataflow_fell_back=bool(f.value & 4), chain_fell_back=bool(f.value & 8),
+                    dataflow_timeouts=(f.value >> 8) & 0xffff)
 
     def flow_replay(self, on):
         """measurement mode (mogp_model_flow_replay): the next gradient evaluations run the dataflow kernel alone on the replay plan"""

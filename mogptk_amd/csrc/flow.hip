@@ -237,7 +237,7 @@ __device__ __forceinline__ void flow_apart(const FlowArgs& g, const int r0, cons
     }
 }
 
-#define FL_IDLE_LIMIT 60000u          // idle looks (1 .. 16 us apart) before a workgroup gives up (the chain's own waits give up after ~0.2 s)
+#define FL_IDLE_LIMIT 15000u          // idle looks (1 .. 16 us apart: ~0.24 s) before a workgroup gives up -- just above the chain's own waits (~0.2 s); round 5: 60000 (0.9 s) was what the rare stall of tools/flow_soak.py cost
 #define FL_LA 8                       // positions behind the head of a compare-and-swap queue whose readiness a look already knows
 
 // How a workgroup gets its next tile.  Wave 0 looks at every queue at once, one lane per candidate:
@@ -694,7 +694,7 @@ bool flow_enabled(const mogp_model* m, const Spd& w) {
     const char* eo = std::getenv("MOGP_FLOW");                 // read per call: tests switch it inside one process
     const char* en = std::getenv("MOGP_FLOW_MIN");
     const int on = eo ? std::atoi(eo) : 1, nmin = en ? std::atoi(en) : 8;          // (two outer blocks: below that there is nothing to overlap)
-    if (!on || m->no_flow || !chain_enabled(m) || !m->ctx->st_priv) return false;
+    if (!on || (m->no_flow && m->n_fact < m->flow_retry_at) || !chain_enabled(m) || !m->ctx->st_priv) return false;      // (after a time-out: the stream schedule until flow_retry_at, then another try)
     if (m->kinv_sparse && &w == &m->k) return false;          // a planned (partial) inverse: the stream schedule knows how
     return w.nb >= nmin && w.nb <= 0xfff0;
 }

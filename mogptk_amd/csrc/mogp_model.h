@@ -315,7 +315,9 @@ struct mogp_model {
     bool flow_ran = false;              // some factorisation of this model has used the dataflow schedule since the last fallback
     const FlowRhs* rhs_job = nullptr;   // set by the prediction around its factorize() call: solve these right-hand sides inside the dataflow schedule
     bool replay_flow = false;           // mogp_model_flow_replay: the next gradient evaluations run the dataflow kernel ALONE on the measurement plan (no chain kernels)
-    bool no_flow = false;               // the dataflow kernel timed out once on this model: stream schedule from now on
+    bool no_flow = false;               // the dataflow kernel timed out: stream schedule until evaluation number flow_retry_at (chain_fallback)
+    long long n_fact = 0, flow_retry_at = 0;      // factorisations so far; when the dataflow schedule is tried again
+    int flow_backoff = 64, flow_timeouts = 0;
     bool no_chain = false;              // the persistent chain kernel timed out once on this model (another process's chain kernel held the reserved CUs): launch-per-step chain from now on
     TitsiasWork* tw = nullptr;
     OaWork oa;
