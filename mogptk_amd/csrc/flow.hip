@@ -320,7 +320,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                         } else if (peek) {                                      // the head looked ready: take a ticket; if others were faster the ticket is a
                             const unsigned hh = __hip_atomic_fetch_add(heads + myq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // later task: hold it
                             if (hh == (unsigned)h) { ok = 1; res = qbase + h; }
-                            else if (hh < (unsigned)qsize) pend = (int)hh;
+                            else if (hh < (unsigned)qsize) { pend = (int)hh; if (g.trace) g.trace[FLOW_TRACE_W * (size_t)(qbase + (int)hh) + 5] = (1ull << 63) | blockIdx.x; }
                             else exhausted = true;
                         } else {
                             ok = 1; res = qbase + pend;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                             // queue, where a task held by a busy workgroup is a task an idle one cannot take
                             if (g.refill && pend + 2 * (int)gridDim.x < qsize) {
                                 const unsigned hh = __hip_atomic_fetch_add(heads + myq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (hh < (unsigned)qsize) pend = (int)hh; else { pend = -1; exhausted = true; }
+                                if (hh < (unsigned)qsize) { pend = (int)hh; if (g.trace) g.trace[FLOW_TRACE_W * (size_t)(qbase + (int)hh) + 5] = (1ull << 63) | blockIdx.x; } else { pend = -1; exhausted = true; }
                             } else pend = -1;
                         }
                     }
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                 }
                 if (want) {
                     const unsigned hh = __hip_atomic_fetch_add(heads + myq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (hh < (unsigned)qsize) { pend = (int)hh; took = true; } else exhausted = true;
+                    if (hh < (unsigned)qsize) { pend = (int)hh; took = true; if (g.trace) g.trace[FLOW_TRACE_W * (size_t)(qbase + (int)hh) + 5] = (1ull << 63) | blockIdx.x; } else exhausted = true;      // (trace: who HOLDS the task; overwritten when it starts)
                 }
                 const bool open = is_cas ? (myk == 0 && h < qsize) : (is_eager && (pend >= 0 || !exhausted));
                 if (!__ballot(open)) { res = -2; break; }                      // every queue is empty and nothing is held: done

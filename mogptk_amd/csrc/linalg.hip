@@ -48,6 +48,8 @@ template <int AKM, int BKM, int WTM, int WTN, int NWJ = 2, int NWI = 2, bool FLO
 __global__ __launch_bounds__(64 * NWI * NWJ, NWI * NWJ / 2) void k_gemm(GemmArgs g) {
     GEMM_STAMP(0);
     if (FLOWH && g.fl_nwait > 0) {      // inside the dataflow schedule: the operands come from workgroups of a kernel that is still running
+        // (the bound: 1.6 M polls, ~0.28 s.  Round 5's soak -- tools/flow_soak.py, profiles/r5_flow_soak.txt -- saw the dataflow kernel stand still for 60 - 70 ms once in a few
+        // thousand evaluations, every one of its workgroups, and go on by itself; with the earlier 400 000 polls this wait gave up just before it did)
         if (threadIdx.x == 0) {
             for (int k = 0; k < g.fl_nwait; ++k) {
                 unsigned spins = 0;
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(64 * NWI * NWJ, NWI * NWJ / 2) void k_gemm(GemmArgs
                     __builtin_amdgcn_s_sleep(2);
                     if ((++spins & 127u) == 0u) {
                         if (__hip_atomic_load(g.fl_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                        if (spins > (g.fl_spins ? g.fl_spins : 400000u)) { __hip_atomic_store(g.fl_err, 0x800u + (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        if (spins > (g.fl_spins ? g.fl_spins : 1600000u)) { __hip_atomic_store(g.fl_err, 0x800u + (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                     }
                 }
             }

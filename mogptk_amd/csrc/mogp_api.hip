@@ -660,6 +660,7 @@ namespace mogp { void flow_debug_dump(mogp_model* m) {
         e = hipMemcpy(tr.data(), m->k.flow_trace.p, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost); (void)e;
     }
     fprintf(stderr, "  error word 0x%x\n", fl[p.base_err]);
+    std::set<unsigned> holders;
     for (int q = 0; q < p.nq; ++q) {
         const unsigned h = fl[p.base_heads + q];
         const unsigned claimed = std::min<unsigned>(h, (unsigned)p.qsize[q]);
@@ -676,10 +677,40 @@ namespace mogp { void flow_debug_dump(mogp_model* m) {
             fprintf(stderr, "\n      %s task %u key %u C(buf %d %d,%d) A(buf %d %d,%d) B(buf %d %d,%d) kt %d var %d:", hh < claimed ? "CLAIMED" : "head   ", hh, t.key,
                     t.cbuf, t.cr, t.cc, t.abuf, t.ar, t.ac, t.bbuf, t.br, t.bc, t.kt, t.var);
             for (int d = 0; d < t.ndep; ++d) fprintf(stderr, " flag[%u]=%u/%u", t.dep[d], fl[t.dep[d]], (unsigned)t.need[d]);
-            if (!tr.empty()) fprintf(stderr, "  (taken by wg %llu: %s)", tr[FLOW_TRACE_W * ti + 5] & 0xffff, tr[FLOW_TRACE_W * ti + 1] ? "running" : "not started");
+            if (!tr.empty()) {
+                const unsigned long long w5 = tr[FLOW_TRACE_W * ti + 5];
+                if (w5 >> 63) { fprintf(stderr, "  (HELD by wg %llu%s)", w5 & 0xffff, tr[FLOW_TRACE_W * ti + 1] ? ": STARTED, not finished" : ""); holders.insert((unsigned)(w5 & 0xffff)); }
+                else fprintf(stderr, "  (taken by wg %llu: %s)", w5 & 0xffff, tr[FLOW_TRACE_W * ti + 1] ? "running" : "not started");
+            }
         }
         if (!tr.empty()) fprintf(stderr, "\n      finished %u", done);
         fprintf(stderr, "\n");
+    }
+    if (!tr.empty() && !holders.empty()) {                                  // what the workgroups that HOLD unfinished tasks did last
+        unsigned long long t0 = ~0ull, tmax = 0;
+        for (size_t i = 0; i < p.tasks.size(); ++i) {
+            const unsigned long long s1 = tr[FLOW_TRACE_W * i + 1];
+            if (s1) { t0 = std::min(t0, s1); tmax = std::max(tmax, std::max(s1, tr[FLOW_TRACE_W * i + 4])); }
+        }
+        fprintf(stderr, "  last time stamp of the evaluation: %.1f us after its first task\n", (double)(tmax - t0) / 100.0);
+        int shown = 0;
+        for (unsigned wg : holders) {
+            size_t last = (size_t)-1, held = 0;
+            for (size_t i = 0; i < p.tasks.size(); ++i) {
+                const unsigned long long w5 = tr[FLOW_TRACE_W * i + 5];
+                if ((unsigned)(w5 & 0xffff) != wg) continue;
+                if (w5 >> 63) { ++held; if (!tr[FLOW_TRACE_W * i + 1]) continue; }
+                if (tr[FLOW_TRACE_W * i + 1] && (last == (size_t)-1 || tr[FLOW_TRACE_W * i + 1] > tr[FLOW_TRACE_W * last + 1])) last = i;
+            }
+            if (shown++ >= 24) break;
+            if (last == (size_t)-1) { fprintf(stderr, "  holder wg %u: holds %zu, has started NO task\n", wg, held); continue; }
+            const FlowTask& t = p.tasks[last];
+            fprintf(stderr, "  holder wg %u (xcc %llu): holds %zu; its last task %zu var %d kt %d: looked %.1f taken %.1f k loop %.1f .. %.1f signalled %.1f us%s\n", wg,
+                    (tr[FLOW_TRACE_W * last + 5] >> 16) & 0xff, held, last, t.var, t.kt,
+                    (double)((long long)(tr[FLOW_TRACE_W * last + 0] - t0)) / 100.0, (double)((long long)(tr[FLOW_TRACE_W * last + 1] - t0)) / 100.0,
+                    (double)((long long)(tr[FLOW_TRACE_W * last + 2] - t0)) / 100.0, (double)((long long)(tr[FLOW_TRACE_W * last + 3] - t0)) / 100.0,
+                    tr[FLOW_TRACE_W * last + 4] ? (double)((long long)(tr[FLOW_TRACE_W * last + 4] - t0)) / 100.0 : -1.0, tr[FLOW_TRACE_W * last + 4] ? "" : "  <- NOT FINISHED");
+        }
     }
     if (!tr.empty()) {                                                      // tasks finished and workgroups seen per 5 ms
         unsigned long long t0 = ~0ull;
