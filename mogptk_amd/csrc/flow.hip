@@ -237,7 +237,7 @@ __device__ __forceinline__ void flow_apart(const FlowArgs& g, const int r0, cons
     }
 }
 
-#define FL_IDLE_LIMIT 15000u          // idle looks (1 .. 16 us apart: ~0.24 s) before a workgroup gives up -- just above the chain's own waits (~0.2 s); round 5: 60000 (0.9 s) was what the rare stall of tools/flow_soak.py cost
+#define FL_IDLE_LIMIT 4000u           // idle looks (1 .. 16 us apart: ~65 ms) before a workgroup gives up.  Round 5: 60000 (0.9 s) was what the rare stall of tools/flow_soak.py cost; a time-out is a detour since (chain_fallback), so a false one is cheap and a true one should be
 #define FL_LA 8                       // positions behind the head of a compare-and-swap queue whose readiness a look already knows
 
 // How a workgroup gets its next tile.  Wave 0 looks at every queue at once, one lane per candidate:
