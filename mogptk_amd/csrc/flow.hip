@@ -24,6 +24,7 @@
 // Replaces torch.linalg.cholesky + the O(N^3) solves of its autograd backward (reference gpr/model.py:242-246, :291).
 #include "mogp_model.h"
 #include <unistd.h>
+#include <chrono>
 
 #include <cstdio>
 #include <cstdlib>
@@ -703,6 +704,7 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     const int nb = w.nb, ob = 4;
     const int64_t ld = w.Npad;
     int rc;
+    const auto host_t0 = std::chrono::steady_clock::now();     // how long the HOST takes to enqueue this evaluation (chain_fallback reports it: a stalled host looks like a stalled device)
     hipStream_t crit = m->st, priv = m->st_priv, bulk = m->st2;
     if (w.Wm.n < (size_t)ld * ld) {                      // nothing ever writes above the block diagonal of W: keep it zero
         if ((rc = w.Wm.ensure((size_t)ld * ld))) return rc;
@@ -838,6 +840,8 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     w.fused_last_inv = nullptr; w.fused_last_wt = nullptr;
     w.flow_used = true;
     m->flow_ran = true;
+    m->flow_enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count();
+    m->flow_enqueue_us_max = std::max(m->flow_enqueue_us_max, m->flow_enqueue_us);
     { const char* e = std::getenv("MOGP_FLOW_DEBUG");
       if (e && std::atoi(e) == 2 && &w == &m->k) { usleep(60000); fprintf(stderr, "mogp: dataflow state 60 ms after the evaluation was enqueued\n"); flow_debug_dump(m); } }
     return 0;

@@ -755,6 +755,7 @@ namespace mogp { int chain_fallback(mogp_model* m) {
             unsigned code = 0;                       // which wait gave up: 0x700 an idle workgroup of the dataflow kernel, 0x800 + k a hook of a private-stream launch, else a chain kernel's
             if (m->k.flow_flags.p && m->k.flow_cur && m->k.flow_cur->base_err > 0) { hipError_t e = hipMemcpy(&code, m->k.flow_flags.p + m->k.flow_cur->base_err, sizeof(code), hipMemcpyDeviceToHost); (void)e; }
             fprintf(stderr, "mogp: the dataflow kernel timed out (wait 0x%x; GPU shared with another process?); using the stream schedule for the next %d evaluations (said once)\n", code, (int)(m->flow_retry_at - m->n_fact));
+            fprintf(stderr, "mogp: the host enqueued that evaluation in %.0f us (longest so far %.0f us)\n", m->flow_enqueue_us, m->flow_enqueue_us_max);
             if (std::getenv("MOGP_FLOW_DEBUG")) flow_debug_dump(m);
         }
         return 0;

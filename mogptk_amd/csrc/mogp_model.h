@@ -318,6 +318,7 @@ struct mogp_model {
     bool no_flow = false;               // the dataflow kernel timed out: stream schedule until evaluation number flow_retry_at (chain_fallback)
     long long n_fact = 0, flow_retry_at = 0;      // factorisations so far; when the dataflow schedule is tried again
     int flow_backoff = 64, flow_timeouts = 0;
+    double flow_enqueue_us = 0.0, flow_enqueue_us_max = 0.0;      // host time spent enqueuing the last dataflow evaluation / the longest so far
     bool no_chain = false;              // the persistent chain kernel timed out once on this model (another process's chain kernel held the reserved CUs): launch-per-step chain from now on
     TitsiasWork* tw = nullptr;
     OaWork oa;
