@@ -174,9 +174,10 @@ def cpu_baseline(N, C, Q, budget_s=240.0):
                        "extrapolated by N^3 (x%.0f)" % (n, t, N, budget_s, scale))
 
 
-def timed_region(step, steps, warmup, dist=None, sync=lambda: None, device="cpu"):
+def timed_region(step, steps, warmup, dist=None, sync=lambda: None, device="cpu", per_step=None):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on both sides; returns the MAX
-    over ranks of the elapsed wall time (seconds).  `dist` is torch.distributed (initialised) or None."""
+    over ranks of the elapsed wall time (seconds).  `dist` is torch.distributed (initialised) or None.  per_step (a list): this rank's
+    wall time of every step is appended -- a step ends with its result on the host, so the stamps cost nothing and split the region exactly."""
     import torch
     for _ in range(warmup):
         step(-1)
@@ -184,8 +185,13 @@ def timed_region(step, steps, warmup, dist=None, sync=lambda: None, device="cpu"
         dist.barrier()
     sync()
     t0 = time.perf_counter()
+    tp = t0
     for i in range(steps):
         step(i)
+        if per_step is not None:
+            tn = time.perf_counter()
+            per_step.append(tn - tp)
+            tp = tn
     sync()
     if dist is not None:
         dist.barrier()
@@ -656,23 +662,31 @@ def main():
             acc["launches"] += nl
             acc["nprof"] += 1
 
-    dt = timed_region(step, steps, warmup, dist, sync, "cuda" if dist is not None else "cpu")
+    step_times = []
+    dt = timed_region(step, steps, warmup, dist, sync, "cuda" if dist is not None else "cpu", per_step=step_times)
     gemm_flops, gemm_launches, nprof = acc["flops"], acc["launches"], max(acc["nprof"], 1)
     h.set_profiling(False)
     # a longer sample of the same step right behind the timed region (the chip's clocks take tens of ms of load to settle, and K = 20 steps of
     # configs[1] are 0.2 s): reported beside `value`, never instead of it
     sustained = None
     if a.sustained > 0 and not big and not sharded_mode:
-        dts = timed_region(lambda i: train_step(), a.sustained, 0, dist, sync, "cuda" if dist is not None else "cpu")
+        sus_times = []
+        dts = timed_region(lambda i: train_step(), a.sustained, 0, dist, sync, "cuda" if dist is not None else "cpu", per_step=sus_times)
         sustained = {"steps": a.sustained, "ms_per_step": 1e3 * dts / a.sustained, "value": aggregate_value(world, a.sustained, dts),
+                     "median_ms_per_step": 1e3 * float(np.median(sus_times)), "max_ms_per_step": 1e3 * float(np.max(sus_times)),
                      "note": "the same step, %d more times behind the timed region" % a.sustained}
     if sharded_mode:
         mogptk_amd.use_single_device()
 
     out = None
     if rank == 0:
-        ms_per_step = 1e3 * dt / steps
-        value = aggregate_value(world, steps, dt, sharded_mode)
+        # SURVEY 8d's statistic: the MEDIAN of the K timed steps (K >= 10) is the headline at N = 1 -- the mean of the same K steps (what the
+        # bracketed region divides out to) stays beside it; at N > 1 the region's max-over-ranks time is the only number all ranks share
+        mean_ms_per_step = 1e3 * dt / steps
+        value_mean = aggregate_value(world, steps, dt, sharded_mode)
+        use_median = world == 1 and not sharded_mode and len(step_times) >= 10
+        ms_per_step = 1e3 * float(np.median(step_times)) if use_median else mean_ms_per_step
+        value = 1e3 / ms_per_step if use_median else value_mean
         # The GEMM launches of one evaluation run on up to five streams at once (potri.hip), so the sum of their durations exceeds the
         # wall-clock time they occupy: `span` prices them over the factorisation + inversion stage, `per_launch` over the sum of their
         # own durations (what a kernel trace averages to); `frac` -- the headline -- prices the ALGORITHMIC flops over the whole step.
@@ -720,7 +734,10 @@ def main():
                    "ONE evaluation split over the GPUs (the north_star's distributed Cholesky) is measured in `sharded`" % (world, world))
         out = {
             "metric": metric, "value": value, "unit": METRICS[kind][1], "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if sharded_mode else "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "statistic": ("median of the %d timed steps (SURVEY.md 8d)" % steps) if use_median else "steps / bracketed region (max over ranks)",
+            "mean_ms_per_step": mean_ms_per_step, "value_mean": value_mean, "timed_region_s": dt,
+            "min_ms_per_step": 1e3 * float(np.min(step_times)) if step_times else None, "max_ms_per_step": 1e3 * float(np.max(step_times)) if step_times else None,
+            "higher_is_better": True, "scaling": "strong" if sharded_mode else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc if not a.n else desc + " [N overridden: %d]" % N, "channels": C, "Q": Q, "N": N, "parallelism": par,
                        "inverse_tiles_formed": inv_frac,
@@ -768,6 +785,12 @@ def main():
         if kind == "exact" and not sharded_mode and acc["nprof"] > 0:
             out["roofline"].update({
                 "algorithmic_bytes_per_launch": 8.0 * N * N * (N / 512.0) / max(gemm_launches / nprof, 1.0),
+                # SURVEY 8d's own figure for one evaluation (24 N^2: Gram written, G read, L read twice) beside the blocked algorithm's minimum C traffic above
+                "algorithmic_bytes_per_eval": 24.0 * N * N,
+                "traffic_over_algorithmic_bytes_per_eval": (out["roofline"]["traffic"] / (24.0 * N * N)) if out["roofline"].get("traffic") else None,
+                # the same algorithmic flops over the DOMINANT KERNEL's own duration (HIP events around its launch in the profiled step): what a
+                # kernel trace's average duration gives -- `frac` above prices them over the whole step (Gram, moments, host share included)
+                "kernel_frac": (algo_flops / (gemm_s / nprof) / 1e12 / FP64_MFMA_PEAK_TFLOPS) if (gemm_s > 0 and gemm_launches / nprof <= 2.0) else None,
                 "span": gemm_flops / span_s / 1e12 if span_s > 0 else None,
                 "per_launch": gemm_flops / gemm_s / 1e12 if gemm_s > 0 else None,
                 "overlap": gemm_s / span_s if span_s > 0 else None,

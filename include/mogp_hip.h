@@ -259,6 +259,13 @@ int  mogp_model_schedule(mogp_model* m, int* flags);
  * the previous evaluation's: use the mode for measurement only.  Requires a completed gradient evaluation on this model.  on = 0: back to normal. */
 int  mogp_model_flow_replay(mogp_model* m, int on);
 
+/* Diagnostic counters of the dataflow schedule, summed over every evaluation of this model so far (no counterpart in the reference).  A workgroup
+ * (or a chain kernel / private-stream hook) that has waited for a few ms re-reads what it waits for with RETURNING read-modify-writes -- a "deep"
+ * look -- next to the sc1 loads every look uses, and counts the answers that differ.  out[0] deep looks of the dataflow kernel, out[1] of them with a
+ * different queue head, out[2] with dependency counters the loads called unmet and the atomics met; out[3] deep polls of the other kernels' waits,
+ * out[4] of them that ended the wait; out[5..7] the last such dependency (counter index, value, workgroup | XCC << 16). */
+int  mogp_model_flow_diag(mogp_model* m, unsigned* out8);
+
 /* The fused factorisation + inversion behind mogp_exact_eval(MOGP_EVAL_GRAD) (reference gpr/model.py:242-246 and the O(N^3) solves of its
  * autograd backward, :291) runs as a static graph of 128 x 128 tile products inside ONE resident kernel (csrc/flow.hip).  This call returns
  * that graph for a matrix of nb tile rows as numbers -- no device work, callable without a GPU -- so that tests can replay it on the CPU

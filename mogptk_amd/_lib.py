@@ -85,6 +85,7 @@ SIGNATURES = {
     "mogp_model_fetch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_dp]),
     "mogp_model_schedule": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
     "mogp_model_flow_replay": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "mogp_model_flow_diag": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint)]),
     "mogp_flow_plan": (ctypes.c_int, [ctypes.c_int, c_i64p, ctypes.c_int64, c_i64p]),
     "mogp_flow_plan_rhs": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_i64p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     "mogp_flow_trace": (ctypes.c_int, [ctypes.c_void_p, c_i64p, ctypes.c_int64, c_i64p]),
@@ -515,13 +516,22 @@ class ExactHandle:
         return dict(dataflow=bool(f.value & 1), chain_kernel=bool(f.value & 2), dataflow_fell_back=bool(f.value & 4), chain_fell_back=bool(f.value & 8),
                     dataflow_timeouts=(f.value >> 8) & 0xffff)
 
+    def flow_diag(self):
+        """-> dict of the dataflow schedule's deep-look counters over this model's life (mogp_model_flow_diag)"""
+        out = (ctypes.c_uint * 8)()
+        check(lib().mogp_model_flow_diag(self._h, out))
+        return dict(deep_looks=out[0], stale_heads=out[1], stale_counters=out[2], deep_polls=out[3], stale_polls=out[4], last=(out[5], out[6], out[7] & 0xffff, out[7] >> 16))
+
     def flow_replay(self, on):
         """measurement mode (mogp_model_flow_replay): the next gradient evaluations run the dataflow kernel alone on the replay plan"""
         check(lib().mogp_model_flow_replay(self._h, 1 if on else 0))
 
+    accurate_mode = False          # what the last set_accurate asked for (a NEW handle starts in the fast mode, as the device object does)
+
     def set_accurate(self, on):
         """gradient evaluations in the backward-stable form (mogp_model_set_accurate): slower, for ill-conditioned Kj"""
         check(lib().mogp_model_set_accurate(self._h, 1 if on else 0))
+        self.accurate_mode = bool(on)
 
     def condition_estimate(self):
         """(largest / smallest diagonal entry of L)^2 of the last factorisation: a lower estimate of cond(Kj); nan when it was not reported"""

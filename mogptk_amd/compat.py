@@ -330,7 +330,11 @@ def _convert_model(bag):
         raise NotImplementedError("likelihood %s with %s inference: only the variational models take a non-Gaussian likelihood" % (lik.cls(), inference_name))
     if inference_name == "Exact":
         dv = g.get("data_variance")
-        inference = _model.Exact(data_variance=None if dv is None else _num(dv), jitter=float(g["jitter"]))
+        if dv is not None:
+            dv = _num(dv)
+            if dv.ndim == 2:                                     # the reference keeps the per-point variances as a dense diagonal MATRIX (gpr/model.py:423)
+                dv = np.diagonal(dv).copy()
+        inference = _model.Exact(data_variance=dv, jitter=float(g["jitter"]))
     elif inference_name == "Titsias":
         Z = g["_parameters"]["Z"]
         inference = _model.Titsias(inducing_points=np.array(Z.data), jitter=float(g["jitter"]))
@@ -528,7 +532,9 @@ class _Exporter:
         own, first = {}, {}
         if name == "Exact":
             dv = g.data_variance
-            first["data_variance"] = None if dv is None else self.tensor(dv)
+            # the reference adds this attribute to Kff as it is (gpr/model.py:442, :466): it must be the N x N diagonal matrix its own constructor
+            # builds with diagflat (:423) -- a vector would broadcast over every row and load without complaint
+            first["data_variance"] = None if dv is None else self.torch.diagflat(self.tensor(np.reshape(dv, -1)))
         own.update({"X": self.tensor(X), "y": self.tensor(np.reshape(g.y, (-1, 1))), "mean": None, "jitter": float(g.jitter),
                     "input_dims": int(X.shape[1]), "_compiled_forward": None})
         pars = []

@@ -47,10 +47,11 @@ struct ChainArgs {
     unsigned* done_flag;
     int wt;                         // W_KK leaves with write-through stores (its readers are workgroups of a kernel that is already running)
     unsigned long long* trace;
+    unsigned* diag;                 // FLOW_DIAG_* counters (null outside the dataflow schedule)
 };
 
 // ---- hand-off -------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void ch_wait(unsigned* flag, unsigned expect, unsigned* err, unsigned code) {
+__device__ __forceinline__ void ch_wait(unsigned* flag, unsigned expect, unsigned* err, unsigned code, unsigned* diag = nullptr) {
     __syncthreads();                                   // this workgroup's own stores and LDS traffic are behind us
     if (threadIdx.x == 0) {
         unsigned spins = 0;
@@ -59,6 +60,11 @@ __device__ __forceinline__ void ch_wait(unsigned* flag, unsigned expect, unsigne
             if ((++spins & 127u) == 0u) {
                 if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                 if (spins > CH_SPIN_LIMIT) { __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if ((spins & 8191u) == 0u) {           // a DEEP poll (~every ms of waiting): a returning read-modify-write instead of the sc1 load
+                    const unsigned v = __hip_atomic_fetch_or(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (diag) __hip_atomic_fetch_add(diag + FLOW_DIAG_WAIT_DEEP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v >= expect) { if (diag) __hip_atomic_fetch_add(diag + FLOW_DIAG_WAIT_STALE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ONE buffer_inv sc1 after the match; plain loads from here on
@@ -172,7 +178,7 @@ __device__ __forceinline__ void ch_strip_window(const ChainArgs& g, double* ctx,
     }
     if (k + 1 >= g.nk) return;
     // the four slabs of L(k + 1, k) -- and with them every earlier panel of that tile row: a slab owner takes its steps in order
-    ch_wait(g.flags + CF_PAN + 4 * k + (k + 1), 4u, g.err, 0x300u + (unsigned)k);
+    ch_wait(g.flags + CF_PAN + 4 * k + (k + 1), 4u, g.err, 0x300u + (unsigned)k, g.diag);
     d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
     for (int i = s; i <= k; ++i) {
         const double* L = Ablk + (int64_t)(k + 1) * MOGP_TILE * g.ld + (int64_t)i * MOGP_TILE;
@@ -194,12 +200,12 @@ __global__ __launch_bounds__(256, 1) void k_chain(ChainArgs g) {
     if (g.trace && blockIdx.x == 0 && tid == 0) g.trace[0] = wall_clock64();
     // dataflow schedule: the diagonal block is complete when the update tasks of the previous panel have all reported (their tiles were
     // stored write-through by another kernel's workgroups: ch_wait's acquire makes them visible)
-    if (g.wait_flag) ch_wait(g.wait_flag, g.wait_val, g.err, 0x500u);
+    if (g.wait_flag) ch_wait(g.wait_flag, g.wait_val, g.err, 0x500u, g.diag);
     if (g.trace && blockIdx.x == 0 && tid == 0) g.trace[1] = wall_clock64();
     if (blockIdx.x == 0) {
         // ---- the leaves ----
         for (int k = 0; k < nk; ++k) {
-            if (k > 0) ch_wait(g.flags + CF_DIAG + k, 4u, g.err, 0x100u + (unsigned)k);
+            if (k > 0) ch_wait(g.flags + CF_DIAG + k, 4u, g.err, 0x100u + (unsigned)k, g.diag);
             leaf_tile<true>(ch_lds, g.A, g.ld, g.t0 + k, g.invd, g.logdet, g.info, g.info_base, 0);
             ch_signal(g.flags + CF_LEAF + k);
         }
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void k_chain(ChainArgs g) {
         double* As = Ablk + (int64_t)(MOGP_TILE * ti + 32 * q) * g.ld;       // the slab's rows, column 0 of the block
         const int nstrips = 8 * (nk - 1);
         for (int k = 0; k < nk; ++k) {
-            ch_wait(g.flags + CF_LEAF + k, 1u, g.err, 0x200u + (unsigned)k);
+            ch_wait(g.flags + CF_LEAF + k, 1u, g.err, 0x200u + (unsigned)k, g.diag);
             if (ti > k && ti < nk) {
                 const double* Dk = g.invd + (int64_t)(g.t0 + k) * MOGP_TILE * MOGP_TILE;
                 double* Ps = As + (int64_t)MOGP_TILE * k;
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(256, 1) void k_chain(ChainArgs g) {
                     ch_signal(g.flags + CF_PAN + 4 * k + ti);
                 }
                 for (int j = k + 1; j <= ti; ++j) {                 // the diagonal tile of the next leaf first
-                    ch_wait(g.flags + CF_PAN + 4 * k + j, 4u, g.err, 0x400u + (unsigned)(4 * k + j));
+                    ch_wait(g.flags + CF_PAN + 4 * k + j, 4u, g.err, 0x400u + (unsigned)(4 * k + j), g.diag);
                     double* Cs = As + (int64_t)MOGP_TILE * j;
                     const double* Pj = Ablk + (int64_t)MOGP_TILE * j * g.ld + (int64_t)MOGP_TILE * k;
                     const int cmax = (j == ti) ? 2 * q + 1 : 7;     // own tile row: only the columns up to the slab's last row
@@ -288,7 +294,8 @@ __global__ __launch_bounds__(256, 1) void k_chain(ChainArgs g) {
             }
         }
     }
-    if (g.done_flag) {              // W_KK (and everything else this workgroup stored) has left the CU before the counter moves
+    if (g.done_flag && __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {              // W_KK (and everything else this workgroup stored) has left the CU before the counter moves
+        // (after a time-out anywhere the counter stays put: nothing downstream may start on a void evaluation)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -316,7 +323,7 @@ int launch_chain(double* A, int64_t ld, int t0, int nk, double* invd, double* lo
     ChainArgs g{};
     g.A = A; g.ld = ld; g.t0 = t0; g.nk = nk; g.invd = invd; g.logdet = logdet; g.info = info; g.info_base = info_base;
     g.Wk = Wk; g.ldw = ldw; g.flags = flags; g.err = err;
-    if (flow) { g.wait_flag = flow->wait_flag; g.wait_val = flow->wait_val; g.done_flag = flow->done_flag; g.wt = flow->write_through; g.trace = flow->trace; }
+    if (flow) { g.wait_flag = flow->wait_flag; g.wait_val = flow->wait_val; g.done_flag = flow->done_flag; g.wt = flow->write_through; g.trace = flow->trace; g.diag = flow->diag; }
     hipLaunchKernelGGL(k_chain, dim3(nk > 1 ? CH_NWG : 2), dim3(256), CH_LDS_BYTES, s, g);
     HIP_TRY(hipGetLastError());
     return 0;

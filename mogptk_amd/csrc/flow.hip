@@ -176,6 +176,10 @@ struct FlowArgs {
     const double* vy; double* vz; double* vzz; double* vpart;         // z = W y and alpha = W^T z as tasks (null: those tasks only count)
     int64_t npad;
     unsigned long long* info;
+    int post_base;                    // (the second, small instance of the kernel reports behind the first one's workgroups)
+    unsigned char* done;              // optional (MOGP_FLOW_DEBUG): one byte per task, set when the task has signalled
+    unsigned* post;                   // optional post-mortem (MOGP_FLOW_DEBUG): [workgroups][FLOW_POST_W]: exit code + 4, idle looks, state, last task, 64 x (held ticket + 1)
+    unsigned* diag;                   // FLOW_DIAG_WORDS counters that outlive the evaluation (deep looks, what they found)
     unsigned long long* trace;        // optional: [FLOW_TRACE_W ntasks] look, claimed, k loop from, to, signalled (100 MHz wall clock), XCC << 16 | workgroup
 };
 
@@ -239,6 +243,8 @@ __device__ __forceinline__ void flow_apart(const FlowArgs& g, const int r0, cons
 }
 
 #define FL_IDLE_LIMIT 4000u           // idle looks (1 .. 16 us apart: ~65 ms) before a workgroup gives up.  Round 5: 60000 (0.9 s) was what the rare stall of tools/flow_soak.py cost; a time-out is a detour since (chain_fallback), so a false one is cheap and a true one should be
+#define FL_DEEP_AFTER 128u            // idle looks (~2 ms) before the first deep look of a wait, then one in FL_DEEP_EVERY
+#define FL_DEEP_EVERY 32u
 #define FL_LA 8                       // positions behind the head of a compare-and-swap queue whose readiness a look already knows
 
 // How a workgroup gets its next tile.  Wave 0 looks at every queue at once, one lane per candidate:
@@ -273,6 +279,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
     unsigned long long t_look = 0;
     for (;;) {
         if (g.trace && tid == 0) t_look = wall_clock64();
+        if (g.post && tid == 0) { g.post[(size_t)(g.post_base + blockIdx.x) * FLOW_POST_W + 2] = 1u; g.post[(size_t)(g.post_base + blockIdx.x) * FLOW_POST_W + 4] = (unsigned)(wall_clock64() >> 4); }      // looking
         if (wave == 0) {
             int res = -1;
             unsigned nap = 0;
@@ -294,6 +301,17 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                     idx = pend;
                 }
                 bool ready = false;
+                // a DEEP look (round 6): a workgroup that has found nothing for a few ms reads its counters with returning read-modify-writes
+                // (fetch-or 0: answered where the atomics are performed) instead of sc1 loads (answered by the XCD's L2), and counts every
+                // answer that differs -- see FLOW_DIAG_* and DESIGN section 4 "the stall"
+                const bool deep = idle >= FL_DEEP_AFTER && (idle & (FL_DEEP_EVERY - 1u)) == 0u;
+                if (deep && is_cas) {
+                    int h2 = (int)__hip_atomic_fetch_or(heads + myq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    h2 = __shfl(h2, lane - myk, 64);
+                    if (h2 != h && myk == 0) __hip_atomic_fetch_add(g.diag + FLOW_DIAG_HEAD_STALE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    h = h2;
+                    idx = h + myk < qsize ? h + myk : -1;
+                }
                 if (idx >= 0) {
                     const FlowTask* t = g.tasks + qbase + idx;
                     const int nd = t->ndep;
@@ -301,8 +319,29 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                     for (int d = 0; d < 4; ++d)
                         if (d < nd && __hip_atomic_load(g.flags + t->dep[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)t->need[d])
                             ready = false;
+                    if (deep && !ready) {
+                        bool ready2 = true;
+                        unsigned seen = 0, which = 0;
+                        for (int d = 0; d < 4; ++d)
+                            if (d < nd) {
+                                const unsigned v = __hip_atomic_fetch_or(g.flags + t->dep[d], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (v < (unsigned)t->need[d]) ready2 = false; else { seen = v; which = t->dep[d]; }
+                            }
+                        if (ready2) {                                          // the loads said "not yet", the memory side says "all there"
+                            __hip_atomic_fetch_add(g.diag + FLOW_DIAG_DEP_STALE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(g.diag + FLOW_DIAG_LAST, which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(g.diag + FLOW_DIAG_LAST + 1, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(g.diag + FLOW_DIAG_LAST + 2, (unsigned)blockIdx.x | ((unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ready = true;
+                        }
+                    }
                 }
+                if (deep && lane == 0) __hip_atomic_fetch_add(g.diag + FLOW_DIAG_DEEP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long mready = __ballot(ready);
+                if (g.post) {                                  // debugging: freeze at once when anybody has given up (the state the host dumps is then the state of the stall)
+                    if (lane == 0) { g.post[(size_t)(g.post_base + blockIdx.x) * FLOW_POST_W + 6] = (unsigned)mready; g.post[(size_t)(g.post_base + blockIdx.x) * FLOW_POST_W + 7] = (unsigned)(mready >> 32); }
+                    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { res = -3; break; }
+                }
                 const unsigned long long cand = mready & (cas_heads | eager_mask);
                 if (cand) {
                     const int wl = __ffsll((long long)cand) - 1;               // lanes are in priority order
@@ -368,6 +407,11 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                 pick[0] = res;
                 if (res >= 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ONE buffer_inv sc1 behind the satisfied counters
             }
+            if (g.post && res < 0) {                           // post-mortem: what this workgroup still held when it left, and why it left
+                unsigned* po = g.post + (size_t)(g.post_base + blockIdx.x) * FLOW_POST_W;
+                po[8 + lane] = is_eager ? (unsigned)(pend + 1) : 0u;
+                if (lane == 0) { po[0] = (unsigned)(res + 4); po[1] = idle; po[2] = 3u; po[5] = (unsigned)(wall_clock64() >> 4); }
+            }
         }
         __syncthreads();
         const int ti = __builtin_amdgcn_readfirstlane(pick[0]);
@@ -389,6 +433,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
         const double alpha = (var & 8) ? -1.0 : 1.0;
         unsigned long long* tr = (g.trace && tid == 0) ? g.trace + FLOW_TRACE_W * (size_t)ti : nullptr;
         if (tr) { tr[0] = t_look; tr[1] = wall_clock64(); }
+        if (g.post && tid == 0) { g.post[(size_t)(g.post_base + blockIdx.x) * FLOW_POST_W + 2] = 2u; g.post[(size_t)(g.post_base + blockIdx.x) * FLOW_POST_W + 3] = (unsigned)ti; }      // running task ti
         if (var & 32) {                                            // vector task: tile row ar (z) or row block ar .. ar + kt - 1, column group ac (alpha)
             if (g.vy) {
                 if (var & 1) flow_apart(g, tp->ar * MOGP_TILE, kt * MOGP_TILE, tp->br, tp->ac, gemm_lds);
@@ -409,6 +454,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
             const unsigned s0 = tp->sig[0], s1 = tp->sig[1];
             if (s0 != FLOW_NOSIG) __hip_atomic_fetch_add(g.flags + s0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (s1 != FLOW_NOSIG) __hip_atomic_fetch_add(g.flags + s1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g.done) g.done[ti] = 1;
             if (tr) {
                 tr[4] = wall_clock64();
                 tr[5] = ((unsigned long long)naps << 32) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16) | blockIdx.x;
@@ -729,6 +775,10 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
         HIP_TRY(dev_upload(d_qmeta.p, qm, sizeof(qm)));
     }
     if ((rc = w.flow_flags.ensure((size_t)plan.nflags))) return rc;
+    if (!w.flow_diag.p) {                                // diagnostic counters that outlive an evaluation (mogp_model_flow_diag)
+        if ((rc = w.flow_diag.ensure(FLOW_DIAG_WORDS))) return rc;
+        HIP_TRY(hipMemsetAsync(w.flow_diag.p, 0, FLOW_DIAG_WORDS * sizeof(unsigned), crit));
+    }
     w.flow_cur = &plan;
     const FlowPlan& p = plan;
     const int nouter = p.nouter;
@@ -766,6 +816,17 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     g.tasks = d_tasks.p; g.qmeta = d_qmeta.p; g.flags = w.flow_flags.p;
     g.nq = p.nq; g.ncas = FLOW_NCAS; g.base_heads = p.base_heads; g.base_err = p.base_err; g.info = m->d_info.p;
     g.trace = want_trace ? w.flow_trace.p : nullptr;
+    g.diag = w.flow_diag.p;
+    static const bool want_post = std::getenv("MOGP_FLOW_DEBUG") && std::atoi(std::getenv("MOGP_FLOW_DEBUG")) != 0;
+    if (want_post) {
+        const size_t nwg = (size_t)wg_per_cu * ((size_t)cus + (size_t)m->ctx->ncu_reserved);
+        if ((rc = w.flow_post.ensure(nwg * FLOW_POST_W))) return rc;
+        HIP_TRY(hipMemsetAsync(w.flow_post.p, 0, w.flow_post.n * sizeof(unsigned), bulk));     // (bulk: in front of the kernel, behind `start`)
+        g.post = w.flow_post.p;
+        if ((rc = w.flow_done.ensure(p.tasks.size()))) return rc;
+        HIP_TRY(hipMemsetAsync(w.flow_done.p, 0, p.tasks.size(), bulk));
+        g.done = w.flow_done.p;
+    }
     g.npad = ld;
     { const char* e = std::getenv("MOGP_FLOW_REFILL"); g.refill = e ? std::atoi(e) : 0; }
     { const char* e = std::getenv("MOGP_FLOW_CLAIM1"); g.claim_one = e ? std::atoi(e) : 0; }
@@ -798,6 +859,7 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
         ChainFlow cf{};
         cf.done_flag = w.flow_flags.p + pc.done_idx; cf.write_through = 1;       // (its diagonal block is complete in stream order: the update below)
         cf.trace = want_trace ? w.flow_trace.p + FLOW_TRACE_W * p.tasks.size() + 4 * (size_t)kb : nullptr;
+        cf.diag = w.flow_diag.p;
         if ((rc = launch_chain(w.A.p, ld, k0, nk, w.invd.p, w.logdet.p, m->d_info.p, 0, w.Wm.p + (int64_t)k0 * MOGP_TILE * (ld + 1), ld,
                                w.chain_flags.p + (size_t)kb * MOGP_CHAIN_FLAGS, ferr, priv, &cf))) return rc;
         if (na <= 0) continue;
@@ -811,7 +873,7 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
         t1.fl_flags = w.flow_flags.p; t1.fl_nwait = pc.t1_nwait;
         for (int k = 0; k < pc.t1_nwait; ++k) { t1.fl_widx[k] = pc.t1_widx[k]; t1.fl_wval[k] = pc.t1_wval[k]; }
         static const unsigned hook_spins = std::getenv("MOGP_FLOW_HOOK_SPINS") ? (unsigned)std::atoll(std::getenv("MOGP_FLOW_HOOK_SPINS")) : 0u;
-        t1.fl_spins = hook_spins;
+        t1.fl_spins = hook_spins; t1.fl_diag = w.flow_diag.p;
         t1.fl_wt = 1; t1.fl_sig = 1; t1.fl_sig_base = pc.t1_sig_base; t1.fl_sig_shift = 1; t1.fl_err = ferr; t1.sk_info = m->d_info.p;
         if ((rc = launch_gemm(t1, priv))) return rc;
         // (the first launch of this stream that touches A beyond its first 512 columns: the rest of the Gram matrix may still be on its way)
@@ -822,7 +884,7 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
         t2.C = w.A.p + (int64_t)k1 * MOGP_TILE * (ld + 1); t2.ldc = ld; t2.alpha = -1.0; t2.beta = 1.0;
         t2.mode = GM_RECT_LOWER; t2.small = 2; t2.mt = 2 * na; t2.nt = 2 * na; t2.K = nk * MOGP_TILE;
         t2.fl_flags = w.flow_flags.p; t2.fl_nwait = pc.t2_wval ? 1 : 0; t2.fl_widx[0] = pc.t2_widx; t2.fl_wval[0] = pc.t2_wval;
-        t2.fl_err = ferr; t2.sk_info = m->d_info.p; t2.fl_spins = hook_spins;
+        t2.fl_err = ferr; t2.sk_info = m->d_info.p; t2.fl_spins = hook_spins; t2.fl_diag = w.flow_diag.p;
         if ((rc = launch_gemm(t2, priv))) return rc;
         m->gemm_flops += gemm_flops(t1, nullptr) + gemm_flops(t2, nullptr);
     }
@@ -831,6 +893,7 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     static const bool tail_on = !(std::getenv("MOGP_FLOW_TAIL") && std::atoi(std::getenv("MOGP_FLOW_TAIL")) == 0);
     if (tail_on && m->ctx->ncu_reserved > 0 && !replay) {
         if (rhs && rhs->ready) HIP_TRY(hipStreamWaitEvent(priv, rhs->ready, 0));
+        g.post_base = wg_per_cu * cus;
         hipLaunchKernelGGL(k_flow, dim3(wg_per_cu * m->ctx->ncu_reserved), dim3(FL_NT), FL_LDS_BYTES, priv, g);
         HIP_TRY(hipGetLastError());
     }

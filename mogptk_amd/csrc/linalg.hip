@@ -58,12 +58,22 @@ __global__ __launch_bounds__(64 * NWI * NWJ, NWI * NWJ / 2) void k_gemm(GemmArgs
                     if ((++spins & 127u) == 0u) {
                         if (__hip_atomic_load(g.fl_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                         if (spins > (g.fl_spins ? g.fl_spins : 1600000u)) { __hip_atomic_store(g.fl_err, 0x800u + (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        if ((spins & 8191u) == 0u) {       // a DEEP poll (chain.hip:ch_wait): what does the memory side say?
+                            const unsigned v = __hip_atomic_fetch_or(g.fl_flags + g.fl_widx[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (g.fl_diag) __hip_atomic_fetch_add(g.fl_diag + FLOW_DIAG_WAIT_DEEP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (v >= g.fl_wval[k]) { if (g.fl_diag) __hip_atomic_fetch_add(g.fl_diag + FLOW_DIAG_WAIT_STALE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        }
                     }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
+        // a wait that gave up (here or anywhere in the schedule): the evaluation is void and will be repeated -- no product of unfinished operands, no signal
+        if (__hip_atomic_load(g.fl_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            if (threadIdx.x == 0 && g.sk_info) atomicMin(g.sk_info, (unsigned long long)MOGP_INFO_CHAIN_TIMEOUT);
+            return;
+        }
     }
     using Cfg = GemmCfg<WTM, WTN, NWJ, NWI>;
     constexpr int TMR = Cfg::TMR, TNC = Cfg::TNC, COLK_A = Cfg::COLK_A, COLK_B = Cfg::COLK_B, NT = Cfg::NT;

@@ -724,6 +724,64 @@ namespace mogp { void flow_debug_dump(mogp_model* m) {
         }
         for (auto& kv : win) fprintf(stderr, "  %4ld ms: %6d tasks done by %3zu workgroups\n", kv.first * 5, kv.second.first, kv.second.second.size());
     }
+    if (m->k.flow_post.p) {             // the workgroups' own reports: why each left, what it still held -- and who never reported
+        std::vector<unsigned> po(m->k.flow_post.n);
+        e = hipMemcpy(po.data(), m->k.flow_post.p, po.size() * sizeof(unsigned), hipMemcpyDeviceToHost); (void)e;
+        std::vector<unsigned char> dn(p.tasks.size(), 0);
+        if (m->k.flow_done.p && m->k.flow_done.n >= dn.size()) { e = hipMemcpy(dn.data(), m->k.flow_done.p, dn.size(), hipMemcpyDeviceToHost); (void)e; }
+        const size_t nwg = po.size() / FLOW_POST_W;
+        const int ncl = FLOW_NCAS * 8;
+        size_t n_to = 0, n_done = 0, n_silent = 0, n_never = 0;
+        std::map<size_t, std::vector<unsigned>> holder;          // task -> workgroups that hold its ticket
+        for (size_t wgi = 0; wgi < nwg; ++wgi) {
+            const unsigned* r = po.data() + wgi * FLOW_POST_W;
+            if (r[0] == 1) ++n_to; else if (r[0] == 2) ++n_done; else if (r[2] == 0) ++n_never; else {
+                ++n_silent;
+                fprintf(stderr, "  workgroup %zu NEVER LEFT: state %u (1 looking, 2 in task %u), last look at clock %u\n", wgi, r[2], r[3], r[4]);
+            }
+            if (r[0] != 1 && r[0] != 2) continue;
+            for (int lane = ncl; lane < 64; ++lane) {
+                if (!r[8 + lane]) continue;
+                const int q = FLOW_NCAS + (lane - ncl);
+                if (q >= p.nq) continue;
+                holder[(size_t)p.qbase[q] + (r[8 + lane] - 1)].push_back((unsigned)wgi);
+            }
+        }
+        fprintf(stderr, "  post-mortem: %zu workgroups left on the time-out, %zu left done, %zu never started, %zu never left; %zu tickets held\n", n_to, n_done, n_never, n_silent, holder.size());
+        // every task that has NOT signalled although its counters are met: who holds it, and what did the holder's last look say?
+        size_t nready = 0, nundone = 0;
+        for (int q = 0; q < p.nq; ++q) {
+            const unsigned h = fl[p.base_heads + q];
+            for (int k = 0; k < p.qsize[q]; ++k) {
+                const size_t ti = (size_t)p.qbase[q] + k;
+                if (dn[ti]) continue;
+                ++nundone;
+                const FlowTask& t = p.tasks[ti];
+                bool ready = true;
+                for (int d = 0; d < t.ndep; ++d) if (fl[t.dep[d]] < (unsigned)t.need[d]) ready = false;
+                if (!ready) continue;
+                if (nready++ >= 40) continue;
+                fprintf(stderr, "  READY BUT NOT DONE: queue %d task %d (head %u) key %u var %d C(buf %d %d,%d):", q, k, h, t.key, t.var, t.cbuf, t.cr, t.cc);
+                for (int d = 0; d < t.ndep; ++d) fprintf(stderr, " flag[%u]=%u/%u", t.dep[d], fl[t.dep[d]], (unsigned)t.need[d]);
+                auto it = holder.find(ti);
+                if (q < FLOW_NCAS) fprintf(stderr, "  [compare-and-swap queue: %s]", (unsigned)k == h ? "AT THE HEAD" : ((unsigned)k < h ? "taken, running or lost" : "behind the head"));
+                else if (it == holder.end()) fprintf(stderr, "  [%s]", (unsigned)k < h ? "TICKET GIVEN OUT, NO HOLDER REPORTED IT (running when the kernel froze, or lost)" : "no ticket given out yet");
+                else for (unsigned wgi : it->second) {
+                    const unsigned* r = po.data() + (size_t)wgi * FLOW_POST_W;
+                    const int lane = ncl + (q - FLOW_NCAS);
+                    const unsigned long long mr = ((unsigned long long)r[7] << 32) | r[6];
+                    fprintf(stderr, "  [held by workgroup %u: %u idle looks, its last look saw this task %s, state %u]", wgi, r[1], ((mr >> lane) & 1ull) ? "READY" : "not ready", r[2]);
+                }
+                fprintf(stderr, "\n");
+            }
+        }
+        fprintf(stderr, "  %zu tasks have not signalled; %zu of them have their counters met\n", nundone, nready);
+        // workgroups in the middle of a task when the kernel froze
+        for (size_t wgi = 0; wgi < nwg; ++wgi) {
+            const unsigned* r = po.data() + wgi * FLOW_POST_W;
+            if (r[2] == 2 && r[3] < p.tasks.size() && !dn[r[3]]) fprintf(stderr, "  workgroup %zu was INSIDE task %u when it was last heard of\n", wgi, r[3]);
+        }
+    }
     for (size_t b = 0; b < p.chain.size(); ++b) {
         const FlowPlan::Chain& c = p.chain[b];
         fprintf(stderr, "  chain %zu done flag[%u]=%u/%u; mini-panel waits", b, c.done_idx, fl[c.done_idx], c.expect);
@@ -756,8 +814,8 @@ namespace mogp { int chain_fallback(mogp_model* m) {
             if (m->k.flow_flags.p && m->k.flow_cur && m->k.flow_cur->base_err > 0) { hipError_t e = hipMemcpy(&code, m->k.flow_flags.p + m->k.flow_cur->base_err, sizeof(code), hipMemcpyDeviceToHost); (void)e; }
             fprintf(stderr, "mogp: the dataflow kernel timed out (wait 0x%x; GPU shared with another process?); using the stream schedule for the next %d evaluations (said once)\n", code, (int)(m->flow_retry_at - m->n_fact));
             fprintf(stderr, "mogp: the host enqueued that evaluation in %.0f us (longest so far %.0f us)\n", m->flow_enqueue_us, m->flow_enqueue_us_max);
-            if (std::getenv("MOGP_FLOW_DEBUG")) flow_debug_dump(m);
         }
+        if (std::getenv("MOGP_FLOW_DEBUG")) { fprintf(stderr, "mogp: dataflow time-out %d of this model\n", m->flow_timeouts); flow_debug_dump(m); }
         return 0;
     }
     if (m->no_chain) return fail(MOGP_EHIP, "chain kernel: a hand-off timed out although the model is on the launch-per-step chain");
@@ -772,7 +830,7 @@ namespace mogp { int chain_fallback(mogp_model* m) {
 // turns them into the LML / the failure report
 static int factorize(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
                      double* lml, double* jitter_abs, int64_t* info, bool fuse_inverse = false, bool defer = false, GramArgs* ga_out = nullptr,
-                     bool factor_only = false) {
+                     bool factor_only = false, bool want_inverse = true) {
     const int C = m->C, D = m->D;
     const int64_t N = m->N, Npad = m->Npad;
     if (m->T <= 0) return fail(MOGP_EINVAL, "mogp_model_set_terms must be called before an evaluation");
@@ -844,7 +902,11 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     if ((rc = mark(m, 1))) return rc;
 
     // every allocation of this evaluation BEFORE the co-operating kernels are enqueued
-    if ((rc = pin_ensure(m, (size_t)m->nb + (size_t)((Npad + 3) / 4) + 1 + (size_t)(C * (C + 1) / 2) * m->T * m->Wt + C))) return rc;
+    // (the two pivot doubles and the accurate form's right-hand-side block included: a hipHostMalloc / hipMalloc behind the enqueue of kernels that
+    // wait for each other is the stall mogp_ctx_create's comment describes)
+    if ((rc = pin_ensure(m, (size_t)m->nb + (size_t)((Npad + 3) / 4) + 1 + (size_t)(C * (C + 1) / 2) * m->T * m->Wt + C + 2))) return rc;
+    if ((rc = m->d_pivots.ensure(2))) return rc;
+    if (m->accurate && (rc = m->acc_rhs.ensure((size_t)Npad * MOGP_TILE))) return rc;
     m->k.flow_used = false;                           // (mogp_model_schedule reports the LAST evaluation: set again by spd_potri_flow)
     m->flow_ran = false;                              // ... and chain_fallback decides from THIS evaluation which schedule to drop, not from an earlier one
     m->k.want_vec = fuse_inverse && !factor_only;     // the dataflow schedule (flow.hip) also forms z = W y and alpha = W^T z
@@ -863,10 +925,12 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
         m->k.tail_ready = nullptr;
         if (rc) return rc;
         if ((rc = mark(m, 2))) return rc;
+        if (want_inverse) {          // (an LML-only evaluation needs L, z and the log-determinant: not the N^2 fill and the two N^3 solves nothing would read)
         HIP_TRY(hipMemsetAsync(m->k.B.p, 0, (size_t)Npad * Npad * sizeof(double), m->st));
         if ((rc = launch_add_diag(m->k.B.p, Npad, Npad, 1.0, m->st))) return rc;
         if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->k.B.p, Npad, Npad, false, nullptr, true))) return rc;      // lower block triangle only (trsm.hip: tri)
         if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->k.B.p, Npad, Npad, true, nullptr, true))) return rc;
+        }
         if ((rc = mark(m, 3))) return rc;
         if ((rc = m->acc_rhs.ensure((size_t)Npad * MOGP_TILE))) return rc;
         HIP_TRY(hipMemsetAsync(m->acc_rhs.p, 0, (size_t)Npad * MOGP_TILE * sizeof(double), m->st));
@@ -1303,7 +1367,7 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
             return mogp_exact_eval(m, noise_var, data_var, jitter, flags, lml, moments, diagG, trG, jitter_abs, info);
         }
     }
-    else if ((rc = factorize(m, noise_var, data_var, jitter, lml, jitter_abs, info, fused, grad, &ga))) {
+    else if ((rc = factorize(m, noise_var, data_var, jitter, lml, jitter_abs, info, fused, grad, &ga, false, grad))) {
         if (rc != MOGP_RETRY_NO_CHAIN) return rc;
         if ((rc = chain_fallback(m))) return rc;
         return mogp_exact_eval(m, noise_var, data_var, jitter, flags, lml, moments, diagG, trG, jitter_abs, info);
@@ -1938,6 +2002,17 @@ int mogp_model_flow_replay(mogp_model* m, int on) {
     if (!m) return fail(MOGP_EINVAL, "mogp_model_flow_replay: null model");
     if (on && !(m->k.Wm.p && m->have_Kinv)) return fail(MOGP_EINVAL, "mogp_model_flow_replay: needs a completed gradient evaluation on this model first (its W_KK blocks are the replay's input)");
     m->replay_flow = on != 0;
+    return MOGP_OK;
+}
+
+int mogp_model_flow_diag(mogp_model* m, unsigned* out8) {
+    if (!m || !out8) return fail(MOGP_EINVAL, "mogp_model_flow_diag: null argument");
+    int rc;
+    if ((rc = use_device(m->ctx))) return rc;
+    std::memset(out8, 0, 8 * sizeof(unsigned));
+    if (!m->k.flow_diag.p) return MOGP_OK;
+    HIP_TRY(hipStreamSynchronize(m->st));
+    HIP_TRY(hipMemcpy(out8, m->k.flow_diag.p, FLOW_DIAG_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost));
     return MOGP_OK;
 }
 

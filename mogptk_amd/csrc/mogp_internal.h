@@ -185,7 +185,7 @@ struct GemmArgs {
     // until fl_flags[fl_widx[k]] >= fl_wval[k] for k < fl_nwait (then ONE agent acquire), stores C write-through when fl_wt, and when fl_sig
     // bumps fl_flags[fl_sig_base + (tile row >> fl_sig_shift)] once its tile has left the CU.  fl_err: the schedule's error word.
     unsigned* fl_flags; int fl_nwait; unsigned fl_widx[4]; unsigned fl_wval[4];
-    int fl_wt, fl_sig; unsigned fl_sig_base; int fl_sig_shift; unsigned* fl_err; unsigned fl_spins;
+    int fl_wt, fl_sig; unsigned fl_sig_base; int fl_sig_shift; unsigned* fl_err; unsigned fl_spins; unsigned* fl_diag;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 double gemm_flops(const GemmArgs& a, const std::vector<GemmTask>* host_tasks);
@@ -213,6 +213,7 @@ struct ChainFlow {
     unsigned* done_flag;
     int write_through;
     unsigned long long* trace;         // optional [4]: launch, after the wait, end (100 MHz wall clock), spare
+    unsigned* diag;                    // optional: the dataflow schedule's diagnostic counters (FLOW_DIAG_*)
 };
 int launch_chain(double* A, int64_t ld, int t0, int nk, double* invd, double* logdet, unsigned long long* info, long long info_base,
                  double* Wk, int64_t ldw, unsigned* flags, unsigned* err, hipStream_t s, const ChainFlow* flow = nullptr);
@@ -221,6 +222,7 @@ int launch_chain(double* A, int64_t ld, int t0, int nk, double* invd, double* lo
 #define FLOW_MAXQ 48                   // queues of a plan at most: 2 * 8 compare-and-swap lanes + one lane per other queue fit one wave
 #define FLOW_NCAS 1                    // the first queues (by priority) are taken ready-only by compare-and-swap, the others eagerly (flow.hip:k_flow)
 #define FLOW_TRACE_W 6
+#define FLOW_POST_W 72                 // words per workgroup of the dataflow kernel's post-mortem (FlowArgs::post)
 #define FLOW_KEY_STEP 1024             // FlowTask::key = FLOW_KEY_STEP * superstep + position inside it
 #define FLOW_NOSIG 0xffffffffu
 struct FlowTask {                      // 64 bytes; static per matrix size
@@ -235,6 +237,11 @@ struct FlowTask {                      // 64 bytes; static per matrix size
     uint32_t pad[2];
 };
 static_assert(sizeof(FlowTask) == 64, "FlowTask layout");
+// Diagnostic words of the dataflow schedule (Spd::flow_diag; they outlive an evaluation; mogp_model_flow_diag reads them):
+// deep looks made by idle workgroups of k_flow; deep looks whose returning atomics saw a queue head / a dependency counter that the sc1 loads
+// of the same look did not; the same two for the waits of the chain kernels and of the private stream's hooks; the last such dependency
+// (flag index, value seen, workgroup | XCC << 16)
+enum { FLOW_DIAG_DEEP = 0, FLOW_DIAG_HEAD_STALE = 1, FLOW_DIAG_DEP_STALE = 2, FLOW_DIAG_WAIT_DEEP = 3, FLOW_DIAG_WAIT_STALE = 4, FLOW_DIAG_LAST = 5, FLOW_DIAG_WORDS = 8 };
 struct FlowPlan {
     int nb = 0, ob = 0, nouter = 0, nq = 0, rhs_nt = 0;
     bool replay = false;               // the measurement plan (flow.hip: flow_build): the private stream's products are tasks too, the chain kernels' counters preset

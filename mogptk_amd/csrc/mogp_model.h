@@ -148,6 +148,9 @@ struct Spd {
     DevBuf<int> flow_qmeta_rhs;
     const FlowPlan* flow_cur = nullptr;                 // the plan of the last dataflow run (debug dump, trace)
     DevBuf<unsigned> flow_flags;
+    DevBuf<unsigned char> flow_done;    // MOGP_FLOW_DEBUG: one byte per task of the last dataflow evaluation, set when it has signalled
+    DevBuf<unsigned> flow_post;         // MOGP_FLOW_DEBUG: per-workgroup post-mortem of the last dataflow evaluation (FLOW_POST_W words each)
+    DevBuf<unsigned> flow_diag;         // FLOW_DIAG_WORDS counters of the schedule's deep looks (zeroed once, never per evaluation)
     DevBuf<unsigned long long> flow_trace;
     hipEvent_t tail_ready = nullptr;    // set by the caller for ONE factorisation: everything of A right of the first 512 columns is in place after this event
                                         // (the Gram build in two launches: the second one runs on the bulk stream underneath the first chain kernel)
@@ -161,7 +164,7 @@ struct Spd {
         for (auto e : sync_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
         for (auto e : inv_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
         inv_ev.clear(); Wm.release(); Wd.release(); chain_flags.release(); for (auto& b : Pb) b.release();
-        Lm.release(); Wt.release(); flow_tasks.release(); flow_qmeta.release(); flow_flags.release(); flow_trace.release(); flow = FlowPlan();
+        Lm.release(); Wt.release(); flow_tasks.release(); flow_qmeta.release(); flow_flags.release(); flow_diag.release(); flow_post.release(); flow_done.release(); flow_trace.release(); flow = FlowPlan();
         flow_tasks_rhs.release(); flow_qmeta_rhs.release(); flow_rhs = FlowPlan(); flow_cur = nullptr;
         flow_tasks_replay.release(); flow_qmeta_replay.release(); flow_replay = FlowPlan();
         levels.clear(); sync_ev.clear();

@@ -87,100 +87,86 @@ class Data:
         return self.X_pred
 
     def _format_X(self, X):
-        X = np.asarray(X, dtype=np.float64)
-        if X.ndim == 1:
-            X = X.reshape(-1, 1)
+        """prediction inputs of this channel as an (n, input_dims) float64 array (a flat vector is one input dimension)"""
+        X = np.atleast_1d(np.asarray(X, dtype=np.float64))
+        X = X[:, None] if X.ndim == 1 else X
         if X.ndim != 2 or X.shape[1] != self.get_input_dims():
             raise ValueError("X must have %d input dimensions" % self.get_input_dims())
         return X, None
 
-    def _get_psd_peaks(self, w, psd):
-        """peaks of a spectrum as (amplitude, position, variance), biggest first -- reference data.py:946-961: scipy's find_peaks,
-        half-maximum widths turned into Gaussian variances (FWHM^2 / 8 ln 2), amplitude = sqrt(peak height)"""
-        from scipy import signal
-        peaks, _ = signal.find_peaks(psd)
-        if len(peaks) == 0:
-            return np.array([]), np.array([]), np.array([])
-        peaks = peaks[np.argsort(psd[peaks])[::-1]]
-        peaks = peaks[0.0 < psd[peaks]]
-        widths, _, _, _ = signal.peak_widths(psd, peaks, rel_height=0.5)
-        widths = widths * (w[1] - w[0])
-        return np.sqrt(psd[peaks]), w[peaks], widths ** 2 / (8.0 * np.log(2.0))
+    # ---- spectrum-based estimates for init_parameters (reference data.py:924-1087: the numbers are boundary, golden-pinned by init_ls.npz / bnse.npz) ----
+    @staticmethod
+    def _get_psd_peaks(w, psd):
+        """local maxima of a sampled spectrum, highest first -> (amplitude, position, variance): amplitude = sqrt(height), variance from the
+        width at half height read as a Gaussian's FWHM (sigma^2 = FWHM^2 / (8 ln 2))"""
+        from scipy.signal import find_peaks, peak_widths
+        at = find_peaks(psd)[0]
+        at = at[psd[at] > 0.0]
+        if at.size == 0:
+            return np.empty(0), np.empty(0), np.empty(0)
+        at = at[np.argsort(-psd[at], kind="stable")]
+        fwhm = peak_widths(psd, at, rel_height=0.5)[0] * (w[1] - w[0])
+        return np.sqrt(psd[at]), w[at], fwhm * fwhm / (8.0 * np.log(2.0))
+
+    def _peak_table(self, Q, spectrum_of):
+        """(amplitudes, means, variances), each (Q, input_dims): column i holds the (at most) Q highest peaks of spectrum_of(i) -> (w, psd),
+        zeros where a dimension has fewer.  spectrum_of also receives how many peaks the previous dimensions kept (see get_ls_estimation)."""
+        table = np.zeros((3, Q, self.get_input_dims()))
+        kept = None
+        for i in range(table.shape[2]):
+            found = self._get_psd_peaks(*spectrum_of(i, kept))
+            if found[1].size:
+                kept = min(Q, found[1].size)
+                table[:, :kept, i] = [f[:kept] for f in found]
+        return table[0], table[1], table[2]
 
     def get_ls_estimation(self, Q=1, n=10000):
-        """Q biggest peaks of the Lomb-Scargle periodogram per input dimension: (amplitudes, means, variances), each (Q, input_dims)
-        -- reference data.py:963-1002, including its re-use of `n` for the number of peaks found (which shortens the frequency grid
-        of the following input dimensions)"""
-        from scipy import signal
-        input_dims = self.get_input_dims()
-        A, B, C = np.zeros((Q, input_dims)), np.zeros((Q, input_dims)), np.zeros((Q, input_dims))
-        nyquist = self.get_nyquist_estimation()
+        """peaks of the Lomb-Scargle periodogram on n frequencies up to the Nyquist estimate, per input dimension.  One oddity of the
+        reference is part of the numbers (data.py:963-1002 reuses the name `n` for the count of peaks it kept): after a dimension with peaks,
+        the NEXT dimension's frequency grid has only that many points."""
+        from scipy.signal import lombscargle
         x, y = self.get_train_data(transformed=True)
-        for i in range(input_dims):
-            w = np.linspace(0.0, nyquist[i], n)[1:]
-            psd = signal.lombscargle(x[:, i] * 2.0 * np.pi, y, w)
-            psd /= x.shape[0] / 4.0
-            amplitudes, positions, variances = self._get_psd_peaks(w, psd)
-            if len(positions) == 0:
-                continue
-            if Q < len(amplitudes):
-                amplitudes, positions, variances = amplitudes[:Q], positions[:Q], variances[:Q]
-            n = len(amplitudes)
-            A[:n, i] = amplitudes
-            B[:n, i] = positions
-            C[:n, i] = variances
-        return A, B, C
+        top = self.get_nyquist_estimation()
 
-    def get_sm_estimation(self, Q=1, method="LS", optimizer="Adam", iters=200, params={}):
-        """fit a single-output spectral mixture to this channel on the device and return its (magnitude, mean, variance) --
-        reference data.py:1053-1087"""
-        from .wrappers import SM
-        input_dims = self.get_input_dims()
-        sm = SM(self, Q)
-        sm.init_parameters(method)
-        sm.train(method=optimizer, iters=iters, **params)
-        A = sm.gpr.kernel[0].magnitude.numpy().reshape(-1, 1).repeat(input_dims, axis=1)
-        return A, sm.gpr.kernel[0].mean.numpy(), sm.gpr.kernel[0].variance.numpy()
+        def periodogram(i, kept):
+            w = np.linspace(0.0, top[i], n if kept is None else kept)[1:]
+            return w, lombscargle(2.0 * np.pi * x[:, i], y, w) * (4.0 / len(x))
+        return self._peak_table(Q, periodogram)
 
     def get_bnse_estimation(self, Q=1, n=1000, iters=200):
-        """Q biggest peaks of the BNSE spectrum per input dimension -- reference data.py:1004-1051 (the GP fit runs on the device)"""
+        """peaks of the Bayesian nonparametric spectral estimate (init.BNSE: a GP fit on the device) per input dimension, scaled by
+        pi / range^2 -- reference data.py:1004-1051; observation errors go through the Y transformer as half the transformed interval"""
         from .init import BNSE
-        input_dims = self.get_input_dims()
-        A, B, C = np.zeros((Q, input_dims)), np.zeros((Q, input_dims)), np.zeros((Q, input_dims))
-        nyquist = self.get_nyquist_estimation()
         x, y = self.get_train_data(transformed=True)
-        y_err = None
+        top = self.get_nyquist_estimation()
+        half_width = None
         if self.Y_err is not None:
-            y_err_lower = self.Y_transformer.forward(y - self.Y_err[self.mask], x)
-            y_err_upper = self.Y_transformer.forward(y + self.Y_err[self.mask], x)
-            y_err = (y_err_upper - y_err_lower) / 2.0
-        for i in range(input_dims):
-            w, psd, _ = BNSE(x[:, i], y, y_err=y_err, max_freq=nyquist[i], n=n, iters=iters)
-            psd /= (np.max(x[:, i]) - np.min(x[:, i])) ** 2
-            psd *= np.pi
-            amplitudes, positions, variances = self._get_psd_peaks(w, psd)
-            if len(positions) == 0:
-                continue
-            if Q < len(amplitudes):
-                amplitudes, positions, variances = amplitudes[:Q], positions[:Q], variances[:Q]
-            num = len(amplitudes)
-            A[:num, i] = amplitudes
-            B[:num, i] = positions
-            C[:num, i] = variances
-        return A, B, C
+            e = self.Y_err[self.mask]
+            half_width = 0.5 * (self.Y_transformer.forward(y + e, x) - self.Y_transformer.forward(y - e, x))
+
+        def posterior_spectrum(i, _):
+            w, psd, _var = BNSE(x[:, i], y, y_err=half_width, max_freq=top[i], n=n, iters=iters)
+            return w, psd * (np.pi / np.ptp(x[:, i]) ** 2)
+        return self._peak_table(Q, posterior_spectrum)
+
+    def get_sm_estimation(self, Q=1, method="LS", optimizer="Adam", iters=200, params={}):
+        """fit a single-output spectral mixture to this channel on the device; its (magnitude repeated per input dimension, mean, variance)
+        -- reference data.py:1053-1087"""
+        from .wrappers import SM
+        fit = SM(self, Q)
+        fit.init_parameters(method)
+        fit.train(method=optimizer, iters=iters, **params)
+        k = fit.gpr.kernel[0]
+        return np.tile(k.magnitude.numpy().reshape(-1, 1), (1, self.get_input_dims())), k.mean.numpy(), k.variance.numpy()
 
     def get_nyquist_estimation(self):
-        """0.5 / (minimum distance between points) per input dimension -- reference data.py:924-944"""
-        input_dims = self.get_input_dims()
-        nyquist = np.empty((input_dims,))
-        for i in range(input_dims):
-            x = np.sort(self.X[self.mask, i])
-            dist = np.abs(x[1:] - x[:-1])
-            if len(dist) == 0:
-                nyquist[i] = 0.0
-            else:
-                nyquist[i] = 0.5 / np.min(dist[np.nonzero(dist)])
-        return nyquist
+        """half the inverse of the smallest non-zero gap between training inputs, per input dimension (0 with fewer than two points)
+        -- reference data.py:924-944"""
+        seen = np.sort(self.X[self.mask], axis=0)
+        if len(seen) < 2:
+            return np.zeros(self.get_input_dims())
+        gaps = np.diff(seen, axis=0)
+        return np.array([0.5 / g[g != 0.0].min() for g in gaps.T])
 
 
 class DataSet:
@@ -282,27 +268,23 @@ class DataSet:
         return [c.get_nyquist_estimation() for c in self.channels]
 
     def _format_X(self, X):
-        """reference dataset.py:199-221"""
+        """prediction inputs per channel from what `predict(X)` accepts (reference dataset.py:199-221): a dict {channel name: inputs} on top of
+        the current prediction inputs, one array for all channels, a (channels, n, input_dims) array, or a list with one entry per channel"""
+        C = self.get_output_dims()
+        if hasattr(X, "detach"):
+            X = X.detach().cpu().numpy()
         if isinstance(X, dict):
-            x_dict = X
-            X = self.get_prediction_data()
-            for name, channel_x in x_dict.items():
-                X[self.get_index(name)] = channel_x
-        elif isinstance(X, np.ndarray) or hasattr(X, "detach"):
-            if hasattr(X, "detach"):
-                X = X.detach().cpu().numpy()
-            if X.ndim == 3 and X.shape[0] == self.get_output_dims():
-                X = [X[i, :, :] for i in range(self.get_output_dims())]
-            else:
-                X = [X] * self.get_output_dims()
-        elif not isinstance(X, list):
+            per_channel = self.get_prediction_data()
+            for name, inputs in X.items():
+                per_channel[self.get_index(name)] = inputs
+        elif isinstance(X, np.ndarray):
+            per_channel = list(X) if X.ndim == 3 and len(X) == C else [X] * C
+        elif isinstance(X, list):
+            nested = any(isinstance(entry, (list, np.ndarray)) for entry in X)
+            per_channel = list(X) if nested else [X] * C
+        else:
             raise ValueError("X must be a list, dict, or numpy.ndarray")
-        elif not any(isinstance(x, (list, np.ndarray)) for x in X):
-            X = [X] * self.get_output_dims()
-        if len(X) != self.get_output_dims():
+        if len(per_channel) != C:
             raise ValueError("X must be of shape (data_points,), (data_points,input_dims), or "
                              "[(data_points,)] * input_dims for each channel")
-        X = list(X)
-        for j, channel in enumerate(self.channels):
-            X[j], _ = channel._format_X(X[j])
-        return X
+        return [channel._format_X(inputs)[0] for channel, inputs in zip(self.channels, per_channel)]

@@ -308,8 +308,8 @@ class Exact(Model):
         est = h.condition_estimate()
         if est != est:
             return None
-        accurate = getattr(self, "_accurate", False)
-        if not accurate and est > self.CONDITION_WARN:
+        accurate = getattr(h, "accurate_mode", False)       # the mode lives in the device handle, so the flag lives ON the handle: a model that is copied,
+        if not accurate and est > self.CONDITION_WARN:      # reloaded or re-sharded gets a new handle in the fast mode and a flag that says so
             fallback = getattr(config, "accurate_fallback", True) and hasattr(h, "set_accurate")
             if not getattr(self, "_cond_warned", False):
                 self._cond_warned = True
@@ -319,12 +319,12 @@ class Exact(Model):
                               % (est, "evaluating in the backward-stable form from here on (about four times slower)" if fallback
                                  else "a larger noise variance or jitter brings it back"), RuntimeWarning, stacklevel=5)
             if fallback:
-                self._accurate = True
                 h.set_accurate(True)
+                h.accurate_mode = True
                 return redo()
         elif accurate and est < 0.1 * self.CONDITION_WARN:
-            self._accurate = False
             h.set_accurate(False)                     # the next evaluation is a fast one again
+            h.accurate_mode = False
         return None
 
     # -- reference surface -------------------------------------------------------------------

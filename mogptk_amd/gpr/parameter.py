@@ -335,12 +335,33 @@ class ParameterHolder:
                 _STRUCTURE_EPOCH[0] += 1            # some holder's registry changed: every cached parameter list is stale
         object.__setattr__(self, name, val)
 
+    def __delattr__(self, name):
+        order = self.__dict__.get("_order")
+        if order is not None and name in order:
+            order.remove(name)
+            _STRUCTURE_EPOCH[0] += 1
+        object.__delattr__(self, name)
+
+    def _registry_shape(self):
+        """lengths and member identities of the registered holder lists, recursively: what an in-place edit of such a list (append, del, item
+        assignment -- none of which passes through __setattr__) changes.  Cheap next to parameters(): no Parameter is visited."""
+        sig = []
+        for name in self.__dict__.get("_order", ()):
+            val = self.__dict__.get(name)
+            if isinstance(val, (list, tuple)):
+                sig.append(tuple(id(v) for v in val))
+                sig.extend(v._registry_shape() for v in val if isinstance(v, ParameterHolder))
+            elif isinstance(val, ParameterHolder):
+                sig.append(val._registry_shape())
+        return tuple(sig)
+
     def _parameter_list(self):
         """`list(self.parameters())`, kept until a registry changes anywhere: the training loop asks for it several times per evaluation
         (zero_grad, log_prior, the optimiser), and the recursive walk was 15 % of the host's share of a configs[1] step"""
         c = self.__dict__.get("_plist")
-        if c is None or c[0] != _STRUCTURE_EPOCH[0]:
-            c = (_STRUCTURE_EPOCH[0], list(self.parameters()))
+        shape = self._registry_shape()
+        if c is None or c[0] != _STRUCTURE_EPOCH[0] or c[2] != shape:
+            c = (_STRUCTURE_EPOCH[0], list(self.parameters()), shape)
             self.__dict__["_plist"] = c
         return c[1]
 

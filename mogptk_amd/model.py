@@ -171,7 +171,9 @@ class _Adam:
             key = tuple(id(p) for p in flat)
             st = self.state.get("flat")
             if st is None or st["key"] != key:
-                # (re)build the flat state from the per-tensor states, so that a change of the set of tensors loses nothing
+                # (re)build the flat state from the per-tensor states, so that a change of the set of tensors loses nothing: the old flat state goes
+                # back into per-tensor states FIRST, whether or not the new set shares a tensor with it
+                self._unflatten()
                 parts = [self._tensor_state(p) for p in flat]
                 st = dict(key=key, t=[q["t"] for q in parts], m=np.concatenate([q["m"].ravel() for q in parts]),
                           v=np.concatenate([q["v"].ravel() for q in parts]), vmax=np.concatenate([q["vmax"].ravel() for q in parts]),
@@ -586,32 +588,30 @@ class Model:
         """reference mogptk/model.py:374-384"""
         return float(self.gpr.loss())
 
+    _ERROR_MEASURES = {"mae": mean_absolute_error, "mape": mean_absolute_percentage_error,
+                       "smape": symmetric_mean_absolute_percentage_error, "mse": mean_squared_error,
+                       "rmse": root_mean_squared_error}
+
     def error(self, method="MAE", use_all_data=False):
-        """reference mogptk/model.py:386-439"""
-        if callable(method) and len(inspect.signature(method).parameters) == 1:
+        """Prediction error on the held-out points (all points when none are held out or `use_all_data`), in the data's own units: the
+        device predicts in transformed space, every channel's slice goes back through its Y transformer.  `method`: MAE, MAPE, sMAPE, MSE,
+        RMSE, a function (y_true, y_pred), or a function of the model alone.  Same contract as reference mogptk/model.py:386-439."""
+        takes_model = callable(method) and len(inspect.signature(method).parameters) == 1
+        if takes_model:
             return method(self)
-        if use_all_data or not any(self.dataset.has_test_data()):
-            X, Y_true = self.dataset.get_data()
+        if not callable(method):
+            measure = self._ERROR_MEASURES.get(str(method).lower())
+            if measure is None:
+                raise ValueError("valid error calculation methods are MAE, MAPE, sMAPE, MSE, and RMSE")
         else:
-            X, Y_true = self.dataset.get_test_data()
-        x = self._to_kernel_format(X)
-        y_pred = self.gpr.predict_y(x)
-        i = 0
-        Y_pred = []
-        for j in range(self.dataset.get_output_dims()):
-            N = X[j].shape[0]
-            Y_pred.append(self.dataset[j].Y_transformer.backward(np.squeeze(y_pred[i:i + N]), X[j]))
-            i += N
-        y_true = np.concatenate(Y_true)
-        y_pred = np.concatenate(Y_pred)
-        if callable(method):
-            return method(y_true, y_pred)
-        fns = {"mae": mean_absolute_error, "mape": mean_absolute_percentage_error,
-               "smape": symmetric_mean_absolute_percentage_error, "mse": mean_squared_error,
-               "rmse": root_mean_squared_error}
-        if method.lower() not in fns:
-            raise ValueError("valid error calculation methods are MAE, MAPE, sMAPE, MSE, and RMSE")
-        return fns[method.lower()](y_true, y_pred)
+            measure = method
+        held_out = any(self.dataset.has_test_data()) and not use_all_data
+        X, truth = self.dataset.get_test_data() if held_out else self.dataset.get_data()
+        flat = np.reshape(self.gpr.predict_y(self._to_kernel_format(X)), -1)
+        ends = np.cumsum([len(x) for x in X])
+        predicted = [channel.Y_transformer.backward(part, x)
+                     for channel, part, x in zip(self.dataset, np.split(flat, ends[:-1]), X)]
+        return measure(np.concatenate(truth), np.concatenate(predicted))
 
     def train(self, method="Adam", iters=500, verbose=False, error=None, plot=False, jit=None, **kwargs):
         """

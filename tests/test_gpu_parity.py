@@ -1173,7 +1173,7 @@ def test_exact_path_conditioning_envelope():
             ld = float(m.loss())
             ld2 = float(m.loss())
         assert len([x for x in w if "ill-conditioned" in str(x.message)]) == 1        # once per model
-        assert m._accurate and ld == ld2
+        assert m._handle.accurate_mode and ld == ld2
         est = m._handle.condition_estimate()
         assert 1e5 < est, est                            # a lower bound of cond(Kj) (8.8e5 where it is 7.4e7)
         el = abs(ld - lt) / abs(lt)
@@ -1196,7 +1196,7 @@ def test_exact_path_conditioning_envelope():
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         mu_a, var_a = mp.predict_f(Xs)
-    assert len([x for x in w if "ill-conditioned" in str(x.message)]) == 1 and mp._accurate
+    assert len([x for x in w if "ill-conditioned" in str(x.message)]) == 1 and mp._handle.accurate_mode
     e = lambda a, b: float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
     print("prediction at sigma 1e-3 against the LAPACK twin: mean fast %.2e refined %.2e; variance fast %.2e refined %.2e" % (e(mu_f, mu_t), e(mu_a, mu_t), e(var_f, var_t), e(var_a, var_t)))
     assert e(mu_a, mu_t) <= 1e-6 and e(var_a, var_t) <= 1e-6

@@ -763,6 +763,56 @@ print("RESULT " + json.dumps(out))
         assert g["iters"] == int(fx[tag + "_history"][0]) + 2
 
 
+def test_written_checkpoint_carries_observation_errors_as_the_reference_keeps_them(tmp_path):
+    """a model with per-point error bars (Y_err -> Exact's data_variance): the written file holds the N x N diagonal matrix the reference's
+    constructor builds (gpr/model.py:423) -- its LML adds the attribute to Kff as it is (:442) --, the reference computes the loss of the
+    numpy oracle with those variances on the diagonal, and this package's loader turns the matrix back into the vector"""
+    pytest.importorskip("torch")
+    import subprocess
+    import sys
+    import json
+    from mogptk_amd import compat
+    import mogptk_amd
+    rng = np.random.default_rng(5)
+    x = np.sort(rng.uniform(0, 10, 24))
+    chans = [mogptk_amd.Data(x, np.sin(x + c) + 0.1 * rng.standard_normal(24), Y_err=0.05 + 0.1 * rng.random(24), name="c%d" % c) for c in range(2)]
+    m = mogptk_amd.MOSM(mogptk_amd.DataSet(chans), Q=2)
+    m.gpr.kernel.mean.assign(0.05 + 0.2 * rng.random((2, 2, 1)))
+    dv = np.asarray(m.gpr.data_variance, dtype=np.float64)
+    assert dv.shape == (48,) and np.allclose(dv, np.concatenate([c.Y_err for c in chans]) ** 2)
+    raw = compat.dump_reference_model(m)
+    (tmp_path / "w_err.npy").write_bytes(raw)
+    back = compat.load_reference_model(raw)
+    assert np.asarray(back.gpr.data_variance).shape == (48,) and np.array_equal(np.asarray(back.gpr.data_variance), dv)
+    script = """
+import sys, types, json
+ip, disp = types.ModuleType("IPython"), types.ModuleType("IPython.display")
+disp.display = lambda *a, **k: None; disp.HTML = lambda s: s; ip.display = disp
+sys.modules["IPython"] = ip; sys.modules["IPython.display"] = disp
+sys.path.insert(0, "/root/reference")
+import numpy as np, mogptk
+m = mogptk.LoadModel(sys.argv[1] + "/w_err")
+dv = m.gpr.data_variance
+print("RESULT " + json.dumps({"shape": list(dv.shape), "diag": dv.diagonal().tolist(), "off": float((dv - dv.diagonal().diagflat()).abs().max()), "lml": float(m.gpr.log_marginal_likelihood())}))
+"""
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("the reference is only present in the build container")
+    r = subprocess.run([sys.executable, "-c", script, str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert got["shape"] == [48, 48] and got["off"] == 0.0 and np.allclose(got["diag"], dv, rtol=0, atol=0)
+    # the same number from the numpy oracle with the variances on the diagonal
+    X = np.asarray(m.gpr.X, dtype=np.float64)
+    K = gram_from_table(np.asarray(m.gpr.kernel._spectral_terms(1)), X)
+    Kn = K + np.diag(m.gpr._noise_var()[np.asarray(m.gpr.X)[:, 0].astype(int)]) + np.diag(dv)
+    Kj = Kn + m.gpr.jitter * np.mean(np.diag(Kn)) * np.eye(48)
+    L = np.linalg.cholesky(Kj)
+    y = np.reshape(m.gpr.y, -1)
+    z = np.linalg.solve(L, y)
+    lml = -0.5 * 48 * np.log(2 * np.pi) - np.sum(np.log(np.diag(L))) - 0.5 * z @ z
+    assert abs(got["lml"] - lml) <= 1e-10 * max(1.0, abs(lml))
+
+
 def test_reference_checkpoints_load_without_the_reference(tmp_path):
     pytest.importorskip("torch")
     import sys

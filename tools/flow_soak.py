@@ -31,3 +31,5 @@ t = np.array(times)
 print("%s: %d evaluations in %.1f s; distinct results: %d %s" % (cfg, n, time.perf_counter() - t_all, len(seen), {k[:8]: (len(v), v[:3]) for k, v in seen.items()}))
 print("time per evaluation: median %.2f ms, max %.1f ms at #%d; the five slowest: %s" % (1e3 * np.median(t), 1e3 * t.max(), int(t.argmax()), ", ".join("%d: %.1f" % (j, 1e3 * t[j]) for j in np.argsort(-t)[:5])))
 print("schedule at the end:", m._handle.schedule() if hasattr(m._handle, "schedule") else None, "fell back at", fell)
+if hasattr(m._handle, "flow_diag"):
+    print("deep looks:", m._handle.flow_diag())
