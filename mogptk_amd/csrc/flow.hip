@@ -45,15 +45,15 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 #define FL_COLK (MOGP_TILE + 16)
 #define FL_OPER (MOGP_TILE * FL_ROWK)            // == 16 * FL_COLK
 #define FL_LDS_DOUBLES (2 * 2 * FL_OPER)
-#define FL_LDS_BYTES (FL_LDS_DOUBLES * 8 + 16)   // + the workgroup's pick word
+#define FL_LDS_BYTES (FL_LDS_DOUBLES * 8 + 16 + 3 * 64 * 4 + 16)   // + the workgroup's pick words + what wave 0's lanes remember between looks (k_flow: lst)
 static_assert(MOGP_TILE * FL_ROWK == 16 * FL_COLK, "one LDS operand slot serves both layouts");
 
 #define FL_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // C = alpha * (sum_k A B) + (fresh ? 0 : C); alpha = +-1.  Stores are write-through (sc1): another workgroup of this launch reads them.
-template <int AKM, int BKM>
+template <int AKM, int BKM, bool MARK = false>
 __device__ __forceinline__ void flow_tile(const double* Ap, const double* Bp, double* Cp, const int64_t ld, const int kt, const bool fresh,
-                                          const double alpha, double* gemm_lds, unsigned long long* tr) {
+                                          const double alpha, double* gemm_lds, unsigned long long* tr, unsigned* prog, double* const* Cpp, const double* alphap) {
     constexpr int WTM = FL_WTM, WTN = FL_WTN, NWJ = FL_NWJ, NWI = FL_NWI, NT = FL_NT;
     constexpr int TMR = MOGP_TILE, TNC = MOGP_TILE, COLK_A = FL_COLK, COLK_B = FL_COLK, OPER_A = FL_OPER, OPER_B = FL_OPER;
     constexpr int EPT_A = TMR * FL_BK / NT, EPT_B = TNC * FL_BK / NT;
@@ -120,11 +120,18 @@ __device__ __forceinline__ void flow_tile(const double* Ap, const double* Bp, do
             for (int n = 0; n < WTN; ++n)
                 acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[n], acc[m][n], 0, 0, 0);
     };
+    // (debugging: prog[wave] = how far this wave has come -- 0x10000 entered, 0x20000 + kb: the loads of k block kb + 1 have returned and gone to LDS,
+    // 0x30000 past the k loop, 0x40000 stores issued; prog[8 + wave]: the clock of that mark)
+#define FL_MARK(v) do { if constexpr (MARK) { if (prog && ln == 0) { const unsigned v__ = (v); prog[wv] = v__; \
+        if (wv == 0) { const unsigned kb__ = v__ & 0xffffu, now__ = (unsigned)(wall_clock64() >> 4); \
+            if (v__ == 0x10000u) prog[8] = now__; else if (v__ == 0x30000u) prog[13] = now__; else if (v__ == 0x40000u) prog[14] = now__; \
+            else if ((v__ >> 16) == 2u && (kb__ & 7u) == 0u) prog[9 + (kb__ >> 3)] = now__; } } } } while (0)
+    FL_MARK(0x10000u);
     load_block(0);
     write_block(0);
     load_block(min(1, kt - 1));
     FL_LDS_BARRIER();
-    if (tr) tr[2] = wall_clock64();
+    if constexpr (MARK) { if (tr) tr[2] = wall_clock64(); }
     {
         double a0[WTM], b0[WTN], a1[WTM], b1[WTN];
         read_frag(a0, b0, 0, 0);
@@ -139,6 +146,7 @@ __device__ __forceinline__ void flow_tile(const double* Ap, const double* Bp, do
             mma(a1, b1);
             __builtin_amdgcn_sched_barrier(0);
             write_block(buf ^ 1);
+            FL_MARK(0x20000u + (unsigned)kb);
             load_block(min(kb + 2, kt - 1));
             read_frag(a1, b1, buf, 3);
             __builtin_amdgcn_sched_barrier(0);
@@ -151,15 +159,26 @@ __device__ __forceinline__ void flow_tile(const double* Ap, const double* Bp, do
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (tr) tr[3] = wall_clock64();
+    FL_MARK(0x30000u);
+    if constexpr (MARK) { if (tr) tr[3] = wall_clock64(); }
+    // the C coordinates again from a fresh opaque copy of the thread id, the C pointer and the sign from an opaque copy of the caller's: what is only
+    // needed behind the k loop must not be kept alive across it (it was spilled to scratch)
+    int t2 = threadIdx.x;
+    asm volatile("" : "+v"(t2));
+    const int ln2 = t2 & 63, wv2 = t2 >> 6;
+    const int crow2 = (wv2 / NWJ) * (TMR / NWI) + (ln2 >> 4), ccol2 = (wv2 % NWJ) * (TNC / NWJ) + (ln2 & 15);
+    double* Cq = *Cpp;
+    const double alpha2 = *alphap;
 #pragma unroll
     for (int m = 0; m < WTM; ++m)
 #pragma unroll
         for (int n = 0; n < WTN; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                __hip_atomic_store(Cp + (int64_t)(crow + m * 16 + 4 * r) * ld + ccol + n * 16, alpha * acc[m][n][r], __ATOMIC_RELAXED,
+                __hip_atomic_store(Cq + (int64_t)(crow2 + m * 16 + 4 * r) * ld + ccol2 + n * 16, alpha2 * acc[m][n][r], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
+    FL_MARK(0x40000u);
+#undef FL_MARK
 }
 
 struct FlowArgs {
@@ -170,6 +189,7 @@ struct FlowArgs {
     unsigned* flags;                  // dependency counters, then the queue heads, then the error word (all zero at the start of an evaluation)
     int nq, ncas, base_heads, base_err;
     unsigned nap_max;                 // an idle workgroup sleeps 2^1 .. 2^nap_max microseconds between looks
+    unsigned nap_calm;                // ... up to 2^nap_calm once it has been idle for FL_CALM_AFTER looks
     int nhi;                          // queues below this index always hold a task per workgroup (claimed at the next look after one was taken)
     int claim_one;                    // nothing ready: take from ONE queue per look (the highest priority with a free slot) instead of from all
     int refill;                       // a taken eager slot is refilled at once (0: only when the workgroup finds nothing ready)
@@ -187,7 +207,9 @@ struct FlowArgs {
 // z rows: tile row i of W is final when its row block's T6 tasks are; one task = the 128 dot products of that tile row (a wave takes 16 rows,
 // four at a time, lanes along k with 16-byte loads).  zz[i] = sum of the 128 z^2 (the caller adds the tile rows up).
 __device__ __forceinline__ void flow_zrow(const FlowArgs& g, const int i, double* lds) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid = threadIdx.x;                                // (opaque: nothing of this rare task is computed ahead at kernel entry and kept -- spilled -- for the kernel's life)
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int K = (i + 1) * MOGP_TILE;
     const double* Wr = g.bWm + (int64_t)(i * MOGP_TILE + wave * 16) * g.ld + 2 * lane;
     const double* yp = g.vy + 2 * lane;
@@ -226,7 +248,8 @@ __device__ __forceinline__ void flow_zrow(const FlowArgs& g, const int i, double
 // alpha, one row block at a time: part[r][col] = sum over the rows of block r of W[row][col] z[row], a thread per column, 512 columns per task
 // (the entries of W above its diagonal are zeros: no triangle logic).  alpha[col] = sum_r part[r][col] is taken by k_alpha_sum afterwards.
 __device__ __forceinline__ void flow_apart(const FlowArgs& g, const int r0, const int nrows, const int rblk, const int jg, double* lds) {
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     if (tid < nrows) lds[tid] = g.vz[r0 + tid];              // vector loads: z came from other workgroups of this launch
     __syncthreads();
     const int64_t col = (int64_t)jg * FL_NT + tid;
@@ -243,6 +266,7 @@ __device__ __forceinline__ void flow_apart(const FlowArgs& g, const int r0, cons
 }
 
 #define FL_IDLE_LIMIT 4000u           // idle looks (1 .. 16 us apart: ~65 ms) before a workgroup gives up.  Round 5: 60000 (0.9 s) was what the rare stall of tools/flow_soak.py cost; a time-out is a detour since (chain_fallback), so a false one is cheap and a true one should be
+#define FL_CALM_AFTER 48u             // idle looks (~0.6 ms) after which a waiting workgroup polls at the calmer rate
 #define FL_DEEP_AFTER 128u            // idle looks (~2 ms) before the first deep look of a wait, then one in FL_DEEP_EVERY
 #define FL_DEEP_EVERY 32u
 #define FL_LA 8                       // positions behind the head of a compare-and-swap queue whose readiness a look already knows
@@ -257,33 +281,50 @@ __device__ __forceinline__ void flow_apart(const FlowArgs& g, const int r0, cons
 // Of everything ready it takes the queue with the highest priority.  No workgroup ever waits holding a slot it could use otherwise, and the
 // globally first unfinished task is either somebody's pending task with its counters met, or at the head of a queue nobody holds a
 // pending task of: progress with any number of resident workgroups.
-__global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
+template <bool MARK>          // MARK: the debugging build of the same kernel (MOGP_FLOW_DEBUG) whose tile bodies leave per-wave progress marks
+__global__ __launch_bounds__(FL_NT, 4) void k_flow(const FlowArgs* __restrict__ gp) {
+    // (the arguments by POINTER: as a by-value struct their ~60 scalar registers were live for the whole kernel, 30-odd of them spilled into vector lanes)
+    const FlowArgs& g = *gp;
     extern __shared__ __attribute__((aligned(16))) double gemm_lds[];
     int* pick = reinterpret_cast<int*>(gemm_lds + FL_LDS_DOUBLES);
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    unsigned* heads = g.flags + g.base_heads;
-    unsigned* err = g.flags + g.base_err;
-    // wave 0's lane roles
-    const int ncl = g.ncas * FL_LA, nlanes = ncl + (g.nq - g.ncas);
-    const bool is_cas = lane < ncl, is_eager = lane >= ncl && lane < nlanes;
-    const int myq = is_cas ? lane / FL_LA : (is_eager ? g.ncas + (lane - ncl) : 0), myk = is_cas ? lane % FL_LA : 0;
-    int qbase = 0, qsize = 0;
-    if (wave == 0 && lane < nlanes) { qbase = g.qmeta[2 * myq]; qsize = g.qmeta[2 * myq + 1]; }
-    int pend = -1;                    // eager lanes: the index (inside the queue) this workgroup holds
-    bool exhausted = false;           // eager lanes: the queue has nothing left to take
-    unsigned long long cas_heads = 0; // bit q * FL_LA for every compare-and-swap queue
-    for (int q = 0; q < g.ncas; ++q) cas_heads |= 1ull << (q * FL_LA);
-    const unsigned long long eager_mask = nlanes >= 64 ? ~0ull << ncl : ((1ull << nlanes) - 1ull) & ~((1ull << ncl) - 1ull);
-    unsigned idle = 0, naps = 0;
-    unsigned long long t_look = 0;
+    // Round 6: NOTHING of the look is live in registers across a tile.  What wave 0's lanes remember between looks -- the ticket each eager lane holds,
+    // the task it looked at last and how many of its dependencies it has seen met, whether its queue is used up -- lives in LDS (`lst`), the lane roles are
+    // recomputed per look.  With that state in VGPRs across flow_tile the kernel needed 39 spilled VGPRs and a scratch load INSIDE the k loop; k_gemm's
+    // identical tile body has none.  (Scratch accesses are also where the rare stall of rounds 5 - 6 caught its workgroups: DESIGN section 9.)
+    int* lst = pick + 4;                                  // [3][64]: pend, met_idx, met_n | exhausted << 8
+    double** ep_C = reinterpret_cast<double**>(lst + 192);          // the running tile's C pointer and sign, for its epilogue
+    double* ep_alpha = reinterpret_cast<double*>(lst + 194);
+    if (threadIdx.x < 64) { lst[threadIdx.x] = -1; lst[64 + threadIdx.x] = -1; lst[128 + threadIdx.x] = 0; }
     for (;;) {
-        if (g.trace && tid == 0) t_look = wall_clock64();
-        if (g.post && tid == 0) { g.post[(size_t)(g.post_base + blockIdx.x) * FLOW_POST_W + 2] = 1u; g.post[(size_t)(g.post_base + blockIdx.x) * FLOW_POST_W + 4] = (unsigned)(wall_clock64() >> 4); }      // looking
+        int tid = threadIdx.x;                            // (re-derived per iteration from an opaque copy: not live across the tile body)
+        asm volatile("" : "+v"(tid));
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        unsigned long long t_look = 0;
+        if (MARK && g.trace && tid == 0) t_look = wall_clock64();
+        if (MARK && g.post && tid == 0) {                                  // looking (word 72: the FIRST look's clock, 74 / 75: where the workgroup runs)
+            unsigned* po = g.post + (size_t)(g.post_base + blockIdx.x) * FLOW_POST_W;
+            const unsigned now = (unsigned)(wall_clock64() >> 4);
+            po[2] = 1u; po[4] = now;
+            if (po[72] == 0u) { po[72] = now | 1u; po[74] = __builtin_amdgcn_s_getreg((31 << 11) | 4); po[75] = __builtin_amdgcn_s_getreg((3 << 11) | 20); }
+        }
         if (wave == 0) {
+            unsigned* heads = g.flags + g.base_heads;
+            unsigned* err = g.flags + g.base_err;
+            // wave 0's lane roles
+            const int ncl = g.ncas * FL_LA, nlanes = ncl + (g.nq - g.ncas);
+            const bool is_cas = lane < ncl, is_eager = lane >= ncl && lane < nlanes;
+            const int myq = is_cas ? lane / FL_LA : (is_eager ? g.ncas + (lane - ncl) : 0), myk = is_cas ? lane % FL_LA : 0;
+            int qbase = 0, qsize = 0;
+            if (lane < nlanes) { qbase = g.qmeta[2 * myq]; qsize = g.qmeta[2 * myq + 1]; }
+            int pend = lst[lane];             // eager lanes: the index (inside the queue) this workgroup holds
+            int met_idx = lst[64 + lane], met_n = lst[128 + lane] & 0xff;      // the task this lane looked at last, and how many of its leading dependencies it has seen met
+            bool exhausted = (lst[128 + lane] >> 8) != 0;                       // eager lanes: the queue has nothing left to take
+            unsigned long long cas_heads = 0; // bit q * FL_LA for every compare-and-swap queue
+            for (int q = 0; q < g.ncas; ++q) cas_heads |= 1ull << (q * FL_LA);
+            const unsigned long long eager_mask = nlanes >= 64 ? ~0ull << ncl : ((1ull << nlanes) - 1ull) & ~((1ull << ncl) - 1ull);
+            unsigned idle = 0, naps = 0;
             int res = -1;
             unsigned nap = 0;
-            naps = 0;
             for (;;) {
                 int h = 0, idx = -1;
                 // the few queues right behind the critical one are LOOKED AT by every workgroup at every look (their head's readiness, like the
@@ -315,10 +356,17 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                 if (idx >= 0) {
                     const FlowTask* t = g.tasks + qbase + idx;
                     const int nd = t->ndep;
+                    // counters only grow: a dependency seen met stays met, so a lane that keeps looking at the SAME task re-reads only what it has not yet
+                    // seen met (met_n leading dependencies of task met_idx) -- a third of the counter loads of a waiting grid (round 6)
+                    if (idx != met_idx) { met_idx = idx; met_n = 0; }
                     ready = true;
+                    int lead = met_n;
                     for (int d = 0; d < 4; ++d)
-                        if (d < nd && __hip_atomic_load(g.flags + t->dep[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)t->need[d])
-                            ready = false;
+                        if (d >= met_n && d < nd) {
+                            if (__hip_atomic_load(g.flags + t->dep[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)t->need[d]) ready = false;
+                            else if (lead == d) lead = d + 1;
+                        }
+                    met_n = lead;
                     if (deep && !ready) {
                         bool ready2 = true;
                         unsigned seen = 0, which = 0;
@@ -338,7 +386,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                 }
                 if (deep && lane == 0) __hip_atomic_fetch_add(g.diag + FLOW_DIAG_DEEP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long mready = __ballot(ready);
-                if (g.post) {                                  // debugging: freeze at once when anybody has given up (the state the host dumps is then the state of the stall)
+                if (MARK && g.post) {                                  // debugging: freeze at once when anybody has given up (the state the host dumps is then the state of the stall)
                     if (lane == 0) { g.post[(size_t)(g.post_base + blockIdx.x) * FLOW_POST_W + 6] = (unsigned)mready; g.post[(size_t)(g.post_base + blockIdx.x) * FLOW_POST_W + 7] = (unsigned)(mready >> 32); }
                     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { res = -3; break; }
                 }
@@ -360,7 +408,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                         } else if (peek) {                                      // the head looked ready: take a ticket; if others were faster the ticket is a
                             const unsigned hh = __hip_atomic_fetch_add(heads + myq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // later task: hold it
                             if (hh == (unsigned)h) { ok = 1; res = qbase + h; }
-                            else if (hh < (unsigned)qsize) { pend = (int)hh; if (g.trace) g.trace[FLOW_TRACE_W * (size_t)(qbase + (int)hh) + 5] = (1ull << 63) | blockIdx.x; }
+                            else if (hh < (unsigned)qsize) { pend = (int)hh; if (MARK && g.trace) g.trace[FLOW_TRACE_W * (size_t)(qbase + (int)hh) + 5] = (1ull << 63) | blockIdx.x; }
                             else exhausted = true;
                         } else {
                             ok = 1; res = qbase + pend;
@@ -368,7 +416,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                             // queue, where a task held by a busy workgroup is a task an idle one cannot take
                             if (g.refill && pend + 2 * (int)gridDim.x < qsize) {
                                 const unsigned hh = __hip_atomic_fetch_add(heads + myq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (hh < (unsigned)qsize) { pend = (int)hh; if (g.trace) g.trace[FLOW_TRACE_W * (size_t)(qbase + (int)hh) + 5] = (1ull << 63) | blockIdx.x; } else { pend = -1; exhausted = true; }
+                                if (hh < (unsigned)qsize) { pend = (int)hh; if (MARK && g.trace) g.trace[FLOW_TRACE_W * (size_t)(qbase + (int)hh) + 5] = (1ull << 63) | blockIdx.x; } else { pend = -1; exhausted = true; }
                             } else pend = -1;
                         }
                     }
@@ -386,12 +434,16 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                 }
                 if (want) {
                     const unsigned hh = __hip_atomic_fetch_add(heads + myq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (hh < (unsigned)qsize) { pend = (int)hh; took = true; if (g.trace) g.trace[FLOW_TRACE_W * (size_t)(qbase + (int)hh) + 5] = (1ull << 63) | blockIdx.x; } else exhausted = true;      // (trace: who HOLDS the task; overwritten when it starts)
+                    if (hh < (unsigned)qsize) { pend = (int)hh; took = true; if (MARK && g.trace) g.trace[FLOW_TRACE_W * (size_t)(qbase + (int)hh) + 5] = (1ull << 63) | blockIdx.x; } else exhausted = true;      // (trace: who HOLDS the task; overwritten when it starts)
                 }
                 const bool open = is_cas ? (myk == 0 && h < qsize) : (is_eager && (pend >= 0 || !exhausted));
                 if (!__ballot(open)) { res = -2; break; }                      // every queue is empty and nothing is held: done
                 if (__ballot(took)) continue;
-                nap = nap < g.nap_max ? nap + 1u : g.nap_max;                  // back off: idle workgroups must not crowd the memory system
+                // back off: idle workgroups must not crowd the memory system.  Two stages (round 6): naps of up to 2^nap_max units while the wait
+                // is an ordinary one (a look that finds nothing waits ~175 us on average), up to 2^nap_calm once it has lasted FL_CALM_AFTER looks -- when most of
+                // the grid waits for a few tasks, ~480 workgroups x ~100 counter loads per look are what those few tasks' operand loads queue behind
+                const unsigned cap = idle >= FL_CALM_AFTER ? g.nap_calm : g.nap_max;
+                nap = nap < cap ? nap + 1u : cap;
                 for (unsigned z = 0; z < (1u << nap); ++z) __builtin_amdgcn_s_sleep(32);
                 ++naps;
                 if ((++idle & 15u) == 0u) {
@@ -403,11 +455,13 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
                     }
                 }
             }
+            lst[lane] = pend; lst[64 + lane] = met_idx; lst[128 + lane] = met_n | (exhausted ? 0x100 : 0);
             if (lane == 0) {
                 pick[0] = res;
+                pick[1] = (int)naps;
                 if (res >= 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ONE buffer_inv sc1 behind the satisfied counters
             }
-            if (g.post && res < 0) {                           // post-mortem: what this workgroup still held when it left, and why it left
+            if (MARK && g.post && res < 0) {                           // post-mortem: what this workgroup still held when it left, and why it left
                 unsigned* po = g.post + (size_t)(g.post_base + blockIdx.x) * FLOW_POST_W;
                 po[8 + lane] = is_eager ? (unsigned)(pend + 1) : 0u;
                 if (lane == 0) { po[0] = (unsigned)(res + 4); po[1] = idle; po[2] = 3u; po[5] = (unsigned)(wall_clock64() >> 4); }
@@ -419,7 +473,6 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
             if (ti == -3 && tid == 0) atomicMin(g.info, (unsigned long long)MOGP_INFO_CHAIN_TIMEOUT);
             break;
         }
-        idle = 0;
         const FlowTask* tp = g.tasks + ti;
         const int var = tp->var, kt = tp->kt;
         const int ab = tp->abuf, bb = tp->bbuf, cb = tp->cbuf;
@@ -431,9 +484,13 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
         double* Cp = Cb + ((int64_t)tp->cr * g.ld + tp->cc) * MOGP_TILE;
         const bool fresh = (var & 4) != 0;
         const double alpha = (var & 8) ? -1.0 : 1.0;
-        unsigned long long* tr = (g.trace && tid == 0) ? g.trace + FLOW_TRACE_W * (size_t)ti : nullptr;
+        unsigned long long* tr = (MARK && g.trace && tid == 0) ? g.trace + FLOW_TRACE_W * (size_t)ti : nullptr;      // (time stamps: the debugging build only)
         if (tr) { tr[0] = t_look; tr[1] = wall_clock64(); }
-        if (g.post && tid == 0) { g.post[(size_t)(g.post_base + blockIdx.x) * FLOW_POST_W + 2] = 2u; g.post[(size_t)(g.post_base + blockIdx.x) * FLOW_POST_W + 3] = (unsigned)ti; }      // running task ti
+        unsigned* prog = (MARK && g.post) ? g.post + (size_t)(g.post_base + blockIdx.x) * FLOW_POST_W + 80 : nullptr;
+        if (MARK && g.post && tid == 0) {                                  // running task ti (word 73: tasks so far, 76: this one's start)
+            unsigned* po = g.post + (size_t)(g.post_base + blockIdx.x) * FLOW_POST_W;
+            po[2] = 2u; po[3] = (unsigned)ti; po[73] += 1u; po[76] = (unsigned)(wall_clock64() >> 4);
+        }
         if (var & 32) {                                            // vector task: tile row ar (z) or row block ar .. ar + kt - 1, column group ac (alpha)
             if (g.vy) {
                 if (var & 1) flow_apart(g, tp->ar * MOGP_TILE, kt * MOGP_TILE, tp->br, tp->ac, gemm_lds);
@@ -441,10 +498,11 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
             }
         } else {
         if (var & 16) __builtin_amdgcn_s_setprio(2);
+        if (tid == 0) { *ep_C = Cp; *ep_alpha = alpha; }           // what the tile's epilogue needs, parked in LDS across the k loop (whose barriers publish it)
         switch (var & 3) {
-            case 0: flow_tile<0, 0>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, tr); break;
-            case 1: flow_tile<0, 1>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, tr); break;
-            default: flow_tile<1, 1>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, tr); break;
+            case 0: flow_tile<0, 0, MARK>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, tr, prog, ep_C, ep_alpha); break;
+            case 1: flow_tile<0, 1, MARK>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, tr, prog, ep_C, ep_alpha); break;
+            default: flow_tile<1, 1, MARK>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, tr, prog, ep_C, ep_alpha); break;
         }
         if (var & 16) __builtin_amdgcn_s_setprio(0);
         }
@@ -454,10 +512,11 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(FlowArgs g) {
             const unsigned s0 = tp->sig[0], s1 = tp->sig[1];
             if (s0 != FLOW_NOSIG) __hip_atomic_fetch_add(g.flags + s0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (s1 != FLOW_NOSIG) __hip_atomic_fetch_add(g.flags + s1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (g.done) g.done[ti] = 1;
+            if (MARK && g.done) g.done[ti] = 1;
+            if (MARK && g.post) g.post[(size_t)(g.post_base + blockIdx.x) * FLOW_POST_W + 77] = (unsigned)(wall_clock64() >> 4);
             if (tr) {
                 tr[4] = wall_clock64();
-                tr[5] = ((unsigned long long)naps << 32) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16) | blockIdx.x;
+                tr[5] = ((unsigned long long)(unsigned)pick[1] << 32) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16) | blockIdx.x;
             }
         }
     }
@@ -808,7 +867,9 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     HIP_TRY(hipStreamWaitEvent(priv, start, 0));
 
     static std::atomic<unsigned long long> attr_done{0ull};                 // one bit per device
-    { int r__ = set_max_dynamic_lds(reinterpret_cast<const void*>(k_flow), FL_LDS_BYTES, attr_done); if (r__) return r__; }
+    static std::atomic<unsigned long long> attr_done_dbg{0ull};
+    { int r__ = set_max_dynamic_lds(reinterpret_cast<const void*>(k_flow<false>), FL_LDS_BYTES, attr_done); if (r__) return r__; }
+    { int r__ = set_max_dynamic_lds(reinterpret_cast<const void*>(k_flow<true>), FL_LDS_BYTES, attr_done_dbg); if (r__) return r__; }
     static const int wg_per_cu = std::getenv("MOGP_FLOW_WGS") ? std::max(1, std::atoi(std::getenv("MOGP_FLOW_WGS"))) : 2;
     const int cus = (m->ctx->ncu > 0 ? m->ctx->ncu : 256) - m->ctx->ncu_reserved;
     FlowArgs g{};
@@ -832,6 +893,7 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     { const char* e = std::getenv("MOGP_FLOW_CLAIM1"); g.claim_one = e ? std::atoi(e) : 0; }
     { const char* e = std::getenv("MOGP_FLOW_NHI"); g.nhi = e ? std::atoi(e) : 0; }            // measured 3 / 4 (semi, the inverse cycle, z and alpha looked at by everybody): 10.74-10.79 vs 10.52-10.65 ms
     { const char* e = std::getenv("MOGP_FLOW_NAP"); g.nap_max = e ? (unsigned)std::max(0, std::atoi(e)) : 4u; }
+    { const char* e = std::getenv("MOGP_FLOW_NAP_CALM"); g.nap_calm = e ? (unsigned)std::max(0, std::atoi(e)) : 7u; if (g.nap_calm < g.nap_max) g.nap_calm = g.nap_max; }
     w.vec_done = false;
     if (!rhs && w.want_vec && w.vec_y && w.vec_z && w.vec_zz && w.vec_part) {       // z = W y, alpha = W^T z as tasks of the same kernel
         g.vy = w.vec_y; g.vz = w.vec_z; g.vzz = w.vec_zz; g.vpart = w.vec_part;
@@ -845,7 +907,17 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
         HIP_TRY(hipEventRecord(pe0, bulk));
     }
     if (rhs && rhs->ready) HIP_TRY(hipStreamWaitEvent(bulk, rhs->ready, 0));          // the right-hand sides are in place (the chain kernels need not wait for them)
-    hipLaunchKernelGGL(k_flow, dim3(wg_per_cu * cus), dim3(FL_NT), FL_LDS_BYTES, bulk, g);
+    const bool dbg_kernel = g.post != nullptr || g.trace != nullptr;        // time stamps and the post-mortem: the debugging build of the kernel
+    // the arguments travel through device memory (k_flow takes a pointer): slot 0 for this launch, slot 1 for the small instance behind the chain.  The host
+    // copies live in the workspace (an asynchronous copy from pageable memory is staged before it returns, but nothing here relies on it)
+    static_assert(sizeof(FlowArgs) <= 512, "Spd::flow_args slots");
+    if ((rc = w.flow_args.ensure(1024))) return rc;
+    w.flow_args_h.resize(1024);
+    std::memcpy(w.flow_args_h.data(), &g, sizeof(g));
+    HIP_TRY(hipMemcpyAsync(w.flow_args.p, w.flow_args_h.data(), sizeof(g), hipMemcpyHostToDevice, bulk));
+    const FlowArgs* d_g = reinterpret_cast<const FlowArgs*>(w.flow_args.p);
+    if (dbg_kernel) hipLaunchKernelGGL(k_flow<true>, dim3(wg_per_cu * cus), dim3(FL_NT), FL_LDS_BYTES, bulk, d_g);
+    else hipLaunchKernelGGL(k_flow<false>, dim3(wg_per_cu * cus), dim3(FL_NT), FL_LDS_BYTES, bulk, d_g);
     HIP_TRY(hipGetLastError());
     if (pe1) HIP_TRY(hipEventRecord(pe1, bulk));
     HIP_TRY(hipEventRecord(e_flow, bulk));
@@ -894,7 +966,11 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     if (tail_on && m->ctx->ncu_reserved > 0 && !replay) {
         if (rhs && rhs->ready) HIP_TRY(hipStreamWaitEvent(priv, rhs->ready, 0));
         g.post_base = wg_per_cu * cus;
-        hipLaunchKernelGGL(k_flow, dim3(wg_per_cu * m->ctx->ncu_reserved), dim3(FL_NT), FL_LDS_BYTES, priv, g);
+        std::memcpy(w.flow_args_h.data() + 512, &g, sizeof(g));
+        HIP_TRY(hipMemcpyAsync(w.flow_args.p + 512, w.flow_args_h.data() + 512, sizeof(g), hipMemcpyHostToDevice, priv));
+        const FlowArgs* d_g2 = reinterpret_cast<const FlowArgs*>(w.flow_args.p + 512);
+        if (dbg_kernel) hipLaunchKernelGGL(k_flow<true>, dim3(wg_per_cu * m->ctx->ncu_reserved), dim3(FL_NT), FL_LDS_BYTES, priv, d_g2);
+        else hipLaunchKernelGGL(k_flow<false>, dim3(wg_per_cu * m->ctx->ncu_reserved), dim3(FL_NT), FL_LDS_BYTES, priv, d_g2);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(e_chain, priv));

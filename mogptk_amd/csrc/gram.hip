@@ -515,14 +515,18 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a, int ntiles) {
 // TC = terms a launch may carry (LDS is sized by it); raw rows of a block of 64 points: x | cos_t | sin_t.  Two workgroups per CU: the
 // arithmetic needs ~200 VGPRs, and three or four waves per SIMD bought with spills ran 1.3x / 2x slower.
 #define GS_TC_MAX 8
-template <int TC>
+// NC = columns per thread: 4 (256 threads, 4 x 4 entries each: ~200 VGPRs, two waves per SIMD) or 2 (512 threads, 4 x 2 entries: under 128 VGPRs,
+// FOUR waves per SIMD -- round 6: the kernel's waves were parked at s_waitcnt / s_barrier 36 % of their cycles with two)
+template <int TC, int NC = 4>
 struct StripLds {
-    static constexpr int RAW = 1 + 2 * TC, PF = (RAW * MOGP_GT + 255) / 256;      // PF: prefetch registers per thread
+    static constexpr int NT = 64 * (MOGP_GT / NC) / 4;
+    static constexpr int RAW = 1 + 2 * TC, PF = (RAW * MOGP_GT + NT - 1) / NT;      // PF: prefetch registers per thread
     // column-side arrays in two planes: a thread's four columns 4 cg .. 4 cg + 3 are two 16-byte reads, and with the points in order lane cg's reads sat
     // 32 bytes apart -- every fourth lane on the same banks (SQ_LDS_BANK_CONFLICT: 54 % of the kernel's LDS cycles).  Columns 4 cg, 4 cg + 1 at
     // [2 cg], columns 4 cg + 2, 4 cg + 3 at [CP + 2 cg]: each read is 16 contiguous lanes x 16 bytes.
+    // (NC = 2: a thread's two columns are ONE 16-byte read, 32 lanes x 16 bytes contiguous in the natural order)
     static constexpr int CP = 36, CL = 72;
-    __device__ static __forceinline__ int cs(int pnt) { return ((pnt & 2) ? CP : 0) + ((pnt >> 2) << 1) + (pnt & 1); }
+    __device__ static __forceinline__ int cs(int pnt) { return NC == 2 ? pnt : ((pnt & 2) ? CP : 0) + ((pnt >> 2) << 1) + (pnt & 1); }
     double rowraw[RAW][MOGP_GT];
     double colraw[2][RAW][CL];
     double cu[TC][MOGP_GT], su[TC][MOGP_GT], cw[TC][CL], sw[TC][CL];
@@ -531,17 +535,17 @@ struct StripLds {
     int deg[TC];
 };
 
-template <int N>
-__device__ __forceinline__ void strip_term(double (&acc)[4][4], const double (&p)[4], const double (&q)[4], double V, double s,
-                                           const double (&cu)[4], const double (&su)[4], const double (&cw)[4], const double (&sw)[4]) {
+template <int N, int NC>
+__device__ __forceinline__ void strip_term(double (&acc)[4][NC], const double (&p)[4], const double (&q)[NC], double V, double s,
+                                           const double (&cu)[4], const double (&su)[4], const double (&cw)[NC], const double (&sw)[NC]) {
     double vp[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) vp[m] = V * p[m];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        if (m == 2) __builtin_amdgcn_sched_barrier(0);      // two groups of eight independent Horner chains (see gram_term)
+        if (m == 2 && NC == 4) __builtin_amdgcn_sched_barrier(0);      // two groups of eight independent Horner chains (see gram_term)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < NC; ++n) {
             double e;
             if (N > 0) {
                 e = exp_taylor<N>(vp[m] * q[n]);
@@ -554,11 +558,12 @@ __device__ __forceinline__ void strip_term(double (&acc)[4][4], const double (&p
     }
 }
 
-template <int TC>
-__global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* __restrict__ segs) {
-    constexpr int GS_TC = TC, GS_PF = StripLds<TC>::PF;
-    __shared__ StripLds<TC> L;
-    const int tid = threadIdx.x, cg = tid & 15, rg = tid >> 4;
+template <int TC, int NC>
+__global__ __launch_bounds__(64 * (MOGP_GT / NC) / 4, NC == 2 ? 4 : 2) void k_gram_strip(GramArgs a, const GSeg* __restrict__ segs) {
+    using SL = StripLds<TC, NC>;
+    constexpr int GS_TC = TC, GS_PF = SL::PF, NT = SL::NT, NCG = MOGP_GT / NC;
+    __shared__ SL L;
+    const int tid = threadIdx.x, cg = tid % NCG, rg = tid / NCG;
     const GSeg sg = segs[blockIdx.x];
     const int T = a.T, W = a.W;
     const int ci = sg.pair / a.C, cj = sg.pair - ci * a.C;
@@ -568,7 +573,7 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* _
     // raw row k of a block of points: 0 = input, 1 .. T = cos of term k - 1, T + 1 .. 2 T = sin of term k - 1 - T; LDS slot of row k
     auto slot = [&](int k) { return k <= T ? k : k - T + GS_TC; };
 
-    for (int e = tid; e < nraw; e += 256) {               // the row block, once per run (rows take the table of the COLUMN channel)
+    for (int e = tid; e < nraw; e += NT) {               // the row block, once per run (rows take the table of the COLUMN channel)
         const int k = e >> 6, pnt = e & 63;
         const int64_t gp = sg.r0 + pnt;
         double val;
@@ -583,7 +588,7 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* _
     auto col_fetch = [&](int c0) {                        // columns take the table of the ROW channel
 #pragma unroll
         for (int k5 = 0; k5 < GS_PF; ++k5) {
-            const int e = tid + 256 * k5;
+            const int e = tid + NT * k5;
             if (e < nraw) {
                 const int k = e >> 6, pnt = e & 63;
                 const int64_t gp = c0 + pnt;
@@ -599,8 +604,8 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* _
     auto col_commit = [&](int b) {
 #pragma unroll
         for (int k5 = 0; k5 < GS_PF; ++k5) {
-            const int e = tid + 256 * k5;
-            if (e < nraw) L.colraw[b][slot(e >> 6)][StripLds<TC>::cs(e & 63)] = pf[k5];
+            const int e = tid + NT * k5;
+            if (e < nraw) L.colraw[b][slot(e >> 6)][SL::cs(e & 63)] = pf[k5];
         }
     };
     col_fetch(sg.c0);
@@ -615,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* _
     for (int u = 0; u < sg.n; ++u) {
         const int b = u & 1, c0 = sg.c0 + u * MOGP_GT;
         // ---- stage the tile-centred factors: (rows | columns) x term x point ----
-        for (int e = tid; e < 2 * T * MOGP_GT; e += 256) {
+        for (int e = tid; e < 2 * T * MOGP_GT; e += NT) {
             const int which = e >= T * MOGP_GT, rem = e - which * T * MOGP_GT, t = rem >> 6, pnt = rem & 63;
             const double A = L.tab[t][0], V = L.tab[t][1], s = (cr - cc) + L.tab[t][2];
             const double zmax = fabs(V) * hr * hc, es = V * s * s;
@@ -628,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* _
             if (pnt == 0 && which == 0) { L.deg[t] = deg; L.V[t] = V; L.s[t] = s; }
             if (deg == GT_SKIP) continue;
             double f = 1.0;
-            if (GRAM_DBG(a, 4)) { L.cu[t][pnt] = 1.0; L.su[t][pnt] = 0.5; L.cw[t][StripLds<TC>::cs(pnt)] = 0.25; L.sw[t][StripLds<TC>::cs(pnt)] = 2.0; continue; }
+            if (GRAM_DBG(a, 4)) { L.cu[t][pnt] = 1.0; L.su[t][pnt] = 0.5; L.cw[t][SL::cs(pnt)] = 0.25; L.sw[t][SL::cs(pnt)] = 2.0; continue; }
             if (which == 0) {
                 if (deg != GT_GENERAL) {
                     const double pp = L.rowraw[0][pnt] - cr;
@@ -638,37 +643,36 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* _
                 L.cu[t][pnt] = f * L.rowraw[1 + t][pnt]; L.su[t][pnt] = f * L.rowraw[1 + GS_TC + t][pnt];
             } else {
                 if (deg != GT_GENERAL) {
-                    const double qq = L.colraw[b][0][StripLds<TC>::cs(pnt)] - cc;
+                    const double qq = L.colraw[b][0][SL::cs(pnt)] - cc;
                     f = fast_exp(-0.5 * (V * (qq * qq - 2.0 * qq * s)));
                 }
-                { const int cp = StripLds<TC>::cs(pnt); L.cw[t][cp] = f * L.colraw[b][1 + t][cp]; L.sw[t][cp] = f * L.colraw[b][1 + GS_TC + t][cp]; }
+                { const int cp = SL::cs(pnt); L.cw[t][cp] = f * L.colraw[b][1 + t][cp]; L.sw[t][cp] = f * L.colraw[b][1 + GS_TC + t][cp]; }
             }
         }
         __syncthreads();
-        double q[4], acc[4][4];
+        double q[NC], acc[4][NC];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) q[n] = L.colraw[b][0][StripLds<TC>::cs(cg * 4 + n)] - cc;
+        for (int n = 0; n < NC; ++n) q[n] = L.colraw[b][0][SL::cs(cg * NC + n)] - cc;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = 0.0;
+            for (int n = 0; n < NC; ++n) acc[m][n] = 0.0;
         for (int t = 0; t < T; ++t) {
             const int deg = __builtin_amdgcn_readfirstlane(L.deg[t]);
             if (deg == GT_SKIP || GRAM_DBG(a, 2)) continue;
             const double V = L.V[t], s = L.s[t];
-            double cu[4], su[4], cw[4], sw[4];
+            double cu[4], su[4], cw[NC], sw[NC];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                cu[m] = L.cu[t][rg * 4 + m]; su[m] = L.su[t][rg * 4 + m];
-                cw[m] = L.cw[t][StripLds<TC>::cs(cg * 4 + m)]; sw[m] = L.sw[t][StripLds<TC>::cs(cg * 4 + m)];
-            }
+            for (int m = 0; m < 4; ++m) { cu[m] = L.cu[t][rg * 4 + m]; su[m] = L.su[t][rg * 4 + m]; }
+#pragma unroll
+            for (int n = 0; n < NC; ++n) { cw[n] = L.cw[t][SL::cs(cg * NC + n)]; sw[n] = L.sw[t][SL::cs(cg * NC + n)]; }
             switch (deg) {
-                case 4: strip_term<4>(acc, p, q, V, s, cu, su, cw, sw); break;
-                case 6: strip_term<6>(acc, p, q, V, s, cu, su, cw, sw); break;
-                case 8: strip_term<8>(acc, p, q, V, s, cu, su, cw, sw); break;
-                case 11: strip_term<11>(acc, p, q, V, s, cu, su, cw, sw); break;
-                case 14: strip_term<14>(acc, p, q, V, s, cu, su, cw, sw); break;
-                default: strip_term<0>(acc, p, q, V, s, cu, su, cw, sw); break;
+                case 4: strip_term<4, NC>(acc, p, q, V, s, cu, su, cw, sw); break;
+                case 6: strip_term<6, NC>(acc, p, q, V, s, cu, su, cw, sw); break;
+                case 8: strip_term<8, NC>(acc, p, q, V, s, cu, su, cw, sw); break;
+                case 11: strip_term<11, NC>(acc, p, q, V, s, cu, su, cw, sw); break;
+                case 14: strip_term<14, NC>(acc, p, q, V, s, cu, su, cw, sw); break;
+                default: strip_term<0, NC>(acc, p, q, V, s, cu, su, cw, sw); break;
             }
         }
         if (u + 1 < sg.n) { col_commit(b ^ 1); cc = cc_n; hc = hc_n; }
@@ -680,8 +684,8 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* _
                 const int lr = rg * 4 + m;
                 const int64_t r = sg.r0 + lr;
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const int lc = cg * 4 + n;
+                for (int n = 0; n < NC; ++n) {
+                    const int lc = cg * NC + n;
                     if (lc > lr) continue;
                     double val = acc[m][n];
                     if (a.noise != nullptr && lc == lr) {
@@ -695,14 +699,14 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip(GramArgs a, const GSeg* _
         } else if (!(GRAM_DBG(a, 1) && acc[0][0] != 12345.678)) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const int64_t at = (int64_t)(sg.r0 + rg * 4 + m) * a.ldo + c0 + cg * 4;
+                const int64_t at = (int64_t)(sg.r0 + rg * 4 + m) * a.ldo + c0 + cg * NC;
                 double* o = a.out + at;
-                *reinterpret_cast<d2_t*>(o) = (d2_t){acc[m][0], acc[m][1]};
-                *reinterpret_cast<d2_t*>(o + 2) = (d2_t){acc[m][2], acc[m][3]};
+#pragma unroll
+                for (int n = 0; n < NC; n += 2) *reinterpret_cast<d2_t*>(o + n) = (d2_t){acc[m][n], acc[m][n + 1]};
                 if (a.out2) {                              // the sparse models' working copy of K_uf (same leading dimension)
                     double* o2 = a.out2 + at;
-                    *reinterpret_cast<d2_t*>(o2) = (d2_t){acc[m][0], acc[m][1]};
-                    *reinterpret_cast<d2_t*>(o2 + 2) = (d2_t){acc[m][2], acc[m][3]};
+#pragma unroll
+                    for (int n = 0; n < NC; n += 2) *reinterpret_cast<d2_t*>(o2 + n) = (d2_t){acc[m][n], acc[m][n + 1]};
                 }
             }
         }
@@ -748,8 +752,14 @@ int launch_gram(const GramArgs& a0, int ntiles, hipStream_t s) {
     if (a.ev0) HIP_TRY(hipEventRecord(a.ev0, s));
     static const bool strip_on = !(std::getenv("MOGP_GRAM_STRIP") && std::atoi(std::getenv("MOGP_GRAM_STRIP")) == 0);
     if (strip_on && a.segs && a.nsegs > 0 && a.D == 1 && a.W == 5 && a.T <= GS_TC_MAX && !a.mirror && (a.ldo & 1) == 0) {
-        if (a.T <= 4) hipLaunchKernelGGL(k_gram_strip<4>, dim3(a.nsegs), dim3(256), 0, s, a, a.segs);
-        else hipLaunchKernelGGL(k_gram_strip<8>, dim3(a.nsegs), dim3(256), 0, s, a, a.segs);
+        static const int strip_nc = []() { const char* e = std::getenv("MOGP_GRAM_NC"); const int v = e ? std::atoi(e) : 2; return v == 4 ? 4 : 2; }();      // MOGP_GRAM_NC=4: the 256-thread form of rounds 4 - 5
+        if (strip_nc == 2) {
+            if (a.T <= 4) hipLaunchKernelGGL((k_gram_strip<4, 2>), dim3(a.nsegs), dim3(512), 0, s, a, a.segs);
+            else hipLaunchKernelGGL((k_gram_strip<8, 2>), dim3(a.nsegs), dim3(512), 0, s, a, a.segs);
+        } else {
+            if (a.T <= 4) hipLaunchKernelGGL((k_gram_strip<4, 4>), dim3(a.nsegs), dim3(256), 0, s, a, a.segs);
+            else hipLaunchKernelGGL((k_gram_strip<8, 4>), dim3(a.nsegs), dim3(256), 0, s, a, a.segs);
+        }
         if (a.nrest > 0) {
             a.tiles = a.rest;
             hipLaunchKernelGGL(k_gram<1>, dim3(std::min(a.nrest, 2 * ncu)), dim3(256), dyn, s, a, a.nrest);

@@ -750,6 +750,7 @@ namespace mogp { void flow_debug_dump(mogp_model* m) {
         fprintf(stderr, "  post-mortem: %zu workgroups left on the time-out, %zu left done, %zu never started, %zu never left; %zu tickets held\n", n_to, n_done, n_never, n_silent, holder.size());
         // every task that has NOT signalled although its counters are met: who holds it, and what did the holder's last look say?
         size_t nready = 0, nundone = 0;
+        std::set<unsigned> suspects;
         for (int q = 0; q < p.nq; ++q) {
             const unsigned h = fl[p.base_heads + q];
             for (int k = 0; k < p.qsize[q]; ++k) {
@@ -770,12 +771,32 @@ namespace mogp { void flow_debug_dump(mogp_model* m) {
                     const unsigned* r = po.data() + (size_t)wgi * FLOW_POST_W;
                     const int lane = ncl + (q - FLOW_NCAS);
                     const unsigned long long mr = ((unsigned long long)r[7] << 32) | r[6];
-                    fprintf(stderr, "  [held by workgroup %u: %u idle looks, its last look saw this task %s, state %u]", wgi, r[1], ((mr >> lane) & 1ull) ? "READY" : "not ready", r[2]);
+                    fprintf(stderr, "  [held by workgroup %u: %u idle looks, its last look saw this task %s]", wgi, r[1], ((mr >> lane) & 1ull) ? "READY" : "not ready");
+                    suspects.insert(wgi);
                 }
                 fprintf(stderr, "\n");
             }
         }
         fprintf(stderr, "  %zu tasks have not signalled; %zu of them have their counters met\n", nundone, nready);
+        // the life of every workgroup that holds such a task, and of the whole grid in numbers (clock: 0.16 us units since the first workgroup's first look)
+        unsigned t0 = ~0u;
+        for (size_t wgi = 0; wgi < nwg; ++wgi) { const unsigned* r = po.data() + wgi * FLOW_POST_W; if (r[72] && r[72] < t0) t0 = r[72]; }
+        auto us = [&](unsigned c) { return c ? 0.16 * (double)(int)(c - t0) : -1.0; };
+        for (unsigned wgi : suspects) {
+            const unsigned* r = po.data() + (size_t)wgi * FLOW_POST_W;
+            fprintf(stderr, "  workgroup %u: XCC %u HW_ID 0x%x (SE %u CU %u); first look at %.0f us, %u tasks run, last task %u started %.0f finished %.0f us, last look %.0f us, left %.0f us after %u idle looks\n",
+                    wgi, r[75] & 0xf, r[74], (r[74] >> 13) & 7, (r[74] >> 8) & 15, us(r[72]), r[73], r[3], us(r[76]), us(r[77]), us(r[4]), us(r[5]), r[1]);
+            fprintf(stderr, "      its waves' last marks (0x1.. entered, 0x2.. + k block whose successor's loads are in, 0x3.. past the k loop, 0x4.. stored) and when:");
+            for (int wv = 0; wv < 8; ++wv) fprintf(stderr, " %x", r[80 + wv]);
+            fprintf(stderr, "; wave 0 of its last task: entered %.0f, k block 0 / 8 / 16 / 24 at %.0f / %.0f / %.0f / %.0f, past the loop %.0f, stored %.0f us\n",
+                    us(r[88]), us(r[89]), us(r[90]), us(r[91]), us(r[92]), us(r[93]), us(r[94]));
+        }
+        {
+            std::vector<double> first, ntask;
+            for (size_t wgi = 0; wgi < nwg; ++wgi) { const unsigned* r = po.data() + wgi * FLOW_POST_W; if (r[72]) { first.push_back(us(r[72])); ntask.push_back((double)r[73]); } }
+            std::sort(first.begin(), first.end()); std::sort(ntask.begin(), ntask.end());
+            if (!first.empty()) fprintf(stderr, "  first looks: median %.0f us, latest %.0f us; tasks run per workgroup: least %.0f, median %.0f, most %.0f\n", first[first.size() / 2], first.back(), ntask.front(), ntask[ntask.size() / 2], ntask.back());
+        }
         // workgroups in the middle of a task when the kernel froze
         for (size_t wgi = 0; wgi < nwg; ++wgi) {
             const unsigned* r = po.data() + wgi * FLOW_POST_W;
@@ -911,8 +932,12 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     m->flow_ran = false;                              // ... and chain_fallback decides from THIS evaluation which schedule to drop, not from an earlier one
     m->k.want_vec = fuse_inverse && !factor_only;     // the dataflow schedule (flow.hip) also forms z = W y and alpha = W^T z
     m->k.vec_y = m->d_y.p; m->k.vec_z = m->d_z.p; m->k.vec_zz = m->d_zz.p; m->k.vec_part = m->d_alpha.p + Npad;
-    const bool accurate = m->accurate && !fuse_inverse && !factor_only;
-    m->accurate_ran = accurate;
+    // MOGP_ACCURATE_LITE=1 (experiment, round 6): the accurate mode keeps the REFINED factorisation but forms W = L^-1 and Kj^-1 = W^T W with the phases
+    // schedule's products (TRTRI levels, LAUUM) instead of two blocked substitutions -- which of the two halves the envelope of the fast schedules needs
+    static const bool acc_lite = std::getenv("MOGP_ACCURATE_LITE") && std::atoi(std::getenv("MOGP_ACCURATE_LITE")) != 0;
+    const bool lite = acc_lite && m->accurate && !fuse_inverse && !factor_only;
+    const bool accurate = m->accurate && !fuse_inverse && !factor_only && !lite;
+    m->accurate_ran = accurate || lite;
     if (accurate) {
         // (round 5) The backward-stable form, for matrices outside the envelope of the schedules below: the launch-per-step Cholesky with
         // every panel refined against L_kk (Spd::refine_panels), then Kj^-1 = L^-T (L^-1 I) by two blocked SUBSTITUTIONS (trsm.hip) instead of
@@ -943,7 +968,11 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
         if ((rc = launch_copy2d(m->d_alpha.p, 1, m->acc_rhs.p, MOGP_TILE, Npad, 1, 1.0, m->st))) return rc;
     } else {
     if (factor_only && !fuse_inverse && m->rhs_job && flow_enabled(m, m->k)) rc = spd_potri_flow(m, m->k, m->rhs_job);      // the prediction: factor + substitute as dataflow
-    else rc = fuse_inverse ? spd_potri_fused(m, m->k) : spd_potrf(m, m->k);
+    else {
+        if (lite) { m->k.keep_L = true; m->k.refine_panels = true; }
+        rc = fuse_inverse ? spd_potri_fused(m, m->k) : spd_potrf(m, m->k);
+        if (lite) { m->k.keep_L = false; m->k.refine_panels = false; }
+    }
     m->k.want_vec = false; m->k.tail_ready = nullptr;
     if (rc) return rc;
     if ((rc = mark(m, 2))) return rc;

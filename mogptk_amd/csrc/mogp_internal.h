@@ -222,7 +222,7 @@ int launch_chain(double* A, int64_t ld, int t0, int nk, double* invd, double* lo
 #define FLOW_MAXQ 48                   // queues of a plan at most: 2 * 8 compare-and-swap lanes + one lane per other queue fit one wave
 #define FLOW_NCAS 1                    // the first queues (by priority) are taken ready-only by compare-and-swap, the others eagerly (flow.hip:k_flow)
 #define FLOW_TRACE_W 6
-#define FLOW_POST_W 72                 // words per workgroup of the dataflow kernel's post-mortem (FlowArgs::post)
+#define FLOW_POST_W 96                 // words per workgroup of the dataflow kernel's post-mortem (FlowArgs::post)
 #define FLOW_KEY_STEP 1024             // FlowTask::key = FLOW_KEY_STEP * superstep + position inside it
 #define FLOW_NOSIG 0xffffffffu
 struct FlowTask {                      // 64 bytes; static per matrix size

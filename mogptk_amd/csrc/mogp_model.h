@@ -148,6 +148,8 @@ struct Spd {
     DevBuf<int> flow_qmeta_rhs;
     const FlowPlan* flow_cur = nullptr;                 // the plan of the last dataflow run (debug dump, trace)
     DevBuf<unsigned> flow_flags;
+    DevBuf<char> flow_args;             // the dataflow kernel's arguments in device memory (two 512-byte slots: the kernel, its small second instance)
+    std::vector<char> flow_args_h;      // ... and their host copies
     DevBuf<unsigned char> flow_done;    // MOGP_FLOW_DEBUG: one byte per task of the last dataflow evaluation, set when it has signalled
     DevBuf<unsigned> flow_post;         // MOGP_FLOW_DEBUG: per-workgroup post-mortem of the last dataflow evaluation (FLOW_POST_W words each)
     DevBuf<unsigned> flow_diag;         // FLOW_DIAG_WORDS counters of the schedule's deep looks (zeroed once, never per evaluation)
@@ -164,7 +166,7 @@ struct Spd {
         for (auto e : sync_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
         for (auto e : inv_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
         inv_ev.clear(); Wm.release(); Wd.release(); chain_flags.release(); for (auto& b : Pb) b.release();
-        Lm.release(); Wt.release(); flow_tasks.release(); flow_qmeta.release(); flow_flags.release(); flow_diag.release(); flow_post.release(); flow_done.release(); flow_trace.release(); flow = FlowPlan();
+        Lm.release(); Wt.release(); flow_tasks.release(); flow_qmeta.release(); flow_flags.release(); flow_args.release(); flow_diag.release(); flow_post.release(); flow_done.release(); flow_trace.release(); flow = FlowPlan();
         flow_tasks_rhs.release(); flow_qmeta_rhs.release(); flow_rhs = FlowPlan(); flow_cur = nullptr;
         flow_tasks_replay.release(); flow_qmeta_replay.release(); flow_replay = FlowPlan();
         levels.clear(); sync_ev.clear();

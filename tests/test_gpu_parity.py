@@ -596,6 +596,36 @@ def test_rccl_communicator_single_rank():
     assert r["snelson"]["rel_loss"] < 1e-10 and r["snelson"]["rel_grad"] < 1e-6 and r["snelson"]["rel_predict"] < 1e-7, r["snelson"]
 
 
+def test_rccl_two_ranks():
+    """RCCL with REAL ranks, the moment the box has them: one process per GPU (up to 8), the library's own communicator over xGMI, the sharded
+    evaluation + prediction (and the data-parallel sparse models) against each rank's own one-GPU result -- at N = 3000 with every model, and at
+    configs[2] size (N = 32768, C = 8, Q = 5; the exact model only).  Skipped on a one-GPU box (the driver's GPU test box is one)."""
+    import json, os, subprocess, sys
+    from mogptk_amd import _lib
+    ngpu = int(_lib.lib().mogp_device_count())
+    if ngpu < 2:
+        pytest.skip("needs two or more GPUs (this box has %d): RCCL between real ranks cannot run here" % ngpu)
+    world = min(ngpu, 8)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra, port):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+                              "--master-port", str(port), os.path.join(root, "tools", "shard_check.py"), "--backend", "nccl"] + extra,
+                             capture_output=True, text=True, timeout=1800, env=dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+    r = run(["--points", "3000"], 29643)
+    assert r["transport"] == "rccl" and r["world"] == world and r["rccl_ranks"] == world, r
+    assert r["rel_loss"] < 1e-10 and r["rel_grad"] < 1e-7 and r["rel_predict"] < 1e-7, r
+    assert r["titsias"]["rel_loss"] < 1e-10 and r["titsias"]["rel_grad"] < 1e-6 and r["titsias"]["rel_predict"] < 1e-7, r["titsias"]
+    assert r["hensman"]["rel_loss"] < 1e-10 and r["hensman"]["rel_grad"] < 1e-6, r["hensman"]
+    assert r["snelson"]["rel_loss"] < 1e-10 and r["snelson"]["rel_grad"] < 1e-6 and r["snelson"]["rel_predict"] < 1e-7, r["snelson"]
+    r = run(["--points", "32768", "--channels", "8", "--q", "5", "--exact-only", "--reps", "1"], 29644)
+    assert r["transport"] == "rccl" and r["world"] == world and r["rccl_ranks"] == world, r
+    assert r["rel_loss"] < 1e-10 and r["rel_grad"] < 1e-7 and r["rel_predict"] < 1e-7, r
+
+
 def test_sgd_adagrad_error_path_and_pegging_on_device():
     """SURVEY 8f-1 remainder on the device: SGD / AdaGrad traces, the per-iteration error= path (a device prediction per iteration)
     and pegged parameters, against the same reference recordings as the CPU suite"""

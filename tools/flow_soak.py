@@ -8,7 +8,11 @@ import bench
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
+replay = len(sys.argv) > 3 and sys.argv[3] == "replay"      # the dataflow kernel ALONE (mogp_model_flow_replay): no chain kernels, no private-stream launches
 m, step, _ = bench.build_model(cfg, 0)
+if replay:
+    step()
+    m._handle.flow_replay(True)
 seen, times = {}, []
 t_all = time.perf_counter()
 for i in range(n):

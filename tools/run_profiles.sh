@@ -21,6 +21,9 @@ for cnt in FETCH_SIZE WRITE_SIZE; do
 done
 (cd $GRAFT_REPO_ROOT; python tools/pmc_flow.py "$(find $O/pmcflow_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find $O/pmcflow_WRITE_SIZE -name '*counter_collection.csv' | head -1)" 8192 $O/pmc_flow_traffic.json > $O/pmc_flow.txt 2>&1)
 (cd $GRAFT_REPO_ROOT; timeout 200 python tools/flow_replay.py 8192 5) > $O/flow_replay.txt 2>&1
+# ... and what its waves do with their cycles (round 6: the counter-backed bound of the headline kernel)
+FLOW_REPLAY_SERIAL=1 timeout -k 5 400 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/pmcflow_mfma -o p -- python $GRAFT_REPO_ROOT/tools/flow_replay.py 8192 3 > $O/pmcflow_mfma.log 2>&1
+FLOW_REPLAY_SERIAL=1 timeout -k 5 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $O/pmcflow_wave -o p -- python $GRAFT_REPO_ROOT/tools/flow_replay.py 8192 3 > $O/pmcflow_wave.log 2>&1
 rm -rf $O/pmcflow_FETCH_SIZE $O/pmcflow_WRITE_SIZE
 for cnt in FETCH_SIZE WRITE_SIZE; do
   MOGP_FLOW=0 timeout -k 5 300 rocprofv3 --pmc $cnt --kernel-trace --output-format csv -d $O/pmc_$cnt -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --sustained 0 --no-cpu-baseline --no-configs --no-shard-probe > $O/pmc_$cnt.log 2>&1
@@ -35,7 +38,7 @@ python - $O <<'PY' > $O/pmc_counters.txt 2>&1
 import csv, glob, collections, sys
 O = sys.argv[1]
 print("# stream schedule (MOGP_FLOW=0: rocprofv3 --pmc serialises dispatches, which the co-operating dataflow / chain kernels cannot run under)")
-for d in ("pmc_valu", "pmc_mfma"):
+for d in ("pmc_valu", "pmc_mfma", "pmcflow_mfma", "pmcflow_wave"):
     for f in glob.glob(O + "/" + d + "/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
@@ -44,6 +47,6 @@ for d in ("pmc_valu", "pmc_mfma"):
         for k, v in sorted(acc.items()):
             print("%-44s launches %5d  " % (k[:44], len(next(iter(v.values())))) + "  ".join("%s=%.4g" % (c, sum(x) / len(x)) for c, x in sorted(v.items())))
 PY
-rm -rf $O/kt_cfg2 $O/kt_cfg3 $O/kt_cfg4 $O/kt_cfg5 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_valu $O/pmc_mfma
+rm -rf $O/kt_cfg2 $O/kt_cfg3 $O/kt_cfg4 $O/kt_cfg5 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_valu $O/pmc_mfma $O/pmcflow_mfma $O/pmcflow_wave
 tail -c 1800 $O/bench_line.json; for c in cfg3 cfg4 cfg5; do python -c "
 import json; d=json.loads(open('$O/b_$c.json').read()); print('$c', round(d['ms_per_step'],2),'ms frac',round(d['roofline']['frac'],3))"; done

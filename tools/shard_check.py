@@ -53,6 +53,10 @@ t_single = (time.perf_counter() - t) / a.reps
 
 comm = mogptk_amd.use_distributed()
 comm.force = True
+rccl_ranks = None
+if a.backend == "nccl":                  # how many ranks a collective issued by the LIBRARY on its own communicator sums over (mogp_comm_selftest)
+    from mogptk_amd import _lib
+    rccl_ranks = int(_lib.comm_selftest(dev)[0])
 l1 = float(m.loss())
 g1 = [p.grad.copy() for p in m.parameters()]
 dist.barrier()
@@ -78,7 +82,7 @@ if a.exact_only:
     dist.all_reduce(errs, op=dist.ReduceOp.MAX)
     if rank == 0:
         print(json.dumps(dict(world=world, backend=a.backend, N=a.points, loss=l0, loss_sharded=l1, rel_loss=float(errs[0]), rel_grad=float(errs[1]),
-                              rel_predict=float(errs[2]), transport=comm.transport, ms_single=1e3 * t_single, ms_sharded=1e3 * t_shard,
+                              rel_predict=float(errs[2]), transport=comm.transport, rccl_ranks=rccl_ranks, ms_single=1e3 * t_single, ms_sharded=1e3 * t_shard,
                               split=os.environ.get("MOGP_SHARD_SPLIT", "1"), factor_once=os.environ.get("MOGP_SHARD_FACTOR_ONCE", "0"))))
     mogptk_amd.shutdown_distributed()
     dist.destroy_process_group()
@@ -168,7 +172,7 @@ per_rank = [None] * world          # every rank's own values: a rank whose ONE-G
 dist.all_gather_object(per_rank, [l0, l1, tl0, tl1, hl0, hl1, nl0, nl1])
 if rank == 0:
     print(json.dumps(dict(world=world, backend=a.backend, N=a.points, loss=l0, loss_sharded=l1, rel_loss=float(errs[0]), rel_grad=float(errs[1]), rel_predict=float(errs[2]),
-                          transport=comm.transport, ms_single=1e3 * t_single, ms_sharded=1e3 * t_shard,
+                          transport=comm.transport, rccl_ranks=rccl_ranks, ms_single=1e3 * t_single, ms_sharded=1e3 * t_shard,
                           titsias=dict(N=a.titsias_points, M=int(mt.Z().shape[0]), loss=tl0, rel_loss=float(errs[3]), rel_grad=float(errs[4]),
                                        rel_predict=float(errs[5]), ms_single=1e3 * tt_single, ms_sharded=1e3 * tt_shard),
                           hensman=dict(N=a.titsias_points, M=int(Mh), likelihood="StudentT", loss=hl0, rel_loss=float(errs[6]), rel_grad=float(errs[7]),
