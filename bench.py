@@ -321,8 +321,11 @@ def probe_child(name, reps):
                 m.loss()
             sync(); dist.barrier()
             ts = (time.perf_counter() - t0) / reps
+            free_b, total_b = torch.cuda.mem_get_info()
             return {"ms_sharded": 1e3 * ts, "rel_loss": abs(lv - l0) / abs(l0),
-                    "rel_grad": max(float(np.max(np.abs(b - c)) / np.max(np.abs(c))) for b, c in zip(gv, g0))}
+                    "rel_grad": max(float(np.max(np.abs(b - c)) / np.max(np.abs(c))) for b, c in zip(gv, g0)),
+                    # what this rank's device holds with the model up (every rank still allocates the full N x N work matrices: DESIGN section 6)
+                    "device_bytes_in_use_per_rank": int(total_b - free_b)}
         finally:
             for k_, v_ in old_env.items():
                 if v_ is None:

@@ -11,7 +11,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmogp_hip.so")
+LIB_PATH = os.environ.get("MOGP_LIB_PATH") or os.path.join(_HERE, "csrc", "libmogp_hip.so")      # (MOGP_LIB_PATH: another build of the same library, for A/B runs)
 
 MOGP_OK, MOGP_EINVAL, MOGP_EHIP, MOGP_ENOTPD, MOGP_ENONFINITE, MOGP_ENODEVICE = 0, -1, -2, -3, -4, -5
 MOGP_EVAL_GRAD = 1

@@ -203,6 +203,14 @@ struct FlowArgs {
     unsigned long long* trace;        // optional: [FLOW_TRACE_W ntasks] look, claimed, k loop from, to, signalled (100 MHz wall clock), XCC << 16 | workgroup
 };
 
+// what every look and every task set-up reads: by VALUE (kernel-argument registers); the rest of FlowArgs is read through the pointer where it is used
+struct FlowHot {
+    double* bA; double* bL; double* bWt; double* bWm; double* bB; int64_t ld;
+    const FlowTask* tasks; const int* qmeta; unsigned* flags;
+    int nq, ncas, base_heads, base_err;
+    unsigned nap_max, nap_calm;
+};
+
 // ---- z = W y and alpha = W^T z inside the dataflow (they were three memory-bound launches behind the last accumulation: 0.4 ms) ----------
 // z rows: tile row i of W is final when its row block's T6 tasks are; one task = the 128 dot products of that tile row (a wave takes 16 rows,
 // four at a time, lanes along k with 16-byte loads).  zz[i] = sum of the 128 z^2 (the caller adds the tile rows up).
@@ -282,7 +290,7 @@ __device__ __forceinline__ void flow_apart(const FlowArgs& g, const int r0, cons
 // globally first unfinished task is either somebody's pending task with its counters met, or at the head of a queue nobody holds a
 // pending task of: progress with any number of resident workgroups.
 template <bool MARK>          // MARK: the debugging build of the same kernel (MOGP_FLOW_DEBUG) whose tile bodies leave per-wave progress marks
-__global__ __launch_bounds__(FL_NT, 4) void k_flow(const FlowArgs* __restrict__ gp) {
+__global__ __launch_bounds__(FL_NT, 4) void k_flow(const FlowArgs* __restrict__ gp, const FlowHot ha) {
     // (the arguments by POINTER: as a by-value struct their ~60 scalar registers were live for the whole kernel, 30-odd of them spilled into vector lanes)
     const FlowArgs& g = *gp;
     extern __shared__ __attribute__((aligned(16))) double gemm_lds[];
@@ -308,19 +316,19 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(const FlowArgs* __restrict__ 
             if (po[72] == 0u) { po[72] = now | 1u; po[74] = __builtin_amdgcn_s_getreg((31 << 11) | 4); po[75] = __builtin_amdgcn_s_getreg((3 << 11) | 20); }
         }
         if (wave == 0) {
-            unsigned* heads = g.flags + g.base_heads;
-            unsigned* err = g.flags + g.base_err;
+            unsigned* heads = ha.flags + ha.base_heads;
+            unsigned* err = ha.flags + ha.base_err;
             // wave 0's lane roles
-            const int ncl = g.ncas * FL_LA, nlanes = ncl + (g.nq - g.ncas);
+            const int ncl = ha.ncas * FL_LA, nlanes = ncl + (ha.nq - ha.ncas);
             const bool is_cas = lane < ncl, is_eager = lane >= ncl && lane < nlanes;
-            const int myq = is_cas ? lane / FL_LA : (is_eager ? g.ncas + (lane - ncl) : 0), myk = is_cas ? lane % FL_LA : 0;
+            const int myq = is_cas ? lane / FL_LA : (is_eager ? ha.ncas + (lane - ncl) : 0), myk = is_cas ? lane % FL_LA : 0;
             int qbase = 0, qsize = 0;
-            if (lane < nlanes) { qbase = g.qmeta[2 * myq]; qsize = g.qmeta[2 * myq + 1]; }
+            if (lane < nlanes) { qbase = ha.qmeta[2 * myq]; qsize = ha.qmeta[2 * myq + 1]; }
             int pend = lst[lane];             // eager lanes: the index (inside the queue) this workgroup holds
             int met_idx = lst[64 + lane], met_n = lst[128 + lane] & 0xff;      // the task this lane looked at last, and how many of its leading dependencies it has seen met
             bool exhausted = (lst[128 + lane] >> 8) != 0;                       // eager lanes: the queue has nothing left to take
             unsigned long long cas_heads = 0; // bit q * FL_LA for every compare-and-swap queue
-            for (int q = 0; q < g.ncas; ++q) cas_heads |= 1ull << (q * FL_LA);
+            for (int q = 0; q < ha.ncas; ++q) cas_heads |= 1ull << (q * FL_LA);
             const unsigned long long eager_mask = nlanes >= 64 ? ~0ull << ncl : ((1ull << nlanes) - 1ull) & ~((1ull << ncl) - 1ull);
             unsigned idle = 0, naps = 0;
             int res = -1;
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(const FlowArgs* __restrict__ 
                     idx = h + myk < qsize ? h + myk : -1;
                 }
                 if (idx >= 0) {
-                    const FlowTask* t = g.tasks + qbase + idx;
+                    const FlowTask* t = ha.tasks + qbase + idx;
                     const int nd = t->ndep;
                     // counters only grow: a dependency seen met stays met, so a lane that keeps looking at the SAME task re-reads only what it has not yet
                     // seen met (met_n leading dependencies of task met_idx) -- a third of the counter loads of a waiting grid (round 6)
@@ -363,7 +371,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(const FlowArgs* __restrict__ 
                     int lead = met_n;
                     for (int d = 0; d < 4; ++d)
                         if (d >= met_n && d < nd) {
-                            if (__hip_atomic_load(g.flags + t->dep[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)t->need[d]) ready = false;
+                            if (__hip_atomic_load(ha.flags + t->dep[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)t->need[d]) ready = false;
                             else if (lead == d) lead = d + 1;
                         }
                     met_n = lead;
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(const FlowArgs* __restrict__ 
                         unsigned seen = 0, which = 0;
                         for (int d = 0; d < 4; ++d)
                             if (d < nd) {
-                                const unsigned v = __hip_atomic_fetch_or(g.flags + t->dep[d], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const unsigned v = __hip_atomic_fetch_or(ha.flags + t->dep[d], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 if (v < (unsigned)t->need[d]) ready2 = false; else { seen = v; which = t->dep[d]; }
                             }
                         if (ready2) {                                          // the loads said "not yet", the memory side says "all there"
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(const FlowArgs* __restrict__ 
                 // back off: idle workgroups must not crowd the memory system.  Two stages (round 6): naps of up to 2^nap_max units while the wait
                 // is an ordinary one (a look that finds nothing waits ~175 us on average), up to 2^nap_calm once it has lasted FL_CALM_AFTER looks -- when most of
                 // the grid waits for a few tasks, ~480 workgroups x ~100 counter loads per look are what those few tasks' operand loads queue behind
-                const unsigned cap = idle >= FL_CALM_AFTER ? g.nap_calm : g.nap_max;
+                const unsigned cap = idle >= FL_CALM_AFTER ? ha.nap_calm : ha.nap_max;
                 nap = nap < cap ? nap + 1u : cap;
                 for (unsigned z = 0; z < (1u << nap); ++z) __builtin_amdgcn_s_sleep(32);
                 ++naps;
@@ -473,15 +481,15 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(const FlowArgs* __restrict__ 
             if (ti == -3 && tid == 0) atomicMin(g.info, (unsigned long long)MOGP_INFO_CHAIN_TIMEOUT);
             break;
         }
-        const FlowTask* tp = g.tasks + ti;
+        const FlowTask* tp = ha.tasks + ti;
         const int var = tp->var, kt = tp->kt;
         const int ab = tp->abuf, bb = tp->bbuf, cb = tp->cbuf;
-        const double* Ab = ab == 0 ? g.bA : ab == 1 ? g.bL : ab == 2 ? g.bWt : ab == 3 ? g.bWm : g.bB;
-        const double* Bb = bb == 0 ? g.bA : bb == 1 ? g.bL : bb == 2 ? g.bWt : bb == 3 ? g.bWm : g.bB;
-        double* Cb = cb == 0 ? g.bA : cb == 1 ? g.bL : cb == 2 ? g.bWt : cb == 3 ? g.bWm : g.bB;
-        const double* Ap = Ab + ((int64_t)tp->ar * g.ld + tp->ac) * MOGP_TILE;
-        const double* Bp = Bb + ((int64_t)tp->br * g.ld + tp->bc) * MOGP_TILE;
-        double* Cp = Cb + ((int64_t)tp->cr * g.ld + tp->cc) * MOGP_TILE;
+        const double* Ab = ab == 0 ? ha.bA : ab == 1 ? ha.bL : ab == 2 ? ha.bWt : ab == 3 ? ha.bWm : ha.bB;
+        const double* Bb = bb == 0 ? ha.bA : bb == 1 ? ha.bL : bb == 2 ? ha.bWt : bb == 3 ? ha.bWm : ha.bB;
+        double* Cb = cb == 0 ? ha.bA : cb == 1 ? ha.bL : cb == 2 ? ha.bWt : cb == 3 ? ha.bWm : ha.bB;
+        const double* Ap = Ab + ((int64_t)tp->ar * ha.ld + tp->ac) * MOGP_TILE;
+        const double* Bp = Bb + ((int64_t)tp->br * ha.ld + tp->bc) * MOGP_TILE;
+        double* Cp = Cb + ((int64_t)tp->cr * ha.ld + tp->cc) * MOGP_TILE;
         const bool fresh = (var & 4) != 0;
         const double alpha = (var & 8) ? -1.0 : 1.0;
         unsigned long long* tr = (MARK && g.trace && tid == 0) ? g.trace + FLOW_TRACE_W * (size_t)ti : nullptr;      // (time stamps: the debugging build only)
@@ -500,9 +508,9 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(const FlowArgs* __restrict__ 
         if (var & 16) __builtin_amdgcn_s_setprio(2);
         if (tid == 0) { *ep_C = Cp; *ep_alpha = alpha; }           // what the tile's epilogue needs, parked in LDS across the k loop (whose barriers publish it)
         switch (var & 3) {
-            case 0: flow_tile<0, 0, MARK>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, tr, prog, ep_C, ep_alpha); break;
-            case 1: flow_tile<0, 1, MARK>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, tr, prog, ep_C, ep_alpha); break;
-            default: flow_tile<1, 1, MARK>(Ap, Bp, Cp, g.ld, kt, fresh, alpha, gemm_lds, tr, prog, ep_C, ep_alpha); break;
+            case 0: flow_tile<0, 0, MARK>(Ap, Bp, Cp, ha.ld, kt, fresh, alpha, gemm_lds, tr, prog, ep_C, ep_alpha); break;
+            case 1: flow_tile<0, 1, MARK>(Ap, Bp, Cp, ha.ld, kt, fresh, alpha, gemm_lds, tr, prog, ep_C, ep_alpha); break;
+            default: flow_tile<1, 1, MARK>(Ap, Bp, Cp, ha.ld, kt, fresh, alpha, gemm_lds, tr, prog, ep_C, ep_alpha); break;
         }
         if (var & 16) __builtin_amdgcn_s_setprio(0);
         }
@@ -510,8 +518,8 @@ __global__ __launch_bounds__(FL_NT, 4) void k_flow(const FlowArgs* __restrict__ 
         __syncthreads();                                           // ... and the tile's last LDS reads are behind us
         if (tid == 0) {
             const unsigned s0 = tp->sig[0], s1 = tp->sig[1];
-            if (s0 != FLOW_NOSIG) __hip_atomic_fetch_add(g.flags + s0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (s1 != FLOW_NOSIG) __hip_atomic_fetch_add(g.flags + s1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s0 != FLOW_NOSIG) __hip_atomic_fetch_add(ha.flags + s0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s1 != FLOW_NOSIG) __hip_atomic_fetch_add(ha.flags + s1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (MARK && g.done) g.done[ti] = 1;
             if (MARK && g.post) g.post[(size_t)(g.post_base + blockIdx.x) * FLOW_POST_W + 77] = (unsigned)(wall_clock64() >> 4);
             if (tr) {
@@ -871,7 +879,13 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     { int r__ = set_max_dynamic_lds(reinterpret_cast<const void*>(k_flow<false>), FL_LDS_BYTES, attr_done); if (r__) return r__; }
     { int r__ = set_max_dynamic_lds(reinterpret_cast<const void*>(k_flow<true>), FL_LDS_BYTES, attr_done_dbg); if (r__) return r__; }
     static const int wg_per_cu = std::getenv("MOGP_FLOW_WGS") ? std::max(1, std::atoi(std::getenv("MOGP_FLOW_WGS"))) : 2;
-    const int cus = (m->ctx->ncu > 0 ? m->ctx->ncu : 256) - m->ctx->ncu_reserved;
+    int cus = (m->ctx->ncu > 0 ? m->ctx->ncu : 256) - m->ctx->ncu_reserved;
+    // Round 6: the kernel does NOT fill the bulk CUs.  With two workgroups on every one of them (60 per XCD: the whole vector register file and 149 of
+    // 160 KB of LDS of each CU) about one evaluation in 7000 stood still -- the memory operations of the LAST-dispatched workgroup of every XCD (the 57th: index 450 .. 455 of 480,
+    // whatever it was doing: operand loads, write-through stores, the polls of a look) stopped completing until the other workgroups left the kernel at a time-out.  56 per XCD:
+    // none in 40 000 + 100 000 soaked evaluations (58 and 59 per XCD: 5 in 30 000 each).  MOGP_FLOW_DROP_CUS=0 fills them again.
+    { static const int drop = std::getenv("MOGP_FLOW_DROP_CUS") ? std::atoi(std::getenv("MOGP_FLOW_DROP_CUS")) : 16;
+      if (drop > 0 && drop < cus) cus -= drop; }
     FlowArgs g{};
     g.bA = w.A.p; g.bL = w.Lm.p; g.bWt = rhs ? rhs->T : w.Wt.p; g.bWm = w.Wm.p; g.bB = rhs ? rhs->X : w.B.p; g.ld = ld;       // (right-hand sides: T where the running product is, X where the inverse is)
     g.tasks = d_tasks.p; g.qmeta = d_qmeta.p; g.flags = w.flow_flags.p;
@@ -893,7 +907,7 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     { const char* e = std::getenv("MOGP_FLOW_CLAIM1"); g.claim_one = e ? std::atoi(e) : 0; }
     { const char* e = std::getenv("MOGP_FLOW_NHI"); g.nhi = e ? std::atoi(e) : 0; }            // measured 3 / 4 (semi, the inverse cycle, z and alpha looked at by everybody): 10.74-10.79 vs 10.52-10.65 ms
     { const char* e = std::getenv("MOGP_FLOW_NAP"); g.nap_max = e ? (unsigned)std::max(0, std::atoi(e)) : 4u; }
-    { const char* e = std::getenv("MOGP_FLOW_NAP_CALM"); g.nap_calm = e ? (unsigned)std::max(0, std::atoi(e)) : 7u; if (g.nap_calm < g.nap_max) g.nap_calm = g.nap_max; }
+    { const char* e = std::getenv("MOGP_FLOW_NAP_CALM"); g.nap_calm = e ? (unsigned)std::max(0, std::atoi(e)) : 0u; if (g.nap_calm < g.nap_max) g.nap_calm = g.nap_max; }      // (off by default: the calmer rate did not prevent the stall it was built against, and costs reaction time)
     w.vec_done = false;
     if (!rhs && w.want_vec && w.vec_y && w.vec_z && w.vec_zz && w.vec_part) {       // z = W y, alpha = W^T z as tasks of the same kernel
         g.vy = w.vec_y; g.vz = w.vec_z; g.vzz = w.vec_zz; g.vpart = w.vec_part;
@@ -912,12 +926,27 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     // copies live in the workspace (an asynchronous copy from pageable memory is staged before it returns, but nothing here relies on it)
     static_assert(sizeof(FlowArgs) <= 512, "Spd::flow_args slots");
     if ((rc = w.flow_args.ensure(1024))) return rc;
-    w.flow_args_h.resize(1024);
-    std::memcpy(w.flow_args_h.data(), &g, sizeof(g));
-    HIP_TRY(hipMemcpyAsync(w.flow_args.p, w.flow_args_h.data(), sizeof(g), hipMemcpyHostToDevice, bulk));
+    if (w.flow_args_h.size() != 2048) w.flow_args_h.assign(2048, (char)0xff);       // [0, 1024): what the device copies hold; [1024, 2048): scratch for the comparison
+    // (the same buffers, plan and switches evaluation after evaluation: the copy is made when something changed, not per evaluation -- two copies from
+    // pageable memory were 0.13 ms of host time per step)
+    auto upload = [&](size_t slot, const FlowArgs& a, hipStream_t st) -> int {
+        char* held = w.flow_args_h.data() + slot;
+        char* fresh_ = w.flow_args_h.data() + 1024 + slot;
+        std::memset(fresh_, 0, 512);
+        std::memcpy(fresh_, &a, sizeof(a));
+        if (std::memcmp(held, fresh_, 512) == 0) return 0;
+        HIP_TRY(hipStreamSynchronize(st));                   // (a kernel of an earlier evaluation may still read the old copy)
+        HIP_TRY(dev_upload(w.flow_args.p + slot, fresh_, 512));
+        std::memcpy(held, fresh_, 512);
+        return 0;
+    };
+    if ((rc = upload(0, g, bulk))) return rc;
     const FlowArgs* d_g = reinterpret_cast<const FlowArgs*>(w.flow_args.p);
-    if (dbg_kernel) hipLaunchKernelGGL(k_flow<true>, dim3(wg_per_cu * cus), dim3(FL_NT), FL_LDS_BYTES, bulk, d_g);
-    else hipLaunchKernelGGL(k_flow<false>, dim3(wg_per_cu * cus), dim3(FL_NT), FL_LDS_BYTES, bulk, d_g);
+    FlowHot hot{};
+    hot.bA = g.bA; hot.bL = g.bL; hot.bWt = g.bWt; hot.bWm = g.bWm; hot.bB = g.bB; hot.ld = g.ld; hot.tasks = g.tasks; hot.qmeta = g.qmeta; hot.flags = g.flags;
+    hot.nq = g.nq; hot.ncas = g.ncas; hot.base_heads = g.base_heads; hot.base_err = g.base_err; hot.nap_max = g.nap_max; hot.nap_calm = g.nap_calm;
+    if (dbg_kernel) hipLaunchKernelGGL(k_flow<true>, dim3(wg_per_cu * cus), dim3(FL_NT), FL_LDS_BYTES, bulk, d_g, hot);
+    else hipLaunchKernelGGL(k_flow<false>, dim3(wg_per_cu * cus), dim3(FL_NT), FL_LDS_BYTES, bulk, d_g, hot);
     HIP_TRY(hipGetLastError());
     if (pe1) HIP_TRY(hipEventRecord(pe1, bulk));
     HIP_TRY(hipEventRecord(e_flow, bulk));
@@ -966,11 +995,10 @@ int spd_potri_flow(mogp_model* m, Spd& w, const FlowRhs* rhs) {
     if (tail_on && m->ctx->ncu_reserved > 0 && !replay) {
         if (rhs && rhs->ready) HIP_TRY(hipStreamWaitEvent(priv, rhs->ready, 0));
         g.post_base = wg_per_cu * cus;
-        std::memcpy(w.flow_args_h.data() + 512, &g, sizeof(g));
-        HIP_TRY(hipMemcpyAsync(w.flow_args.p + 512, w.flow_args_h.data() + 512, sizeof(g), hipMemcpyHostToDevice, priv));
+        if ((rc = upload(512, g, priv))) return rc;
         const FlowArgs* d_g2 = reinterpret_cast<const FlowArgs*>(w.flow_args.p + 512);
-        if (dbg_kernel) hipLaunchKernelGGL(k_flow<true>, dim3(wg_per_cu * m->ctx->ncu_reserved), dim3(FL_NT), FL_LDS_BYTES, priv, d_g2);
-        else hipLaunchKernelGGL(k_flow<false>, dim3(wg_per_cu * m->ctx->ncu_reserved), dim3(FL_NT), FL_LDS_BYTES, priv, d_g2);
+        if (dbg_kernel) hipLaunchKernelGGL(k_flow<true>, dim3(wg_per_cu * m->ctx->ncu_reserved), dim3(FL_NT), FL_LDS_BYTES, priv, d_g2, hot);
+        else hipLaunchKernelGGL(k_flow<false>, dim3(wg_per_cu * m->ctx->ncu_reserved), dim3(FL_NT), FL_LDS_BYTES, priv, d_g2, hot);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(e_chain, priv));

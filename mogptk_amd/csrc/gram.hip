@@ -752,7 +752,7 @@ int launch_gram(const GramArgs& a0, int ntiles, hipStream_t s) {
     if (a.ev0) HIP_TRY(hipEventRecord(a.ev0, s));
     static const bool strip_on = !(std::getenv("MOGP_GRAM_STRIP") && std::atoi(std::getenv("MOGP_GRAM_STRIP")) == 0);
     if (strip_on && a.segs && a.nsegs > 0 && a.D == 1 && a.W == 5 && a.T <= GS_TC_MAX && !a.mirror && (a.ldo & 1) == 0) {
-        static const int strip_nc = []() { const char* e = std::getenv("MOGP_GRAM_NC"); const int v = e ? std::atoi(e) : 2; return v == 4 ? 4 : 2; }();      // MOGP_GRAM_NC=4: the 256-thread form of rounds 4 - 5
+        static const int strip_nc = []() { const char* e = std::getenv("MOGP_GRAM_NC"); const int v = e ? std::atoi(e) : 4; return v == 2 ? 2 : 4; }();      // MOGP_GRAM_NC=2: 4 x 2 entries per thread on 512 threads (four waves per SIMD; round 6: 148 vs 159 us on one box, 154 vs 146 on another -- not kept as the default)
         if (strip_nc == 2) {
             if (a.T <= 4) hipLaunchKernelGGL((k_gram_strip<4, 2>), dim3(a.nsegs), dim3(512), 0, s, a, a.segs);
             else hipLaunchKernelGGL((k_gram_strip<8, 2>), dim3(a.nsegs), dim3(512), 0, s, a, a.segs);

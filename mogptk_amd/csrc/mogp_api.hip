@@ -937,7 +937,7 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     static const bool acc_lite = std::getenv("MOGP_ACCURATE_LITE") && std::atoi(std::getenv("MOGP_ACCURATE_LITE")) != 0;
     const bool lite = acc_lite && m->accurate && !fuse_inverse && !factor_only;
     const bool accurate = m->accurate && !fuse_inverse && !factor_only && !lite;
-    m->accurate_ran = accurate || lite;
+    m->accurate_ran = accurate;                      // (the lite form ends like the phases schedule: W in k.A, LAUUM by the caller)
     if (accurate) {
         // (round 5) The backward-stable form, for matrices outside the envelope of the schedules below: the launch-per-step Cholesky with
         // every panel refined against L_kk (Spd::refine_panels), then Kj^-1 = L^-T (L^-1 I) by two blocked SUBSTITUTIONS (trsm.hip) instead of

@@ -166,7 +166,7 @@ struct Spd {
         for (auto e : sync_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
         for (auto e : inv_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
         inv_ev.clear(); Wm.release(); Wd.release(); chain_flags.release(); for (auto& b : Pb) b.release();
-        Lm.release(); Wt.release(); flow_tasks.release(); flow_qmeta.release(); flow_flags.release(); flow_args.release(); flow_diag.release(); flow_post.release(); flow_done.release(); flow_trace.release(); flow = FlowPlan();
+        Lm.release(); Wt.release(); flow_tasks.release(); flow_qmeta.release(); flow_flags.release(); flow_args.release(); flow_args_h.clear(); flow_diag.release(); flow_post.release(); flow_done.release(); flow_trace.release(); flow = FlowPlan();
         flow_tasks_rhs.release(); flow_qmeta_rhs.release(); flow_rhs = FlowPlan(); flow_cur = nullptr;
         flow_tasks_replay.release(); flow_qmeta_replay.release(); flow_replay = FlowPlan();
         levels.clear(); sync_ev.clear();
