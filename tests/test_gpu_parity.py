@@ -1238,10 +1238,10 @@ def test_exact_path_conditioning_envelope():
         warnings.simplefilter("always")
         m2 = model(0.2)
         m2.loss()
-    assert not [x for x in w if "ill-conditioned" in str(x.message)] and m2._handle.condition_estimate() < 1e4 and not getattr(m2, "_accurate", False)
+    assert not [x for x in w if "ill-conditioned" in str(x.message)] and m2._handle.condition_estimate() < 1e4 and not getattr(m2._handle, "accurate_mode", False)
     m.likelihood.scale.assign(0.2)
     m.loss()
-    assert not m._accurate
+    assert not m._handle.accurate_mode
     l_fast = float(m.loss())
     assert abs(l_fast - float(m2.loss())) <= 1e-12 * abs(l_fast)
 

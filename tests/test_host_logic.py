@@ -1244,20 +1244,20 @@ def test_ill_conditioned_models_warn_once_and_switch_to_the_backward_stable_form
             warnings.simplefilter("always")
             Reporting.estimate = 5e3
             l0 = m.loss()
-            assert not w and m._handle.evals == [False] and not getattr(m, "_accurate", False)
+            assert not w and m._handle.evals == [False] and not getattr(m._handle, "accurate_mode", False)
             Reporting.estimate = 3e6                       # the factor's diagonal says: ill-conditioned
             l1 = m.loss()
             assert len(w) == 1 and issubclass(w[0].category, RuntimeWarning) and "ill-conditioned" in str(w[0].message)
-            assert m._accurate and m._handle.evals == [False, False, True]            # the evaluation was repeated in the other form
+            assert m._handle.accurate_mode and m._handle.evals == [False, False, True]            # the evaluation was repeated in the other form
             m.loss()
             assert len(w) == 1 and m._handle.evals[-1] is True and len(m._handle.evals) == 4      # stays there, says it once
             m.log_marginal_likelihood()                   # (the LML alone does not take part)
             Reporting.estimate = 5e4                       # better, but not by the factor of ten that switches back
             m.loss()
-            assert m._accurate
+            assert m._handle.accurate_mode
             Reporting.estimate = 5e3
             m.loss()
-            assert not m._accurate and m._handle.accurate is False
+            assert not m._handle.accurate_mode and m._handle.accurate is False
             n = len(m._handle.evals)
             m.loss()
             assert m._handle.evals[n:] == [False]
@@ -1273,7 +1273,7 @@ def test_ill_conditioned_models_warn_once_and_switch_to_the_backward_stable_form
                 Reporting.estimate = 3e6
                 mu1, _ = m3.predict_f(X[:5])
                 mu2, _ = m3.predict_f(X[:5])
-            assert len(w) == 1 and m3._accurate and calls == [False, True, True] and np.array_equal(mu1, mu2)
+            assert len(w) == 1 and m3._handle.accurate_mode and calls == [False, True, True] and np.array_equal(mu1, mu2)
         finally:
             Reporting.predict = orig
         # the switch that only warns
@@ -1283,7 +1283,7 @@ def test_ill_conditioned_models_warn_once_and_switch_to_the_backward_stable_form
             warnings.simplefilter("always")
             Reporting.estimate = 3e6
             m2.loss(); m2.loss()
-        assert len(w) == 1 and not getattr(m2, "_accurate", False) and m2._handle.evals == [False, False]
+        assert len(w) == 1 and not getattr(m2._handle, "accurate_mode", False) and m2._handle.evals == [False, False]
     finally:
         gpr.config.accurate_fallback = True
         L.ExactHandle = old
