@@ -709,7 +709,7 @@ def main():
         mom_gbs = gram_bytes * nprof / (stage[_lib.ST_MOMENT_KERNEL] * 1e-3) / 1e9 if stage[_lib.ST_MOMENT_KERNEL] > 0 else None
         traffic, traffic_src, traffic_eval = None, None, None
         sched = h.schedule() if (kind in ("exact", "predict") and not sharded_mode and hasattr(h, "schedule")) else None
-        for tf in ("r5_pmc_traffic_stream_schedule.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"):     # L2<->fabric bytes per k_gemm launch from the committed rocprofv3 --pmc passes of this command
+        for tf in ("r6_pmc_traffic_stream_schedule.json", "r5_pmc_traffic_stream_schedule.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"):     # L2<->fabric bytes per k_gemm launch from the committed rocprofv3 --pmc passes of this command
             try:
                 with open(os.path.join(ROOT, "profiles", tf)) as f:
                     t = json.load(f)
@@ -764,7 +764,7 @@ def main():
             # the stream schedule's launches of the same products stay beside it.
             stream = {"bytes_per_eval": traffic_eval, "bytes_per_launch": traffic, "source": traffic_src} if traffic is not None else None
             flow_t = None
-            for tf in ("r5_pmc_traffic.json",):
+            for tf in ("r6_pmc_traffic.json", "r5_pmc_traffic.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", tf)) as f:
                         flow_t = json.load(f)

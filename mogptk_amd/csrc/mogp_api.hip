@@ -932,12 +932,11 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
     m->flow_ran = false;                              // ... and chain_fallback decides from THIS evaluation which schedule to drop, not from an earlier one
     m->k.want_vec = fuse_inverse && !factor_only;     // the dataflow schedule (flow.hip) also forms z = W y and alpha = W^T z
     m->k.vec_y = m->d_y.p; m->k.vec_z = m->d_z.p; m->k.vec_zz = m->d_zz.p; m->k.vec_part = m->d_alpha.p + Npad;
-    // MOGP_ACCURATE_LITE=1 (experiment, round 6): the accurate mode keeps the REFINED factorisation but forms W = L^-1 and Kj^-1 = W^T W with the phases
-    // schedule's products (TRTRI levels, LAUUM) instead of two blocked substitutions -- which of the two halves the envelope of the fast schedules needs
-    static const bool acc_lite = std::getenv("MOGP_ACCURATE_LITE") && std::atoi(std::getenv("MOGP_ACCURATE_LITE")) != 0;
-    const bool lite = acc_lite && m->accurate && !fuse_inverse && !factor_only;
-    const bool accurate = m->accurate && !fuse_inverse && !factor_only && !lite;
-    m->accurate_ran = accurate;                      // (the lite form ends like the phases schedule: W in k.A, LAUUM by the caller)
+    // (round 6, measured and dropped -- profiles/r6_exact_illcond.txt: the refined factorisation followed by the phases schedule's TRTRI / LAUUM products instead of
+    // the two substitutions repairs the LML (2e-10 at cond 7e7) but NOT the gradient (2.8e-4, the fast schedules' 2.0e-4; the substitutions: 5.9e-6): it is the
+    // inverse formed through explicit block inverses that costs the gradient its digits, so Kj^-1 stays with trsm.hip here)
+    const bool accurate = m->accurate && !fuse_inverse && !factor_only;
+    m->accurate_ran = accurate;
     if (accurate) {
         // (round 5) The backward-stable form, for matrices outside the envelope of the schedules below: the launch-per-step Cholesky with
         // every panel refined against L_kk (Spd::refine_panels), then Kj^-1 = L^-T (L^-1 I) by two blocked SUBSTITUTIONS (trsm.hip) instead of
@@ -950,29 +949,42 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
         m->k.tail_ready = nullptr;
         if (rc) return rc;
         if ((rc = mark(m, 2))) return rc;
-        if (want_inverse) {          // (an LML-only evaluation needs L, z and the log-determinant: not the N^2 fill and the two N^3 solves nothing would read)
-        HIP_TRY(hipMemsetAsync(m->k.B.p, 0, (size_t)Npad * Npad * sizeof(double), m->st));
-        if ((rc = launch_add_diag(m->k.B.p, Npad, Npad, 1.0, m->st))) return rc;
-        if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->k.B.p, Npad, Npad, false, nullptr, true))) return rc;      // lower block triangle only (trsm.hip: tri)
-        if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->k.B.p, Npad, Npad, true, nullptr, true))) return rc;
+        // Round 6: (i) the two vector solves (128 dependent leaf + update steps, ~10 ms at N = 8192, latency-bound) run on a side stream UNDERNEATH the
+        // matrix solve; (ii) Kj^-1 = W^T W with W = L^-1 from ONE substitution (every column a backward-stable solve) and one LAUUM-mode product at the
+        // matrix cores' rate, instead of a second substitution L^-T W at the solves' rate.  42.7 -> see profiles/r6_exact_illcond.txt.
+        hipStream_t vs = (want_inverse && m->st3) ? m->st3 : m->st;
+        if (vs != m->st) {
+            while ((int)m->k.inv_ev.size() < 4) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m->k.inv_ev.push_back(e); }
+            HIP_TRY(hipEventRecord(m->k.inv_ev[0], m->st));                  // the factor is complete
+            HIP_TRY(hipStreamWaitEvent(vs, m->k.inv_ev[0], 0));
+        }
+        if ((rc = m->acc_rhs.ensure((size_t)Npad * MOGP_TILE))) return rc;
+        HIP_TRY(hipMemsetAsync(m->acc_rhs.p, 0, (size_t)Npad * MOGP_TILE * sizeof(double), vs));
+        if ((rc = launch_copy2d(m->acc_rhs.p, MOGP_TILE, m->d_y.p, 1, Npad, 1, 1.0, vs))) return rc;
+        if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->acc_rhs.p, MOGP_TILE, MOGP_TILE, false, vs))) return rc;
+        if ((rc = launch_copy2d(m->d_z.p, 1, m->acc_rhs.p, MOGP_TILE, Npad, 1, 1.0, vs))) return rc;
+        HIP_TRY(hipMemsetAsync(m->d_zz.p, 0, (size_t)((Npad + 3) / 4) * sizeof(double), vs));
+        if ((rc = launch_gemv_rows(m->d_z.p, Npad, 1, Npad, m->d_z.p, m->d_zz.p, vs))) return rc;       // z^T z into the first part
+        if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->acc_rhs.p, MOGP_TILE, MOGP_TILE, true, vs))) return rc;
+        if ((rc = launch_copy2d(m->d_alpha.p, 1, m->acc_rhs.p, MOGP_TILE, Npad, 1, 1.0, vs))) return rc;
+        if (want_inverse) {          // (an LML-only evaluation needs L, z and the log-determinant: not the N^2 fill and the N^3 solve nothing would read)
+            if ((rc = m->k.Wm.ensure((size_t)Npad * Npad))) return rc;
+            HIP_TRY(hipMemsetAsync(m->k.Wm.p, 0, (size_t)Npad * Npad * sizeof(double), m->st));      // (above its block diagonal W stays zero: flow.hip relies on it)
+            if ((rc = launch_add_diag(m->k.Wm.p, Npad, Npad, 1.0, m->st))) return rc;
+            if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->k.Wm.p, Npad, Npad, false, nullptr, true))) return rc;      // W = L^-1 I, lower block triangle only (trsm.hip: tri)
+            GemmArgs g{};
+            g.A = m->k.Wm.p; g.lda = Npad; g.a_kmajor = 1; g.B = m->k.Wm.p; g.ldb = Npad; g.b_kmajor = 1;
+            g.C = m->k.B.p; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0; g.mode = GM_LAUUM; g.mt = g.nt = m->nb; g.K = (int)Npad;
+            if ((rc = gemm_call(m, g, gemm_flops(g, nullptr)))) return rc;
+        }
+        if (vs != m->st) {
+            HIP_TRY(hipEventRecord(m->k.inv_ev[1], vs));
+            HIP_TRY(hipStreamWaitEvent(m->st, m->k.inv_ev[1], 0));
         }
         if ((rc = mark(m, 3))) return rc;
-        if ((rc = m->acc_rhs.ensure((size_t)Npad * MOGP_TILE))) return rc;
-        HIP_TRY(hipMemsetAsync(m->acc_rhs.p, 0, (size_t)Npad * MOGP_TILE * sizeof(double), m->st));
-        if ((rc = launch_copy2d(m->acc_rhs.p, MOGP_TILE, m->d_y.p, 1, Npad, 1, 1.0, m->st))) return rc;
-        if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->acc_rhs.p, MOGP_TILE, MOGP_TILE, false))) return rc;
-        if ((rc = launch_copy2d(m->d_z.p, 1, m->acc_rhs.p, MOGP_TILE, Npad, 1, 1.0, m->st))) return rc;
-        HIP_TRY(hipMemsetAsync(m->d_zz.p, 0, (size_t)((Npad + 3) / 4) * sizeof(double), m->st));
-        if ((rc = launch_gemv_rows(m->d_z.p, Npad, 1, Npad, m->d_z.p, m->d_zz.p, m->st))) return rc;       // z^T z into the first part
-        if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->acc_rhs.p, MOGP_TILE, MOGP_TILE, true))) return rc;
-        if ((rc = launch_copy2d(m->d_alpha.p, 1, m->acc_rhs.p, MOGP_TILE, Npad, 1, 1.0, m->st))) return rc;
     } else {
     if (factor_only && !fuse_inverse && m->rhs_job && flow_enabled(m, m->k)) rc = spd_potri_flow(m, m->k, m->rhs_job);      // the prediction: factor + substitute as dataflow
-    else {
-        if (lite) { m->k.keep_L = true; m->k.refine_panels = true; }
-        rc = fuse_inverse ? spd_potri_fused(m, m->k) : spd_potrf(m, m->k);
-        if (lite) { m->k.keep_L = false; m->k.refine_panels = false; }
-    }
+    else rc = fuse_inverse ? spd_potri_fused(m, m->k) : spd_potrf(m, m->k);
     m->k.want_vec = false; m->k.tail_ready = nullptr;
     if (rc) return rc;
     if ((rc = mark(m, 2))) return rc;
