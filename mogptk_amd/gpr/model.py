@@ -301,7 +301,7 @@ class Exact(Model):
     def _check_conditioning(self, h, redo):
         """The reference's torch.linalg.cholesky is backward stable and silent; the fast schedules of this path form their panels with explicit block
         inverses and lose accuracy as K + noise becomes ill-conditioned.  The factor's own diagonal says when: the model then says so
-        (once), repeats the evaluation in the backward-stable form (mogp_model_set_accurate; 43 ms against 10 at N = 8192) and stays there until the matrix is
+        (once), repeats the evaluation in the backward-stable form (mogp_model_set_accurate; 25 ms against 10 at N = 8192) and stays there until the matrix is
         well-conditioned again.  `config.accurate_fallback = False` keeps the fast form and only warns."""
         if not hasattr(h, "condition_estimate"):
             return None
@@ -316,7 +316,7 @@ class Exact(Model):
                 import warnings
                 warnings.warn("the kernel matrix plus noise is ill-conditioned (cond >= %.1e from the Cholesky factor's diagonal): beyond ~1e6 - 1e7 the "
                               "fast schedules' LML and gradients leave a backward-stable factorisation's by more than 1e-9 / 1e-5 (at 1e8: ~1e-7 / ~1e-4); %s"
-                              % (est, "evaluating in the backward-stable form from here on (about four times slower)" if fallback
+                              % (est, "evaluating in the backward-stable form from here on (about two and a half times slower)" if fallback
                                  else "a larger noise variance or jitter brings it back"), RuntimeWarning, stacklevel=5)
             if fallback:
                 h.set_accurate(True)
