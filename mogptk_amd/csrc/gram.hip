@@ -40,6 +40,11 @@ __device__ __forceinline__ double frac_turn(double p) { return p - rint(p); }
 #define GT_SKIP (-1)     // term negligible in this tile
 #define GT_GENERAL 0     // exp per entry
 #define GT_SKIP_EXPONENT 50.0
+// Taylor degree of the cross term exp(V p q) from max |V p q| over the tile: the smallest N with zmax^(N+1) / (N+1)! <= 2e-17 (round 6: every degree from 4 to 12 instead
+// of 4 / 6 / 8 / 11 / 14 -- at configs[1] (zmax 0.012 .. 0.12) an entry's polynomial is 1 - 2 terms shorter)
+#define GT_DEGREE(zmax) ((zmax) <= 1.19e-3 ? 4 : (zmax) <= 4.93e-3 ? 5 : (zmax) <= 0.0139 ? 6 : (zmax) <= 0.0308 ? 7 : (zmax) <= 0.0578 ? 8 : (zmax) <= 0.0968 ? 9 : \
+                         (zmax) <= 0.149 ? 10 : (zmax) <= 0.2147 ? 11 : (zmax) <= 0.294 ? 12 : 14)
+#define GT_DEGREE_CASES(X) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(14)
 
 // e^x for |x| < 700: Cody-Waite reduction, degree-13 Taylor on |r| <= ln2 / 2 (truncation 4e-18), ldexp
 __device__ __forceinline__ double fast_exp(double x) {
@@ -244,7 +249,7 @@ __device__ __forceinline__ void stage_item_compute(TileLds<DM>& L, const StageIt
     int deg;
     if ((AMP && A == 0.0) || 0.5 * emin > GT_SKIP_EXPONENT) deg = GT_SKIP;
     else if (!(zmax <= 0.45) || !(0.5 * es < 600.0) || !(0.5 * efac < 600.0)) deg = GT_GENERAL;
-    else deg = zmax <= 1.19e-3 ? 4 : (zmax <= 0.0139 ? 6 : (zmax <= 0.0578 ? 8 : (zmax <= 0.2147 ? 11 : 14)));
+    else deg = GT_DEGREE(zmax);
     if (pnt == 0 && which == 0) {
         L.deg[t] = deg; L.A[t] = A;
         for (int d = 0; d < D; ++d) {
@@ -489,11 +494,9 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs a, int ntiles) {
                     cw[m] = L.cw[t][cg * 4 + m]; sw[m] = L.sw[t][cg * 4 + m];
                 }
                 switch (deg) {
-                    case 4: gram_term<DM, 4>(acc, pc, qc, L, t, D, cu, su, cw, sw); break;
-                    case 6: gram_term<DM, 6>(acc, pc, qc, L, t, D, cu, su, cw, sw); break;
-                    case 8: gram_term<DM, 8>(acc, pc, qc, L, t, D, cu, su, cw, sw); break;
-                    case 11: gram_term<DM, 11>(acc, pc, qc, L, t, D, cu, su, cw, sw); break;
-                    case 14: gram_term<DM, 14>(acc, pc, qc, L, t, D, cu, su, cw, sw); break;
+                    #define GT_CASE(N) case N: gram_term<DM, N>(acc, pc, qc, L, t, D, cu, su, cw, sw); break;
+                    GT_DEGREE_CASES(GT_CASE)
+#undef GT_CASE
                     default: gram_term<DM, 0>(acc, pc, qc, L, t, D, cu, su, cw, sw); break;
                 }
             }
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(64 * (MOGP_GT / NC) / 4, NC == 2 ? 4 : 2) void k_gr
             int deg;
             if (A == 0.0 || 0.5 * emin > GT_SKIP_EXPONENT) deg = GT_SKIP;
             else if (!(zmax <= 0.45) || !(0.5 * es < 600.0) || !(0.5 * efac < 600.0)) deg = GT_GENERAL;
-            else deg = zmax <= 1.19e-3 ? 4 : (zmax <= 0.0139 ? 6 : (zmax <= 0.0578 ? 8 : (zmax <= 0.2147 ? 11 : 14)));
+            else deg = GT_DEGREE(zmax);
             if (pnt == 0 && which == 0) { L.deg[t] = deg; L.V[t] = V; L.s[t] = s; }
             if (deg == GT_SKIP) continue;
             double f = 1.0;
@@ -667,11 +670,9 @@ __global__ __launch_bounds__(64 * (MOGP_GT / NC) / 4, NC == 2 ? 4 : 2) void k_gr
 #pragma unroll
             for (int n = 0; n < NC; ++n) { cw[n] = L.cw[t][SL::cs(cg * NC + n)]; sw[n] = L.sw[t][SL::cs(cg * NC + n)]; }
             switch (deg) {
-                case 4: strip_term<4, NC>(acc, p, q, V, s, cu, su, cw, sw); break;
-                case 6: strip_term<6, NC>(acc, p, q, V, s, cu, su, cw, sw); break;
-                case 8: strip_term<8, NC>(acc, p, q, V, s, cu, su, cw, sw); break;
-                case 11: strip_term<11, NC>(acc, p, q, V, s, cu, su, cw, sw); break;
-                case 14: strip_term<14, NC>(acc, p, q, V, s, cu, su, cw, sw); break;
+                #define GT_CASE(N) case N: strip_term<N, NC>(acc, p, q, V, s, cu, su, cw, sw); break;
+                GT_DEGREE_CASES(GT_CASE)
+#undef GT_CASE
                 default: strip_term<0, NC>(acc, p, q, V, s, cu, su, cw, sw); break;
             }
         }
@@ -946,11 +947,9 @@ __global__ __launch_bounds__(256, (DT == 1 ? 2 : 1)) void k_moments(MomentArgs a
                 cw[m] = L.cw[t][cg * 4 + m]; sw[m] = L.sw[t][cg * 4 + m];
             }
             switch (deg) {
-                case 4: moment_term<DM, 4, ZG, ENV>(mom, g, p, q, L, t, D, cu, su, cw, sw, zr, zc); break;
-                case 6: moment_term<DM, 6, ZG, ENV>(mom, g, p, q, L, t, D, cu, su, cw, sw, zr, zc); break;
-                case 8: moment_term<DM, 8, ZG, ENV>(mom, g, p, q, L, t, D, cu, su, cw, sw, zr, zc); break;
-                case 11: moment_term<DM, 11, ZG, ENV>(mom, g, p, q, L, t, D, cu, su, cw, sw, zr, zc); break;
-                case 14: moment_term<DM, 14, ZG, ENV>(mom, g, p, q, L, t, D, cu, su, cw, sw, zr, zc); break;
+                #define GT_CASE(N) case N: moment_term<DM, N, ZG, ENV>(mom, g, p, q, L, t, D, cu, su, cw, sw, zr, zc); break;
+                GT_DEGREE_CASES(GT_CASE)
+#undef GT_CASE
                 default: moment_term<DM, 0, ZG, ENV>(mom, g, p, q, L, t, D, cu, su, cw, sw, zr, zc); break;
             }
             // workgroup reduction of the W moments of this term through LDS, fixed order: thread (w, i) adds the values of threads
@@ -1155,11 +1154,9 @@ __global__ __launch_bounds__(512, 2) void k_moments_x(MomentArgs a) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) { cw[n] = L.cw[t][4 * cg + n]; sw[n] = L.sw[t][4 * cg + n]; }
             switch (deg) {
-                case 4: mx_term<4>(mom[t], g, p, q, V, sft, cu, su, cw, sw); break;
-                case 6: mx_term<6>(mom[t], g, p, q, V, sft, cu, su, cw, sw); break;
-                case 8: mx_term<8>(mom[t], g, p, q, V, sft, cu, su, cw, sw); break;
-                case 11: mx_term<11>(mom[t], g, p, q, V, sft, cu, su, cw, sw); break;
-                case 14: mx_term<14>(mom[t], g, p, q, V, sft, cu, su, cw, sw); break;
+                #define GT_CASE(N) case N: mx_term<N>(mom[t], g, p, q, V, sft, cu, su, cw, sw); break;
+                GT_DEGREE_CASES(GT_CASE)
+#undef GT_CASE
                 default: mx_term<0>(mom[t], g, p, q, V, sft, cu, su, cw, sw); break;
             }
         }

@@ -949,38 +949,38 @@ static int factorize(mogp_model* m, const double* noise_var, const double* data_
         m->k.tail_ready = nullptr;
         if (rc) return rc;
         if ((rc = mark(m, 2))) return rc;
-        // Round 6: (i) the two vector solves (128 dependent leaf + update steps, ~10 ms at N = 8192, latency-bound) run on a side stream UNDERNEATH the
-        // matrix solve; (ii) Kj^-1 = W^T W with W = L^-1 from ONE substitution (every column a backward-stable solve) and one LAUUM-mode product at the
-        // matrix cores' rate, instead of a second substitution L^-T W at the solves' rate.  42.7 -> see profiles/r6_exact_illcond.txt.
-        hipStream_t vs = (want_inverse && m->st3) ? m->st3 : m->st;
-        if (vs != m->st) {
-            while ((int)m->k.inv_ev.size() < 4) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m->k.inv_ev.push_back(e); }
-            HIP_TRY(hipEventRecord(m->k.inv_ev[0], m->st));                  // the factor is complete
-            HIP_TRY(hipStreamWaitEvent(vs, m->k.inv_ev[0], 0));
-        }
-        if ((rc = m->acc_rhs.ensure((size_t)Npad * MOGP_TILE))) return rc;
-        HIP_TRY(hipMemsetAsync(m->acc_rhs.p, 0, (size_t)Npad * MOGP_TILE * sizeof(double), vs));
-        if ((rc = launch_copy2d(m->acc_rhs.p, MOGP_TILE, m->d_y.p, 1, Npad, 1, 1.0, vs))) return rc;
-        if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->acc_rhs.p, MOGP_TILE, MOGP_TILE, false, vs))) return rc;
-        if ((rc = launch_copy2d(m->d_z.p, 1, m->acc_rhs.p, MOGP_TILE, Npad, 1, 1.0, vs))) return rc;
-        HIP_TRY(hipMemsetAsync(m->d_zz.p, 0, (size_t)((Npad + 3) / 4) * sizeof(double), vs));
-        if ((rc = launch_gemv_rows(m->d_z.p, Npad, 1, Npad, m->d_z.p, m->d_zz.p, vs))) return rc;       // z^T z into the first part
-        if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->acc_rhs.p, MOGP_TILE, MOGP_TILE, true, vs))) return rc;
-        if ((rc = launch_copy2d(m->d_alpha.p, 1, m->acc_rhs.p, MOGP_TILE, Npad, 1, 1.0, vs))) return rc;
+        // Round 6: (i) the matrix solve and the two vector solves (128 dependent leaf + update steps, ~10 ms at N = 8192, latency-bound) overlap -- the SMALL launches stay
+        // on the main stream (highest priority), the matrix solve goes to the all-CU stream of normal priority: the other way round a 4-workgroup leaf waits until the
+        // large launch's queued workgroups have drained (titsias.hip found the same in configs[4]); (ii) Kj^-1 = W^T W with W = L^-1 from ONE substitution (every column a
+        // backward-stable solve) and one LAUUM-mode product at the matrix cores' rate, instead of a second substitution L^-T W.  42.7 -> 25 ms (profiles/r6_exact_illcond.txt).
+        static const bool acc_aside = !(std::getenv("MOGP_ACC_ASIDE") && std::atoi(std::getenv("MOGP_ACC_ASIDE")) == 0);
+        hipStream_t ms = (want_inverse && m->st2u && acc_aside) ? m->st2u : m->st;
         if (want_inverse) {          // (an LML-only evaluation needs L, z and the log-determinant: not the N^2 fill and the N^3 solve nothing would read)
+            if (ms != m->st) {
+                while ((int)m->k.inv_ev.size() < 4) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m->k.inv_ev.push_back(e); }
+                HIP_TRY(hipEventRecord(m->k.inv_ev[0], m->st));                  // the factor is complete
+                HIP_TRY(hipStreamWaitEvent(ms, m->k.inv_ev[0], 0));
+            }
             if ((rc = m->k.Wm.ensure((size_t)Npad * Npad))) return rc;
-            HIP_TRY(hipMemsetAsync(m->k.Wm.p, 0, (size_t)Npad * Npad * sizeof(double), m->st));      // (above its block diagonal W stays zero: flow.hip relies on it)
-            if ((rc = launch_add_diag(m->k.Wm.p, Npad, Npad, 1.0, m->st))) return rc;
-            if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->k.Wm.p, Npad, Npad, false, nullptr, true))) return rc;      // W = L^-1 I, lower block triangle only (trsm.hip: tri)
+            HIP_TRY(hipMemsetAsync(m->k.Wm.p, 0, (size_t)Npad * Npad * sizeof(double), ms));      // (above its block diagonal W stays zero: flow.hip relies on it)
+            if ((rc = launch_add_diag(m->k.Wm.p, Npad, Npad, 1.0, ms))) return rc;
+            if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->k.Wm.p, Npad, Npad, false, ms, true))) return rc;      // W = L^-1 I, lower block triangle only (trsm.hip: tri)
             GemmArgs g{};
             g.A = m->k.Wm.p; g.lda = Npad; g.a_kmajor = 1; g.B = m->k.Wm.p; g.ldb = Npad; g.b_kmajor = 1;
             g.C = m->k.B.p; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0; g.mode = GM_LAUUM; g.mt = g.nt = m->nb; g.K = (int)Npad;
-            if ((rc = gemm_call(m, g, gemm_flops(g, nullptr)))) return rc;
+            if ((rc = gemm_call(m, g, gemm_flops(g, nullptr), ms))) return rc;
+            if (ms != m->st) HIP_TRY(hipEventRecord(m->k.inv_ev[1], ms));
         }
-        if (vs != m->st) {
-            HIP_TRY(hipEventRecord(m->k.inv_ev[1], vs));
-            HIP_TRY(hipStreamWaitEvent(m->st, m->k.inv_ev[1], 0));
-        }
+        if ((rc = m->acc_rhs.ensure((size_t)Npad * MOGP_TILE))) return rc;
+        HIP_TRY(hipMemsetAsync(m->acc_rhs.p, 0, (size_t)Npad * MOGP_TILE * sizeof(double), m->st));
+        if ((rc = launch_copy2d(m->acc_rhs.p, MOGP_TILE, m->d_y.p, 1, Npad, 1, 1.0, m->st))) return rc;
+        if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->acc_rhs.p, MOGP_TILE, MOGP_TILE, false))) return rc;
+        if ((rc = launch_copy2d(m->d_z.p, 1, m->acc_rhs.p, MOGP_TILE, Npad, 1, 1.0, m->st))) return rc;
+        HIP_TRY(hipMemsetAsync(m->d_zz.p, 0, (size_t)((Npad + 3) / 4) * sizeof(double), m->st));
+        if ((rc = launch_gemv_rows(m->d_z.p, Npad, 1, Npad, m->d_z.p, m->d_zz.p, m->st))) return rc;       // z^T z into the first part
+        if ((rc = trsm_lower(m, m->k.A.p, Npad, m->nb, m->acc_rhs.p, MOGP_TILE, MOGP_TILE, true))) return rc;
+        if ((rc = launch_copy2d(m->d_alpha.p, 1, m->acc_rhs.p, MOGP_TILE, Npad, 1, 1.0, m->st))) return rc;
+        if (want_inverse && ms != m->st) HIP_TRY(hipStreamWaitEvent(m->st, m->k.inv_ev[1], 0));
         if ((rc = mark(m, 3))) return rc;
     } else {
     if (factor_only && !fuse_inverse && m->rhs_job && flow_enabled(m, m->k)) rc = spd_potri_flow(m, m->k, m->rhs_job);      // the prediction: factor + substitute as dataflow

@@ -204,6 +204,7 @@ struct TitsiasWork {
     SortedX pred_ss;                                    // the test inputs of the last sparse prediction (a = L^-1 Kus in Aus, b in Bus): what
     bool pred_valid = false;                            // mogp_sparse_predict_cov needs for the full covariance K_ss - a^T a + b^T b
     hipEvent_t side_ev[2] = {nullptr, nullptr};         // fork / join of the M x M adjoint chain on a side stream (side_fork / side_join)
+    hipEvent_t prod_ev[2] = {nullptr, nullptr};         // fork / join of the backward part's M x M x N product on the normal-priority stream (titsias.hip)
     DevBuf<int> blk_z, blk_x;                           // [first point, count] of the 64-point blocks of Z and of X (tile_blocks): the slots of
     std::vector<int> hblk_z, hblk_x;                    // the fixed-order reduction of d/dZ (gz_prepare / gz_attach)
     DevBuf<double> gzp;
@@ -221,6 +222,7 @@ struct TitsiasWork {
         Kus.release(); Aus.release(); Bus.release(); zero_col.release(); kslices.release(); nvec.release(); kd_point.release(); red.release();
         blk_z.release(); blk_x.release(); gzp.release(); hblk_z.clear(); hblk_x.clear();
         for (auto& e : side_ev) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
+        for (auto& e : prod_ev) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
     }
 };
 

@@ -353,9 +353,14 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
     double* btb = t.vec.p + 8 * Mpad;             // [Npad]
     double* r = btb + Npad;                       // [Npad]
     // GA = 1/2 L^-T E L^-1 (symmetric), E = 2I - Pq - Qs: T1 = L^-T E in place, then L^-T T1^T, then the lower triangle of the symmetrised half.
-    // M x M only: on the side stream, underneath the M x N work below
-    hipStream_t side;
-    RC(side_fork(m, t, &side));
+    // M x M only, underneath the M x N work below.  Round 6 (experiment, see prod_aside): the adjoint chain (~70 launches of 4 .. 200 workgroups) stays on the MAIN stream (highest priority) and the
+    // M x M x N product goes to the all-CU stream of normal priority instead -- on a lower-priority side stream (rounds 3 - 5) a 4-workgroup leaf that arrived while the
+    // product's 12 000 workgroups were queued was not dispatched until the product had drained: 12.8 ms for a 67 us kernel in EVERY configs[4] evaluation
+    // (profiles/r5_cfg5_bench_kernel_stats.csv: max 12.9 ms, median 67 us), i.e. the chain ran BEHIND the product, not under it.  MOGP_SIDE_URGENT=1 switches this on.
+    static const bool prod_aside = std::getenv("MOGP_SIDE_URGENT") && std::atoi(std::getenv("MOGP_SIDE_URGENT")) != 0;      // measured: 42.8 vs 40.0 ms -- the chain is hidden, the product and the memory-bound passes behind the chain slow each other by more.  OFF by default
+    const bool aside = prod_aside && m->st2u != nullptr;
+    hipStream_t side = m->st;
+    if (!aside) RC(side_fork(m, t, &side));
     // GB = L^-T (R v) / s2, and beta = L^-T t1 riding along: when N is not a multiple of 128 the right-hand side has zero padding columns,
     // and t1 travels through the blocked solve in the first of them (a vector solve of its own is 2 nb dependent, almost empty launches).
     // The large product is ENQUEUED before the side chain's ~70 launches, so that a slow host does not hold it back.
@@ -372,6 +377,13 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
     // in from memory once -- row by row it came in mt times (27 GB fetched at configs[4] for a 1.6 GB panel)
     static const bool rv_cols = !(std::getenv("MOGP_RV_COLS") && atoi(std::getenv("MOGP_RV_COLS")) == 0);
     g.col_major = rv_cols ? 1 : 0;
+    if (aside) {
+        for (auto& e : t.prod_ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(t.prod_ev[0], m->st));
+        HIP_TRY(hipStreamWaitEvent(m->st2u, t.prod_ev[0], 0));
+        RC(gemm_call(m, g, gemm_flops(g, nullptr), m->st2u));
+        HIP_TRY(hipEventRecord(t.prod_ev[1], m->st2u));        // (the main stream waits for it right in front of the (Z, X) moment pass, its first reader)
+    } else
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
     RC(launch_combine(t.E.p, t.q.B.p, t.Qs.p, Mpad, Mpad, 2.0, 1.0, 1.0, side));
     RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.E.p, Mpad, Mpad, true, side));
@@ -405,6 +417,7 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
     ma.table = m->d_table.p; ma.T = T; ma.D = D; ma.C = C; ma.W = W;
     ma.G = t.GB.p; ma.ldg = Npad; ma.ru = beta; ma.rw = r; ma.rcoef = 1.0; ma.sym = 0;
     ma.gzr = t.gz.p; ma.gzc = nullptr; ma.ldgz = Mpad; ma.partial = t.partial_uf.p;
+    if (aside) HIP_TRY(hipStreamWaitEvent(m->st, t.prod_ev[1], 0));       // GB is there
     RC(launch_moments(ma, m->st));
     RC(launch_moment_reduce(t.partial_uf.p, t.ps_uf.p, C * C, T, W, D, t.mom_uf.p, m->st, 0));
     if (sharded) {                       // the (Z, X) moments and their share of d/dZ are sums over data points; the (Z, Z) pass below is not
