@@ -263,7 +263,9 @@ int  mogp_model_flow_replay(mogp_model* m, int on);
  * (or a chain kernel / private-stream hook) that has waited for a few ms re-reads what it waits for with RETURNING read-modify-writes -- a "deep"
  * look -- next to the sc1 loads every look uses, and counts the answers that differ.  out[0] deep looks of the dataflow kernel, out[1] of them with a
  * different queue head, out[2] with dependency counters the loads called unmet and the atomics met; out[3] deep polls of the other kernels' waits,
- * out[4] of them that ended the wait; out[5..7] the last such dependency (counter index, value, workgroup | XCC << 16). */
+ * out[4] of them that ended the wait; out[5..7] the last such dependency (counter index, value, workgroup | XCC << 16).
+ * A difference is not by itself a stale read: the two reads are 1 - 2 us apart and counters move (25 differences in 2129 deep looks of a healthy 100 000-evaluation
+ * soak); what round 6 used the counters for is the opposite finding -- during a stalled evaluation, where nothing moves, 0 differences in 1.5 M deep looks. */
 int  mogp_model_flow_diag(mogp_model* m, unsigned* out8);
 
 /* The fused factorisation + inversion behind mogp_exact_eval(MOGP_EVAL_GRAD) (reference gpr/model.py:242-246 and the O(N^3) solves of its

@@ -1,6 +1,6 @@
 """Soak test of the dataflow schedule: the SAME evaluation (configs[1], fixed parameters) n times -- every loss and every gradient must come back with
 identical bits, and the schedule must not have fallen back.  Reports the slowest evaluations (a hand-off that stalls shows up as one).
-usage: python tools/flow_soak.py [n] [config]"""
+usage: python tools/flow_soak.py [n] [config] [replay|-] [N]"""
 import os, sys, time, hashlib
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,8 @@ import bench
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
 replay = len(sys.argv) > 3 and sys.argv[3] == "replay"      # the dataflow kernel ALONE (mogp_model_flow_replay): no chain kernels, no private-stream launches
-m, step, _ = bench.build_model(cfg, 0)
+n_override = int(sys.argv[4]) if len(sys.argv) > 4 else None      # another N for the same kernel and channel count (cfg2 only)
+m, step, _ = bench.build_model(cfg, 0, n_override)
 if replay:
     step()
     m._handle.flow_replay(True)
