@@ -339,7 +339,8 @@ namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base) {
     // Bulk stream: the one masked to everything but the reserved CUs while the serial chain matters -- the chain's small kernels (this
     // stream, all CUs) then find idle CUs instead of sharing one with GEMM waves: 15.9 vs 21.1 ms per evaluation at N = 8192, 74 vs 82 ms
     // for the N = 16384 prediction.  Once the work is flop-bound the 6 % of CUs matter more (sweep at N = 32768: 597 vs 638 ms): all CUs.
-    hipStream_t bulk_q = (w.nb > MOGP_CHAIN_BOUND_TILES && m->st2u) ? m->st2u : m->st2;
+    static const int bound_tiles = std::getenv("MOGP_CHAIN_BOUND") ? std::atoi(std::getenv("MOGP_CHAIN_BOUND")) : MOGP_CHAIN_BOUND_TILES;      // (experiment switch: tile rows up to which the bulk stream stays off the reserved CUs)
+    hipStream_t bulk_q = (w.nb > bound_tiles && m->st2u) ? m->st2u : m->st2;
     // ---- two-level blocked right-looking Cholesky with look-ahead.
     // Outer blocks of MOGP_OUTER tiles.  "chain(kb)" = for each 128-column of the block: leaf (factor + inverse) -> panel =
     // panel * inv(Lkk)^T for ALL rows below -> update of the block's remaining columns (64x64-tile GEMMs: latency-bound).
