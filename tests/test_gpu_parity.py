@@ -596,6 +596,22 @@ def test_rccl_communicator_single_rank():
     assert r["snelson"]["rel_loss"] < 1e-10 and r["snelson"]["rel_grad"] < 1e-6 and r["snelson"]["rel_predict"] < 1e-7, r["snelson"]
 
 
+def test_dataflow_schedule_short_soak():
+    """a short soak of the headline evaluation (tools/flow_soak.py in small: BASELINE.json configs[1], the SAME evaluation 400 times): every loss and every
+    gradient with identical bits, every evaluation on the dataflow schedule, no time-out -- and the kernel on the 56 workgroups per XCD that round 6's 100 000-evaluation
+    soak was run on (profiles/r6_flow_soak_100k.txt; with all 60 about one evaluation in 7000 stalls until a bounded wait gives up: profiles/r6_flow_stall.txt)"""
+    import hashlib, os
+    assert os.environ.get("MOGP_FLOW_DROP_CUS") in (None, "16"), "the soak describes the default grid"
+    m = _synth_mosm(8192, 4, 3)
+    seen = set()
+    for _ in range(400):
+        l = m.loss()
+        seen.add(hashlib.sha1(np.float64(l).tobytes() + b"".join(np.ascontiguousarray(p.grad).tobytes() for p in m.parameters())).hexdigest())
+    s = m._handle.schedule()
+    assert len(seen) == 1, len(seen)
+    assert s["dataflow"] and not s["dataflow_fell_back"] and s["dataflow_timeouts"] == 0, s
+
+
 def test_rccl_two_ranks():
     """RCCL with REAL ranks, the moment the box has them: one process per GPU (up to 8), the library's own communicator over xGMI, the sharded
     evaluation + prediction (and the data-parallel sparse models) against each rank's own one-GPU result -- at N = 3000 with every model, and at
