@@ -217,6 +217,12 @@ int  mogp_exact_predict_sharded(mogp_model* m, const double* noise_var, const do
  *   alpha -> ALL-REDUCE(vec, count, sum) -> finish -> ALL-REDUCE(moments), ALL-REDUCE(diagG) on the host arrays.
  * Pointers returned through void** are DEVICE pointers owned by the handle, counts are in doubles. */
 int  mogp_shard_config(mogp_model* m, int rank, int nranks);
+/* How much of the N x N work matrix this handle holds physical memory for.  A model whose FIRST evaluation is a sharded one over P > 1 ranks gets the
+ * matrix in the owned-rows form: the address range whole, memory only under the 128-row tile rows i with i % P == rank (block-cyclic
+ * ownership) -- ceil(T / P) of T tile rows, and no second matrix -- so P ranks hold an N that one GPU could not.  The first one-GPU call on such a
+ * handle (mogp_exact_eval, mogp_exact_predict, mogp_oa_forward) backs the rest.  backed = bytes under the matrix now, whole = 8 Npad^2.
+ * MOGP_SHARD_OWNED=0 in the environment keeps the replicated-matrix form of rounds 1-5.  No reference seam (mogptk is single-device). */
+int  mogp_model_work_bytes(mogp_model* m, int64_t* backed, int64_t* whole);
 int  mogp_shard_begin(mogp_model* m, const double* noise_var, const double* data_var, double jitter, double* jitter_abs, int* nblocks);
 int  mogp_shard_pack(mogp_model* m, int kb, void** send, void** recv, int64_t* count);
 int  mogp_shard_unpack(mogp_model* m, int kb);

@@ -73,6 +73,7 @@ SIGNATURES = {
     "mogp_exact_eval_sharded": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, c_dp, c_dp, c_dp, c_dp, c_dp, c_i64p]),
     "mogp_exact_predict_sharded": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.c_int64, c_dp, c_dp, c_dp, c_i64p]),
     "mogp_shard_config": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "mogp_model_work_bytes": (ctypes.c_int, [ctypes.c_void_p, c_i64p, c_i64p]),
     "mogp_shard_begin": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_double, c_dp, ctypes.POINTER(ctypes.c_int)]),
     "mogp_shard_pack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_i64p]),
     "mogp_shard_unpack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
@@ -538,6 +539,13 @@ class ExactHandle:
         lo, hi = np.zeros(1), np.zeros(1)
         check(lib().mogp_model_pivot_range(self._h, _dp(lo), _dp(hi)))
         return float((hi[0] / lo[0]) ** 2) if lo[0] > 0.0 else float("nan")
+
+    def work_bytes(self):
+        """(bytes of the N x N work matrix this handle has physical memory for, bytes of the whole matrix): a rank of a sharded evaluation holds its own
+        tile rows only (mogp_model_work_bytes)"""
+        b, w = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(lib().mogp_model_work_bytes(self._h, ctypes.byref(b), ctypes.byref(w)))
+        return int(b.value), int(w.value)
 
     def inverse_fraction(self):
         """fraction of the lower tiles of Kj^-1 the last gradient evaluation formed (1.0 = all; see include/mogp_hip.h)"""

@@ -463,13 +463,22 @@ namespace mogp { int spd_lauum(mogp_model* m, Spd& w) {
 }
 }  // namespace mogp
 
-namespace mogp { int spd_alloc(Spd& w, int64_t Npad) {
+namespace mogp { int spd_alloc(Spd& w, int64_t Npad, int owned_rows_device) {
     if (w.Npad == Npad) return 0;
     w.release();
     w.Npad = Npad; w.nb = (int)(Npad / MOGP_TILE);
     int rc;
-    if ((rc = w.A.ensure((size_t)Npad * Npad))) return rc;
-    if ((rc = w.B.ensure((size_t)Npad * Npad))) return rc;
+    const bool owned = owned_rows_device >= 0;
+    if (owned) {
+        // the work matrix of a sharded evaluation: the whole address range, physical memory only where mogp_shard_config asks for it; no B
+        // (nothing of the sharded gradient evaluation uses it -- the sharded prediction allocates it when it comes)
+        if ((rc = w.Arows.reserve((size_t)Npad * Npad * sizeof(double), owned_rows_device))) return rc;
+        w.A.p = reinterpret_cast<double*>(w.Arows.base); w.A.n = (size_t)Npad * Npad; w.A.borrowed = true;
+        w.owned_rows = true;
+    } else {
+        if ((rc = w.A.ensure((size_t)Npad * Npad))) return rc;
+        if ((rc = w.B.ensure((size_t)Npad * Npad))) return rc;
+    }
     if ((rc = w.invd.ensure((size_t)w.nb * MOGP_TILE * MOGP_TILE))) return rc;
     if ((rc = w.logdet.ensure(w.nb))) return rc;
     build_trtri_levels(w);
@@ -479,9 +488,21 @@ namespace mogp { int spd_alloc(Spd& w, int64_t Npad) {
         HIP_TRY(dev_upload(lv.d1.p, lv.h1.data(), lv.h1.size() * sizeof(GemmTask)));
         HIP_TRY(dev_upload(lv.d2.p, lv.h2.data(), lv.h2.size() * sizeof(GemmTask)));
     }
-    // nothing ever writes above the block diagonal of A / B; keep it finite
+    // nothing ever writes above the block diagonal of A / B; keep it finite (an owned-rows A is zeroed granule by granule as it is backed)
+    if (owned) return 0;
     { int r__ = dev_fill_zero(w.A.p, (size_t)Npad * Npad * sizeof(double)); if (r__) return r__; }
     { int r__ = dev_fill_zero(w.B.p, (size_t)Npad * Npad * sizeof(double)); if (r__) return r__; }
+    return 0;
+}
+int spd_make_whole(Spd& w) {
+    int rc;
+    if (!w.owned_rows) return 0;
+    if ((rc = w.Arows.back(0, (size_t)w.Npad * w.Npad * sizeof(double)))) return rc;
+    if (!w.B.p) {
+        if ((rc = w.B.ensure((size_t)w.Npad * w.Npad))) return rc;
+        if ((rc = dev_fill_zero(w.B.p, (size_t)w.Npad * w.Npad * sizeof(double)))) return rc;
+    }
+    w.owned_rows = false;
     return 0;
 }
 }  // namespace mogp
@@ -529,6 +550,10 @@ namespace mogp { double table_diag_points(const mogp_model* m, const SortedX& pt
 }
 }  // namespace mogp
 
+// every entry point that evaluates on this GPU alone: whatever a sharded evaluation of the same model left behind (row ownership: the moment pass,
+// the alpha sums and the sweep's updates mask by it; the owned-rows form of the work matrix) no longer applies
+namespace mogp { void one_gpu_call(mogp_model* m) { m->sh_n = 1; m->sh_rank = 0; m->sh_owned = false; } }
+
 namespace mogp { int ensure_system(mogp_model* m) {
     int rc;
     if (m->tiles.empty()) {
@@ -549,7 +574,10 @@ namespace mogp { int ensure_system(mogp_model* m) {
         HIP_TRY(dev_upload(m->d_pair_start.p, m->pair_start.data(), m->pair_start.size() * sizeof(int)));
     }
     if ((rc = m->d_partial.ensure(m->tiles.size() * (size_t)std::max(m->T, 1) * (size_t)std::max(m->Wt, 1)))) return rc;
-    return spd_alloc(m->k, m->Npad);
+    // a model whose FIRST evaluation is a sharded one gets its work matrix in the owned-rows form (mogp_shard_config backs the rows); the first
+    // one-GPU call on such a model makes it whole
+    if (m->k.Npad == m->Npad) return (m->k.owned_rows && !m->sh_owned) ? spd_make_whole(m->k) : 0;
+    return spd_alloc(m->k, m->Npad, m->sh_owned ? m->ctx->device : -1);
 } }
 
 // ---- which tiles of Kj^-1 a gradient evaluation needs ------------------------------------------------------------------------------------
@@ -1128,7 +1156,9 @@ static int sweep_eval_begin(mogp_model* m, const double* noise_var, const double
     if (own) ga.tiles = m->d_tiles_own.p;
     (own ? m->strip_own : m->strip).attach(ga);
     if ((rc = launch_gram(ga, (int)(own ? m->tiles_own.size() : m->tiles.size()), m->st))) return rc;
-    if ((rc = launch_pad_identity(m->k.A.p, Npad, N, Npad, m->st))) return rc;
+    // (owned-rows form: the padding rows lie in the last tile row -- its owner's business; everybody else gets them with the pivot block)
+    if (!(m->sh_owned && m->sh_n > 1 && (m->nb - 1) % m->sh_n != m->sh_rank))
+        if ((rc = launch_pad_identity(m->k.A.p, Npad, N, Npad, m->st))) return rc;
     if ((rc = mark(m, 1))) return rc;
     return 0;
 }
@@ -1383,6 +1413,7 @@ int mogp_exact_eval(mogp_model* m, const double* noise_var, const double* data_v
     int rc;
     if ((rc = use_device(m->ctx))) return rc;
     if (info) *info = 0;
+    one_gpu_call(m);
     // Gradient evaluation, three schedules of the same arithmetic (MOGP_GRAD_PATH = fused | phases | sweep overrides the choice):
     //   fused   potri.hip: the inverse streamed behind the Cholesky chain.  Wins while the serial chain dominates: 15.1 vs 15.9 ms at
     //           N = 8192, 20.1 vs 21.1 ms at N = 9216, even at N = 10240 -- the default up to 80 tile rows (112 as dataflow, below).
@@ -1458,6 +1489,7 @@ static int predict_core(mogp_model* m, const double* noise_var, const double* da
     int rc;
     if ((rc = use_device(m->ctx))) return rc;
     if (info) *info = 0;
+    one_gpu_call(m);
     // Cholesky factor only: the predictive equations need V = L^-1 K_fs and z = L^-1 y, never L^-1 itself (reference gpr/model.py:470-472 solves).
     // Round 1 / 2a formed W = L^-1 (N^3/3 flop) and multiplied; here [V | z] comes from ONE blocked forward substitution, N^2 (S+1) flop,
     // streamed behind the factorisation: block column K is solved as soon as the factorisation's chain has finished block K.
@@ -1719,6 +1751,10 @@ static int sharded_rc(mogp_model* m, int rc) {
 int mogp_shard_config(mogp_model* m, int rank, int nranks) {
     if (!m || nranks < 1 || rank < 0 || rank >= nranks) return fail(MOGP_EINVAL, "mogp_shard_config: bad argument");
     m->sh_rank = rank; m->sh_n = nranks;
+    // MOGP_SHARD_OWNED: 1 (default) the owned-rows form for every group of more than one rank, 0 the replicated-matrix form of rounds 1-5,
+    // 2 the owned-rows form for a one-rank group as well (its code path on one GPU: tests)
+    static const int owned_mode = []() { const char* e = std::getenv("MOGP_SHARD_OWNED"); return e ? std::atoi(e) : 1; }();
+    m->sh_owned = (owned_mode >= 1 && nranks > 1) || owned_mode >= 2;
     { int r__ = use_device(m->ctx); if (r__) return r__; r__ = ensure_system(m); if (r__) return r__; }
     if (nranks > 1 && (m->own_rank != rank || m->own_n != nranks)) {
         // each rank generates exactly the Gram / moment tiles it owns: a 64-row tile is kept if one of the (at most two)
@@ -1742,6 +1778,26 @@ int mogp_shard_config(mogp_model* m, int rank, int nranks) {
         HIP_TRY(dev_upload(m->d_pair_start_own.p, m->pair_start_own.data(), m->pair_start_own.size() * sizeof(int)));
         m->own_rank = rank; m->own_n = nranks;
     }
+    if (m->k.owned_rows && (m->backed_rank != rank || m->backed_n != nranks)) {
+        // physical memory under this rank's part of the work matrix: its tile rows (i % nranks == rank) and, where a channel does not start on a
+        // 128-row boundary, the rows of a neighbouring tile row that one of its 64-row Gram tiles reaches into
+        int rc;
+        const size_t row_bytes = (size_t)m->Npad * sizeof(double);
+        for (int i = rank; i < m->nb; i += nranks)
+            if ((rc = m->k.Arows.back((size_t)i * MOGP_TILE * row_bytes, (size_t)MOGP_TILE * row_bytes))) return rc;
+        if (nranks > 1)
+            for (const GTile& g : m->tiles_own)
+                if ((rc = m->k.Arows.back((size_t)g.r0 * row_bytes, (size_t)g.nr * row_bytes))) return rc;
+        m->backed_rank = rank; m->backed_n = nranks;
+    }
+    return MOGP_OK;
+}
+
+int mogp_model_work_bytes(mogp_model* m, int64_t* backed, int64_t* whole) {
+    if (!m || !backed || !whole) return fail(MOGP_EINVAL, "mogp_model_work_bytes: bad argument");
+    const int64_t one = (int64_t)m->k.Npad * m->k.Npad * (int64_t)sizeof(double);
+    *whole = one;
+    *backed = m->k.Npad == 0 ? 0 : (m->k.owned_rows || m->k.Arows.base ? (int64_t)m->k.Arows.backed_bytes() : one);
     return MOGP_OK;
 }
 
@@ -1951,6 +2007,10 @@ int mogp_exact_predict_sharded(mogp_model* m, const double* noise_var, const dou
     const int64_t chunk = (int64_t)maxrows * MOGP_TILE * Npad;
     if ((rc = m->sh_send.ensure((size_t)chunk))) return rc;
     if ((rc = m->sh_recv.ensure((size_t)chunk * P))) return rc;
+    if (!m->k.B.p) {                  // (an owned-rows work space has no second matrix until the prediction's design asks for the whole inverse on every rank)
+        if ((rc = m->k.B.ensure((size_t)Npad * Npad))) return rc;
+        if ((rc = dev_fill_zero(m->k.B.p, (size_t)Npad * Npad * sizeof(double)))) return rc;
+    }
     hipLaunchKernelGGL(k_rows_pack, dim3(maxrows, 64), dim3(256), 0, m->st, m->k.A.p, Npad, nb, P, rank, m->sh_send.p);
     HIP_TRY(hipGetLastError());
     if ((rc = comm_allgather(m->ctx, m->sh_send.p, m->sh_recv.p, chunk, m->st))) return rc;
@@ -2122,6 +2182,7 @@ int mogp_model_fetch(mogp_model* m, int which, double* out) {
     if (which == 0 && !m->have_W) return fail(MOGP_EINVAL, "mogp_model_fetch: no evaluation has completed yet");
     if (which == 1 && !m->have_Kinv) return fail(MOGP_EINVAL, "mogp_model_fetch: Kj^-1 needs an evaluation with MOGP_EVAL_GRAD");
     if (which != 0 && which != 1) return fail(MOGP_EINVAL, "mogp_model_fetch: which must be 0, 1 or 2");
+    if (m->k.owned_rows) return fail(MOGP_EINVAL, "mogp_model_fetch: this rank of a sharded evaluation holds only its own tile rows of the matrix");
     if (which == 1 && m->kinv_sparse && !m->kinv_in_A) {
         // the evaluation formed only the tiles of Kj^-1 its gradient reads (kinv_plan): form all of them now, W^T W from the W it left
         m->kinv_sparse = false;

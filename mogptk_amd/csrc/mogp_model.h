@@ -32,14 +32,80 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    bool borrowed = false;              // p points into memory somebody else owns (Spd::A over a RowBacked range): never freed here, never regrown
     int ensure(size_t count) {
         if (count <= n) return 0;
+        if (borrowed) { set_error("DevBuf: a borrowed range cannot grow"); return -1; }
         if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; n = 0; }
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
         n = count;
         return 0;
     }
-    void release() { if (p) { hipError_t e = hipFree(p); (void)e; } p = nullptr; n = 0; }
+    void release() { if (p && !borrowed) { hipError_t e = hipFree(p); (void)e; } p = nullptr; n = 0; borrowed = false; }
+};
+
+// A device address range that is reserved whole and given physical memory granule by granule, where somebody asks for it (HIP's virtual
+// memory management: hipMemAddressReserve / hipMemCreate / hipMemMap).  The work matrix of a SHARDED exact evaluation lives in one: every rank
+// keeps the global (row, column) -> address map of the one-GPU code, but only the granules under the tile rows it owns exist -- a rank of P
+// holds ceil(T / P) tile rows of the N x N matrix (block-cyclic ownership), and a kernel that strays into somebody else's rows
+// faults instead of reading stale numbers.  Everything mapped is zero-filled once.
+struct RowBacked {
+    // One physical allocation per 2 MB granule, every one mapped and given access by itself.  That is the form this runtime takes reliably: with
+    // allocations of DIFFERENT sizes mapped into one reserved range hipMemSetAccess answers "invalid argument" from the second or third size on
+    // (tools/micro/vmm_probe.hip, ROCm 7.2 on MI355X: runs of 4, 4, 1 granules fail at the third; equal sizes at any offsets never do).  The runtime reports a
+    // granularity of 4 KB; 2 MB is the page size the device's address translation wants for a matrix that is streamed.
+    static constexpr size_t GRAN = (size_t)2 << 20;
+    char* base = nullptr;
+    size_t bytes = 0, gran = GRAN;
+    int device = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handle;          // per granule
+    std::vector<char> have;                                       // per granule: mapped
+    size_t nbacked = 0;
+    int reserve(size_t nbytes, int dev) {
+        release();
+        bytes = (nbytes + gran - 1) / gran * gran;
+        void* q = nullptr;
+        HIP_TRY(hipMemAddressReserve(&q, bytes, gran, nullptr, 0));
+        base = static_cast<char*>(q); device = dev;
+        have.assign(bytes / gran, 0);
+        handle.resize(bytes / gran);
+        return 0;
+    }
+    // physical memory (zeroed) under every granule that meets [off, off + len)
+    int back(size_t off, size_t len) {
+        if (len == 0) return 0;
+        if (!base || off + len > bytes) { set_error("RowBacked::back: outside the reserved range"); return -1; }
+        const size_t g_lo = off / gran, g_hi = (off + len - 1) / gran;
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+        hipMemAccessDesc acc{};
+        acc.location.type = hipMemLocationTypeDevice; acc.location.id = device; acc.flags = hipMemAccessFlagsProtReadWrite;
+        for (size_t g = g_lo; g <= g_hi;) {
+            if (have[g]) { ++g; continue; }
+            size_t e = g;
+            for (; e <= g_hi && !have[e]; ++e) {
+                HIP_TRY(hipMemCreate(&handle[e], gran, &prop, 0));
+                hipError_t me = hipMemMap(base + e * gran, gran, 0, handle[e], 0);
+                if (me == hipSuccess) me = hipMemSetAccess(base + e * gran, gran, &acc, 1);
+                if (me != hipSuccess) { hipError_t x = hipMemUnmap(base + e * gran, gran); x = hipMemRelease(handle[e]); (void)x; HIP_TRY(me); }
+                have[e] = 1; ++nbacked;
+            }
+            { int z__ = dev_fill_zero(base + g * gran, (e - g) * gran); if (z__) return z__; }
+            g = e;
+        }
+        return 0;
+    }
+    size_t backed_bytes() const { return nbacked * gran; }
+    void release() {
+        for (size_t g = 0; g < have.size(); ++g)
+            if (have[g]) {
+                hipError_t e = hipMemUnmap(base + g * gran, gran); (void)e;
+                e = hipMemRelease(handle[g]); (void)e;
+            }
+        have.clear(); handle.clear(); nbacked = 0;
+        if (base) { hipError_t e = hipMemAddressFree(base, bytes); (void)e; }
+        base = nullptr; bytes = 0;
+    }
 };
 
 // phase-table workspace for Gram / moment launches over one (row inputs, column inputs) combination: scratch + the device copies
@@ -127,6 +193,8 @@ struct Spd {
     bool refine_panels = false;         // spd_potrf refines every panel once against L_kk itself (ill-conditioned K_uu of the sparse models; needs keep_L)
     DevBuf<double> pscr;                // its scratch: one panel (Npad x 128)
     DevBuf<double> A, B, invd, logdet;
+    RowBacked Arows;                    // owned-rows form (a sharded evaluation's work matrix): A.p points into it, B does not exist until someone needs it
+    bool owned_rows = false;
     DevBuf<double> Wm;                  // W = L^-1 when the inverse is streamed behind the factorisation (spd_potrf fuse_inverse)
     std::vector<TrtriLevel> levels;
     std::vector<hipEvent_t> sync_ev;    // cross-stream dependencies of the look-ahead schedule
@@ -171,6 +239,7 @@ struct Spd {
         flow_tasks_replay.release(); flow_qmeta_replay.release(); flow_replay = FlowPlan();
         levels.clear(); sync_ev.clear();
         A.release(); B.release(); invd.release(); logdet.release(); pscr.release();
+        Arows.release(); owned_rows = false;
     }
 };
 
@@ -254,8 +323,12 @@ struct mogp_model {
     Spd k;                              // the N x N system
     Spd ws, ws_tail;                    // Schur-block workspaces of the sweep inversion (outer block / last partial block)
     DevBuf<double> swU[2], swUr[2];     // old panels of the block being swept (column part, row part), double buffered
+    DevBuf<double> swXr[2];             // owned-rows form: the NEW row part of the panel (all four pivot tile rows; the matrix keeps the owned ones)
     std::vector<hipEvent_t> sw_ev;
     int sh_rank = 0, sh_n = 1;          // sharded evaluation: this rank owns tile rows i with i % sh_n == sh_rank
+    bool sh_owned = false;              // ... in the owned-rows form: nothing outside the owned tile rows of k.A is read or written (sweep.hip); set by
+                                        // mogp_shard_config, cleared by every one-GPU entry point
+    int backed_rank = -1, backed_n = 0; // (rank, nranks) k.Arows has its granules for
     std::vector<GTile> tiles_own;       // the Gram / moment tiles that touch an owned tile row (grouped by pair like `tiles`)
     std::vector<int> pair_start_own;
     DevBuf<GTile> d_tiles_own;
@@ -338,7 +411,8 @@ int gemm_call(mogp_model* m, const GemmArgs& g, double flops, hipStream_t st = n
 int mark(mogp_model* m, int idx);
 double table_diag(const mogp_model* m, int c);
 double table_diag_points(const mogp_model* m, const SortedX& pts);      // sum of K(x, x) over the points (per point when the terms carry an envelope)
-int spd_alloc(Spd& w, int64_t Npad);
+int spd_alloc(Spd& w, int64_t Npad, int owned_rows_device = -1);   // >= 0: the owned-rows form (A reserved on that device, nothing backed yet, no B)
+int spd_make_whole(Spd& w);           // an owned-rows workspace becomes an ordinary one (every granule of A backed, B allocated)
 // helpers shared by the sparse / variational models (titsias.hip)
 inline GemmArgs make_gemm(const double* A, int64_t lda, int akm, const double* B, int64_t ldb, int bkm, double* C, int64_t ldc,
                           double alpha, int mode, int mt, int nt, int64_t K) {
@@ -371,6 +445,7 @@ int spd_invert(mogp_model* m, Spd& w, const char* which, int64_t* info, const do
 // out (Mpad x Mpad, lower tiles) = alpha A B^T over K (leading dimension ldk), K cut into slices so that the launch fills the chip
 int mm_lower_splitk(mogp_model* m, TitsiasWork& t, const double* A, const double* B, double* out, int mt, int64_t Mpad, int64_t ldk, int64_t K,
                     double alpha = 1.0);
+void one_gpu_call(mogp_model* m);   // ownership state of a previous sharded evaluation off (every one-GPU entry point calls this first)
 int ensure_system(mogp_model* m);     // the N x N system of the exact / OA paths and the tile lists over (X, X), on first use (mogp_api.hip)
 int spd_potrf(mogp_model* m, Spd& w, long long info_base = 0);
 int spd_potri_fused(mogp_model* m, Spd& w);

@@ -97,6 +97,7 @@ int mogp_oa_forward(mogp_model* m, const double* q_nu, const double* q_lambda, d
         if (!(q_lambda[i] > 0.0)) return fail(MOGP_EINVAL, "mogp_oa_forward: q_lambda must be positive");
     OaWork& o = m->oa;
     o.valid = false;
+    one_gpu_call(m);
     RC(ensure_system(m));
     m->have_W = m->have_Kinv = false;
     m->kinv_sparse = false;                    // this model reads every entry of the inverse (the exact model's gradient plan does not apply)

@@ -10,6 +10,11 @@
 // Look-ahead: the critical stream applies the update to the NEXT pivot block's panels first (a1, b1) and goes on to invert
 // it while the bulk stream applies the rest (a2, b2, c).  Old panels are copied out (double buffered) so the new ones can
 // be written in place.
+// Owned-rows form (m->sh_owned: every sharded evaluation over more than one rank): a rank touches the matrix ONLY in the tile rows it owns.  What
+// a block needs from the other ranks never enters the matrix: the exchange is unpacked straight into the block's work buffers -- the pivot block into the
+// Schur workspace (where the chain factors it), the old column panel into Uc, the old row panel into Ur -- and the new row panel, which every rank forms
+// for all four pivot tile rows, goes to a buffer of its own (Xr) with the owned rows copied into the matrix.  The matrix can then live in a RowBacked range
+// with physical memory under the owned rows only (mogp_model.h).
 #include "mogp_model.h"
 
 #include <cstdlib>
@@ -39,6 +44,7 @@ int sweep_prepare(mogp_model* m, Spd& w) {
     for (int b = 0; b < 2; ++b) {
         RC(m->swU[b].ensure((size_t)ld * SW_OB * MOGP_TILE));
         RC(m->swUr[b].ensure((size_t)ld * SW_OB * MOGP_TILE));
+        if (m->sh_owned) RC(m->swXr[b].ensure((size_t)ld * SW_OB * MOGP_TILE));
     }
     while ((int)m->sw_ev.size() < 2 * nouter) {
         hipEvent_t e;
@@ -56,6 +62,8 @@ int sweep_block(mogp_model* m, Spd& w, int kb, hipEvent_t* prof, hipEvent_t pane
     const int nb = w.nb;
     const int64_t ld = w.Npad;
     const int rm = m->sh_n > 1 ? m->sh_n : 0, rr = m->sh_rank;
+    const bool ow = m->sh_owned;                                 // owned-rows form (head of this file)
+    auto owned = [&](int i) { return rm == 0 || i % rm == rr; };
     // bulk stream: see spd_potrf; a rank of a sharded evaluation updates 1 / sh_n of the rows, so its chain matters at every size
     static const int force_masked = std::getenv("MOGP_SWEEP_MASKED") ? std::atoi(std::getenv("MOGP_SWEEP_MASKED")) : 0;    // measurement switch
     hipStream_t q1 = m->st, q2 = (rm == 0 && !force_masked && w.nb > MOGP_CHAIN_BOUND_TILES && m->st2u) ? m->st2u : m->st2;
@@ -91,7 +99,9 @@ int sweep_block(mogp_model* m, Spd& w, int kb, hipEvent_t* prof, hipEvent_t pane
             RC(s.Wm.ensure((size_t)Kd * Kd));
             HIP_TRY(hipMemsetAsync(s.Wm.p, 0, (size_t)Kd * Kd * sizeof(double), q1));     // the tiles above the diagonal are never written
         }
-        RC(launch_chain(A, ld, k0, nk, w.invd.p, w.logdet.p, m->d_info.p, 0, s.Wm.p, Kd, w.chain_flags.p + (size_t)kb * MOGP_CHAIN_FLAGS,
+        // (owned-rows form: the block is in the Schur workspace, Kd x Kd; the kernel addresses its block as base + k0 * 128 * (ld + 1) and nothing else)
+        double* cA = ow ? s.A.p - (int64_t)k0 * MOGP_TILE * (Kd + 1) : A;
+        RC(launch_chain(cA, ow ? Kd : ld, k0, nk, w.invd.p, w.logdet.p, m->d_info.p, 0, s.Wm.p, Kd, w.chain_flags.p + (size_t)kb * MOGP_CHAIN_FLAGS,
                         w.chain_flags.p + (size_t)nouter * MOGP_CHAIN_FLAGS, q1));
         GemmArgs g{};
         g.A = s.Wm.p; g.lda = Kd; g.a_kmajor = 1; g.B = s.Wm.p; g.ldb = Kd; g.b_kmajor = 1;
@@ -99,7 +109,7 @@ int sweep_block(mogp_model* m, Spd& w, int kb, hipEvent_t* prof, hipEvent_t pane
         g.mode = GM_LAUUM; g.mt = g.nt = nk; g.K = (int)Kd;
         RC(gemm_call(m, g, gemm_flops(g, nullptr), q1));
     } else {
-        RC(launch_copy2d(s.A.p, Kd, Akk, ld, Kd, Kd, 1.0, q1));
+        if (!ow) RC(launch_copy2d(s.A.p, Kd, Akk, ld, Kd, Kd, 1.0, q1));
         RC(spd_potrf(m, s, (long long)k0 * MOGP_TILE));
         HIP_TRY(hipMemcpyAsync(w.logdet.p + k0, s.logdet.p, nk * sizeof(double), hipMemcpyDeviceToDevice, q1));
         RC(spd_trtri(m, s));
@@ -114,8 +124,11 @@ int sweep_block(mogp_model* m, Spd& w, int kb, hipEvent_t* prof, hipEvent_t pane
     // ---- old panels out, new panels X = U P in place, diagonal block = -P
     double* Uc = m->swU[kb & 1].p;                                                     // [below*128][Kd]
     double* Ur = m->swUr[kb & 1].p;                                                    // [Kd][ld] (first k0*128 columns used)
-    RC(launch_copy2d(Uc, Kd, Acol, ld, (int64_t)below * MOGP_TILE, Kd, 1.0, q1));
-    RC(launch_copy2d(Ur, ld, Arow, ld, Kd, (int64_t)k0 * MOGP_TILE, 1.0, q1));
+    double* Xrow = ow ? m->swXr[kb & 1].p : Arow;                                     // the new row part [Kd][ld]
+    if (!ow) {                                                                         // (owned-rows form: the unpack has put the old panels there)
+        RC(launch_copy2d(Uc, Kd, Acol, ld, (int64_t)below * MOGP_TILE, Kd, 1.0, q1));
+        RC(launch_copy2d(Ur, ld, Arow, ld, Kd, (int64_t)k0 * MOGP_TILE, 1.0, q1));
+    }
     if (below > 0) {
         GemmArgs g = upd(Uc, Kd, 0, P, Kd, 0, Acol, ld, GM_RECT, 2 * below, nk, Kd, 1);
         g.alpha = 1.0; g.beta = 0.0;
@@ -123,11 +136,18 @@ int sweep_block(mogp_model* m, Spd& w, int kb, hipEvent_t* prof, hipEvent_t pane
         RC(gemm_call(m, g, gemm_flops(g, nullptr), q1));
     }
     if (k0 > 0) {
-        GemmArgs g = upd(P, Kd, 0, Ur, ld, 1, Arow, ld, GM_RECT, nk, k0, Kd);
+        GemmArgs g = upd(P, Kd, 0, Ur, ld, 1, Xrow, ld, GM_RECT, nk, k0, Kd);
         g.alpha = 1.0; g.beta = 0.0;
         RC(gemm_call(m, g, gemm_flops(g, nullptr), q1));
     }
-    RC(launch_copy2d(Akk, ld, P, Kd, Kd, Kd, -1.0, q1));
+    if (!ow) RC(launch_copy2d(Akk, ld, P, Kd, Kd, Kd, -1.0, q1));
+    else
+        for (int i = k0; i < k1; ++i) {
+            if (!owned(i)) continue;
+            const int64_t r = (int64_t)(i - k0) * MOGP_TILE;
+            if (k0 > 0) RC(launch_copy2d(A + (int64_t)i * MOGP_TILE * ld, ld, Xrow + r * ld, ld, MOGP_TILE, (int64_t)k0 * MOGP_TILE, 1.0, q1));
+            RC(launch_copy2d(A + (int64_t)i * MOGP_TILE * ld + (int64_t)k0 * MOGP_TILE, ld, P + r * Kd, Kd, MOGP_TILE, Kd, -1.0, q1));
+        }
     HIP_TRY(hipEventRecord(m->sw_ev[2 * kb], q1));                                     // X(kb) ready
     if (prof) HIP_TRY(hipEventRecord(prof[0], q1));
     // ---- rank-Kd update of everything outside the pivot block
@@ -160,7 +180,7 @@ int sweep_block(mogp_model* m, Spd& w, int kb, hipEvent_t* prof, hipEvent_t pane
         }
     }
     if (k0 > 0) {
-        GemmArgs c = upd(Arow, ld, 1, Ur, ld, 1, A, ld, GM_LOWER, k0, k0, Kd);
+        GemmArgs c = upd(Xrow, ld, 1, Ur, ld, 1, A, ld, GM_LOWER, k0, k0, Kd);
         c.row_mod = rm; c.row_rem = rr; c.row_off = 0;
         RC(gemm_call(m, c, gemm_flops(c, nullptr), q2));
     }
@@ -212,6 +232,20 @@ __global__ __launch_bounds__(256) void k_shard_unpack(double* __restrict__ A, in
         const int rr = e / kd2, c = 2 * (e - rr * kd2);
         *reinterpret_cast<double2*>(dst + (int64_t)rr * ld + c) = *reinterpret_cast<const double2*>(src + (int64_t)rr * Kd + c);
     }
+}
+
+// owned-rows form: EVERY rank's rows (this rank's own included) from the receive buffer into the block's work buffers, never into the matrix: tile rows of
+// the pivot block -> the Schur workspace S (Kd x Kd), tile rows below it -> the old column panel Uc ([below * 128][Kd]); 128 x Kd contiguous on both sides
+__global__ __launch_bounds__(256) void k_shard_unpack_owned(const double* __restrict__ recv, int64_t chunk, int row_lo, int row_hi, int P, int k0, int k1, int64_t Kd,
+                                                            double* __restrict__ S, double* __restrict__ Uc) {
+    const int r = blockIdx.z;
+    const int first = row_lo + ((r - row_lo % P) + P) % P;
+    const int i = first + (int)blockIdx.x * P;
+    if (i >= row_hi) return;
+    const int64_t slab = 16 * Kd, off = (int64_t)blockIdx.y * slab;
+    const double* src = recv + (int64_t)r * chunk + (int64_t)blockIdx.x * MOGP_TILE * Kd + off;
+    double* dst = (i < k1 ? S + (int64_t)(i - k0) * MOGP_TILE * Kd : Uc + (int64_t)(i - k1) * MOGP_TILE * Kd) + off;
+    for (int64_t e = 2 * (int64_t)threadIdx.x; e < slab; e += 512) *reinterpret_cast<double2*>(dst + e) = *reinterpret_cast<const double2*>(src + e);
 }
 
 // factor-once: [P (Kd x Kd) | nk log-det parts | pivot report as a double (0: none, else index + 1)] in one buffer, so that ONE all-reduce carries
@@ -289,6 +323,20 @@ int shard_unpack_part(mogp_model* m, Spd& w, int kb, int part, DevBuf<double>& r
     int maxrows, lo, hi; int64_t rowoff;
     const int64_t chunk = part_chunk(g, w.nb, P, part, maxrows, rowoff);
     part_rows(g, w.nb, part, lo, hi);
+    if (m->sh_owned) {
+        Spd& s = (g.nk == m->ws.nb) ? m->ws : m->ws_tail;
+        if (maxrows > 0) {
+            hipLaunchKernelGGL(k_shard_unpack_owned, dim3(maxrows, 8, P), dim3(256), 0, st, recvb.p, chunk, lo, hi, P, g.k0, g.k1, g.Kd, s.A.p, m->swU[kb & 1].p);
+            HIP_TRY(hipGetLastError());
+        }
+        if (part != 1 && g.cols > 0)
+            for (int i = g.k0; i < g.k1; ++i) {
+                const int r = i % P, idx = (i - first_owned(g.k0, P, r)) / P;
+                RC(launch_copy2d(m->swUr[kb & 1].p + (int64_t)(i - g.k0) * MOGP_TILE * w.Npad, w.Npad,
+                                 recvb.p + (int64_t)r * chunk + rowoff + (int64_t)idx * MOGP_TILE * g.cols, g.cols, MOGP_TILE, g.cols, 1.0, st));
+            }
+        return 0;
+    }
     if (maxrows > 0) {
         if (P > 1) hipLaunchKernelGGL(k_shard_unpack, dim3(maxrows, 8, P), dim3(256), 0, st, w.A.p, w.Npad, g.k0, lo, hi, P, g.Kd, chunk, recvb.p, m->sh_rank);
         HIP_TRY(hipGetLastError());

@@ -536,6 +536,17 @@ def test_gradient_with_only_the_needed_tiles_of_the_inverse(path):
         assert "PLAN_OK" in r2.stdout, r2.stdout[-1500:] + r2.stderr[-3000:]
 
 
+def _check_owned_rows(o, world):
+    """tools/shard_check.py's owned-rows case: a model whose first evaluation is sharded (physical memory under its own tile rows only), the sharded
+    prediction on it, then a one-GPU evaluation of the same handle (the matrix made whole, the ownership masks gone)"""
+    assert o["rel_loss"] < 1e-10 and o["rel_grad"] < 1e-7 and o["rel_predict"] < 1e-7, o
+    assert o["rel_loss_one_gpu_after"] < 1e-10 and o["rel_grad_one_gpu_after"] < 1e-7, o
+    assert o["backed_after_one_gpu_call"] == o["whole_bytes"], o
+    assert o["backed_bytes"] <= o["whole_bytes"], o
+    if world >= 4:
+        assert o["backed_bytes"] < o["whole_bytes"], o
+
+
 @pytest.mark.parametrize("ranks", [2, 4, 8])
 def test_sharded_eval_ranks_sharing_one_gpu(ranks):
     """the multi-GPU evaluation and prediction (mogp_exact_eval_sharded / mogp_exact_predict_sharded: owned Gram + moment tiles, the
@@ -553,6 +564,7 @@ def test_sharded_eval_ranks_sharing_one_gpu(ranks):
     assert r["rel_loss"] < 1e-10, r
     assert r["rel_grad"] < 1e-7, r          # tolerance: 1e-5 (north_star); measured ~1e-10
     assert r["rel_predict"] < 1e-7, r       # sharded prediction (Kj^-1 all-gathered, test points split) against the one-GPU solve
+    _check_owned_rows(r["owned_rows"], ranks)
     t = r["titsias"]                        # the sparse bound data-parallel (every rank holds every world-th point; sums over points all-reduced)
     assert t["rel_loss"] < 1e-10 and t["rel_grad"] < 1e-6 and t["rel_predict"] < 1e-7, t
     assert r["hensman"]["rel_loss"] < 1e-10 and r["hensman"]["rel_grad"] < 1e-6, r["hensman"]          # SparseHensman + Student-t, data-parallel
@@ -577,6 +589,42 @@ def test_sharded_eval_exchange_variants(variant):
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert r["world"] == 4 and r["rel_loss"] < 1e-10 and r["rel_grad"] < 1e-7 and r["rel_predict"] < 1e-7, r
+    _check_owned_rows(r["owned_rows"], 4)
+
+
+def test_sharded_owned_rows_allocation():
+    """SURVEY.md 8e, block-cyclic ownership: a rank of a sharded evaluation holds ceil(T / P) tile rows of the work matrix and no second matrix.  N = 8192
+    (64 tile rows of 8 MB, channels on tile boundaries), four ranks sharing this GPU: each has physical memory for exactly a quarter of the matrix
+    (mogp_model_work_bytes; the rest of the address range is reserved but unmapped -- a kernel straying into another rank's rows would fault, so the run
+    itself is the proof that nothing does), results as on one GPU; MOGP_SHARD_OWNED=0 keeps the replicated form (the whole matrix on every rank)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode, port in (("1", 29661), ("0", 29662)):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+                              "--master-port", str(port), os.path.join(root, "tools", "shard_check.py"), "--points", "8192", "--backend", "gloo", "--exact-only",
+                              "--reps", "1"], capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1", MOGP_SHARD_OWNED=mode))
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+        r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert r["world"] == 4 and r["rel_loss"] < 1e-10 and r["rel_grad"] < 1e-7 and r["rel_predict"] < 1e-7, r
+        o = r["owned_rows"]
+        _check_owned_rows(o, 4 if mode == "1" else 1)
+        assert o["whole_bytes"] == 8 * 8192 * 8192, o
+        assert o["backed_bytes"] == (o["whole_bytes"] // 4 if mode == "1" else o["whole_bytes"]), o
+
+
+def test_rccl_communicator_single_rank_owned_rows_form():
+    """the owned-rows form of the sharded evaluation on the path only real multi-GPU ranks take -- the persistent chain kernel factoring the pivot block in the
+    Schur workspace the exchange was unpacked into, RCCL's own all-gather delivering this rank's rows too -- forced onto a one-rank group (MOGP_SHARD_OWNED=2)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29663", os.path.join(root, "tools", "shard_check.py"), "--points", "3000", "--backend", "nccl", "--exact-only"],
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1", MOGP_SHARD_OWNED="2"))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["transport"] == "rccl" and r["world"] == 1
+    assert r["rel_loss"] < 1e-10 and r["rel_grad"] < 1e-7 and r["rel_predict"] < 1e-7, r
+    _check_owned_rows(r["owned_rows"], 1)
 
 
 def test_rccl_communicator_single_rank():
@@ -637,9 +685,13 @@ def test_rccl_two_ranks():
     assert r["titsias"]["rel_loss"] < 1e-10 and r["titsias"]["rel_grad"] < 1e-6 and r["titsias"]["rel_predict"] < 1e-7, r["titsias"]
     assert r["hensman"]["rel_loss"] < 1e-10 and r["hensman"]["rel_grad"] < 1e-6, r["hensman"]
     assert r["snelson"]["rel_loss"] < 1e-10 and r["snelson"]["rel_grad"] < 1e-6 and r["snelson"]["rel_predict"] < 1e-7, r["snelson"]
+    _check_owned_rows(r["owned_rows"], world)
     r = run(["--points", "32768", "--channels", "8", "--q", "5", "--exact-only", "--reps", "1"], 29644)
     assert r["transport"] == "rccl" and r["world"] == world and r["rccl_ranks"] == world, r
     assert r["rel_loss"] < 1e-10 and r["rel_grad"] < 1e-7 and r["rel_predict"] < 1e-7, r
+    _check_owned_rows(r["owned_rows"], world)
+    if 256 % world == 0:
+        assert r["owned_rows"]["backed_bytes"] * world == r["owned_rows"]["whole_bytes"], r      # 256 tile rows of 32 MB: exactly 1 / world each
 
 
 def test_sgd_adagrad_error_path_and_pegging_on_device():

@@ -75,13 +75,42 @@ perr = max(float(np.max(np.abs(mu1 - mu0)) / np.max(np.abs(mu0))), float(np.max(
 
 err = max(float(np.max(np.abs(b - c)) / np.max(np.abs(c))) for b, c in zip(g1, g0))
 
+# owned-rows allocation: a model whose FIRST evaluation is the sharded one holds physical memory only under its own tile rows of the work matrix
+# (mogp_model_work_bytes); the sharded prediction on it adds the second matrix; the first one-GPU call afterwards makes it whole -- and must give the
+# one-GPU gradient again (the row ownership of the sharded call no longer applies)
+def _fresh():
+    kk = gpr.MultiOutputSpectralMixtureKernel(Q=a.q, output_dims=a.channels)
+    for name in ("weight", "mean", "variance", "delay", "phase"):
+        getattr(kk, name).assign(h[name])
+    mm = gpr.Exact(kk, X, y, variance=h["scale"] ** 2)
+    mm.likelihood.scale.assign(h["scale"])
+    return mm
+mogptk_amd.use_distributed().force = True
+m2 = _fresh()
+l2 = float(m2.loss())
+g2 = [p.grad.copy() for p in m2.parameters()]
+backed, whole = m2._handle.work_bytes()
+mu2, var2 = m2.predict_f(Xs)
+mogptk_amd.use_single_device()
+l3 = float(m2.loss())
+g3 = [p.grad.copy() for p in m2.parameters()]
+backed_after, _ = m2._handle.work_bytes()
+owned = dict(rel_loss=abs(l2 - l0) / abs(l0), rel_grad=max(float(np.max(np.abs(b - c)) / np.max(np.abs(c))) for b, c in zip(g2, g0)),
+             rel_predict=max(float(np.max(np.abs(mu2 - mu0)) / np.max(np.abs(mu0))), float(np.max(np.abs(var2 - var0)) / np.max(np.abs(var0)))),
+             backed_bytes=backed, whole_bytes=whole, backed_after_one_gpu_call=backed_after,
+             rel_loss_one_gpu_after=abs(l3 - l0) / abs(l0), rel_grad_one_gpu_after=max(float(np.max(np.abs(b - c)) / np.max(np.abs(c))) for b, c in zip(g3, g0)))
+del m2
+
 if a.exact_only:
     errs = torch.tensor([abs(l1 - l0) / abs(l0), err, perr], dtype=torch.float64)
     if a.backend == "nccl":
         errs = errs.cuda()
     dist.all_reduce(errs, op=dist.ReduceOp.MAX)
+    owned_all = [None] * world
+    dist.all_gather_object(owned_all, owned)
+    owned = {k: max(o[k] for o in owned_all) for k in owned}          # the worst rank of each
     if rank == 0:
-        print(json.dumps(dict(world=world, backend=a.backend, N=a.points, loss=l0, loss_sharded=l1, rel_loss=float(errs[0]), rel_grad=float(errs[1]),
+        print(json.dumps(dict(owned_rows=owned, world=world, backend=a.backend, N=a.points, loss=l0, loss_sharded=l1, rel_loss=float(errs[0]), rel_grad=float(errs[1]),
                               rel_predict=float(errs[2]), transport=comm.transport, rccl_ranks=rccl_ranks, ms_single=1e3 * t_single, ms_sharded=1e3 * t_shard,
                               split=os.environ.get("MOGP_SHARD_SPLIT", "1"), factor_once=os.environ.get("MOGP_SHARD_FACTOR_ONCE", "0"))))
     mogptk_amd.shutdown_distributed()
@@ -168,10 +197,13 @@ errs = torch.tensor([abs(l1 - l0) / abs(l0), err, perr, abs(tl1 - tl0) / abs(tl0
 if a.backend == "nccl":
     errs = errs.cuda()
 dist.all_reduce(errs, op=dist.ReduceOp.MAX)
+owned_all = [None] * world
+dist.all_gather_object(owned_all, owned)
+owned = {k: max(o[k] for o in owned_all) for k in owned}          # the worst rank of each
 per_rank = [None] * world          # every rank's own values: a rank whose ONE-GPU evaluation went wrong shows here, not in the sharded ones
 dist.all_gather_object(per_rank, [l0, l1, tl0, tl1, hl0, hl1, nl0, nl1])
 if rank == 0:
-    print(json.dumps(dict(world=world, backend=a.backend, N=a.points, loss=l0, loss_sharded=l1, rel_loss=float(errs[0]), rel_grad=float(errs[1]), rel_predict=float(errs[2]),
+    print(json.dumps(dict(owned_rows=owned, world=world, backend=a.backend, N=a.points, loss=l0, loss_sharded=l1, rel_loss=float(errs[0]), rel_grad=float(errs[1]), rel_predict=float(errs[2]),
                           transport=comm.transport, rccl_ranks=rccl_ranks, ms_single=1e3 * t_single, ms_sharded=1e3 * t_shard,
                           titsias=dict(N=a.titsias_points, M=int(mt.Z().shape[0]), loss=tl0, rel_loss=float(errs[3]), rel_grad=float(errs[4]),
                                        rel_predict=float(errs[5]), ms_single=1e3 * tt_single, ms_sharded=1e3 * tt_shard),
