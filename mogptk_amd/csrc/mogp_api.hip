@@ -131,6 +131,31 @@ static int wait_stream(hipStream_t st) {
 int StripTiles::build(const std::vector<GTile>& tiles) {
     static const int maxrun = []() { const char* e = std::getenv("MOGP_STRIP_RUN"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 4; }();
     split_strip_tiles(tiles, maxrun, segs, rest);
+    // The hardware hands out workgroups in index order as slots free up: the launch ends when its LAST runs end, so those should be short.  The runs
+    // that would be dispatched last (the final `tail` tiles' worth) are cut into single tiles, the `tail` tiles before them into pairs; a list with
+    // fewer runs than there are workgroup slots is cut into single tiles altogether (the head launch of the dataflow schedule: 8 column tiles a row).
+    static const int grade = []() { const char* e = std::getenv("MOGP_STRIP_GRADE"); return e ? std::atoi(e) : 1; }();
+    if (grade > 0 && maxrun > 1 && !segs.empty()) {
+        static const int slots = []() { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 512; return 2 * pr.multiProcessorCount; }();
+        const long tail = (long)grade * slots;
+        long total = 0;
+        for (const GSeg& g : segs) total += g.n;
+        std::vector<GSeg> out;
+        out.reserve(segs.size() * 2);
+        long seen = 0;
+        const bool all_single = (long)segs.size() < 2L * slots;
+        for (const GSeg& g : segs) {
+            const long left = total - seen;                      // tiles from this run to the end of the list
+            const int cut = (all_single || left <= tail) ? 1 : (left <= 2 * tail ? 2 : maxrun);
+            for (int o = 0; o < g.n; o += cut) {
+                GSeg h = g;
+                h.c0 = g.c0 + o * MOGP_GT; h.n = std::min(cut, g.n - o); h.diag = (o + cut >= g.n) ? g.diag : 0;
+                out.push_back(h);
+            }
+            seen += g.n;
+        }
+        segs.swap(out);
+    }
     int rc;
     if ((rc = d_segs.ensure(std::max<size_t>(segs.size(), 1)))) return rc;
     if ((rc = d_rest.ensure(std::max<size_t>(rest.size(), 1)))) return rc;
@@ -357,10 +382,17 @@ namespace mogp { int spd_potrf(mogp_model* m, Spd& w, long long info_base) {
         w.sync_ev.push_back(e);
     }
     int last_bulk = -1;
+    if (w.want_row_ev)
+        while ((int)w.row_ev.size() < nb) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            w.row_ev.push_back(e);
+        }
     for (int kb = 0; kb < nouter; ++kb) {
         const int k0 = kb * MOGP_OUTER, k1 = std::min(k0 + MOGP_OUTER, nb);
         for (int k = k0; k < k1; ++k) {
             if ((rc = launch_potrf_trtri_tile(w.A.p, w.Npad, k, w.invd.p, w.logdet.p, m->d_info.p, cq, info_base, w.keep_L ? 1 : 0))) return rc;
+            if (w.want_row_ev) HIP_TRY(hipEventRecord(w.row_ev[k], cq));      // block row k of L: the panels of the columns left of it are behind us on this stream, L_kk is this leaf's
             const int rem = nb - k - 1;
             if (rem <= 0) break;
             double* panel = w.A.p + (int64_t)(k + 1) * MOGP_TILE * w.Npad + (int64_t)k * MOGP_TILE;

@@ -198,6 +198,8 @@ struct Spd {
     DevBuf<double> Wm;                  // W = L^-1 when the inverse is streamed behind the factorisation (spd_potrf fuse_inverse)
     std::vector<TrtriLevel> levels;
     std::vector<hipEvent_t> sync_ev;    // cross-stream dependencies of the look-ahead schedule
+    std::vector<hipEvent_t> row_ev;     // want_row_ev: spd_potrf records row_ev[k] behind the leaf of tile column k -- block row k of L (its tiles left of the diagonal and
+    bool want_row_ev = false;           // L_kk itself) is final then, and a forward substitution on another stream may take it (trsm_lower's row_ready)
     std::vector<hipEvent_t> inv_ev;     // events of the fused schedule (potri.hip)
     hipEvent_t fused_last_inv = nullptr, fused_last_wt = nullptr;
     DevBuf<double> Wd;                  // W_KK = L_KK^-1 of every outer block of the fused schedule (512 x 512 each, wkk.hip)
@@ -232,6 +234,8 @@ struct Spd {
     void release() {
         for (auto& lv : levels) { lv.d1.release(); lv.d2.release(); }
         for (auto e : sync_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
+        for (auto e : row_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
+        row_ev.clear();
         for (auto e : inv_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
         inv_ev.clear(); Wm.release(); Wd.release(); chain_flags.release(); for (auto& b : Pb) b.release();
         Lm.release(); Wt.release(); flow_tasks.release(); flow_qmeta.release(); flow_flags.release(); flow_args.release(); flow_args_h.clear(); flow_diag.release(); flow_post.release(); flow_done.release(); flow_trace.release(); flow = FlowPlan();
@@ -463,7 +467,8 @@ int sweep_block(mogp_model* m, Spd& w, int kb, hipEvent_t* prof = nullptr, hipEv
 int sweep_finish(mogp_model* m, Spd& w);
 // B (nb*128 rows x ncols, leading dimension ldb, ncols a multiple of 128) <- L^-1 B  (trans: L^-T B) by blocked substitution, in place;
 // L lower triangular nb*128 square with leading dimension ldl, diagonal tiles included (Spd::keep_L).  trsm.hip
-int trsm_lower(mogp_model* m, const double* L, int64_t ldl, int nb, double* B, int64_t ldb, int64_t ncols, bool trans, hipStream_t st = nullptr, bool tri = false);
+int trsm_lower(mogp_model* m, const double* L, int64_t ldl, int nb, double* B, int64_t ldb, int64_t ncols, bool trans, hipStream_t st = nullptr, bool tri = false,
+               const hipEvent_t* row_ready = nullptr);   // row_ready[i] (forward, wide right-hand sides): block row i of L is final after this event -- the substitution follows a factorisation still running (Spd::row_ev)
 int launch_transpose(double* dst, const double* src, int64_t ld, int64_t n, hipStream_t s);            // dst = src^T, n x n, n % 64 == 0
 int launch_sym_lower_avg(double* A, int64_t ld, int64_t n, double scale, hipStream_t s);               // lower(A) <- scale * (A + A^T) / 2
 int comm_allgather(mogp_ctx* ctx, const double* send, double* recv, int64_t count, hipStream_t st);   // count doubles per rank, device memory

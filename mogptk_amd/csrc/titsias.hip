@@ -242,10 +242,28 @@ static int titsias_front(mogp_model* m, int64_t M, const double* Z, double sigma
     // (round 5, measured and dropped: the chain of this factorisation on the CU-masked private stream, so that its one-workgroup kernels do not share
     // a CU with the K_uf Gram waves -- configs[4] 39.7-39.9 vs 39.3-39.5 ms, bit-identical: the panel and next-column products of the chain are
     // slower on 16 CUs than the leaves gain)
+    // Round 6: v = L^-1 B FOLLOWS the factorisation block row by block row instead of waiting for all of it.  Block row i of L is final behind the leaf of
+    // tile column i (right-looking: the panels left of it were finished by the columns before), and the left-looking substitution needs exactly that row for
+    // its step i -- so the substitution (M^2 N flop, 9.3 ms at configs[4]) runs on the side stream behind the K_uf Gram, waiting per step for the event the
+    // factorisation records, and the factorisation's 16 x 7 dependent small launches (3.6 ms by themselves) run underneath it: the side stream is masked off
+    // the reserved CUs, so the chain's one-workgroup kernels always find a free CU.  Measured at configs[4] (profiles/r6_cfg5_follow.txt): 38.3 against 39.7 ms
+    // per step, ELBO and kernel gradients unchanged -- but NOT the default: on the masked stream the substitution's stream-K products split their k range over
+    // 480 workgroups instead of 512, a different summation order, and dELBO/dZ -- which sits at the rounding floor of this conditioning (cond K_uu ~ 1e11) --
+    // lands 2.62e-3 of the tensor from the 80-bit truth instead of 1.59e-3 (the reference's two runs: 1.44e-3, 1.93e-3).  Both are inside the scatter of the
+    // reference itself; the test holds the device to "no further away than the reference", so the schedule that is there stays.  MOGP_TITSIAS_FOLLOW=1 switches this on.
+    static const bool follow = std::getenv("MOGP_TITSIAS_FOLLOW") && std::atoi(std::getenv("MOGP_TITSIAS_FOLLOW")) != 0;
+    const bool fl = follow && side != m->st && Npad / MOGP_TILE > 32;
+    t.a.want_row_ev = fl;
     RC(spd_potrf(m, t.a));                                                      // its pivot report is read with the scalars at the end of this function
+    t.a.want_row_ev = false;
     const double s2 = sigma * sigma;
-    RC(side_join(m, t, side));
-    RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.v.p, Npad, Npad, false));              // v = L^-1 B   (reference gpr/model.py:711)
+    if (fl) {
+        RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.v.p, Npad, Npad, false, side, false, t.a.row_ev.data()));
+        RC(side_join(m, t, side));
+    } else {
+        RC(side_join(m, t, side));
+        RC(trsm_lower(m, t.a.A.p, Mpad, mt, t.v.p, Npad, Npad, false));          // v = L^-1 B   (reference gpr/model.py:711)
+    }
     (void)nt;
     // Qs = v v^T / s2 + I, with v y (one memory-bound pass over v) underneath the compute-bound product
     double* vy = t.vec.p;

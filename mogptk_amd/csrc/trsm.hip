@@ -347,17 +347,20 @@ int launch_sym_lower_avg(double* A, int64_t ld, int64_t n, double scale, hipStre
 // tri (square right-hand side): the solution is wanted -- forward: IS, the right-hand side being lower triangular -- in its lower block triangle only:
 // right-looking, block row i solved in and its update applied to the first i + 1 column tiles (L^-1 I and the lower half of L^-T (L^-1 I): half the
 // products of the full solves; the accurate form of the exact evaluation, mogp_api.hip:factorize)
-int trsm_lower(mogp_model* m, const double* L, int64_t ldl, int nb, double* B, int64_t ldb, int64_t ncols, bool trans, hipStream_t st, bool tri) {
+int trsm_lower(mogp_model* m, const double* L, int64_t ldl, int nb, double* B, int64_t ldb, int64_t ncols, bool trans, hipStream_t st, bool tri,
+               const hipEvent_t* row_ready) {
     if (!st) st = m->st;
     if (ncols % MOGP_TILE) return fail(MOGP_EINVAL, "trsm_lower: the number of right-hand sides must be a multiple of 128");
     const int nt = (int)(ncols / MOGP_TILE);
     // Wide right-hand sides (N columns): left-looking -- block row i is updated once, by one GEMM with K = 128 i, and B is swept once.
     // Narrow ones (M x M): right-looking -- every solved block updates all remaining block rows at once (K = 128, but (nb - i) nt
     // workgroups per launch instead of nt; the matrix stays in the Infinity Cache).
+    if (row_ready && (trans || tri || nt <= 32)) return fail(MOGP_EINVAL, "trsm_lower: following a running factorisation row by row is the forward left-looking form's (wide right-hand sides)");
     const bool right = tri || nt <= 32;        // (tri: a square system -- one tile row per launch would use (i + 1) of the chip's 256 CUs: 75 ms for the two solves at N = 8192, 2/3 of the accurate evaluation)
     for (int step = 0; step < nb; ++step) {
         const int i = trans ? nb - 1 - step : step;
         double* Bi = B + (int64_t)i * MOGP_TILE * ldb;
+        if (row_ready) HIP_TRY(hipStreamWaitEvent(st, row_ready[i], 0));
         if (!right && step > 0) {
             GemmArgs g{};
             if (!trans) {            // B_i -= L[i, 0:i] X[0:i]
