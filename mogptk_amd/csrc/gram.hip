@@ -716,6 +716,216 @@ __global__ __launch_bounds__(64 * (MOGP_GT / NC) / 4, NC == 2 ? 4 : 2) void k_gr
     }
 }
 
+// ---- strip kernel, second form (round 6): ONE barrier per tile ---------------------------------------------------------------------
+// k_gram_strip above synchronises twice per tile (staged factors written -> read; read -> the buffers are restaged) and its waves were parked at
+// s_waitcnt / s_barrier 36 % of their cycles.  Here the tile-centred factors are double buffered and staged one tile AHEAD: iteration u stages tile
+// u + 1 into F[b ^ 1], computes tile u from F[b], commits the columns of tile u + 2 (prefetched an iteration earlier) and the scalars of tile u + 2
+// (degree, centre distance: computed ONCE per tile and term by wave 0, not by every staging item), stores tile u; one barrier; the columns of tile
+// u + 3 are requested behind it.  The 2 T 64 staging items of a tile do not divide over 256 threads for T = 3 (384): the half wave-pair that takes a
+// second item alternates with the tile's parity.  The addresses of the column prefetch and the LDS slots of its commit are per-thread constants,
+// worked out once per run.  Same arithmetic, entry by entry, as k_gram_strip (the same row / column factors, the same polynomial): same bits.
+template <int TC>
+struct Strip2Lds {
+    static constexpr int RAW = 1 + 2 * TC, PF = (RAW * MOGP_GT + 255) / 256;
+    static constexpr int CP = 36, CL = 72;
+    __device__ static __forceinline__ int cs(int pnt) { return ((pnt & 2) ? CP : 0) + ((pnt >> 2) << 1) + (pnt & 1); }
+    double rowraw[RAW][MOGP_GT];
+    double colraw[2][RAW][CL];
+    double cu[2][TC][MOGP_GT], su[2][TC][MOGP_GT], cw[2][TC][CL], sw[2][TC][CL];
+    double qv[2][CL];                             // q = x_b - (column tile centre) of the staged tile, in the column planes' order
+    double tab[TC][3];                            // A, V, Delta of the pair's terms
+    double s[3][TC];                              // centre distance + delay of tile u mod 3 (written two tiles ahead of its last reader)
+    int deg[3][TC];
+};
+
+template <int TC>
+__global__ __launch_bounds__(256, 2) void k_gram_strip2(GramArgs a, const GSeg* __restrict__ segs) {
+    using SL = Strip2Lds<TC>;
+    constexpr int PF = SL::PF, NT = 256;
+    __shared__ SL L;
+    const int tid = threadIdx.x, cg = tid & 15, rg = tid >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const GSeg sg = segs[blockIdx.x];
+    const int T = a.T, W = a.W;
+    const int ci = sg.pair / a.C, cj = sg.pair - ci * a.C;
+    const PhaseView v = phase_view(a.ph.ws, a.C, T, 1, a.ldxr, a.ldxc);
+    const double* __restrict__ tab = a.table + (size_t)sg.pair * T * W;
+    const int nraw = (1 + 2 * T) * MOGP_GT;
+    auto slot = [&](int k) { return k <= T ? k : k - T + TC; };
+
+    for (int e = tid; e < nraw; e += NT) {               // the row block, once per run (rows take the table of the COLUMN channel)
+        const int k = e >> 6, pnt = e & 63;
+        const int64_t gp = sg.r0 + pnt;
+        double val;
+        if (k == 0) val = a.xr[gp];
+        else if (k <= T) val = v.rcs[((size_t)cj * T + (k - 1)) * a.ldxr + gp];
+        else val = v.rsn[((size_t)cj * T + (k - 1 - T)) * a.ldxr + gp];
+        L.rowraw[slot(k)][pnt] = val;
+    }
+    if (tid < 3 * T) { const int t = tid / 3, k = tid - 3 * t; L.tab[t][k] = tab[(size_t)t * W + (k == 0 ? 0 : 2 * k)]; }      // columns 0, 2, 4
+    const double cr = v.rcen[sg.r0], hr = v.rhalf[sg.r0];
+    // column prefetch: per-thread constants (source array + point, LDS slot), columns take the table of the ROW channel
+    const double* psrc[PF];
+    int pdst[PF];
+#pragma unroll
+    for (int k5 = 0; k5 < PF; ++k5) {
+        const int e = tid + NT * k5, k = e >> 6, pnt = e & 63;
+        psrc[k5] = nullptr; pdst[k5] = 0;
+        if (e < nraw) {
+            if (k == 0) psrc[k5] = a.xc + pnt;
+            else if (k <= T) psrc[k5] = v.ccs + ((size_t)ci * T + (k - 1)) * a.ldxc + pnt;
+            else psrc[k5] = v.csn + ((size_t)ci * T + (k - 1 - T)) * a.ldxc + pnt;
+            pdst[k5] = slot(k) * SL::CL + SL::cs(pnt);
+        }
+    }
+    double pf[PF], cc_n = 0.0, hc_n = 0.0;
+    auto col_fetch = [&](int c0) {
+#pragma unroll
+        for (int k5 = 0; k5 < PF; ++k5) if (psrc[k5]) pf[k5] = psrc[k5][c0];
+        cc_n = v.ccen[c0]; hc_n = v.chalf[c0];
+    };
+    auto col_commit = [&](int b) {
+        double* plane = &L.colraw[b][0][0];
+#pragma unroll
+        for (int k5 = 0; k5 < PF; ++k5) if (psrc[k5]) plane[pdst[k5]] = pf[k5];
+    };
+    // degree / centre distance of tile `u` (column centre cc, half span hc): ONE wave, one lane per term
+    auto scalars = [&](int u, double cc, double hc) {
+        if (wave == 0 && tid < T) {
+            const double A = L.tab[tid][0], V = L.tab[tid][1], s = (cr - cc) + L.tab[tid][2];
+            const double zmax = fabs(V) * hr * hc, es = V * s * s;
+            const double mu = fmax(0.0, fabs(s) - hr - hc), emin = V * mu * mu;
+            const double efac = fabs(V) * (hr * hr + hc * hc + 2.0 * (hr + hc) * fabs(s));
+            int deg;
+            if (A == 0.0 || 0.5 * emin > GT_SKIP_EXPONENT) deg = GT_SKIP;
+            else if (!(zmax <= 0.45) || !(0.5 * es < 600.0) || !(0.5 * efac < 600.0)) deg = GT_GENERAL;
+            else deg = GT_DEGREE(zmax);
+            L.deg[u % 3][tid] = deg; L.s[u % 3][tid] = s;
+        }
+    };
+    // the tile-centred factors of tile u (columns in colraw[u & 1], centre cc) into F[u & 1]
+    auto stage = [&](int u, double cc) {
+        const int b = u & 1, u3 = u % 3;
+        auto item = [&](int e) {
+            const int which = e >= T * MOGP_GT, rem = e - which * T * MOGP_GT, t = rem >> 6, pnt = rem & 63;
+            const int deg = L.deg[u3][t];
+            if (deg == GT_SKIP) return;
+            if (GRAM_DBG(a, 4)) { L.cu[b][t][pnt] = 1.0; L.su[b][t][pnt] = 0.5; L.cw[b][t][SL::cs(pnt)] = 0.25; L.sw[b][t][SL::cs(pnt)] = 2.0; return; }
+            const double V = L.tab[t][1], s = L.s[u3][t];
+            double f = 1.0;
+            if (which == 0) {
+                if (deg != GT_GENERAL) {
+                    const double pp = L.rowraw[0][pnt] - cr;
+                    f = fast_exp(-0.5 * (V * (fma(pp, pp, s * s) + 2.0 * pp * s)));
+                }
+                f *= L.tab[t][0];
+                L.cu[b][t][pnt] = f * L.rowraw[1 + t][pnt]; L.su[b][t][pnt] = f * L.rowraw[1 + TC + t][pnt];
+            } else {
+                const int cp = SL::cs(pnt);
+                const double qq = L.colraw[b][0][cp] - cc;
+                if (deg != GT_GENERAL) f = fast_exp(-0.5 * (V * (qq * qq - 2.0 * qq * s)));
+                L.cw[b][t][cp] = f * L.colraw[b][1 + t][cp]; L.sw[b][t][cp] = f * L.colraw[b][1 + TC + t][cp];
+            }
+        };
+        const int items = 2 * T * MOGP_GT, full = items / NT;                // (items come in multiples of 128: which / t are wave-uniform)
+        for (int r = 0; r < full; ++r) item(tid + NT * r);
+        if ((items & (NT - 1)) && (wave & 2) == ((u & 1) << 1)) item(NT * full + (tid & 127));      // T odd: 128 items left, the wave pairs take turns
+        if (tid < MOGP_GT) { const int cp = SL::cs(tid); L.qv[b][cp] = L.colraw[b][0][cp] - cc; }
+    };
+
+    // ---- prologue: tile 0 staged, tile 1's columns and scalars in LDS, tile 2's columns requested ----
+    col_fetch(sg.c0);
+    col_commit(0);
+    double cc0 = cc_n, cc1 = 0.0;                       // centres of the tile being computed next (u) and the one staged next (u + 1)
+    __syncthreads();                                    // rowraw, tab, colraw[0]
+    scalars(0, cc0, hc_n);
+    if (sg.n > 1) {
+        col_fetch(sg.c0 + MOGP_GT);
+        col_commit(1);
+        cc1 = cc_n;
+    }
+    __syncthreads();                                    // scalars(0), colraw[1]
+    if (sg.n > 1) scalars(1, cc1, hc_n);
+    stage(0, cc0);
+    if (sg.n > 2) col_fetch(sg.c0 + 2 * MOGP_GT);
+    __syncthreads();                                    // F[0], scalars(1)
+    double p[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) p[m] = L.rowraw[0][rg * 4 + m] - cr;
+
+    for (int u = 0; u < sg.n; ++u) {
+        const int b = u & 1, u3 = u % 3, c0 = sg.c0 + u * MOGP_GT;
+        if (u + 1 < sg.n) stage(u + 1, cc1);
+        double q[4], acc[4][4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) q[n] = L.qv[b][SL::cs(cg * 4 + n)];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = 0.0;
+        for (int t = 0; t < T; ++t) {
+            const int deg = __builtin_amdgcn_readfirstlane(L.deg[u3][t]);
+            if (deg == GT_SKIP || GRAM_DBG(a, 2)) continue;
+            const double V = L.tab[t][1], s = L.s[u3][t];
+            double cu[4], su[4], cw[4], sw[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { cu[m] = L.cu[b][t][rg * 4 + m]; su[m] = L.su[b][t][rg * 4 + m]; }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) { cw[n] = L.cw[b][t][SL::cs(cg * 4 + n)]; sw[n] = L.sw[b][t][SL::cs(cg * 4 + n)]; }
+            switch (deg) {
+                #define GT_CASE(N) case N: strip_term<N, 4>(acc, p, q, V, s, cu, su, cw, sw); break;
+                GT_DEGREE_CASES(GT_CASE)
+#undef GT_CASE
+                default: strip_term<0, 4>(acc, p, q, V, s, cu, su, cw, sw); break;
+            }
+        }
+        if (u + 2 < sg.n) {                                // the columns of tile u + 2 (requested an iteration ago) and its scalars
+            col_commit(b);
+            scalars(u + 2, cc_n, hc_n);
+        }
+        cc0 = cc1; cc1 = cc_n;
+        if (sg.diag && u + 1 == sg.n) {
+            // the run's last tile sits on the matrix diagonal: lower part only, noise + jitter (+ per-point variance) on the diagonal entries
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int lr = rg * 4 + m;
+                const int64_t r = sg.r0 + lr;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int lc = cg * 4 + n;
+                    if (lc > lr) continue;
+                    double val = acc[m][n];
+                    if (a.noise != nullptr && lc == lr) {
+                        val += a.noise[ci] + a.jitter_abs;
+                        if (a.dvar != nullptr) val += a.dvar[r];
+                    }
+                    a.out[r * a.ldo + c0 + lc] = val;
+                    if (a.out2) a.out2[r * a.ldo + c0 + lc] = val;
+                }
+            }
+        } else if (!(GRAM_DBG(a, 1) && acc[0][0] != 12345.678)) {
+            double* o = a.out + (int64_t)(sg.r0 + rg * 4) * a.ldo + c0 + cg * 4;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                *reinterpret_cast<d2_t*>(o + m * a.ldo) = (d2_t){acc[m][0], acc[m][1]};
+                *reinterpret_cast<d2_t*>(o + m * a.ldo + 2) = (d2_t){acc[m][2], acc[m][3]};
+            }
+            if (a.out2) {                                  // the sparse models' working copy of K_uf (same leading dimension)
+                double* o2 = a.out2 + (int64_t)(sg.r0 + rg * 4) * a.ldo + c0 + cg * 4;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    *reinterpret_cast<d2_t*>(o2 + m * a.ldo) = (d2_t){acc[m][0], acc[m][1]};
+                    *reinterpret_cast<d2_t*>(o2 + m * a.ldo + 2) = (d2_t){acc[m][2], acc[m][3]};
+                }
+            }
+        }
+        // F[b ^ 1], colraw[b], the scalars of tile u + 2: written; F[b], qv[b]: read.  An LDS-only barrier: __syncthreads() would also wait for the
+        // tile's stores to land, which nobody here reads
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (u + 3 < sg.n) col_fetch(c0 + 3 * MOGP_GT);
+    }
+}
+
 void split_strip_tiles(const std::vector<GTile>& tiles, int maxrun, std::vector<GSeg>& segs, std::vector<GTile>& rest) {
     segs.clear(); rest.clear();
     for (const GTile& t : tiles) {
@@ -754,7 +964,11 @@ int launch_gram(const GramArgs& a0, int ntiles, hipStream_t s) {
     static const bool strip_on = !(std::getenv("MOGP_GRAM_STRIP") && std::atoi(std::getenv("MOGP_GRAM_STRIP")) == 0);
     if (strip_on && a.segs && a.nsegs > 0 && a.D == 1 && a.W == 5 && a.T <= GS_TC_MAX && !a.mirror && (a.ldo & 1) == 0) {
         static const int strip_nc = []() { const char* e = std::getenv("MOGP_GRAM_NC"); const int v = e ? std::atoi(e) : 4; return v == 2 ? 2 : 4; }();      // MOGP_GRAM_NC=2: 4 x 2 entries per thread on 512 threads (four waves per SIMD; round 6: 148 vs 159 us on one box, 154 vs 146 on another -- not kept as the default)
-        if (strip_nc == 2) {
+        static const bool strip2 = !(std::getenv("MOGP_GRAM_STRIP2") && std::atoi(std::getenv("MOGP_GRAM_STRIP2")) == 0);      // the one-barrier form (k_gram_strip2)
+        if (strip2 && strip_nc == 4) {
+            if (a.T <= 4) hipLaunchKernelGGL((k_gram_strip2<4>), dim3(a.nsegs), dim3(256), 0, s, a, a.segs);
+            else hipLaunchKernelGGL((k_gram_strip2<8>), dim3(a.nsegs), dim3(256), 0, s, a, a.segs);
+        } else if (strip_nc == 2) {
             if (a.T <= 4) hipLaunchKernelGGL((k_gram_strip<4, 2>), dim3(a.nsegs), dim3(512), 0, s, a, a.segs);
             else hipLaunchKernelGGL((k_gram_strip<8, 2>), dim3(a.nsegs), dim3(512), 0, s, a, a.segs);
         } else {

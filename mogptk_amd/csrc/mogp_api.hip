@@ -129,7 +129,7 @@ static int wait_stream(hipStream_t st) {
 }
 
 int StripTiles::build(const std::vector<GTile>& tiles) {
-    static const int maxrun = []() { const char* e = std::getenv("MOGP_STRIP_RUN"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 4; }();
+    static const int maxrun = []() { const char* e = std::getenv("MOGP_STRIP_RUN"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 8; }();      // (round 6, with the graded tail and the one-barrier kernel: 103 us at 8 against 105 at 4 and 108 at 6, configs[1])
     split_strip_tiles(tiles, maxrun, segs, rest);
     // The hardware hands out workgroups in index order as slots free up: the launch ends when its LAST runs end, so those should be short.  The runs
     // that would be dispatched last (the final `tail` tiles' worth) are cut into single tiles, the `tail` tiles before them into pairs; a list with
