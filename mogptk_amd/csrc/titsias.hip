@@ -376,9 +376,19 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
     // product's 12 000 workgroups were queued was not dispatched until the product had drained: 12.8 ms for a 67 us kernel in EVERY configs[4] evaluation
     // (profiles/r5_cfg5_bench_kernel_stats.csv: max 12.9 ms, median 67 us), i.e. the chain ran BEHIND the product, not under it.  MOGP_SIDE_URGENT=1 switches this on.
     static const bool prod_aside = std::getenv("MOGP_SIDE_URGENT") && std::atoi(std::getenv("MOGP_SIDE_URGENT")) != 0;      // measured: 42.8 vs 40.0 ms -- the chain is hidden, the product and the memory-bound passes behind the chain slow each other by more.  OFF by default
-    const bool aside = prod_aside && m->st2u != nullptr;
+    // MOGP_SIDE_URGENT=2 (round 6, second session): the two on DISJOINT CUs -- the product on the bulk stream (masked off the reserved CUs), the chain on the private
+    // stream (the reserved CUs only): neither priority nor slots are shared.  Same tiles, same bits.
+    static const int urgent_mode = std::getenv("MOGP_SIDE_URGENT") ? std::atoi(std::getenv("MOGP_SIDE_URGENT")) : 0;
+    const bool disjoint = urgent_mode == 2 && m->st_priv && m->st2;
+    const bool aside = (prod_aside && m->st2u != nullptr) || disjoint;
+    hipStream_t prod_q = disjoint ? m->st2 : m->st2u;
     hipStream_t side = m->st;
-    if (!aside) RC(side_fork(m, t, &side));
+    if (disjoint) {
+        for (auto& e : t.side_ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(t.side_ev[0], m->st));
+        HIP_TRY(hipStreamWaitEvent(m->st_priv, t.side_ev[0], 0));
+        side = m->st_priv;
+    } else if (!aside) RC(side_fork(m, t, &side));
     // GB = L^-T (R v) / s2, and beta = L^-T t1 riding along: when N is not a multiple of 128 the right-hand side has zero padding columns,
     // and t1 travels through the blocked solve in the first of them (a vector solve of its own is 2 nb dependent, almost empty launches).
     // The large product is ENQUEUED before the side chain's ~70 launches, so that a slow host does not hold it back.
@@ -398,9 +408,9 @@ static int titsias_eval_impl(mogp_model* m, int64_t M, const double* Z, double s
     if (aside) {
         for (auto& e : t.prod_ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(t.prod_ev[0], m->st));
-        HIP_TRY(hipStreamWaitEvent(m->st2u, t.prod_ev[0], 0));
-        RC(gemm_call(m, g, gemm_flops(g, nullptr), m->st2u));
-        HIP_TRY(hipEventRecord(t.prod_ev[1], m->st2u));        // (the main stream waits for it right in front of the (Z, X) moment pass, its first reader)
+        HIP_TRY(hipStreamWaitEvent(prod_q, t.prod_ev[0], 0));
+        RC(gemm_call(m, g, gemm_flops(g, nullptr), prod_q));
+        HIP_TRY(hipEventRecord(t.prod_ev[1], prod_q));        // (the main stream waits for it right in front of the (Z, X) moment pass, its first reader)
     } else
     RC(gemm_call(m, g, gemm_flops(g, nullptr)));
     RC(launch_combine(t.E.p, t.q.B.p, t.Qs.p, Mpad, Mpad, 2.0, 1.0, 1.0, side));

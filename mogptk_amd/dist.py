@@ -14,10 +14,11 @@ The collectives of the hot path are issued by the native library itself (mogptk_
 What is exchanged per LML+gradient evaluation of an N-point model (Npad = N rounded up to 128, 512-wide pivot blocks): per pivot block
 ONE all-gather -- the block's column panel, each tile row from its owner, plus the part left of the block of the pivot tile rows (N^2
 doubles per evaluation in total); once: all-reduce of alpha (Npad doubles), of the gradient moments (C(C+1)/2 x T x (2+3D)) and of the
-diagonal sums (C).  Every rank holds the full training set and a full-size work matrix (8.6 GB at N = 32768: nothing against 288 GB) but
-BUILDS only the Gram / moment tiles of the 128-row tile rows it owns (i % world == rank), repeats the cheap serial chain (512 x 512 block
-inversions, panels) and applies the rank-512 updates to its own rows only: the O(N^3) work is divided by `world`.  A sharded prediction
-adds one all-gather of Kj^-1 and splits the test points over the ranks.
+diagonal sums (C).  Every rank holds the full training set but only ITS tile rows of the work matrix (the 128-row tile rows i % world == rank:
+1 / world of 8 Npad^2 bytes, physical memory under those rows only -- mogp_model_work_bytes; what it needs of the other ranks' rows arrives with the
+exchange and goes straight into the pivot block's work buffers), BUILDS only the Gram / moment tiles of those rows, repeats the cheap serial chain
+(512 x 512 block inversions, panels) and applies the rank-512 updates to its own rows only: the O(N^3) work and the O(N^2) memory are divided by
+`world`.  A sharded prediction adds one all-gather of Kj^-1 (every rank then holds the whole inverse) and splits the test points over the ranks.
 
 `sharded_eval` below is the same protocol spelt out stage by stage over the `mogp_shard_*` entry points; the numpy twin of the device
 stages (oracle/table_model.py) runs it under gloo on CPU ranks in tests/test_dist_cpu.py.
