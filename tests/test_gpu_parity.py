@@ -612,6 +612,21 @@ def test_sharded_owned_rows_allocation():
         assert o["backed_bytes"] == (o["whole_bytes"] // 4 if mode == "1" else o["whole_bytes"]), o
 
 
+def test_sharded_stage_protocol_on_device():
+    """the sharded evaluation stage by stage on the DEVICE (mogp_shard_config / begin / pack / unpack / block / alpha / finish, the collectives issued by the
+    caller: mogptk_amd.dist.sharded_eval -- the sequence the numpy twin runs under gloo in tests/test_dist_cpu.py), two ranks sharing this GPU, in the owned-rows
+    form: loss and gradients as on one GPU (the prediction of this mode is the one-GPU one)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29664", os.path.join(root, "tools", "shard_check.py"), "--points", "3000", "--backend", "gloo", "--protocol"],
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["world"] == 2 and r["rel_loss"] < 1e-10 and r["rel_grad"] < 1e-7, r
+    _check_owned_rows(r["owned_rows"], 2)
+
+
 def test_rccl_communicator_single_rank_owned_rows_form():
     """the owned-rows form of the sharded evaluation on the path only real multi-GPU ranks take -- the persistent chain kernel factoring the pivot block in the
     Schur workspace the exchange was unpacked into, RCCL's own all-gather delivering this rank's rows too -- forced onto a one-rank group (MOGP_SHARD_OWNED=2)"""

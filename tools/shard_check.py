@@ -20,7 +20,11 @@ ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--titsias-points", type=int, default=6000)
 ap.add_argument("--inducing", type=int, default=96, help="inducing points per channel of the Titsias check")
 ap.add_argument("--exact-only", action="store_true", help="the exact model's evaluation and prediction only (the exchange-variant tests)")
+ap.add_argument("--protocol", action="store_true", help="the sharded evaluation through the stage-by-stage entry points (mogp_shard_begin / pack / unpack / block / alpha / finish), "
+                                                        "the collectives issued by the caller (mogptk_amd.dist.sharded_eval); implies --exact-only")
 a = ap.parse_args()
+if a.protocol:
+    a.exact_only = True
 
 import torch
 import torch.distributed as dist
@@ -51,7 +55,8 @@ for _ in range(a.reps):
     m.loss()
 t_single = (time.perf_counter() - t) / a.reps
 
-comm = mogptk_amd.use_distributed()
+_use = mogptk_amd.use_protocol if a.protocol else mogptk_amd.use_distributed
+comm = _use()
 comm.force = True
 rccl_ranks = None
 if a.backend == "nccl":                  # how many ranks a collective issued by the LIBRARY on its own communicator sums over (mogp_comm_selftest)
@@ -85,7 +90,7 @@ def _fresh():
     mm = gpr.Exact(kk, X, y, variance=h["scale"] ** 2)
     mm.likelihood.scale.assign(h["scale"])
     return mm
-mogptk_amd.use_distributed().force = True
+_use().force = True
 m2 = _fresh()
 l2 = float(m2.loss())
 g2 = [p.grad.copy() for p in m2.parameters()]
@@ -111,7 +116,7 @@ if a.exact_only:
     owned = {k: max(o[k] for o in owned_all) for k in owned}          # the worst rank of each
     if rank == 0:
         print(json.dumps(dict(owned_rows=owned, world=world, backend=a.backend, N=a.points, loss=l0, loss_sharded=l1, rel_loss=float(errs[0]), rel_grad=float(errs[1]),
-                              rel_predict=float(errs[2]), transport=comm.transport, rccl_ranks=rccl_ranks, ms_single=1e3 * t_single, ms_sharded=1e3 * t_shard,
+                              rel_predict=float(errs[2]), transport=getattr(comm, "transport", "caller (stage protocol)"), rccl_ranks=rccl_ranks, ms_single=1e3 * t_single, ms_sharded=1e3 * t_shard,
                               split=os.environ.get("MOGP_SHARD_SPLIT", "1"), factor_once=os.environ.get("MOGP_SHARD_FACTOR_ONCE", "0"))))
     mogptk_amd.shutdown_distributed()
     dist.destroy_process_group()
