@@ -833,22 +833,29 @@ __global__ __launch_bounds__(256, 2) void k_gram_strip2(GramArgs a, const GSeg* 
         if (tid < MOGP_GT) { const int cp = SL::cs(tid); L.qv[b][cp] = L.colraw[b][0][cp] - cc; }
     };
 
-    // ---- prologue: tile 0 staged, tile 1's columns and scalars in LDS, tile 2's columns requested ----
+    // ---- prologue: tile 0 staged, tile 1's columns and scalars in LDS, tile 2's columns requested.  The columns of tiles 0 and 1 are requested TOGETHER
+    // (one memory round trip behind the run descriptor's, not two) ----
+    double pf1[PF], cc0, hc0, cc1 = 0.0, hc1 = 0.0;
     col_fetch(sg.c0);
-    col_commit(0);
-    double cc0 = cc_n, cc1 = 0.0;                       // centres of the tile being computed next (u) and the one staged next (u + 1)
-    __syncthreads();                                    // rowraw, tab, colraw[0]
-    scalars(0, cc0, hc_n);
     if (sg.n > 1) {
-        col_fetch(sg.c0 + MOGP_GT);
-        col_commit(1);
-        cc1 = cc_n;
+#pragma unroll
+        for (int k5 = 0; k5 < PF; ++k5) if (psrc[k5]) pf1[k5] = psrc[k5][sg.c0 + MOGP_GT];
+        cc1 = v.ccen[sg.c0 + MOGP_GT]; hc1 = v.chalf[sg.c0 + MOGP_GT];
     }
-    __syncthreads();                                    // scalars(0), colraw[1]
-    if (sg.n > 1) scalars(1, cc1, hc_n);
-    stage(0, cc0);
+    col_commit(0);
+    cc0 = cc_n; hc0 = hc_n;
+    if (sg.n > 1) {
+        double* plane = &L.colraw[1][0][0];
+#pragma unroll
+        for (int k5 = 0; k5 < PF; ++k5) if (psrc[k5]) plane[pdst[k5]] = pf1[k5];
+    }
+    __syncthreads();                                    // rowraw, tab, colraw[0], colraw[1]
+    scalars(0, cc0, hc0);
+    if (sg.n > 1) scalars(1, cc1, hc1);
     if (sg.n > 2) col_fetch(sg.c0 + 2 * MOGP_GT);
-    __syncthreads();                                    // F[0], scalars(1)
+    __syncthreads();                                    // the scalars of tiles 0 and 1
+    stage(0, cc0);
+    __syncthreads();                                    // F[0]
     double p[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) p[m] = L.rowraw[0][rg * 4 + m] - cr;
