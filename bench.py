@@ -693,6 +693,8 @@ def main():
     # chain kernel and next to the resident dataflow kernel's polling workgroups (which is where it is hidden, and why its duration there -- gram_kernel in
     # stages_ms_per_eval -- says little about the kernel); an LML-only evaluation builds the same matrix in ONE launch with nothing beside it
     gram_alone_ms = None
+    # (how the LAST evaluation was scheduled is read here, behind the timed steps: the LML-only evaluations below are not gradient evaluations)
+    sched_timed = h.schedule() if (kind in ("exact", "predict") and not sharded_mode and hasattr(h, "schedule")) else None
     if rank == 0 and kind == "exact" and not sharded_mode and hasattr(m, "log_marginal_likelihood"):
         try:
             h.set_profiling(True)
@@ -705,6 +707,7 @@ def main():
             gram_alone_ms = None
         finally:
             h.set_profiling(False)
+        train_step()                  # the handle's "last evaluation" is a gradient evaluation again (inverse_fraction, schedule)
     if sharded_mode:
         mogptk_amd.use_single_device()
 
@@ -736,7 +739,7 @@ def main():
         gram_gbs = gram_bytes / (gram_alone_ms * 1e-3) / 1e9 if gram_alone_ms else gram_sched_gbs
         mom_gbs = gram_bytes * nprof / (stage[_lib.ST_MOMENT_KERNEL] * 1e-3) / 1e9 if stage[_lib.ST_MOMENT_KERNEL] > 0 else None
         traffic, traffic_src, traffic_eval = None, None, None
-        sched = h.schedule() if (kind in ("exact", "predict") and not sharded_mode and hasattr(h, "schedule")) else None
+        sched = sched_timed
         for tf in ("r6_pmc_traffic_stream_schedule.json", "r5_pmc_traffic_stream_schedule.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"):     # L2<->fabric bytes per k_gemm launch from the committed rocprofv3 --pmc passes of this command
             try:
                 with open(os.path.join(ROOT, "profiles", tf)) as f:
