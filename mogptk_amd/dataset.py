@@ -63,22 +63,19 @@ class Data:
             m &= (self.X[:, i] >= lo[i]) & (self.X[:, i] <= hi[i])
         self.mask[m] = False
 
+    def _observations(self, rows, transformed):
+        """(X, Y) of the selected observations (None: all of them), Y through the fitted transformers on request -- reference data.py:585-640"""
+        X, Y = (self.X, self.Y) if rows is None else (self.X[rows, :], self.Y[rows])
+        return X, (self.Y_transformer.forward(Y, X) if transformed else Y)
+
     def get_data(self, transformed=False):
-        if transformed:
-            return self.X, self.Y_transformer.forward(self.Y, self.X)
-        return self.X, self.Y
+        return self._observations(None, transformed)
 
     def get_train_data(self, transformed=False):
-        """reference data.py:602-619"""
-        if transformed:
-            return self.X[self.mask, :], self.Y_transformer.forward(self.Y[self.mask], self.X[self.mask, :])
-        return self.X[self.mask, :], self.Y[self.mask]
+        return self._observations(self.mask, transformed)
 
     def get_test_data(self, transformed=False):
-        X, Y = self.X[~self.mask, :], self.Y[~self.mask]
-        if transformed:
-            return X, self.Y_transformer.forward(Y, X)
-        return X, Y
+        return self._observations(~self.mask, transformed)
 
     def set_prediction_data(self, X):
         self.X_pred, _ = self._format_X(X)
@@ -125,7 +122,7 @@ class Data:
         reference is part of the numbers (data.py:963-1002 reuses the name `n` for the count of peaks it kept): after a dimension with peaks,
         the NEXT dimension's frequency grid has only that many points."""
         from scipy.signal import lombscargle
-        x, y = self.get_train_data(transformed=True)
+        x, y = self._observations(self.mask, True)
         top = self.get_nyquist_estimation()
 
         def periodogram(i, kept):
@@ -137,7 +134,7 @@ class Data:
         """peaks of the Bayesian nonparametric spectral estimate (init.BNSE: a GP fit on the device) per input dimension, scaled by
         pi / range^2 -- reference data.py:1004-1051; observation errors go through the Y transformer as half the transformed interval"""
         from .init import BNSE
-        x, y = self.get_train_data(transformed=True)
+        x, y = self._observations(self.mask, True)
         top = self.get_nyquist_estimation()
         half_width = None
         if self.Y_err is not None:
@@ -185,10 +182,8 @@ class DataSet:
                 self.append(arg)
 
     def append(self, arg):
-        if isinstance(arg, Data):
-            self.channels.append(arg)
-        elif isinstance(arg, DataSet):
-            self.channels.extend(arg.channels)
+        if isinstance(arg, (Data, DataSet)):
+            self.channels += [arg] if isinstance(arg, Data) else arg.channels
         elif isinstance(arg, (list, tuple)) and all(isinstance(a, Data) for a in arg):
             self.channels.extend(arg)
         elif isinstance(arg, dict) and all(isinstance(a, Data) for a in arg.values()):
@@ -205,9 +200,7 @@ class DataSet:
         return len(self.channels)
 
     def __getitem__(self, key):
-        if isinstance(key, str):
-            return self.channels[self.get_names().index(key)]
-        return self.channels[key]
+        return self.channels[self.get_index(key) if isinstance(key, str) else key]
 
     def get_names(self):
         return [c.get_name() for c in self.channels]
@@ -246,8 +239,8 @@ class DataSet:
 
     def transform(self, transformer):
         """the same Y transformer (fitted per channel) on every channel -- reference dataset.py:transform"""
-        for channel in self.channels:
-            channel.transform(transformer)
+        for c in self.channels:
+            c.transform(transformer)
 
     def get_ls_estimation(self, Q=1, n=10000):
         """per channel -- reference dataset.py:579-603"""

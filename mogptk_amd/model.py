@@ -662,38 +662,34 @@ class Model:
             print("‣ Training points: %d" % self.num_training_points())
             print("‣ Iterations: %d" % iters)
 
-        iter_offset = 0
-        times = np.zeros((iters + 1,))
-        losses = np.zeros((iters + 1,))
-        errors = np.zeros((iters + 1,))
-        if self.times.shape[0] != 0:
-            iter_offset = self.times.shape[0] - 1
-            times = np.concatenate((self.times[:-1], times))
-            losses = np.concatenate((self.losses[:-1], losses))
-            errors = np.concatenate((self.errors[:-1] if self.errors.shape[0] == self.times.shape[0]
-                                     else np.zeros(iter_offset), errors))
-        initial_time = time.time()
-        progress_time = 0.0
-
-        iters_len = 1 if iters == 0 else int(math.log10(iter_offset + iters)) + 1
+        # the trace of this call behind the trace of the earlier ones: row 0 seconds, row 1 loss, row 2 error; the last entry of an earlier call
+        # (its closing evaluation) is this call's first
+        done = max(int(self.times.shape[0]) - 1, 0)
+        trace = np.zeros((3, done + iters + 1))
+        if done:
+            trace[0, :done] = self.times[:done]
+            trace[1, :done] = self.losses[:done]
+            if self.errors.shape[0] == self.times.shape[0]:
+                trace[2, :done] = self.errors[:done]
+        t_start = time.time()
+        quiet_until = 0.0                              # seconds into the call before which no progress line is due
+        width = 1 if iters == 0 else int(math.log10(done + iters)) + 1
 
         def progress(i, loss, last=False):
-            nonlocal progress_time
-            elapsed_time = time.time() - initial_time
-            write = verbose and (last or 0.0 <= elapsed_time - progress_time)
-            i += iter_offset
-            times[i] = elapsed_time
-            losses[i] = loss
+            nonlocal quiet_until, trace
+            at = done + i
+            if at >= trace.shape[1]:                   # (LBFGS may evaluate more often than it was given iterations)
+                trace = np.concatenate((trace, np.zeros((3, at + 1 - trace.shape[1]))), axis=1)
+            now = time.time() - t_start
+            trace[0, at], trace[1, at] = now, loss
             if error is not None:
-                errors[i] = float(self.error(error, error_use_all_data))
-                if write:
-                    print("  %*d/%*d %s  loss=%12g  error=%12g" % (iters_len, i, iters_len, iter_offset + iters,
-                                                                   _format_time(elapsed_time), losses[i], errors[i]))
-            elif write:
-                print("  %*d/%*d %s  loss=%12g" % (iters_len, i, iters_len, iter_offset + iters,
-                                                  _format_time(elapsed_time), losses[i]))
-            if write:
-                progress_time += 10.0 + float(int((elapsed_time - progress_time) / 10.0)) * 10.0
+                trace[2, at] = float(self.error(error, error_use_all_data))
+            if verbose and (last or now >= quiet_until):
+                line = "  %*d/%*d %s  loss=%12g" % (width, at, width, done + iters, _format_time(now), trace[1, at])
+                if error is not None:
+                    line += "  error=%12g" % trace[2, at]
+                print(line)
+                quiet_until += 10.0 * (1 + int((now - quiet_until) / 10.0))
 
         params = list(self.gpr.parameters())
         if method == "LBFGS":
@@ -725,14 +721,14 @@ class Model:
         progress(iters, self.loss(), last=True)
 
         if verbose:
-            print("Optimization finished in %s" % _format_duration(time.time() - initial_time))
+            print("Optimization finished in %s" % _format_duration(time.time() - t_start))
 
-        self.iters = iter_offset + iters
-        self.times = times[:iter_offset + iters + 1]
-        self.losses = losses[:iter_offset + iters + 1]
+        kept = done + iters + 1
+        self.iters = kept - 1
+        self.times, self.losses = trace[0, :kept].copy(), trace[1, :kept].copy()
         if error is not None:
-            self.errors = errors[:iter_offset + iters + 1]
-        return losses, errors
+            self.errors = trace[2, :kept].copy()
+        return trace[1], trace[2]
 
     # ---- predictions ---------------------------------------------------------------------
     def _to_kernel_format(self, X, Y=None):

@@ -965,7 +965,8 @@ def test_opper_archambeau_matches_reference():
 
 
 def test_opper_archambeau_through_the_model_wrapper():
-    t = np.linspace(0, 10, 30)
+    np.random.seed(20251001)          # the wrapper draws its initial weights / means from numpy's global generator (as the reference does from torch's):
+    t = np.linspace(0, 10, 30)        # three Adam steps from an unlucky draw need not lower the loss
     ds = mogptk_amd.DataSet(t, [np.sin(t), np.cos(t)])
     m = mogptk_amd.MOSM(ds, Q=1, inference=mogptk_amd.OpperArchambeau())
     assert type(m.gpr).__name__ == "OpperArchambeau" and m.gpr.q_nu().shape == (60, 1) and m.gpr.q_lambda().shape == (60, 1)
