@@ -500,11 +500,17 @@ namespace mogp { int spd_alloc(Spd& w, int64_t Npad, int owned_rows_device) {
     w.release();
     w.Npad = Npad; w.nb = (int)(Npad / MOGP_TILE);
     int rc;
-    const bool owned = owned_rows_device >= 0;
+    bool owned = owned_rows_device >= 0;
+    if (owned && w.Arows.reserve((size_t)Npad * Npad * sizeof(double), owned_rows_device)) {
+        // a runtime without virtual memory management (or out of address space): the ordinary allocation -- the owned-rows code path does not care
+        // whether the rows it never touches exist
+        w.Arows.release();
+        (void)hipGetLastError();
+        owned = false;
+    }
     if (owned) {
         // the work matrix of a sharded evaluation: the whole address range, physical memory only where mogp_shard_config asks for it; no B
         // (nothing of the sharded gradient evaluation uses it -- the sharded prediction allocates it when it comes)
-        if ((rc = w.Arows.reserve((size_t)Npad * Npad * sizeof(double), owned_rows_device))) return rc;
         w.A.p = reinterpret_cast<double*>(w.Arows.base); w.A.n = (size_t)Npad * Npad; w.A.borrowed = true;
         w.owned_rows = true;
     } else {
