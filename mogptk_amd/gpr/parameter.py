@@ -51,7 +51,7 @@ class Softplus(Transform):
     def forward(self, x):
         z = self.beta * x
         big = z > self.threshold
-        if not big.any():                  # (every training step of every model passes here several times: the same values without two selects and a context manager)
+        if not np.any(big):                # (every training step of every model passes here several times: the same values without two selects and a context manager)
             return self.lower + np.log1p(np.exp(z)) / self.beta
         with np.errstate(over="ignore"):
             sp = np.where(big, x, np.log1p(np.exp(np.where(big, 0.0, z))) / self.beta)
@@ -60,7 +60,7 @@ class Softplus(Transform):
     def dforward(self, x):
         z = self.beta * x
         big = z > self.threshold
-        if not big.any():
+        if not np.any(big):
             return 1.0 / (1.0 + np.exp(-z))
         with np.errstate(over="ignore"):
             return np.where(big, 1.0, 1.0 / (1.0 + np.exp(-np.where(big, 0.0, z))))
