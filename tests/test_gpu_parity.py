@@ -1233,7 +1233,7 @@ def test_titsias_inducing_gradient_against_extended_precision_truth(fixture):
     assert abs(err_ref - float(fx["ref_err"])) < 1e-12
     if "gz_ref_alt" in fx:
         # configs[4] itself: where the reference lands depends on its summation order -- 1.442e-3 of the tensor from the truth on 8 torch
-        # threads, 1.928e-3 on 3 (the two runs 2.35e-3 apart); the device, the same bits on every run, 2.188e-3 (2.598e-3 before the panels of
+        # threads, 1.928e-3 on 3 (the two runs 2.35e-3 apart); the device, the same bits on every run, 1.591e-3 (round 6; 2.188e-3 before the Gram kernels' polynomial degrees changed, 2.598e-3 before the panels of
         # the K_uu factorisation were refined: DESIGN 4b)
         err_alt = float(np.max(np.abs(fx["gz_ref_alt"] - truth)) / scale)
         print("    the reference again on %d threads: %.3e" % (int(fx["ref_alt_threads"]), err_alt))
