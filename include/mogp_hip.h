@@ -205,9 +205,10 @@ int  mogp_model_set_accurate(mogp_model* m, int on);
 /* mogp_exact_eval(..., MOGP_EVAL_GRAD) sharded over the context's communicator: same outputs, identical on every rank. */
 int  mogp_exact_eval_sharded(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
                              double* lml, double* moments, double* diagG, double* trG, double* jitter_abs, int64_t* info);
-/* mogp_exact_predict (diagonal variance) sharded: the inversion as above, one all-gather of Kj^-1 (N^2 doubles), then every rank takes a
- * block of the test points ("column blocks of K_fs are independent") and the results are summed into full mu / var on
- * every rank. */
+/* mogp_exact_predict (diagonal variance) sharded: the inversion as above; every rank builds the test Gram K_sf for all test points and forms, from the tile rows
+ * of Kj^-1 it OWNS, its share of the quadratic form K_s. Kj^-1 K_.s (strictly lower tiles twice, diagonal tiles once); ONE all-reduce of S doubles makes the
+ * variances, the mean is K_sf alpha with the all-reduced alpha.  No rank ever holds more of Kj^-1 than its own rows (rounds 3 - 5 all-gathered the whole inverse:
+ * N^2 doubles over the links and on every rank).  Same mu / var on every rank. */
 int  mogp_exact_predict_sharded(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
                                 const double* kss_diag, int64_t S, const double* Xs, double* mu, double* var, int64_t* info);
 

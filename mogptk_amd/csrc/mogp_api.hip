@@ -1377,7 +1377,7 @@ int mogp_model_destroy(mogp_model* m) {
     for (auto& e : m->pred_ev) if (e) { hipError_t r = hipEventDestroy(e); (void)r; e = nullptr; }
     for (hipStream_t q : {m->st2, m->st2u, m->st3, m->st4, m->ctx->st5, m->st_priv}) if (q) { hipError_t e = hipStreamSynchronize(q); (void)e; }
     m->k.release(); m->ws.release(); m->ws_tail.release();
-    for (int b = 0; b < 2; ++b) { m->swU[b].release(); m->swUr[b].release(); }
+    for (int b = 0; b < 2; ++b) { m->swU[b].release(); m->swUr[b].release(); m->swXr[b].release(); }
     for (auto e : m->sw_ev) { hipError_t r = hipEventDestroy(e); (void)r; }
     for (auto e : m->sh_prof) { hipError_t r = hipEventDestroy(e); (void)r; }
     m->d_symv.release(); m->sh_send.release(); m->sh_recv.release(); m->sh_send1.release(); m->sh_recv1.release(); m->sh_fact.release();
@@ -1392,7 +1392,7 @@ int mogp_model_destroy(mogp_model* m) {
     if (m->gram_tail_ev) { hipError_t r = hipEventDestroy(m->gram_tail_ev); (void)r; m->gram_tail_ev = nullptr; }
     m->d_chan_off.release(); m->d_flag.release(); m->d_info.release(); m->d_pivots.release(); m->acc_rhs.release();
     m->d_xs.release(); m->d_Ksf.release(); m->d_Vt.release(); m->d_mu.release(); m->d_var.release(); m->d_kdiag.release();
-    m->d_Kss.release(); m->d_ptiles.release();
+    m->d_Kss.release(); m->d_ptiles.release(); m->d_pred_tasks.release();
     m->ph_xx.release(); m->ph_sx.release(); m->ph_ss.release();
     if (m->h_pin) { hipError_t e = hipHostFree(m->h_pin); (void)e; m->h_pin = nullptr; }
 
@@ -1998,33 +1998,27 @@ int mogp_exact_eval_sharded(mogp_model* m, const double* noise_var, const double
     return MOGP_OK;
 }
 
-// tile row i (128 rows, full width) of A: packed [idx][128][Npad] in the send buffer of its owner, idx = i / P
-__global__ void k_rows_pack(const double* __restrict__ A, int64_t ld, int nb, int P, int rank, double* __restrict__ send) {
-    const int i = rank + (int)blockIdx.x * P;
-    if (i >= nb) return;
-    const double* src = A + (int64_t)i * MOGP_TILE * ld;
-    double* dst = send + (int64_t)blockIdx.x * MOGP_TILE * ld;
-    for (int64_t e = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; e < (int64_t)MOGP_TILE * ld; e += (int64_t)gridDim.y * blockDim.x) dst[e] = src[e];
-}
-__global__ void k_rows_unpack(double* __restrict__ Kfull, int64_t ld, int nb, int P, int64_t chunk, const double* __restrict__ recv, double scale) {
-    const int r = blockIdx.z;
-    const int i = r + (int)blockIdx.x * P;
-    if (i >= nb) return;
-    const double* src = recv + (int64_t)r * chunk + (int64_t)blockIdx.x * MOGP_TILE * ld;
-    double* dst = Kfull + (int64_t)i * MOGP_TILE * ld;
-    for (int64_t e = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; e < (int64_t)MOGP_TILE * ld; e += (int64_t)gridDim.y * blockDim.x) dst[e] = scale * src[e];
-}
-// out[r] = base[r] - sum_k A[r][k] B[r][k]
-__global__ __launch_bounds__(256) void k_row_dot_sub(const double* __restrict__ A, const double* __restrict__ B, int64_t ld, int64_t rows, int64_t n,
-                                                     const double* __restrict__ base, double* __restrict__ out) {
+// part[s] = sum over this rank's tile rows j (T[s][j*128 + k], the rows' share of K_s. Kj^-1) and k of Ksf[s][row(j)*128 + k] * T[s][j*128 + k]
+// (one wave per test point; rows: the tile rows i = rank, rank + P, ...)
+__global__ __launch_bounds__(256) void k_owned_quadform(const double* __restrict__ Ksf, int64_t ldk, const double* __restrict__ T, int64_t ldt, int64_t S,
+                                                        int nown, int P, int rank, double* __restrict__ part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
-    if (i >= rows) return;
-    double s = 0.0;
-    for (int64_t k = lane; k < n; k += 64) s = fma(A[i * ld + k], B[i * ld + k], s);
+    const int64_t s = (int64_t)blockIdx.x * 4 + wave;
+    if (s >= S) return;
+    double acc = 0.0;
+    for (int j = 0; j < nown; ++j) {
+        const double* kr = Ksf + s * ldk + (int64_t)(rank + j * P) * MOGP_TILE;
+        const double* tr = T + s * ldt + (int64_t)j * MOGP_TILE;
+        acc = fma(kr[lane], tr[lane], acc);
+        acc = fma(kr[lane + 64], tr[lane + 64], acc);
+    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) out[i] = base[i] - s;
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) part[s] = acc;
+}
+__global__ void k_var_finish(const double* __restrict__ kdiag, const double* __restrict__ part, int64_t S, double* __restrict__ var) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < S) var[i] = kdiag[i] + part[i];               // (the work matrix holds MINUS Kj^-1)
 }
 
 int mogp_exact_predict_sharded(mogp_model* m, const double* noise_var, const double* data_var, double jitter,
@@ -2036,73 +2030,88 @@ int mogp_exact_predict_sharded(mogp_model* m, const double* noise_var, const dou
     mogp_comm& cm = m->ctx->comm;
     const int P = cm.n, rank = cm.rank, C = m->C, D = m->D, nb = m->nb;
     const int64_t Npad = m->Npad;
-    // 1. the inversion, sharded exactly like the gradient evaluation: owned rows of -Kj^-1 in k.A, alpha complete on every rank
+    // 1. the inversion, sharded exactly like the gradient evaluation: owned tile rows of -Kj^-1 (lower tiles, whole diagonal tiles) in k.A, alpha complete on every rank
     if ((rc = sharded_inverse(m, noise_var, data_var, jitter, nullptr))) return rc;
     double lml = 0.0;
     if ((rc = sweep_eval_scalars(m, &lml, info))) return sharded_rc(m, rc);            // failure report (not positive definite)
-    // 2. ONE all-gather of the owned tile rows -> the full Kj^-1 (lower) in k.B on every rank, then mirrored
-    const int maxrows = (nb + P - 1) / P;
-    const int64_t chunk = (int64_t)maxrows * MOGP_TILE * Npad;
-    if ((rc = m->sh_send.ensure((size_t)chunk))) return rc;
-    if ((rc = m->sh_recv.ensure((size_t)chunk * P))) return rc;
-    if (!m->k.B.p) {                  // (an owned-rows work space has no second matrix until the prediction's design asks for the whole inverse on every rank)
-        if ((rc = m->k.B.ensure((size_t)Npad * Npad))) return rc;
-        if ((rc = dev_fill_zero(m->k.B.p, (size_t)Npad * Npad * sizeof(double)))) return rc;
-    }
-    hipLaunchKernelGGL(k_rows_pack, dim3(maxrows, 64), dim3(256), 0, m->st, m->k.A.p, Npad, nb, P, rank, m->sh_send.p);
-    HIP_TRY(hipGetLastError());
-    if ((rc = comm_allgather(m->ctx, m->sh_send.p, m->sh_recv.p, chunk, m->st))) return rc;
-    hipLaunchKernelGGL(k_rows_unpack, dim3(maxrows, 64, P), dim3(256), 0, m->st, m->k.B.p, Npad, nb, P, chunk, m->sh_recv.p, -1.0);
-    HIP_TRY(hipGetLastError());
-    if ((rc = launch_symmetrize(m->k.B.p, Npad, Npad, m->st))) return rc;
-    // 3. this rank's block of the (channel-sorted) test points: 128-row tiles t0 .. t1
+    // 2. Round 6: the predictive variance FROM THE OWNED ROWS, no all-gather of Kj^-1 (N^2 doubles, and the whole inverse on every rank, in rounds 3 - 5).
+    //    k_ss - K_s. Kj^-1 K_.s is a quadratic form: with the rows a of Kj^-1 dealt out to the ranks,
+    //        sum_ab K_sa Kinv_ab K_sb = sum over ranks, over their tile rows i, of  sum_{a in i} K_sa ( 2 sum_{b left of tile i} Kinv_ab K_sb + sum_{b in tile i} Kinv_ab K_sb )
+    //    -- the strictly lower tiles count twice, the diagonal tile (held whole) once.  Every rank: the test Gram K_sf for ALL test points, one task-list GEMM
+    //    T[:, tile row] = K_sf[:, left of it] A[row, left of it]^T (x 2) behind one for the diagonal tiles, a row-wise dot, and ONE all-reduce of S doubles.
     SortedX ss;
     if ((rc = sort_inputs(Xs, S, D, C, MOGP_TILE, ss))) return rc;
     const int64_t Spad = ss.Mpad;
-    const int st = (int)(Spad / MOGP_TILE), per = (st + P - 1) / P;
-    const int t0 = std::min(st, rank * per), t1 = std::min(st, t0 + per);
-    const int64_t row0 = (int64_t)t0 * MOGP_TILE, rows = (int64_t)(t1 - t0) * MOGP_TILE;
-    std::vector<GTile> all, pt;
-    build_rect_tiles(ss.off, m->sx.off, C, all);
-    for (const GTile& g : all) if (g.r0 + g.nr > row0 && g.r0 < row0 + rows) pt.push_back(g);
+    const int st = (int)(Spad / MOGP_TILE);
+    const int nown = rank < nb ? (nb - rank + P - 1) / P : 0;                          // tile rows rank, rank + P, ...
+    const int64_t ldt = (int64_t)std::max(nown, 1) * MOGP_TILE;
+    std::vector<GTile> pt;
+    build_rect_tiles(ss.off, m->sx.off, C, pt);
     if ((rc = m->d_xs.ensure((size_t)D * Spad))) return rc;
     if ((rc = m->d_Ksf.ensure((size_t)Spad * Npad))) return rc;
-    if ((rc = m->d_Vt.ensure((size_t)Spad * Npad))) return rc;
+    if ((rc = m->d_Vt.ensure((size_t)Spad * ldt))) return rc;
     if ((rc = m->d_mu.ensure(Spad))) return rc;
-    if ((rc = m->d_var.ensure(Spad))) return rc;
+    if ((rc = m->d_var.ensure(2 * Spad))) return rc;                                   // [variance | this rank's share of the quadratic form]
     if ((rc = m->d_kdiag.ensure(Spad))) return rc;
     if ((rc = m->d_ptiles.ensure(std::max<size_t>(pt.size(), 1)))) return rc;
     std::vector<double> kd(Spad, 0.0);
     const bool per_point = m->Wt > 2 + 3 * D;
     for (int c = 0; c < C; ++c)
         for (int pos = ss.off[c]; pos < ss.off[c + 1]; ++pos) kd[pos] = per_point ? kss_diag[ss.perm[pos]] : kss_diag[c];
+    // the two task lists: [diagonal tiles | strictly lower parts], longest k range first within each
+    std::vector<GemmTask> tasks;
+    for (int j = 0; j < nown; ++j)
+        for (int t = 0; t < st; ++t) {
+            const int64_t i = rank + (int64_t)j * P;
+            GemmTask g{};
+            g.a_off = (int64_t)t * MOGP_TILE * Npad + i * MOGP_TILE; g.b_off = i * MOGP_TILE * Npad + i * MOGP_TILE;
+            g.c_off = (int64_t)t * MOGP_TILE * ldt + (int64_t)j * MOGP_TILE; g.kt = MOGP_TILE / 16; g.pad = 0;
+            tasks.push_back(g);
+        }
+    const size_t ndiag = tasks.size();
+    for (int j = nown - 1; j >= 0; --j)
+        for (int t = 0; t < st; ++t) {
+            const int64_t i = rank + (int64_t)j * P;
+            if (i == 0) continue;
+            GemmTask g{};
+            g.a_off = (int64_t)t * MOGP_TILE * Npad; g.b_off = i * MOGP_TILE * Npad;
+            g.c_off = (int64_t)t * MOGP_TILE * ldt + (int64_t)j * MOGP_TILE; g.kt = (int)(i * MOGP_TILE / 16); g.pad = 0;
+            tasks.push_back(g);
+        }
+    if ((rc = m->d_pred_tasks.ensure(std::max<size_t>(tasks.size(), 1)))) return rc;
     HIP_TRY(hipMemcpyAsync(m->d_xs.p, ss.xs.data(), (size_t)D * Spad * sizeof(double), hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->d_kdiag.p, kd.data(), Spad * sizeof(double), hipMemcpyHostToDevice, m->st));
     HIP_TRY(hipMemcpyAsync(m->d_ptiles.p, pt.data(), pt.size() * sizeof(GTile), hipMemcpyHostToDevice, m->st));
-    HIP_TRY(hipMemsetAsync(m->d_mu.p, 0, Spad * sizeof(double), m->st));
-    HIP_TRY(hipMemsetAsync(m->d_var.p, 0, Spad * sizeof(double), m->st));
-    if (rows > 0) {
-        HIP_TRY(hipMemsetAsync(m->d_Ksf.p + row0 * Npad, 0, (size_t)rows * Npad * sizeof(double), m->st));   // padded rows / columns stay zero
-        GramArgs ga{};
-        ga.tiles = m->d_ptiles.p; ga.xr = m->d_xs.p; ga.ldxr = Spad; ga.xc = m->d_x.p; ga.ldxc = Npad; ga.nrows = S; ga.ncols = m->N;
-        if ((rc = m->ph_sx.prepare(ss.off, m->sx.off, C, m->T, Spad, Npad, m->st, ga.ph))) return rc;
-        ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = m->Wt; ga.out = m->d_Ksf.p; ga.ldo = Npad;
-        ga.noise = nullptr; ga.dvar = nullptr; ga.jitter_abs = 0.0; ga.mirror = 0;
-        if ((rc = launch_gram(ga, (int)pt.size(), m->st))) return rc;
-        const double* Kloc = m->d_Ksf.p + row0 * Npad;
-        if ((rc = launch_gemv_rows(Kloc, Npad, rows, Npad, m->d_alpha.p, m->d_mu.p + row0, m->st))) return rc;            // mu = K_sf alpha
-        GemmArgs g{};                                                                                                  // V = K_sf Kj^-1
-        g.A = Kloc; g.lda = Npad; g.a_kmajor = 0; g.B = m->k.B.p; g.ldb = Npad; g.b_kmajor = 0;
-        g.C = m->d_Vt.p + row0 * Npad; g.ldc = Npad; g.alpha = 1.0; g.beta = 0.0;
-        g.mode = GM_RECT; g.mt = t1 - t0; g.nt = nb; g.K = (int)Npad;
-        if ((rc = gemm_call(m, g, gemm_flops(g, nullptr)))) return rc;
-        hipLaunchKernelGGL(k_row_dot_sub, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, m->st, Kloc, m->d_Vt.p + row0 * Npad, Npad, rows, Npad,
-                           m->d_kdiag.p + row0, m->d_var.p + row0);                                                    // var = K_ss - rowsum(K_sf o V)
+    if (!tasks.empty()) HIP_TRY(hipMemcpyAsync(m->d_pred_tasks.p, tasks.data(), tasks.size() * sizeof(GemmTask), hipMemcpyHostToDevice, m->st));
+    HIP_TRY(hipMemsetAsync(m->d_Ksf.p, 0, (size_t)Spad * Npad * sizeof(double), m->st));           // padded rows / columns stay zero
+    HIP_TRY(hipMemsetAsync(m->d_var.p, 0, 2 * Spad * sizeof(double), m->st));
+    GramArgs ga{};
+    ga.tiles = m->d_ptiles.p; ga.xr = m->d_xs.p; ga.ldxr = Spad; ga.xc = m->d_x.p; ga.ldxc = Npad; ga.nrows = S; ga.ncols = m->N;
+    if ((rc = m->ph_sx.prepare(ss.off, m->sx.off, C, m->T, Spad, Npad, m->st, ga.ph))) return rc;
+    ga.table = m->d_table.p; ga.T = m->T; ga.D = D; ga.C = C; ga.W = m->Wt; ga.out = m->d_Ksf.p; ga.ldo = Npad;
+    ga.noise = nullptr; ga.dvar = nullptr; ga.jitter_abs = 0.0; ga.mirror = 0;
+    if ((rc = launch_gram(ga, (int)pt.size(), m->st))) return rc;
+    if ((rc = launch_gemv_rows(m->d_Ksf.p, Npad, Spad, Npad, m->d_alpha.p, m->d_mu.p, m->st))) return rc;            // mu = K_sf alpha (alpha is complete on every rank)
+    if (nown > 0) {
+        GemmArgs g{};
+        g.A = m->d_Ksf.p; g.lda = Npad; g.a_kmajor = 0; g.B = m->k.A.p; g.ldb = Npad; g.b_kmajor = 0;
+        g.C = m->d_Vt.p; g.ldc = ldt; g.mode = GM_TASKS; g.mt = g.nt = 0; g.K = 0;
+        g.alpha = 1.0; g.beta = 0.0; g.tasks = m->d_pred_tasks.p; g.ntasks = (int)ndiag;
+        if ((rc = gemm_call(m, g, 2.0 * MOGP_TILE * MOGP_TILE * MOGP_TILE * (double)ndiag))) return rc;
+        if (tasks.size() > ndiag) {
+            double fl = 0.0;
+            for (size_t k = ndiag; k < tasks.size(); ++k) fl += 2.0 * MOGP_TILE * MOGP_TILE * 16.0 * tasks[k].kt;
+            g.alpha = 2.0; g.beta = 1.0; g.tasks = m->d_pred_tasks.p + ndiag; g.ntasks = (int)(tasks.size() - ndiag);
+            if ((rc = gemm_call(m, g, fl))) return rc;
+        }
+        hipLaunchKernelGGL(k_owned_quadform, dim3((unsigned)((Spad + 3) / 4)), dim3(256), 0, m->st, m->d_Ksf.p, Npad, m->d_Vt.p, ldt, Spad, nown, P, rank,
+                           m->d_var.p + Spad);
         HIP_TRY(hipGetLastError());
     }
-    // 4. every rank gets every block: the vectors are zero outside the own block, so a sum is a gather
-    if ((rc = comm_allreduce(m->ctx, m->d_mu.p, Spad, m->st))) return rc;
-    if ((rc = comm_allreduce(m->ctx, m->d_var.p, Spad, m->st))) return rc;
+    // 3. the ranks' shares of the quadratic form: one sum of S doubles
+    if ((rc = comm_allreduce(m->ctx, m->d_var.p + Spad, Spad, m->st))) return rc;
+    hipLaunchKernelGGL(k_var_finish, dim3((unsigned)((Spad + 255) / 256)), dim3(256), 0, m->st, m->d_kdiag.p, m->d_var.p + Spad, Spad, m->d_var.p);
+    HIP_TRY(hipGetLastError());
     std::vector<double> hmu(Spad), hv(Spad);
     HIP_TRY(hipMemcpyAsync(hmu.data(), m->d_mu.p, Spad * sizeof(double), hipMemcpyDeviceToHost, m->st));
     HIP_TRY(hipMemcpyAsync(hv.data(), m->d_var.p, Spad * sizeof(double), hipMemcpyDeviceToHost, m->st));

@@ -382,6 +382,7 @@ struct mogp_model {
     // prediction workspaces
     DevBuf<double> d_xs, d_Ksf, d_Vt, d_mu, d_var, d_kdiag, d_Kss;
     DevBuf<GTile> d_ptiles;
+    DevBuf<GemmTask> d_pred_tasks;      // the sharded prediction's task lists (this rank's tile rows x test-point tiles)
     PhaseWs ph_xx, ph_sx, ph_ss;                        // phase tables: (X, X), (Xs, X), (Xs, Xs)
 
     double* h_pin = nullptr;            // pinned host block for the per-evaluation scalars (log-det parts, z^T z parts, pivot report, moments):

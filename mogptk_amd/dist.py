@@ -18,7 +18,8 @@ diagonal sums (C).  Every rank holds the full training set but only ITS tile row
 1 / world of 8 Npad^2 bytes, physical memory under those rows only -- mogp_model_work_bytes; what it needs of the other ranks' rows arrives with the
 exchange and goes straight into the pivot block's work buffers), BUILDS only the Gram / moment tiles of those rows, repeats the cheap serial chain
 (512 x 512 block inversions, panels) and applies the rank-512 updates to its own rows only: the O(N^3) work and the O(N^2) memory are divided by
-`world`.  A sharded prediction adds one all-gather of Kj^-1 (every rank then holds the whole inverse) and splits the test points over the ranks.
+`world`.  A sharded prediction keeps it that way: every rank forms its rows' share of the quadratic form K_s. Kj^-1 K_.s for all test points, one all-reduce of
+S doubles makes the variances (no all-gather of the inverse).
 
 `sharded_eval` below is the same protocol spelt out stage by stage over the `mogp_shard_*` entry points; the numpy twin of the device
 stages (oracle/table_model.py) runs it under gloo on CPU ranks in tests/test_dist_cpu.py.

@@ -543,6 +543,7 @@ def _check_owned_rows(o, world):
     assert o["rel_loss_one_gpu_after"] < 1e-10 and o["rel_grad_one_gpu_after"] < 1e-7, o
     assert o["backed_after_one_gpu_call"] == o["whole_bytes"], o
     assert o["backed_bytes"] <= o["whole_bytes"], o
+    assert o["backed_after_sharded_predict"] == o["backed_bytes"], o          # the sharded prediction needs no more of the matrix than the evaluation
     if world >= 4:
         assert o["backed_bytes"] < o["whole_bytes"], o
 
@@ -563,7 +564,7 @@ def test_sharded_eval_ranks_sharing_one_gpu(ranks):
     assert r["world"] == ranks
     assert r["rel_loss"] < 1e-10, r
     assert r["rel_grad"] < 1e-7, r          # tolerance: 1e-5 (north_star); measured ~1e-10
-    assert r["rel_predict"] < 1e-7, r       # sharded prediction (Kj^-1 all-gathered, test points split) against the one-GPU solve
+    assert r["rel_predict"] < 1e-7, r       # sharded prediction (every rank its own rows of Kj^-1: shares of the quadratic form, one all-reduce) against the one-GPU solve
     _check_owned_rows(r["owned_rows"], ranks)
     t = r["titsias"]                        # the sparse bound data-parallel (every rank holds every world-th point; sums over points all-reduced)
     assert t["rel_loss"] < 1e-10 and t["rel_grad"] < 1e-6 and t["rel_predict"] < 1e-7, t
